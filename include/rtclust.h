@@ -1,0 +1,157 @@
+/*
+ * rtclust.h -- C ABI of the MI355X-native sketch + all-pairs-distance path of RabbitTClust.
+ *
+ * The reference has no FFI; the path sits behind the RabbitSketch C++ class API and the
+ * intermediate-folder file formats.  Each entry point below names the reference
+ * code it replaces (paths relative to the RabbitTClust tree).  Plain pointers and sizes only;
+ * every function returns an rtc_status; no exceptions cross the boundary.
+ *
+ * Pointer naming: d_* = device (HBM) pointer, h_* = host pointer.  All device work is enqueued
+ * on the context's HIP stream (rtc_ctx_set_stream); *_dev entry points do not synchronise unless
+ * stated.  A context is bound to one GPU and may be used by one host thread at a time.
+ */
+#ifndef RTCLUST_H
+#define RTCLUST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  RTC_OK = 0,
+  RTC_ERR_ARG = 1,         /* bad argument (null pointer, k out of range, misaligned buffer) */
+  RTC_ERR_HIP = 2,         /* HIP runtime failure; see rtc_last_error() */
+  RTC_ERR_UNSUPPORTED = 3, /* valid request outside what the GPU path implements */
+  RTC_ERR_OVERFLOW = 4,    /* caller-provided output capacity too small; required size reported */
+  RTC_ERR_NOMEM = 5
+} rtc_status;
+
+typedef struct rtc_ctx rtc_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+int rtc_ctx_create(int device, rtc_ctx** out);
+void rtc_ctx_destroy(rtc_ctx* ctx);
+int rtc_ctx_set_stream(rtc_ctx* ctx, void* hip_stream); /* NULL = default stream */
+int rtc_ctx_sync(rtc_ctx* ctx);
+const char* rtc_last_error(const rtc_ctx* ctx);
+const char* rtc_version(void);
+/* device properties: out[0]=CU count, out[1]=LDS bytes per workgroup, out[2]=wavefront size */
+int rtc_device_info(rtc_ctx* ctx, int out[3]);
+
+/* device memory for hosts that do not link a HIP runtime themselves (the C++ CLI) */
+int rtc_dev_alloc(rtc_ctx* ctx, size_t bytes, void** d_ptr);
+int rtc_dev_free(rtc_ctx* ctx, void* d_ptr);
+int rtc_copy_h2d(rtc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* synchronous */
+int rtc_copy_d2h(rtc_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* synchronous */
+int rtc_memset_dev(rtc_ctx* ctx, void* d_ptr, int value, size_t bytes);
+
+/* ---- timing of the last launches (HIP events on the context stream) -------------------- */
+/* Brackets subsequently enqueued work; rtc_timer_stop synchronises and returns milliseconds. */
+int rtc_timer_start(rtc_ctx* ctx);
+int rtc_timer_stop(rtc_ctx* ctx, float* ms_out);
+
+/* ---- synthetic genomes (benchmark / test input) -------------------------- */
+typedef struct {
+  uint64_t fam_seed; /* ancestor stream */
+  uint64_t mut_seed; /* this member's substitution stream */
+  uint32_t mut_thr;  /* substitute where a 14-bit draw < mut_thr (rate = mut_thr/16384) */
+  uint32_t n_every;  /* 0: none; else an 8-base run of 'N' every n_every bases */
+} rtc_synth_desc;
+/* Writes genome g's bases (ASCII ACGT/N) to d_seq[h_off[g] .. h_off[g+1]). */
+int rtc_synth_genomes_dev(rtc_ctx* ctx, const rtc_synth_desc* h_desc, const uint64_t* h_off,
+                          uint32_t n, uint8_t* d_seq);
+
+/* ---- MinHash sketching ----------------------------------------------------------------- */
+/* Replaces, for a batch of genomes, `new Sketch::MinHash(k, size)` + `update(seq)` per FASTA
+ * record + `storeMinHashes()`  (src/SketchInfo.cpp:918-924, :942, :969; RabbitSketch library).
+ * d_seq: concatenated genomes, 16-byte aligned; records of one genome are separated by any
+ *   non-ACGT byte (k-mers never span records); lower case is folded to upper.
+ * h_off[n+1]: byte offsets of the genomes in d_seq.  h_sizes[n]: sketch size per genome
+ *   (fixed-size mode: all equal; containment mode: max(fileBytes/compress,100),
+ *   src/SketchInfo.cpp:919-924), or NULL to use `size` for all.
+ * d_out: n * stride u64; genome g's ascending distinct hashes at d_out + g*stride;
+ * d_cnt[n]: number of hashes produced (< size only when the genome has fewer distinct k-mers).
+ * Hash: first 64 bits of MurmurHash3_x64_128(canonical k-mer ASCII, k, seed) for k > 16,
+ * first 32 bits for k <= 16 (Mash / RabbitSketch convention). 1 <= k <= 32. */
+int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uint64_t* h_off, uint32_t n,
+                           int k, uint32_t seed, const uint32_t* h_sizes, uint32_t size,
+                           uint64_t* d_out, uint32_t stride, uint32_t* d_cnt);
+
+/* ---- KSSD sketching (--fast) ------------------------------------------------------------- */
+/* Replaces the per-file body of sketchFileWithKssd (src/SketchInfo.cpp:994-1252): 2-bit rolling
+ * k-mer (k rounded up to even, :1019-1020), canonical min, shuffled-dimension filter, dr_tuple,
+ * dedup, ascending sort.  h_shuffled_dim: the 2^(4*half_subk) table of generate_shuffle_dim
+ * (:91-102; built on the host with the same glibc srand/rand calls).
+ * width_out: 4 (u32 hashes) or 8 (u64) as decided by half_k - drlevel > 8 (:1021).
+ * d_out: n * stride elements of that width; d_cnt[n] = hashes per genome.
+ * Returns RTC_ERR_OVERFLOW if some genome yields more than `stride` hashes; h_need (optional)
+ * then holds the required stride. */
+int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uint64_t* h_off, uint32_t n,
+                        int kmer_size, int drlevel, const int32_t* h_shuffled_dim, void* d_out,
+                        uint32_t stride, uint32_t* d_cnt, int* width_out, uint32_t* h_need);
+
+/* ---- all-pairs sorted-sketch intersection ----------------------------------------------- */
+/* common[i][j] = |A_i ∩ A_j| for i in [row0,row1), j in [col0,col1): the integers that
+ * compute_minhash_mst / compute_kssd_mst obtain through their inverted index
+ * (src/MST.cpp:1408-1435, :428-487) and that modifyMST's distance()/jaccard() calls derive
+ * (src/MST.cpp:851-866).  Sketches: `d_hashes` (u64 when width==8, u32 when width==4), genome g
+ * occupies d_hashes[d_start[g] .. d_start[g]+d_len[g]) ascending and distinct.
+ * d_common: (row1-row0) x ld u32, row-major.  lower_only != 0: only entries with j < i are
+ * defined (others are left untouched).  algo: 0 = auto, 1 = per-pair merge (generic),
+ * 2 = LDS mask-table tiles. */
+int rtc_pair_common_dev(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+                        const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1,
+                        uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld,
+                        int lower_only, int algo);
+
+/* ---- candidate edges ----------------------------------------------------------------------- */
+typedef struct { uint32_t i, j, common; } rtc_cedge; /* i > j */
+/* Scans the common matrix produced above and appends every pair the reference would turn into
+ * an EdgeInfo: j < i, common > 0, both sketches non-empty, max(|A|,|B|) <= radio*min(|A|,|B|)
+ * (src/MST.cpp:1468-1487; radio = (int)(2*exp(threshold*(k-1))-1), :1292).  d_count is a u64
+ * counter the caller zeroes; edges beyond `cap` are counted but not stored. */
+int rtc_extract_edges_dev(rtc_ctx* ctx, const uint32_t* d_common, uint64_t ld, uint32_t row0,
+                          uint32_t row1, uint32_t col0, uint32_t col1, const uint32_t* d_len,
+                          int radio, rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count);
+
+/* ---- minimum spanning forest over candidate edges (Boruvka, order-exact integer weights) -- */
+/* One Boruvka round primitive for row-sharded multi-GPU use: for every current component c
+ * (d_comp[v] = component label of vertex v) computes the minimum key over the local edges that
+ * leave c.  Pass 1 (d_wkey): weight key = bit pattern of the exact rational similarity order
+ * (see DESIGN.md); pass 2 (d_ekey): (i<<32|j) among edges attaining d_wkey.  Between the passes
+ * the caller all-reduces (MIN) d_wkey across ranks; after pass 2 it all-reduces d_ekey. */
+int rtc_boruvka_minweight_dev(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m,
+                              const uint32_t* d_len, int is_containment, const uint32_t* d_comp,
+                              uint32_t n, uint64_t* d_wkey);
+int rtc_boruvka_minedge_dev(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m,
+                            const uint32_t* d_len, int is_containment, const uint32_t* d_comp,
+                            uint32_t n, const uint64_t* d_wkey, uint64_t* d_ekey);
+
+/* EdgeInfo of the reference (src/MST.h:17-21); the on-disk edge.mst record (src/MST_IO.cpp:200-217) */
+typedef struct { int32_t preNode, sufNode; double dist; } rtc_edge;
+
+/* Whole single-GPU MST step: compute_minhash_mst / compute_kssd_mst (src/MST.cpp:1290-1737,
+ * :216-807) from device-resident sketches.  Distances are evaluated on the HOST with the
+ * reference's expression order (src/MST.cpp:1295,1489-1515) so doubles are bit-identical.
+ * h_edges_out must hold n entries; *h_n_edges receives the forest size.  Synchronous. */
+int rtc_mst(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+            const uint32_t* d_len, uint32_t n, int kmer_size, int is_containment, double threshold,
+            rtc_edge* h_edges_out, uint64_t* h_n_edges);
+
+/* ---- greedy incremental clustering ------------------------------------------------------- */
+/* MinHashGreedyClusterWithInvertedIndex at -t 1 (src/greedy.cpp:986-1399) and
+ * KssdGreedyClusterWithInvertedIndex (:566-899; caller sorts by size first, :594-597).
+ * Genomes are processed in the given order; the GPU computes query-batch x representative
+ * intersections, the host applies the reference's filter / best-match / tie rules.
+ * h_size_cfg[n]: what getSketchSize() returns for each genome (configured size, :1201); NULL for
+ * KSSD.  h_rep_of[n] receives the representative of each genome (itself if it is one). */
+int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+               const uint32_t* d_len, uint32_t n, const uint32_t* h_size_cfg, int kmer_size,
+               int is_containment, int is_kssd, double threshold, int32_t* h_rep_of,
+               uint32_t* h_n_clusters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTCLUST_H */

@@ -1,0 +1,85 @@
+"""ctypes loader for librtclust_hip.so (the C ABI declared in include/rtclust.h).
+
+The HIP extension IS the product: there is no CPU fallback.  Importing this module without the
+built library raises; calling any op without a GPU returns RTC_ERR_HIP which `check` turns into
+an exception.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtclust_hip.so")
+
+RTC_OK, RTC_ERR_ARG, RTC_ERR_HIP, RTC_ERR_UNSUPPORTED, RTC_ERR_OVERFLOW, RTC_ERR_NOMEM = range(6)
+STATUS_NAMES = {0: "RTC_OK", 1: "RTC_ERR_ARG", 2: "RTC_ERR_HIP", 3: "RTC_ERR_UNSUPPORTED",
+                4: "RTC_ERR_OVERFLOW", 5: "RTC_ERR_NOMEM"}
+
+
+class RtcError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {msg}")
+        self.status = status
+
+
+class SynthDesc(C.Structure):
+    _fields_ = [("fam_seed", C.c_uint64), ("mut_seed", C.c_uint64),
+                ("mut_thr", C.c_uint32), ("n_every", C.c_uint32)]
+
+
+class CEdge(C.Structure):
+    _fields_ = [("i", C.c_uint32), ("j", C.c_uint32), ("common", C.c_uint32)]
+
+
+class Edge(C.Structure):
+    _fields_ = [("preNode", C.c_int32), ("sufNode", C.c_int32), ("dist", C.c_double)]
+
+
+# every symbol include/rtclust.h declares, with its ctypes signature
+_vp, _u32, _u64, _i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+SIGNATURES = {
+    "rtc_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "rtc_ctx_destroy": (None, [_vp]),
+    "rtc_ctx_set_stream": (_i, [_vp, _vp]),
+    "rtc_ctx_sync": (_i, [_vp]),
+    "rtc_last_error": (C.c_char_p, [_vp]),
+    "rtc_version": (C.c_char_p, []),
+    "rtc_device_info": (_i, [_vp, C.POINTER(_i)]),
+    "rtc_dev_alloc": (_i, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "rtc_dev_free": (_i, [_vp, _vp]),
+    "rtc_copy_h2d": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "rtc_copy_d2h": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "rtc_memset_dev": (_i, [_vp, _vp, _i, C.c_size_t]),
+    "rtc_timer_start": (_i, [_vp]),
+    "rtc_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "rtc_synth_genomes_dev": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "rtc_sketch_minhash_dev": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _vp, _u32, _vp, _u32, _vp]),
+    "rtc_sketch_kssd_dev": (_i, [_vp, _vp, _vp, _u32, _i, _i, _vp, _vp, _u32, _vp,
+                                 C.POINTER(_i), C.POINTER(_u32)]),
+    "rtc_pair_common_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _u64,
+                                 _i, _i]),
+    "rtc_extract_edges_dev": (_i, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _vp, _i, _vp, _u64, _vp]),
+    "rtc_boruvka_minweight_dev": (_i, [_vp, _vp, _u64, _vp, _i, _vp, _u32, _vp]),
+    "rtc_boruvka_minedge_dev": (_i, [_vp, _vp, _u64, _vp, _i, _vp, _u32, _vp, _vp]),
+    "rtc_mst": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64)]),
+    "rtc_greedy": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _vp, _i, _i, _i, C.c_double, _vp,
+                        C.POINTER(_u32)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (no GPU needed to load; needed to run anything)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

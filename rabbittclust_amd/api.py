@@ -1,0 +1,262 @@
+"""Host-side Python mirror of the sketch + all-pairs path, over the C ABI (include/rtclust.h).
+
+PyTorch is plumbing here: device buffers (torch tensors), the current HIP stream and
+torch.distributed.  All compute goes through librtclust_hip.so; nothing in this module has a
+CPU fallback.  Names follow the reference's vocabulary (genomes, sketches, hashes, MST edges).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import RtcError, SynthDesc
+
+SYNTH_DT = np.dtype([("fam_seed", "<u8"), ("mut_seed", "<u8"), ("mut_thr", "<u4"), ("n_every", "<u4")])
+CEDGE_DT = np.dtype([("i", "<u4"), ("j", "<u4"), ("common", "<u4")])
+EDGE_DT = np.dtype([("preNode", "<i4"), ("sufNode", "<i4"), ("dist", "<f8")])  # edge.mst record
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _t_ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class SketchSet:
+    """Device-resident sketches: `hashes` flat tensor (int64 view of u64, or int32 view of u32),
+    `start` (int64, element offsets) and `len` (int32) per genome -- the CSR the pair kernels read."""
+
+    def __init__(self, hashes, start, length, width, k, kind):
+        self.hashes, self.start, self.len, self.width, self.k, self.kind = hashes, start, length, width, k, kind
+
+    @property
+    def n(self):
+        return int(self.len.numel())
+
+    def to_host(self):
+        np_dt = np.uint64 if self.width == 8 else np.uint32
+        flat = self.hashes.cpu().numpy().view(np_dt).reshape(-1)
+        start = self.start.cpu().numpy().astype(np.uint64)
+        ln = self.len.cpu().numpy().astype(np.uint32)
+        return [flat[int(s):int(s) + int(l)].copy() for s, l in zip(start, ln)]
+
+    @staticmethod
+    def from_host(sketches, device, k=21, kind="minhash", width=8):
+        np_dt = np.uint64 if width == 8 else np.uint32
+        t_dt = torch.int64 if width == 8 else torch.int32
+        lens = np.array([len(s) for s in sketches], dtype=np.int32)
+        start = np.zeros(len(sketches), dtype=np.int64)
+        if len(sketches) > 1:
+            start[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+        flat = (np.concatenate([np.asarray(s, dtype=np_dt) for s in sketches])
+                if len(sketches) and lens.sum() else np.zeros(0, dtype=np_dt))
+        flat = np.ascontiguousarray(flat)
+        h = torch.from_numpy(flat.view(np.int64 if width == 8 else np.int32).copy()).to(device)
+        if h.numel() == 0:
+            h = torch.zeros(2, dtype=t_dt, device=device)
+        return SketchSet(h, torch.from_numpy(start).to(device), torch.from_numpy(lens).to(device), width, k, kind)
+
+
+class Context:
+    """One context per GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RtcError(_lib.RTC_ERR_HIP, "no HIP device visible: the MI355X path has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        st = self.lib.rtc_ctx_create(device, C.byref(h))
+        if st != _lib.RTC_OK:
+            raise RtcError(st, "rtc_ctx_create failed")
+        self.h = h
+        self.use_torch_stream()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rtc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, st):
+        if st != _lib.RTC_OK:
+            raise RtcError(st, self.lib.rtc_last_error(self.h).decode(errors="replace"))
+
+    def use_torch_stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self.check(self.lib.rtc_ctx_set_stream(self.h, C.c_void_p(s)))
+
+    def sync(self):
+        self.check(self.lib.rtc_ctx_sync(self.h))
+
+    def timer_start(self):
+        self.check(self.lib.rtc_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self.check(self.lib.rtc_timer_stop(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    # ---- inputs -------------------------------------------------------------------------------
+    def synth_genomes(self, desc, off):
+        """desc: numpy SYNTH_DT[n]; off: u64[n+1].  Returns uint8 tensor with all genomes."""
+        desc = np.ascontiguousarray(desc, dtype=SYNTH_DT)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(desc)
+        seq = torch.empty(int(off[-1]) + 64, dtype=torch.uint8, device=self.device)
+        self.check(self.lib.rtc_synth_genomes_dev(self.h, _np_ptr(desc), _np_ptr(off), n, _t_ptr(seq)))
+        return seq
+
+    def upload_sequences(self, seq_np):
+        t = torch.empty(len(seq_np) + 64, dtype=torch.uint8, device=self.device)
+        t[:len(seq_np)] = torch.from_numpy(np.ascontiguousarray(seq_np, dtype=np.uint8)).to(self.device)
+        return t
+
+    # ---- sketching ----------------------------------------------------------------------------
+    def sketch_minhash(self, seq, off, k=21, size=1000, sizes=None, seed=42):
+        """Sketch::MinHash(k,size) + update() + storeMinHashes() for every genome.
+        Returns a SketchSet (strided: start[g] = g*stride)."""
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        if sizes is not None:
+            sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+            stride = int(sizes.max()) if n else 1
+        else:
+            stride = int(size)
+        stride = max(stride, 1)
+        out = torch.empty((max(n, 1), stride), dtype=torch.int64, device=self.device)
+        cnt = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+        self.check(self.lib.rtc_sketch_minhash_dev(
+            self.h, _t_ptr(seq), _np_ptr(off), n, k, seed,
+            _np_ptr(sizes) if sizes is not None else None, int(size), _t_ptr(out), stride, _t_ptr(cnt)))
+        start = torch.arange(n, dtype=torch.int64, device=self.device) * stride
+        return SketchSet(out.view(-1), start, cnt[:n], 8, k, "minhash")
+
+    def sketch_kssd(self, seq, off, shuffled_dim, kmer_size=21, drlevel=3, stride=None):
+        """sketchFileWithKssd's per-file body.  shuffled_dim: int32[2^(4*half_subk)] from the host."""
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        sd = np.ascontiguousarray(shuffled_dim, dtype=np.int32)
+        half_k = (kmer_size + 1) // 2
+        use64 = half_k - drlevel > 8
+        maxlen = int((off[1:] - off[:-1]).max()) if n else 0
+        if stride is None:
+            keep = 1.0 / (16 ** drlevel)
+            stride = int(maxlen * keep * 1.5) + 256
+        while True:
+            t_dt = torch.int64 if use64 else torch.int32
+            out = torch.empty((max(n, 1), stride), dtype=t_dt, device=self.device)
+            cnt = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+            width = C.c_int()
+            need = C.c_uint32()
+            st = self.lib.rtc_sketch_kssd_dev(self.h, _t_ptr(seq), _np_ptr(off), n, kmer_size, drlevel,
+                                              _np_ptr(sd), _t_ptr(out), stride, _t_ptr(cnt),
+                                              C.byref(width), C.byref(need))
+            if st == _lib.RTC_ERR_OVERFLOW:
+                stride = int(need.value) + 64
+                continue
+            self.check(st)
+            break
+        start = torch.arange(n, dtype=torch.int64, device=self.device) * stride
+        return SketchSet(out.view(-1), start, cnt[:n], int(width.value), half_k * 2, "kssd")
+
+    # ---- all pairs ----------------------------------------------------------------------------
+    def pair_common(self, sk, row0=0, row1=None, col0=0, col1=None, lower_only=False, algo=0, out=None):
+        n = sk.n
+        row1 = n if row1 is None else row1
+        col1 = n if col1 is None else col1
+        ld = col1 - col0
+        if out is None:
+            out = torch.zeros((max(row1 - row0, 1), max(ld, 1)), dtype=torch.int32, device=self.device)
+        self.check(self.lib.rtc_pair_common_dev(self.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start),
+                                                _t_ptr(sk.len), n, row0, row1, col0, col1, _t_ptr(out),
+                                                out.stride(0), int(lower_only), algo))
+        return out
+
+    def extract_edges(self, common, sk, row0, row1, col0, col1, radio, cap):
+        edges = torch.empty((max(cap, 1), 3), dtype=torch.int32, device=self.device)
+        count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.check(self.lib.rtc_extract_edges_dev(self.h, _t_ptr(common), common.stride(0), row0, row1,
+                                                  col0, col1, _t_ptr(sk.len), radio, _t_ptr(edges), cap,
+                                                  _t_ptr(count)))
+        return edges, count
+
+    def mst(self, sk, threshold, is_containment=False):
+        """compute_minhash_mst / compute_kssd_mst: returns numpy EDGE_DT array (edge.mst records)."""
+        n = sk.n
+        out = np.zeros(max(n, 1), dtype=EDGE_DT)
+        m = C.c_uint64()
+        self.check(self.lib.rtc_mst(self.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start), _t_ptr(sk.len),
+                                    n, sk.k, int(is_containment), float(threshold), _np_ptr(out), C.byref(m)))
+        return out[:m.value].copy()
+
+    def greedy(self, sk, threshold, size_cfg=None, is_containment=False):
+        n = sk.n
+        rep = np.zeros(max(n, 1), dtype=np.int32)
+        nc = C.c_uint32()
+        cfg = None
+        if size_cfg is not None:
+            cfg = np.ascontiguousarray(np.broadcast_to(np.asarray(size_cfg, dtype=np.uint32), (n,)))
+        self.check(self.lib.rtc_greedy(self.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start), _t_ptr(sk.len),
+                                       n, _np_ptr(cfg) if cfg is not None else None, sk.k,
+                                       int(is_containment), int(sk.kind == "kssd"), float(threshold),
+                                       _np_ptr(rep), C.byref(nc)))
+        return int(nc.value), rep[:n].copy()
+
+
+# ---- host-side arithmetic shared by CLI-equivalent flows (reference expression order) -------------
+def mst_radio(threshold, kmer_size):
+    """src/MST.cpp:26-37,1292: (int)(2*exp(thr*(k-1)) - 1)."""
+    return int(2.0 * math.exp(threshold * (kmer_size - 1)) - 1.0)
+
+
+def mst_distance(common, size0, size1, kmer_size, is_containment):
+    """src/MST.cpp:1295,1489-1515 evaluated with the same operation order (host libm)."""
+    inv_k = 1.0 / kmer_size
+    if not is_containment:
+        denom = size0 + size1 - common
+        jac = 0.0 if denom == 0 else common / denom
+        if jac == 1.0:
+            return 0.0
+        if jac == 0.0:
+            return 1.0
+        ratio = (2.0 * jac) / (1.0 + jac)
+        return -inv_k * math.log(ratio)
+    denom = min(size0, size1)
+    c = 0.0 if denom == 0 else common / denom
+    if c == 1.0:
+        return 0.0
+    if c == 0.0:
+        return 1.0
+    return -inv_k * math.log(c)
+
+
+def synth_family_descs(n_families, per_family, global_seed=42, max_rate=0.08, n_every=0):
+    """SURVEY.md 8d synthetic design: families of `per_family` members, member 0 is the ancestor,
+    member m>0 carries substitutions at rate U[0,max_rate] drawn from a counter-based stream."""
+    def mix(x):
+        x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+    n = n_families * per_family
+    d = np.zeros(n, dtype=SYNTH_DT)
+    for f in range(n_families):
+        fs = mix((global_seed << 20) ^ (f * 2 + 1))
+        for m in range(per_family):
+            g = f * per_family + m
+            ms = mix(fs ^ (m * 0x632BE59BD9B4E019 & 0xFFFFFFFFFFFFFFFF))
+            rate = 0.0 if m == 0 else max_rate * ((mix(ms ^ 0xABCDEF) >> 11) / float(1 << 53))
+            d[g] = (fs, ms, int(rate * 16384), n_every)
+    return d

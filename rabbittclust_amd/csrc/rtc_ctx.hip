@@ -1,0 +1,158 @@
+// rtc_ctx.hip -- context, error reporting, device memory helpers, event timer.
+#include <stdarg.h>
+#include <string.h>
+
+#include "rtc_internal.h"
+
+int rtc_fail(rtc_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+int rtc_ws(rtc_ctx* ctx, int slot, size_t bytes, void** out) {
+  if (slot < 0 || slot >= 4) return rtc_fail(ctx, RTC_ERR_ARG, "bad scratch slot %d", slot);
+  if (bytes > ctx->ws_bytes[slot]) {
+    RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ws[slot]) RTC_HIP(ctx, hipFree(ctx->ws[slot]));
+    ctx->ws[slot] = nullptr;
+    ctx->ws_bytes[slot] = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&ctx->ws[slot], want);
+    if (e != hipSuccess) return rtc_fail(ctx, RTC_ERR_NOMEM, "hipMalloc(%zu) scratch: %s", want, hipGetErrorString(e));
+    ctx->ws_bytes[slot] = want;
+  }
+  *out = ctx->ws[slot];
+  return RTC_OK;
+}
+
+int rtc_pinned(rtc_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->pinned_bytes) {
+    if (ctx->pinned) RTC_HIP(ctx, hipHostFree(ctx->pinned));
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    size_t want = bytes + 4096;
+    RTC_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+    ctx->pinned_bytes = want;
+  }
+  *out = ctx->pinned;
+  return RTC_OK;
+}
+
+extern "C" {
+
+const char* rtc_version(void) { return "rabbittclust_amd 0.1 (gfx950)"; }
+
+int rtc_ctx_create(int device, rtc_ctx** out) {
+  if (!out) return RTC_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RTC_ERR_HIP;
+  if (device < 0 || device >= ndev) return RTC_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return RTC_ERR_HIP;
+  rtc_ctx* ctx = new rtc_ctx();
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    ctx->num_cu = prop.multiProcessorCount;
+    ctx->lds_per_wg = (int)prop.sharedMemPerBlock;
+  }
+  if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+    delete ctx;
+    return RTC_ERR_HIP;
+  }
+  *out = ctx;
+  return RTC_OK;
+}
+
+void rtc_ctx_destroy(rtc_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < 4; i++)
+    if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  delete ctx;
+}
+
+int rtc_ctx_set_stream(rtc_ctx* ctx, void* hip_stream) {
+  if (!ctx) return RTC_ERR_ARG;
+  ctx->stream = (hipStream_t)hip_stream;
+  return RTC_OK;
+}
+
+int rtc_ctx_sync(rtc_ctx* ctx) {
+  if (!ctx) return RTC_ERR_ARG;
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RTC_OK;
+}
+
+const char* rtc_last_error(const rtc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rtc_device_info(rtc_ctx* ctx, int out[3]) {
+  if (!ctx || !out) return RTC_ERR_ARG;
+  out[0] = ctx->num_cu;
+  out[1] = ctx->lds_per_wg;
+  out[2] = 64;
+  return RTC_OK;
+}
+
+int rtc_dev_alloc(rtc_ctx* ctx, size_t bytes, void** d_ptr) {
+  if (!ctx || !d_ptr) return RTC_ERR_ARG;
+  *d_ptr = nullptr;
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(d_ptr, bytes);
+  if (e != hipSuccess) return rtc_fail(ctx, RTC_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  return RTC_OK;
+}
+
+int rtc_dev_free(rtc_ctx* ctx, void* d_ptr) {
+  if (!ctx) return RTC_ERR_ARG;
+  if (d_ptr) RTC_HIP(ctx, hipFree(d_ptr));
+  return RTC_OK;
+}
+
+int rtc_copy_h2d(rtc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  if (!ctx || (bytes && (!d_dst || !h_src))) return RTC_ERR_ARG;
+  if (!bytes) return RTC_OK;
+  RTC_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RTC_OK;
+}
+
+int rtc_copy_d2h(rtc_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+  if (!ctx || (bytes && (!h_dst || !d_src))) return RTC_ERR_ARG;
+  if (!bytes) return RTC_OK;
+  RTC_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RTC_OK;
+}
+
+int rtc_memset_dev(rtc_ctx* ctx, void* d_ptr, int value, size_t bytes) {
+  if (!ctx || (bytes && !d_ptr)) return RTC_ERR_ARG;
+  if (!bytes) return RTC_OK;
+  RTC_HIP(ctx, hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
+  return RTC_OK;
+}
+
+int rtc_timer_start(rtc_ctx* ctx) {
+  if (!ctx) return RTC_ERR_ARG;
+  RTC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return RTC_OK;
+}
+
+int rtc_timer_stop(rtc_ctx* ctx, float* ms_out) {
+  if (!ctx || !ms_out) return RTC_ERR_ARG;
+  RTC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  RTC_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  RTC_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+  return RTC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// rtc_pairs.hip -- all-pairs |A_i ∩ A_j| over sorted distinct sketches.
+//
+// Produces the integers compute_minhash_mst / compute_kssd_mst get from their inverted index
+// (src/MST.cpp:1408-1435, :428-487 in the reference tree) for every (i, j) of a tile, i.e. the
+// dense form of modifyMST's pair loop (src/MST.cpp:851-866).
+//
+//   algo 1  pair_merge_kernel : one lane per pair, two-pointer merge straight from global memory.
+//           Handles any sketch size / width; used as fallback and as on-device cross-check.
+//   algo 2  (rtc_pairs_tiled.hip) LDS mask-table tiles.
+#include "rtc_internal.h"
+
+int rtc_pair_common_tiled(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+                          const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1,
+                          uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld,
+                          int lower_only, int* handled);
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void pair_merge_kernel(const T* __restrict__ hashes,
+                                                         const uint64_t* __restrict__ start,
+                                                         const uint32_t* __restrict__ len,
+                                                         uint32_t row0, uint32_t row1, uint32_t col0,
+                                                         uint32_t col1, uint32_t* __restrict__ out,
+                                                         uint64_t ld, int lower_only) {
+  const uint32_t col = col0 + blockIdx.x * 64 + (threadIdx.x & 63);
+  const uint32_t row = row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (row >= row1 || col >= col1) return;
+  if (lower_only && col >= row) return;
+  const T* a = hashes + start[row];
+  const T* b = hashes + start[col];
+  const uint32_t na = len[row], nb = len[col];
+  uint32_t i = 0, j = 0, c = 0;
+  if (na && nb) {
+    T va = a[0], vb = b[0];
+    while (true) {
+      if (va < vb) { if (++i >= na) break; va = a[i]; }
+      else if (vb < va) { if (++j >= nb) break; vb = b[j]; }
+      else { c++; ++i; ++j; if (i >= na || j >= nb) break; va = a[i]; vb = b[j]; }
+    }
+  }
+  out[(uint64_t)(row - row0) * ld + (col - col0)] = c;
+}
+
+}  // namespace
+
+extern "C" int rtc_pair_common_dev(rtc_ctx* ctx, const void* d_hashes, int width,
+                                   const uint64_t* d_start, const uint32_t* d_len, uint32_t n,
+                                   uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1,
+                                   uint32_t* d_common, uint64_t ld, int lower_only, int algo) {
+  if (!ctx || !d_start || !d_len || !d_common) return RTC_ERR_ARG;
+  if (width != 4 && width != 8) return rtc_fail(ctx, RTC_ERR_ARG, "width must be 4 or 8");
+  if (row1 > n || col1 > n || row0 > row1 || col0 > col1) return rtc_fail(ctx, RTC_ERR_ARG, "tile outside [0,n)");
+  if (ld < (uint64_t)(col1 - col0)) return rtc_fail(ctx, RTC_ERR_ARG, "ld smaller than tile width");
+  if (algo < 0 || algo > 2) return rtc_fail(ctx, RTC_ERR_ARG, "unknown algo %d", algo);
+  if (row0 == row1 || col0 == col1) return RTC_OK;
+  if (!d_hashes) return RTC_ERR_ARG;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  if (algo == 0 || algo == 2) {
+    int handled = 0;
+    int st = rtc_pair_common_tiled(ctx, d_hashes, width, d_start, d_len, n, row0, row1, col0, col1,
+                                   d_common, ld, lower_only, &handled);
+    if (st != RTC_OK) return st;
+    if (handled) return RTC_OK;
+    if (algo == 2) return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "tiled pair kernel cannot take this input");
+  }
+  dim3 grid((col1 - col0 + 63) / 64, (row1 - row0 + 3) / 4);
+  if (grid.y > 65535) return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "more than 262140 rows per call in merge path");
+  if (width == 8)
+    hipLaunchKernelGGL(pair_merge_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream,
+                       (const uint64_t*)d_hashes, d_start, d_len, row0, row1, col0, col1, d_common, ld, lower_only);
+  else
+    hipLaunchKernelGGL(pair_merge_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream,
+                       (const uint32_t*)d_hashes, d_start, d_len, row0, row1, col0, col1, d_common, ld, lower_only);
+  RTC_CHECK_LAUNCH(ctx);
+  return RTC_OK;
+}

@@ -1,0 +1,113 @@
+"""GPU parity: MinHash sketch kernel vs the CPU oracle (bit-exact hash sets)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_genomes(rng, lens, n_rate=0.0, lower_rate=0.0):
+    parts, off = [], [0]
+    for L in lens:
+        g = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L)
+        if n_rate and L:
+            idx = rng.random(L) < n_rate
+            g[idx] = rng.choice(np.frombuffer(b"NRYKMnx-", dtype=np.uint8), size=int(idx.sum()))
+        if lower_rate and L:
+            idx = rng.random(L) < lower_rate
+            g[idx] |= 0x20
+        parts.append(g)
+        off.append(off[-1] + L)
+    seq = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    return seq, np.array(off, dtype=np.uint64)
+
+
+def _check(ctx, oracle, seq, off, k, size=None, sizes=None):
+    d = ctx.upload_sequences(seq)
+    sk = ctx.sketch_minhash(d, off, k=k, size=size if size else 1, sizes=sizes)
+    ctx.sync()
+    got = sk.to_host()
+    want = oracle.sketch_minhash_batch(seq, off, k, sizes if sizes is not None else size)
+    assert len(got) == len(want)
+    for g, (a, b) in enumerate(zip(got, want)):
+        assert np.array_equal(a, b), f"genome {g}: k={k} got {len(a)} want {len(b)}"
+
+
+@pytest.mark.parametrize("k", [21, 17, 16, 11, 32, 5])
+def test_sketch_matches_oracle_various_k(ctx, oracle, k):
+    rng = np.random.default_rng(100 + k)
+    seq, off = _random_genomes(rng, [50_000, 123_457, 80_001, 15_359, 15_361, 30_720])
+    _check(ctx, oracle, seq, off, k, size=1000)
+
+
+def test_sketch_with_n_runs_and_lowercase(ctx, oracle):
+    rng = np.random.default_rng(7)
+    seq, off = _random_genomes(rng, [200_000, 100_000, 60_000], n_rate=0.003, lower_rate=0.3)
+    _check(ctx, oracle, seq, off, 21, size=1000)
+
+
+def test_sketch_short_empty_and_ragged(ctx, oracle):
+    rng = np.random.default_rng(8)
+    lens = [0, 1, 20, 21, 22, 100, 0, 999, 5000, 16, 15375, 3]
+    seq, off = _random_genomes(rng, lens)
+    _check(ctx, oracle, seq, off, 21, size=1000)
+    _check(ctx, oracle, seq, off, 21, size=50)
+
+
+def test_sketch_multi_record_separator(ctx, oracle):
+    rng = np.random.default_rng(9)
+    recs = [rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L) for L in (5000, 30, 20, 7000, 21)]
+    sep = np.frombuffer(b"\n", dtype=np.uint8)
+    g = np.concatenate([x for r in recs for x in (r, sep)])
+    seq = np.concatenate([g, g[::-1].copy()])
+    off = np.array([0, len(g), 2 * len(g)], dtype=np.uint64)
+    _check(ctx, oracle, seq, off, 21, size=400)
+    # the oracle's own per-record update() must agree with the separator convention
+    m = oracle.lib().orc_mh_new(21, 400, 42)
+    import ctypes as C
+    for r in recs:
+        oracle.lib().orc_mh_update(C.c_void_p(m), r.ctypes.data_as(C.c_void_p), C.c_uint64(len(r)))
+    out = np.zeros(400, dtype=np.uint64)
+    oracle.lib().orc_mh_store.restype = C.c_uint32
+    c = oracle.lib().orc_mh_store(C.c_void_p(m), out.ctypes.data_as(C.c_void_p), C.c_uint32(400))
+    want = oracle.sketch_minhash_batch(g, np.array([0, len(g)], dtype=np.uint64), 21, 400)[0]
+    assert np.array_equal(out[:c], want)
+
+
+def test_sketch_variable_sizes_containment_mode(ctx, oracle):
+    rng = np.random.default_rng(10)
+    lens = [400_000, 150_000, 90_000, 1_000_000]
+    seq, off = _random_genomes(rng, lens)
+    sizes = np.array([max(L // 100, 100) for L in lens], dtype=np.uint32)  # fileBytes/compress
+    _check(ctx, oracle, seq, off, 21, sizes=sizes)
+
+
+def test_sketch_repetitive_genome(ctx, oracle):
+    # heavy duplication: the same 3 kb unit repeated -> every k-mer recurs ~70 times
+    rng = np.random.default_rng(11)
+    unit = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=3000)
+    g = np.tile(unit, 70)
+    poly = np.full(50_000, ord("A"), dtype=np.uint8)
+    seq = np.concatenate([g, poly])
+    off = np.array([0, len(g), len(g) + len(poly)], dtype=np.uint64)
+    _check(ctx, oracle, seq, off, 21, size=1000)
+
+
+def test_sketch_large_genome_is_segmented(ctx, oracle):
+    # one 6 Mbp genome in a tiny batch is split into segments and merged
+    d = oracle.synth_genome(1234, 99, 300, 6_000_000)
+    off = np.array([0, len(d)], dtype=np.uint64)
+    _check(ctx, oracle, d, off, 21, size=1000)
+
+
+def test_synth_device_matches_oracle(ctx, oracle):
+    from rabbittclust_amd import api
+    desc = api.synth_family_descs(3, 3, global_seed=5, n_every=0)
+    desc["n_every"][4] = 5000
+    lens = [10_000, 33_333, 16, 70_001, 15, 60_000, 1, 100, 4097]
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    seq = ctx.synth_genomes(desc, off).cpu().numpy()
+    for g, L in enumerate(lens):
+        ref = oracle.synth_genome(int(desc[g]["fam_seed"]), int(desc[g]["mut_seed"]),
+                                  int(desc[g]["mut_thr"]), L, int(desc[g]["n_every"]))
+        assert np.array_equal(ref, seq[int(off[g]):int(off[g + 1])]), g
