@@ -34,7 +34,7 @@ int rtc_ctx_create(int device, rtc_ctx** out);
 void rtc_ctx_destroy(rtc_ctx* ctx);
 int rtc_ctx_set_stream(rtc_ctx* ctx, void* hip_stream); /* NULL = default stream */
 int rtc_ctx_sync(rtc_ctx* ctx);
-const char* rtc_last_error(const rtc_ctx* ctx);
+const char* rtc_last_error(const rtc_ctx* ctx); /* ctx may be NULL: last context-less failure */
 const char* rtc_version(void);
 /* device properties: out[0]=CU count, out[1]=LDS bytes per workgroup, out[2]=wavefront size */
 int rtc_device_info(rtc_ctx* ctx, int out[3]);
@@ -128,8 +128,24 @@ int rtc_boruvka_minedge_dev(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m,
                             const uint32_t* d_len, int is_containment, const uint32_t* d_comp,
                             uint32_t n, const uint64_t* d_wkey, uint64_t* d_ekey);
 
+/* After d_ekey is final (all-reduced), the rank owning each winning edge publishes its `common`
+ * into d_ecommon[component] (others leave 0; all-reduce(MAX) across ranks). */
+int rtc_boruvka_fetch_dev(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_comp,
+                          uint32_t n, const uint64_t* d_ekey, uint32_t* d_ecommon);
+
+/* Host helper closing one Boruvka round: unions the components joined by the winning edges
+ * (h_ekey[c] = i<<32|j or 0x7FFF...F for none), appends them to h_sel (capacity n) and relabels
+ * h_comp[v] with the new root vertex ids.  *h_added == 0 means the forest is complete. */
+int rtc_boruvka_merge_host(uint32_t n, const uint64_t* h_ekey, const uint32_t* h_ecommon, uint32_t* h_comp,
+                           rtc_cedge* h_sel, uint64_t* h_n_sel, uint64_t* h_added);
+
 /* EdgeInfo of the reference (src/MST.h:17-21); the on-disk edge.mst record (src/MST_IO.cpp:200-217) */
 typedef struct { int32_t preNode, sufNode; double dist; } rtc_edge;
+
+/* Host helper: selected forest edges (i, j, common) -> EdgeInfo records with the reference's
+ * double arithmetic (src/MST.cpp:1295,1489-1515), sorted by (dist, preNode, sufNode). */
+int rtc_edges_to_mst_host(const rtc_cedge* h_sel, uint64_t m, const uint32_t* h_len, int kmer_size,
+                          int is_containment, rtc_edge* h_out);
 
 /* Whole single-GPU MST step: compute_minhash_mst / compute_kssd_mst (src/MST.cpp:1290-1737,
  * :216-807) from device-resident sketches.  Distances are evaluated on the HOST with the

@@ -60,6 +60,9 @@ SIGNATURES = {
     "rtc_extract_edges_dev": (_i, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _vp, _i, _vp, _u64, _vp]),
     "rtc_boruvka_minweight_dev": (_i, [_vp, _vp, _u64, _vp, _i, _vp, _u32, _vp]),
     "rtc_boruvka_minedge_dev": (_i, [_vp, _vp, _u64, _vp, _i, _vp, _u32, _vp, _vp]),
+    "rtc_boruvka_fetch_dev": (_i, [_vp, _vp, _u64, _vp, _u32, _vp, _vp]),
+    "rtc_boruvka_merge_host": (_i, [_u32, _vp, _vp, _vp, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "rtc_edges_to_mst_host": (_i, [_vp, _u64, _vp, _i, _i, _vp]),
     "rtc_mst": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64)]),
     "rtc_greedy": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _vp, _i, _i, _i, C.c_double, _vp,
                         C.POINTER(_u32)]),
@@ -76,6 +79,10 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  It must be the first HIP
+        # runtime in the process so that our DT_NEEDED entry binds to it; two runtimes in one
+        # process cannot both see the GPU.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol

@@ -70,10 +70,12 @@ class Context:
             raise RtcError(_lib.RTC_ERR_HIP, "no HIP device visible: the MI355X path has no CPU fallback")
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
+        torch.cuda.init()
+        torch.empty(1, device=self.device)  # force the HIP runtime torch bundles to initialise first
         h = C.c_void_p()
         st = self.lib.rtc_ctx_create(device, C.byref(h))
         if st != _lib.RTC_OK:
-            raise RtcError(st, "rtc_ctx_create failed")
+            raise RtcError(st, "rtc_ctx_create: " + self.lib.rtc_last_error(None).decode(errors="replace"))
         self.h = h
         self.use_torch_stream()
 

@@ -4,6 +4,8 @@
 
 #include "rtc_internal.h"
 
+static thread_local std::string g_err;  // failures that happen without a context
+
 int rtc_fail(rtc_ctx* ctx, int code, const char* fmt, ...) {
   char buf[1024];
   va_list ap;
@@ -11,6 +13,7 @@ int rtc_fail(rtc_ctx* ctx, int code, const char* fmt, ...) {
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
   if (ctx) ctx->err = buf;
+  else g_err = buf;
   return code;
 }
 
@@ -51,9 +54,12 @@ int rtc_ctx_create(int device, rtc_ctx** out) {
   if (!out) return RTC_ERR_ARG;
   *out = nullptr;
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RTC_ERR_HIP;
-  if (device < 0 || device >= ndev) return RTC_ERR_ARG;
-  if (hipSetDevice(device) != hipSuccess) return RTC_ERR_HIP;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return rtc_fail(nullptr, RTC_ERR_HIP, "hipGetDeviceCount -> %s (%d devices)", hipGetErrorString(e), ndev);
+  if (device < 0 || device >= ndev) return rtc_fail(nullptr, RTC_ERR_ARG, "device %d of %d", device, ndev);
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return rtc_fail(nullptr, RTC_ERR_HIP, "hipSetDevice(%d) -> %s", device, hipGetErrorString(e));
   rtc_ctx* ctx = new rtc_ctx();
   ctx->device = device;
   hipDeviceProp_t prop;
@@ -63,7 +69,7 @@ int rtc_ctx_create(int device, rtc_ctx** out) {
   }
   if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
     delete ctx;
-    return RTC_ERR_HIP;
+    return rtc_fail(nullptr, RTC_ERR_HIP, "hipEventCreate failed");
   }
   *out = ctx;
   return RTC_OK;
@@ -93,7 +99,7 @@ int rtc_ctx_sync(rtc_ctx* ctx) {
   return RTC_OK;
 }
 
-const char* rtc_last_error(const rtc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char* rtc_last_error(const rtc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
 int rtc_device_info(rtc_ctx* ctx, int out[3]) {
   if (!ctx || !out) return RTC_ERR_ARG;

@@ -1,0 +1,173 @@
+"""clust-mst hot path as one step: sketch -> [all-gather] -> row-sharded all-pairs -> edges -> MSF.
+
+Mirrors clust_from_genomes -> compute_sketches -> compute_clusters of the reference
+(src/sub_command.cpp:2302-2315, :2858-2889, :2924-3053) from the sketching call down to the
+`vector<EdgeInfo> mst`.  Multi-GPU: one process per GPU; sketches are all-gathered once (RCCL),
+the strict lower triangle of the N x N pair space is split into contiguous row ranges of equal
+area, and every Boruvka round all-reduces (MIN) two u64 arrays (weight key, then edge id).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .api import CEDGE_DT, EDGE_DT, SketchSet, _np_ptr, _t_ptr, mst_radio
+
+KEY_NONE = 0x7FFFFFFFFFFFFFFF
+
+
+def triangle_row_ranges(n, world):
+    """Contiguous row ranges [b_r, b_{r+1}) of the strict lower triangle with ~equal pair counts
+    (row i owns i pairs, so boundaries go like n*sqrt(r/world))."""
+    b = [int(round(n * math.sqrt(r / world))) for r in range(world + 1)]
+    b[0], b[-1] = 0, n
+    for r in range(1, world + 1):
+        b[r] = max(b[r], b[r - 1])
+    return b
+
+
+class MstPipeline:
+    def __init__(self, ctx, k=21, sketch_size=1000, threshold=0.05, is_containment=False,
+                 dist=None, rank=0, world=1, row_chunk_bytes=2 << 30):
+        self.ctx, self.k, self.s, self.threshold = ctx, k, sketch_size, threshold
+        self.is_containment = is_containment
+        self.dist, self.rank, self.world = dist, rank, world
+        self.row_chunk_bytes = row_chunk_bytes
+        self.last_sketches = None
+        self.last_mst = None
+        self._edge_cap = 1 << 20
+        self._edges = None
+
+    # ---- pieces ---------------------------------------------------------------------------------
+    def gather_sketches(self, sk):
+        """All ranks end up with every genome's sketch (strided layout, stride = sketch_size)."""
+        if self.world == 1:
+            return sk
+        n_local = sk.n
+        stride = sk.hashes.numel() // max(n_local, 1)
+        hashes = torch.empty(self.world * sk.hashes.numel(), dtype=sk.hashes.dtype, device=sk.hashes.device)
+        lens = torch.empty(self.world * n_local, dtype=sk.len.dtype, device=sk.len.device)
+        self.dist.all_gather_into_tensor(hashes, sk.hashes.contiguous())
+        self.dist.all_gather_into_tensor(lens, sk.len.contiguous())
+        n = self.world * n_local
+        start = torch.arange(n, dtype=torch.int64, device=sk.hashes.device) * stride
+        return SketchSet(hashes, start, lens, sk.width, sk.k, sk.kind)
+
+    def candidate_edges(self, sk, row0, row1):
+        """Dense common counts for rows [row0,row1) x cols [0,row) in chunks, filtered into a
+        compact (i, j, common) list on the device."""
+        ctx = self.ctx
+        n = sk.n
+        radio = mst_radio(self.threshold, sk.k)
+        count = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+        if self._edges is None or self._edges.shape[0] < self._edge_cap:
+            self._edges = torch.empty((self._edge_cap, 3), dtype=torch.int32, device=ctx.device)
+        rows_per = max(64, min(max(row1 - row0, 1), self.row_chunk_bytes // (max(n, 1) * 4)))
+        rows_per = max(64, (rows_per // 64) * 64)
+        m = 0
+        r0 = max(row0, 1)
+        common = None
+        while r0 < row1:
+            r1 = min(row1, r0 + rows_per)
+            c1 = r1 - 1
+            if common is None or common.shape[0] < (r1 - r0) or common.shape[1] < c1:
+                common = torch.empty((rows_per, max(n, 1)), dtype=torch.int32, device=ctx.device)
+            ctx.check(ctx.lib.rtc_pair_common_dev(ctx.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start),
+                                                  _t_ptr(sk.len), n, r0, r1, 0, c1, _t_ptr(common),
+                                                  common.stride(0), 1, 0))
+            while True:
+                ctx.check(ctx.lib.rtc_extract_edges_dev(ctx.h, _t_ptr(common), common.stride(0), r0, r1, 0, c1,
+                                                        _t_ptr(sk.len), radio, _t_ptr(self._edges),
+                                                        self._edges.shape[0], _t_ptr(count)))
+                cnt = int(count.item())
+                if cnt <= self._edges.shape[0]:
+                    m = cnt
+                    break
+                self._edge_cap = max(cnt + cnt // 2, self._edge_cap * 2)
+                bigger = torch.empty((self._edge_cap, 3), dtype=torch.int32, device=ctx.device)
+                bigger[:m] = self._edges[:m]
+                self._edges = bigger
+                count.fill_(m)
+            r0 = r1
+        return self._edges, m
+
+    def boruvka(self, sk, edges, m):
+        ctx, n = self.ctx, sk.n
+        dev = ctx.device
+        wkey = torch.empty(n, dtype=torch.int64, device=dev)
+        ekey = torch.empty(n, dtype=torch.int64, device=dev)
+        ecommon = torch.empty(n, dtype=torch.int32, device=dev)
+        comp_h = np.arange(n, dtype=np.uint32)
+        comp = torch.empty(n, dtype=torch.int32, device=dev)
+        sel = np.zeros(max(n, 1), dtype=CEDGE_DT)
+        nsel, added = C.c_uint64(0), C.c_uint64(0)
+        ic = int(self.is_containment)
+        rounds = 0
+        for _ in range(64):
+            comp.copy_(torch.from_numpy(comp_h.view(np.int32)))
+            ctx.check(ctx.lib.rtc_boruvka_minweight_dev(ctx.h, _t_ptr(edges), m, _t_ptr(sk.len), ic,
+                                                        _t_ptr(comp), n, _t_ptr(wkey)))
+            if self.world > 1:
+                self.dist.all_reduce(wkey, op=self.dist.ReduceOp.MIN)
+            ctx.check(ctx.lib.rtc_boruvka_minedge_dev(ctx.h, _t_ptr(edges), m, _t_ptr(sk.len), ic,
+                                                      _t_ptr(comp), n, _t_ptr(wkey), _t_ptr(ekey)))
+            if self.world > 1:
+                self.dist.all_reduce(ekey, op=self.dist.ReduceOp.MIN)
+            ctx.check(ctx.lib.rtc_boruvka_fetch_dev(ctx.h, _t_ptr(edges), m, _t_ptr(comp), n, _t_ptr(ekey),
+                                                    _t_ptr(ecommon)))
+            if self.world > 1:
+                self.dist.all_reduce(ecommon, op=self.dist.ReduceOp.MAX)
+            ekey_h = ekey.cpu().numpy().view(np.uint64)
+            ecommon_h = ecommon.cpu().numpy().view(np.uint32)
+            st = ctx.lib.rtc_boruvka_merge_host(n, _np_ptr(ekey_h), _np_ptr(ecommon_h), _np_ptr(comp_h),
+                                                _np_ptr(sel), C.byref(nsel), C.byref(added))
+            if st != _lib.RTC_OK:
+                raise _lib.RtcError(st, "rtc_boruvka_merge_host")
+            rounds += 1
+            if added.value == 0:
+                break
+        return sel[: nsel.value], rounds
+
+    def finish(self, sk, sel):
+        """(i, j, common) -> EdgeInfo records with the reference's double arithmetic, sorted."""
+        lens_h = sk.len.cpu().numpy().view(np.uint32)
+        out = np.zeros(max(len(sel), 1), dtype=EDGE_DT)
+        sel = np.ascontiguousarray(sel)
+        st = self.ctx.lib.rtc_edges_to_mst_host(_np_ptr(sel), len(sel), _np_ptr(lens_h), sk.k,
+                                                int(self.is_containment), _np_ptr(out))
+        if st != _lib.RTC_OK:
+            raise _lib.RtcError(st, "rtc_edges_to_mst_host")
+        return out[: len(sel)]
+
+    # ---- one step ---------------------------------------------------------------------------------
+    def step(self, seq, off, sizes=None):
+        ctx = self.ctx
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        sk_local = ctx.sketch_minhash(seq, off, k=self.k, size=self.s, sizes=sizes)
+        ev[1].record()
+        sk = self.gather_sketches(sk_local)
+        ev[2].record()
+        b = triangle_row_ranges(sk.n, self.world)
+        row0, row1 = b[self.rank], b[self.rank + 1]
+        edges, m = self.candidate_edges(sk, row0, row1)
+        ev[3].record()
+        sel, rounds = self.boruvka(sk, edges, m)
+        mst = self.finish(sk, sel)
+        ev[4].record()
+        torch.cuda.synchronize()
+        self.last_sketches, self.last_mst = sk, mst
+        pairs_local = (row1 * (row1 - 1) - row0 * (row0 - 1)) // 2 if row1 > 0 else 0
+        return {
+            "sketch_ms": ev[0].elapsed_time(ev[1]),
+            "gather_ms": ev[1].elapsed_time(ev[2]),
+            "pair_ms": ev[2].elapsed_time(ev[3]),
+            "mst_ms": ev[3].elapsed_time(ev[4]),
+            "dist_ms": ev[2].elapsed_time(ev[4]),
+            "pairs_local": float(pairs_local),
+            "cand_edges": float(m),
+            "boruvka_rounds": float(rounds),
+            "mst_edges": float(len(mst)),
+        }

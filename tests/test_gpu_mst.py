@@ -1,0 +1,107 @@
+"""GPU parity: candidate edges and the minimum spanning forest vs the oracle's restatement of
+compute_minhash_mst (src/MST.cpp:1290-1737).  Ties make the edge SET ambiguous (the reference
+uses an unstable sort), so the asserted invariants are: identical sorted multiset of edge
+weights (bit-for-bit doubles), identical partition at the threshold, forest size."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _partition(clusters):
+    return sorted(tuple(sorted(c)) for c in clusters)
+
+
+def _clusters_from_edges(edges, thr, n):
+    parent = list(range(n))
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for e in edges:
+        if e["dist"] <= thr:
+            a, b = find(int(e["preNode"])), find(int(e["sufNode"]))
+            if a != b:
+                parent[a] = b
+    groups = {}
+    for v in range(n):
+        groups.setdefault(find(v), []).append(v)
+    return list(groups.values())
+
+
+def _family_sketches(ctx, n_fam, per, L, size=1000, seed=3):
+    from rabbittclust_amd import api
+    desc = api.synth_family_descs(n_fam, per, global_seed=seed)
+    off = np.arange(len(desc) + 1, dtype=np.uint64) * L
+    seq = ctx.synth_genomes(desc, off)
+    return ctx.sketch_minhash(seq, off, k=21, size=size), seq, off
+
+
+@pytest.mark.parametrize("containment", [False, True])
+def test_mst_matches_oracle_on_families(ctx, oracle, containment):
+    sk, _, _ = _family_sketches(ctx, 12, 6, 100_000)
+    host = sk.to_host()
+    flat, start, lens = oracle.to_csr(host)
+    for thr in (0.01, 0.05, 0.1):
+        got = ctx.mst(sk, thr, is_containment=containment)
+        want = oracle.mst(flat, start, lens, 21, containment, thr, threads=1)
+        assert len(got) == len(want)
+        assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
+        pw = _partition(oracle.forest_clusters(want, thr, len(host)))
+        pg = _partition(_clusters_from_edges(got, thr, len(host)))
+        assert pw == pg
+
+
+def test_mst_random_overlapping_sets_many_ties(ctx, oracle):
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(5)
+    pool = np.unique(rng.integers(1, 1 << 62, size=4000, dtype=np.uint64))
+    sk = []
+    for g in range(200):
+        size = int(rng.integers(20, 200))
+        sk.append(np.sort(rng.choice(pool, size=size, replace=False)))
+    sk[17] = np.zeros(0, dtype=np.uint64)
+    dev = api.SketchSet.from_host(sk, ctx.device, k=21)
+    flat, start, lens = oracle.to_csr(sk)
+    for containment in (False, True):
+        got = ctx.mst(dev, 0.05, is_containment=containment)
+        want = oracle.mst(flat, start, lens, 21, containment, 0.05, threads=1)
+        assert len(got) == len(want)
+        assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
+        for thr in (0.05, 0.2, 0.4):
+            assert _partition(oracle.forest_clusters(want, thr, 200)) == _partition(_clusters_from_edges(got, thr, 200))
+
+
+def test_extract_edges_equals_oracle_candidates(ctx, oracle):
+    from rabbittclust_amd import api
+    sk, _, _ = _family_sketches(ctx, 8, 5, 60_000, seed=9)
+    host = sk.to_host()
+    n = len(host)
+    flat, start, lens = oracle.to_csr(host)
+    cand = oracle.candidate_pairs(flat, start, lens)
+    common = ctx.pair_common(sk, lower_only=True)
+    radio = api.mst_radio(0.05, 21)
+    edges, count = ctx.extract_edges(common, sk, 0, n, 0, n, radio, cap=n * n)
+    m = int(count.item())
+    got = edges[:m].cpu().numpy().view(np.uint32)
+    got = sorted(map(tuple, got.tolist()))
+    want = sorted((int(e["pre"]), int(e["suf"]), int(e["common"])) for e in cand)  # equal sizes -> radio passes
+    assert got == want
+
+
+def test_pipeline_step_single_gpu(ctx, oracle):
+    from rabbittclust_amd import api, pipeline
+    desc = api.synth_family_descs(10, 5, global_seed=21)
+    L = 80_000
+    off = np.arange(len(desc) + 1, dtype=np.uint64) * L
+    seq = ctx.synth_genomes(desc, off)
+    pipe = pipeline.MstPipeline(ctx, k=21, sketch_size=500, threshold=0.05)
+    stats = pipe.step(seq, off)
+    host = pipe.last_sketches.to_host()
+    flat, start, lens = oracle.to_csr(host)
+    want = oracle.mst(flat, start, lens, 21, 0, 0.05)
+    got = pipe.last_mst
+    assert stats["mst_edges"] == len(want)
+    assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
