@@ -1,7 +1,352 @@
-// rtc_pairs_tiled.hip -- LDS mask-table tiles (placeholder until the tiled kernel lands).
+// rtc_pairs_tiled.hip -- all-pairs |A_i ∩ A_j| with an LDS-resident row-block inverted table.
+//
+// Dense (every pair is evaluated, no data-dependent skipping of pairs) but work-efficient form of
+// the reference's inverted-index intersection (src/MST.cpp:1408-1435): instead of one merge per
+// pair, a workgroup owns a block of 64 rows x 1024 columns and, for each hash-range partition p,
+//   1. builds in LDS an open-addressing table  hash -> 64-bit mask of the rows containing it
+//      (bucketised, 4 keys per 32-byte bucket; ds_cmpst_b64 / ds_or_b64), from the rows' sorted
+//      slices that fall in partition p;
+//   2. every lane (= one column sketch) streams its own slice of partition p and probes the table
+//      with two ds_read_b128; a hit returns the mask of ALL 64 rows containing that hash;
+//   3. masks are accumulated in per-lane bit-sliced counters (plane k holds bit k of the 64 row
+//      counters), i.e. one probe serves 64 pairs and the add is a wave-uniform ripple of
+//      AND/XOR on 64-bit registers.
+// After the last partition each lane unpacks its 64 counters and writes them (coalesced across
+// lanes) to common[row][col].  Partition boundaries are data quantiles computed from a sample, so
+// the table load stays ~25 %; blocks whose slices would overflow the table are split into row
+// sub-blocks inside the kernel, and inputs the scheme cannot take fall back to the merge kernel.
+#include <algorithm>
+#include <vector>
+
 #include "rtc_internal.h"
-int rtc_pair_common_tiled(rtc_ctx*, const void*, int, const uint64_t*, const uint32_t*, uint32_t, uint32_t,
-                          uint32_t, uint32_t, uint32_t, uint32_t*, uint64_t, int, int* handled) {
-  *handled = 0;
+
+namespace {
+
+constexpr int TW = 1024;                // lanes per workgroup = columns per block
+constexpr int ROWS = 64;                // rows per block = mask width
+constexpr int SLOTS = 8192;             // table slots
+constexpr int BUCKET = 4;               // keys per bucket
+constexpr int NB = SLOTS / BUCKET;      // 2048 buckets
+constexpr int LOG2NB = 11;
+constexpr uint32_t KCAP_HARD = 5632;    // max keys per table build (~69 % load)
+constexpr uint32_t KTARGET = 2048;      // planned mean keys per table (25 % load)
+constexpr int MAXP = 512;
+
+template <typename T> struct KeyTraits;
+template <> struct KeyTraits<uint64_t> {
+  static constexpr uint64_t EMPTY = ~0ULL;
+  __device__ static __forceinline__ uint32_t bucket(uint64_t k) {
+    return (((uint32_t)k ^ (uint32_t)(k >> 32)) * 0x9E3779B1u) >> (32 - LOG2NB);
+  }
+};
+template <> struct KeyTraits<uint32_t> {
+  static constexpr uint32_t EMPTY = ~0u;
+  __device__ static __forceinline__ uint32_t bucket(uint32_t k) { return (k * 0x9E3779B1u) >> (32 - LOG2NB); }
+};
+
+struct TileShared {
+  uint32_t rlo[ROWS], rhi[ROWS];
+  uint64_t rstart[ROWS];
+  unsigned long long special;  // rows containing the EMPTY sentinel value itself
+  uint32_t nsub;
+  uint32_t sub_end[ROWS + 1];
+};
+
+__device__ __forceinline__ unsigned long long lds_cas(unsigned long long* p, unsigned long long cmp, unsigned long long v) {
+  return atomicCAS(p, cmp, v);
+}
+__device__ __forceinline__ uint32_t lds_cas(uint32_t* p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
+
+template <typename T>
+__device__ __forceinline__ void table_insert(T* keys, unsigned long long* masks, TileShared* sh, T key, int r) {
+  const unsigned long long bit = 1ULL << r;
+  if (key == KeyTraits<T>::EMPTY) { atomicOr(&sh->special, bit); return; }
+  uint32_t b = KeyTraits<T>::bucket(key);
+  while (true) {
+#pragma unroll
+    for (int j = 0; j < BUCKET; j++) {
+      const uint32_t slot = b * BUCKET + j;
+      T old;
+      if constexpr (sizeof(T) == 8) old = (T)lds_cas((unsigned long long*)&keys[slot], (unsigned long long)KeyTraits<T>::EMPTY, (unsigned long long)key);
+      else old = (T)lds_cas((uint32_t*)&keys[slot], (uint32_t)KeyTraits<T>::EMPTY, (uint32_t)key);
+      if (old == KeyTraits<T>::EMPTY || old == key) { atomicOr(&masks[slot], bit); return; }
+    }
+    b = (b + 1) & (NB - 1);
+  }
+}
+
+__device__ __forceinline__ unsigned long long table_lookup(const uint64_t* keys, const unsigned long long* masks,
+                                                           const TileShared* sh, uint64_t key) {
+  if (key == ~0ULL) return sh->special;
+  uint32_t b = KeyTraits<uint64_t>::bucket(key);
+  while (true) {
+    const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&keys[b * BUCKET]);
+    const ulonglong2 k23 = *reinterpret_cast<const ulonglong2*>(&keys[b * BUCKET + 2]);
+    int hit = -1;
+    if (k01.x == key) hit = 0;
+    if (k01.y == key) hit = 1;
+    if (k23.x == key) hit = 2;
+    if (k23.y == key) hit = 3;
+    if (hit >= 0) return masks[b * BUCKET + hit];
+    if (k01.x == ~0ULL || k01.y == ~0ULL || k23.x == ~0ULL || k23.y == ~0ULL) return 0ULL;
+    b = (b + 1) & (NB - 1);
+  }
+}
+
+__device__ __forceinline__ unsigned long long table_lookup(const uint32_t* keys, const unsigned long long* masks,
+                                                           const TileShared* sh, uint32_t key) {
+  if (key == ~0u) return sh->special;
+  uint32_t b = KeyTraits<uint32_t>::bucket(key);
+  while (true) {
+    const uint4 k = *reinterpret_cast<const uint4*>(&keys[b * BUCKET]);
+    int hit = -1;
+    if (k.x == key) hit = 0;
+    if (k.y == key) hit = 1;
+    if (k.z == key) hit = 2;
+    if (k.w == key) hit = 3;
+    if (hit >= 0) return masks[b * BUCKET + hit];
+    if (k.x == ~0u || k.y == ~0u || k.z == ~0u || k.w == ~0u) return 0ULL;
+    b = (b + 1) & (NB - 1);
+  }
+}
+
+// so: [(P+1)][n] slice offsets (so[p][g] = lower_bound(sketch g, bound[p])), so[0]=0, so[P]=len.
+template <typename T, int NPL>
+__global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ hashes,
+                                                        const uint64_t* __restrict__ start,
+                                                        const uint32_t* __restrict__ so, int P, uint32_t n,
+                                                        uint32_t row0, uint32_t row1, uint32_t col0,
+                                                        uint32_t col1, uint32_t* __restrict__ out, uint64_t ld,
+                                                        int lower_only) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* keys = reinterpret_cast<T*>(smem);
+  unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem + (size_t)SLOTS * sizeof(T));
+  TileShared* sh = reinterpret_cast<TileShared*>(smem + (size_t)SLOTS * (sizeof(T) + 8));
+
+  const int tid = threadIdx.x;
+  const uint32_t rb0 = row0 + blockIdx.y * ROWS;
+  const uint32_t nrows = min((uint32_t)ROWS, row1 - rb0);
+  const uint32_t cb0 = col0 + blockIdx.x * TW;
+  if (lower_only && cb0 + 1 > rb0 + nrows - 1) return;  // no (row, col) with col < row in this block
+  const uint32_t c = cb0 + tid;
+  const bool col_active = c < col1;
+  const uint32_t wave = tid >> 6, lane = tid & 63;
+
+  unsigned long long planes[NPL];
+#pragma unroll
+  for (int k = 0; k < NPL; k++) planes[k] = 0ULL;
+
+  const T* colp = hashes + (col_active ? start[c] : 0);
+  uint32_t clo = col_active ? so[c] : 0;  // so[0][c]
+  if (tid < ROWS) sh->rstart[tid] = tid < (int)nrows ? start[rb0 + tid] : 0;
+
+  for (int p = 0; p < P; p++) {
+    const uint32_t chi = col_active ? so[(size_t)(p + 1) * n + c] : 0;
+    __syncthreads();  // previous partition's probes are done (table and rlo/rhi reusable)
+    if (tid < ROWS) {
+      const bool rv = tid < (int)nrows;
+      sh->rlo[tid] = rv ? so[(size_t)p * n + rb0 + tid] : 0;
+      sh->rhi[tid] = rv ? so[(size_t)(p + 1) * n + rb0 + tid] : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {  // split the row block so that no table build exceeds KCAP_HARD keys
+      uint32_t ns = 0, acc = 0;
+      for (uint32_t r = 0; r < nrows; r++) {
+        const uint32_t sz = sh->rhi[r] - sh->rlo[r];
+        if (acc + sz > KCAP_HARD && acc > 0) { sh->sub_end[ns++] = r; acc = 0; }
+        acc += sz;
+      }
+      sh->sub_end[ns++] = nrows;
+      sh->nsub = ns;
+    }
+    __syncthreads();
+    const uint32_t nsub = sh->nsub;
+    uint32_t ra = 0;
+    for (uint32_t sb = 0; sb < nsub; sb++) {
+      const uint32_t rbnd = sh->sub_end[sb];
+      // ---- clear ----
+      {
+        uint4* kq = reinterpret_cast<uint4*>(keys);
+        for (int i = tid; i < (int)(SLOTS * sizeof(T) / 16); i += TW) kq[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        uint4* mq = reinterpret_cast<uint4*>(masks);
+        for (int i = tid; i < SLOTS * 8 / 16; i += TW) mq[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid == 0) sh->special = 0ULL;
+      }
+      __syncthreads();
+      // ---- build: wave w inserts rows ra+w, ra+w+16, ... ----
+      for (uint32_t r = ra + wave; r < rbnd; r += TW / 64) {
+        const T* rp = hashes + sh->rstart[r];
+        const uint32_t hi = sh->rhi[r];
+        for (uint32_t e = sh->rlo[r] + lane; e < hi; e += 64) table_insert<T>(keys, masks, sh, rp[e], (int)r);
+      }
+      __syncthreads();
+      // ---- probe: this lane's column slice ----
+      for (uint32_t e = clo; e < chi; e++) {
+        const unsigned long long m = table_lookup(keys, masks, sh, colp[e]);
+        unsigned long long carry = m;
+#pragma unroll
+        for (int k = 0; k < NPL; k++) {
+          if (!__any(carry != 0ULL)) break;  // wave-uniform
+          const unsigned long long t = planes[k] & carry;
+          planes[k] ^= carry;
+          carry = t;
+        }
+      }
+      if (sb + 1 < nsub) __syncthreads();
+      ra = rbnd;
+    }
+    clo = chi;
+  }
+
+  // ---- unpack the 64 bit-sliced counters of this lane's column ----
+  for (uint32_t r = 0; r < nrows; r++) {
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < NPL; k++) cnt |= (uint32_t)((planes[k] >> r) & 1ULL) << k;
+    const uint32_t row = rb0 + r;
+    if (col_active && (!lower_only || c < row)) out[(uint64_t)(row - row0) * ld + (c - col0)] = cnt;
+  }
+}
+
+template <typename T>
+__global__ void slice_offsets_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
+                                     const uint32_t* __restrict__ len, const T* __restrict__ bounds, int P,
+                                     uint32_t n, uint32_t* __restrict__ so) {
+  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (uint64_t)n * (P + 1)) return;
+  const uint32_t p = (uint32_t)(idx / n), g = (uint32_t)(idx % n);
+  const uint32_t L = len[g];
+  uint32_t r;
+  if (p == 0) r = 0;
+  else if (p == (uint32_t)P) r = L;
+  else {
+    const T* a = hashes + start[g];
+    const T b = bounds[p];
+    uint32_t lo = 0, hi = L;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (a[mid] < b) lo = mid + 1; else hi = mid; }
+    r = lo;
+  }
+  so[(size_t)p * n + g] = r;
+}
+
+// max single slice over all genomes/partitions (a slice larger than the table cannot be built)
+__global__ void max_slice_kernel(const uint32_t* __restrict__ so, int P, uint32_t n, uint32_t* __restrict__ out_max) {
+  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t v = 0;
+  if (idx < (uint64_t)n * P) {
+    const uint32_t p = (uint32_t)(idx / n), g = (uint32_t)(idx % n);
+    v = so[(size_t)(p + 1) * n + g] - so[(size_t)p * n + g];
+  }
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+  if ((threadIdx.x & 63) == 0 && v) atomicMax(out_max, v);
+}
+
+template <typename T, int NPL>
+int launch_tiled(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const uint32_t* d_so, int P, uint32_t n,
+                 uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld,
+                 int lower_only) {
+  const size_t lds = (size_t)SLOTS * (sizeof(T) + 8) + sizeof(TileShared);
+  auto kern = pair_tiled_kernel<T, NPL>;
+  RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid((col1 - col0 + TW - 1) / TW, (row1 - row0 + ROWS - 1) / ROWS);
+  hipLaunchKernelGGL(kern, grid, dim3(TW), lds, ctx->stream, d_hashes, d_start, d_so, P, n, row0, row1, col0, col1,
+                     d_common, ld, lower_only);
+  RTC_CHECK_LAUNCH(ctx);
   return RTC_OK;
+}
+
+template <typename T>
+int tiled_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const uint32_t* d_len, uint32_t n,
+               uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld,
+               int lower_only, int* handled) {
+  *handled = 0;
+  // ---- host view of the sketch geometry ----
+  std::vector<uint64_t> h_start(n);
+  std::vector<uint32_t> h_len(n);
+  RTC_HIP(ctx, hipMemcpyAsync(h_start.data(), d_start, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t tot = 0;
+  uint32_t lmax = 0;
+  for (uint32_t g = 0; g < n; g++) { tot += h_len[g]; lmax = std::max(lmax, h_len[g]); }
+  if (tot == 0 || lmax >= (1u << 20)) return RTC_OK;  // nothing to gain / counters too wide: merge path
+  const double avg = (double)tot / n;
+  int P = 1;
+  while (P < MAXP && (double)ROWS * avg / P > KTARGET) P <<= 1;
+
+  // ---- partition boundaries = quantiles of a sample of up to 64 sketches ----
+  std::vector<T> sample;
+  {
+    const uint32_t ns = std::min<uint32_t>(n, 64);
+    std::vector<T> tmp;
+    for (uint32_t i = 0; i < ns; i++) {
+      const uint32_t g = (uint32_t)((uint64_t)i * n / ns);
+      if (!h_len[g]) continue;
+      tmp.resize(h_len[g]);
+      RTC_HIP(ctx, hipMemcpyAsync(tmp.data(), d_hashes + h_start[g], (size_t)h_len[g] * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+      RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      sample.insert(sample.end(), tmp.begin(), tmp.end());
+    }
+    std::sort(sample.begin(), sample.end());
+  }
+  if (sample.empty()) return RTC_OK;
+
+  for (int attempt = 0; attempt < 3; attempt++) {
+    std::vector<T> bounds(P + 1);
+    bounds[0] = 0;
+    for (int p = 1; p < P; p++) bounds[p] = sample[(size_t)((uint64_t)p * sample.size() / P)];
+    bounds[P] = (T)~(T)0;
+    void* ws = nullptr;
+    const size_t bso = (size_t)(P + 1) * n * 4;
+    const size_t bb = (size_t)(P + 1) * sizeof(T);
+    RTC_TRY(rtc_ws(ctx, 1, bso + bb + 64, &ws));
+    uint32_t* d_so = (uint32_t*)ws;
+    T* d_bounds = (T*)((char*)ws + bso);
+    uint32_t* d_max = (uint32_t*)((char*)ws + bso + bb + (8 - bb % 8) % 8);
+    void* hp = nullptr;
+    RTC_TRY(rtc_pinned(ctx, bb + 64, &hp));
+    memcpy(hp, bounds.data(), bb);
+    RTC_HIP(ctx, hipMemcpyAsync(d_bounds, hp, bb, hipMemcpyHostToDevice, ctx->stream));
+    RTC_HIP(ctx, hipMemsetAsync(d_max, 0, 4, ctx->stream));
+    const uint64_t work = (uint64_t)n * (P + 1);
+    hipLaunchKernelGGL(slice_offsets_kernel<T>, dim3((uint32_t)((work + 255) / 256)), dim3(256), 0, ctx->stream,
+                       d_hashes, d_start, d_len, d_bounds, P, n, d_so);
+    RTC_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(max_slice_kernel, dim3((uint32_t)(((uint64_t)n * P + 255) / 256)), dim3(256), 0, ctx->stream,
+                       d_so, P, n, d_max);
+    RTC_CHECK_LAUNCH(ctx);
+    uint32_t h_max = 0;
+    RTC_HIP(ctx, hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_max > KCAP_HARD) {  // some single slice does not fit a table: refine the partition
+      if (P >= MAXP) return RTC_OK;
+      P = std::min(MAXP, P * 4);
+      continue;
+    }
+    int npl = 1;
+    while ((1u << npl) <= lmax) npl++;
+    int st;
+    if (npl <= 10) st = launch_tiled<T, 10>(ctx, d_hashes, d_start, d_so, P, n, row0, row1, col0, col1, d_common, ld, lower_only);
+    else if (npl <= 13) st = launch_tiled<T, 13>(ctx, d_hashes, d_start, d_so, P, n, row0, row1, col0, col1, d_common, ld, lower_only);
+    else if (npl <= 16) st = launch_tiled<T, 16>(ctx, d_hashes, d_start, d_so, P, n, row0, row1, col0, col1, d_common, ld, lower_only);
+    else st = launch_tiled<T, 20>(ctx, d_hashes, d_start, d_so, P, n, row0, row1, col0, col1, d_common, ld, lower_only);
+    if (st != RTC_OK) return st;
+    *handled = 1;
+    return RTC_OK;
+  }
+  return RTC_OK;
+}
+
+}  // namespace
+
+int rtc_pair_common_tiled(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+                          const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0,
+                          uint32_t col1, uint32_t* d_common, uint64_t ld, int lower_only, int* handled) {
+  *handled = 0;
+  if (n == 0) return RTC_OK;
+  if (width == 8)
+    return tiled_impl<uint64_t>(ctx, (const uint64_t*)d_hashes, d_start, d_len, n, row0, row1, col0, col1, d_common,
+                                ld, lower_only, handled);
+  return tiled_impl<uint32_t>(ctx, (const uint32_t*)d_hashes, d_start, d_len, n, row0, row1, col0, col1, d_common, ld,
+                              lower_only, handled);
 }

@@ -68,3 +68,77 @@ def test_pair_common_on_real_sketches(ctx, oracle):
         got = ctx.pair_common(dev, algo=algo).cpu().numpy()
         assert np.array_equal(got, want), algo
     assert want[1, 0] > 100 and want[5, 0] == 0  # families share hashes, strangers do not
+
+
+def test_tiled_sentinel_values_and_variable_sizes(ctx, oracle):
+    """Hash values equal to the table's EMPTY sentinel (all ones) and ragged sizes up to 5000."""
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(17)
+    pool = np.unique(rng.integers(0, 1 << 63, size=30000, dtype=np.uint64))
+    sk = []
+    for g in range(130):
+        size = int(rng.integers(1, 5000)) if g % 7 else int(rng.integers(0, 3))
+        v = np.sort(rng.choice(pool, size=size, replace=False))
+        if g % 3 == 0:
+            v = np.append(v, np.uint64(0xFFFFFFFFFFFFFFFF))
+        if g % 5 == 0 and len(v):
+            v = np.insert(v, 0, np.uint64(0)) if v[0] != 0 else v
+        sk.append(v.astype(np.uint64))
+    dev = api.SketchSet.from_host(sk, ctx.device)
+    want = _oracle_matrix(oracle, sk)
+    got = ctx.pair_common(dev, algo=2).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_tiled_u32_sentinel(ctx, oracle):
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(18)
+    sk = []
+    for g in range(90):
+        v = np.unique(rng.integers(0, 1 << 14, size=int(rng.integers(0, 700)), dtype=np.uint64)).astype(np.uint32)
+        if g % 2:
+            v = np.append(v, np.uint32(0xFFFFFFFF))
+        sk.append(v)
+    dev = api.SketchSet.from_host(sk, ctx.device, width=4)
+    want = _oracle_matrix(oracle, sk)
+    got = ctx.pair_common(dev, algo=2).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_tiled_skewed_slices_force_row_subblocks(ctx, oracle):
+    """All sketches crowd into a narrow value range except a few outliers that drag the sampled
+    quantile boundaries: some (row block, partition) then holds far more keys than one table."""
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(19)
+    sk = []
+    n = 200
+    for g in range(n):
+        if g % 64 == 0:  # the sampled genomes (every n/64-th) are wide-range
+            v = np.unique(rng.integers(0, 1 << 62, size=1500, dtype=np.uint64))
+        else:            # everyone else lives in [2^40, 2^40 + 2^16)
+            v = np.unique((1 << 40) + rng.integers(0, 1 << 16, size=900, dtype=np.uint64)).astype(np.uint64)
+        sk.append(np.sort(v))
+    dev = api.SketchSet.from_host(sk, ctx.device)
+    want = _oracle_matrix(oracle, sk)
+    got = ctx.pair_common(dev, algo=0).cpu().numpy()
+    assert np.array_equal(got, want)
+    low = ctx.pair_common(dev, row0=64, row1=190, col0=0, col1=189, lower_only=True, algo=0).cpu().numpy()
+    for i in range(64, 190):
+        assert np.array_equal(low[i - 64, :min(i, 189)], want[i, :min(i, 189)])
+
+
+def test_tiled_matches_merge_kernel_at_scale(ctx):
+    """Size-independent cross-check at a larger size: the two device algorithms must agree."""
+    from rabbittclust_amd import api
+    desc = api.synth_family_descs(150, 8, global_seed=23)
+    L = 30_000
+    off = np.arange(len(desc) + 1, dtype=np.uint64) * L
+    seq = ctx.synth_genomes(desc, off)
+    dev = ctx.sketch_minhash(seq, off, k=21, size=1000)
+    a = ctx.pair_common(dev, lower_only=True, algo=1)
+    b = ctx.pair_common(dev, lower_only=True, algo=2)
+    il = np.tril_indices(dev.n, -1)
+    assert np.array_equal(a.cpu().numpy()[il], b.cpu().numpy()[il])
+    full = ctx.pair_common(dev, algo=2).cpu().numpy()
+    assert np.array_equal(full, full.T)            # symmetry
+    assert np.array_equal(np.diag(full), dev.len.cpu().numpy())  # |A ∩ A| = |A|
