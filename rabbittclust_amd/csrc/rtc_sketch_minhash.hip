@@ -1,12 +1,14 @@
 // rtc_sketch_minhash.hip -- bottom-s MinHash sketching on gfx950.
 //
 // Replaces Sketch::MinHash::{update,storeMinHashes} driven from src/SketchInfo.cpp:918-942,969
-// (reference tree paths).  One workgroup (256 lanes = 4 wave64) walks one *segment* of a genome:
-//   * 16-byte coalesced loads stage a 15 KiB tile of ASCII bases into LDS;
+// (reference tree paths).  One workgroup (512 lanes = 8 wave64) walks one *segment* of a genome:
+//   * 16-byte coalesced loads stage a ~30 KiB tile of ASCII bases into LDS;
 //   * every lane owns 60 consecutive k-mer end positions of the tile (lane stride 15 dwords ->
 //     conflict-free ds_read_b32) and rolls the 2-bit forward / reverse-complement words;
-//   * the canonical word is expanded to ASCII with v_perm_b32 and hashed with MurmurHash3_x64_128
-//     (runtime k, seed) -- integer-ALU bound: ten 64x64 multiplies per k-mer;
+//   * MurmurHash3_x64_128 of the canonical k-mer's ASCII bytes is evaluated from the 2-bit word:
+//     the first multiplication of every input word comes out of LDS product tables (linearity of
+//     multiplication mod 2^64), leaving seven 64x64 multiplies per k-mer; four k-mers per lane
+//     are hashed back to back so their table reads and multiply chains overlap;
 //   * hashes below the running threshold T are appended to an LDS candidate buffer with a
 //     wave ballot + one LDS atomic per wave; when the buffer fills, an in-LDS bitonic sort +
 //     dedup keeps the s smallest distinct values and lowers T.
@@ -18,13 +20,16 @@
 
 namespace {
 
-constexpr int WG = 256;
+constexpr int WG = 512;                               // lanes per workgroup (8 waves)
+constexpr int NWAVE = WG / 64;
 constexpr int RUN_DW = 15;                            // dwords of owned bases per lane per tile
 constexpr int WARM_DW = 8;                            // 32 warm-up bases (k-1 <= 31)
-constexpr int TILE_BASES = WG * RUN_DW * 4;           // 15360
-constexpr int TILE_DW = WG * RUN_DW + WARM_DW;        // 3848 dwords in LDS
+constexpr int TILE_BASES = WG * RUN_DW * 4;           // bases per tile
+constexpr int TILE_DW = WG * RUN_DW + WARM_DW;        // dwords of the tile in LDS
 constexpr int STEP_APPENDS = WG * 4;                  // worst-case appends per dword iteration
+constexpr int MIN_ROOM = STEP_APPENDS;                // candidate room the buffer always offers
 constexpr uint64_t SENT = ~0ULL;
+constexpr size_t LUT_BYTES = 8 * 256 * 8;             // eight 256-entry u64 product tables
 
 struct Segment {
   uint64_t g_begin, g_end;  // genome byte range in d_seq
@@ -40,10 +45,16 @@ struct Ctrl {
   uint32_t overflow;
   uint32_t saw_max;
   uint32_t scan_base;
-  uint32_t wave_tot[4];
+  uint32_t wave_tot[NWAVE];
 };
 
-// ---- MurmurHash3_x64_128, first output word, for a k-byte key held in w[0..7] (zero padded) ----
+// ---- MurmurHash3_x64_128 (first output word) of the canonical k-mer's ASCII bytes ----------------
+// The first operation MurmurHash3 applies to every 64-bit input word is a multiplication by a
+// constant (c1 for the k1 words, c2 for the k2 words).  Multiplication mod 2^64 is linear, so
+//     (bytes 0-3 | bytes 4-7 << 32) * c  =  LUT[d][codes of bytes 0-3] + LUT[d+1][codes of bytes 4-7]
+// with LUT[d][e] = ((ascii4(e) & bytemask_d) << 32*(d&1)) * c.  Eight 256-entry tables (16 KiB of
+// LDS, built once per workgroup for the runtime k) replace both the 2-bit -> ASCII expansion and
+// three of the ten 64x64 multiplies per k-mer; the lookups run on the LDS pipe beside the VALU.
 __device__ __forceinline__ uint64_t fmix64(uint64_t x) {
   x ^= x >> 33;
   x *= 0xff51afd7ed558ccdULL;
@@ -53,45 +64,11 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t x) {
   return x;
 }
 
-__device__ __forceinline__ uint64_t murmur3_h1(const uint32_t (&w)[8], int k, uint32_t seed) {
-  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
-  uint64_t h1 = seed, h2 = seed;
-  uint64_t t0, t1;  // tail words
-  if (k >= 16) {    // wave-uniform
-    uint64_t k1 = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-    uint64_t k2 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
-    k1 *= c1; k1 = rtc_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-    h1 = rtc_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-    k2 *= c2; k2 = rtc_rotl64(k2, 33); k2 *= c1; h2 ^= k2;
-    h2 = rtc_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
-    t0 = (uint64_t)w[4] | ((uint64_t)w[5] << 32);
-    t1 = (uint64_t)w[6] | ((uint64_t)w[7] << 32);
-    if (k == 32) {
-      uint64_t k1b = t0, k2b = t1;
-      k1b *= c1; k1b = rtc_rotl64(k1b, 31); k1b *= c2; h1 ^= k1b;
-      h1 = rtc_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-      k2b *= c2; k2b = rtc_rotl64(k2b, 33); k2b *= c1; h2 ^= k2b;
-      h2 = rtc_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
-      t0 = t1 = 0;
-    }
-  } else {
-    t0 = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-    t1 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
-  }
-  const int tail = k & 15;
-  if (tail > 8) { uint64_t k2 = t1; k2 *= c2; k2 = rtc_rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
-  if (tail > 0) { uint64_t k1 = t0; k1 *= c1; k1 = rtc_rotl64(k1, 31); k1 *= c2; h1 ^= k1; }
-  h1 ^= (uint64_t)k; h2 ^= (uint64_t)k;
-  h1 += h2; h2 += h1;
-  h1 = fmix64(h1); h2 = fmix64(h2);
-  h1 += h2;
-  return h1;
-}
+constexpr uint64_t MM_C1 = 0x87c37b91114253d5ULL, MM_C2 = 0x4cf5ad432745937fULL;
 
-// expand the canonical 2-bit word (first base in the top bits after left alignment) into the
-// ASCII bytes MurmurHash3 consumes: 4 codes -> 4 selector bytes -> v_perm_b32 over "ACGT".
 __device__ __forceinline__ uint32_t codes_to_ascii(uint32_t e) {
-  uint32_t t = ((e << 24) | (e << 14) | (e << 4) | (e >> 6)) & 0x03030303u;
+  // e holds 4 base codes, first base in bits 7..6; returns the 4 ASCII bytes, first base lowest
+  const uint32_t t = ((e >> 6) & 3u) | (((e >> 4) & 3u) << 8) | (((e >> 2) & 3u) << 16) | ((e & 3u) << 24);
   return __builtin_amdgcn_perm(0u, 0x54474341u, t);
 }
 
@@ -102,36 +79,66 @@ struct KParams {
   int lshift;          // 64 - 2k
   int rc_shift;        // 2k - 2
   uint64_t kmask;      // low 2k bits
-  uint32_t bmask[8];   // byte masks of the 8 key dwords
 };
-
-__device__ __forceinline__ uint64_t kmer_hash(uint64_t canon, const KParams& P) {
-  const uint64_t x = canon << P.lshift;
-  const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
-  uint32_t w[8];
-  w[0] = codes_to_ascii(hi >> 24) & P.bmask[0];
-  w[1] = codes_to_ascii((hi >> 16) & 0xff) & P.bmask[1];
-  w[2] = codes_to_ascii((hi >> 8) & 0xff) & P.bmask[2];
-  w[3] = codes_to_ascii(hi & 0xff) & P.bmask[3];
-  w[4] = codes_to_ascii(lo >> 24) & P.bmask[4];
-  w[5] = codes_to_ascii((lo >> 16) & 0xff) & P.bmask[5];
-  w[6] = codes_to_ascii((lo >> 8) & 0xff) & P.bmask[6];
-  w[7] = codes_to_ascii(lo & 0xff) & P.bmask[7];
-  uint64_t h = murmur3_h1(w, P.k, P.seed);
-  return P.use64 ? h : (h & 0xffffffffULL);
-}
 
 __device__ __forceinline__ KParams make_kparams(int k, uint32_t seed) {
   KParams P;
   P.k = k; P.seed = seed; P.use64 = k > 16 ? 1u : 0u;
   P.lshift = 64 - 2 * k; P.rc_shift = 2 * k - 2;
   P.kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  return P;
+}
+
+// lut: [8][256] u64 in LDS.  Called by all WG threads; the first 256 fill one column each.
+__device__ __forceinline__ void build_kmer_lut(uint64_t* lut, int k) {
+  const uint32_t e = threadIdx.x;
+  if (e >= 256) return;
+  const uint32_t a4 = codes_to_ascii(e);
 #pragma unroll
   for (int d = 0; d < 8; d++) {
-    int nb = k - 4 * d;
-    P.bmask[d] = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+    const int nb = k - 4 * d;
+    const uint32_t bm = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+    const uint64_t v = (uint64_t)(a4 & bm) << (32 * (d & 1));
+    lut[d * 256 + e] = v * ((d & 2) ? MM_C2 : MM_C1);
   }
-  return P;
+}
+
+__device__ __forceinline__ void mm_body(uint64_t& h1, uint64_t& h2, uint64_t k1m, uint64_t k2m) {
+  uint64_t k1 = rtc_rotl64(k1m, 31) * MM_C2; h1 ^= k1;
+  h1 = rtc_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+  uint64_t k2 = rtc_rotl64(k2m, 33) * MM_C1; h2 ^= k2;
+  h2 = rtc_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+}
+
+__device__ __forceinline__ uint64_t kmer_hash(uint64_t canon, const KParams& P, const uint64_t* lut) {
+  const uint64_t x = canon << P.lshift;  // first base in the top bits
+  const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+  const int k = P.k;
+  // byte offsets into the tables: (code byte) * 8
+  uint64_t A0 = lut[0 * 256 + (hi >> 24)];
+  uint64_t B0 = 0, A1 = 0, B1 = 0;
+  if (k > 4) A0 += lut[1 * 256 + ((hi >> 16) & 0xff)];
+  if (k > 8) B0 = lut[2 * 256 + ((hi >> 8) & 0xff)];
+  if (k > 12) B0 += lut[3 * 256 + (hi & 0xff)];
+  if (k > 16) A1 = lut[4 * 256 + (lo >> 24)];
+  if (k > 20) A1 += lut[5 * 256 + ((lo >> 16) & 0xff)];
+  if (k > 24) B1 = lut[6 * 256 + ((lo >> 8) & 0xff)];
+  if (k > 28) B1 += lut[7 * 256 + (lo & 0xff)];
+  uint64_t h1 = P.seed, h2 = P.seed;
+  uint64_t t0 = A0, t1 = B0;  // tail words (already multiplied by c1 / c2)
+  if (k >= 16) {
+    mm_body(h1, h2, A0, B0);
+    t0 = A1; t1 = B1;
+    if (k == 32) { mm_body(h1, h2, A1, B1); t0 = 0; t1 = 0; }
+  }
+  const int tail = k & 15;
+  if (tail > 8) { h2 ^= rtc_rotl64(t1, 33) * MM_C1; }
+  if (tail > 0) { h1 ^= rtc_rotl64(t0, 31) * MM_C2; }
+  h1 ^= (uint64_t)k; h2 ^= (uint64_t)k;
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  h1 += h2;
+  return P.use64 ? h1 : (h1 & 0xffffffffULL);
 }
 
 // ---- block-wide merge: sort buf[0..CAP), drop duplicates, keep the `s` smallest ----------------
@@ -157,6 +164,9 @@ __device__ void merge_block(uint64_t* buf, Ctrl* ctrl, int cap, uint32_t s) {
   const int t = threadIdx.x;
   __syncthreads();
   const uint32_t n = ctrl->count < (uint32_t)cap ? ctrl->count : (uint32_t)cap;
+  bool saw = false;  // a genuine hash equal to the padding value: remembered, re-appended at the end
+  for (uint32_t i = t; i < n; i += WG) saw |= buf[i] == SENT;
+  if (saw) ctrl->saw_max = 1;
   for (int i = n + t; i < cap; i += WG) buf[i] = SENT;
   if (t == 0) ctrl->scan_base = 0;
   __syncthreads();
@@ -172,12 +182,17 @@ __device__ void merge_block(uint64_t* buf, Ctrl* ctrl, int cap, uint32_t s) {
     if (lane == 0) ctrl->wave_tot[wave] = (uint32_t)__popcll(bal);
     __syncthreads();  // all reads of this round done; wave totals visible
     const uint32_t sb = ctrl->scan_base;
-    const uint32_t w0 = ctrl->wave_tot[0], w1 = ctrl->wave_tot[1], w2 = ctrl->wave_tot[2], w3 = ctrl->wave_tot[3];
-    const uint32_t base = sb + (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+    uint32_t base = sb, total = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVE; w++) {
+      const uint32_t wt = ctrl->wave_tot[w];
+      if ((uint32_t)w < wave) base += wt;
+      total += wt;
+    }
     const uint32_t dest = base + before;
     if (keep && dest < s) buf[dest] = v;
     __syncthreads();  // writes done; wave_tot / scan_base may be rewritten
-    if (t == 0) ctrl->scan_base = sb + w0 + w1 + w2 + w3;  // read again only after the next barrier
+    if (t == 0) ctrl->scan_base = sb + total;  // read again only after the next barrier
   }
   __syncthreads();
   if (t == 0) {
@@ -190,28 +205,32 @@ __device__ void merge_block(uint64_t* buf, Ctrl* ctrl, int cap, uint32_t s) {
 }
 
 // ---- the sketch kernel ---------------------------------------------------------------------------
+template <int KT>  // KT > 0: k known at compile time (uniform branches fold away); 0: runtime k
 __global__ __launch_bounds__(WG) void sketch_minhash_kernel(const uint8_t* __restrict__ seq,
                                                             const Segment* __restrict__ segs,
-                                                            int k, uint32_t seed, int cap,
+                                                            int k_arg, uint32_t seed, int cap,
                                                             uint64_t* __restrict__ out,
                                                             uint32_t* __restrict__ cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
-  uint32_t* tile = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 8);
-  Ctrl* ctrl = reinterpret_cast<Ctrl*>(smem + (size_t)cap * 8 + (size_t)TILE_DW * 4);
+  uint64_t* lut = reinterpret_cast<uint64_t*>(smem + (size_t)cap * 8);
+  uint32_t* tile = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 8 + LUT_BYTES);
+  Ctrl* ctrl = reinterpret_cast<Ctrl*>(smem + (size_t)cap * 8 + LUT_BYTES + (size_t)TILE_DW * 4);
 
   const Segment sg = segs[blockIdx.x];
+  const int k = KT > 0 ? KT : k_arg;
   const KParams P = make_kparams(k, seed);
   const int t = threadIdx.x;
   const uint32_t lane = t & 63;
   const uint32_t s = sg.sketch_size;
 
   if (t == 0) { ctrl->T = SENT; ctrl->count = 0; ctrl->overflow = 0; ctrl->saw_max = 0; ctrl->scan_base = 0; }
+  build_kmer_lut(lut, k);
   __syncthreads();
 
   uint64_t T = SENT;
   bool safe_mode = true;
-  const uint32_t room = (uint32_t)cap - s;  // >= 2048 by construction
+  const uint32_t room = (uint32_t)cap - s;  // >= MIN_ROOM by construction
 
   for (uint64_t T0 = sg.s_begin & ~15ULL; T0 < sg.s_end && s > 0; T0 += TILE_BASES) {
     // ---- stage the tile: positions [T0-32, T0+TILE_BASES) ----
@@ -258,31 +277,46 @@ __global__ __launch_bounds__(WG) void sketch_minhash_kernel(const uint8_t* __res
           const uint32_t wv = tile[t * RUN_DW + d];
           const bool hashing = d >= WARM_DW;
           const int rel0 = 60 * t + 4 * (d - WARM_DW);
+          uint64_t canon[4];
+          bool ok[4];
 #pragma unroll
           for (int b = 0; b < 4; b++) {
             const uint32_t c = (wv >> (8 * b)) & 0xffu;
-            const uint32_t code2 = (c >> 1) & 3u;
-            const uint32_t code = code2 ^ (code2 >> 1);
+            const uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;  // A,C,G,T (either case) -> 0,1,2,3
             const bool valid = ((c & 0xC0u) == 0x40u) && ((0x0010008Au >> (c & 31u)) & 1u);
             fwd = ((fwd << 2) | code) & P.kmask;
             rc = (rc >> 2) | ((uint64_t)(code ^ 3u) << P.rc_shift);
             run = valid ? run + 1 : 0;
-            if (hashing) {
-              const int rel = rel0 + b;
-              const bool ok = run >= P.k && rel >= rel_lo && rel < rel_hi;
-              const uint64_t canon = fwd < rc ? fwd : rc;
-              const uint64_t h = kmer_hash(canon, P);
-              const bool pass = ok && h < T;
-              if (ok && h == SENT) ctrl->saw_max = 1;
-              const uint64_t bal = __ballot(pass);
-              if (bal) {  // wave-uniform
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&ctrl->count, (uint32_t)__popcll(bal));
-                base = __shfl(base, 0);
-                const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
-                if (pass) {
-                  if (idx < (uint32_t)cap) buf[idx] = h;
-                  else ctrl->overflow = 1;
+            const int rel = rel0 + b;
+            ok[b] = run >= P.k && rel >= rel_lo && rel < rel_hi;
+            canon[b] = fwd < rc ? fwd : rc;
+          }
+          if (hashing) {  // wave-uniform
+            // four independent hash chains: their LDS table reads and multiplies overlap
+            uint64_t h[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) h[b] = kmer_hash(canon[b], P, lut);
+            bool pass[4];
+            bool anyp = false;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+              // T == SENT means "sketch not full yet": everything passes (also a hash == SENT)
+              pass[b] = ok[b] && (h[b] < T || T == SENT);
+              anyp |= pass[b];
+            }
+            if (__any(anyp)) {
+#pragma unroll
+              for (int b = 0; b < 4; b++) {
+                const uint64_t bal = __ballot(pass[b]);
+                if (bal) {  // wave-uniform
+                  uint32_t base = 0;
+                  if (lane == 0) base = atomicAdd(&ctrl->count, (uint32_t)__popcll(bal));
+                  base = __shfl(base, 0);
+                  const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
+                  if (pass[b]) {
+                    if (idx < (uint32_t)cap) buf[idx] = h[b];
+                    else ctrl->overflow = 1;
+                  }
                 }
               }
             }
@@ -404,10 +438,13 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     if (s > stride) return rtc_fail(ctx, RTC_ERR_ARG, "sketch size %u of genome %u exceeds stride %u", s, g, stride);
     smax = std::max(smax, s);
   }
-  const int cap = pow2ceil((int)std::max<uint32_t>(2 * smax, smax + 2048));
-  const size_t lds = (size_t)cap * 8 + (size_t)TILE_DW * 4 + sizeof(Ctrl);
-  if (lds > (size_t)160 * 1024)
-    return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "sketch size %u needs %zu B of LDS (> 160 KiB)", smax, lds);
+  // candidate buffer of the sketch kernel: s + room; of the partial-merge kernel: two s-lists
+  const int cap = pow2ceil((int)(smax + MIN_ROOM));
+  const int cap_merge = pow2ceil((int)std::max<uint32_t>(2 * smax, 1024));
+  const size_t lds = (size_t)cap * 8 + LUT_BYTES + (size_t)TILE_DW * 4 + sizeof(Ctrl);
+  const size_t lds_m = (size_t)cap_merge * 8 + sizeof(Ctrl);
+  if (lds > (size_t)160 * 1024 || lds_m > (size_t)160 * 1024)
+    return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "sketch size %u needs %zu B of LDS (> 160 KiB); the GPU path takes sizes up to 6144", smax, std::max(lds, lds_m));
 
   // ---- plan segments ----
   uint64_t total = 0;
@@ -476,22 +513,21 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     d_pcnt = (uint32_t*)((char*)ws1 + part_elems * 8);
   }
 
-  RTC_HIP(ctx, hipFuncSetAttribute((const void*)sketch_minhash_kernel,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto kern = k == 21 ? sketch_minhash_kernel<21> : sketch_minhash_kernel<0>;
+  RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (!direct.empty()) {
-    hipLaunchKernelGGL(sketch_minhash_kernel, dim3((uint32_t)direct.size()), dim3(WG), lds, ctx->stream,
+    hipLaunchKernelGGL(kern, dim3((uint32_t)direct.size()), dim3(WG), lds, ctx->stream,
                        d_seq, d_direct, k, seed, cap, d_out, d_cnt);
     RTC_CHECK_LAUNCH(ctx);
   }
   if (!partial.empty()) {
-    hipLaunchKernelGGL(sketch_minhash_kernel, dim3((uint32_t)partial.size()), dim3(WG), lds, ctx->stream,
+    hipLaunchKernelGGL(kern, dim3((uint32_t)partial.size()), dim3(WG), lds, ctx->stream,
                        d_seq, d_partial, k, seed, cap, d_parts, d_pcnt);
     RTC_CHECK_LAUNCH(ctx);
-    const size_t lds_m = (size_t)cap * 8 + sizeof(Ctrl);
     RTC_HIP(ctx, hipFuncSetAttribute((const void*)merge_partials_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
     hipLaunchKernelGGL(merge_partials_kernel, dim3((uint32_t)jobs.size()), dim3(WG), lds_m, ctx->stream,
-                       d_jobs, d_parts, d_pcnt, cap, d_out, d_cnt);
+                       d_jobs, d_parts, d_pcnt, cap_merge, d_out, d_cnt);
     RTC_CHECK_LAUNCH(ctx);
   }
   return RTC_OK;

@@ -112,3 +112,13 @@ def test_synth_device_matches_oracle(ctx, oracle):
         ref = oracle.synth_genome(int(desc[g]["fam_seed"]), int(desc[g]["mut_seed"]),
                                   int(desc[g]["mut_thr"]), L, int(desc[g]["n_every"]))
         assert np.array_equal(ref, seq[int(off[g]):int(off[g + 1])]), g
+
+
+def test_sketch_size_beyond_lds_fails_loudly(ctx):
+    from rabbittclust_amd import RtcError
+    seq = np.frombuffer(b"ACGT" * 1000, dtype=np.uint8)
+    d = ctx.upload_sequences(seq)
+    off = np.array([0, len(seq)], dtype=np.uint64)
+    with pytest.raises(RtcError) as ei:
+        ctx.sketch_minhash(d, off, k=21, size=20000)
+    assert ei.value.status == 3  # RTC_ERR_UNSUPPORTED: no silent fallback
