@@ -1,0 +1,373 @@
+// rtc_sketch_kssd.hip -- KSSD (--fast) sketching on gfx950.
+//
+// Replaces the per-file body of sketchFileWithKssd (src/SketchInfo.cpp:994-1252 in the reference
+// tree): rolling 2-bit k-mer and reverse complement (:1126-1135), canonical minimum (:1141),
+// shuffled-dimension filter (:1142-1149), dimension-reduced tuple (:1150-1152), set + ascending
+// sort (:1154-1157, :1180-1193).
+//
+// The reference probes a phmap of the kept (dim_id -> rank) pairs per k-mer.  Here the kept set
+// (dim_end of 2^(4*half_subk) ids; 4096 of 16 Mi at the default drlevel 3) is compiled on the
+// host into a two-level exact index -- 4096 buckets on the top 12 bits of dim_id, each a short
+// list of (low bits, rank) -- that lives in 24 KiB of LDS, so the filter costs a couple of
+// ds_reads instead of a random HBM access.  Configurations that keep more than 8192 ids
+// (drlevel <= 2) fall back to a table lookup in HBM.  Survivors are appended to the genome's
+// output row with wave-aggregated atomics; kssd_sort_unique_kernel then sorts and deduplicates
+// each row in LDS.
+#include <algorithm>
+#include <vector>
+
+#include "rtc_internal.h"
+
+namespace {
+
+constexpr int WG = 512;
+constexpr int RUN_DW = 15;
+constexpr int WARM_DW = 8;
+constexpr int TILE_BASES = WG * RUN_DW * 4;
+constexpr int TILE_DW = WG * RUN_DW + WARM_DW;
+constexpr int NBUCKET = 4096;
+constexpr int MAX_LDS_KEEP = 8192;
+
+struct KSegment {
+  uint64_t g_begin, g_end;
+  uint64_t s_begin, s_end;
+  uint32_t genome;
+  uint32_t pad;
+};
+
+struct KssdParams {
+  int K;             // even k-mer length (2*half_k)
+  int drlevel;
+  int use64;
+  int rev_add_move;  // 4*half_k - 2
+  int dim_shift;     // 2*half_outctx_len
+  int und1_shl;      // 2K - 4*half_outctx_len
+  int lobits;        // 4*half_subk - 12
+  int dim_end;
+  uint64_t tupmask, domask, undomask0, undomask1;
+};
+
+template <typename OutT, bool LDS_INDEX>
+__global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restrict__ seq,
+                                                         const KSegment* __restrict__ segs, KssdParams P,
+                                                         const uint16_t* __restrict__ g_off,   // [NBUCKET+1]
+                                                         const uint32_t* __restrict__ g_ent,   // [dim_end]
+                                                         const int32_t* __restrict__ g_table,  // full table (HBM path)
+                                                         OutT* __restrict__ out, uint32_t stride,
+                                                         uint32_t* __restrict__ cnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* tile = reinterpret_cast<uint32_t*>(smem);
+  uint16_t* l_off = reinterpret_cast<uint16_t*>(smem + (size_t)TILE_DW * 4);
+  uint32_t* l_ent = reinterpret_cast<uint32_t*>(smem + (size_t)TILE_DW * 4 + (NBUCKET + 2) * 2);
+
+  const KSegment sg = segs[blockIdx.x];
+  const int t = threadIdx.x;
+  const uint32_t lane = t & 63;
+  if (LDS_INDEX) {
+    for (int i = t; i < NBUCKET + 1; i += WG) l_off[i] = g_off[i];
+    for (int i = t; i < P.dim_end; i += WG) l_ent[i] = g_ent[i];
+  }
+  OutT* orow = out + (uint64_t)sg.genome * stride;
+  uint32_t* ocnt = cnt + sg.genome;
+
+  for (uint64_t T0 = sg.s_begin & ~15ULL; T0 < sg.s_end; T0 += TILE_BASES) {
+    __syncthreads();  // previous tile fully consumed (also covers the index copy above)
+    for (int c = t; c < TILE_DW / 4; c += WG) {
+      const int64_t q = (int64_t)T0 - 32 + 16 * (int64_t)c;
+      uint4 v;
+      if (q >= (int64_t)sg.g_begin && q + 16 <= (int64_t)sg.g_end) {
+        v = *reinterpret_cast<const uint4*>(seq + q);
+      } else {
+        uint32_t ww[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          uint32_t x = 0;
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            const int64_t p = q + 4 * d + b;
+            const uint32_t ch = (p >= (int64_t)sg.g_begin && p < (int64_t)sg.g_end) ? seq[p] : (uint32_t)'N';
+            x |= ch << (8 * b);
+          }
+          ww[d] = x;
+        }
+        v = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+      }
+      *reinterpret_cast<uint4*>(tile + 4 * c) = v;
+    }
+    __syncthreads();
+
+    const int64_t lo64 = (int64_t)sg.s_begin - (int64_t)T0;
+    const int64_t hi64 = (int64_t)sg.s_end - (int64_t)T0;
+    const int rel_lo = lo64 < 0 ? 0 : (int)lo64;
+    const int rel_hi = hi64 > TILE_BASES ? TILE_BASES : (int)hi64;
+
+    uint64_t tuple = 0, rvs = 0;
+    int run = 0;
+    for (int d = 0; d < WARM_DW + RUN_DW; d++) {
+      const uint32_t wv = tile[t * RUN_DW + d];
+      const bool emitting = d >= WARM_DW;
+      const int rel0 = 60 * t + 4 * (d - WARM_DW);
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const uint32_t c = (wv >> (8 * b)) & 0xffu;
+        const uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;  // BaseMap, src/SketchInfo.cpp:1007-1017
+        const bool valid = ((c & 0xC0u) == 0x40u) && ((0x0010008Au >> (c & 31u)) & 1u);
+        tuple = ((tuple << 2) | code) & P.tupmask;                               // :1134
+        rvs = (rvs >> 2) + ((uint64_t)(code ^ 3u) << P.rev_add_move);            // :1135
+        run = valid ? run + 1 : 0;                                               // base counter :1136,1161
+        if (emitting) {
+          const int rel = rel0 + b;
+          bool keep = run >= P.K && rel >= rel_lo && rel < rel_hi;               // :1139
+          const uint64_t uni = tuple < rvs ? tuple : rvs;                        // :1141
+          const uint32_t dim_id = (uint32_t)((uni & P.domask) >> P.dim_shift);   // :1142
+          uint32_t rank = 0;
+          if (LDS_INDEX) {
+            const uint32_t hi = dim_id >> P.lobits, lo = dim_id & ((1u << P.lobits) - 1u);
+            uint32_t j = l_off[hi];
+            const uint32_t e = l_off[hi + 1];
+            bool found = false;
+            for (; j < e; j++) {
+              const uint32_t v = l_ent[j];
+              if ((v >> 13) == lo) { rank = v & 8191u; found = true; }
+            }
+            keep = keep && found;
+          } else {
+            if (keep) {
+              const int32_t sd = g_table[dim_id];
+              keep = sd >= 0 && sd < P.dim_end;                                  // :1054
+              rank = (uint32_t)sd;
+            }
+          }
+          const uint64_t bal = __ballot(keep);
+          if (bal) {  // wave-uniform
+            const uint64_t dr = (((uni & P.undomask0) | ((uni & P.undomask1) << P.und1_shl)) >> (P.drlevel * 4)) |
+                                (uint64_t)rank;                                  // :1150-1152
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(ocnt, (uint32_t)__popcll(bal));
+            base = __shfl(base, 0);
+            const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
+            if (keep && idx < stride) orow[idx] = (OutT)dr;
+          }
+        }
+      }
+    }
+  }
+}
+
+// one workgroup per genome: sort + dedup the appended tuples in LDS (hashArr sort :1185,:1192)
+template <typename OutT>
+__global__ __launch_bounds__(WG) void kssd_sort_unique_kernel(OutT* __restrict__ out, uint32_t stride,
+                                                              uint32_t* __restrict__ cnt, int cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  OutT* buf = reinterpret_cast<OutT*>(smem);
+  uint32_t* wave_tot = reinterpret_cast<uint32_t*>(smem + (size_t)cap * sizeof(OutT));  // [WG/64]
+  uint32_t& scan_base = wave_tot[WG / 64];
+  const uint32_t g = blockIdx.x;
+  const int t = threadIdx.x;
+  const uint32_t m = min(cnt[g], stride);
+  if (m == 0) return;
+  OutT* row = out + (uint64_t)g * stride;
+  int n2 = 1024;
+  while (n2 < (int)m) n2 <<= 1;  // n2 <= cap by host-side check
+  for (int i = t; i < n2; i += WG) buf[i] = i < (int)m ? row[i] : (OutT)~(OutT)0;
+  if (t == 0) scan_base = 0;
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < (n2 >> 1); i += WG) {
+        const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        const int b = a | j;
+        const bool up = (a & k) == 0;
+        const OutT va = buf[a], vb = buf[b];
+        if ((va > vb) == up) { buf[a] = vb; buf[b] = va; }
+      }
+      __syncthreads();
+    }
+  }
+  // the first m sorted entries are exactly the real ones (padding is the maximum value)
+  const uint32_t lane = t & 63, wave = t >> 6;
+  for (int r = 0; r < n2; r += WG) {
+    const int idx = r + t;
+    const OutT v = buf[idx];
+    const bool keep = idx < (int)m && (idx == 0 || v != buf[idx - 1]);
+    const uint64_t bal = __ballot(keep);
+    if (lane == 0) wave_tot[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    const uint32_t sb = scan_base;
+    uint32_t base = sb, total = 0;
+#pragma unroll
+    for (int w = 0; w < WG / 64; w++) { const uint32_t wt = wave_tot[w]; if ((uint32_t)w < wave) base += wt; total += wt; }
+    if (keep) row[base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL))] = v;
+    __syncthreads();
+    if (t == 0) scan_base = sb + total;
+  }
+  __syncthreads();
+  if (t == 0) cnt[g] = scan_base;
+}
+
+__global__ void max_u32_kernel(const uint32_t* __restrict__ a, uint32_t n, uint32_t* __restrict__ out_max) {
+  uint32_t v = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v = max(v, a[i]);
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+  if ((threadIdx.x & 63) == 0 && v) atomicMax(out_max, v);
+}
+
+// cached device copies of the filter structures (deterministic per half_subk/drlevel)
+struct KssdCache {
+  int half_subk = -1, drlevel = -1;
+  uint64_t checksum = 0;
+  void* d_index = nullptr;    // u16 off[NBUCKET+1 (+1 pad)] then u32 ent[dim_end]
+  int32_t* d_table = nullptr;
+  size_t table_elems = 0;
+};
+KssdCache g_cache[8];  // per device ordinal
+
+uint64_t table_checksum(const int32_t* t, size_t n) {
+  uint64_t h = 1469598103934665603ULL;
+  const size_t step = n > 4096 ? n / 4096 : 1;
+  for (size_t i = 0; i < n; i += step) { h ^= (uint32_t)t[i]; h *= 1099511628211ULL; }
+  return h ^ n;
+}
+
+}  // namespace
+
+extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uint64_t* h_off, uint32_t n,
+                                   int kmer_size, int drlevel, const int32_t* h_shuffled_dim, void* d_out,
+                                   uint32_t stride, uint32_t* d_cnt, int* width_out, uint32_t* h_need) {
+  if (!ctx || !h_off || !h_shuffled_dim || !width_out || (n && (!d_seq || !d_out || !d_cnt))) return RTC_ERR_ARG;
+  if (kmer_size < 2 || kmer_size > 32) return rtc_fail(ctx, RTC_ERR_ARG, "kmer_size=%d outside 2..32", kmer_size);
+  if (drlevel < 0 || drlevel > 8) return rtc_fail(ctx, RTC_ERR_ARG, "drlevel=%d outside 0..8", drlevel);
+  // src/SketchInfo.cpp:1019-1048
+  const int half_k = (kmer_size + 1) / 2;
+  const int K = half_k * 2;
+  const int use64 = half_k - drlevel > 8 ? 1 : 0;
+  const int half_subk = 6 - drlevel >= 2 ? 6 : drlevel + 2;
+  *width_out = use64 ? 8 : 4;
+  if (half_subk > 7) return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "drlevel %d needs a 2^%d-entry shuffle table (the reference's int arithmetic overflows there too)", drlevel, 4 * half_subk);
+  if (half_k < half_subk) return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "kmer_size %d too small for half_subk %d", kmer_size, half_subk);
+  const int dim_size = 1 << (4 * half_subk);
+  const int dim_end = 1 << (4 * (half_subk - drlevel));
+  const int comp_bittl = 64 - 4 * half_k;
+  const int half_outctx_len = half_k - half_subk;
+  KssdParams P;
+  P.K = K; P.drlevel = drlevel; P.use64 = use64;
+  P.rev_add_move = 4 * half_k - 2;
+  P.tupmask = 0xffffffffffffffffULL >> comp_bittl;
+  P.domask = (P.tupmask >> (4 * half_outctx_len)) << (2 * half_outctx_len);
+  const uint64_t undomask = (P.tupmask ^ P.domask) & P.tupmask;
+  P.undomask1 = undomask & (P.tupmask >> ((half_k + half_subk) * 2));
+  P.undomask0 = undomask ^ P.undomask1;
+  P.dim_shift = 2 * half_outctx_len;
+  P.und1_shl = K * 2 - half_outctx_len * 4;
+  P.lobits = 4 * half_subk - 12;
+  P.dim_end = dim_end;
+  if (n == 0) return RTC_OK;
+  if (((uintptr_t)d_seq & 15) != 0) return rtc_fail(ctx, RTC_ERR_ARG, "d_seq must be 16-byte aligned");
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+
+  // ---- filter structures (cached per device) ----
+  const bool lds_index = dim_end <= MAX_LDS_KEEP;
+  KssdCache& kc = g_cache[ctx->device & 7];
+  const uint64_t cs = table_checksum(h_shuffled_dim, (size_t)dim_size);
+  if (kc.half_subk != half_subk || kc.drlevel != drlevel || kc.checksum != cs) {
+    RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (kc.d_index) { (void)hipFree(kc.d_index); kc.d_index = nullptr; }
+    if (kc.d_table) { (void)hipFree(kc.d_table); kc.d_table = nullptr; }
+    if (lds_index) {
+      std::vector<uint32_t> bcount(NBUCKET + 1, 0);
+      std::vector<std::pair<uint32_t, uint32_t>> kept;  // (dim_id, rank)
+      kept.reserve(dim_end);
+      for (int t = 0; t < dim_size; t++)
+        if (h_shuffled_dim[t] >= 0 && h_shuffled_dim[t] < dim_end) kept.emplace_back((uint32_t)t, (uint32_t)h_shuffled_dim[t]);
+      if ((int)kept.size() > MAX_LDS_KEEP) return rtc_fail(ctx, RTC_ERR_ARG, "shuffle table is not a permutation");
+      std::vector<uint16_t> off(NBUCKET + 2, 0);
+      std::vector<uint32_t> ent(std::max<size_t>(kept.size(), 1));
+      for (auto& kv : kept) bcount[kv.first >> P.lobits]++;
+      uint32_t acc = 0;
+      for (int b = 0; b < NBUCKET; b++) { off[b] = (uint16_t)acc; acc += bcount[b]; }
+      off[NBUCKET] = (uint16_t)acc;
+      std::vector<uint32_t> cur(off.begin(), off.begin() + NBUCKET);
+      for (auto& kv : kept) ent[cur[kv.first >> P.lobits]++] = ((kv.first & ((1u << P.lobits) - 1u)) << 13) | kv.second;
+      const size_t boff = (NBUCKET + 2) * 2, bent = ent.size() * 4;
+      RTC_HIP(ctx, hipMalloc(&kc.d_index, boff + bent));
+      RTC_HIP(ctx, hipMemcpy(kc.d_index, off.data(), boff, hipMemcpyHostToDevice));
+      RTC_HIP(ctx, hipMemcpy((char*)kc.d_index + boff, ent.data(), bent, hipMemcpyHostToDevice));
+    } else {
+      RTC_HIP(ctx, hipMalloc((void**)&kc.d_table, (size_t)dim_size * 4));
+      RTC_HIP(ctx, hipMemcpy(kc.d_table, h_shuffled_dim, (size_t)dim_size * 4, hipMemcpyHostToDevice));
+    }
+    kc.half_subk = half_subk; kc.drlevel = drlevel; kc.checksum = cs;
+  }
+
+  // ---- segments (all segments of a genome append to the same row) ----
+  uint64_t total = 0;
+  for (uint32_t g = 0; g < n; g++) {
+    if (h_off[g + 1] < h_off[g]) return rtc_fail(ctx, RTC_ERR_ARG, "offsets not monotone at genome %u", g);
+    total += h_off[g + 1] - h_off[g];
+  }
+  uint64_t seg_len = total / ((uint64_t)ctx->num_cu * 12);
+  const uint64_t min_seg = 8ull * TILE_BASES;
+  if (seg_len < min_seg) seg_len = min_seg;
+  std::vector<KSegment> segs;
+  segs.reserve(n + 1024);
+  for (uint32_t g = 0; g < n; g++) {
+    const uint64_t b = h_off[g], e = h_off[g + 1], len = e - b;
+    uint64_t ns = (len + seg_len / 2) / seg_len;
+    if (ns < 1) ns = 1;
+    if (ns > 4096) ns = 4096;
+    for (uint64_t i = 0; i < ns; i++) segs.push_back(KSegment{b, e, b + len * i / ns, b + len * (i + 1) / ns, g, 0});
+  }
+  void* ws0 = nullptr;
+  const size_t bseg = segs.size() * sizeof(KSegment);
+  RTC_TRY(rtc_ws(ctx, 0, bseg + 64, &ws0));
+  void* hp = nullptr;
+  RTC_TRY(rtc_pinned(ctx, bseg + 64, &hp));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(hp, segs.data(), bseg);
+  RTC_HIP(ctx, hipMemcpyAsync(ws0, hp, bseg, hipMemcpyHostToDevice, ctx->stream));
+  RTC_HIP(ctx, hipMemsetAsync(d_cnt, 0, (size_t)n * 4, ctx->stream));
+
+  const uint16_t* d_ioff = (const uint16_t*)kc.d_index;
+  const uint32_t* d_ient = kc.d_index ? (const uint32_t*)((char*)kc.d_index + (NBUCKET + 2) * 2) : nullptr;
+  const size_t lds = (size_t)TILE_DW * 4 + (lds_index ? (NBUCKET + 2) * 2 + (size_t)std::max(dim_end, 1) * 4 : 0);
+#define LAUNCH_KSSD(OT, LI)                                                                                         \
+  do {                                                                                                               \
+    auto kern = sketch_kssd_kernel<OT, LI>;                                                                          \
+    RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+    hipLaunchKernelGGL(kern, dim3((uint32_t)segs.size()), dim3(WG), lds, ctx->stream, d_seq, (const KSegment*)ws0, P, \
+                       d_ioff, d_ient, (const int32_t*)kc.d_table, (OT*)d_out, stride, d_cnt);                        \
+  } while (0)
+  if (use64) { if (lds_index) LAUNCH_KSSD(uint64_t, true); else LAUNCH_KSSD(uint64_t, false); }
+  else       { if (lds_index) LAUNCH_KSSD(uint32_t, true); else LAUNCH_KSSD(uint32_t, false); }
+#undef LAUNCH_KSSD
+  RTC_CHECK_LAUNCH(ctx);
+
+  // ---- capacity check, then per-genome sort + dedup ----
+  void* ws3 = nullptr;
+  RTC_TRY(rtc_ws(ctx, 3, 64, &ws3));
+  uint32_t* d_max = (uint32_t*)ws3;
+  RTC_HIP(ctx, hipMemsetAsync(d_max, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(max_u32_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 1024)), dim3(256), 0, ctx->stream, d_cnt, n, d_max);
+  RTC_CHECK_LAUNCH(ctx);
+  uint32_t h_max = 0;
+  RTC_HIP(ctx, hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h_need) *h_need = h_max;
+  if (h_max > stride) return rtc_fail(ctx, RTC_ERR_OVERFLOW, "a genome produced %u KSSD tuples, stride is %u", h_max, stride);
+  int cap = 1024;
+  while (cap < (int)h_max) cap <<= 1;
+  const size_t lds_s = (size_t)cap * (use64 ? 8 : 4) + (WG / 64 + 1) * 4;
+  if (lds_s > (size_t)150 * 1024)
+    return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "%u KSSD tuples per genome exceed the in-LDS sort (%zu B)", h_max, lds_s);
+  if (use64) {
+    auto kern = kssd_sort_unique_kernel<uint64_t>;
+    RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+    hipLaunchKernelGGL(kern, dim3(n), dim3(WG), lds_s, ctx->stream, (uint64_t*)d_out, stride, d_cnt, cap);
+  } else {
+    auto kern = kssd_sort_unique_kernel<uint32_t>;
+    RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+    hipLaunchKernelGGL(kern, dim3(n), dim3(WG), lds_s, ctx->stream, (uint32_t*)d_out, stride, d_cnt, cap);
+  }
+  RTC_CHECK_LAUNCH(ctx);
+  return RTC_OK;
+}

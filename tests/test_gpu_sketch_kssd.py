@@ -1,0 +1,74 @@
+"""GPU parity: KSSD (--fast) sketch kernel vs the oracle's restatement of sketchFileWithKssd
+(src/SketchInfo.cpp:994-1193).  Bit-exact sorted tuple lists."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _genomes(rng, lens, n_rate=0.0):
+    parts, off = [], [0]
+    for L in lens:
+        g = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L)
+        if n_rate and L:
+            idx = rng.random(L) < n_rate
+            g[idx] = rng.choice(np.frombuffer(b"NnRy\n", dtype=np.uint8), size=int(idx.sum()))
+        low = rng.random(L) < 0.1
+        g[low] |= 0x20
+        parts.append(g)
+        off.append(off[-1] + L)
+    return np.concatenate(parts), np.array(off, dtype=np.uint64)
+
+
+def _check(ctx, oracle, seq, off, k, drlevel):
+    p = oracle.kssd_params(k, drlevel)
+    sd = oracle.kssd_shuffle_dim(p.half_subk)
+    d = ctx.upload_sequences(seq)
+    sk = ctx.sketch_kssd(d, off, sd, kmer_size=k, drlevel=drlevel)
+    ctx.sync()
+    got = sk.to_host()
+    assert sk.width == (8 if p.use64 else 4)
+    assert sk.k == p.kmer_size
+    for g in range(len(off) - 1):
+        want = oracle.kssd_sketch(seq[int(off[g]):int(off[g + 1])], k, drlevel)
+        assert np.array_equal(got[g], want), f"genome {g} k={k} dr={drlevel}: got {len(got[g])} want {len(want)}"
+    return got
+
+
+@pytest.mark.parametrize("k,drlevel", [(21, 3), (22, 3), (19, 3), (21, 4), (31, 3), (25, 3)])
+def test_kssd_matches_oracle(ctx, oracle, k, drlevel):
+    rng = np.random.default_rng(k * 10 + drlevel)
+    seq, off = _genomes(rng, [600_000, 250_001, 30_720, 10, 0, 123_456], n_rate=0.001)
+    got = _check(ctx, oracle, seq, off, k, drlevel)
+    assert len(got[0]) > 50 or drlevel > 3
+
+
+def test_kssd_hbm_table_path_drlevel2(ctx, oracle):
+    # drlevel 2 keeps 65536 dimensions: the HBM table path instead of the LDS index
+    rng = np.random.default_rng(5)
+    seq, off = _genomes(rng, [200_000, 90_000])
+    _check(ctx, oracle, seq, off, 21, 2)
+
+
+def test_kssd_overflow_protocol_and_duplicates(ctx, oracle):
+    # highly repetitive genome: many occurrences per kept tuple; tiny stride forces the retry path
+    rng = np.random.default_rng(6)
+    unit = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=40_000)
+    g = np.tile(unit, 12)
+    off = np.array([0, len(g)], dtype=np.uint64)
+    p = oracle.kssd_params(21, 3)
+    sd = oracle.kssd_shuffle_dim(p.half_subk)
+    d = ctx.upload_sequences(g)
+    sk = ctx.sketch_kssd(d, off, sd, kmer_size=21, drlevel=3, stride=16)
+    got = sk.to_host()[0]
+    want = oracle.kssd_sketch(g, 21, 3)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.skip(reason="covered by the CPU suite")
+def test_kssd_shuffle_table_fixture(oracle):
+    """The 4096 surviving (dim_id, rank) pairs of generate_shuffle_dim(6) pin glibc rand()."""
+    sd = oracle.kssd_shuffle_dim(6)
+    assert sorted(sd.tolist()) == list(range(1 << 24))
+    kept = np.nonzero(sd < 4096)[0]
+    assert len(kept) == 4096
