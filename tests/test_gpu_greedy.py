@@ -1,0 +1,77 @@
+"""GPU parity: greedy incremental clustering vs the oracle's -t 1 restatement of
+MinHashGreedyClusterWithInvertedIndex / KssdGreedyClusterWithInvertedIndex (src/greedy.cpp)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _family_sets(rng, n_fam, per, size, drift, pool_bits=40, dtype=np.uint64, ragged=False):
+    """Families of sketches: members share most of the ancestor's hashes; exact duplicates included
+    so that equal `common` ties occur."""
+    out = []
+    for f in range(n_fam):
+        anc = np.unique(rng.integers(0, 1 << pool_bits, size=size * 2, dtype=np.uint64))[:size]
+        for m in range(per):
+            s = size if not ragged else int(size * rng.uniform(0.3, 1.0))
+            keep = anc[: s].copy()
+            if m % 3 != 0:  # every third member is an exact copy of a prefix of the ancestor
+                nrep = int(len(keep) * drift * rng.uniform(0, 1))
+                idx = rng.choice(len(keep), size=nrep, replace=False)
+                keep[idx] = rng.integers(0, 1 << pool_bits, size=nrep, dtype=np.uint64)
+            out.append(np.unique(keep).astype(dtype))
+    order = rng.permutation(len(out))
+    return [out[i] for i in order]
+
+
+def test_greedy_fixed_size_fast_path(ctx, oracle):
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(31)
+    sk = _family_sets(rng, 60, 7, 400, 0.6)
+    dev = api.SketchSet.from_host(sk, ctx.device, k=21)
+    flat, start, lens = oracle.to_csr(sk)
+    for thr in (0.02, 0.05):
+        want_n, want = oracle.greedy_minhash(flat, start, lens, 400, 21, False, thr)
+        got_n, got = ctx.greedy(dev, thr, size_cfg=400, is_containment=False)
+        assert got_n == want_n
+        assert np.array_equal(got, want)
+
+
+def test_greedy_containment_variable_sizes(ctx, oracle):
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(32)
+    sk = _family_sets(rng, 40, 6, 600, 0.5, ragged=True)
+    cfg = np.array([max(len(s), 100) for s in sk], dtype=np.uint32)  # what getSketchSize() reports
+    dev = api.SketchSet.from_host(sk, ctx.device, k=21)
+    flat, start, lens = oracle.to_csr(sk)
+    want_n, want = oracle.greedy_minhash(flat, start, lens, cfg, 21, True, 0.05)
+    got_n, got = ctx.greedy(dev, 0.05, size_cfg=cfg, is_containment=True)
+    assert got_n == want_n
+    assert np.array_equal(got, want)
+
+
+def test_greedy_kssd_u32(ctx, oracle):
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(33)
+    sk = _family_sets(rng, 50, 6, 300, 0.5, pool_bits=30, dtype=np.uint32, ragged=True)
+    sk.sort(key=lambda a: -len(a))  # caller-side std::sort by size, src/greedy.cpp:594-597
+    dev = api.SketchSet.from_host(sk, ctx.device, k=22, kind="kssd", width=4)
+    flat, start, lens = oracle.to_csr(sk, dtype=np.uint32)
+    want_n, want = oracle.greedy_kssd(flat, start, lens, 22, 0.05)
+    got_n, got = ctx.greedy(dev, 0.05)
+    assert got_n == want_n
+    assert np.array_equal(got, want)
+
+
+def test_greedy_spans_several_batches(ctx, oracle):
+    """More genomes than one 1024-query batch, so in-batch new representatives matter."""
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(34)
+    sk = _family_sets(rng, 450, 6, 120, 0.7)
+    dev = api.SketchSet.from_host(sk, ctx.device, k=21)
+    flat, start, lens = oracle.to_csr(sk)
+    want_n, want = oracle.greedy_minhash(flat, start, lens, 120, 21, False, 0.05)
+    got_n, got = ctx.greedy(dev, 0.05, size_cfg=120, is_containment=False)
+    assert got_n == want_n
+    assert np.array_equal(got, want)
+    assert 1 < got_n < len(sk)
