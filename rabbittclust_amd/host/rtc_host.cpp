@@ -1,0 +1,582 @@
+// rtc_host.cpp -- host side of the drop-in (see rtc_host.h).  Plain C++17 + zlib; no GPU code.
+#include "rtc_host.h"
+
+#include <ctype.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <fstream>
+#include <iostream>
+#include <queue>
+
+namespace rtc {
+
+// =================================================================================================
+// FASTA / FASTQ reader.  Behaviour follows klib kseq as the reference drives it
+// (src/kseq.h:176-226 kseq_read, :92-140 ks_getuntil2):
+//   * records start at a line whose first character is '>' or '@';
+//   * name = header text up to the first isspace() character; comment = rest of the header line
+//     (absent when the name is terminated by the newline);
+//   * sequence = following lines concatenated, up to a line starting with '>', '@' or '+';
+//     a trailing '\r' is dropped after each appended line when the accumulated length is > 1;
+//   * '+' starts a FASTQ quality block: rest of that line skipped, then quality lines until the
+//     quality is as long as the sequence.
+// =================================================================================================
+namespace {
+
+class GzStream {
+ public:
+  explicit GzStream(const std::string& path) { f_ = gzopen(path.c_str(), "r"); if (f_) gzbuffer(f_, 1 << 20); }
+  ~GzStream() { if (f_) gzclose(f_); }
+  bool ok() const { return f_ != nullptr; }
+  int getc() {
+    if (begin_ >= end_) { if (!fill()) return -1; }
+    return (unsigned char)buf_[begin_++];
+  }
+  // appends to `s` up to (not including) the delimiter class; returns the delimiter char or -1 at EOF.
+  // mode 0: isspace()  mode 2: '\n'.  *gotany reports whether the stream had any data left.
+  int get_until(int mode, std::string& s, bool append, bool* gotany) {
+    if (!append) s.clear();
+    *gotany = false;
+    int dret = -1;
+    for (;;) {
+      if (begin_ >= end_) { if (!fill()) break; }
+      int i = begin_;
+      if (mode == 2) { const void* p = memchr(buf_ + begin_, '\n', end_ - begin_); i = p ? (int)((const char*)p - buf_) : end_; }
+      else { for (; i < end_; ++i) if (isspace((unsigned char)buf_[i])) break; }
+      *gotany = true;
+      s.append(buf_ + begin_, i - begin_);
+      begin_ = i + 1;
+      if (i < end_) { dret = (unsigned char)buf_[i]; break; }
+    }
+    if (mode == 2 && s.size() > 1 && s.back() == '\r') s.pop_back();
+    return dret;
+  }
+  bool eof() const { return eof_ && begin_ >= end_; }
+
+ private:
+  bool fill() {
+    if (eof_) return false;
+    begin_ = 0;
+    end_ = gzread(f_, buf_, sizeof buf_);
+    if (end_ <= 0) { end_ = 0; eof_ = true; return false; }
+    return true;
+  }
+  gzFile f_ = nullptr;
+  char buf_[1 << 16];
+  int begin_ = 0, end_ = 0;
+  bool eof_ = false;
+};
+
+// returns sequence length, -1 at EOF, -2 on truncated quality
+int next_record(GzStream& ks, int& last_char, FastaRecord& r) {
+  int c;
+  if (last_char == 0) {
+    while ((c = ks.getc()) != -1 && c != '>' && c != '@') {}
+    if (c == -1) return -1;
+    last_char = c;
+  }
+  r.comment.clear(); r.seq.clear(); r.has_comment = false;
+  bool got;
+  int d = ks.get_until(0, r.name, false, &got);
+  if (!got && ks.eof()) return -1;
+  if (d != '\n' && d != -1) { std::string cm; ks.get_until(2, cm, false, &got); r.comment = cm; r.has_comment = true; }
+  while ((c = ks.getc()) != -1 && c != '>' && c != '+' && c != '@') {
+    if (c == '\n') continue;
+    r.seq.push_back((char)c);
+    ks.get_until(2, r.seq, true, &got);
+  }
+  if (c == '>' || c == '@') last_char = c;
+  if (c != '+') return (int)r.seq.size();
+  while ((c = ks.getc()) != -1 && c != '\n') {}
+  if (c == -1) return -2;
+  std::string qual;
+  while (true) {
+    int dd = ks.get_until(2, qual, true, &got);
+    if ((!got && ks.eof()) || qual.size() >= r.seq.size()) break;
+    (void)dd;
+  }
+  last_char = 0;
+  if (qual.size() != r.seq.size()) return -2;
+  return (int)r.seq.size();
+}
+
+}  // namespace
+
+bool read_fasta(const std::string& path, std::vector<FastaRecord>& out) {
+  GzStream ks(path);
+  if (!ks.ok()) return false;
+  int last_char = 0;
+  FastaRecord r;
+  while (next_record(ks, last_char, r) >= 0) out.push_back(r);
+  return true;
+}
+
+bool read_genome_file(const std::string& path, std::string& bases, SequenceInfo& first, uint64_t& total_len,
+                      uint64_t& n_records) {
+  GzStream ks(path);
+  if (!ks.ok()) return false;
+  int last_char = 0;
+  FastaRecord r;
+  total_len = 0; n_records = 0;
+  int len;
+  while ((len = next_record(ks, last_char, r)) >= 0) {
+    total_len += (uint64_t)len;                                       // src/SketchInfo.cpp:933
+    if (n_records == 0) {                                             // :934-947, only the first record is kept
+      first.name = r.name;
+      first.comment = r.has_comment ? r.comment : std::string("noName");
+      first.strand = 0;
+      first.length = len;
+    }
+    bases.append(r.seq);
+    bases.push_back('\n');  // record separator: any non-ACGT byte resets the k-mer window
+    n_records++;
+  }
+  return true;
+}
+
+// =================================================================================================
+// calSize (list mode), src/SketchInfo.cpp:438-482,536-552
+// =================================================================================================
+bool cal_size(const std::string& list_file, uint64_t minLen, uint64_t& maxSize, uint64_t& minSize, uint64_t& averageSize) {
+  maxSize = 0; minSize = 1u << 31; averageSize = 0;
+  uint64_t totalSize = 0; int number = 0, badNumber = 0;
+  std::ifstream ifs(list_file);
+  if (!ifs) { std::cerr << "ERROR: calSize(), cannot open the inputFile: " << list_file << std::endl; return false; }
+  std::string line;
+  while (getline(ifs, line)) {
+    if (line.size() < 2) continue;
+    uint64_t curSize;
+    if (line.substr(line.length() - 2) == "gz") {
+      FILE* fp = fopen(line.c_str(), "r");
+      if (!fp) { std::cerr << "cannot open the genome file: " << line << std::endl; return false; }
+      fseek(fp, -4, SEEK_END);
+      int nUnCompress = 0;
+      if (fread(&nUnCompress, sizeof(int), 1, fp) != 1) nUnCompress = 0;
+      curSize = (uint64_t)(int64_t)nUnCompress;
+      fclose(fp);
+    } else {
+      struct stat statbuf;
+      if (stat(line.c_str(), &statbuf) != 0) { std::cerr << "cannot open the genome file: " << line << std::endl; return false; }
+      curSize = (uint64_t)statbuf.st_size;
+    }
+    if (curSize < minLen) { badNumber++; continue; }
+    maxSize = std::max(maxSize, curSize); minSize = std::min(minSize, curSize);
+    totalSize += curSize; number++;
+  }
+  if (number == 0) { std::cerr << "ERROR: calSize(), no genome passes the minimum length filter" << std::endl; return false; }
+  averageSize = totalSize / number;
+  int totalNumber = number + badNumber;
+  std::cerr << "\t===the genome number for clustering is: " << number << std::endl;
+  std::cerr << "\t===the genome number below the minimum genome length threshold is: " << badNumber << std::endl;
+  std::cerr << "\t===the total genome number is: " << totalNumber << std::endl;
+  if ((double)badNumber / totalNumber >= 0.2)
+    fprintf(stderr, "Warning: there are %d poor quality (length < %ld) genome assemblies in the total %d genome assemblied.\n",
+            badNumber, (long)minLen, totalNumber);
+  std::cerr << "\t===the totalSize is: " << totalSize << std::endl;
+  std::cerr << "\t===the maxSize is: " << maxSize << std::endl;
+  std::cerr << "\t===the minSize is: " << minSize << std::endl;
+  std::cerr << "\t===the averageSize is: " << averageSize << std::endl;
+  return true;
+}
+
+int file_length_for_containment(const std::string& path) {
+  FILE* fp = fopen(path.c_str(), "r");
+  if (!fp) return 0;
+  int fileLength = 0;
+  if (path.size() >= 2 && path.substr(path.length() - 2) == "gz") {
+    fseek(fp, -4, SEEK_END);
+    int nUnCompress = 0;
+    if (fread(&nUnCompress, sizeof(int), 1, fp) != 1) nUnCompress = 0;
+    fileLength = nUnCompress;
+  } else {
+    fseek(fp, 0, SEEK_END);
+    fileLength = (int)ftell(fp);
+  }
+  fclose(fp);
+  return fileLength;
+}
+
+// src/sub_command.cpp:2383-2467
+bool tune_parameters(bool greedy, bool isSetKmer, uint64_t maxSize, uint64_t minSize, uint64_t averageSize,
+                     bool& isContainment, bool isJaccard, int& kmerSize, double threshold, int& containCompress,
+                     int sketchSize) {
+  if (isContainment && isJaccard) {
+    std::cerr << "ERROR: tune_parameters(), conflict distance measurement of Mash distance (fixed-sketch-size) and AAF distance (variable-sketch-size) " << std::endl;
+    return false;
+  }
+  if (greedy) {
+    if (!isContainment && !isJaccard) { containCompress = (int)(averageSize / 1000); isContainment = true; }
+    else if (!isContainment && isJaccard) { }
+    else if (averageSize / containCompress < 10) {
+      std::cerr << "the containCompress " << containCompress << " is too large and the sketch size is too small" << std::endl;
+      containCompress = (int)(averageSize / 1000);
+      std::cerr << "set the containCompress to: " << containCompress << std::endl;
+    }
+  }
+  double warning_rate = 0.01, recommend_rate = 0.0001;
+  int recommendedKmerSize = (int)ceil(log(maxSize * (1 - recommend_rate) / recommend_rate) / log(4));
+  int warningKmerSize = (int)ceil(log(maxSize * (1 - warning_rate) / warning_rate) / log(4));
+  if (!isSetKmer) kmerSize = recommendedKmerSize;
+  else if (kmerSize < warningKmerSize) {
+    std::cerr << "the kmerSize " << kmerSize << " is too small for the maximum genome size of " << maxSize << std::endl;
+    std::cerr << "replace the kmerSize to the: " << recommendedKmerSize << " for reducing the random collision of kmers" << std::endl;
+    kmerSize = recommendedKmerSize;
+  } else if (kmerSize > recommendedKmerSize + 3) {
+    std::cerr << "the kmerSize " << kmerSize << " maybe too large for the maximum genome size of " << maxSize << std::endl;
+    std::cerr << "replace the kmerSize to the " << recommendedKmerSize << " for increasing the sensitivity of genome comparison" << std::endl;
+    kmerSize = recommendedKmerSize;
+  }
+  double minJaccard;
+  if (!isContainment) minJaccard = 1.0 / sketchSize;
+  else minJaccard = 1.0 / (minSize / containCompress);
+  double maxDist = minJaccard >= 1.0 ? 1.0 : -1.0 / kmerSize * log(2 * minJaccard / (1.0 + minJaccard));
+  std::cerr << "-----the max recommand distance threshold is: " << maxDist << std::endl;
+  if (threshold > maxDist) {
+    std::cerr << "ERROR: tune_parameters(), the threshold: " << threshold << " is out of the valid distance range estimated by Mash distance or AAF distance" << std::endl;
+    std::cerr << "Please set a distance threshold with -d option" << std::endl;
+    return false;
+  }
+  std::cerr << "-----the kmerSize is: " << kmerSize << std::endl;
+  std::cerr << "-----the threshold is: " << threshold << std::endl;
+  if (isContainment) std::cerr << "-----use the AAF distance (variable-sketch-size), the sketchSize is in proportion with 1/" << containCompress << std::endl;
+  else std::cerr << "-----use the Mash distance (fixed-sketch-size), the sketchSize is: " << sketchSize << std::endl;
+  return true;
+}
+
+// src/sub_command.cpp:2317-2381
+bool tune_kssd_parameters(bool isSetKmer, uint64_t maxSize, uint64_t minSize, uint64_t averageSize, bool isContainment,
+                          int& kmerSize, double threshold, int drlevel) {
+  int compression = 1 << (4 * drlevel);
+  int sketchSize = (int)(averageSize / compression);
+  double warning_rate = 0.01, recommend_rate = 0.0001;
+  int recommendedKmerSize = (int)ceil(log(maxSize * (1 - recommend_rate) / recommend_rate) / log(4));
+  int warningKmerSize = (int)ceil(log(maxSize * (1 - warning_rate) / warning_rate) / log(4));
+  if (!isSetKmer) kmerSize = recommendedKmerSize;
+  else if (kmerSize < warningKmerSize) {
+    std::cerr << "the kmerSize " << kmerSize << " is too small for the maximum genome size of " << maxSize << std::endl;
+    std::cerr << "replace the kmerSize to the: " << recommendedKmerSize << " for reducing the random collision of kmers" << std::endl;
+    kmerSize = recommendedKmerSize;
+  } else if (kmerSize > recommendedKmerSize + 3) {
+    std::cerr << "the kmerSize " << kmerSize << " maybe too large for the maximum genome size of " << maxSize << std::endl;
+    std::cerr << "replace the kmerSize to the " << recommendedKmerSize << " for increasing the sensitivity of genome comparison" << std::endl;
+    kmerSize = recommendedKmerSize;
+  }
+  double minJaccard;
+  if (!isContainment) minJaccard = 1.0 / sketchSize;
+  else minJaccard = 1.0 / (minSize / compression);
+  double maxDist = minJaccard >= 1.0 ? 1.0 : -1.0 / kmerSize * log(2 * minJaccard / (1.0 + minJaccard));
+  std::cerr << "-----the max recommand distance threshold is: " << maxDist << std::endl;
+  if (threshold > maxDist) {
+    std::cerr << "ERROR: tune_parameters(), the threshold: " << threshold << " is out of the valid distance range estimated by Mash distance or AAF distance" << std::endl;
+    std::cerr << "Please set a distance threshold with -d option" << std::endl;
+    return false;
+  }
+  std::cerr << "-----the kmerSize is: " << kmerSize << std::endl;
+  std::cerr << "-----the threshold is: " << threshold << std::endl;
+  return true;
+}
+
+// src/SketchInfo.cpp:60-102: two Fisher-Yates passes driven by glibc srand()/rand()
+std::vector<int32_t> generate_shuffle_dim(int half_subk) {
+  const int dim_size = 1 << (4 * half_subk);
+  std::vector<int32_t> arr(dim_size);
+  for (int i = 0; i < dim_size; i++) arr[i] = i;
+  const unsigned seeds[2] = {23u, 348842630u};
+  for (unsigned seed : seeds) {
+    srand(seed);
+    for (int i = dim_size - 1; i > 0; i--) {
+      int j = rand() % (i + 1);
+      std::swap(arr[i], arr[j]);
+    }
+  }
+  return arr;
+}
+
+// =================================================================================================
+// on-disk formats
+// =================================================================================================
+namespace {
+template <typename T> void wr(FILE* fp, const T& v) { fwrite(&v, sizeof(T), 1, fp); }
+template <typename T> bool rd(FILE* fp, T& v) { return fread(&v, sizeof(T), 1, fp) == 1; }
+FILE* open_or_die(const std::string& path, const char* mode, const char* who) {
+  FILE* fp = fopen(path.c_str(), mode);
+  if (!fp) { std::cerr << "ERROR: " << who << ", cannot open the file: " << path << std::endl; exit(1); }
+  return fp;
+}
+}  // namespace
+
+// src/Sketch_IO.cpp:36-134: info.sketch / info.mst / kssd.info.sketch / kssd.info.mst
+void save_genome_info(const std::vector<GenomeInfo>& g, const std::string& folder, const std::string& type,
+                      bool sketchByFile, bool kssd) {
+  const std::string path = folder + '/' + (kssd ? "kssd.info." : "info.") + type;
+  FILE* fp = open_or_die(path, "w+", "save_genome_info()");
+  wr(fp, sketchByFile);
+  size_t n = g.size();
+  wr(fp, n);
+  for (const GenomeInfo& s : g) {
+    if (sketchByFile) {
+      int a = (int)s.fileName.length(), b = (int)s.seq0.name.length(), c = (int)s.seq0.comment.length();
+      wr(fp, a); wr(fp, b); wr(fp, c); wr(fp, s.seq0.strand); wr(fp, s.totalSeqLength);
+      fwrite(s.fileName.c_str(), 1, a, fp); fwrite(s.seq0.name.c_str(), 1, b, fp); fwrite(s.seq0.comment.c_str(), 1, c, fp);
+    } else {
+      int b = (int)s.seq0.name.length(), c = (int)s.seq0.comment.length();
+      wr(fp, b); wr(fp, c); wr(fp, s.seq0.strand); wr(fp, s.seq0.length);
+      fwrite(s.seq0.name.c_str(), 1, b, fp); fwrite(s.seq0.comment.c_str(), 1, c, fp);
+    }
+    if (kssd) wr(fp, s.use64);
+  }
+  fclose(fp);
+}
+
+bool load_genome_info(const std::string& folder, const std::string& type, std::vector<GenomeInfo>& g, bool kssd,
+                      bool& sketchByFile) {
+  const std::string path = folder + '/' + (kssd ? "kssd.info." : "info.") + type;
+  FILE* fp = fopen(path.c_str(), "r");
+  if (!fp) { std::cerr << "ERROR: load_genome_info(), cannot open file: " << path << std::endl; return false; }
+  size_t n = 0;
+  if (!rd(fp, sketchByFile) || !rd(fp, n)) { fclose(fp); return false; }
+  g.clear(); g.reserve(n);
+  auto rdstr = [&](int len, std::string& s) { s.resize(len > 0 ? len : 0); return len <= 0 || fread(&s[0], 1, len, fp) == (size_t)len; };
+  for (size_t i = 0; i < n; i++) {
+    GenomeInfo s; s.id = (int)i;
+    if (sketchByFile) {
+      int a, b, c;
+      if (!rd(fp, a) || !rd(fp, b) || !rd(fp, c) || !rd(fp, s.seq0.strand) || !rd(fp, s.totalSeqLength)) { fclose(fp); return false; }
+      if (!rdstr(a, s.fileName) || !rdstr(b, s.seq0.name) || !rdstr(c, s.seq0.comment)) { fclose(fp); return false; }
+    } else {
+      int b, c;
+      if (!rd(fp, b) || !rd(fp, c) || !rd(fp, s.seq0.strand) || !rd(fp, s.seq0.length)) { fclose(fp); return false; }
+      if (!rdstr(b, s.seq0.name) || !rdstr(c, s.seq0.comment)) { fclose(fp); return false; }
+    }
+    if (kssd && !rd(fp, s.use64)) { fclose(fp); return false; }
+    g.push_back(std::move(s));
+  }
+  fclose(fp);
+  return true;
+}
+
+// src/Sketch_IO.cpp:169-226 (MinHash branch)
+void save_minhash_sketches(const std::vector<GenomeInfo>& g, const MinHashSketchFile& f, const std::string& folder,
+                           bool sketchByFile) {
+  save_genome_info(g, folder, "sketch", sketchByFile, false);
+  FILE* fp = open_or_die(folder + "/hash.sketch", "w+", "saveSketch()");
+  int sketch_func_id = 0;
+  wr(fp, sketch_func_id); wr(fp, f.kmerSize); wr(fp, f.isContainment);
+  if (f.isContainment) wr(fp, f.containCompress); else wr(fp, f.sketchSize);
+  for (const auto& h : f.hashes) { size_t m = h.size(); wr(fp, m); fwrite(h.data(), sizeof(uint64_t), m, fp); }
+  fclose(fp);
+  std::cerr << "-----save the sketches into: " << folder << std::endl;
+}
+
+// src/Sketch_IO.cpp:284-353
+bool load_minhash_sketches(const std::string& folder, std::vector<GenomeInfo>& g, MinHashSketchFile& f, bool& sketchByFile) {
+  FILE* fp = fopen((folder + "/hash.sketch").c_str(), "r");
+  if (!fp) {
+    std::cerr << "ERROR: loadSketches(), cannot open the file: " << folder << "/hash.sketch" << std::endl;
+    FILE* t = fopen((folder + "/kssd.hash.sketch").c_str(), "r");
+    if (t) { std::cerr << "Do you want to load the kssd sketches directory? Try again with '--fast' option" << std::endl; fclose(t); }
+    return false;
+  }
+  int sketch_func_id = 0;
+  if (!rd(fp, sketch_func_id) || sketch_func_id != 0) { fclose(fp); std::cerr << "ERROR: loadSketches(), only MinHash sketch folders are supported" << std::endl; return false; }
+  if (!rd(fp, f.kmerSize) || !rd(fp, f.isContainment)) { fclose(fp); return false; }
+  if (f.isContainment) { if (!rd(fp, f.containCompress)) { fclose(fp); return false; } }
+  else if (!rd(fp, f.sketchSize)) { fclose(fp); return false; }
+  if (!load_genome_info(folder, "sketch", g, false, sketchByFile)) { fclose(fp); return false; }
+  f.hashes.assign(g.size(), {});
+  for (size_t i = 0; i < g.size(); i++) {
+    size_t m = 0;
+    if (!rd(fp, m)) { fclose(fp); return false; }
+    f.hashes[i].resize(m);
+    if (m && fread(f.hashes[i].data(), sizeof(uint64_t), m, fp) != m) { fclose(fp); return false; }
+  }
+  fclose(fp);
+  return true;
+}
+
+// src/SketchInfo.h:115-160 "MHIDX001".  Entries are written in ascending hash order (the reference
+// writes hash-map iteration order; its loader accepts any order).
+void save_minhash_index(const MinHashSketchFile& f, const std::string& folder) {
+  std::vector<std::pair<uint64_t, uint32_t>> all;
+  size_t tot = 0;
+  for (const auto& h : f.hashes) tot += h.size();
+  all.reserve(tot);
+  for (size_t g = 0; g < f.hashes.size(); g++) for (uint64_t h : f.hashes[g]) all.emplace_back(h, (uint32_t)g);
+  std::sort(all.begin(), all.end());
+  size_t nuniq = 0;
+  for (size_t i = 0; i < all.size(); i++) if (i == 0 || all[i].first != all[i - 1].first) nuniq++;
+  FILE* fp = fopen((folder + "/minhash.sketch.index").c_str(), "wb");
+  if (!fp) { std::cerr << "WARNING: cannot save MinHash index to: " << folder << "/minhash.sketch.index" << std::endl; return; }
+  fwrite("MHIDX001", 1, 8, fp);
+  wr(fp, nuniq);
+  for (size_t i = 0; i < all.size();) {
+    size_t j = i;
+    while (j < all.size() && all[j].first == all[i].first) j++;
+    uint64_t h = all[i].first; uint32_t m = (uint32_t)(j - i);
+    wr(fp, h); wr(fp, m);
+    for (size_t t = i; t < j; t++) wr(fp, all[t].second);
+    i = j;
+  }
+  fclose(fp);
+  std::cerr << "-----MinHash inverted index saved: " << folder << "/minhash.sketch.index (" << nuniq << " unique hashes)" << std::endl;
+}
+
+// src/Sketch_IO.cpp:136-167
+void save_kssd_sketches(const std::vector<GenomeInfo>& g, const KssdSketchFile& f, const std::string& folder, bool sketchByFile) {
+  save_genome_info(g, folder, "sketch", sketchByFile, true);
+  FILE* fp = open_or_die(folder + "/kssd.hash.sketch", "w+", "saveSketch()");
+  fwrite(&f.info, sizeof(KssdParameters), 1, fp);
+  for (size_t i = 0; i < g.size(); i++) {
+    if (f.use64) { size_t m = f.h64[i].size(); wr(fp, m); fwrite(f.h64[i].data(), sizeof(uint64_t), m, fp); }
+    else { size_t m = f.h32[i].size(); wr(fp, m); fwrite(f.h32[i].data(), sizeof(uint32_t), m, fp); }
+  }
+  fclose(fp);
+  std::cerr << "-----save the kssd sketches into: " << folder << std::endl;
+}
+
+// src/Sketch_IO.cpp:228-282
+bool load_kssd_sketches(const std::string& folder, std::vector<GenomeInfo>& g, KssdSketchFile& f, bool& sketchByFile) {
+  FILE* fp = fopen((folder + "/kssd.hash.sketch").c_str(), "r");
+  if (!fp) {
+    std::cerr << "ERROR: loadKssdSketches(), cannot open the file: " << folder << "/kssd.hash.sketch" << std::endl;
+    FILE* t = fopen((folder + "/hash.sketch").c_str(), "r");
+    if (t) { std::cerr << "Do you want to load the minHash sketches directory? Try again without '--fast' option" << std::endl; fclose(t); }
+    return false;
+  }
+  if (fread(&f.info, sizeof(KssdParameters), 1, fp) != 1) { fclose(fp); return false; }
+  if (!load_genome_info(folder, "sketch", g, true, sketchByFile) || g.empty()) { fclose(fp); return false; }
+  f.use64 = g[0].use64;
+  f.h32.assign(f.use64 ? 0 : g.size(), {}); f.h64.assign(f.use64 ? g.size() : 0, {});
+  for (size_t i = 0; i < g.size(); i++) {
+    size_t m = 0;
+    if (!rd(fp, m)) { fclose(fp); return false; }
+    if (f.use64) { f.h64[i].resize(m); if (m && fread(f.h64[i].data(), 8, m, fp) != m) { fclose(fp); return false; } }
+    else { f.h32[i].resize(m); if (m && fread(f.h32[i].data(), 4, m, fp) != m) { fclose(fp); return false; } }
+  }
+  fclose(fp);
+  return true;
+}
+
+// src/SketchInfo.cpp:1379-1467: kssd.sketch.index = {size_t H; hash[H]; u32 count[H]}, .dict = ids
+void save_kssd_index(const KssdSketchFile& f, const std::string& folder) {
+  std::vector<std::pair<uint64_t, uint32_t>> all;
+  const size_t n = f.use64 ? f.h64.size() : f.h32.size();
+  for (size_t g = 0; g < n; g++) {
+    if (f.use64) for (uint64_t h : f.h64[g]) all.emplace_back(h, (uint32_t)g);
+    else for (uint32_t h : f.h32[g]) all.emplace_back((uint64_t)h, (uint32_t)g);
+  }
+  std::sort(all.begin(), all.end());
+  std::vector<uint64_t> keys; std::vector<uint32_t> counts;
+  FILE* fd = open_or_die(folder + "/kssd.sketch.dict", "w+", "transSketchesFromIndex");
+  for (size_t i = 0; i < all.size();) {
+    size_t j = i;
+    while (j < all.size() && all[j].first == all[i].first) j++;
+    keys.push_back(all[i].first); counts.push_back((uint32_t)(j - i));
+    for (size_t t = i; t < j; t++) wr(fd, all[t].second);
+    i = j;
+  }
+  fclose(fd);
+  FILE* fi = open_or_die(folder + "/kssd.sketch.index", "w+", "transSketchesFromIndex");
+  size_t H = keys.size();
+  wr(fi, H);
+  if (f.use64) fwrite(keys.data(), 8, H, fi);
+  else for (uint64_t k : keys) { uint32_t k32 = (uint32_t)k; wr(fi, k32); }
+  fwrite(counts.data(), 4, H, fi);
+  fclose(fi);
+}
+
+// src/MST_IO.cpp:200-217, :47-70
+void save_mst(const std::vector<rtc_edge>& mst, const std::string& folder) {
+  FILE* fp = open_or_die(folder + "/edge.mst", "w+", "saveMST()");
+  size_t m = mst.size();
+  wr(fp, m);
+  for (const rtc_edge& e : mst) { wr(fp, e.preNode); wr(fp, e.sufNode); wr(fp, e.dist); }
+  fclose(fp);
+  std::cerr << "-----save the mst into: " << folder << std::endl;
+}
+bool load_mst(const std::string& folder, std::vector<rtc_edge>& mst) {
+  FILE* fp = fopen((folder + "/edge.mst").c_str(), "r");
+  if (!fp) { std::cerr << "ERROR: loadMST(), cannot open the file: " << folder << "/edge.mst" << std::endl; return false; }
+  size_t m = 0;
+  if (!rd(fp, m)) { fclose(fp); return false; }
+  mst.clear(); mst.reserve(m);
+  for (size_t i = 0; i < m; i++) {
+    rtc_edge e;
+    if (!rd(fp, e.preNode) || !rd(fp, e.sufNode) || !rd(fp, e.dist)) { fclose(fp); return false; }
+    mst.push_back(e);
+  }
+  fclose(fp);
+  std::cerr << "-----read the mst file from " << folder << "/edge.mst" << std::endl;
+  return true;
+}
+
+// =================================================================================================
+// forest cut + BFS clusters + text output
+// =================================================================================================
+std::vector<rtc_edge> generate_forest(const std::vector<rtc_edge>& mst, double threshold) {  // src/MST.cpp:77-85
+  std::vector<rtc_edge> forest;
+  for (const rtc_edge& e : mst) if (e.dist <= threshold) forest.push_back(e);
+  return forest;
+}
+
+std::vector<std::vector<int>> generate_cluster_with_bfs(const std::vector<rtc_edge>& forest, int vertices) {  // :109-142
+  std::vector<std::vector<int>> res, G(vertices);
+  for (const rtc_edge& e : forest) { G[e.preNode].push_back(e.sufNode); G[e.sufNode].push_back(e.preNode); }
+  std::vector<char> visited(vertices, 0);
+  for (int i = 0; i < vertices; i++) {
+    if (visited[i]) continue;
+    visited[i] = 1;
+    std::queue<int> Q; Q.push(i);
+    std::vector<int> cl{i};
+    while (!Q.empty()) {
+      int k = Q.front(); Q.pop();
+      for (int v : G[k]) { if (visited[v]) continue; visited[v] = 1; Q.push(v); cl.push_back(v); }
+    }
+    res.push_back(std::move(cl));
+  }
+  return res;
+}
+
+// src/MST_IO.cpp:72-179 (printResult / printKssdResult share the layout)
+void print_result(const std::vector<std::vector<int>>& cluster, const std::vector<GenomeInfo>& g, bool sketchByFile,
+                  const std::string& outputFile, double threshold) {
+  FILE* fp = fopen(outputFile.c_str(), "w");
+  if (!fp) { std::cerr << "Error in printResult(), cannot open file: " << outputFile << std::endl; exit(1); }
+  if (threshold >= 0.0) {
+    fprintf(fp, "# Clustering threshold: %.6f\n", threshold);
+    fprintf(fp, "# Total clusters: %zu\n", cluster.size());
+    fprintf(fp, "#\n");
+  }
+  for (size_t i = 0; i < cluster.size(); i++) {
+    fprintf(fp, "the cluster %d is: \n", (int)i);
+    for (size_t j = 0; j < cluster[i].size(); j++) {
+      const int curId = cluster[i][j];
+      if (curId < 0 || curId >= (int)g.size()) continue;
+      const GenomeInfo& s = g[curId];
+      if (sketchByFile)
+        fprintf(fp, "\t%5d\t%6d\t%12dnt\t%20s\t%20s\t%s\n", (int)j, curId, (int)s.totalSeqLength, s.fileName.c_str(),
+                s.seq0.name.c_str(), s.seq0.comment.c_str());
+      else
+        fprintf(fp, "\t%6d\t%6d\t%12dnt\t%20s\t%s\n", (int)j, curId, s.seq0.length, s.seq0.name.c_str(), s.seq0.comment.c_str());
+    }
+    fprintf(fp, "\n");
+  }
+  fclose(fp);
+}
+
+std::string current_date_time() {
+  time_t now = time(0);
+  struct tm tstruct = *localtime(&now);
+  char buf[80];
+  strftime(buf, sizeof(buf), "%Y_%m_%d_%H-%M-%S", &tstruct);
+  return buf;
+}
+
+}  // namespace rtc

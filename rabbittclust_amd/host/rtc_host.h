@@ -1,0 +1,95 @@
+// rtc_host.h -- host side of the drop-in: FASTA reading, parameter tuning, on-disk formats,
+// cluster extraction and text output, mirroring the reference's interface for this path
+// (names, argument meaning, error behaviour).  The compute goes through include/rtclust.h.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rtclust.h"
+
+namespace rtc {
+
+// == SequenceInfo / SketchInfo metadata, src/SketchInfo.h:14-39 (reference tree) ==
+struct SequenceInfo {
+  std::string name, comment;
+  int strand = 0;
+  int length = 0;
+};
+
+struct GenomeInfo {
+  int id = 0;
+  std::string fileName;          // list mode
+  uint64_t totalSeqLength = 0;   // list mode: sum of record lengths
+  SequenceInfo seq0;             // list mode: first record; sequence mode: the record
+  bool use64 = false;            // KSSD only (kssd.info.* trailing byte)
+};
+
+// ---- FASTA / FASTQ reading with the semantics of klib kseq as used at src/SketchInfo.cpp:880-948 ----
+struct FastaRecord {
+  std::string name, comment;
+  bool has_comment = false;  // false -> the reference substitutes "noName"
+  std::string seq;
+};
+// Reads every record of `path` (plain or gzip).  Returns false if the file cannot be opened.
+bool read_fasta(const std::string& path, std::vector<FastaRecord>& out);
+// Streaming variant used by the sketch driver: appends the records' bases to `bases`, separated by
+// '\n' (a non-ACGT byte, so k-mers never span records), and reports first-record metadata.
+bool read_genome_file(const std::string& path, std::string& bases, SequenceInfo& first, uint64_t& total_len,
+                      uint64_t& n_records);
+
+// ---- calSize / tune_parameters / tune_kssd_parameters, src/SketchInfo.cpp:438-552, src/sub_command.cpp:2317-2467 ----
+bool cal_size(const std::string& list_file, uint64_t minLen, uint64_t& maxSize, uint64_t& minSize, uint64_t& averageSize);
+bool tune_parameters(bool greedy, bool isSetKmer, uint64_t maxSize, uint64_t minSize, uint64_t averageSize,
+                     bool& isContainment, bool isJaccard, int& kmerSize, double threshold, int& containCompress,
+                     int sketchSize);
+bool tune_kssd_parameters(bool isSetKmer, uint64_t maxSize, uint64_t minSize, uint64_t averageSize, bool isContainment,
+                          int& kmerSize, double threshold, int drlevel);
+// file size the reference uses for containment sketch sizes (gz: ISIZE trailer), src/SketchInfo.cpp:892-915
+int file_length_for_containment(const std::string& path);
+
+// ---- generate_shuffle_dim, src/SketchInfo.cpp:60-102 (glibc srand/rand) ----
+std::vector<int32_t> generate_shuffle_dim(int half_subk);
+
+// ---- on-disk formats (src/Sketch_IO.cpp, src/MST_IO.cpp, src/SketchInfo.h:115-160) ----
+struct KssdParameters { int id, half_k, half_subk, drlevel, genomeNumber; };  // src/SketchInfo.h:50-56
+
+void save_genome_info(const std::vector<GenomeInfo>& g, const std::string& folder, const std::string& type,
+                      bool sketchByFile, bool kssd);
+bool load_genome_info(const std::string& folder, const std::string& type, std::vector<GenomeInfo>& g, bool kssd,
+                      bool& sketchByFile);
+
+struct MinHashSketchFile {
+  int kmerSize = 21;
+  bool isContainment = false;
+  int containCompress = 1000, sketchSize = 1000;
+  std::vector<std::vector<uint64_t>> hashes;
+};
+void save_minhash_sketches(const std::vector<GenomeInfo>& g, const MinHashSketchFile& f, const std::string& folder,
+                           bool sketchByFile);
+bool load_minhash_sketches(const std::string& folder, std::vector<GenomeInfo>& g, MinHashSketchFile& f, bool& sketchByFile);
+void save_minhash_index(const MinHashSketchFile& f, const std::string& folder);  // minhash.sketch.index (MHIDX001)
+
+struct KssdSketchFile {
+  KssdParameters info{};
+  bool use64 = false;
+  std::vector<std::vector<uint32_t>> h32;
+  std::vector<std::vector<uint64_t>> h64;
+};
+void save_kssd_sketches(const std::vector<GenomeInfo>& g, const KssdSketchFile& f, const std::string& folder, bool sketchByFile);
+bool load_kssd_sketches(const std::string& folder, std::vector<GenomeInfo>& g, KssdSketchFile& f, bool& sketchByFile);
+void save_kssd_index(const KssdSketchFile& f, const std::string& folder);  // kssd.sketch.index + .dict
+
+void save_mst(const std::vector<rtc_edge>& mst, const std::string& folder);   // edge.mst
+bool load_mst(const std::string& folder, std::vector<rtc_edge>& mst);
+
+// ---- forest cut, BFS clusters, result text (src/MST.cpp:77-85,109-142; src/MST_IO.cpp:72-179) ----
+std::vector<rtc_edge> generate_forest(const std::vector<rtc_edge>& mst, double threshold);
+std::vector<std::vector<int>> generate_cluster_with_bfs(const std::vector<rtc_edge>& forest, int vertices);
+void print_result(const std::vector<std::vector<int>>& cluster, const std::vector<GenomeInfo>& g, bool sketchByFile,
+                  const std::string& outputFile, double threshold = -1.0);
+
+std::string current_date_time();  // src/common.hpp:36-44
+
+}  // namespace rtc

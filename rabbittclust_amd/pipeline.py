@@ -28,6 +28,66 @@ def triangle_row_ranges(n, world):
     return b
 
 
+class HipBoruvkaBackend:
+    """Per-round primitives on this rank's candidate edges (device tensors, HIP kernels)."""
+
+    def __init__(self, ctx, sk, edges, m, is_containment):
+        self.ctx, self.sk, self.edges, self.m, self.ic = ctx, sk, edges, m, int(is_containment)
+        self.device = ctx.device
+
+    def minweight(self, comp, wkey):
+        c = self.ctx
+        c.check(c.lib.rtc_boruvka_minweight_dev(c.h, _t_ptr(self.edges), self.m, _t_ptr(self.sk.len), self.ic,
+                                                _t_ptr(comp), self.sk.n, _t_ptr(wkey)))
+
+    def minedge(self, comp, wkey, ekey):
+        c = self.ctx
+        c.check(c.lib.rtc_boruvka_minedge_dev(c.h, _t_ptr(self.edges), self.m, _t_ptr(self.sk.len), self.ic,
+                                              _t_ptr(comp), self.sk.n, _t_ptr(wkey), _t_ptr(ekey)))
+
+    def fetch(self, comp, ekey, ecommon):
+        c = self.ctx
+        c.check(c.lib.rtc_boruvka_fetch_dev(c.h, _t_ptr(self.edges), self.m, _t_ptr(comp), self.sk.n,
+                                            _t_ptr(ekey), _t_ptr(ecommon)))
+
+
+def boruvka_rounds(backend, n, lib, dist=None, world=1):
+    """Boruvka over row-sharded candidate edges.  Per round: local per-component minimum weight key
+    -> all-reduce(MIN) -> local minimum edge id among edges attaining it -> all-reduce(MIN) ->
+    owner publishes `common` -> all-reduce(MAX); then every rank applies the identical host-side
+    union (rtc_boruvka_merge_host).  `backend` supplies the three local primitives."""
+    dev = backend.device
+    wkey = torch.empty(n, dtype=torch.int64, device=dev)
+    ekey = torch.empty(n, dtype=torch.int64, device=dev)
+    ecommon = torch.empty(n, dtype=torch.int32, device=dev)
+    comp_h = np.arange(n, dtype=np.uint32)
+    comp = torch.empty(n, dtype=torch.int32, device=dev)
+    sel = np.zeros(max(n, 1), dtype=CEDGE_DT)
+    nsel, added = C.c_uint64(0), C.c_uint64(0)
+    rounds = 0
+    for _ in range(64):
+        comp.copy_(torch.from_numpy(comp_h.view(np.int32)))
+        backend.minweight(comp, wkey)
+        if world > 1:
+            dist.all_reduce(wkey, op=dist.ReduceOp.MIN)
+        backend.minedge(comp, wkey, ekey)
+        if world > 1:
+            dist.all_reduce(ekey, op=dist.ReduceOp.MIN)
+        backend.fetch(comp, ekey, ecommon)
+        if world > 1:
+            dist.all_reduce(ecommon, op=dist.ReduceOp.MAX)
+        ekey_h = np.ascontiguousarray(ekey.cpu().numpy().view(np.uint64))
+        ecommon_h = np.ascontiguousarray(ecommon.cpu().numpy().view(np.uint32))
+        st = lib.rtc_boruvka_merge_host(n, _np_ptr(ekey_h), _np_ptr(ecommon_h), _np_ptr(comp_h),
+                                        _np_ptr(sel), C.byref(nsel), C.byref(added))
+        if st != _lib.RTC_OK:
+            raise _lib.RtcError(st, "rtc_boruvka_merge_host")
+        rounds += 1
+        if added.value == 0:
+            break
+    return sel[: nsel.value], rounds
+
+
 class MstPipeline:
     def __init__(self, ctx, k=21, sketch_size=1000, threshold=0.05, is_containment=False,
                  dist=None, rank=0, world=1, row_chunk_bytes=2 << 30):
@@ -94,41 +154,8 @@ class MstPipeline:
         return self._edges, m
 
     def boruvka(self, sk, edges, m):
-        ctx, n = self.ctx, sk.n
-        dev = ctx.device
-        wkey = torch.empty(n, dtype=torch.int64, device=dev)
-        ekey = torch.empty(n, dtype=torch.int64, device=dev)
-        ecommon = torch.empty(n, dtype=torch.int32, device=dev)
-        comp_h = np.arange(n, dtype=np.uint32)
-        comp = torch.empty(n, dtype=torch.int32, device=dev)
-        sel = np.zeros(max(n, 1), dtype=CEDGE_DT)
-        nsel, added = C.c_uint64(0), C.c_uint64(0)
-        ic = int(self.is_containment)
-        rounds = 0
-        for _ in range(64):
-            comp.copy_(torch.from_numpy(comp_h.view(np.int32)))
-            ctx.check(ctx.lib.rtc_boruvka_minweight_dev(ctx.h, _t_ptr(edges), m, _t_ptr(sk.len), ic,
-                                                        _t_ptr(comp), n, _t_ptr(wkey)))
-            if self.world > 1:
-                self.dist.all_reduce(wkey, op=self.dist.ReduceOp.MIN)
-            ctx.check(ctx.lib.rtc_boruvka_minedge_dev(ctx.h, _t_ptr(edges), m, _t_ptr(sk.len), ic,
-                                                      _t_ptr(comp), n, _t_ptr(wkey), _t_ptr(ekey)))
-            if self.world > 1:
-                self.dist.all_reduce(ekey, op=self.dist.ReduceOp.MIN)
-            ctx.check(ctx.lib.rtc_boruvka_fetch_dev(ctx.h, _t_ptr(edges), m, _t_ptr(comp), n, _t_ptr(ekey),
-                                                    _t_ptr(ecommon)))
-            if self.world > 1:
-                self.dist.all_reduce(ecommon, op=self.dist.ReduceOp.MAX)
-            ekey_h = ekey.cpu().numpy().view(np.uint64)
-            ecommon_h = ecommon.cpu().numpy().view(np.uint32)
-            st = ctx.lib.rtc_boruvka_merge_host(n, _np_ptr(ekey_h), _np_ptr(ecommon_h), _np_ptr(comp_h),
-                                                _np_ptr(sel), C.byref(nsel), C.byref(added))
-            if st != _lib.RTC_OK:
-                raise _lib.RtcError(st, "rtc_boruvka_merge_host")
-            rounds += 1
-            if added.value == 0:
-                break
-        return sel[: nsel.value], rounds
+        backend = HipBoruvkaBackend(self.ctx, sk, edges, m, self.is_containment)
+        return boruvka_rounds(backend, sk.n, self.ctx.lib, self.dist, self.world)
 
     def finish(self, sk, sel):
         """(i, j, common) -> EdgeInfo records with the reference's double arithmetic, sorted."""

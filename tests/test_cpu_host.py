@@ -1,0 +1,211 @@
+"""CPU suite: host side of the drop-in -- FASTA reader vs the reference's kseq (golden dumps made
+with oracle/_ref, plus a live comparison when the harness is present), on-disk formats written
+independently here per SURVEY Appendix A and re-saved by the host library byte-for-byte,
+--premsted cluster text, parameter tuning vs the oracle, KSSD shuffle table vs the oracle."""
+import ctypes as C
+import glob
+import os
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+HOSTLIB = os.path.join(ROOT, "rabbittclust_amd", "librtclust_host.so")
+
+
+@pytest.fixture(scope="module")
+def host():
+    if not os.path.exists(HOSTLIB):
+        pytest.fail("librtclust_host.so missing: run __graft_entry__.build()")
+    lib = C.CDLL(HOSTLIB)
+    lib.rtch_fasta_dump.restype = C.c_long
+    lib.rtch_premsted.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, C.c_int]
+    lib.rtch_tune.argtypes = [C.c_int] * 5 + [C.c_double, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
+                                               C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    return lib
+
+
+def _dump(lib, fn, path):
+    need = fn(path.encode(), None, 0)
+    if need < 0:
+        return None
+    buf = C.create_string_buffer(max(need, 1))
+    fn(path.encode(), buf, need)
+    return buf.raw[:need]
+
+
+def test_fasta_reader_matches_reference_kseq_golden(host):
+    files = sorted(glob.glob(os.path.join(GOLD, "fasta", "*")))
+    assert len(files) >= 7
+    for f in files:
+        want = open(os.path.join(GOLD, "kseq_dump_" + os.path.basename(f) + ".txt"), "rb").read()
+        assert _dump(host, host.rtch_fasta_dump, f) == want, f
+    assert host.rtch_fasta_dump(b"/nonexistent/file.fa", None, 0) == -1
+
+
+def test_fasta_reader_matches_reference_kseq_live(host, tmp_path):
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libref_harness.so")
+    if not os.path.exists(ref_path):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    ref = C.CDLL(ref_path)
+    ref.ref_kseq_dump.restype = C.c_long
+    rng = np.random.default_rng(9)
+    for t in range(20):
+        parts = []
+        for r in range(int(rng.integers(0, 5))):
+            hdr = ">" + "".join(rng.choice(list("abcXYZ_ \t|.:"), size=int(rng.integers(0, 20))))
+            eol = "\r\n" if rng.random() < 0.3 else "\n"
+            parts.append(hdr + eol)
+            for _ in range(int(rng.integers(0, 4))):
+                parts.append("".join(rng.choice(list("ACGTNacgt"), size=int(rng.integers(0, 90)))) + eol)
+                if rng.random() < 0.2:
+                    parts.append(eol)
+        p = tmp_path / f"r{t}.fa"
+        p.write_bytes("".join(parts).encode())
+        assert _dump(host, host.rtch_fasta_dump, str(p)) == _dump(ref, ref.ref_kseq_dump, str(p)), "".join(parts)
+
+
+# ---- independent writers of the on-disk formats ----
+def _write_info(path, genomes, kssd=False, use64=False):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<?Q", True, len(genomes)))
+        for fn, name, cm, length in genomes:
+            f.write(struct.pack("<iiiiQ", len(fn), len(name), len(cm), 0, length))
+            f.write(fn.encode() + name.encode() + cm.encode())
+            if kssd:
+                f.write(struct.pack("<?", use64))
+
+
+def _genomes(n):
+    return [(f"/data/genome_{i}.fna", f"seq{i}", f"comment number {i}" if i % 3 else "noName", 5_000_000 + 17 * i)
+            for i in range(n)]
+
+
+def test_minhash_folder_roundtrip_bytes(host, tmp_path):
+    src, dst = tmp_path / "src", tmp_path / "dst"
+    src.mkdir(); dst.mkdir()
+    rng = np.random.default_rng(11)
+    g = _genomes(9)
+    sk = [np.unique(rng.integers(0, 1 << 20, size=int(rng.integers(0, 60)), dtype=np.uint64)) for _ in g]
+    sk[4] = np.zeros(0, dtype=np.uint64)
+    _write_info(src / "info.sketch", g)
+    for containment, val in ((False, 1000), (True, 777)):
+        with open(src / "hash.sketch", "wb") as f:
+            f.write(struct.pack("<ii?i", 0, 21, containment, val))
+            for h in sk:
+                f.write(struct.pack("<Q", len(h)) + h.astype("<u8").tobytes())
+        assert host.rtch_resave_folder(str(src).encode(), str(dst).encode(), 0) == 0
+        for name in ("info.sketch", "hash.sketch"):
+            assert (src / name).read_bytes() == (dst / name).read_bytes(), name
+        # MHIDX001 index: magic, count, then {hash, m, ids[m]} -- check it inverts the sketches
+        raw = (dst / "minhash.sketch.index").read_bytes()
+        assert raw[:8] == b"MHIDX001"
+        (H,) = struct.unpack_from("<Q", raw, 8)
+        pos, inv = 16, {}
+        for _ in range(H):
+            h, m = struct.unpack_from("<QI", raw, pos); pos += 12
+            inv[h] = list(struct.unpack_from(f"<{m}I", raw, pos)); pos += 4 * m
+        assert pos == len(raw)
+        want = {}
+        for gi, h in enumerate(sk):
+            for x in h.tolist():
+                want.setdefault(x, []).append(gi)
+        assert inv == want
+
+
+@pytest.mark.parametrize("use64", [False, True])
+def test_kssd_folder_roundtrip_bytes(host, tmp_path, use64):
+    src, dst = tmp_path / "src", tmp_path / "dst"
+    src.mkdir(); dst.mkdir()
+    rng = np.random.default_rng(12)
+    g = _genomes(7)
+    dt = np.uint64 if use64 else np.uint32
+    sk = [np.unique(rng.integers(0, 1 << 18, size=int(rng.integers(1, 50)), dtype=np.uint64)).astype(dt) for _ in g]
+    _write_info(src / "kssd.info.sketch", g, kssd=True, use64=use64)
+    half_k, half_subk, dr = (16, 6, 3) if use64 else (11, 6, 3)
+    with open(src / "kssd.hash.sketch", "wb") as f:
+        f.write(struct.pack("<iiiii", (half_k << 8) + (half_subk << 4) + dr, half_k, half_subk, dr, len(g)))
+        for h in sk:
+            f.write(struct.pack("<Q", len(h)) + h.tobytes())
+    assert host.rtch_resave_folder(str(src).encode(), str(dst).encode(), 1) == 0
+    for name in ("kssd.info.sketch", "kssd.hash.sketch"):
+        assert (src / name).read_bytes() == (dst / name).read_bytes(), name
+    idx = (dst / "kssd.sketch.index").read_bytes()
+    (H,) = struct.unpack_from("<Q", idx, 0)
+    w = 8 if use64 else 4
+    keys = np.frombuffer(idx, dtype=dt, count=H, offset=8)
+    counts = np.frombuffer(idx, dtype=np.uint32, count=H, offset=8 + w * H)
+    assert len(idx) == 8 + (w + 4) * H
+    ids = np.frombuffer((dst / "kssd.sketch.dict").read_bytes(), dtype=np.uint32)
+    assert counts.sum() == len(ids) == sum(len(h) for h in sk)
+    pos = 0
+    for k_, c in zip(keys.tolist(), counts.tolist()):
+        assert sorted(ids[pos:pos + c].tolist()) == [gi for gi, h in enumerate(sk) if k_ in h.tolist()]
+        pos += c
+
+
+def test_premsted_cluster_text_and_mst_roundtrip(host, tmp_path, oracle):
+    src, dst = tmp_path / "src", tmp_path / "dst"
+    src.mkdir(); dst.mkdir()
+    g = _genomes(8)
+    _write_info(src / "info.mst", g)
+    edges = [(1, 0, 0.01), (2, 1, 0.04), (5, 4, 0.0), (6, 2, 0.2), (7, 6, 0.05)]
+    with open(src / "edge.mst", "wb") as f:
+        f.write(struct.pack("<Q", len(edges)))
+        for a, b, d in edges:
+            f.write(struct.pack("<iid", a, b, d))
+    out = tmp_path / "result.out"
+    assert host.rtch_premsted(str(src).encode(), str(dst).encode(), str(out).encode(), 0.05, 0) == 0
+    assert (src / "edge.mst").read_bytes() == (dst / "edge.mst").read_bytes()
+    assert (src / "info.mst").read_bytes() == (dst / "info.mst").read_bytes()
+    text = out.read_text().splitlines()
+    assert text[0] == "# Clustering threshold: 0.050000" and text[1] == "# Total clusters: 4" and text[2] == "#"
+    # clusters in BFS order from ascending ids: {0,1,2}, {3}, {4,5}, {6,7}
+    e = np.array(edges, dtype=oracle.EDGE_DT)
+    want = oracle.forest_clusters(e, 0.05, 8)
+    assert want == [[0, 1, 2], [3], [4, 5], [6, 7]]
+    body = [ln for ln in text[3:] if ln]
+    assert body[0] == "the cluster 0 is: "
+    fn, name, cm, length = g[0]
+    assert body[1] == "\t%5d\t%6d\t%12dnt\t%20s\t%20s\t%s" % (0, 0, length, fn, name, cm)
+    ids = [int(ln.split("\t")[2]) for ln in body if ln.startswith("\t")]
+    assert ids == [x for c in want for x in c]
+
+
+def test_tune_parameters_matches_oracle(host, oracle):
+    cases = [(0, 1, 0, 1, 21, 0.05, 1000, 1000, 1012520, 1012520, 1012520),
+             (0, 1, 0, 1, 21, 0.05, 1000, 1000, 5062520, 4000000, 4800000),
+             (1, 0, 0, 0, 19, 0.05, 1000, 1000, 5062520, 3000000, 4100000),
+             (1, 1, 1, 0, 21, 0.05, 9000000, 1000, 5062520, 3000000, 4100000),
+             (0, 1, 0, 1, 12, 0.05, 1000, 1000, 2025040, 2025040, 2025040),
+             (0, 1, 0, 1, 21, 0.6, 1000, 1000, 5062520, 5062520, 5062520),
+             (0, 1, 1, 1, 21, 0.05, 1000, 1000, 5062520, 5062520, 5062520)]
+    for cs in cases:
+        r = oracle.tune_parameters(*cs)
+        k, cc, ic = C.c_int(), C.c_int(), C.c_int()
+        ok = host.rtch_tune(*cs[:5], cs[5], cs[6], cs[7], cs[8], cs[9], cs[10], C.byref(k), C.byref(cc), C.byref(ic))
+        assert ok == r.ok, cs
+        if r.ok:
+            assert (k.value, cc.value, ic.value) == (r.kmer_size, r.contain_compress, r.is_containment), cs
+
+
+def test_shuffle_dim_matches_oracle_and_file_sizes(host, oracle, tmp_path):
+    out = np.zeros(1 << 24, dtype=np.int32)
+    assert host.rtch_shuffle_dim(6, out.ctypes.data_as(C.c_void_p)) == 1 << 24
+    assert np.array_equal(out, oracle.kssd_shuffle_dim(6))
+    # calSize / containment file length: plain = stat size, gz = ISIZE trailer
+    import gzip
+    payload = b">x\n" + b"ACGT" * 5000 + b"\n"
+    p1, p2 = tmp_path / "a.fna", tmp_path / "b.fna.gz"
+    p1.write_bytes(payload)
+    with gzip.open(p2, "wb") as f:
+        f.write(payload)
+    assert host.rtch_file_length(str(p1).encode()) == len(payload)
+    assert host.rtch_file_length(str(p2).encode()) == len(payload)
+    lst = tmp_path / "list.txt"
+    lst.write_text(f"{p1}\n{p2}\n")
+    mx, mn, avg = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    assert host.rtch_cal_size(str(lst).encode(), C.c_uint64(10000), C.byref(mx), C.byref(mn), C.byref(avg)) == 1
+    assert mx.value == mn.value == avg.value == len(payload)
