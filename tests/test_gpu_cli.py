@@ -1,0 +1,179 @@
+"""GPU end-to-end: the clust-mst / clust-greedy command lines on FASTA files, checked against the
+oracle run on the same bytes (sketch file contents, MST weights, cluster partition, resume flows)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "rabbittclust_amd", "bin")
+
+
+def _write_family_fastas(oracle, tmp, n_fam, per, L, seed=1, two_records=False):
+    from rabbittclust_amd import api
+    desc = api.synth_family_descs(n_fam, per, global_seed=seed)
+    paths, seqs = [], []
+    for g, d in enumerate(desc):
+        s = oracle.synth_genome(int(d["fam_seed"]), int(d["mut_seed"]), int(d["mut_thr"]), L)
+        p = os.path.join(tmp, f"g{g:03d}.fna")
+        raw = s.tobytes()
+        with open(p, "wb") as f:
+            if two_records and g % 2:
+                cut = L // 3
+                recs = [(f">g{g}_a synthetic family {g // per}\n", raw[:cut]), (f">g{g}_b\n", raw[cut:])]
+            else:
+                recs = [(f">g{g} synthetic family {g // per}\n", raw)]
+            for hdr, body in recs:
+                f.write(hdr.encode())
+                for i in range(0, len(body), 80):
+                    f.write(body[i:i + 80] + b"\n")
+        paths.append(p)
+        seqs.append(s)
+    lst = os.path.join(tmp, "list.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    return lst, paths, seqs
+
+
+def _parse_clusters(path):
+    clusters, cur = [], None
+    for ln in open(path):
+        if ln.startswith("the cluster"):
+            cur = []
+            clusters.append(cur)
+        elif ln.startswith("\t"):
+            cur.append(int(ln.split("\t")[2]))
+    return clusters
+
+
+def _partition(cl):
+    return sorted(tuple(sorted(c)) for c in cl)
+
+
+def _run(args, cwd):
+    r = subprocess.run(args, cwd=cwd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r.stderr
+
+
+def _read_hash_sketch(folder):
+    raw = open(os.path.join(folder, "hash.sketch"), "rb").read()
+    fid, k, cont, val = struct.unpack_from("<ii?i", raw, 0)
+    pos, out = 13, []
+    while pos < len(raw):
+        (m,) = struct.unpack_from("<Q", raw, pos); pos += 8
+        out.append(np.frombuffer(raw, dtype="<u8", count=m, offset=pos).copy()); pos += 8 * m
+    return (fid, k, cont, val), out
+
+
+def _read_edges(folder):
+    raw = open(os.path.join(folder, "edge.mst"), "rb").read()
+    (m,) = struct.unpack_from("<Q", raw, 0)
+    return np.frombuffer(raw, dtype=np.dtype([("pre", "<i4"), ("suf", "<i4"), ("dist", "<f8")]), count=m, offset=8)
+
+
+def test_clust_mst_end_to_end_and_resume(oracle, tmp_path):
+    tmp = str(tmp_path)
+    L = 2_000_000  # large enough that tune_parameters keeps -k 21
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 3, 3, L, seed=4, two_records=True)
+    out = os.path.join(tmp, "mst.out")
+    _run([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "1000", "-d", "0.05", "-t", "4", "-o", out], tmp)
+    folders = [d for d in os.listdir(tmp) if os.path.isdir(os.path.join(tmp, d)) and d[:2] == "20"]
+    assert len(folders) == 1
+    folder = os.path.join(tmp, folders[0])
+    # oracle on the same bytes (records of a file are separated, k-mers do not span them)
+    parts, off = [], [0]
+    for g, s in enumerate(seqs):
+        b = s.tobytes()
+        body = (b[:L // 3] + b"\n" + b[L // 3:]) if g % 2 else b
+        parts.append(np.frombuffer(body, dtype=np.uint8)); off.append(off[-1] + len(body))
+    want_sk = oracle.sketch_minhash_batch(np.concatenate(parts), np.array(off, dtype=np.uint64), 21, 1000)
+    hdr, got_sk = _read_hash_sketch(folder)
+    assert hdr == (0, 21, False, 1000)
+    assert len(got_sk) == len(want_sk) and all(np.array_equal(a, b) for a, b in zip(got_sk, want_sk))
+    flat, start, lens = oracle.to_csr(want_sk)
+    want_mst = oracle.mst(flat, start, lens, 21, 0, 0.05)
+    got_mst = _read_edges(folder)
+    assert np.array_equal(np.sort(got_mst["dist"]).view(np.uint64), np.sort(want_mst["dist"]).view(np.uint64))
+    want_cl = oracle.forest_clusters(want_mst, 0.05, len(seqs))
+    got_cl = _parse_clusters(out)
+    assert _partition(got_cl) == _partition(want_cl)
+    assert [c[0] for c in got_cl] == sorted(c[0] for c in got_cl)  # numbered by smallest member
+    text = open(out).read()
+    assert text.startswith("# Clustering threshold: 0.050000\n# Total clusters: %d\n#\n" % len(got_cl))
+    assert ("\t%5d\t%6d\t%12dnt\t%20s\t%20s\t%s\n" % (0, 0, L, paths[0], "g0", "synthetic family 0")) in text
+    # resume flows reproduce the same partition
+    out2, out3 = os.path.join(tmp, "mst2.out"), os.path.join(tmp, "mst3.out")
+    _run([os.path.join(BIN, "clust-mst"), "--presketched", folder, "-d", "0.05", "-o", out2], tmp)
+    _run([os.path.join(BIN, "clust-mst"), "--premsted", folder, "-d", "0.05", "-o", out3], tmp)
+    assert _partition(_parse_clusters(out2)) == _partition(got_cl) == _partition(_parse_clusters(out3))
+    assert open(out3).read() == text  # --premsted re-cuts the saved MST: identical text
+
+
+def test_clust_mst_fast_kssd_end_to_end(oracle, tmp_path):
+    tmp = str(tmp_path)
+    L = 2_000_000
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 2, 3, L, seed=5)
+    out = os.path.join(tmp, "kssd.out")
+    _run([os.path.join(BIN, "clust-mst"), "--fast", "-l", "-i", lst, "-k", "21", "-d", "0.05", "-t", "4", "-o", out], tmp)
+    want_sk = [oracle.kssd_sketch(s, 21, 3) for s in seqs]
+    folder = [os.path.join(tmp, d) for d in os.listdir(tmp) if os.path.isdir(os.path.join(tmp, d)) and d[:2] == "20"][0]
+    raw = open(os.path.join(folder, "kssd.hash.sketch"), "rb").read()
+    assert struct.unpack_from("<iiiii", raw, 0) == ((11 << 8) + (6 << 4) + 3, 11, 6, 3, len(seqs))
+    pos = 20
+    for w in want_sk:
+        (m,) = struct.unpack_from("<Q", raw, pos); pos += 8
+        assert np.array_equal(np.frombuffer(raw, dtype="<u4", count=m, offset=pos), w); pos += 4 * m
+    flat, start, lens = oracle.to_csr(want_sk, dtype=np.uint32)
+    want_mst = oracle.mst(flat, start, lens, 22, 0, 0.05)
+    assert _partition(_parse_clusters(out)) == _partition(oracle.forest_clusters(want_mst, 0.05, len(seqs)))
+    for f in ("kssd.info.sketch", "kssd.sketch.index", "kssd.sketch.dict", "kssd.info.mst", "edge.mst"):
+        assert os.path.exists(os.path.join(folder, f)), f
+
+
+def test_clust_greedy_default_containment_end_to_end(oracle, tmp_path):
+    tmp = str(tmp_path)
+    L = 2_000_000
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 3, 3, L, seed=6)
+    out = os.path.join(tmp, "greedy.out")
+    _run([os.path.join(BIN, "clust-greedy"), "-l", "-i", lst, "-k", "21", "-d", "0.05", "-t", "4", "-e", "-o", out], tmp)
+    sizes = [os.path.getsize(p) for p in paths]
+    compress = (sum(sizes) // len(sizes)) // 1000           # tune_parameters GREEDY default
+    cfg = np.array([max(s // compress, 100) for s in sizes], dtype=np.uint32)
+    off = np.arange(len(seqs) + 1, dtype=np.uint64) * L
+    sk = oracle.sketch_minhash_batch(np.concatenate(seqs), off, 21, cfg)
+    flat, start, lens = oracle.to_csr(sk)
+    ncl, rep = oracle.greedy_minhash(flat, start, lens, cfg, 21, True, 0.05)
+    got = _parse_clusters(out)
+    assert len(got) == ncl
+    want = {}
+    for i, r in enumerate(rep):
+        want.setdefault(int(r), []).append(i)
+    assert [c for c in got] == [[r] + [m for m in ms if m != r] for r, ms in sorted(want.items())]
+    assert not open(out).read().startswith("#")            # greedy output has no threshold header
+    assert not [d for d in os.listdir(tmp) if os.path.isdir(os.path.join(tmp, d)) and d[:2] == "20"]  # -e
+
+
+def test_gpu_sketches_match_committed_fixture(ctx):
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "sketch_fixture.npz"), allow_pickle=True)
+    from rabbittclust_amd import api
+    L = int(fx["L"])
+    desc = np.zeros(len(fx["descs"]), dtype=api.SYNTH_DT)
+    for i, (f, m, t, ne) in enumerate(fx["descs"]):
+        desc[i] = (int(f), int(m), int(t), int(ne))
+    off = np.arange(len(desc) + 1, dtype=np.uint64) * L
+    seq = ctx.synth_genomes(desc, off)
+    mh = ctx.sketch_minhash(seq, off, k=21, size=400).to_host()
+    assert all(np.array_equal(a, b) for a, b in zip(mh, fx["minhash"]))
+    import ctypes as C
+    host = C.CDLL(os.path.join(ROOT, "rabbittclust_amd", "librtclust_host.so"))
+    sd = np.zeros(1 << 24, dtype=np.int32)
+    host.rtch_shuffle_dim(6, sd.ctypes.data_as(C.c_void_p))
+    ks = ctx.sketch_kssd(seq, off, sd, kmer_size=21, drlevel=3).to_host()
+    assert all(np.array_equal(a, b) for a, b in zip(ks, fx["kssd"]))
+    sk = ctx.sketch_minhash(seq, off, k=21, size=400)
+    mst = ctx.mst(sk, 0.05)
+    assert np.array_equal(np.sort(mst["dist"]).view(np.uint64), np.sort(fx["mst"]["dist"]).view(np.uint64))
