@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("-s", type=int, default=1000)
     ap.add_argument("--threshold", type=float, default=0.05)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-genomes", type=int, default=16)
+    ap.add_argument("--cpu-sample-genomes", type=int, default=0, help="0 = max(16, host cores)")
     ap.add_argument("--cpu-sample-sketches", type=int, default=4000)
     return ap.parse_args()
 
@@ -49,7 +49,7 @@ def cpu_baseline(args, ctx, seq, off, sketches_host):
     """Oracle ("port") timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import pyoracle as O
     cores = os.cpu_count() or 1
-    ns = min(args.cpu_sample_genomes, len(off) - 1)
+    ns = min(args.cpu_sample_genomes or max(16, cores), len(off) - 1)
     L = int(off[1] - off[0])
     sub = seq[: ns * L].cpu().numpy()
     suboff = np.ascontiguousarray(off[: ns + 1])

@@ -256,8 +256,7 @@ int rtc_mst(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_sta
   // ---- all-pairs in row chunks -> compacted candidate edges ----
   const uint64_t budget = 2ull << 30;  // bytes of dense common matrix resident at a time
   uint32_t rows_per = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(n, budget / ((uint64_t)n * 4)));
-  rows_per = (rows_per / 64) * 64;
-  if (rows_per == 0) rows_per = 64;
+  rows_per = ((rows_per + 63) / 64) * 64;
   uint32_t* d_common = nullptr;
   RTC_TRY(rtc_ws(ctx, 2, (size_t)rows_per * n * 4, (void**)&d_common));
   uint64_t cap = std::max<uint64_t>(1u << 20, (uint64_t)n * 16);

@@ -241,6 +241,39 @@ __global__ void max_slice_kernel(const uint32_t* __restrict__ so, int P, uint32_
   if ((threadIdx.x & 63) == 0 && v) atomicMax(out_max, v);
 }
 
+// planning inputs in one launch: sum / max of the sketch lengths and SAMPLE_PER evenly spaced
+// hashes from each of up to SAMPLE_SK evenly spaced sketches (quantiles -> partition bounds)
+constexpr int SAMPLE_SK = 64;
+constexpr int SAMPLE_PER = 256;
+struct PlanStats { unsigned long long total; uint32_t lmax; uint32_t pad; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void plan_stats_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
+                                                         const uint32_t* __restrict__ len, uint32_t n,
+                                                         PlanStats* __restrict__ stats, T* __restrict__ samples,
+                                                         uint32_t* __restrict__ nsamples) {
+  unsigned long long sum = 0; uint32_t mx = 0;
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) { sum += len[g]; mx = max(mx, len[g]); }
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_xor((unsigned long long)sum, o);
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+  }
+  if ((threadIdx.x & 63) == 0) { if (sum) atomicAdd(&stats->total, sum); if (mx) atomicMax(&stats->lmax, mx); }
+  if (blockIdx.x == 0) {  // every thread derives the same running offset from len[], no atomics needed
+    const uint32_t ns = min(n, (uint32_t)SAMPLE_SK);
+    uint32_t base = 0;
+    for (uint32_t i = 0; i < ns; i++) {
+      const uint32_t g = (uint32_t)((uint64_t)i * n / ns);
+      const uint32_t L = len[g];
+      const uint32_t take = min(L, (uint32_t)SAMPLE_PER);
+      for (uint32_t t = threadIdx.x; t < take; t += blockDim.x)
+        samples[base + t] = hashes[start[g] + (uint64_t)t * L / take];
+      base += take;
+    }
+    if (threadIdx.x == 0) *nsamples = base;
+  }
+}
+
 template <typename T, int NPL>
 int launch_tiled(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const uint32_t* d_so, int P, uint32_t n,
                  uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld,
@@ -260,36 +293,33 @@ int tiled_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
                uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld,
                int lower_only, int* handled) {
   *handled = 0;
-  // ---- host view of the sketch geometry ----
-  std::vector<uint64_t> h_start(n);
-  std::vector<uint32_t> h_len(n);
-  RTC_HIP(ctx, hipMemcpyAsync(h_start.data(), d_start, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  RTC_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  // ---- planning inputs: one kernel, one small read-back ----
+  void* wsp = nullptr;
+  const size_t bsamp = (size_t)SAMPLE_SK * SAMPLE_PER * sizeof(T);
+  RTC_TRY(rtc_ws(ctx, 0, sizeof(PlanStats) + 8 + bsamp + 64, &wsp));
+  PlanStats* d_stats = (PlanStats*)wsp;
+  uint32_t* d_ns = (uint32_t*)((char*)wsp + sizeof(PlanStats));
+  T* d_samples = (T*)((char*)wsp + sizeof(PlanStats) + 8);
+  RTC_HIP(ctx, hipMemsetAsync(wsp, 0, sizeof(PlanStats) + 8, ctx->stream));
+  hipLaunchKernelGGL(plan_stats_kernel<T>, dim3(std::min<uint32_t>((n + 255) / 256, 256)), dim3(256), 0, ctx->stream,
+                     d_hashes, d_start, d_len, n, d_stats, d_samples, d_ns);
+  RTC_CHECK_LAUNCH(ctx);
+  void* hpin = nullptr;
+  RTC_TRY(rtc_pinned(ctx, sizeof(PlanStats) + 8 + bsamp + 64 + (size_t)(MAXP + 1) * sizeof(T), &hpin));
+  RTC_HIP(ctx, hipMemcpyAsync(hpin, wsp, sizeof(PlanStats) + 8 + bsamp, hipMemcpyDeviceToHost, ctx->stream));
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  uint64_t tot = 0;
-  uint32_t lmax = 0;
-  for (uint32_t g = 0; g < n; g++) { tot += h_len[g]; lmax = std::max(lmax, h_len[g]); }
-  if (tot == 0 || lmax >= (1u << 20)) return RTC_OK;  // nothing to gain / counters too wide: merge path
+  const PlanStats hst = *(const PlanStats*)hpin;
+  const uint32_t nsamp = *(const uint32_t*)((const char*)hpin + sizeof(PlanStats));
+  const uint64_t tot = hst.total;
+  const uint32_t lmax = hst.lmax;
+  if (tot == 0 || lmax >= (1u << 20) || nsamp == 0) return RTC_OK;  // nothing to gain / counters too wide: merge path
   const double avg = (double)tot / n;
   int P = 1;
   while (P < MAXP && (double)ROWS * avg / P > KTARGET) P <<= 1;
-
-  // ---- partition boundaries = quantiles of a sample of up to 64 sketches ----
-  std::vector<T> sample;
-  {
-    const uint32_t ns = std::min<uint32_t>(n, 64);
-    std::vector<T> tmp;
-    for (uint32_t i = 0; i < ns; i++) {
-      const uint32_t g = (uint32_t)((uint64_t)i * n / ns);
-      if (!h_len[g]) continue;
-      tmp.resize(h_len[g]);
-      RTC_HIP(ctx, hipMemcpyAsync(tmp.data(), d_hashes + h_start[g], (size_t)h_len[g] * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-      RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      sample.insert(sample.end(), tmp.begin(), tmp.end());
-    }
-    std::sort(sample.begin(), sample.end());
-  }
-  if (sample.empty()) return RTC_OK;
+  std::vector<T> sample((const T*)((const char*)hpin + sizeof(PlanStats) + 8),
+                        (const T*)((const char*)hpin + sizeof(PlanStats) + 8) + nsamp);
+  std::sort(sample.begin(), sample.end());
+  T* h_bounds_pin = (T*)((char*)hpin + sizeof(PlanStats) + 8 + bsamp + 64 - ((sizeof(PlanStats) + 8 + bsamp + 64) % 8));
 
   for (int attempt = 0; attempt < 3; attempt++) {
     std::vector<T> bounds(P + 1);
@@ -303,10 +333,8 @@ int tiled_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
     uint32_t* d_so = (uint32_t*)ws;
     T* d_bounds = (T*)((char*)ws + bso);
     uint32_t* d_max = (uint32_t*)((char*)ws + bso + bb + (8 - bb % 8) % 8);
-    void* hp = nullptr;
-    RTC_TRY(rtc_pinned(ctx, bb + 64, &hp));
-    memcpy(hp, bounds.data(), bb);
-    RTC_HIP(ctx, hipMemcpyAsync(d_bounds, hp, bb, hipMemcpyHostToDevice, ctx->stream));
+    memcpy(h_bounds_pin, bounds.data(), bb);
+    RTC_HIP(ctx, hipMemcpyAsync(d_bounds, h_bounds_pin, bb, hipMemcpyHostToDevice, ctx->stream));
     RTC_HIP(ctx, hipMemsetAsync(d_max, 0, 4, ctx->stream));
     const uint64_t work = (uint64_t)n * (P + 1);
     hipLaunchKernelGGL(slice_offsets_kernel<T>, dim3((uint32_t)((work + 255) / 256)), dim3(256), 0, ctx->stream,

@@ -125,7 +125,7 @@ class MstPipeline:
         if self._edges is None or self._edges.shape[0] < self._edge_cap:
             self._edges = torch.empty((self._edge_cap, 3), dtype=torch.int32, device=ctx.device)
         rows_per = max(64, min(max(row1 - row0, 1), self.row_chunk_bytes // (max(n, 1) * 4)))
-        rows_per = max(64, (rows_per // 64) * 64)
+        rows_per = ((rows_per + 63) // 64) * 64  # whole 64-row blocks, one launch when it fits
         m = 0
         r0 = max(row0, 1)
         common = None
