@@ -28,6 +28,19 @@ from rabbittclust_amd import pipeline  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def measured_traffic(kernel, args):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    profiles/r01_pmc_traffic.json), valid only for the workload they were collected on."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        w = prof["workload"]
+        if (w["genomes"], w["length"], w["k"], w["s"]) != (args.genomes, args.length, args.k, args.s):
+            return None
+        return prof["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,7 +93,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("RTC_FORCE_DIST") == "1":  # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
@@ -146,11 +159,13 @@ def main():
             "mst_edges": int(phases[-1]["mst_edges"]),
             "roofline": {"bound": "hbm", "kernel": "sketch_minhash_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "note": "algorithmic bytes = 1 B/base + 8 B/hash out; kernel is integer-ALU bound "
-                                 "(10 64-bit multiplies per k-mer), see DESIGN.md"},
+                         "traffic": measured_traffic("sketch_minhash_kernel", args),
+                         "note": "algorithmic bytes = 1 B/base + 8 B/hash out per launch; traffic = rocprofv3 PMC "
+                                 "bytes per launch (profiles/r01_pmc_traffic.json); the kernel is integer-VALU-issue "
+                                 "bound (~125 VALU instructions per k-mer), see DESIGN.md 3.1"},
             "roofline_dist": {"bound": "hbm", "kernel": "pair kernel", "achieved": dist_ach, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": dist_ach / HBM_PEAK_GBS, "traffic": None,
+                              "unit": "GB/s", "frac": dist_ach / HBM_PEAK_GBS,
+                              "traffic": measured_traffic("pair_tiled_kernel", args),
                               "note": "algorithmic bytes = (|A|+|B|)*8 = 16000 B/pair; tiles are reused from "
                                       "LDS/L2 so this may exceed 1"},
         }

@@ -23,9 +23,8 @@ namespace {
 constexpr int WG = 512;                               // lanes per workgroup (8 waves)
 constexpr int NWAVE = WG / 64;
 constexpr int RUN_DW = 15;                            // dwords of owned bases per lane per tile
-constexpr int WARM_DW = 8;                            // 32 warm-up bases (k-1 <= 31)
+constexpr int WARM_DW = 9;                            // 36 warm-up bases (k-1 <= 31); 9+15 dwords = six 16-byte loads
 constexpr int TILE_BASES = WG * RUN_DW * 4;           // bases per tile
-constexpr int TILE_DW = WG * RUN_DW + WARM_DW;        // dwords of the tile in LDS
 constexpr int STEP_APPENDS = WG * 4;                  // worst-case appends per dword iteration
 constexpr int MIN_ROOM = STEP_APPENDS;                // candidate room the buffer always offers
 constexpr uint64_t SENT = ~0ULL;
@@ -160,7 +159,7 @@ __device__ void bitonic_sort_lds(uint64_t* buf, int cap) {
 
 // On entry: buf[0..ctrl->count) holds candidates (unsorted, duplicates allowed), all threads
 // arrive.  On exit: buf[0..count) ascending distinct, count <= s, ctrl->T updated.
-__device__ void merge_block(uint64_t* buf, Ctrl* ctrl, int cap, uint32_t s) {
+__device__ __noinline__ uint32_t merge_block(uint64_t* buf, Ctrl* ctrl, int cap, uint32_t s, uint64_t& T_out) {
   const int t = threadIdx.x;
   __syncthreads();
   const uint32_t n = ctrl->count < (uint32_t)cap ? ctrl->count : (uint32_t)cap;
@@ -195,18 +194,43 @@ __device__ void merge_block(uint64_t* buf, Ctrl* ctrl, int cap, uint32_t s) {
     if (t == 0) ctrl->scan_base = sb + total;  // read again only after the next barrier
   }
   __syncthreads();
-  if (t == 0) {
-    uint32_t c = ctrl->scan_base < s ? ctrl->scan_base : s;
-    ctrl->count = c;
-    ctrl->T = (c == s && s > 0) ? buf[s - 1] : SENT;
-    ctrl->overflow = 0;
-  }
+  // every thread derives the result itself (no read after the closing barrier: a fast thread may
+  // already be appending again by then)
+  const uint32_t sbv = ctrl->scan_base;
+  const uint32_t c = sbv < s ? sbv : s;
+  const uint64_t newT = (c == s && s > 0) ? buf[s - 1] : SENT;
   __syncthreads();
+  if (t == 0) { ctrl->count = c; ctrl->T = newT; ctrl->overflow = 0; }
+  __syncthreads();
+  T_out = newT;
+  return c;
 }
 
-// ---- the sketch kernel ---------------------------------------------------------------------------
+// One lane's view of a tile: 96 consecutive bases = 36 warm-up + 60 owned k-mer end positions,
+// fetched straight from global memory as six 16-byte loads (no LDS staging: the 30 KiB tile would
+// cost a third of the occupancy, and each line is still read from HBM once -- neighbouring lanes
+// share lines through L2).
+__device__ __forceinline__ uint4 load_bases16(const uint8_t* __restrict__ seq, int64_t q, uint64_t g_begin,
+                                              uint64_t g_end) {
+  if (q >= (int64_t)g_begin && q + 16 <= (int64_t)g_end) return *reinterpret_cast<const uint4*>(seq + q);
+  uint32_t ww[4];
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    uint32_t x = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int64_t p = q + 4 * d + b;
+      const uint32_t ch = (p >= (int64_t)g_begin && p < (int64_t)g_end) ? seq[p] : (uint32_t)'N';
+      x |= ch << (8 * b);
+    }
+    ww[d] = x;
+  }
+  return make_uint4(ww[0], ww[1], ww[2], ww[3]);
+}
+
 template <int KT>  // KT > 0: k known at compile time (uniform branches fold away); 0: runtime k
-__global__ __launch_bounds__(WG) void sketch_minhash_kernel(const uint8_t* __restrict__ seq,
+// second launch bound: 6 waves/SIMD = 3 workgroups per CU (caps the allocation at 80 VGPRs)
+__global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __restrict__ seq,
                                                             const Segment* __restrict__ segs,
                                                             int k_arg, uint32_t seed, int cap,
                                                             uint64_t* __restrict__ out,
@@ -214,8 +238,7 @@ __global__ __launch_bounds__(WG) void sketch_minhash_kernel(const uint8_t* __res
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
   uint64_t* lut = reinterpret_cast<uint64_t*>(smem + (size_t)cap * 8);
-  uint32_t* tile = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 8 + LUT_BYTES);
-  Ctrl* ctrl = reinterpret_cast<Ctrl*>(smem + (size_t)cap * 8 + LUT_BYTES + (size_t)TILE_DW * 4);
+  Ctrl* ctrl = reinterpret_cast<Ctrl*>(smem + (size_t)cap * 8 + LUT_BYTES);
 
   const Segment sg = segs[blockIdx.x];
   const int k = KT > 0 ? KT : k_arg;
@@ -223,6 +246,7 @@ __global__ __launch_bounds__(WG) void sketch_minhash_kernel(const uint8_t* __res
   const int t = threadIdx.x;
   const uint32_t lane = t & 63;
   const uint32_t s = sg.sketch_size;
+  const bool fastroll = k <= 28;  // 2k+8 bits fit the 64-bit extended window
 
   if (t == 0) { ctrl->T = SENT; ctrl->count = 0; ctrl->overflow = 0; ctrl->saw_max = 0; ctrl->scan_base = 0; }
   build_kmer_lut(lut, k);
@@ -232,64 +256,75 @@ __global__ __launch_bounds__(WG) void sketch_minhash_kernel(const uint8_t* __res
   bool safe_mode = true;
   const uint32_t room = (uint32_t)cap - s;  // >= MIN_ROOM by construction
 
+  uint32_t count_at_tile_start = 0;  // carried in registers: identical in every thread
   for (uint64_t T0 = sg.s_begin & ~15ULL; T0 < sg.s_end && s > 0; T0 += TILE_BASES) {
-    // ---- stage the tile: positions [T0-32, T0+TILE_BASES) ----
-    for (int c = t; c < TILE_DW / 4; c += WG) {
-      const int64_t q = (int64_t)T0 - 32 + 16 * (int64_t)c;
-      uint4 v;
-      if (q >= (int64_t)sg.g_begin && q + 16 <= (int64_t)sg.g_end) {
-        v = *reinterpret_cast<const uint4*>(seq + q);
-      } else {
-        uint32_t ww[4];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          uint32_t x = 0;
-#pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const int64_t p = q + 4 * d + b;
-            const uint32_t ch = (p >= (int64_t)sg.g_begin && p < (int64_t)sg.g_end) ? seq[p] : (uint32_t)'N';
-            x |= ch << (8 * b);
-          }
-          ww[d] = x;
-        }
-        v = make_uint4(ww[0], ww[1], ww[2], ww[3]);
-      }
-      *reinterpret_cast<uint4*>(tile + 4 * c) = v;
-    }
-    __syncthreads();
-
-    const uint32_t count_at_tile_start = ctrl->count;
     // owned positions of this lane relative to T0: [60t, 60t+60); hash window limits
     const int64_t lo64 = (int64_t)sg.s_begin - (int64_t)T0;
     const int64_t hi64 = (int64_t)sg.s_end - (int64_t)T0;
     const int rel_lo = lo64 < 0 ? 0 : (int)lo64;
     const int rel_hi = hi64 > TILE_BASES ? TILE_BASES : (int)hi64;
+    const int64_t p0 = (int64_t)T0 + 60 * t - 4 * WARM_DW;  // first base of this lane's window
 
     bool redo;
     do {
       redo = false;
       uint64_t fwd = 0, rc = 0;
       int run = 0;
-      int d = 0;
-      int d_stop = safe_mode ? WARM_DW : (WARM_DW + RUN_DW);
-      while (true) {
-        for (; d < d_stop; d++) {
-          const uint32_t wv = tile[t * RUN_DW + d];
-          const bool hashing = d >= WARM_DW;
+      uint4 nxt = load_bases16(seq, p0, sg.g_begin, sg.g_end);
+      for (int grp = 0; grp < (WARM_DW + RUN_DW) / 4; grp++) {
+        const uint4 cur = nxt;
+        if (grp + 1 < (WARM_DW + RUN_DW) / 4) nxt = load_bases16(seq, p0 + 16 * (grp + 1), sg.g_begin, sg.g_end);
+        const uint32_t wv4[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+          const int d = grp * 4 + qd;
+          const uint32_t wv = wv4[qd];
+          const bool hashing = d >= WARM_DW;  // wave-uniform
           const int rel0 = 60 * t + 4 * (d - WARM_DW);
+          if (safe_mode && hashing) {
+            // bound the next dword's appends so the buffer cannot overflow
+            __syncthreads();
+            const uint32_t cn = ctrl->count;
+            if ((uint32_t)cap - cn < (uint32_t)STEP_APPENDS) merge_block(buf, ctrl, cap, s, T);
+            __syncthreads();
+          }
           uint64_t canon[4];
           bool ok[4];
+          bool allok = false;  // wave-uniform: all four k-mers of every lane are valid and owned
+          // ---- decode four bases at once ----
+          const uint32_t up = wv & 0xDFDFDFDFu;
+          const uint32_t codes4 = ((wv >> 1) ^ (wv >> 2)) & 0x03030303u;  // A,C,G,T (either case) -> 0..3 per byte
+          const bool allvalid = __builtin_amdgcn_perm(0u, 0x54474341u, codes4) == up;
+          if (fastroll && __all(allvalid)) {
+            // pack = c0<<6|c1<<4|c2<<2|c3 ; rp = complement codes in reverse significance
+            const uint32_t pack = (codes4 * 0x40100401u) >> 24;
+            const uint32_t rp = ((codes4 * 0x01041040u) >> 24) ^ 0xffu;
+            const uint64_t F = (fwd << 8) | pack;
+            const uint64_t R = rc | ((uint64_t)rp << (2 * P.k));
+            allok = __all(run + 1 >= P.k && rel0 >= rel_lo && rel0 + 3 < rel_hi);
 #pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const uint32_t c = (wv >> (8 * b)) & 0xffu;
-            const uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;  // A,C,G,T (either case) -> 0,1,2,3
-            const bool valid = ((c & 0xC0u) == 0x40u) && ((0x0010008Au >> (c & 31u)) & 1u);
-            fwd = ((fwd << 2) | code) & P.kmask;
-            rc = (rc >> 2) | ((uint64_t)(code ^ 3u) << P.rc_shift);
-            run = valid ? run + 1 : 0;
-            const int rel = rel0 + b;
-            ok[b] = run >= P.k && rel >= rel_lo && rel < rel_hi;
-            canon[b] = fwd < rc ? fwd : rc;
+            for (int b = 0; b < 4; b++) {
+              const uint64_t f = (F >> (6 - 2 * b)) & P.kmask;
+              const uint64_t r = (R >> (2 * b + 2)) & P.kmask;
+              const int rel = rel0 + b;
+              ok[b] = allok || (run + b + 1 >= P.k && rel >= rel_lo && rel < rel_hi);
+              canon[b] = f < r ? f : r;
+              if (b == 3) { fwd = f; rc = r; }
+            }
+            run += 4;
+          } else {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+              const uint32_t c = (wv >> (8 * b)) & 0xffu;
+              const uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;
+              const bool valid = ((c & 0xC0u) == 0x40u) && ((0x0010008Au >> (c & 31u)) & 1u);
+              fwd = ((fwd << 2) | code) & P.kmask;
+              rc = (rc >> 2) | ((uint64_t)(code ^ 3u) << P.rc_shift);
+              run = valid ? run + 1 : 0;
+              const int rel = rel0 + b;
+              ok[b] = run >= P.k && rel >= rel_lo && rel < rel_hi;
+              canon[b] = fwd < rc ? fwd : rc;
+            }
           }
           if (hashing) {  // wave-uniform
             // four independent hash chains: their LDS table reads and multiplies overlap
@@ -298,11 +333,16 @@ __global__ __launch_bounds__(WG) void sketch_minhash_kernel(const uint8_t* __res
             for (int b = 0; b < 4; b++) h[b] = kmer_hash(canon[b], P, lut);
             bool pass[4];
             bool anyp = false;
+            if (allok && T != SENT) {  // the steady state: one 64-bit compare per k-mer
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-              // T == SENT means "sketch not full yet": everything passes (also a hash == SENT)
-              pass[b] = ok[b] && (h[b] < T || T == SENT);
-              anyp |= pass[b];
+              for (int b = 0; b < 4; b++) { pass[b] = h[b] < T; anyp |= pass[b]; }
+            } else {
+#pragma unroll
+              for (int b = 0; b < 4; b++) {
+                // T == SENT means "sketch not full yet": everything passes (also a hash == SENT)
+                pass[b] = ok[b] && (h[b] < T || T == SENT);
+                anyp |= pass[b];
+              }
             }
             if (__any(anyp)) {
 #pragma unroll
@@ -322,26 +362,12 @@ __global__ __launch_bounds__(WG) void sketch_minhash_kernel(const uint8_t* __res
             }
           }
         }
-        if (d >= WARM_DW + RUN_DW) break;
-        // safe mode: bound the next chunk so the buffer cannot overflow
-        __syncthreads();
-        uint32_t cn = ctrl->count;
-        if ((uint32_t)cap - cn < (uint32_t)STEP_APPENDS) {
-          merge_block(buf, ctrl, cap, s);
-          T = ctrl->T;
-          cn = ctrl->count;
-        }
-        int chunk = (int)(((uint32_t)cap - cn) / (uint32_t)STEP_APPENDS);
-        d_stop = d + chunk;
-        if (d_stop > WARM_DW + RUN_DW) d_stop = WARM_DW + RUN_DW;
-        __syncthreads();  // everyone has read count before anyone appends again
       }
       __syncthreads();
       if (ctrl->overflow) {
         // optimistic pass lost candidates: fold what we have, then redo this tile safely
         // (count may exceed cap: clamp happens inside merge_block)
-        merge_block(buf, ctrl, cap, s);
-        T = ctrl->T;
+        count_at_tile_start = merge_block(buf, ctrl, cap, s, T);
         safe_mode = true;
         redo = true;
       }
@@ -352,16 +378,12 @@ __global__ __launch_bounds__(WG) void sketch_minhash_kernel(const uint8_t* __res
     const uint32_t appended = cn - (count_at_tile_start < cn ? count_at_tile_start : cn);
     const bool need_merge = cn > s + room / 2;
     safe_mode = appended > room / 4;
-    __syncthreads();  // all reads of ctrl->count / tile done before merge or next staging
-    if (need_merge) {
-      merge_block(buf, ctrl, cap, s);
-      T = ctrl->T;
-    }
+    __syncthreads();  // all reads of ctrl->count done before merge or the next tile's appends
+    count_at_tile_start = need_merge ? merge_block(buf, ctrl, cap, s, T) : cn;
   }
 
   // ---- final fold and write-out ----
-  merge_block(buf, ctrl, cap, s);
-  uint32_t n = ctrl->count;
+  uint32_t n = merge_block(buf, ctrl, cap, s, T);
   uint64_t* o = out + sg.out_off;
   for (uint32_t i = t; i < n; i += WG) o[i] = buf[i];
   if (t == 0) {
@@ -395,10 +417,11 @@ __global__ __launch_bounds__(WG) void merge_partials_kernel(const MergeJob* __re
   const uint32_t s = jb.sketch_size;
   if (t == 0) { ctrl->T = SENT; ctrl->count = 0; ctrl->overflow = 0; ctrl->saw_max = 0; ctrl->scan_base = 0; }
   __syncthreads();
+  uint32_t nmerged = 0;
   for (uint32_t p = 0; p < jb.nparts; p++) {
     const uint32_t pc = pcnt[jb.part_cnt0 + p];
     const uint64_t* src = parts + jb.part_off + (uint64_t)p * jb.stride;
-    const uint32_t base = ctrl->count;
+    const uint32_t base = nmerged;
     __syncthreads();
     for (uint32_t i = t; i < pc; i += WG) {
       uint64_t v = src[i];
@@ -407,9 +430,10 @@ __global__ __launch_bounds__(WG) void merge_partials_kernel(const MergeJob* __re
     }
     __syncthreads();
     if (t == 0) ctrl->count = base + pc;
-    merge_block(buf, ctrl, cap, s);
+    uint64_t Tm;
+    nmerged = merge_block(buf, ctrl, cap, s, Tm);
   }
-  uint32_t n = ctrl->count;
+  uint32_t n = nmerged;
   uint64_t* o = out + jb.out_off;
   for (uint32_t i = t; i < n; i += WG) o[i] = buf[i];
   if (t == 0) {
@@ -441,7 +465,7 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   // candidate buffer of the sketch kernel: s + room; of the partial-merge kernel: two s-lists
   const int cap = pow2ceil((int)(smax + MIN_ROOM));
   const int cap_merge = pow2ceil((int)std::max<uint32_t>(2 * smax, 1024));
-  const size_t lds = (size_t)cap * 8 + LUT_BYTES + (size_t)TILE_DW * 4 + sizeof(Ctrl);
+  const size_t lds = (size_t)cap * 8 + LUT_BYTES + sizeof(Ctrl);
   const size_t lds_m = (size_t)cap_merge * 8 + sizeof(Ctrl);
   if (lds > (size_t)160 * 1024 || lds_m > (size_t)160 * 1024)
     return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "sketch size %u needs %zu B of LDS (> 160 KiB); the GPU path takes sizes up to 6144", smax, std::max(lds, lds_m));

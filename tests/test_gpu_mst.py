@@ -105,3 +105,22 @@ def test_pipeline_step_single_gpu(ctx, oracle):
     got = pipe.last_mst
     assert stats["mst_edges"] == len(want)
     assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
+
+
+def test_bench_rccl_path_single_rank(tmp_path):
+    """bench.py under torch.distributed.run with one rank and RTC_FORCE_DIST=1: the all-gather and
+    the per-round all-reduces go through RCCL (backend "nccl") exactly as in the multi-GPU run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RTC_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29611", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1",
+           "--warmup", "1", "--genomes", "200", "--length", "200000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["mst_edges"] > 0 and line["value"] > 0
+    assert line["roofline"]["frac"] > 0 and line["scaling"] == "weak"
