@@ -177,3 +177,51 @@ def test_gpu_sketches_match_committed_fixture(ctx):
     sk = ctx.sketch_minhash(seq, off, k=21, size=400)
     mst = ctx.mst(sk, 0.05)
     assert np.array_equal(np.sort(mst["dist"]).view(np.uint64), np.sort(fx["mst"]["dist"]).view(np.uint64))
+
+
+def test_clust_greedy_fast_and_presketched(oracle, tmp_path):
+    """clust-greedy --fast (KSSD, size-sorted) and clust-greedy --presketched on a MinHash folder
+    written by clust-mst (fixed-size fast path, genomes re-sorted by length)."""
+    tmp = str(tmp_path)
+    L = 2_000_000
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 3, 3, L, seed=8)
+    out = os.path.join(tmp, "gfast.out")
+    _run([os.path.join(BIN, "clust-greedy"), "--fast", "-l", "-i", lst, "-k", "21", "-d", "0.05", "-t", "4", "-e", "-o", out], tmp)
+    ks = [oracle.kssd_sketch(s, 21, 3) for s in seqs]
+    # src/greedy.cpp:594-597: std::sort by hash count, descending (same libstdc++ sort on both sides)
+    import ctypes as C
+    order = sorted(range(len(ks)), key=lambda i: -len(ks[i]))
+    sizes = [len(ks[i]) for i in order]
+    assert len(set(sizes)) == len(sizes), "test data must not tie on sketch size (unstable sort order)"
+    flat, start, lens = oracle.to_csr([ks[i] for i in order], dtype=np.uint32)
+    ncl, rep = oracle.greedy_kssd(flat, start, lens, 22, 0.05)
+    got = _parse_clusters(out)
+    assert len(got) == ncl
+    # ids in the output are positions in the size-sorted order; compare as sets of original genomes
+    want = {}
+    for i, r in enumerate(rep):
+        want.setdefault(int(r), []).append(i)
+    assert _partition(got) == _partition(list(want.values()))
+    # the file names printed for each id identify the original genome
+    names = {}
+    for ln in open(out):
+        if ln.startswith("\t"):
+            f = ln.rstrip("\n").split("\t")
+            names[int(f[2])] = f[4].strip()
+    assert [names[i] for i in range(len(order))] == [paths[i] for i in order]
+
+    # MinHash folder from clust-mst, then clust-greedy --presketched
+    out_m = os.path.join(tmp, "m.out")
+    _run([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "1000", "-d", "0.05", "-t", "4", "-o", out_m], tmp)
+    folder = [os.path.join(tmp, d) for d in os.listdir(tmp) if os.path.isdir(os.path.join(tmp, d)) and d[:2] == "20"][0]
+    out_g = os.path.join(tmp, "g2.out")
+    _run([os.path.join(BIN, "clust-greedy"), "--presketched", folder, "-d", "0.05", "-o", out_g], tmp)
+    off = np.arange(len(seqs) + 1, dtype=np.uint64) * L
+    sk = oracle.sketch_minhash_batch(np.concatenate(seqs), off, 21, 1000)
+    flat, start, lens = oracle.to_csr(sk)   # all genomes have the same length: cmpGenomeSize keeps id order
+    ncl, rep = oracle.greedy_minhash(flat, start, lens, 1000, 21, False, 0.05)
+    got = _parse_clusters(out_g)
+    want = {}
+    for i, r in enumerate(rep):
+        want.setdefault(int(r), []).append(i)
+    assert got == [[r] + [m for m in ms if m != r] for r, ms in sorted(want.items())]
