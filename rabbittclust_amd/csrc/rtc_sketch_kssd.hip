@@ -7,10 +7,11 @@
 //
 // The reference probes a phmap of the kept (dim_id -> rank) pairs per k-mer.  Here the kept set
 // (dim_end of 2^(4*half_subk) ids; 4096 of 16 Mi at the default drlevel 3) is compiled on the
-// host into a two-level exact index -- 4096 buckets on the top 12 bits of dim_id, each a short
-// list of (low bits, rank) -- that lives in 24 KiB of LDS, so the filter costs a couple of
-// ds_reads instead of a random HBM access.  Configurations that keep more than 8192 ids
-// (drlevel <= 2) fall back to a table lookup in HBM.  Survivors are appended to the genome's
+// host into a two-table cuckoo index in 64 KiB of LDS: table 1 is addressed by the low 13 bits of
+// dim_id and stores the remaining high bits + rank, table 2 is addressed by the high 13 bits and
+// stores the low bits + rank.  A lookup is two ds_read_b32 and a few compares, no loop, exact.
+// Configurations that keep more than 8192 ids (drlevel <= 2), or a kept set the cuckoo build cannot
+// place, fall back to a table lookup in HBM.  Survivors are appended to the genome's
 // output row with wave-aggregated atomics; kssd_sort_unique_kernel then sorts and deduplicates
 // each row in LDS.
 #include <algorithm>
@@ -22,11 +23,10 @@ namespace {
 
 constexpr int WG = 512;
 constexpr int RUN_DW = 15;
-constexpr int WARM_DW = 8;
+constexpr int WARM_DW = 9;   // 36 warm-up bases; 9 + 15 dwords = six 16-byte loads per lane and tile
 constexpr int TILE_BASES = WG * RUN_DW * 4;
-constexpr int TILE_DW = WG * RUN_DW + WARM_DW;
-constexpr int NBUCKET = 4096;
 constexpr int MAX_LDS_KEEP = 8192;
+constexpr uint32_t CK_EMPTY = 0xFFFFFFFFu;
 
 struct KSegment {
   uint64_t g_begin, g_end;
@@ -42,111 +42,151 @@ struct KssdParams {
   int rev_add_move;  // 4*half_k - 2
   int dim_shift;     // 2*half_outctx_len
   int und1_shl;      // 2K - 4*half_outctx_len
-  int lobits;        // 4*half_subk - 12
+  int dimbits;       // 4*half_subk (24 or 28)
+  int ck1, ck2;      // log2 slots of cuckoo table 1 (low bits of dim_id) / table 2 (high bits)
   int dim_end;
   uint64_t tupmask, domask, undomask0, undomask1;
 };
 
+__device__ __forceinline__ uint4 load_bases16(const uint8_t* __restrict__ seq, int64_t q, uint64_t g_begin,
+                                              uint64_t g_end) {
+  if (q >= (int64_t)g_begin && q + 16 <= (int64_t)g_end) return *reinterpret_cast<const uint4*>(seq + q);
+  uint32_t ww[4];
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    uint32_t x = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int64_t p = q + 4 * d + b;
+      const uint32_t ch = (p >= (int64_t)g_begin && p < (int64_t)g_end) ? seq[p] : (uint32_t)'N';
+      x |= ch << (8 * b);
+    }
+    ww[d] = x;
+  }
+  return make_uint4(ww[0], ww[1], ww[2], ww[3]);
+}
+
+// Each lane walks 96 consecutive bases per tile (36 warm-up + 60 owned k-mer end positions) read
+// straight from global memory as six 16-byte loads; four bases are decoded at once (SWAR) and the
+// four k-mers of a dword are filtered back to back.
 template <typename OutT, bool LDS_INDEX>
 __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restrict__ seq,
                                                          const KSegment* __restrict__ segs, KssdParams P,
-                                                         const uint16_t* __restrict__ g_off,   // [NBUCKET+1]
-                                                         const uint32_t* __restrict__ g_ent,   // [dim_end]
+                                                         const uint32_t* __restrict__ g_t1,    // cuckoo table 1 [1 << ck1]
+                                                         const uint32_t* __restrict__ g_t2,    // cuckoo table 2 [1 << ck2]
                                                          const int32_t* __restrict__ g_table,  // full table (HBM path)
                                                          OutT* __restrict__ out, uint32_t stride,
                                                          uint32_t* __restrict__ cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* tile = reinterpret_cast<uint32_t*>(smem);
-  uint16_t* l_off = reinterpret_cast<uint16_t*>(smem + (size_t)TILE_DW * 4);
-  uint32_t* l_ent = reinterpret_cast<uint32_t*>(smem + (size_t)TILE_DW * 4 + (NBUCKET + 2) * 2);
+  uint32_t* l_t1 = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* l_t2 = l_t1 + (1u << P.ck1);
 
   const KSegment sg = segs[blockIdx.x];
   const int t = threadIdx.x;
   const uint32_t lane = t & 63;
   if (LDS_INDEX) {
-    for (int i = t; i < NBUCKET + 1; i += WG) l_off[i] = g_off[i];
-    for (int i = t; i < P.dim_end; i += WG) l_ent[i] = g_ent[i];
+    for (int i = t; i < (1 << P.ck1); i += WG) l_t1[i] = g_t1[i];
+    for (int i = t; i < (1 << P.ck2); i += WG) l_t2[i] = g_t2[i];
+    __syncthreads();
   }
   OutT* orow = out + (uint64_t)sg.genome * stride;
   uint32_t* ocnt = cnt + sg.genome;
+  const bool fastroll = P.K <= 28;  // 2K+8 bits fit the 64-bit extended window
+  const int hishift = P.dimbits - P.ck2;  // table 2 is addressed by the high ck2 bits
+  const uint32_t m1mask = (1u << P.ck1) - 1u, m2mask = (1u << hishift) - 1u;
 
   for (uint64_t T0 = sg.s_begin & ~15ULL; T0 < sg.s_end; T0 += TILE_BASES) {
-    __syncthreads();  // previous tile fully consumed (also covers the index copy above)
-    for (int c = t; c < TILE_DW / 4; c += WG) {
-      const int64_t q = (int64_t)T0 - 32 + 16 * (int64_t)c;
-      uint4 v;
-      if (q >= (int64_t)sg.g_begin && q + 16 <= (int64_t)sg.g_end) {
-        v = *reinterpret_cast<const uint4*>(seq + q);
-      } else {
-        uint32_t ww[4];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          uint32_t x = 0;
-#pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const int64_t p = q + 4 * d + b;
-            const uint32_t ch = (p >= (int64_t)sg.g_begin && p < (int64_t)sg.g_end) ? seq[p] : (uint32_t)'N';
-            x |= ch << (8 * b);
-          }
-          ww[d] = x;
-        }
-        v = make_uint4(ww[0], ww[1], ww[2], ww[3]);
-      }
-      *reinterpret_cast<uint4*>(tile + 4 * c) = v;
-    }
-    __syncthreads();
-
     const int64_t lo64 = (int64_t)sg.s_begin - (int64_t)T0;
     const int64_t hi64 = (int64_t)sg.s_end - (int64_t)T0;
     const int rel_lo = lo64 < 0 ? 0 : (int)lo64;
     const int rel_hi = hi64 > TILE_BASES ? TILE_BASES : (int)hi64;
+    const int64_t p0 = (int64_t)T0 + 60 * t - 4 * WARM_DW;
 
     uint64_t tuple = 0, rvs = 0;
     int run = 0;
-    for (int d = 0; d < WARM_DW + RUN_DW; d++) {
-      const uint32_t wv = tile[t * RUN_DW + d];
-      const bool emitting = d >= WARM_DW;
-      const int rel0 = 60 * t + 4 * (d - WARM_DW);
+    uint4 nxt = load_bases16(seq, p0, sg.g_begin, sg.g_end);
+    for (int grp = 0; grp < (WARM_DW + RUN_DW) / 4; grp++) {
+      const uint4 cur = nxt;
+      if (grp + 1 < (WARM_DW + RUN_DW) / 4) nxt = load_bases16(seq, p0 + 16 * (grp + 1), sg.g_begin, sg.g_end);
+      const uint32_t wv4[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const uint32_t c = (wv >> (8 * b)) & 0xffu;
-        const uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;  // BaseMap, src/SketchInfo.cpp:1007-1017
-        const bool valid = ((c & 0xC0u) == 0x40u) && ((0x0010008Au >> (c & 31u)) & 1u);
-        tuple = ((tuple << 2) | code) & P.tupmask;                               // :1134
-        rvs = (rvs >> 2) + ((uint64_t)(code ^ 3u) << P.rev_add_move);            // :1135
-        run = valid ? run + 1 : 0;                                               // base counter :1136,1161
-        if (emitting) {
-          const int rel = rel0 + b;
-          bool keep = run >= P.K && rel >= rel_lo && rel < rel_hi;               // :1139
-          const uint64_t uni = tuple < rvs ? tuple : rvs;                        // :1141
-          const uint32_t dim_id = (uint32_t)((uni & P.domask) >> P.dim_shift);   // :1142
-          uint32_t rank = 0;
+      for (int qd = 0; qd < 4; qd++) {
+        const int d = grp * 4 + qd;
+        const uint32_t wv = wv4[qd];
+        const bool emitting = d >= WARM_DW;  // wave-uniform
+        const int rel0 = 60 * t + 4 * (d - WARM_DW);
+        uint64_t uni[4];
+        bool ok[4];
+        const uint32_t up = wv & 0xDFDFDFDFu;
+        const uint32_t codes4 = ((wv >> 1) ^ (wv >> 2)) & 0x03030303u;  // BaseMap, src/SketchInfo.cpp:1007-1017
+        const bool allvalid = __builtin_amdgcn_perm(0u, 0x54474341u, codes4) == up;
+        if (fastroll && __all(allvalid)) {
+          const uint32_t pack = (codes4 * 0x40100401u) >> 24;
+          const uint32_t rp = ((codes4 * 0x01041040u) >> 24) ^ 0xffu;
+          const uint64_t F = (tuple << 8) | pack;
+          const uint64_t R = rvs | ((uint64_t)rp << (2 * P.K));
+          const bool allok = __all(run + 1 >= P.K && rel0 >= rel_lo && rel0 + 3 < rel_hi);
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            const uint64_t f = (F >> (6 - 2 * b)) & P.tupmask;                      // :1134 four times
+            const uint64_t r = (R >> (2 * b + 2)) & P.tupmask;                      // :1135 four times
+            const int rel = rel0 + b;
+            ok[b] = allok || (run + b + 1 >= P.K && rel >= rel_lo && rel < rel_hi);  // :1139
+            uni[b] = f < r ? f : r;                                                 // :1141
+            if (b == 3) { tuple = f; rvs = r; }
+          }
+          run += 4;
+        } else {
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            const uint32_t c = (wv >> (8 * b)) & 0xffu;
+            const uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;
+            const bool valid = ((c & 0xC0u) == 0x40u) && ((0x0010008Au >> (c & 31u)) & 1u);
+            tuple = ((tuple << 2) | code) & P.tupmask;                               // :1134
+            rvs = (rvs >> 2) + ((uint64_t)(code ^ 3u) << P.rev_add_move);            // :1135
+            run = valid ? run + 1 : 0;                                               // base counter :1136,1161
+            const int rel = rel0 + b;
+            ok[b] = run >= P.K && rel >= rel_lo && rel < rel_hi;
+            uni[b] = tuple < rvs ? tuple : rvs;
+          }
+        }
+        if (!emitting) continue;
+        uint32_t rank[4];
+        bool keep[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const uint32_t dim_id = (uint32_t)((uni[b] & P.domask) >> P.dim_shift);   // :1142
+          rank[b] = 0;
           if (LDS_INDEX) {
-            const uint32_t hi = dim_id >> P.lobits, lo = dim_id & ((1u << P.lobits) - 1u);
-            uint32_t j = l_off[hi];
-            const uint32_t e = l_off[hi + 1];
-            bool found = false;
-            for (; j < e; j++) {
-              const uint32_t v = l_ent[j];
-              if ((v >> 13) == lo) { rank = v & 8191u; found = true; }
-            }
-            keep = keep && found;
+            // entry = (remaining key bits << 13) | rank ; CK_EMPTY when unused
+            const uint32_t e1 = l_t1[dim_id & m1mask];
+            const uint32_t e2 = l_t2[dim_id >> hishift];
+            const bool m1 = (e1 >> 13) == (dim_id >> P.ck1) && e1 != CK_EMPTY;
+            const bool m2 = (e2 >> 13) == (dim_id & m2mask) && e2 != CK_EMPTY;
+            rank[b] = (m1 ? e1 : e2) & 8191u;
+            keep[b] = ok[b] && (m1 || m2);
           } else {
-            if (keep) {
+            keep[b] = false;
+            if (ok[b]) {
               const int32_t sd = g_table[dim_id];
-              keep = sd >= 0 && sd < P.dim_end;                                  // :1054
-              rank = (uint32_t)sd;
+              keep[b] = sd >= 0 && sd < P.dim_end;                                   // :1054
+              rank[b] = (uint32_t)sd;
             }
           }
-          const uint64_t bal = __ballot(keep);
+        }
+        if (!__any(keep[0] | keep[1] | keep[2] | keep[3])) continue;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const uint64_t bal = __ballot(keep[b]);
           if (bal) {  // wave-uniform
-            const uint64_t dr = (((uni & P.undomask0) | ((uni & P.undomask1) << P.und1_shl)) >> (P.drlevel * 4)) |
-                                (uint64_t)rank;                                  // :1150-1152
+            const uint64_t u = uni[b];
+            const uint64_t dr = (((u & P.undomask0) | ((u & P.undomask1) << P.und1_shl)) >> (P.drlevel * 4)) |
+                                (uint64_t)rank[b];                                   // :1150-1152
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(ocnt, (uint32_t)__popcll(bal));
             base = __shfl(base, 0);
             const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
-            if (keep && idx < stride) orow[idx] = (OutT)dr;
+            if (keep[b] && idx < stride) orow[idx] = (OutT)dr;
           }
         }
       }
@@ -216,7 +256,8 @@ __global__ void max_u32_kernel(const uint32_t* __restrict__ a, uint32_t n, uint3
 struct KssdCache {
   int half_subk = -1, drlevel = -1;
   uint64_t checksum = 0;
-  void* d_index = nullptr;    // u16 off[NBUCKET+1 (+1 pad)] then u32 ent[dim_end]
+  void* d_index = nullptr;    // cuckoo table 1 then table 2 (u32 entries)
+  int ck1 = 13, ck2 = 13;
   int32_t* d_table = nullptr;
   size_t table_elems = 0;
 };
@@ -259,14 +300,14 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   P.undomask0 = undomask ^ P.undomask1;
   P.dim_shift = 2 * half_outctx_len;
   P.und1_shl = K * 2 - half_outctx_len * 4;
-  P.lobits = 4 * half_subk - 12;
+  P.dimbits = 4 * half_subk;
   P.dim_end = dim_end;
   if (n == 0) return RTC_OK;
   if (((uintptr_t)d_seq & 15) != 0) return rtc_fail(ctx, RTC_ERR_ARG, "d_seq must be 16-byte aligned");
   RTC_HIP(ctx, hipSetDevice(ctx->device));
 
   // ---- filter structures (cached per device) ----
-  const bool lds_index = dim_end <= MAX_LDS_KEEP;
+  bool lds_index = dim_end <= MAX_LDS_KEEP;
   KssdCache& kc = g_cache[ctx->device & 7];
   const uint64_t cs = table_checksum(h_shuffled_dim, (size_t)dim_size);
   if (kc.half_subk != half_subk || kc.drlevel != drlevel || kc.checksum != cs) {
@@ -274,24 +315,48 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
     if (kc.d_index) { (void)hipFree(kc.d_index); kc.d_index = nullptr; }
     if (kc.d_table) { (void)hipFree(kc.d_table); kc.d_table = nullptr; }
     if (lds_index) {
-      std::vector<uint32_t> bcount(NBUCKET + 1, 0);
-      std::vector<std::pair<uint32_t, uint32_t>> kept;  // (dim_id, rank)
-      kept.reserve(dim_end);
-      for (int t = 0; t < dim_size; t++)
-        if (h_shuffled_dim[t] >= 0 && h_shuffled_dim[t] < dim_end) kept.emplace_back((uint32_t)t, (uint32_t)h_shuffled_dim[t]);
-      if ((int)kept.size() > MAX_LDS_KEEP) return rtc_fail(ctx, RTC_ERR_ARG, "shuffle table is not a permutation");
-      std::vector<uint16_t> off(NBUCKET + 2, 0);
-      std::vector<uint32_t> ent(std::max<size_t>(kept.size(), 1));
-      for (auto& kv : kept) bcount[kv.first >> P.lobits]++;
-      uint32_t acc = 0;
-      for (int b = 0; b < NBUCKET; b++) { off[b] = (uint16_t)acc; acc += bcount[b]; }
-      off[NBUCKET] = (uint16_t)acc;
-      std::vector<uint32_t> cur(off.begin(), off.begin() + NBUCKET);
-      for (auto& kv : kept) ent[cur[kv.first >> P.lobits]++] = ((kv.first & ((1u << P.lobits) - 1u)) << 13) | kv.second;
-      const size_t boff = (NBUCKET + 2) * 2, bent = ent.size() * 4;
-      RTC_HIP(ctx, hipMalloc(&kc.d_index, boff + bent));
-      RTC_HIP(ctx, hipMemcpy(kc.d_index, off.data(), boff, hipMemcpyHostToDevice));
-      RTC_HIP(ctx, hipMemcpy((char*)kc.d_index + boff, ent.data(), bent, hipMemcpyHostToDevice));
+      // two-table cuckoo placement of the kept (dim_id -> rank) pairs; smallest tables that work
+      const int dimbits = 4 * half_subk;
+      std::vector<uint32_t> t1, t2;
+      bool placed_all = false;
+      size_t nkept = 0;
+      const int tries[3][2] = {{12, 12}, {13, 12}, {13, 13}};
+      for (int tr = 0; tr < 3 && !placed_all; tr++) {
+        const int b1 = tries[tr][0], b2 = tries[tr][1], hishift = dimbits - b2;
+        if ((size_t)dim_end * 10 > (((size_t)1 << b1) + ((size_t)1 << b2)) * 6 && tr < 2) continue;  // keep load <= 60 %
+        t1.assign((size_t)1 << b1, CK_EMPTY); t2.assign((size_t)1 << b2, CK_EMPTY);
+        auto enc1 = [&](uint32_t key, uint32_t rank) { return ((key >> b1) << 13) | rank; };
+        auto enc2 = [&](uint32_t key, uint32_t rank) { return ((key & ((1u << hishift) - 1u)) << 13) | rank; };
+        auto key1 = [&](uint32_t slot, uint32_t e) { return ((e >> 13) << b1) | slot; };
+        auto key2 = [&](uint32_t slot, uint32_t e) { return (slot << hishift) | (e >> 13); };
+        placed_all = true; nkept = 0;
+        for (int t = 0; t < dim_size && placed_all; t++) {
+          if (h_shuffled_dim[t] < 0 || h_shuffled_dim[t] >= dim_end) continue;
+          nkept++;
+          uint32_t key = (uint32_t)t, rank = (uint32_t)h_shuffled_dim[t];
+          bool done = false;
+          for (int kick = 0; kick < 512 && !done; kick++) {
+            const uint32_t s1 = key & ((1u << b1) - 1u);
+            if (t1[s1] == CK_EMPTY) { t1[s1] = enc1(key, rank); done = true; break; }
+            const uint32_t s2 = key >> hishift;
+            if (t2[s2] == CK_EMPTY) { t2[s2] = enc2(key, rank); done = true; break; }
+            // evict alternately from table 1 / table 2
+            if (kick & 1) { const uint32_t e = t2[s2]; t2[s2] = enc2(key, rank); key = key2(s2, e); rank = e & 8191u; }
+            else { const uint32_t e = t1[s1]; t1[s1] = enc1(key, rank); key = key1(s1, e); rank = e & 8191u; }
+          }
+          if (!done) placed_all = false;
+        }
+        if (placed_all) { kc.ck1 = b1; kc.ck2 = b2; }
+      }
+      if (nkept > (size_t)MAX_LDS_KEEP) return rtc_fail(ctx, RTC_ERR_ARG, "shuffle table is not a permutation");
+      if (placed_all) {
+        RTC_HIP(ctx, hipMalloc(&kc.d_index, (t1.size() + t2.size()) * 4));
+        RTC_HIP(ctx, hipMemcpy(kc.d_index, t1.data(), t1.size() * 4, hipMemcpyHostToDevice));
+        RTC_HIP(ctx, hipMemcpy((char*)kc.d_index + t1.size() * 4, t2.data(), t2.size() * 4, hipMemcpyHostToDevice));
+      } else {  // could not place every key: use the HBM table for this configuration
+        RTC_HIP(ctx, hipMalloc((void**)&kc.d_table, (size_t)dim_size * 4));
+        RTC_HIP(ctx, hipMemcpy(kc.d_table, h_shuffled_dim, (size_t)dim_size * 4, hipMemcpyHostToDevice));
+      }
     } else {
       RTC_HIP(ctx, hipMalloc((void**)&kc.d_table, (size_t)dim_size * 4));
       RTC_HIP(ctx, hipMemcpy(kc.d_table, h_shuffled_dim, (size_t)dim_size * 4, hipMemcpyHostToDevice));
@@ -327,15 +392,17 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   RTC_HIP(ctx, hipMemcpyAsync(ws0, hp, bseg, hipMemcpyHostToDevice, ctx->stream));
   RTC_HIP(ctx, hipMemsetAsync(d_cnt, 0, (size_t)n * 4, ctx->stream));
 
-  const uint16_t* d_ioff = (const uint16_t*)kc.d_index;
-  const uint32_t* d_ient = kc.d_index ? (const uint32_t*)((char*)kc.d_index + (NBUCKET + 2) * 2) : nullptr;
-  const size_t lds = (size_t)TILE_DW * 4 + (lds_index ? (NBUCKET + 2) * 2 + (size_t)std::max(dim_end, 1) * 4 : 0);
+  lds_index = kc.d_index != nullptr;  // false when the cuckoo build fell back to the HBM table
+  const uint32_t* d_t1 = (const uint32_t*)kc.d_index;
+  P.ck1 = kc.ck1; P.ck2 = kc.ck2;
+  const uint32_t* d_t2 = kc.d_index ? d_t1 + ((size_t)1 << kc.ck1) : nullptr;
+  const size_t lds = lds_index ? (((size_t)1 << kc.ck1) + ((size_t)1 << kc.ck2)) * 4 : 16;
 #define LAUNCH_KSSD(OT, LI)                                                                                         \
   do {                                                                                                               \
     auto kern = sketch_kssd_kernel<OT, LI>;                                                                          \
     RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
     hipLaunchKernelGGL(kern, dim3((uint32_t)segs.size()), dim3(WG), lds, ctx->stream, d_seq, (const KSegment*)ws0, P, \
-                       d_ioff, d_ient, (const int32_t*)kc.d_table, (OT*)d_out, stride, d_cnt);                        \
+                       d_t1, d_t2, (const int32_t*)kc.d_table, (OT*)d_out, stride, d_cnt);                        \
   } while (0)
   if (use64) { if (lds_index) LAUNCH_KSSD(uint64_t, true); else LAUNCH_KSSD(uint64_t, false); }
   else       { if (lds_index) LAUNCH_KSSD(uint32_t, true); else LAUNCH_KSSD(uint32_t, false); }

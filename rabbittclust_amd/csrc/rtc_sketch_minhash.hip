@@ -28,7 +28,8 @@ constexpr int TILE_BASES = WG * RUN_DW * 4;           // bases per tile
 constexpr int STEP_APPENDS = WG * 4;                  // worst-case appends per dword iteration
 constexpr int MIN_ROOM = STEP_APPENDS;                // candidate room the buffer always offers
 constexpr uint64_t SENT = ~0ULL;
-constexpr size_t LUT_BYTES = 8 * 256 * 8;             // eight 256-entry u64 product tables
+constexpr size_t LUT_TABLE_BYTES = 256 * 8;           // one 256-entry u64 product table per 4 bases of k
+__host__ __device__ constexpr size_t lut_bytes(int k) { return (size_t)((k + 3) / 4) * LUT_TABLE_BYTES; }
 
 struct Segment {
   uint64_t g_begin, g_end;  // genome byte range in d_seq
@@ -88,7 +89,7 @@ __device__ __forceinline__ KParams make_kparams(int k, uint32_t seed) {
   return P;
 }
 
-// lut: [8][256] u64 in LDS.  Called by all WG threads; the first 256 fill one column each.
+// lut: [ceil(k/4)][256] u64 in LDS.  Called by all WG threads; the first 256 fill one column each.
 __device__ __forceinline__ void build_kmer_lut(uint64_t* lut, int k) {
   const uint32_t e = threadIdx.x;
   if (e >= 256) return;
@@ -96,7 +97,8 @@ __device__ __forceinline__ void build_kmer_lut(uint64_t* lut, int k) {
 #pragma unroll
   for (int d = 0; d < 8; d++) {
     const int nb = k - 4 * d;
-    const uint32_t bm = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+    if (nb <= 0) break;  // only ceil(k/4) tables exist
+    const uint32_t bm = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
     const uint64_t v = (uint64_t)(a4 & bm) << (32 * (d & 1));
     lut[d * 256 + e] = v * ((d & 2) ? MM_C2 : MM_C1);
   }
@@ -238,10 +240,10 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
   uint64_t* lut = reinterpret_cast<uint64_t*>(smem + (size_t)cap * 8);
-  Ctrl* ctrl = reinterpret_cast<Ctrl*>(smem + (size_t)cap * 8 + LUT_BYTES);
+  const int k = KT > 0 ? KT : k_arg;
+  Ctrl* ctrl = reinterpret_cast<Ctrl*>(smem + (size_t)cap * 8 + lut_bytes(k));
 
   const Segment sg = segs[blockIdx.x];
-  const int k = KT > 0 ? KT : k_arg;
   const KParams P = make_kparams(k, seed);
   const int t = threadIdx.x;
   const uint32_t lane = t & 63;
@@ -465,7 +467,7 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   // candidate buffer of the sketch kernel: s + room; of the partial-merge kernel: two s-lists
   const int cap = pow2ceil((int)(smax + MIN_ROOM));
   const int cap_merge = pow2ceil((int)std::max<uint32_t>(2 * smax, 1024));
-  const size_t lds = (size_t)cap * 8 + LUT_BYTES + sizeof(Ctrl);
+  const size_t lds = (size_t)cap * 8 + lut_bytes(k) + sizeof(Ctrl);
   const size_t lds_m = (size_t)cap_merge * 8 + sizeof(Ctrl);
   if (lds > (size_t)160 * 1024 || lds_m > (size_t)160 * 1024)
     return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "sketch size %u needs %zu B of LDS (> 160 KiB); the GPU path takes sizes up to 6144", smax, std::max(lds, lds_m));
