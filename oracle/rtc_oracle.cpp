@@ -113,6 +113,8 @@ static const int8_t* base_lut() {
   return lut;
 }
 
+static const uint32_t* ascii4_lut();
+
 struct orc_minhash {
   int k;
   uint32_t s;
@@ -128,15 +130,34 @@ extern "C" orc_minhash* orc_mh_new(int k, uint32_t sketch_size, uint32_t seed) {
   m->k = k; m->s = sketch_size; m->seed = seed;
   m->use64 = k > 16;  // Mash: 4^k > 2^32
   (void)base_lut();
+  (void)ascii4_lut();
   return m;
 }
 extern "C" void orc_mh_free(orc_minhash* m) { delete m; }
 
+// 4 bases (8 bits, first base in the top two bits) -> 4 ASCII bytes, first base lowest
+static const uint32_t* ascii4_lut() {
+  static uint32_t lut[256];
+  static bool init = false;
+  if (!init) {
+    for (int e = 0; e < 256; e++) {
+      uint32_t v = 0;
+      for (int j = 0; j < 4; j++) v |= (uint32_t)(uint8_t)"ACGT"[(e >> (6 - 2 * j)) & 3] << (8 * j);
+      lut[e] = v;
+    }
+    init = true;
+  }
+  return lut;
+}
+
 static inline uint64_t kmer_hash_packed(uint64_t canon, int k, uint32_t seed, bool use64) {
-  char buf[32];
-  for (int i = 0; i < k; i++) buf[i] = "ACGT"[(canon >> (2 * (k - 1 - i))) & 3];
+  // expand the 2-bit word to the ASCII bytes MurmurHash3 consumes, 4 bases per table lookup
+  const uint32_t* a4 = ascii4_lut();
+  const uint64_t x = k == 32 ? canon : canon << (64 - 2 * k);
+  uint32_t w[8];
+  for (int d = 0; d < 8; d++) w[d] = a4[(x >> (56 - 8 * d)) & 0xff];
   uint64_t o[2];
-  orc_murmur3_x64_128(buf, k, seed, o);
+  orc_murmur3_x64_128(w, k, seed, o);  // only the first k bytes are read
   return use64 ? o[0] : (o[0] & 0xffffffffULL);
 }
 
