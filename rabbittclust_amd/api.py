@@ -121,7 +121,7 @@ class Context:
 
     def upload_sequences(self, seq_np):
         t = torch.empty(len(seq_np) + 64, dtype=torch.uint8, device=self.device)
-        t[:len(seq_np)] = torch.from_numpy(np.ascontiguousarray(seq_np, dtype=np.uint8)).to(self.device)
+        t[:len(seq_np)] = torch.from_numpy(np.array(seq_np, dtype=np.uint8, copy=True)).to(self.device)
         return t
 
     # ---- sketching ----------------------------------------------------------------------------

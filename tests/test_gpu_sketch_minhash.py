@@ -122,3 +122,16 @@ def test_sketch_size_beyond_lds_fails_loudly(ctx):
     with pytest.raises(RtcError) as ei:
         ctx.sketch_minhash(d, off, k=21, size=20000)
     assert ei.value.status == 3  # RTC_ERR_UNSUPPORTED: no silent fallback
+
+
+def test_sketch_many_tiny_genomes_and_max_size(ctx, oracle):
+    rng = np.random.default_rng(12)
+    lens = [int(x) for x in rng.integers(0, 3000, size=600)]
+    lens[5] = 0
+    seq, off = _random_genomes(rng, lens, n_rate=0.01, lower_rate=0.2)
+    _check(ctx, oracle, seq, off, 21, size=1000)
+    _check(ctx, oracle, seq, off, 32, size=64)
+    # largest sketch size the LDS-resident selection takes (6144), on a genome with fewer k-mers than that
+    seq2, off2 = _random_genomes(rng, [4000, 250_000])
+    _check(ctx, oracle, seq2, off2, 21, size=6144)
+    _check(ctx, oracle, seq2, off2, 17, size=6144)
