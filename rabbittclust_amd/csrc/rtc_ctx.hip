@@ -18,7 +18,7 @@ int rtc_fail(rtc_ctx* ctx, int code, const char* fmt, ...) {
 }
 
 int rtc_ws(rtc_ctx* ctx, int slot, size_t bytes, void** out) {
-  if (slot < 0 || slot >= 4) return rtc_fail(ctx, RTC_ERR_ARG, "bad scratch slot %d", slot);
+  if (slot < 0 || slot >= 6) return rtc_fail(ctx, RTC_ERR_ARG, "bad scratch slot %d", slot);
   if (bytes > ctx->ws_bytes[slot]) {
     RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->ws[slot]) RTC_HIP(ctx, hipFree(ctx->ws[slot]));
@@ -79,7 +79,7 @@ void rtc_ctx_destroy(rtc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < 6; i++)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

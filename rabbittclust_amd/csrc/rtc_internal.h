@@ -17,8 +17,8 @@ struct rtc_ctx {
   int lds_per_wg = 65536;
   std::string err;
   // growable device scratch (segment tables, partial sketches, partition tables ...)
-  void* ws[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t ws_bytes[4] = {0, 0, 0, 0};
+  void* ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t ws_bytes[6] = {0, 0, 0, 0, 0, 0};
   // pinned host staging for small synchronous read-backs
   void* pinned = nullptr;
   size_t pinned_bytes = 0;

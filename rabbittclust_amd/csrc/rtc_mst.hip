@@ -153,7 +153,7 @@ int rtc_extract_edges_dev(rtc_ctx* ctx, const uint32_t* d_common, uint64_t ld, u
   if (!ctx || !d_common || !d_len || !d_count || (cap && !d_edges)) return RTC_ERR_ARG;
   if (row0 >= row1 || col0 >= col1) return RTC_OK;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
-  dim3 grid((col1 - col0 + 255) / 256, std::min<uint32_t>(row1 - row0, 16384));
+  dim3 grid((col1 - col0 + 255) / 256, std::min<uint32_t>(row1 - row0, 2048));
   hipLaunchKernelGGL(extract_edges_kernel, grid, dim3(256), 0, ctx->stream, d_common, ld, row0, row1, col0, col1,
                      d_len, radio, d_edges, cap, (unsigned long long*)d_count);
   RTC_CHECK_LAUNCH(ctx);

@@ -11,6 +11,8 @@
 //   3. masks are accumulated in per-lane bit-sliced counters (plane k holds bit k of the 64 row
 //      counters), i.e. one probe serves 64 pairs and the add is a wave-uniform ripple of
 //      AND/XOR on 64-bit registers.
+// The column slices are first copied into a partition-major, element-major, column-minor layout
+// (tcols[base[p] + e*n + c]) so that the probe loop's loads are coalesced across lanes (= columns).
 // After the last partition each lane unpacks its 64 counters and writes them (coalesced across
 // lanes) to common[row][col].  Partition boundaries are data quantiles computed from a sample, so
 // the table load stays ~25 %; blocks whose slices would overflow the table are split into row
@@ -114,6 +116,8 @@ __device__ __forceinline__ unsigned long long table_lookup(const uint32_t* keys,
 template <typename T, int NPL>
 __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ hashes,
                                                         const uint64_t* __restrict__ start,
+                                                        const T* __restrict__ tcols,          // transposed column slices
+                                                        const uint64_t* __restrict__ tbase,   // [P] element offsets
                                                         const uint32_t* __restrict__ so, int P, uint32_t n,
                                                         uint32_t row0, uint32_t row1, uint32_t col0,
                                                         uint32_t col1, uint32_t* __restrict__ out, uint64_t ld,
@@ -136,7 +140,6 @@ __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ ha
 #pragma unroll
   for (int k = 0; k < NPL; k++) planes[k] = 0ULL;
 
-  const T* colp = hashes + (col_active ? start[c] : 0);
   uint32_t clo = col_active ? so[c] : 0;  // so[0][c]
   if (tid < ROWS) sh->rstart[tid] = tid < (int)nrows ? start[rb0 + tid] : 0;
 
@@ -149,15 +152,22 @@ __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ ha
       sh->rhi[tid] = rv ? so[(size_t)(p + 1) * n + rb0 + tid] : 0;
     }
     __syncthreads();
-    if (tid == 0) {  // split the row block so that no table build exceeds KCAP_HARD keys
-      uint32_t ns = 0, acc = 0;
-      for (uint32_t r = 0; r < nrows; r++) {
-        const uint32_t sz = sh->rhi[r] - sh->rlo[r];
-        if (acc + sz > KCAP_HARD && acc > 0) { sh->sub_end[ns++] = r; acc = 0; }
-        acc += sz;
+    if (wave == 0) {  // split the row block only if its keys would overflow one table (rare)
+      uint32_t sz = (lane < nrows) ? sh->rhi[lane] - sh->rlo[lane] : 0;
+      uint32_t tot = sz;
+      for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+      if (tot <= KCAP_HARD) {
+        if (lane == 0) { sh->sub_end[0] = nrows; sh->nsub = 1; }
+      } else if (lane == 0) {
+        uint32_t ns = 0, acc = 0;
+        for (uint32_t r = 0; r < nrows; r++) {
+          const uint32_t szr = sh->rhi[r] - sh->rlo[r];
+          if (acc + szr > KCAP_HARD && acc > 0) { sh->sub_end[ns++] = r; acc = 0; }
+          acc += szr;
+        }
+        sh->sub_end[ns++] = nrows;
+        sh->nsub = ns;
       }
-      sh->sub_end[ns++] = nrows;
-      sh->nsub = ns;
     }
     __syncthreads();
     const uint32_t nsub = sh->nsub;
@@ -180,16 +190,20 @@ __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ ha
         for (uint32_t e = sh->rlo[r] + lane; e < hi; e += 64) table_insert<T>(keys, masks, sh, rp[e], (int)r);
       }
       __syncthreads();
-      // ---- probe: this lane's column slice ----
-      for (uint32_t e = clo; e < chi; e++) {
-        const unsigned long long m = table_lookup(keys, masks, sh, colp[e]);
-        unsigned long long carry = m;
+      // ---- probe: this lane's column slice, read coalesced from the transposed copy ----
+      {
+        const T* tp = tcols + tbase[p] + c;
+        const uint32_t mylen = chi - clo;
+        for (uint32_t e = 0; e < mylen; e++) {
+          const unsigned long long m = table_lookup(keys, masks, sh, tp[(size_t)e * n]);
+          unsigned long long carry = m;
 #pragma unroll
-        for (int k = 0; k < NPL; k++) {
-          if (!__any(carry != 0ULL)) break;  // wave-uniform
-          const unsigned long long t = planes[k] & carry;
-          planes[k] ^= carry;
-          carry = t;
+          for (int k = 0; k < NPL; k++) {
+            if (!__any(carry != 0ULL)) break;  // wave-uniform
+            const unsigned long long t = planes[k] & carry;
+            planes[k] ^= carry;
+            carry = t;
+          }
         }
       }
       if (sb + 1 < nsub) __syncthreads();
@@ -229,16 +243,29 @@ __global__ void slice_offsets_kernel(const T* __restrict__ hashes, const uint64_
   so[(size_t)p * n + g] = r;
 }
 
-// max single slice over all genomes/partitions (a slice larger than the table cannot be built)
-__global__ void max_slice_kernel(const uint32_t* __restrict__ so, int P, uint32_t n, uint32_t* __restrict__ out_max) {
-  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// per-partition maximum slice length (sizes the transposed copy) -- pmax[P]; grid.y = partition
+__global__ __launch_bounds__(256) void partition_max_kernel(const uint32_t* __restrict__ so, int P, uint32_t n,
+                                                            uint32_t* __restrict__ pmax) {
+  const uint32_t p = blockIdx.y;
   uint32_t v = 0;
-  if (idx < (uint64_t)n * P) {
-    const uint32_t p = (uint32_t)(idx / n), g = (uint32_t)(idx % n);
-    v = so[(size_t)(p + 1) * n + g] - so[(size_t)p * n + g];
-  }
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x)
+    v = max(v, so[(size_t)(p + 1) * n + g] - so[(size_t)p * n + g]);
   for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
-  if ((threadIdx.x & 63) == 0 && v) atomicMax(out_max, v);
+  if ((threadIdx.x & 63) == 0 && v) atomicMax(&pmax[p], v);
+}
+
+// tcols[tbase[p] + e*n + c] = element e of column c's slice in partition p
+template <typename T>
+__global__ void transpose_slices_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
+                                        const uint32_t* __restrict__ so, const uint64_t* __restrict__ tbase, int P,
+                                        uint32_t n, T* __restrict__ tcols) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t p = blockIdx.y;
+  if (c >= n) return;
+  const uint32_t lo = so[(size_t)p * n + c], hi = so[(size_t)(p + 1) * n + c];
+  const T* src = hashes + start[c] + lo;
+  T* dst = tcols + tbase[p] + c;
+  for (uint32_t e = 0; e < hi - lo; e++) dst[(size_t)e * n] = src[e];
 }
 
 // planning inputs in one launch: sum / max of the sketch lengths and SAMPLE_PER evenly spaced
@@ -275,15 +302,15 @@ __global__ __launch_bounds__(256) void plan_stats_kernel(const T* __restrict__ h
 }
 
 template <typename T, int NPL>
-int launch_tiled(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const uint32_t* d_so, int P, uint32_t n,
-                 uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld,
-                 int lower_only) {
+int launch_tiled(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const T* d_tcols, const uint64_t* d_tbase,
+                 const uint32_t* d_so, int P, uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1,
+                 uint32_t* d_common, uint64_t ld, int lower_only) {
   const size_t lds = (size_t)SLOTS * (sizeof(T) + 8) + sizeof(TileShared);
   auto kern = pair_tiled_kernel<T, NPL>;
   RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((col1 - col0 + TW - 1) / TW, (row1 - row0 + ROWS - 1) / ROWS);
-  hipLaunchKernelGGL(kern, grid, dim3(TW), lds, ctx->stream, d_hashes, d_start, d_so, P, n, row0, row1, col0, col1,
-                     d_common, ld, lower_only);
+  hipLaunchKernelGGL(kern, grid, dim3(TW), lds, ctx->stream, d_hashes, d_start, d_tcols, d_tbase, d_so, P, n, row0, row1,
+                     col0, col1, d_common, ld, lower_only);
   RTC_CHECK_LAUNCH(ctx);
   return RTC_OK;
 }
@@ -305,7 +332,7 @@ int tiled_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
                      d_hashes, d_start, d_len, n, d_stats, d_samples, d_ns);
   RTC_CHECK_LAUNCH(ctx);
   void* hpin = nullptr;
-  RTC_TRY(rtc_pinned(ctx, sizeof(PlanStats) + 8 + bsamp + 64 + (size_t)(MAXP + 1) * sizeof(T), &hpin));
+  RTC_TRY(rtc_pinned(ctx, sizeof(PlanStats) + 8 + bsamp + 64 + (size_t)(MAXP + 1) * 8, &hpin));
   RTC_HIP(ctx, hipMemcpyAsync(hpin, wsp, sizeof(PlanStats) + 8 + bsamp, hipMemcpyDeviceToHost, ctx->stream));
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const PlanStats hst = *(const PlanStats*)hpin;
@@ -329,35 +356,54 @@ int tiled_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
     void* ws = nullptr;
     const size_t bso = (size_t)(P + 1) * n * 4;
     const size_t bb = (size_t)(P + 1) * sizeof(T);
-    RTC_TRY(rtc_ws(ctx, 1, bso + bb + 64, &ws));
+    RTC_TRY(rtc_ws(ctx, 1, bso + bb + 64 + (size_t)(P + 1) * 4, &ws));
     uint32_t* d_so = (uint32_t*)ws;
     T* d_bounds = (T*)((char*)ws + bso);
-    uint32_t* d_max = (uint32_t*)((char*)ws + bso + bb + (8 - bb % 8) % 8);
+    uint32_t* d_max = (uint32_t*)((char*)ws + bso + bb + (8 - bb % 8) % 8);  // [0] = max slice, [1..P] = per-partition max
+    uint32_t* d_pmax = d_max + 1;
     memcpy(h_bounds_pin, bounds.data(), bb);
     RTC_HIP(ctx, hipMemcpyAsync(d_bounds, h_bounds_pin, bb, hipMemcpyHostToDevice, ctx->stream));
-    RTC_HIP(ctx, hipMemsetAsync(d_max, 0, 4, ctx->stream));
+    RTC_HIP(ctx, hipMemsetAsync(d_max, 0, (size_t)(P + 1) * 4, ctx->stream));
     const uint64_t work = (uint64_t)n * (P + 1);
     hipLaunchKernelGGL(slice_offsets_kernel<T>, dim3((uint32_t)((work + 255) / 256)), dim3(256), 0, ctx->stream,
                        d_hashes, d_start, d_len, d_bounds, P, n, d_so);
     RTC_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(max_slice_kernel, dim3((uint32_t)(((uint64_t)n * P + 255) / 256)), dim3(256), 0, ctx->stream,
-                       d_so, P, n, d_max);
+    hipLaunchKernelGGL(partition_max_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 64), (uint32_t)P), dim3(256), 0,
+                       ctx->stream, d_so, P, n, d_pmax);
     RTC_CHECK_LAUNCH(ctx);
-    uint32_t h_max = 0;
-    RTC_HIP(ctx, hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<uint32_t> h_maxes(P + 1);
+    RTC_HIP(ctx, hipMemcpyAsync(h_maxes.data(), d_max, (size_t)(P + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
     RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t* h_pmax = h_maxes.data() + 1;
+    uint32_t h_max = 0;  // largest single slice: must fit one table build
+    for (int p = 0; p < P; p++) h_max = std::max(h_max, h_pmax[p]);
     if (h_max > KCAP_HARD) {  // some single slice does not fit a table: refine the partition
       if (P >= MAXP) return RTC_OK;
       P = std::min(MAXP, P * 4);
       continue;
     }
+    // ---- partition-major transposed copy of the column slices ----
+    std::vector<uint64_t> tbase(P + 1, 0);
+    for (int p = 0; p < P; p++) tbase[p + 1] = tbase[p] + (uint64_t)h_pmax[p] * n;
+    void* ws4 = nullptr;
+    const size_t btb = (size_t)P * 8;
+    RTC_TRY(rtc_ws(ctx, 4, tbase[P] * sizeof(T) + btb + 256, &ws4));
+    uint64_t* d_tbase = (uint64_t*)ws4;
+    T* d_tcols = (T*)((char*)ws4 + ((btb + 255) / 256) * 256);
+    memcpy(h_bounds_pin, tbase.data(), btb);  // the bounds upload completed before the read-back above
+    RTC_HIP(ctx, hipMemcpyAsync(d_tbase, h_bounds_pin, btb, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(transpose_slices_kernel<T>, dim3((n + 255) / 256, (uint32_t)P), dim3(256), 0, ctx->stream, d_hashes,
+                       d_start, d_so, d_tbase, P, n, d_tcols);
+    RTC_CHECK_LAUNCH(ctx);
     int npl = 1;
     while ((1u << npl) <= lmax) npl++;
     int st;
-    if (npl <= 10) st = launch_tiled<T, 10>(ctx, d_hashes, d_start, d_so, P, n, row0, row1, col0, col1, d_common, ld, lower_only);
-    else if (npl <= 13) st = launch_tiled<T, 13>(ctx, d_hashes, d_start, d_so, P, n, row0, row1, col0, col1, d_common, ld, lower_only);
-    else if (npl <= 16) st = launch_tiled<T, 16>(ctx, d_hashes, d_start, d_so, P, n, row0, row1, col0, col1, d_common, ld, lower_only);
-    else st = launch_tiled<T, 20>(ctx, d_hashes, d_start, d_so, P, n, row0, row1, col0, col1, d_common, ld, lower_only);
+#define LT(NPLV) launch_tiled<T, NPLV>(ctx, d_hashes, d_start, d_tcols, d_tbase, d_so, P, n, row0, row1, col0, col1, d_common, ld, lower_only)
+    if (npl <= 10) st = LT(10);
+    else if (npl <= 13) st = LT(13);
+    else if (npl <= 16) st = LT(16);
+    else st = LT(20);
+#undef LT
     if (st != RTC_OK) return st;
     *handled = 1;
     return RTC_OK;

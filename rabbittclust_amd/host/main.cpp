@@ -96,6 +96,7 @@ static void sketch_files(rtc_ctx* ctx, const string& inputFile, const SketchJob&
   size_t next = 0;
   while (next < fileList.size()) {
     // ---- parse a batch on the host ----
+    const double tb0 = get_sec();
     vector<string> bases; vector<SequenceInfo> firsts; vector<uint64_t> totals; vector<int> flens; vector<size_t> idx;
     size_t bytes = 0, end = next;
     while (end < fileList.size() && (bytes < BATCH_BYTES || end == next)) {
@@ -115,6 +116,7 @@ static void sketch_files(rtc_ctx* ctx, const string& inputFile, const SketchJob&
       end += chunk;
     }
     // ---- filter (:963), pack, upload ----
+    const double tb1 = get_sec();
     vector<uint64_t> off{0}; vector<uint32_t> sizes; vector<size_t> kept;
     for (size_t i = 0; i < idx.size(); i++) {
       if (totals[i] < job.minLen) continue;
@@ -124,11 +126,23 @@ static void sketch_files(rtc_ctx* ctx, const string& inputFile, const SketchJob&
     }
     const uint32_t nb = (uint32_t)kept.size();
     if (nb) {
-      vector<unsigned char> packed(off.back() + 64);
-      for (uint32_t g = 0; g < nb; g++) memcpy(packed.data() + off[g], bases[kept[g]].data(), bases[kept[g]].size());
+      // pack in parallel into an uninitialised buffer (first touch by the copying threads)
+      const size_t packed_size = off.back() + 64;
+      unsigned char* packed = (unsigned char*)malloc(packed_size);
+      if (!packed) { fprintf(stderr, "ERROR: cannot allocate %zu bytes for the sequence batch\n", packed_size); exit(1); }
+#pragma omp parallel for num_threads(job.threads) schedule(dynamic)
+      for (long g = 0; g < (long)nb; g++) {
+        memcpy(packed + off[g], bases[kept[g]].data(), bases[kept[g]].size());
+        string().swap(bases[kept[g]]);  // release as we go
+      }
+      memset(packed + off.back(), 'N', 64);
+      const double tb2 = get_sec();
       void* d_seq = nullptr;
-      CHECK(ctx, rtc_dev_alloc(ctx, packed.size(), &d_seq));
-      CHECK(ctx, rtc_copy_h2d(ctx, d_seq, packed.data(), packed.size()));
+      CHECK(ctx, rtc_dev_alloc(ctx, packed_size, &d_seq));
+      CHECK(ctx, rtc_copy_h2d(ctx, d_seq, packed, packed_size));
+      free(packed);
+      const double tb3 = get_sec();
+      if (getenv("RTC_VERBOSE")) fprintf(stderr, "[batch] parse %.3fs pack %.3fs alloc+h2d %.3fs (%.2f GB)\n", tb1 - tb0, tb2 - tb1, tb3 - tb2, packed_size / 1e9);
       uint32_t* d_cnt = nullptr;
       CHECK(ctx, rtc_dev_alloc(ctx, (size_t)nb * 4, (void**)&d_cnt));
       vector<uint32_t> cnt(nb);
