@@ -194,15 +194,24 @@ __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ ha
       {
         const T* tp = tcols + tbase[p] + c;
         const uint32_t mylen = chi - clo;
-        for (uint32_t e = 0; e < mylen; e++) {
-          const unsigned long long m = table_lookup(keys, masks, sh, tp[(size_t)e * n]);
-          unsigned long long carry = m;
+        // four elements per trip: the global loads are issued together, then the four LDS lookups
+        for (uint32_t e = 0; e < mylen; e += 4) {
+          T bq[4];
 #pragma unroll
-          for (int k = 0; k < NPL; k++) {
-            if (!__any(carry != 0ULL)) break;  // wave-uniform
-            const unsigned long long t = planes[k] & carry;
-            planes[k] ^= carry;
-            carry = t;
+          for (int j = 0; j < 4; j++) bq[j] = (e + j < mylen) ? tp[(size_t)(e + j) * n] : (T)0;
+          unsigned long long mq[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) mq[j] = (e + j < mylen) ? table_lookup(keys, masks, sh, bq[j]) : 0ULL;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            unsigned long long carry = mq[j];
+#pragma unroll
+            for (int k = 0; k < NPL; k++) {
+              if (!__any(carry != 0ULL)) break;  // wave-uniform
+              const unsigned long long t = planes[k] & carry;
+              planes[k] ^= carry;
+              carry = t;
+            }
           }
         }
       }
