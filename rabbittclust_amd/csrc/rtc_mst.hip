@@ -33,29 +33,43 @@ __global__ __launch_bounds__(256) void extract_edges_kernel(const uint32_t* __re
                                                             uint32_t col1, const uint32_t* __restrict__ len,
                                                             int radio, rtc_cedge* __restrict__ edges,
                                                             uint64_t cap, unsigned long long* __restrict__ count) {
+  // each lane covers 4 consecutive columns (one 16-byte load when aligned); a block covers 1024
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t col = col0 + blockIdx.x * 256 + threadIdx.x;
+  const uint32_t cbase = col0 + blockIdx.x * 1024;
+  const uint32_t c4 = cbase + threadIdx.x * 4;
+  const bool vec_ok = (ld & 3) == 0 && (((uintptr_t)common) & 15) == 0;
   for (uint32_t row = row0 + blockIdx.y; row < row1; row += gridDim.y) {
-    if (col0 + blockIdx.x * 256 >= row) continue;  // whole block on/above the diagonal (uniform)
-    bool keep = false;
-    uint32_t c = 0;
-    if (col < col1 && col < row) {
-      c = common[(uint64_t)(row - row0) * ld + (col - col0)];
-      if (c > 0) {
-        const uint32_t s0 = len[row], s1 = len[col];
-        if (s0 > 0 && s1 > 0) {
+    if (cbase >= row) continue;  // whole block on/above the diagonal (uniform)
+    const uint32_t* rp = common + (uint64_t)(row - row0) * ld;
+    uint32_t v[4] = {0, 0, 0, 0};
+    const uint32_t off = c4 - col0;
+    if (c4 + 3 < col1 && vec_ok) {
+      const uint4 q = *reinterpret_cast<const uint4*>(rp + off);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (c4 + j < col1) v[j] = rp[off + j];
+    }
+    const uint32_t s0 = len[row];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t col = c4 + j;
+      bool keep = false;
+      if (col < col1 && col < row && v[j] > 0 && s0 > 0) {
+        const uint32_t s1 = len[col];
+        if (s1 > 0) {
           const uint32_t mn = s0 < s1 ? s0 : s1, mx = s0 > s1 ? s0 : s1;
           keep = !((uint64_t)mx > (uint64_t)(int64_t)radio * (uint64_t)mn);  // src/MST.cpp:1484
         }
       }
-    }
-    const uint64_t bal = __ballot(keep);
-    if (bal) {
-      unsigned long long base = 0;
-      if (lane == (uint32_t)(__ffsll((long long)bal) - 1)) base = atomicAdd(count, (unsigned long long)__popcll(bal));
-      base = __shfl(base, __ffsll((long long)bal) - 1);
-      const uint64_t idx = base + (uint64_t)__popcll(bal & ((1ULL << lane) - 1ULL));
-      if (keep && idx < cap) edges[idx] = rtc_cedge{row, col, c};
+      const uint64_t bal = __ballot(keep);
+      if (bal) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(bal));
+        base = __shfl(base, 0);
+        const uint64_t idx = base + (uint64_t)__popcll(bal & ((1ULL << lane) - 1ULL));
+        if (keep && idx < cap) edges[idx] = rtc_cedge{row, col, v[j]};
+      }
     }
   }
 }
@@ -153,7 +167,7 @@ int rtc_extract_edges_dev(rtc_ctx* ctx, const uint32_t* d_common, uint64_t ld, u
   if (!ctx || !d_common || !d_len || !d_count || (cap && !d_edges)) return RTC_ERR_ARG;
   if (row0 >= row1 || col0 >= col1) return RTC_OK;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
-  dim3 grid((col1 - col0 + 255) / 256, std::min<uint32_t>(row1 - row0, 2048));
+  dim3 grid((col1 - col0 + 1023) / 1024, std::min<uint32_t>(row1 - row0, 4096));
   hipLaunchKernelGGL(extract_edges_kernel, grid, dim3(256), 0, ctx->stream, d_common, ld, row0, row1, col0, col1,
                      d_len, radio, d_edges, cap, (unsigned long long*)d_count);
   RTC_CHECK_LAUNCH(ctx);
