@@ -35,8 +35,11 @@ struct Segment {
   uint64_t g_begin, g_end;  // genome byte range in d_seq
   uint64_t s_begin, s_end;  // k-mer END positions owned by this segment (absolute)
   uint64_t out_off;         // element offset into out buffer
+  uint64_t lo_off;          // pass > 0: offset (final buffer) of the largest hash kept by earlier passes
   uint32_t cnt_slot;        // index into cnt buffer
-  uint32_t sketch_size;
+  uint32_t sketch_size;     // hashes to select in this pass
+  uint32_t final_slot;      // genome index in the final count buffer
+  uint32_t expect;          // pass > 0: run only if the genome already holds exactly this many hashes
 };
 
 struct Ctrl {
@@ -235,8 +238,9 @@ template <int KT>  // KT > 0: k known at compile time (uniform branches fold awa
 __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __restrict__ seq,
                                                             const Segment* __restrict__ segs,
                                                             int k_arg, uint32_t seed, int cap,
-                                                            uint64_t* __restrict__ out,
-                                                            uint32_t* __restrict__ cnt) {
+                                                            uint64_t* out,
+                                                            uint32_t* cnt, int pass_no,
+                                                            const uint64_t* fin_out, const uint32_t* fin_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
   uint64_t* lut = reinterpret_cast<uint64_t*>(smem + (size_t)cap * 8);
@@ -249,6 +253,19 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
   const uint32_t lane = t & 63;
   const uint32_t s = sg.sketch_size;
   const bool fastroll = k <= 28;  // 2k+8 bits fit the 64-bit extended window
+
+  // Sketch sizes beyond one LDS buffer are selected in passes of ascending hash ranges: pass p only
+  // admits hashes above the largest one kept so far (lo1 = that hash + 1; 0 in the first pass).
+  uint64_t lo1 = 0;
+  if (pass_no > 0) {  // workgroup-uniform
+    const bool live = fin_cnt[sg.final_slot] == sg.expect;  // genome not exhausted by earlier passes
+    const uint64_t lo = live ? fin_out[sg.lo_off] : SENT;
+    if (!live || lo == SENT) {
+      if (t == 0 && cnt != fin_cnt) cnt[sg.cnt_slot] = 0;  // partial slot: nothing from this segment
+      return;
+    }
+    lo1 = lo + 1;
+  }
 
   if (t == 0) { ctrl->T = SENT; ctrl->count = 0; ctrl->overflow = 0; ctrl->saw_max = 0; ctrl->scan_base = 0; }
   build_kmer_lut(lut, k);
@@ -337,15 +354,20 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
             bool anyp = false;
             if (allok && T != SENT) {  // the steady state: one 64-bit compare per k-mer
 #pragma unroll
-              for (int b = 0; b < 4; b++) { pass[b] = h[b] < T; anyp |= pass[b]; }
+              for (int b = 0; b < 4; b++) pass[b] = h[b] < T;
             } else {
 #pragma unroll
               for (int b = 0; b < 4; b++) {
                 // T == SENT means "sketch not full yet": everything passes (also a hash == SENT)
                 pass[b] = ok[b] && (h[b] < T || T == SENT);
-                anyp |= pass[b];
               }
             }
+            if (lo1) {  // workgroup-uniform: later passes of a large sketch
+#pragma unroll
+              for (int b = 0; b < 4; b++) pass[b] = pass[b] && h[b] >= lo1;
+            }
+#pragma unroll
+            for (int b = 0; b < 4; b++) anyp |= pass[b];
             if (__any(anyp)) {
 #pragma unroll
               for (int b = 0; b < 4; b++) {
@@ -390,7 +412,8 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
   for (uint32_t i = t; i < n; i += WG) o[i] = buf[i];
   if (t == 0) {
     if (ctrl->saw_max && n < s) { o[n] = SENT; n++; }
-    cnt[sg.cnt_slot] = n;
+    // direct segments accumulate over passes; partial slots hold this pass's count only
+    cnt[sg.cnt_slot] = (pass_no > 0 && cnt == fin_cnt) ? sg.expect + n : n;
   }
 }
 
@@ -403,20 +426,23 @@ struct MergeJob {
   uint32_t cnt_slot;
   uint32_t sketch_size;
   uint32_t stride;
+  uint32_t expect;     // hashes the genome holds from earlier passes (0 in the first pass)
+  uint32_t pass;
   uint32_t pad;
 };
 
 __global__ __launch_bounds__(WG) void merge_partials_kernel(const MergeJob* __restrict__ jobs,
                                                             const uint64_t* __restrict__ parts,
                                                             const uint32_t* __restrict__ pcnt, int cap,
-                                                            uint64_t* __restrict__ out,
-                                                            uint32_t* __restrict__ cnt) {
+                                                            uint64_t* out,
+                                                            uint32_t* cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
   Ctrl* ctrl = reinterpret_cast<Ctrl*>(smem + (size_t)cap * 8);
   const MergeJob jb = jobs[blockIdx.x];
   const int t = threadIdx.x;
   const uint32_t s = jb.sketch_size;
+  if (jb.pass > 0 && cnt[jb.cnt_slot] != jb.expect) return;  // genome exhausted by earlier passes
   if (t == 0) { ctrl->T = SENT; ctrl->count = 0; ctrl->overflow = 0; ctrl->saw_max = 0; ctrl->scan_base = 0; }
   __syncthreads();
   uint32_t nmerged = 0;
@@ -440,7 +466,7 @@ __global__ __launch_bounds__(WG) void merge_partials_kernel(const MergeJob* __re
   for (uint32_t i = t; i < n; i += WG) o[i] = buf[i];
   if (t == 0) {
     if (ctrl->saw_max && n < s) { o[n] = SENT; n++; }
-    cnt[jb.cnt_slot] = n;
+    cnt[jb.cnt_slot] = jb.expect + n;
   }
 }
 
@@ -464,13 +490,18 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     if (s > stride) return rtc_fail(ctx, RTC_ERR_ARG, "sketch size %u of genome %u exceeds stride %u", s, g, stride);
     smax = std::max(smax, s);
   }
+  // One pass selects up to CHUNK hashes per genome in LDS; larger sketches take ceil(s/CHUNK) passes
+  // over ascending hash ranges (pass p admits only hashes above everything kept so far).
+  const uint32_t CHUNK = 6144;
+  const uint32_t chunk_max = std::min(smax, CHUNK);
+  const uint32_t npass = smax == 0 ? 1 : (smax + CHUNK - 1) / CHUNK;
   // candidate buffer of the sketch kernel: s + room; of the partial-merge kernel: two s-lists
-  const int cap = pow2ceil((int)(smax + MIN_ROOM));
-  const int cap_merge = pow2ceil((int)std::max<uint32_t>(2 * smax, 1024));
+  const int cap = pow2ceil((int)(chunk_max + MIN_ROOM));
+  const int cap_merge = pow2ceil((int)std::max<uint32_t>(2 * chunk_max, 1024));
   const size_t lds = (size_t)cap * 8 + lut_bytes(k) + sizeof(Ctrl);
   const size_t lds_m = (size_t)cap_merge * 8 + sizeof(Ctrl);
   if (lds > (size_t)160 * 1024 || lds_m > (size_t)160 * 1024)
-    return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "sketch size %u needs %zu B of LDS (> 160 KiB); the GPU path takes sizes up to 6144", smax, std::max(lds, lds_m));
+    return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "sketch chunk %u needs %zu B of LDS (> 160 KiB)", chunk_max, std::max(lds, lds_m));
 
   // ---- plan segments ----
   uint64_t total = 0;
@@ -482,79 +513,88 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   uint64_t seg_len = total / target_segs;
   const uint64_t min_seg = 8ull * TILE_BASES;
   if (seg_len < min_seg) seg_len = min_seg;
-  std::vector<Segment> segs;
-  std::vector<MergeJob> jobs;
-  segs.reserve(n + 1024);
-  uint64_t part_elems = 0;
-  uint32_t part_slots = 0;
-  for (uint32_t g = 0; g < n; g++) {
-    const uint64_t b = h_off[g], e = h_off[g + 1], len = e - b;
-    const uint32_t s = h_sizes ? h_sizes[g] : size;
-    uint64_t ns = (len + seg_len / 2) / seg_len;
-    if (ns < 1) ns = 1;
-    if (ns > 4096) ns = 4096;
-    if (ns == 1) {
-      segs.push_back(Segment{b, e, b, e, (uint64_t)g * stride, g, s});
-    } else {
-      MergeJob jb{part_elems, part_slots, (uint32_t)ns, (uint64_t)g * stride, g, s, stride, 0};
-      for (uint64_t i = 0; i < ns; i++) {
-        uint64_t sb = b + len * i / ns, se = b + len * (i + 1) / ns;
-        // partial sketches live in scratch: offsets are relative to the partial buffer and
-        // flagged by cnt_slot >= n (resolved below)
-        segs.push_back(Segment{b, e, sb, se, part_elems, n + part_slots, s});
-        part_elems += stride;
-        part_slots++;
-      }
-      jobs.push_back(jb);
-    }
-  }
-  // Partial outputs and final outputs use different base pointers: launch the kernel twice over
-  // disjoint segment lists (direct-to-output first, partials second) to keep the kernel simple.
+
+  struct PassPlan { size_t direct0, ndirect, partial0, npartial, job0, njobs; };
+  std::vector<PassPlan> plans(npass);
   std::vector<Segment> direct, partial;
-  for (const Segment& sgm : segs) {
-    if (sgm.cnt_slot < n) direct.push_back(sgm);
-    else { Segment p = sgm; p.cnt_slot -= n; partial.push_back(p); }
+  std::vector<MergeJob> jobs;
+  uint64_t part_elems_max = 0;
+  uint32_t part_slots_max = 0;
+  for (uint32_t ps = 0; ps < npass; ps++) {
+    PassPlan& pl = plans[ps];
+    pl.direct0 = direct.size(); pl.partial0 = partial.size(); pl.job0 = jobs.size();
+    uint64_t part_elems = 0;
+    uint32_t part_slots = 0;
+    for (uint32_t g = 0; g < n; g++) {
+      const uint64_t b = h_off[g], e = h_off[g + 1], len = e - b;
+      const uint32_t sg_full = h_sizes ? h_sizes[g] : size;
+      if (ps > 0 && sg_full <= ps * CHUNK) continue;  // this genome's sketch is complete
+      const uint32_t s = std::min(CHUNK, sg_full - ps * CHUNK);
+      const uint32_t expect = ps * CHUNK;
+      const uint64_t out_off = (uint64_t)g * stride + expect;
+      const uint64_t lo_off = ps ? out_off - 1 : 0;
+      uint64_t ns = (len + seg_len / 2) / seg_len;
+      if (ns < 1) ns = 1;
+      if (ns > 4096) ns = 4096;
+      if (ns == 1) {
+        direct.push_back(Segment{b, e, b, e, out_off, lo_off, g, s, g, expect});
+      } else {
+        jobs.push_back(MergeJob{part_elems, part_slots, (uint32_t)ns, out_off, g, s, chunk_max, expect, ps, 0});
+        for (uint64_t i = 0; i < ns; i++) {
+          const uint64_t sb = b + len * i / ns, se = b + len * (i + 1) / ns;
+          partial.push_back(Segment{b, e, sb, se, part_elems, lo_off, part_slots, s, g, expect});
+          part_elems += chunk_max;
+          part_slots++;
+        }
+      }
+    }
+    pl.ndirect = direct.size() - pl.direct0; pl.npartial = partial.size() - pl.partial0; pl.njobs = jobs.size() - pl.job0;
+    part_elems_max = std::max(part_elems_max, part_elems);
+    part_slots_max = std::max(part_slots_max, part_slots);
   }
-  const size_t bseg = (direct.size() + partial.size()) * sizeof(Segment);
+  const size_t bdir = direct.size() * sizeof(Segment), bpar = partial.size() * sizeof(Segment);
   const size_t bjobs = jobs.size() * sizeof(MergeJob);
   void* ws0 = nullptr;
-  RTC_TRY(rtc_ws(ctx, 0, bseg + bjobs + 64, &ws0));
+  RTC_TRY(rtc_ws(ctx, 0, bdir + bpar + bjobs + 64, &ws0));
   Segment* d_direct = (Segment*)ws0;
-  Segment* d_partial = d_direct + direct.size();
-  MergeJob* d_jobs = (MergeJob*)((char*)ws0 + bseg);
+  Segment* d_partial = (Segment*)((char*)ws0 + bdir);
+  MergeJob* d_jobs = (MergeJob*)((char*)ws0 + bdir + bpar);
   void* hp = nullptr;
-  RTC_TRY(rtc_pinned(ctx, bseg + bjobs + 64, &hp));
+  RTC_TRY(rtc_pinned(ctx, bdir + bpar + bjobs + 64, &hp));
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pinned staging may still be in flight
-  memcpy(hp, direct.data(), direct.size() * sizeof(Segment));
-  memcpy((char*)hp + direct.size() * sizeof(Segment), partial.data(), partial.size() * sizeof(Segment));
-  memcpy((char*)hp + bseg, jobs.data(), bjobs);
-  RTC_HIP(ctx, hipMemcpyAsync(ws0, hp, bseg + bjobs, hipMemcpyHostToDevice, ctx->stream));
+  memcpy(hp, direct.data(), bdir);
+  memcpy((char*)hp + bdir, partial.data(), bpar);
+  memcpy((char*)hp + bdir + bpar, jobs.data(), bjobs);
+  RTC_HIP(ctx, hipMemcpyAsync(ws0, hp, bdir + bpar + bjobs, hipMemcpyHostToDevice, ctx->stream));
 
   uint64_t* d_parts = nullptr;
   uint32_t* d_pcnt = nullptr;
   if (!partial.empty()) {
     void* ws1 = nullptr;
-    RTC_TRY(rtc_ws(ctx, 1, part_elems * 8 + (size_t)part_slots * 4 + 64, &ws1));
+    RTC_TRY(rtc_ws(ctx, 1, part_elems_max * 8 + (size_t)part_slots_max * 4 + 64, &ws1));
     d_parts = (uint64_t*)ws1;
-    d_pcnt = (uint32_t*)((char*)ws1 + part_elems * 8);
+    d_pcnt = (uint32_t*)((char*)ws1 + part_elems_max * 8);
   }
 
   auto kern = k == 21 ? sketch_minhash_kernel<21> : sketch_minhash_kernel<0>;
   RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (!direct.empty()) {
-    hipLaunchKernelGGL(kern, dim3((uint32_t)direct.size()), dim3(WG), lds, ctx->stream,
-                       d_seq, d_direct, k, seed, cap, d_out, d_cnt);
-    RTC_CHECK_LAUNCH(ctx);
-  }
-  if (!partial.empty()) {
-    hipLaunchKernelGGL(kern, dim3((uint32_t)partial.size()), dim3(WG), lds, ctx->stream,
-                       d_seq, d_partial, k, seed, cap, d_parts, d_pcnt);
-    RTC_CHECK_LAUNCH(ctx);
-    RTC_HIP(ctx, hipFuncSetAttribute((const void*)merge_partials_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-    hipLaunchKernelGGL(merge_partials_kernel, dim3((uint32_t)jobs.size()), dim3(WG), lds_m, ctx->stream,
-                       d_jobs, d_parts, d_pcnt, cap_merge, d_out, d_cnt);
-    RTC_CHECK_LAUNCH(ctx);
+  RTC_HIP(ctx, hipFuncSetAttribute((const void*)merge_partials_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+  for (uint32_t ps = 0; ps < npass; ps++) {
+    const PassPlan& pl = plans[ps];
+    if (pl.ndirect) {
+      hipLaunchKernelGGL(kern, dim3((uint32_t)pl.ndirect), dim3(WG), lds, ctx->stream, d_seq, d_direct + pl.direct0, k,
+                         seed, cap, d_out, d_cnt, (int)ps, (const uint64_t*)d_out, (const uint32_t*)d_cnt);
+      RTC_CHECK_LAUNCH(ctx);
+    }
+    if (pl.npartial) {
+      hipLaunchKernelGGL(kern, dim3((uint32_t)pl.npartial), dim3(WG), lds, ctx->stream, d_seq, d_partial + pl.partial0, k,
+                         seed, cap, d_parts, d_pcnt, (int)ps, (const uint64_t*)d_out, (const uint32_t*)d_cnt);
+      RTC_CHECK_LAUNCH(ctx);
+      hipLaunchKernelGGL(merge_partials_kernel, dim3((uint32_t)pl.njobs), dim3(WG), lds_m, ctx->stream,
+                         d_jobs + pl.job0, d_parts, d_pcnt, cap_merge, d_out, d_cnt);
+      RTC_CHECK_LAUNCH(ctx);
+    }
   }
   return RTC_OK;
 }

@@ -114,14 +114,42 @@ def test_synth_device_matches_oracle(ctx, oracle):
         assert np.array_equal(ref, seq[int(off[g]):int(off[g + 1])]), g
 
 
-def test_sketch_size_beyond_lds_fails_loudly(ctx):
-    from rabbittclust_amd import RtcError
+def test_sketch_size_beyond_one_lds_pass(ctx, oracle):
+    """Sketch sizes above 6144 are selected in passes over ascending hash ranges: same bottom-s set."""
+    rng = np.random.default_rng(31)
+    # short (exhausted in pass 0), exhausted mid-pass, exactly-full, long single-segment and multi-segment genomes
+    lens = [3000, 6164, 9000, 12308, 40_000, 700_000, 0, 25]
+    seq, off = _random_genomes(rng, lens, n_rate=0.001, lower_rate=0.1)
+    _check(ctx, oracle, seq, off, 21, size=8000)
+    _check(ctx, oracle, seq, off, 21, size=6145)
+    _check(ctx, oracle, seq, off, 21, size=12288)
+    _check(ctx, oracle, seq, off, 17, size=20000)
+    sizes = np.array([100, 7000, 20000, 6144, 6145, 13000, 9000, 8000], dtype=np.uint32)
+    _check(ctx, oracle, seq, off, 21, sizes=sizes)
+
+
+def test_sketch_large_size_multi_segment(ctx, oracle):
+    """One large genome split into segments, several passes, partial-sketch merge per pass."""
+    rng = np.random.default_rng(32)
+    seq, off = _random_genomes(rng, [6_000_000, 50_000], n_rate=0.0005)
+    _check(ctx, oracle, seq, off, 21, size=15000)
+    # low-complexity genome: few distinct k-mers, exhausted before the last pass
+    rep = np.tile(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=7001), 300)
+    off2 = np.array([0, len(rep)], dtype=np.uint64)
+    _check(ctx, oracle, rep, off2, 21, size=20000)
+
+
+def test_sketch_stride_smaller_than_size_fails_loudly(ctx):
+    from rabbittclust_amd import _lib
+    import torch
     seq = np.frombuffer(b"ACGT" * 1000, dtype=np.uint8)
     d = ctx.upload_sequences(seq)
     off = np.array([0, len(seq)], dtype=np.uint64)
-    with pytest.raises(RtcError) as ei:
-        ctx.sketch_minhash(d, off, k=21, size=20000)
-    assert ei.value.status == 3  # RTC_ERR_UNSUPPORTED: no silent fallback
+    out = torch.empty(100, dtype=torch.int64, device=ctx.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+    st = ctx.lib.rtc_sketch_minhash_dev(ctx.h, d.data_ptr(), off.ctypes.data, 1, 21, 42, None, 1000,
+                                        out.data_ptr(), 100, cnt.data_ptr())
+    assert st == _lib.RTC_ERR_ARG
 
 
 def test_sketch_many_tiny_genomes_and_max_size(ctx, oracle):
