@@ -45,6 +45,10 @@ int rtc_dev_free(rtc_ctx* ctx, void* d_ptr);
 int rtc_copy_h2d(rtc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* synchronous */
 int rtc_copy_d2h(rtc_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* synchronous */
 int rtc_memset_dev(rtc_ctx* ctx, void* d_ptr, int value, size_t bytes);
+/* page-locked host staging memory: the CLI parses FASTA files straight into it (the reference's
+ * per-thread kseq buffers, src/SketchInfo.cpp:880-948) so the PCIe copy runs at link speed */
+int rtc_host_alloc(rtc_ctx* ctx, size_t bytes, void** h_ptr);
+int rtc_host_free(rtc_ctx* ctx, void* h_ptr);
 
 /* ---- timing of the last launches (HIP events on the context stream) -------------------- */
 /* Brackets subsequently enqueued work; rtc_timer_stop synchronises and returns milliseconds. */

@@ -113,6 +113,7 @@ int rtc_dev_alloc(rtc_ctx* ctx, size_t bytes, void** d_ptr) {
   if (!ctx || !d_ptr) return RTC_ERR_ARG;
   *d_ptr = nullptr;
   if (bytes == 0) bytes = 16;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));  // the current device is per host thread
   hipError_t e = hipMalloc(d_ptr, bytes);
   if (e != hipSuccess) return rtc_fail(ctx, RTC_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
   return RTC_OK;
@@ -124,9 +125,26 @@ int rtc_dev_free(rtc_ctx* ctx, void* d_ptr) {
   return RTC_OK;
 }
 
+int rtc_host_alloc(rtc_ctx* ctx, size_t bytes, void** h_ptr) {
+  if (!ctx || !h_ptr) return RTC_ERR_ARG;
+  *h_ptr = nullptr;
+  if (bytes == 0) bytes = 16;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipHostMalloc(h_ptr, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) return rtc_fail(ctx, RTC_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  return RTC_OK;
+}
+
+int rtc_host_free(rtc_ctx* ctx, void* h_ptr) {
+  if (!ctx) return RTC_ERR_ARG;
+  if (h_ptr) RTC_HIP(ctx, hipHostFree(h_ptr));
+  return RTC_OK;
+}
+
 int rtc_copy_h2d(rtc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
   if (!ctx || (bytes && (!d_dst || !h_src))) return RTC_ERR_ARG;
   if (!bytes) return RTC_OK;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
   RTC_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RTC_OK;
@@ -135,6 +153,7 @@ int rtc_copy_h2d(rtc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
 int rtc_copy_d2h(rtc_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
   if (!ctx || (bytes && (!h_dst || !d_src))) return RTC_ERR_ARG;
   if (!bytes) return RTC_OK;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
   RTC_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RTC_OK;

@@ -278,6 +278,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   if (!ctx || !h_off || !h_shuffled_dim || !width_out || (n && (!d_seq || !d_out || !d_cnt))) return RTC_ERR_ARG;
   if (kmer_size < 2 || kmer_size > 32) return rtc_fail(ctx, RTC_ERR_ARG, "kmer_size=%d outside 2..32", kmer_size);
   if (drlevel < 0 || drlevel > 8) return rtc_fail(ctx, RTC_ERR_ARG, "drlevel=%d outside 0..8", drlevel);
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
   // src/SketchInfo.cpp:1019-1048
   const int half_k = (kmer_size + 1) / 2;
   const int K = half_k * 2;

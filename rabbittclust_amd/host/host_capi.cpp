@@ -81,4 +81,25 @@ int rtch_cal_size(const char* list_file, uint64_t minLen, uint64_t* mx, uint64_t
 }
 
 int rtch_file_length(const char* path) { return file_length_for_containment(path); }
+
+// The two genome readers of the sketch driver: mode 0 = read_genome_file (std::string), mode 1 =
+// read_genome_file_flat into out[0..cap).  Writes the byte stream (records joined by '\n'), returns
+// its length (the needed capacity when cap is too small for mode 1), -1 if the file cannot be opened.
+long rtch_genome_bases(const char* path, int flat, char* out, long cap, uint64_t* total, uint64_t* nrec, int* first_len,
+                       uint64_t* slot) {
+  SequenceInfo first;
+  *slot = genome_slot_bytes(path);
+  if (flat) {
+    uint64_t used = 0;
+    const int st = read_genome_file_flat(path, out, (uint64_t)cap, used, first, *total, *nrec);
+    if (st == 1) return -1;
+    *first_len = first.length;
+    return (long)used;
+  }
+  std::string bases;
+  if (!read_genome_file(path, bases, first, *total, *nrec)) return -1;
+  *first_len = first.length;
+  if ((long)bases.size() <= cap) memcpy(out, bases.data(), bases.size());
+  return (long)bases.size();
+}
 }

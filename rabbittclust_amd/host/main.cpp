@@ -13,12 +13,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/time.h>
 
 #include <algorithm>
 #include <fstream>
 #include <iostream>
 #include <numeric>
+#include <thread>
 
 #include "rtc_host.h"
 
@@ -78,129 +80,253 @@ struct SketchJob {
   int drlevel = 3; uint64_t minLen = 10000; int threads = 1;
 };
 
+// One batch of consecutive list entries: file f gets the slot [slot_off, slot_off + slot_len) of the
+// page-locked staging buffer; parser threads write the bases straight into it.
+static char* alloc_pageable(size_t bytes) {  // 2 MiB-aligned, transparent huge pages if the host allows
+  void* p = nullptr;
+  if (posix_memalign(&p, (size_t)2 << 20, bytes) != 0) return nullptr;
+  madvise(p, bytes, MADV_HUGEPAGE);
+  return (char*)p;
+}
+
+struct Batch { vector<size_t> files; vector<uint64_t> slot_off, slot_len; uint64_t bytes = 0; };
+
+struct FileResult {           // indexed by list position, so late (retried) files keep list order
+  SequenceInfo first; uint64_t total = 0; int flen = 0; bool kept = false;
+  vector<uint64_t> h64; vector<uint32_t> h32;
+};
+
 static void sketch_files(rtc_ctx* ctx, const string& inputFile, const SketchJob& job, vector<GenomeInfo>& genomes,
                          MinHashSketchFile* mh, KssdSketchFile* ks) {
+  const double tp00 = get_sec();
   const vector<string> fileList = read_list(inputFile);
-  const size_t BATCH_BYTES = (size_t)3 << 30;
+  const size_t nfiles = fileList.size();
+  const bool verbose = getenv("RTC_VERBOSE") != nullptr;
+  uint64_t BATCH_BYTES = (uint64_t)1 << 30;  // measured best on a 16-core quota: 0.5-1 GiB
+  if (const char* e = getenv("RTC_BATCH_BYTES")) BATCH_BYTES = std::max<uint64_t>(strtoull(e, nullptr, 10), 1 << 20);
   vector<int32_t> shuffled;
+  std::thread shuffle_thread;  // the 2^24-entry glibc-rand shuffle takes ~0.7 s: built while batch 0 is parsed
   int half_subk = 6;
   if (job.kssd) {
     const int half_k = (job.kmerSize + 1) / 2;
     half_subk = 6 - job.drlevel >= 2 ? 6 : job.drlevel + 2;
-    shuffled = generate_shuffle_dim(half_subk);
+    shuffle_thread = std::thread([&shuffled, half_subk]() { shuffled = generate_shuffle_dim(half_subk); });
     ks->info.half_k = half_k; ks->info.half_subk = half_subk; ks->info.drlevel = job.drlevel;
     ks->info.id = (half_k << 8) + (half_subk << 4) + job.drlevel;        // :1030
     ks->info.genomeNumber = (int)fileList.size();                         // :1031
     ks->use64 = half_k - job.drlevel > 8;
   }
-  size_t next = 0;
-  while (next < fileList.size()) {
-    // ---- parse a batch on the host ----
-    const double tb0 = get_sec();
-    vector<string> bases; vector<SequenceInfo> firsts; vector<uint64_t> totals; vector<int> flens; vector<size_t> idx;
-    size_t bytes = 0, end = next;
-    while (end < fileList.size() && (bytes < BATCH_BYTES || end == next)) {
-      const size_t chunk = std::min(fileList.size() - end, (size_t)std::max(job.threads * 4, 16));
-      const size_t base = bases.size();
-      bases.resize(base + chunk); firsts.resize(base + chunk); totals.resize(base + chunk); flens.resize(base + chunk);
-#pragma omp parallel for num_threads(job.threads) schedule(dynamic)
-      for (long i = 0; i < (long)chunk; i++) {
-        uint64_t nrec = 0;
-        if (!read_genome_file(fileList[end + i], bases[base + i], firsts[base + i], totals[base + i], nrec)) {
-          fprintf(stderr, "cannot open the genome file: %s\n", fileList[end + i].c_str());
-          exit(1);
-        }
-        flens[base + i] = job.isContainment ? file_length_for_containment(fileList[end + i]) : 0;
-      }
-      for (size_t i = 0; i < chunk; i++) { idx.push_back(end + i); bytes += bases[base + i].size(); }
-      end += chunk;
+  const bool use64 = job.kssd ? ks->use64 : true;
+  if (verbose) fprintf(stderr, "[init]  list + shuffle table in %.3fs\n", get_sec() - tp00);
+
+  // ---- slot sizes (upper bound of the bases a file yields), batches of ~BATCH_BYTES ----
+  const double tp0 = get_sec();
+  vector<uint64_t> slot(nfiles);
+  vector<FileResult> res(nfiles);
+#pragma omp parallel for num_threads(job.threads) schedule(dynamic, 16)
+  for (long i = 0; i < (long)nfiles; i++) {
+    slot[i] = genome_slot_bytes(fileList[i]);
+    res[i].flen = job.isContainment ? file_length_for_containment(fileList[i]) : 0;
+  }
+  for (size_t i = 0; i < nfiles; i++)
+    if (slot[i] == 0) { fprintf(stderr, "cannot open the genome file: %s\n", fileList[i].c_str()); exit(1); }
+  auto plan = [&](const vector<size_t>& files, const vector<uint64_t>& need) {
+    vector<Batch> out;
+    for (size_t q = 0; q < files.size(); q++) {
+      if (out.empty() || (out.back().bytes + need[q] > BATCH_BYTES && !out.back().files.empty())) out.emplace_back();
+      Batch& b = out.back();
+      b.files.push_back(files[q]); b.slot_off.push_back(b.bytes); b.slot_len.push_back(need[q]);
+      b.bytes += need[q];
     }
-    // ---- filter (:963), pack, upload ----
-    const double tb1 = get_sec();
-    vector<uint64_t> off{0}; vector<uint32_t> sizes; vector<size_t> kept;
-    for (size_t i = 0; i < idx.size(); i++) {
-      if (totals[i] < job.minLen) continue;
-      kept.push_back(i);
-      off.push_back(off.back() + bases[i].size());
-      sizes.push_back(job.isContainment ? (uint32_t)std::max(flens[i] / job.containCompress, 100) : (uint32_t)job.sketchSize);  // :919-924
+    return out;
+  };
+  vector<size_t> all(nfiles);
+  iota(all.begin(), all.end(), 0);
+  vector<Batch> batches = plan(all, slot);
+
+  // ---- staging: two page-locked host buffers and one device buffer, reused by every batch ----
+  uint64_t buf_bytes = 0;
+  char* stage[2] = {nullptr, nullptr};
+  void* d_seq = nullptr;
+  // Pageable staging by default: page-locking costs ~0.15 s/GB up front while the pageable PCIe copy
+  // already runs at > 30 GB/s on the MI355X hosts measured; RTC_STAGE_PINNED=1 page-locks instead.
+  bool pinned = getenv("RTC_STAGE_PINNED") != nullptr;
+  auto free_stage = [&]() {
+    for (int i = 0; i < 2; i++) {
+      if (stage[i] && pinned) CHECK(ctx, rtc_host_free(ctx, stage[i]));
+      else free(stage[i]);
+      stage[i] = nullptr;
+    }
+  };
+  auto ensure_buffers = [&](uint64_t need) {
+    if (need <= buf_bytes) return;
+    free_stage();
+    if (d_seq) CHECK(ctx, rtc_dev_free(ctx, d_seq));
+    buf_bytes = need;
+    for (int i = 0; i < 2; i++) {
+      if (pinned && rtc_host_alloc(ctx, buf_bytes + 64, (void**)&stage[i]) != RTC_OK) {
+        // the host refuses to page-lock this much (ulimit -l): stage through pageable memory instead
+        fprintf(stderr, "-----cannot page-lock %.2f GB (%s), staging through pageable memory\n", buf_bytes / 1e9, rtc_last_error(ctx));
+        free_stage();
+        pinned = false; i = -1;
+        continue;
+      }
+      if (!pinned && !(stage[i] = alloc_pageable(buf_bytes + 64))) { fprintf(stderr, "ERROR: cannot allocate %.2f GB of staging memory\n", buf_bytes / 1e9); exit(1); }
+    }
+    CHECK(ctx, rtc_dev_alloc(ctx, buf_bytes + 64, &d_seq));
+  };
+  uint64_t maxb = 0;
+  for (const Batch& b : batches) maxb = std::max(maxb, b.bytes);
+  ensure_buffers(maxb);
+  if (verbose) fprintf(stderr, "[plan] %zu files, %zu batches, staging 2 x %.2f GB, %.3fs\n", nfiles, batches.size(), buf_bytes / 1e9, get_sec() - tp0);
+
+  // ---- GPU side of one batch (runs on its own host thread while the next batch is parsed) ----
+  auto gpu_batch = [&](const Batch& b, const char* h_seq) {
+    const double t0 = get_sec();
+    vector<uint64_t> off; vector<uint32_t> sizes; vector<size_t> kept;
+    for (size_t q = 0; q < b.files.size(); q++) {
+      FileResult& r = res[b.files[q]];
+      if (!r.kept) continue;
+      kept.push_back(b.files[q]);
+      off.push_back(b.slot_off[q]);  // a genome extends to the next kept one: the gap holds only 'N'
+      sizes.push_back(job.isContainment ? (uint32_t)std::max(r.flen / job.containCompress, 100) : (uint32_t)job.sketchSize);  // :919-924
     }
     const uint32_t nb = (uint32_t)kept.size();
-    if (nb) {
-      // pack in parallel into an uninitialised buffer (first touch by the copying threads)
-      const size_t packed_size = off.back() + 64;
-      unsigned char* packed = (unsigned char*)malloc(packed_size);
-      if (!packed) { fprintf(stderr, "ERROR: cannot allocate %zu bytes for the sequence batch\n", packed_size); exit(1); }
-#pragma omp parallel for num_threads(job.threads) schedule(dynamic)
-      for (long g = 0; g < (long)nb; g++) {
-        memcpy(packed + off[g], bases[kept[g]].data(), bases[kept[g]].size());
-        string().swap(bases[kept[g]]);  // release as we go
-      }
-      memset(packed + off.back(), 'N', 64);
-      const double tb2 = get_sec();
-      void* d_seq = nullptr;
-      CHECK(ctx, rtc_dev_alloc(ctx, packed_size, &d_seq));
-      CHECK(ctx, rtc_copy_h2d(ctx, d_seq, packed, packed_size));
-      free(packed);
-      const double tb3 = get_sec();
-      if (getenv("RTC_VERBOSE")) fprintf(stderr, "[batch] parse %.3fs pack %.3fs alloc+h2d %.3fs (%.2f GB)\n", tb1 - tb0, tb2 - tb1, tb3 - tb2, packed_size / 1e9);
-      uint32_t* d_cnt = nullptr;
-      CHECK(ctx, rtc_dev_alloc(ctx, (size_t)nb * 4, (void**)&d_cnt));
-      vector<uint32_t> cnt(nb);
-      if (!job.kssd) {
-        const uint32_t stride = *std::max_element(sizes.begin(), sizes.end());
-        uint64_t* d_out = nullptr;
-        CHECK(ctx, rtc_dev_alloc(ctx, (size_t)nb * stride * 8, (void**)&d_out));
-        CHECK(ctx, rtc_sketch_minhash_dev(ctx, (const uint8_t*)d_seq, off.data(), nb, job.kmerSize, 42, sizes.data(), stride,
-                                          d_out, stride, d_cnt));
-        vector<uint64_t> out((size_t)nb * stride);
-        CHECK(ctx, rtc_copy_d2h(ctx, out.data(), d_out, out.size() * 8));
+    if (!nb) return;
+    off.push_back(b.bytes);
+    CHECK(ctx, rtc_copy_h2d(ctx, d_seq, h_seq, b.bytes + 64));
+    const double t1 = get_sec();
+    uint32_t* d_cnt = nullptr;
+    CHECK(ctx, rtc_dev_alloc(ctx, (size_t)nb * 4, (void**)&d_cnt));
+    vector<uint32_t> cnt(nb);
+    if (!job.kssd) {
+      const uint32_t stride = *std::max_element(sizes.begin(), sizes.end());
+      uint64_t* d_out = nullptr;
+      CHECK(ctx, rtc_dev_alloc(ctx, (size_t)nb * stride * 8, (void**)&d_out));
+      CHECK(ctx, rtc_sketch_minhash_dev(ctx, (const uint8_t*)d_seq, off.data(), nb, job.kmerSize, 42, sizes.data(), stride,
+                                        d_out, stride, d_cnt));
+      vector<uint64_t> out((size_t)nb * stride);
+      CHECK(ctx, rtc_copy_d2h(ctx, out.data(), d_out, out.size() * 8));
+      CHECK(ctx, rtc_copy_d2h(ctx, cnt.data(), d_cnt, (size_t)nb * 4));
+      for (uint32_t g = 0; g < nb; g++) res[kept[g]].h64.assign(out.begin() + (size_t)g * stride, out.begin() + (size_t)g * stride + cnt[g]);
+      CHECK(ctx, rtc_dev_free(ctx, d_out));
+    } else {
+      uint64_t maxlen = 0;
+      for (uint32_t g = 0; g < nb; g++) maxlen = std::max(maxlen, off[g + 1] - off[g]);
+      uint32_t stride = (uint32_t)(maxlen / (1ull << (4 * job.drlevel)) * 3 / 2 + 256);
+      const int w = use64 ? 8 : 4;
+      while (true) {
+        void* d_out = nullptr;
+        CHECK(ctx, rtc_dev_alloc(ctx, (size_t)nb * stride * w, &d_out));
+        int width = 0; uint32_t need = 0;
+        int st = rtc_sketch_kssd_dev(ctx, (const uint8_t*)d_seq, off.data(), nb, job.kmerSize, job.drlevel, shuffled.data(),
+                                     d_out, stride, d_cnt, &width, &need);
+        if (st == RTC_ERR_OVERFLOW) { CHECK(ctx, rtc_dev_free(ctx, d_out)); stride = need + 64; continue; }
+        CHECK(ctx, st);
         CHECK(ctx, rtc_copy_d2h(ctx, cnt.data(), d_cnt, (size_t)nb * 4));
-        for (uint32_t g = 0; g < nb; g++) mh->hashes.emplace_back(out.begin() + (size_t)g * stride, out.begin() + (size_t)g * stride + cnt[g]);
-        CHECK(ctx, rtc_dev_free(ctx, d_out));
-      } else {
-        uint64_t maxlen = 0;
-        for (uint32_t g = 0; g < nb; g++) maxlen = std::max(maxlen, off[g + 1] - off[g]);
-        uint32_t stride = (uint32_t)(maxlen / (1ull << (4 * job.drlevel)) * 3 / 2 + 256);
-        const int w = ks->use64 ? 8 : 4;
-        while (true) {
-          void* d_out = nullptr;
-          CHECK(ctx, rtc_dev_alloc(ctx, (size_t)nb * stride * w, &d_out));
-          int width = 0; uint32_t need = 0;
-          int st = rtc_sketch_kssd_dev(ctx, (const uint8_t*)d_seq, off.data(), nb, job.kmerSize, job.drlevel, shuffled.data(),
-                                       d_out, stride, d_cnt, &width, &need);
-          if (st == RTC_ERR_OVERFLOW) { CHECK(ctx, rtc_dev_free(ctx, d_out)); stride = need + 64; continue; }
-          CHECK(ctx, st);
-          CHECK(ctx, rtc_copy_d2h(ctx, cnt.data(), d_cnt, (size_t)nb * 4));
-          vector<unsigned char> out((size_t)nb * stride * w);
-          CHECK(ctx, rtc_copy_d2h(ctx, out.data(), d_out, out.size()));
-          for (uint32_t g = 0; g < nb; g++) {
-            if (ks->use64) { const uint64_t* p = (const uint64_t*)out.data() + (size_t)g * stride; ks->h64.emplace_back(p, p + cnt[g]); }
-            else { const uint32_t* p = (const uint32_t*)out.data() + (size_t)g * stride; ks->h32.emplace_back(p, p + cnt[g]); }
-          }
-          CHECK(ctx, rtc_dev_free(ctx, d_out));
-          break;
+        vector<unsigned char> out((size_t)nb * stride * w);
+        CHECK(ctx, rtc_copy_d2h(ctx, out.data(), d_out, out.size()));
+        for (uint32_t g = 0; g < nb; g++) {
+          if (use64) { const uint64_t* p = (const uint64_t*)out.data() + (size_t)g * stride; res[kept[g]].h64.assign(p, p + cnt[g]); }
+          else { const uint32_t* p = (const uint32_t*)out.data() + (size_t)g * stride; res[kept[g]].h32.assign(p, p + cnt[g]); }
         }
-      }
-      CHECK(ctx, rtc_dev_free(ctx, d_cnt));
-      CHECK(ctx, rtc_dev_free(ctx, d_seq));
-      for (uint32_t g = 0; g < nb; g++) {
-        GenomeInfo gi;
-        gi.id = (int)genomes.size();                                        // :964-965 (list order here)
-        gi.fileName = fileList[idx[kept[g]]];
-        gi.totalSeqLength = totals[kept[g]];
-        gi.seq0 = firsts[kept[g]];
-        gi.use64 = job.kssd ? ks->use64 : false;
-        genomes.push_back(std::move(gi));
+        CHECK(ctx, rtc_dev_free(ctx, d_out));
+        break;
       }
     }
-    for (size_t i = next; i < end; i++) if (i % 10000 == 0) cerr << "---finished sketching: " << i << " genomes" << endl;
-    next = end;
+    CHECK(ctx, rtc_dev_free(ctx, d_cnt));
+    if (verbose) fprintf(stderr, "[gpu]   %u genomes, %.2f GB: h2d %.3fs sketch+d2h %.3fs\n", nb, b.bytes / 1e9, t1 - t0, get_sec() - t1);
+  };
+
+  // ---- pipeline: parse batch i into stage[i&1] while the GPU thread works on batch i-1 ----
+  vector<size_t> retry_files; vector<uint64_t> retry_need;
+  std::thread worker;
+  size_t done_files = 0, bi = 0;
+  for (int round = 0; round < 2; round++) {  // round 1: files whose slot guess was too small (gzip ISIZE)
+    for (const Batch& b : batches) {
+      const double t0 = get_sec();
+      char* buf = stage[bi & 1];
+      vector<uint64_t> need(b.files.size(), 0);
+#pragma omp parallel for num_threads(job.threads) schedule(dynamic)
+      for (long q = 0; q < (long)b.files.size(); q++) {
+        FileResult& r = res[b.files[q]];
+        uint64_t used = 0, nrec = 0;
+        char* dst = buf + b.slot_off[q];
+        const int st = read_genome_file_flat(fileList[b.files[q]], dst, b.slot_len[q], used, r.first, r.total, nrec);
+        if (st == 1) { fprintf(stderr, "cannot open the genome file: %s\n", fileList[b.files[q]].c_str()); exit(1); }
+        if (st == 2) { need[q] = used + 1; used = 0; r.kept = false; }
+        else r.kept = r.total >= job.minLen;                                 // :963
+        if (!r.kept) used = 0;
+        memset(dst + used, 'N', b.slot_len[q] - used);  // no k-mers in the gap, nor in dropped genomes
+      }
+      memset(buf + b.bytes, 'N', 64);
+      for (size_t q = 0; q < b.files.size(); q++) if (need[q]) { retry_files.push_back(b.files[q]); retry_need.push_back(need[q]); }
+      if (verbose) fprintf(stderr, "[parse] batch %zu: %zu files, %.2f GB in %.3fs\n", bi, b.files.size(), b.bytes / 1e9, get_sec() - t0);
+      if (worker.joinable()) worker.join();
+      if (shuffle_thread.joinable()) shuffle_thread.join();
+      const Batch* bp = &b;
+      worker = std::thread([&gpu_batch, bp, buf]() { gpu_batch(*bp, buf); });
+      for (size_t q = 0; q < b.files.size(); q++, done_files++) if (done_files % 10000 == 0) cerr << "---finished sketching: " << done_files << " genomes" << endl;
+      bi++;
+    }
+    if (worker.joinable()) worker.join();
+    if (round == 1 || retry_files.empty()) break;
+    batches = plan(retry_files, retry_need);
+    maxb = 0;
+    for (const Batch& b : batches) maxb = std::max(maxb, b.bytes);
+    ensure_buffers(maxb);
+    done_files -= retry_files.size();
+    retry_files.clear(); retry_need.clear();
   }
+  if (shuffle_thread.joinable()) shuffle_thread.join();
+  const double tf0 = get_sec();
+  if (pinned) free_stage();
+  else {  // returning GBs of touched pages to the kernel takes a while: do it beside the clustering
+    char* s0 = stage[0]; char* s1 = stage[1];
+    stage[0] = stage[1] = nullptr;
+    std::thread([s0, s1]() { free(s0); free(s1); }).detach();
+  }
+  // The device staging buffer stays allocated until the process ends: hipFree of a multi-GB buffer
+  // costs ~0.4 s here and the clustering phase needs far less than the 288 GB that are there.
+  (void)d_seq;
+  if (verbose) fprintf(stderr, "[free]  host staging %.3fs\n", get_sec() - tf0);
+
+  // ---- assemble in list order ----
+  for (size_t i = 0; i < nfiles; i++) {
+    FileResult& r = res[i];
+    if (!r.kept) continue;
+    GenomeInfo gi;
+    gi.id = (int)genomes.size();                                        // :964-965 (list order here)
+    gi.fileName = fileList[i];
+    gi.totalSeqLength = r.total;
+    gi.seq0 = r.first;
+    gi.use64 = job.kssd ? ks->use64 : false;
+    genomes.push_back(std::move(gi));
+    if (!job.kssd) mh->hashes.push_back(std::move(r.h64));
+    else if (use64) ks->h64.push_back(std::move(r.h64));
+    else ks->h32.push_back(std::move(r.h32));
+  }
+}
+
+// "all CPUs of the platform" (src/main.cpp:75-76,113), bounded by what this process may actually
+// use: the affinity mask (omp_get_num_procs) and a cgroup-v2 CPU quota.  Oversubscribing a quota
+// makes the parser threads time-slice against each other.
+static int default_threads() {
+  int n = omp_get_num_procs();
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32] = {0}; long period = 0;
+    if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      const long quota = atol(q);
+      if (quota > 0) n = (int)std::min<long>(n, std::max<long>(1, (quota + period - 1) / period));
+    }
+    fclose(f);
+  }
+  return std::max(n, 1);
 }
 
 struct Options {
   string inputFile, outputFile, folder_path, premsted;
-  int threads = omp_get_num_procs();
+  int threads = default_threads();
   bool sketchByFile = false, noSave = false, is_fast = false, isContainment = false, isJaccard = false, isSetKmer = false;
   bool has_threshold = false, has_input = false, has_presketched = false, has_premsted = false, has_output = false;
   double threshold = 0.05;
@@ -327,6 +453,7 @@ int main(int argc, char** argv) {
     SketchJob job;
     job.kssd = o.is_fast; job.kmerSize = o.kmerSize; job.sketchSize = o.sketchSize; job.isContainment = o.isContainment;
     job.containCompress = o.containCompress; job.drlevel = o.drlevel; job.minLen = o.minLen; job.threads = o.threads;
+    if (getenv("RTC_VERBOSE")) fprintf(stderr, "[tune]  cal_size + tune_parameters in %.3fs\n", get_sec() - t0);
     sketch_files(ctx, o.inputFile, job, genomes, &mh, &ks);
     mh.kmerSize = o.kmerSize; mh.isContainment = o.isContainment; mh.containCompress = o.containCompress; mh.sketchSize = o.sketchSize;
     cerr << "-----the size of sketches (number of genomes or sequences) is: " << genomes.size() << endl;

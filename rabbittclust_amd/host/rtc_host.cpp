@@ -2,6 +2,9 @@
 #include "rtc_host.h"
 
 #include <ctype.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -30,18 +33,38 @@ namespace rtc {
 // =================================================================================================
 namespace {
 
+// Byte source: zlib for gzip files; plain files (no 1f 8b magic) are read with read(2) directly,
+// which yields the same bytes zlib's transparent mode would.
 class GzStream {
  public:
-  explicit GzStream(const std::string& path) { f_ = gzopen(path.c_str(), "r"); if (f_) gzbuffer(f_, 1 << 20); }
-  ~GzStream() { if (f_) gzclose(f_); }
-  bool ok() const { return f_ != nullptr; }
+  explicit GzStream(const std::string& path) {
+    fd_ = open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) return;
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got = pread(fd_, magic, 2, 0);
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+      f_ = gzdopen(fd_, "r");
+      if (!f_) { close(fd_); fd_ = -1; return; }
+      gzbuffer(f_, 1 << 20);
+    }
+    buf_ = (char*)malloc(BUF);
+  }
+  ~GzStream() {
+    if (f_) gzclose(f_);  // closes fd_ too
+    else if (fd_ >= 0) close(fd_);
+    free(buf_);
+  }
+  GzStream(const GzStream&) = delete;
+  GzStream& operator=(const GzStream&) = delete;
+  bool ok() const { return fd_ >= 0 && buf_; }
   int getc() {
     if (begin_ >= end_) { if (!fill()) return -1; }
     return (unsigned char)buf_[begin_++];
   }
   // appends to `s` up to (not including) the delimiter class; returns the delimiter char or -1 at EOF.
   // mode 0: isspace()  mode 2: '\n'.  *gotany reports whether the stream had any data left.
-  int get_until(int mode, std::string& s, bool append, bool* gotany) {
+  template <typename Sink>
+  int get_until(int mode, Sink& s, bool append, bool* gotany) {
     if (!append) s.clear();
     *gotany = false;
     int dret = -1;
@@ -61,50 +84,79 @@ class GzStream {
   bool eof() const { return eof_ && begin_ >= end_; }
 
  private:
+  static constexpr int BUF = 1 << 18;
   bool fill() {
     if (eof_) return false;
     begin_ = 0;
-    end_ = gzread(f_, buf_, sizeof buf_);
+    if (f_) end_ = gzread(f_, buf_, BUF);
+    else {
+      ssize_t r;
+      do { r = read(fd_, buf_, BUF); } while (r < 0 && errno == EINTR);
+      end_ = (int)r;
+    }
     if (end_ <= 0) { end_ = 0; eof_ = true; return false; }
     return true;
   }
+  int fd_ = -1;
   gzFile f_ = nullptr;
-  char buf_[1 << 16];
+  char* buf_ = nullptr;
   int begin_ = 0, end_ = 0;
   bool eof_ = false;
 };
 
+// Sequence sink over a caller-supplied flat buffer.  size()/back()/pop_back() are relative to the
+// current record, as kseq's seq.l is.  Writes beyond `cap` are dropped but still counted, so the
+// caller learns the capacity a retry needs.
+struct FlatSink {
+  char* base; size_t cap;
+  size_t pos = 0, rec = 0;
+  void clear() { rec = pos; }
+  void append(const char* p, size_t n) {
+    if (pos + n <= cap) memcpy(base + pos, p, n);
+    else if (pos < cap) memcpy(base + pos, p, cap - pos);
+    pos += n;
+  }
+  void push_back(char c) { if (pos < cap) base[pos] = c; pos++; }
+  size_t size() const { return pos - rec; }
+  char back() const { return pos - 1 < cap ? base[pos - 1] : 0; }
+  void pop_back() { pos--; }
+};
+
 // returns sequence length, -1 at EOF, -2 on truncated quality
-int next_record(GzStream& ks, int& last_char, FastaRecord& r) {
+template <typename Sink>
+int next_record_t(GzStream& ks, int& last_char, std::string& name, std::string& comment, bool& has_comment, Sink& seq) {
   int c;
   if (last_char == 0) {
     while ((c = ks.getc()) != -1 && c != '>' && c != '@') {}
     if (c == -1) return -1;
     last_char = c;
   }
-  r.comment.clear(); r.seq.clear(); r.has_comment = false;
+  comment.clear(); seq.clear(); has_comment = false;
   bool got;
-  int d = ks.get_until(0, r.name, false, &got);
+  int d = ks.get_until(0, name, false, &got);
   if (!got && ks.eof()) return -1;
-  if (d != '\n' && d != -1) { std::string cm; ks.get_until(2, cm, false, &got); r.comment = cm; r.has_comment = true; }
+  if (d != '\n' && d != -1) { ks.get_until(2, comment, false, &got); has_comment = true; }
   while ((c = ks.getc()) != -1 && c != '>' && c != '+' && c != '@') {
     if (c == '\n') continue;
-    r.seq.push_back((char)c);
-    ks.get_until(2, r.seq, true, &got);
+    seq.push_back((char)c);
+    ks.get_until(2, seq, true, &got);
   }
   if (c == '>' || c == '@') last_char = c;
-  if (c != '+') return (int)r.seq.size();
+  if (c != '+') return (int)seq.size();
   while ((c = ks.getc()) != -1 && c != '\n') {}
   if (c == -1) return -2;
   std::string qual;
   while (true) {
-    int dd = ks.get_until(2, qual, true, &got);
-    if ((!got && ks.eof()) || qual.size() >= r.seq.size()) break;
-    (void)dd;
+    ks.get_until(2, qual, true, &got);
+    if ((!got && ks.eof()) || qual.size() >= seq.size()) break;
   }
   last_char = 0;
-  if (qual.size() != r.seq.size()) return -2;
-  return (int)r.seq.size();
+  if (qual.size() != seq.size()) return -2;
+  return (int)seq.size();
+}
+
+int next_record(GzStream& ks, int& last_char, FastaRecord& r) {
+  return next_record_t(ks, last_char, r.name, r.comment, r.has_comment, r.seq);
 }
 
 }  // namespace
@@ -139,6 +191,52 @@ bool read_genome_file(const std::string& path, std::string& bases, SequenceInfo&
     n_records++;
   }
   return true;
+}
+
+uint64_t genome_slot_bytes(const std::string& path) {
+  struct stat st;
+  if (stat(path.c_str(), &st) != 0) return 0;
+  uint64_t sz = (uint64_t)st.st_size;
+  FILE* fp = fopen(path.c_str(), "rb");
+  if (!fp) return 0;
+  unsigned char magic[2] = {0, 0};
+  const bool gz = fread(magic, 1, 2, fp) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+  if (gz && sz >= 18) {
+    uint32_t isize = 0;
+    fseek(fp, -4, SEEK_END);
+    if (fread(&isize, 4, 1, fp) != 1) isize = 0;
+    sz = std::max<uint64_t>(isize, sz);  // single-member guess; the reader reports the exact need on overflow
+  }
+  fclose(fp);
+  return sz + 1;
+}
+
+int read_genome_file_flat(const std::string& path, char* dst, uint64_t cap, uint64_t& used, SequenceInfo& first,
+                          uint64_t& total_len, uint64_t& n_records) {
+  GzStream ks(path);
+  if (!ks.ok()) return 1;
+  int last_char = 0;
+  std::string name, comment;
+  bool has_comment = false;
+  FlatSink sink{dst, (size_t)cap};
+  total_len = 0; n_records = 0;
+  int len;
+  while ((len = next_record_t(ks, last_char, name, comment, has_comment, sink)) >= 0) {
+    total_len += (uint64_t)len;
+    if (n_records == 0) {
+      first.name = name;
+      first.comment = has_comment ? comment : std::string("noName");
+      first.strand = 0;
+      first.length = len;
+    }
+    sink.push_back('\n');
+    n_records++;
+  }
+  // a record that ends on a truncated quality block (-2) stops the reader like kseq_read() < 0 does;
+  // bases appended for it are not part of any returned record
+  if (len == -2) sink.pos = sink.rec;
+  used = sink.pos;
+  return sink.pos > cap ? 2 : 0;
 }
 
 // =================================================================================================
@@ -283,17 +381,61 @@ bool tune_kssd_parameters(bool isSetKmer, uint64_t maxSize, uint64_t minSize, ui
   return true;
 }
 
-// src/SketchInfo.cpp:60-102: two Fisher-Yates passes driven by glibc srand()/rand()
+// src/SketchInfo.cpp:60-102: two Fisher-Yates passes driven by glibc srand()/rand().
+// The generator is restated here (glibc random_r TYPE_3: 31-word additive feedback r[i] = r[i-3] +
+// r[i-31], seeded by the Lehmer recurrence 16807*x mod 2^31-1, first 310 outputs discarded, result
+// >> 1) so the table does not depend on the C library in use and the draws can be produced a block
+// ahead of the swaps, which lets the swap targets be prefetched.  tests/test_cpu_host.py pins the
+// table against the golden one made with the C library's own rand().
+namespace {
+struct GlibcRand {
+  int32_t r[34];
+  int f, b;  // front / rear indices into the 31-word state
+  explicit GlibcRand(unsigned seed) {
+    int32_t st[31];
+    st[0] = seed ? (int32_t)seed : 1;
+    for (int i = 1; i < 31; i++) {
+      const long hi = st[i - 1] / 127773, lo = st[i - 1] % 127773;
+      long word = 16807 * lo - 2836 * hi;
+      if (word < 0) word += 2147483647;
+      st[i] = (int32_t)word;
+    }
+    for (int i = 0; i < 31; i++) r[i] = st[i];
+    f = 3; b = 0;
+    for (int i = 0; i < 310; i++) next();
+  }
+  inline int32_t next() {
+    const uint32_t v = (uint32_t)r[f] + (uint32_t)r[b];
+    r[f] = (int32_t)v;
+    if (++f == 31) f = 0;
+    if (++b == 31) b = 0;
+    return (int32_t)(v >> 1);
+  }
+};
+}  // namespace
+
 std::vector<int32_t> generate_shuffle_dim(int half_subk) {
   const int dim_size = 1 << (4 * half_subk);
   std::vector<int32_t> arr(dim_size);
   for (int i = 0; i < dim_size; i++) arr[i] = i;
   const unsigned seeds[2] = {23u, 348842630u};
+  constexpr int BLK = 64;
+  int js[2][BLK];
   for (unsigned seed : seeds) {
-    srand(seed);
-    for (int i = dim_size - 1; i > 0; i--) {
-      int j = rand() % (i + 1);
-      std::swap(arr[i], arr[j]);
+    GlibcRand g(seed);
+    // draws for block `nb` are made (and their targets prefetched) while block `nb-1` is swapped
+    auto draw = [&](int* out, int i_hi, int cnt) {
+      for (int q = 0; q < cnt; q++) { out[q] = g.next() % (i_hi - q + 1); __builtin_prefetch(&arr[out[q]], 1); }
+    };
+    int i = dim_size - 1, cur = 0;
+    int cnt = std::min(BLK, i);
+    draw(js[cur], i, cnt);
+    while (cnt > 0) {
+      const int i_next = i - cnt;
+      const int cnt_next = std::min(BLK, i_next);
+      if (cnt_next > 0) draw(js[cur ^ 1], i_next, cnt_next);
+      for (int q = 0; q < cnt; q++) std::swap(arr[i - q], arr[js[cur][q]]);
+      i = i_next; cnt = cnt_next; cur ^= 1;
     }
   }
   return arr;

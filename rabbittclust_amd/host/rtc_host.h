@@ -38,6 +38,13 @@ bool read_fasta(const std::string& path, std::vector<FastaRecord>& out);
 // '\n' (a non-ACGT byte, so k-mers never span records), and reports first-record metadata.
 bool read_genome_file(const std::string& path, std::string& bases, SequenceInfo& first, uint64_t& total_len,
                       uint64_t& n_records);
+// Zero-copy variant: writes the same byte stream into dst[0..cap) (e.g. a pinned staging slot).
+// Returns 0 ok, 1 cannot open, 2 capacity too small (`used` then holds a capacity that suffices).
+int read_genome_file_flat(const std::string& path, char* dst, uint64_t cap, uint64_t& used, SequenceInfo& first,
+                          uint64_t& total_len, uint64_t& n_records);
+// Upper bound of the bytes read_genome_file_flat writes for `path` (exact bound for plain files, the
+// ISIZE-based guess for gzip); 0 if the file cannot be opened.
+uint64_t genome_slot_bytes(const std::string& path);
 
 // ---- calSize / tune_parameters / tune_kssd_parameters, src/SketchInfo.cpp:438-552, src/sub_command.cpp:2317-2467 ----
 bool cal_size(const std::string& list_file, uint64_t minLen, uint64_t& maxSize, uint64_t& minSize, uint64_t& averageSize);

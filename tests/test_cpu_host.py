@@ -209,3 +209,47 @@ def test_shuffle_dim_matches_oracle_and_file_sizes(host, oracle, tmp_path):
     mx, mn, avg = C.c_uint64(), C.c_uint64(), C.c_uint64()
     assert host.rtch_cal_size(str(lst).encode(), C.c_uint64(10000), C.byref(mx), C.byref(mn), C.byref(avg)) == 1
     assert mx.value == mn.value == avg.value == len(payload)
+
+
+def test_flat_genome_reader_matches_string_reader(host, tmp_path):
+    """The zero-copy reader the CLI parses into pinned memory with yields the same byte stream as
+    the std::string reader (itself pinned on the reference's kseq dumps above), for every golden
+    FASTA/FASTQ/gzip file, and reports the capacity it needs when the slot is too small."""
+    import glob
+    import gzip
+    host.rtch_genome_bases.restype = C.c_long
+    host.rtch_genome_bases.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_long, C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+
+    def run(path, flat, cap):
+        buf = np.zeros(max(cap, 1), dtype=np.uint8)
+        tot, nrec, fl, slot = C.c_uint64(), C.c_uint64(), C.c_int(), C.c_uint64()
+        n = host.rtch_genome_bases(str(path).encode(), flat, buf.ctypes.data_as(C.c_void_p), cap, C.byref(tot),
+                                   C.byref(nrec), C.byref(fl), C.byref(slot))
+        return n, bytes(buf[:max(min(n, cap), 0)]), tot.value, nrec.value, fl.value, slot.value
+
+    files = sorted(glob.glob(os.path.join(GOLD, "fasta", "*")))
+    assert len(files) >= 6
+    rng = np.random.default_rng(3)
+    big = tmp_path / "big.fa"
+    seq = rng.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8), size=700_000).tobytes()
+    with open(big, "wb") as f:  # lines longer than the reader's buffer, CRLF, blank lines, no final EOL
+        f.write(b">r1 first\r\n" + seq[:300_000] + b"\r\n\n>r2\n" + seq[300_000:300_070] + b"\n" + seq[300_070:])
+    biggz = tmp_path / "big.fa.gz"
+    with gzip.GzipFile(biggz, "wb", mtime=0) as f:
+        f.write(open(big, "rb").read())
+    multi = tmp_path / "multi.fa.gz"  # two gzip members: the ISIZE trailer under-reports the content
+    with open(multi, "wb") as f:
+        f.write(gzip.compress(b">a x\n" + seq[:5000] + b"\n", mtime=0) + gzip.compress(b">b\n" + seq[5000:5100] + b"\n", mtime=0))
+    for path in files + [big, biggz, multi]:
+        n0, b0, tot0, nrec0, fl0, slot = run(path, 0, 1 << 21)
+        assert n0 >= 0
+        n1, b1, tot1, nrec1, fl1, _ = run(path, 1, 1 << 21)
+        assert (n1, b1, tot1, nrec1, fl1) == (n0, b0, tot0, nrec0, fl0), path
+        if not str(path).endswith("multi.fa.gz"):
+            assert slot >= n0, path  # the planned slot always holds a single-member file
+        if n0 > 4:  # too-small slot: reports the need, never writes past cap
+            n2, b2, *_ = run(path, 1, n0 - 3)
+            assert n2 >= n0 and b2 == b0[: n0 - 3], path  # need is an upper bound (CRs past cap are counted)
+    assert run(multi, 0, 1 << 21)[5] < run(multi, 0, 1 << 21)[0]  # exercises the CLI's retry round
+    assert run("/nonexistent/x.fa", 1, 16)[0] == -1

@@ -225,3 +225,42 @@ def test_clust_greedy_fast_and_presketched(oracle, tmp_path):
     for i, r in enumerate(rep):
         want.setdefault(int(r), []).append(i)
     assert got == [[r] + [m for m in ms if m != r] for r, ms in sorted(want.items())]
+
+
+def test_clust_mst_batching_gzip_retry_and_min_length_filter(oracle, tmp_path):
+    """Several small staging batches, a multi-member gzip input whose ISIZE trailer under-reports
+    its content (re-parsed in the retry round), and a too-short genome in the middle of the list
+    (dropped by -m): sketches must still come out in list order and equal the oracle's."""
+    import gzip
+    tmp = str(tmp_path)
+    L = 2_000_000  # tune_parameters keeps -k 21 at this size
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 2, 3, L, seed=9)
+    # genome 1 -> two gzip members; genome 4 -> plain gzip
+    raw1 = open(paths[1], "rb").read()
+    half = raw1.index(b"\n", len(raw1) // 2) + 1
+    with open(paths[1] + ".gz", "wb") as f:
+        f.write(gzip.compress(raw1[:half], mtime=0) + gzip.compress(raw1[half:], mtime=0))
+    with gzip.GzipFile(paths[4] + ".gz", "wb", mtime=0) as f:
+        f.write(open(paths[4], "rb").read())
+    short = os.path.join(tmp, "short.fna")
+    open(short, "wb").write(b">tiny genome\n" + seqs[0].tobytes()[:5000] + b"\n")
+    files = [paths[0], paths[1] + ".gz", short, paths[2], paths[3], paths[4] + ".gz", paths[5]]
+    open(lst, "w").write("\n".join(files) + "\n")
+    out = os.path.join(tmp, "mst.out")
+    env = dict(os.environ, RTC_BATCH_BYTES=str(5_000_000), RTC_VERBOSE="1")
+    r = subprocess.run([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "1000", "-d", "0.05", "-t", "3",
+                        "-o", out], cwd=tmp, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stderr.count("[parse] batch") >= 4  # 3 planned batches + the retry batch
+    folder = [os.path.join(tmp, d) for d in os.listdir(tmp) if os.path.isdir(os.path.join(tmp, d)) and d[:2] == "20"][0]
+    _, got_sk = _read_hash_sketch(folder)
+    keep = [0, 1, 2, 3, 4, 5]
+    off = np.arange(len(keep) + 1, dtype=np.uint64) * np.uint64(L)
+    want_sk = oracle.sketch_minhash_batch(np.concatenate([seqs[g] for g in keep]), off, 21, 1000)
+    assert len(got_sk) == 6
+    assert [g for g in range(6) if not np.array_equal(got_sk[g], want_sk[g])] == [], r.stderr[-2000:]
+    text = open(out).read()
+    assert "short.fna" not in text and paths[1] + ".gz" in text
+    flat, start, lens = oracle.to_csr(want_sk)
+    want_cl = oracle.forest_clusters(oracle.mst(flat, start, lens, 21, 0, 0.05), 0.05, 6)
+    assert _partition(_parse_clusters(out)) == _partition(want_cl)
