@@ -205,10 +205,10 @@ __global__ __launch_bounds__(WG) void kssd_sort_unique_kernel(OutT* __restrict__
   const uint32_t g = blockIdx.x;
   const int t = threadIdx.x;
   const uint32_t m = min(cnt[g], stride);
-  if (m == 0) return;
+  if (m == 0 || m > (uint32_t)cap) return;  // rows beyond one LDS buffer go through kssd_big_* below
   OutT* row = out + (uint64_t)g * stride;
   int n2 = 1024;
-  while (n2 < (int)m) n2 <<= 1;  // n2 <= cap by host-side check
+  while (n2 < (int)m) n2 <<= 1;
   for (int i = t; i < n2; i += WG) buf[i] = i < (int)m ? row[i] : (OutT)~(OutT)0;
   if (t == 0) scan_base = 0;
   __syncthreads();
@@ -245,6 +245,138 @@ __global__ __launch_bounds__(WG) void kssd_sort_unique_kernel(OutT* __restrict__
   if (t == 0) cnt[g] = scan_base;
 }
 
+// ---- rows with more tuples than one LDS buffer: global merge sort ------------------------------
+// (a 100 Mbp genome at drlevel 3 yields ~24 000 tuples, a 3 Gbp one ~730 000.)  Chunks of `cap`
+// tuples are sorted in LDS, then log2(#chunks) merge passes ping-pong between the output row and a
+// scratch row: every workgroup produces one 2048-element tile of a merged run pair, found with two
+// merge-path searches, and the final pass is followed by a streaming dedup back into the row.
+struct BigRow {
+  uint32_t genome, count;
+  uint64_t tmp_off;          // element offset of this row in the scratch buffer
+  uint32_t chunk0, tile0;    // first chunk / tile index of this row in the flattened grids
+};
+constexpr int BIG_TILE = 2048;
+
+__device__ __forceinline__ int find_row(const BigRow* rows, int nrows, uint32_t idx, bool by_tile) {
+  int lo = 0, hi = nrows - 1;
+  while (lo < hi) {  // last row whose first chunk/tile index is <= idx
+    const int mid = (lo + hi + 1) >> 1;
+    if ((by_tile ? rows[mid].tile0 : rows[mid].chunk0) <= idx) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+template <typename OutT>
+__device__ __forceinline__ void bitonic_lds(OutT* buf, int n2) {
+  const int t = threadIdx.x;
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < (n2 >> 1); i += WG) {
+        const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        const int b = a | j;
+        const bool up = (a & k) == 0;
+        const OutT va = buf[a], vb = buf[b];
+        if ((va > vb) == up) { buf[a] = vb; buf[b] = va; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(WG) void kssd_big_chunk_sort_kernel(OutT* __restrict__ out, uint32_t stride,
+                                                                 const BigRow* __restrict__ rows, int nrows, int cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  OutT* buf = reinterpret_cast<OutT*>(smem);
+  const int r = find_row(rows, nrows, blockIdx.x, false);
+  const BigRow br = rows[r];
+  const uint32_t c0 = (blockIdx.x - br.chunk0) * (uint32_t)cap;
+  const uint32_t len = min((uint32_t)cap, br.count - c0);
+  OutT* row = out + (uint64_t)br.genome * stride + c0;
+  const int t = threadIdx.x;
+  for (int i = t; i < cap; i += WG) buf[i] = i < (int)len ? row[i] : (OutT)~(OutT)0;
+  __syncthreads();
+  bitonic_lds(buf, cap);
+  for (int i = t; i < (int)len; i += WG) row[i] = buf[i];  // real entries sort before the padding (ties are equal values)
+}
+
+// merged position d of runs A[0..la) and B[0..lb): how many of the first d outputs come from A (ties: A first)
+template <typename OutT>
+__device__ __forceinline__ uint32_t merge_path(const OutT* A, uint32_t la, const OutT* B, uint32_t lb, uint32_t d) {
+  uint32_t lo = d > lb ? d - lb : 0, hi = d < la ? d : la;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (A[mid] <= B[d - 1 - mid]) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(WG) void kssd_big_merge_pass_kernel(OutT* out, uint32_t stride, OutT* tmp,
+                                                                 const BigRow* __restrict__ rows, int nrows,
+                                                                 uint32_t w, int src_is_tmp) {
+  __shared__ OutT buf[BIG_TILE];
+  __shared__ uint32_t cut[2];
+  const int r = find_row(rows, nrows, blockIdx.x, true);
+  const BigRow br = rows[r];
+  OutT* rowp = out + (uint64_t)br.genome * stride;
+  OutT* tmpp = tmp + br.tmp_off;
+  const OutT* src = src_is_tmp ? tmpp : rowp;
+  OutT* dst = src_is_tmp ? rowp : tmpp;
+  const uint32_t c = br.count;
+  const uint32_t o0 = (blockIdx.x - br.tile0) * (uint32_t)BIG_TILE;
+  const uint32_t o1 = min(c, o0 + (uint32_t)BIG_TILE);
+  const uint32_t ps = o0 / (2 * w) * (2 * w);        // w is a multiple of BIG_TILE: a tile never straddles run pairs
+  const uint32_t am = min(c, ps + w), bm = min(c, ps + 2 * w);
+  const OutT* A = src + ps; const uint32_t la = am - ps;
+  const OutT* B = src + am; const uint32_t lb = bm - am;
+  const int t = threadIdx.x;
+  if (t < 2) cut[t] = merge_path(A, la, B, lb, (t ? o1 : o0) - ps);
+  __syncthreads();
+  const uint32_t a0 = cut[0], a1 = cut[1];
+  const uint32_t b0 = (o0 - ps) - a0, b1 = (o1 - ps) - a1;
+  const uint32_t na = a1 - a0, nb = b1 - b0;  // na + nb == o1 - o0
+  for (uint32_t i = t; i < (uint32_t)BIG_TILE; i += WG)
+    buf[i] = i < na ? A[a0 + i] : (i < na + nb ? B[b0 + (i - na)] : (OutT)~(OutT)0);
+  __syncthreads();
+  bitonic_lds(buf, BIG_TILE);
+  for (uint32_t i = t; i < o1 - o0; i += WG) dst[o0 + i] = buf[i];
+}
+
+// sorted src (row itself or scratch) -> distinct values at the front of the row; cnt[genome] = #distinct
+template <typename OutT>
+__global__ __launch_bounds__(WG) void kssd_big_dedup_kernel(OutT* out, uint32_t stride, const OutT* tmp,
+                                                            const BigRow* __restrict__ rows, uint32_t* __restrict__ cnt,
+                                                            int src_is_tmp) {
+  __shared__ uint32_t wave_tot[WG / 64];
+  __shared__ OutT carry[2];
+  const BigRow br = rows[blockIdx.x];
+  OutT* row = out + (uint64_t)br.genome * stride;
+  const OutT* src = src_is_tmp ? tmp + br.tmp_off : row;
+  const int t = threadIdx.x;
+  const uint32_t lane = t & 63, wave = t >> 6;
+  uint32_t written = 0;  // identical in every thread
+  for (uint32_t r0 = 0; r0 < br.count; r0 += WG) {
+    const uint32_t idx = r0 + t;
+    const bool in = idx < br.count;
+    const OutT v = in ? src[idx] : (OutT)0;
+    // the predecessor of a round's first element was saved before the previous round's writes
+    const OutT prev = (in && idx > 0) ? (t == 0 ? carry[(r0 / WG) & 1] : src[idx - 1]) : (OutT)0;
+    const bool keep = in && (idx == 0 || v != prev);
+    const uint64_t bal = __ballot(keep);
+    if (lane == 0) wave_tot[wave] = (uint32_t)__popcll(bal);
+    if (t == WG - 1) carry[((r0 / WG) + 1) & 1] = v;
+    __syncthreads();  // every read of this round is done before any write (dst <= src positions)
+    uint32_t base = written, total = 0;
+#pragma unroll
+    for (int wv = 0; wv < WG / 64; wv++) { const uint32_t wt = wave_tot[wv]; if ((uint32_t)wv < wave) base += wt; total += wt; }
+    if (keep) row[base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL))] = v;
+    written += total;
+    __syncthreads();
+  }
+  if (t == 0) cnt[br.genome] = written;
+}
+
 __global__ void max_u32_kernel(const uint32_t* __restrict__ a, uint32_t n, uint32_t* __restrict__ out_max) {
   uint32_t v = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v = max(v, a[i]);
@@ -271,6 +403,55 @@ uint64_t table_checksum(const int32_t* t, size_t n) {
 }
 
 }  // namespace
+
+// rows with more than `cap` appended tuples: chunk sort + merge passes + dedup (see kssd_big_* kernels)
+static int kssd_sort_big_rows(rtc_ctx* ctx, void* d_out, uint32_t stride, uint32_t* d_cnt, uint32_t n, int use64, int cap) {
+  std::vector<uint32_t> h_cnt(n);
+  RTC_HIP(ctx, hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<BigRow> rows;
+  uint64_t tmp_elems = 0;
+  uint32_t chunks = 0, tiles = 0, cmax = 0;
+  for (uint32_t g = 0; g < n; g++) {
+    if (h_cnt[g] <= (uint32_t)cap) continue;
+    rows.push_back(BigRow{g, h_cnt[g], tmp_elems, chunks, tiles});
+    tmp_elems += h_cnt[g];
+    chunks += (h_cnt[g] + cap - 1) / cap;
+    tiles += (h_cnt[g] + BIG_TILE - 1) / BIG_TILE;
+    cmax = std::max(cmax, h_cnt[g]);
+  }
+  if (rows.empty()) return RTC_OK;
+  const int w8 = use64 ? 8 : 4;
+  void *ws1 = nullptr, *ws2 = nullptr, *hp = nullptr;
+  RTC_TRY(rtc_ws(ctx, 1, tmp_elems * w8 + 64, &ws1));
+  RTC_TRY(rtc_ws(ctx, 2, rows.size() * sizeof(BigRow) + 64, &ws2));
+  RTC_TRY(rtc_pinned(ctx, rows.size() * sizeof(BigRow) + 64, &hp));
+  memcpy(hp, rows.data(), rows.size() * sizeof(BigRow));
+  RTC_HIP(ctx, hipMemcpyAsync(ws2, hp, rows.size() * sizeof(BigRow), hipMemcpyHostToDevice, ctx->stream));
+  const BigRow* d_rows = (const BigRow*)ws2;
+  const int nrows = (int)rows.size();
+  const size_t lds_c = (size_t)cap * w8;
+#define BIG_PIPELINE(OT)                                                                                              \
+  do {                                                                                                                \
+    auto ks = kssd_big_chunk_sort_kernel<OT>;                                                                         \
+    RTC_HIP(ctx, hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));       \
+    hipLaunchKernelGGL(ks, dim3(chunks), dim3(WG), lds_c, ctx->stream, (OT*)d_out, stride, d_rows, nrows, cap);       \
+    RTC_CHECK_LAUNCH(ctx);                                                                                            \
+    int src_is_tmp = 0;                                                                                               \
+    for (uint64_t w = (uint64_t)cap; w < cmax; w <<= 1) {                                                             \
+      hipLaunchKernelGGL(kssd_big_merge_pass_kernel<OT>, dim3(tiles), dim3(WG), 0, ctx->stream, (OT*)d_out, stride,   \
+                         (OT*)ws1, d_rows, nrows, (uint32_t)w, src_is_tmp);                                           \
+      RTC_CHECK_LAUNCH(ctx);                                                                                          \
+      src_is_tmp ^= 1;                                                                                                \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(kssd_big_dedup_kernel<OT>, dim3(nrows), dim3(WG), 0, ctx->stream, (OT*)d_out, stride,          \
+                       (const OT*)ws1, d_rows, d_cnt, src_is_tmp);                                                    \
+    RTC_CHECK_LAUNCH(ctx);                                                                                            \
+  } while (0)
+  if (use64) BIG_PIPELINE(uint64_t); else BIG_PIPELINE(uint32_t);
+#undef BIG_PIPELINE
+  return RTC_OK;
+}
 
 extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uint64_t* h_off, uint32_t n,
                                    int kmer_size, int drlevel, const int32_t* h_shuffled_dim, void* d_out,
@@ -422,11 +603,10 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (h_need) *h_need = h_max;
   if (h_max > stride) return rtc_fail(ctx, RTC_ERR_OVERFLOW, "a genome produced %u KSSD tuples, stride is %u", h_max, stride);
+  const int cap_max = use64 ? 16384 : 32768;  // one LDS buffer (128 KiB)
   int cap = 1024;
-  while (cap < (int)h_max) cap <<= 1;
+  while (cap < (int)h_max && cap < cap_max) cap <<= 1;
   const size_t lds_s = (size_t)cap * (use64 ? 8 : 4) + (WG / 64 + 1) * 4;
-  if (lds_s > (size_t)150 * 1024)
-    return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "%u KSSD tuples per genome exceed the in-LDS sort (%zu B)", h_max, lds_s);
   if (use64) {
     auto kern = kssd_sort_unique_kernel<uint64_t>;
     RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
@@ -437,5 +617,6 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
     hipLaunchKernelGGL(kern, dim3(n), dim3(WG), lds_s, ctx->stream, (uint32_t*)d_out, stride, d_cnt, cap);
   }
   RTC_CHECK_LAUNCH(ctx);
+  if (h_max > (uint32_t)cap) RTC_TRY(kssd_sort_big_rows(ctx, d_out, stride, d_cnt, n, use64, cap));
   return RTC_OK;
 }

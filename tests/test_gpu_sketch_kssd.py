@@ -65,6 +65,44 @@ def test_kssd_overflow_protocol_and_duplicates(ctx, oracle):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("k,drlevel,lens", [
+    (21, 2, [12_000_000, 300_000, 20_000_000]),   # u32 tuples: 2 chunks (one merge pass, dedup from scratch) and 3 chunks
+    (25, 2, [12_000_000, 50_000]),                # u64 tuples: 3 chunks of 16384 (two passes, in-place dedup)
+    (21, 3, [140_000_000]),                       # LDS cuckoo index path with a row just above one LDS buffer
+])
+def test_kssd_rows_beyond_one_lds_buffer(ctx, oracle, k, drlevel, lens):
+    """Genomes yielding more tuples than the in-LDS sort holds (32 768 u32 / 16 384 u64) go through
+    the chunk-sort + merge-pass + dedup path; small rows of the same batch keep the LDS path."""
+    from rabbittclust_amd import api
+    desc = api.synth_family_descs(len(lens), 1, global_seed=900 + k + drlevel, n_every=0)
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    d = ctx.synth_genomes(desc, off)
+    p = oracle.kssd_params(k, drlevel)
+    sd = oracle.kssd_shuffle_dim(p.half_subk)
+    sk = ctx.sketch_kssd(d, off, sd, kmer_size=k, drlevel=drlevel)
+    got = sk.to_host()
+    seq = d.cpu().numpy()
+    cap = 16384 if p.use64 else 32768
+    assert max(len(x) for x in got) > cap
+    for g in range(len(lens)):
+        want = oracle.kssd_sketch(seq[int(off[g]):int(off[g + 1])], k, drlevel)
+        assert np.array_equal(got[g], want), f"genome {g}: got {len(got[g])} want {len(want)}"
+
+
+def test_kssd_big_row_with_heavy_duplication(ctx, oracle):
+    """A repetitive genome: ~10x more appended tuples than distinct ones, all beyond one LDS buffer."""
+    rng = np.random.default_rng(77)
+    unit = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=3_000_000)
+    g = np.tile(unit, 10)
+    off = np.array([0, len(g)], dtype=np.uint64)
+    p = oracle.kssd_params(21, 2)
+    sd = oracle.kssd_shuffle_dim(p.half_subk)
+    sk = ctx.sketch_kssd(ctx.upload_sequences(g), off, sd, kmer_size=21, drlevel=2)
+    want = oracle.kssd_sketch(g, 21, 2)
+    assert np.array_equal(sk.to_host()[0], want)
+
+
 @pytest.mark.skip(reason="covered by the CPU suite")
 def test_kssd_shuffle_table_fixture(oracle):
     """The 4096 surviving (dim_id, rank) pairs of generate_shuffle_dim(6) pin glibc rand()."""
