@@ -142,3 +142,35 @@ def test_tiled_matches_merge_kernel_at_scale(ctx):
     full = ctx.pair_common(dev, algo=2).cpu().numpy()
     assert np.array_equal(full, full.T)            # symmetry
     assert np.array_equal(np.diag(full), dev.len.cpu().numpy())  # |A ∩ A| = |A|
+
+
+def test_tiled_large_sketches_match_merge_kernel(ctx):
+    """Sketch sizes well beyond the default (multi-pass sketching, 20 000 hashes per genome): the tiled
+    kernel must agree with the one-lane-per-pair merge kernel, and counts must be symmetric."""
+    from rabbittclust_amd import api
+    desc = api.synth_family_descs(13, 10, global_seed=29)
+    L = 400_000
+    off = np.arange(len(desc) + 1, dtype=np.uint64) * L
+    seq = ctx.synth_genomes(desc, off)
+    dev = ctx.sketch_minhash(seq, off, k=21, size=20000)
+    assert int(dev.len.min()) == 20000
+    a = ctx.pair_common(dev, algo=1).cpu().numpy()
+    b = ctx.pair_common(dev, algo=2).cpu().numpy()
+    assert np.array_equal(a, b)
+    assert np.array_equal(b, b.T) and np.array_equal(np.diag(b), dev.len.cpu().numpy())
+    assert (b[np.triu_indices(dev.n, 1)] > 2000).sum() >= 13 * 45 // 2  # family members share a large part
+
+
+def test_auto_dispatch_with_a_huge_sketch(ctx, oracle):
+    """One sketch of 1.2 M hashes (a KSSD sketch of a multi-Gbp genome) among ordinary ones: algo 0
+    must still return exact counts (falls back to the merge kernel when the tiled plan cannot take it)."""
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(41)
+    sk = _make_sketches(rng, 40, 500, 1500, pool_bits=22, dtype=np.uint32)
+    huge = np.unique(rng.integers(0, 1 << 22, size=1_500_000, dtype=np.uint64)).astype(np.uint32)[:1_200_000]
+    sk[7] = np.sort(huge)
+    dev = api.SketchSet.from_host(sk, ctx.device, width=4)
+    got = ctx.pair_common(dev, algo=0).cpu().numpy()
+    for i in (0, 7, 8, 39):
+        for j in range(40):
+            assert got[i, j] == oracle.common(sk[i], sk[j]) == got[j, i], (i, j)
