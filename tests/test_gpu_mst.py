@@ -107,6 +107,69 @@ def test_pipeline_step_single_gpu(ctx, oracle):
     assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
 
 
+class _LockstepRanks:
+    """`world` simulated ranks on one GPU: every rank owns the candidate edges of its triangle row
+    range; the three per-round primitives run on each rank's edge list and are reduced exactly as
+    the RCCL all-reduces would (MIN, MIN, MAX)."""
+
+    def __init__(self, backends):
+        self.b = backends
+        self.device = backends[0].device
+
+    def _reduce(self, call, out, op):
+        import torch
+        acc = None
+        for b in self.b:
+            tmp = torch.empty_like(out)
+            call(b, tmp)
+            acc = tmp if acc is None else op(acc, tmp)
+        out.copy_(acc)
+
+    def minweight(self, comp, wkey):
+        import torch
+        self._reduce(lambda b, o: b.minweight(comp, o), wkey, torch.minimum)
+
+    def minedge(self, comp, wkey, ekey):
+        import torch
+        self._reduce(lambda b, o: b.minedge(comp, wkey, o), ekey, torch.minimum)
+
+    def fetch(self, comp, ekey, ecommon):
+        import torch
+        self._reduce(lambda b, o: b.fetch(comp, ekey, o), ecommon, torch.maximum)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_row_sharded_boruvka_equals_single_rank(ctx, oracle, world):
+    """The multi-GPU decomposition on real HIP kernels: triangle row ranges -> per-rank candidate
+    edges -> lockstep Boruvka rounds with MIN/MIN/MAX reductions -> same forest weights as the
+    oracle's Kruskal over all pairs."""
+    import torch
+    from rabbittclust_amd import api, pipeline
+    desc = api.synth_family_descs(60, 7, global_seed=57)
+    L = 60_000
+    off = np.arange(len(desc) + 1, dtype=np.uint64) * L
+    seq = ctx.synth_genomes(desc, off)
+    sk = ctx.sketch_minhash(seq, off, k=21, size=400)
+    n = sk.n
+    bounds = pipeline.triangle_row_ranges(n, world)
+    assert bounds[0] == 0 and bounds[-1] == n
+    backends, total_edges = [], 0
+    for r in range(world):
+        pipe = pipeline.MstPipeline(ctx, k=21, sketch_size=400, threshold=0.05, rank=r, world=world)
+        edges, m = pipe.candidate_edges(sk, bounds[r], bounds[r + 1])
+        backends.append(pipeline.HipBoruvkaBackend(ctx, sk, edges[:m].clone(), m, False))
+        total_edges += m
+    sel, rounds = pipeline.boruvka_rounds(_LockstepRanks(backends), n, ctx.lib)
+    pipe = pipeline.MstPipeline(ctx, k=21, sketch_size=400, threshold=0.05)
+    got = pipe.finish(sk, sel)
+    flat, start, lens = oracle.to_csr(sk.to_host())
+    want = oracle.mst(flat, start, lens, 21, 0, 0.05)
+    assert total_edges == len(oracle.candidate_pairs(flat, start, lens))  # equal sizes: the radio filter passes all
+    assert len(got) == len(want) and rounds >= 2
+    assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
+    assert _partition(oracle.forest_clusters(got, 0.05, n)) == _partition(oracle.forest_clusters(want, 0.05, n))
+
+
 def test_bench_rccl_path_single_rank(tmp_path):
     """bench.py under torch.distributed.run with one rank and RTC_FORCE_DIST=1: the all-gather and
     the per-round all-reduces go through RCCL (backend "nccl") exactly as in the multi-GPU run."""
