@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtclust_hip.so")
+LIB_PATH = os.environ.get("RTC_HIP_LIB") or os.path.join(_HERE, "librtclust_hip.so")  # override: alternative builds
 
 RTC_OK, RTC_ERR_ARG, RTC_ERR_HIP, RTC_ERR_UNSUPPORTED, RTC_ERR_OVERFLOW, RTC_ERR_NOMEM = range(6)
 STATUS_NAMES = {0: "RTC_OK", 1: "RTC_ERR_ARG", 2: "RTC_ERR_HIP", 3: "RTC_ERR_UNSUPPORTED",

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -44,7 +45,21 @@ int rtc_pinned(rtc_ctx* ctx, size_t bytes, void** out);
     if (s__ != RTC_OK) return s__;     \
   } while (0)
 
-#define RTC_CHECK_LAUNCH(ctx) RTC_HIP(ctx, hipGetLastError())
+// RTC_DEBUG_SYNC=1 in the environment synchronises after every launch and names it on stderr, so
+// an asynchronous device fault can be pinned on a kernel
+#define RTC_CHECK_LAUNCH(ctx)                                                        \
+  do {                                                                               \
+    RTC_HIP(ctx, hipGetLastError());                                                 \
+    if (rtc_debug_sync()) {                                                          \
+      fprintf(stderr, "[rtc] %s:%d launched, syncing\n", __FILE__, __LINE__);        \
+      RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));                               \
+      fprintf(stderr, "[rtc] %s:%d ok\n", __FILE__, __LINE__);                       \
+    }                                                                                \
+  } while (0)
+static inline bool rtc_debug_sync() {
+  static const bool on = getenv("RTC_DEBUG_SYNC") != nullptr;
+  return on;
+}
 
 // ---- device helpers shared by kernels ------------------------------------------------------
 __device__ __forceinline__ uint64_t rtc_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }

@@ -51,6 +51,14 @@ struct Ctrl {
   uint32_t wave_tot[NWAVE];
 };
 
+// Every LDS object is reached through address_space(3) pointers: the accesses are ds_* instructions
+// by construction (not flat ones whose selection depends on what the optimiser can prove).
+#define RTC_LDS __attribute__((address_space(3)))
+typedef RTC_LDS uint64_t* lds_u64_ptr;
+typedef RTC_LDS Ctrl* lds_ctrl_ptr;
+typedef RTC_LDS unsigned char* lds_byte_ptr;
+struct MergeResult { uint32_t count; uint64_t T; };
+
 // ---- MurmurHash3_x64_128 (first output word) of the canonical k-mer's ASCII bytes ----------------
 // The first operation MurmurHash3 applies to every 64-bit input word is a multiplication by a
 // constant (c1 for the k1 words, c2 for the k2 words).  Multiplication mod 2^64 is linear, so
@@ -93,7 +101,7 @@ __device__ __forceinline__ KParams make_kparams(int k, uint32_t seed) {
 }
 
 // lut: [ceil(k/4)][256] u64 in LDS.  Called by all WG threads; the first 256 fill one column each.
-__device__ __forceinline__ void build_kmer_lut(uint64_t* lut, int k) {
+__device__ __forceinline__ void build_kmer_lut(lds_u64_ptr lut, int k) {
   const uint32_t e = threadIdx.x;
   if (e >= 256) return;
   const uint32_t a4 = codes_to_ascii(e);
@@ -107,27 +115,67 @@ __device__ __forceinline__ void build_kmer_lut(uint64_t* lut, int k) {
   }
 }
 
-__device__ __forceinline__ void mm_body(uint64_t& h1, uint64_t& h2, uint64_t k1m, uint64_t k2m) {
-  uint64_t k1 = rtc_rotl64(k1m, 31) * MM_C2; h1 ^= k1;
-  h1 = rtc_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-  uint64_t k2 = rtc_rotl64(k2m, 33) * MM_C1; h2 ^= k2;
-  h2 = rtc_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+// 64-bit rotate as two v_alignbit_b32 (the generic shift/or form costs three to four instructions)
+template <int R>
+__device__ __forceinline__ uint64_t rotl64c(uint64_t x) {
+  static_assert(R > 0 && R < 64 && R != 32, "rotation amount");
+  const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+  uint32_t nh, nl;
+  if (R < 32) {
+    nh = __builtin_amdgcn_alignbit(hi, lo, 32 - R);
+    nl = __builtin_amdgcn_alignbit(lo, hi, 32 - R);
+  } else {
+    nh = __builtin_amdgcn_alignbit(lo, hi, 64 - R);
+    nl = __builtin_amdgcn_alignbit(hi, lo, 64 - R);
+  }
+  return ((uint64_t)nh << 32) | nl;
 }
 
-__device__ __forceinline__ uint64_t kmer_hash(uint64_t canon, const KParams& P, const uint64_t* lut) {
-  const uint64_t x = canon << P.lshift;  // first base in the top bits
+// x*5 as one v_lshl_add_u64 ((x << 2) + x); the compiler's choice is two v_mad_u64_u32 plus moves
+__device__ __forceinline__ uint64_t times5(uint64_t x) {
+  uint64_t r;
+  asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// byte B of w, times 8 (the byte offset of a u64 table entry), as one SDWA shift
+template <int B>
+__device__ __forceinline__ uint32_t byte_x8(uint32_t w, uint32_t three) {
+  uint32_t r;
+  if (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(three), "v"(w));
+  if (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(three), "v"(w));
+  if (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(three), "v"(w));
+  if (B == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(three), "v"(w));
+  return r;
+}
+
+__device__ __forceinline__ void mm_body(uint64_t& h1, uint64_t& h2, uint64_t k1m, uint64_t k2m) {
+  uint64_t k1 = rotl64c<31>(k1m) * MM_C2; h1 ^= k1;
+  h1 = rotl64c<27>(h1); h1 += h2; h1 = times5(h1) + 0x52dce729;
+  uint64_t k2 = rotl64c<33>(k2m) * MM_C1; h2 ^= k2;
+  h2 = rotl64c<31>(h2); h2 += h1; h2 = times5(h2) + 0x38495ab5;
+}
+
+// x: canonical k-mer, 2 bits per base, first base in the top bits (canon << (64 - 2k))
+__device__ __forceinline__ uint64_t kmer_hash(uint64_t x, const KParams& P) {
   const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
   const int k = P.k;
-  // byte offsets into the tables: (code byte) * 8
-  uint64_t A0 = lut[0 * 256 + (hi >> 24)];
+  // table d sits at byte offset d*2048 of the LDS allocation (constant offsets fold into ds_read);
+  // the entry offset is (code byte)*8, one SDWA shift each
+  // (the tables start at LDS address 0 -- checked at kernel entry -- so the LDS address is the offset)
+  typedef const RTC_LDS uint64_t* lds_u64_cptr;
+  const uint32_t three = 3;
+#define RTC_LUT(d, off) (*(lds_u64_cptr)(uintptr_t)((off) + (uint32_t)((d) * LUT_TABLE_BYTES)))
+  uint64_t A0 = RTC_LUT(0, byte_x8<3>(hi, three));
   uint64_t B0 = 0, A1 = 0, B1 = 0;
-  if (k > 4) A0 += lut[1 * 256 + ((hi >> 16) & 0xff)];
-  if (k > 8) B0 = lut[2 * 256 + ((hi >> 8) & 0xff)];
-  if (k > 12) B0 += lut[3 * 256 + (hi & 0xff)];
-  if (k > 16) A1 = lut[4 * 256 + (lo >> 24)];
-  if (k > 20) A1 += lut[5 * 256 + ((lo >> 16) & 0xff)];
-  if (k > 24) B1 = lut[6 * 256 + ((lo >> 8) & 0xff)];
-  if (k > 28) B1 += lut[7 * 256 + (lo & 0xff)];
+  if (k > 4) A0 += RTC_LUT(1, byte_x8<2>(hi, three));
+  if (k > 8) B0 = RTC_LUT(2, byte_x8<1>(hi, three));
+  if (k > 12) B0 += RTC_LUT(3, byte_x8<0>(hi, three));
+  if (k > 16) A1 = RTC_LUT(4, byte_x8<3>(lo, three));
+  if (k > 20) A1 += RTC_LUT(5, byte_x8<2>(lo, three));
+  if (k > 24) B1 = RTC_LUT(6, byte_x8<1>(lo, three));
+  if (k > 28) B1 += RTC_LUT(7, byte_x8<0>(lo, three));
+#undef RTC_LUT
   uint64_t h1 = P.seed, h2 = P.seed;
   uint64_t t0 = A0, t1 = B0;  // tail words (already multiplied by c1 / c2)
   if (k >= 16) {
@@ -136,8 +184,8 @@ __device__ __forceinline__ uint64_t kmer_hash(uint64_t canon, const KParams& P, 
     if (k == 32) { mm_body(h1, h2, A1, B1); t0 = 0; t1 = 0; }
   }
   const int tail = k & 15;
-  if (tail > 8) { h2 ^= rtc_rotl64(t1, 33) * MM_C1; }
-  if (tail > 0) { h1 ^= rtc_rotl64(t0, 31) * MM_C2; }
+  if (tail > 8) { h2 ^= rotl64c<33>(t1) * MM_C1; }
+  if (tail > 0) { h1 ^= rotl64c<31>(t0) * MM_C2; }
   h1 ^= (uint64_t)k; h2 ^= (uint64_t)k;
   h1 += h2; h2 += h1;
   h1 = fmix64(h1); h2 = fmix64(h2);
@@ -146,7 +194,7 @@ __device__ __forceinline__ uint64_t kmer_hash(uint64_t canon, const KParams& P, 
 }
 
 // ---- block-wide merge: sort buf[0..CAP), drop duplicates, keep the `s` smallest ----------------
-__device__ void bitonic_sort_lds(uint64_t* buf, int cap) {
+__device__ void bitonic_sort_lds(lds_u64_ptr buf, int cap) {
   const int t = threadIdx.x;
   for (int k = 2; k <= cap; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -164,7 +212,7 @@ __device__ void bitonic_sort_lds(uint64_t* buf, int cap) {
 
 // On entry: buf[0..ctrl->count) holds candidates (unsorted, duplicates allowed), all threads
 // arrive.  On exit: buf[0..count) ascending distinct, count <= s, ctrl->T updated.
-__device__ __noinline__ uint32_t merge_block(uint64_t* buf, Ctrl* ctrl, int cap, uint32_t s, uint64_t& T_out) {
+__device__ __noinline__ MergeResult merge_block(lds_u64_ptr buf, lds_ctrl_ptr ctrl, int cap, uint32_t s) {
   const int t = threadIdx.x;
   __syncthreads();
   const uint32_t n = ctrl->count < (uint32_t)cap ? ctrl->count : (uint32_t)cap;
@@ -207,8 +255,7 @@ __device__ __noinline__ uint32_t merge_block(uint64_t* buf, Ctrl* ctrl, int cap,
   __syncthreads();
   if (t == 0) { ctrl->count = c; ctrl->T = newT; ctrl->overflow = 0; }
   __syncthreads();
-  T_out = newT;
-  return c;
+  return MergeResult{c, newT};
 }
 
 // One lane's view of a tile: 96 consecutive bases = 36 warm-up + 60 owned k-mer end positions,
@@ -233,6 +280,13 @@ __device__ __forceinline__ uint4 load_bases16(const uint8_t* __restrict__ seq, i
   return make_uint4(ww[0], ww[1], ww[2], ww[3]);
 }
 
+// values every lane holds identically (read from LDS after a barrier): move them to SGPRs so the
+// compiler emits scalar branches and compares against scalar operands
+__device__ __forceinline__ uint32_t uniform32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+  return ((uint64_t)uniform32((uint32_t)(v >> 32)) << 32) | uniform32((uint32_t)v);
+}
+
 template <int KT>  // KT > 0: k known at compile time (uniform branches fold away); 0: runtime k
 // second launch bound: 6 waves/SIMD = 3 workgroups per CU (caps the allocation at 80 VGPRs)
 __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __restrict__ seq,
@@ -242,10 +296,14 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
                                                             uint32_t* cnt, int pass_no,
                                                             const uint64_t* fin_out, const uint32_t* fin_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
-  uint64_t* lut = reinterpret_cast<uint64_t*>(smem + (size_t)cap * 8);
   const int k = KT > 0 ? KT : k_arg;
-  Ctrl* ctrl = reinterpret_cast<Ctrl*>(smem + (size_t)cap * 8 + lut_bytes(k));
+  const lds_byte_ptr lds0 = (lds_byte_ptr)smem;
+  const lds_u64_ptr lut = (lds_u64_ptr)lds0;  // at LDS offset 0: table offsets become ds_read immediates
+  // kmer_hash addresses the tables by absolute LDS address; this kernel has no static LDS, so the
+  // dynamic allocation starts at 0 -- trap rather than hash with wrong tables if that ever changes
+  if ((uint32_t)(uintptr_t)lds0 != 0u) __builtin_trap();
+  const lds_u64_ptr buf = (lds_u64_ptr)(lds0 + lut_bytes(k));
+  const lds_ctrl_ptr ctrl = (lds_ctrl_ptr)(lds0 + lut_bytes(k) + (size_t)cap * 8);
 
   const Segment sg = segs[blockIdx.x];
   const KParams P = make_kparams(k, seed);
@@ -303,33 +361,37 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
           if (safe_mode && hashing) {
             // bound the next dword's appends so the buffer cannot overflow
             __syncthreads();
-            const uint32_t cn = ctrl->count;
-            if ((uint32_t)cap - cn < (uint32_t)STEP_APPENDS) merge_block(buf, ctrl, cap, s, T);
+            const uint32_t cn = uniform32(ctrl->count);
+            if ((uint32_t)cap - cn < (uint32_t)STEP_APPENDS) T = uniform64(merge_block(buf, ctrl, cap, s).T);
             __syncthreads();
           }
-          uint64_t canon[4];
-          bool ok[4];
+          uint64_t canon[4];  // top-aligned (first base in bit 63)
+          bool ok[4] = {false, false, false, false};  // slow path only; the fast path derives it on demand
           bool allok = false;  // wave-uniform: all four k-mers of every lane are valid and owned
           // ---- decode four bases at once ----
           const uint32_t up = wv & 0xDFDFDFDFu;
           const uint32_t codes4 = ((wv >> 1) ^ (wv >> 2)) & 0x03030303u;  // A,C,G,T (either case) -> 0..3 per byte
           const bool allvalid = __builtin_amdgcn_perm(0u, 0x54474341u, codes4) == up;
-          if (fastroll && __all(allvalid)) {
+          const bool fast = fastroll && __all(allvalid);  // wave-uniform
+          const int run_in = run;
+          if (fast) {
             // pack = c0<<6|c1<<4|c2<<2|c3 ; rp = complement codes in reverse significance
             const uint32_t pack = (codes4 * 0x40100401u) >> 24;
             const uint32_t rp = ((codes4 * 0x01041040u) >> 24) ^ 0xffu;
             const uint64_t F = (fwd << 8) | pack;
             const uint64_t R = rc | ((uint64_t)rp << (2 * P.k));
-            allok = __all(run + 1 >= P.k && rel0 >= rel_lo && rel0 + 3 < rel_hi);
+            if (hashing) allok = __all(run + 1 >= P.k && rel0 >= rel_lo && rel0 + 3 < rel_hi);
+            // the four windows are cut out of F / R already top-aligned (one shift + one mask each):
+            // the order of two k-mers does not depend on the alignment, and the hash wants them there
+            const uint64_t topmask = P.kmask << P.lshift;
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-              const uint64_t f = (F >> (6 - 2 * b)) & P.kmask;
-              const uint64_t r = (R >> (2 * b + 2)) & P.kmask;
-              const int rel = rel0 + b;
-              ok[b] = allok || (run + b + 1 >= P.k && rel >= rel_lo && rel < rel_hi);
+              const uint64_t f = (F << (P.lshift - 6 + 2 * b)) & topmask;   // lshift >= 8 in this path
+              const uint64_t r = (R << (P.lshift - 2 - 2 * b)) & topmask;
               canon[b] = f < r ? f : r;
-              if (b == 3) { fwd = f; rc = r; }
             }
+            fwd = F & P.kmask;
+            rc = (R >> 8) & P.kmask;
             run += 4;
           } else {
 #pragma unroll
@@ -342,42 +404,42 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
               run = valid ? run + 1 : 0;
               const int rel = rel0 + b;
               ok[b] = run >= P.k && rel >= rel_lo && rel < rel_hi;
-              canon[b] = fwd < rc ? fwd : rc;
+              canon[b] = (fwd < rc ? fwd : rc) << P.lshift;
             }
           }
           if (hashing) {  // wave-uniform
             // four independent hash chains: their LDS table reads and multiplies overlap
             uint64_t h[4];
 #pragma unroll
-            for (int b = 0; b < 4; b++) h[b] = kmer_hash(canon[b], P, lut);
-            bool pass[4];
-            bool anyp = false;
+            for (int b = 0; b < 4; b++) h[b] = kmer_hash(canon[b], P);
+            // lanes that append, as wave masks (T is scalar: compares write the masks directly)
+            uint64_t m[4];
             if (allok && T != SENT) {  // the steady state: one 64-bit compare per k-mer
 #pragma unroll
-              for (int b = 0; b < 4; b++) pass[b] = h[b] < T;
+              for (int b = 0; b < 4; b++) m[b] = __ballot(h[b] < T);
             } else {
 #pragma unroll
               for (int b = 0; b < 4; b++) {
+                const int rel = rel0 + b;
+                const bool okb = fast ? (run_in + b + 1 >= P.k && rel >= rel_lo && rel < rel_hi) : ok[b];
                 // T == SENT means "sketch not full yet": everything passes (also a hash == SENT)
-                pass[b] = ok[b] && (h[b] < T || T == SENT);
+                m[b] = __ballot(okb && (h[b] < T || T == SENT));
               }
             }
             if (lo1) {  // workgroup-uniform: later passes of a large sketch
 #pragma unroll
-              for (int b = 0; b < 4; b++) pass[b] = pass[b] && h[b] >= lo1;
+              for (int b = 0; b < 4; b++) m[b] &= __ballot(h[b] >= lo1);
             }
-#pragma unroll
-            for (int b = 0; b < 4; b++) anyp |= pass[b];
-            if (__any(anyp)) {
+            if (m[0] | m[1] | m[2] | m[3]) {
 #pragma unroll
               for (int b = 0; b < 4; b++) {
-                const uint64_t bal = __ballot(pass[b]);
+                const uint64_t bal = m[b];
                 if (bal) {  // wave-uniform
                   uint32_t base = 0;
-                  if (lane == 0) base = atomicAdd(&ctrl->count, (uint32_t)__popcll(bal));
+                  if (lane == 0) base = __hip_atomic_fetch_add(&ctrl->count, (uint32_t)__popcll(bal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                   base = __shfl(base, 0);
                   const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
-                  if (pass[b]) {
+                  if ((bal >> lane) & 1ULL) {
                     if (idx < (uint32_t)cap) buf[idx] = h[b];
                     else ctrl->overflow = 1;
                   }
@@ -388,26 +450,33 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
         }
       }
       __syncthreads();
-      if (ctrl->overflow) {
+      if (uniform32(ctrl->overflow)) {
         // optimistic pass lost candidates: fold what we have, then redo this tile safely
         // (count may exceed cap: clamp happens inside merge_block)
-        count_at_tile_start = merge_block(buf, ctrl, cap, s, T);
+        const MergeResult mr = merge_block(buf, ctrl, cap, s);
+        count_at_tile_start = uniform32(mr.count);
+        T = uniform64(mr.T);
         safe_mode = true;
         redo = true;
       }
     } while (redo);
 
     // ---- end of tile: decide about merging and the next tile's mode ----
-    const uint32_t cn = ctrl->count;
+    const uint32_t cn = uniform32(ctrl->count);
     const uint32_t appended = cn - (count_at_tile_start < cn ? count_at_tile_start : cn);
     const bool need_merge = cn > s + room / 2;
     safe_mode = appended > room / 4;
     __syncthreads();  // all reads of ctrl->count done before merge or the next tile's appends
-    count_at_tile_start = need_merge ? merge_block(buf, ctrl, cap, s, T) : cn;
+    if (need_merge) {
+      const MergeResult mr = merge_block(buf, ctrl, cap, s);
+      count_at_tile_start = uniform32(mr.count);
+      T = uniform64(mr.T);
+    }
+    else count_at_tile_start = cn;
   }
 
   // ---- final fold and write-out ----
-  uint32_t n = merge_block(buf, ctrl, cap, s, T);
+  uint32_t n = merge_block(buf, ctrl, cap, s).count;
   uint64_t* o = out + sg.out_off;
   for (uint32_t i = t; i < n; i += WG) o[i] = buf[i];
   if (t == 0) {
@@ -437,8 +506,8 @@ __global__ __launch_bounds__(WG) void merge_partials_kernel(const MergeJob* __re
                                                             uint64_t* out,
                                                             uint32_t* cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
-  Ctrl* ctrl = reinterpret_cast<Ctrl*>(smem + (size_t)cap * 8);
+  const lds_u64_ptr buf = (lds_u64_ptr)(lds_byte_ptr)smem;
+  const lds_ctrl_ptr ctrl = (lds_ctrl_ptr)((lds_byte_ptr)smem + (size_t)cap * 8);
   const MergeJob jb = jobs[blockIdx.x];
   const int t = threadIdx.x;
   const uint32_t s = jb.sketch_size;
@@ -458,8 +527,7 @@ __global__ __launch_bounds__(WG) void merge_partials_kernel(const MergeJob* __re
     }
     __syncthreads();
     if (t == 0) ctrl->count = base + pc;
-    uint64_t Tm;
-    nmerged = merge_block(buf, ctrl, cap, s, Tm);
+    nmerged = merge_block(buf, ctrl, cap, s).count;
   }
   uint32_t n = nmerged;
   uint64_t* o = out + jb.out_off;

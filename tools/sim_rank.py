@@ -1,0 +1,29 @@
+"""Per-rank work of the multi-GPU bench shape on ONE GPU: n_total sketches, rank r of `world`.
+Usage: sim_rank.py [n_total] [world] [rank] [length]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from rabbittclust_amd import api, pipeline
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 80000
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+rank = int(sys.argv[3]) if len(sys.argv) > 3 else world - 1
+L = int(sys.argv[4]) if len(sys.argv) > 4 else 100_000
+ctx = api.Context(0)
+desc = api.synth_family_descs(n // 10, 10, global_seed=42)
+off = np.arange(len(desc) + 1, dtype=np.uint64) * np.uint64(L)
+seq = ctx.synth_genomes(desc, off)
+sk = ctx.sketch_minhash(seq, off, k=21, size=1000)
+ctx.sync()
+del seq
+b = pipeline.triangle_row_ranges(sk.n, world)
+pipe = pipeline.MstPipeline(ctx, k=21, sketch_size=1000, threshold=0.05, rank=rank, world=world)
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.time()
+    edges, m = pipe.candidate_edges(sk, b[rank], b[rank + 1])
+    torch.cuda.synchronize(); t1 = time.time()
+    sel, rounds = pipeline.boruvka_rounds(pipeline.HipBoruvkaBackend(ctx, sk, edges, m, False), sk.n, ctx.lib)
+    torch.cuda.synchronize(); t2 = time.time()
+    rows = b[rank + 1] - b[rank]
+    pairs = (b[rank + 1] * (b[rank + 1] - 1) - b[rank] * (b[rank] - 1)) // 2
+    print(f"n={sk.n} rank {rank}/{world}: rows {rows}, pairs {pairs:.3e}, cand edges {m}, pair phase {1e3*(t1-t0):.1f} ms "
+          f"({pairs/(t1-t0):.3e} pairs/s), local boruvka {1e3*(t2-t1):.1f} ms ({rounds} rounds, {len(sel)} forest edges)", flush=True)
