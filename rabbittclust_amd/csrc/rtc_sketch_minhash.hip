@@ -2,9 +2,9 @@
 //
 // Replaces Sketch::MinHash::{update,storeMinHashes} driven from src/SketchInfo.cpp:918-942,969
 // (reference tree paths).  One workgroup (512 lanes = 8 wave64) walks one *segment* of a genome:
-//   * 16-byte coalesced loads stage a ~30 KiB tile of ASCII bases into LDS;
-//   * every lane owns 60 consecutive k-mer end positions of the tile (lane stride 15 dwords ->
-//     conflict-free ds_read_b32) and rolls the 2-bit forward / reverse-complement words;
+//   * every lane owns 124 consecutive k-mer end positions of a 62 KiB tile and reads its 160 bases
+//     (36 warm-up + 124 owned) straight from global memory as ten 16-byte loads, decoding four
+//     bases at once and rolling the 2-bit forward / reverse-complement words;
 //   * MurmurHash3_x64_128 of the canonical k-mer's ASCII bytes is evaluated from the 2-bit word:
 //     the first multiplication of every input word comes out of LDS product tables (linearity of
 //     multiplication mod 2^64), leaving seven 64x64 multiplies per k-mer; four k-mers per lane
@@ -22,7 +22,12 @@ namespace {
 
 constexpr int WG = 512;                               // lanes per workgroup (8 waves)
 constexpr int NWAVE = WG / 64;
-constexpr int RUN_DW = 15;                            // dwords of owned bases per lane per tile
+#ifndef RTC_RUN_DW
+#define RTC_RUN_DW 31
+#endif
+constexpr int RUN_DW = RTC_RUN_DW;                    // dwords of owned bases per lane per tile
+constexpr int OWN = RUN_DW * 4;                       // k-mer end positions a lane owns per tile
+static_assert((RUN_DW + 9) % 4 == 0, "a lane's window must be whole 16-byte loads");
 constexpr int WARM_DW = 9;                            // 36 warm-up bases (k-1 <= 31); 9+15 dwords = six 16-byte loads
 constexpr int TILE_BASES = WG * RUN_DW * 4;           // bases per tile
 constexpr int STEP_APPENDS = WG * 4;                  // worst-case appends per dword iteration
@@ -128,7 +133,8 @@ __device__ __forceinline__ uint64_t rotl64c(uint64_t x) {
     nh = __builtin_amdgcn_alignbit(lo, hi, 64 - R);
     nl = __builtin_amdgcn_alignbit(hi, lo, 64 - R);
   }
-  return ((uint64_t)nh << 32) | nl;
+  // assembled as a register pair (a shift-or would be re-associated into the additions that follow)
+  return __builtin_bit_cast(uint64_t, make_uint2(nl, nh));
 }
 
 // x*5 as one v_lshl_add_u64 ((x << 2) + x); the compiler's choice is two v_mad_u64_u32 plus moves
@@ -179,7 +185,11 @@ __device__ __forceinline__ uint64_t kmer_hash(uint64_t x, const KParams& P) {
   uint64_t h1 = P.seed, h2 = P.seed;
   uint64_t t0 = A0, t1 = B0;  // tail words (already multiplied by c1 / c2)
   if (k >= 16) {
-    mm_body(h1, h2, A0, B0);
+    // first block with h1 == h2 == seed folded in: 5*(rotl27(seed ^ k1) + seed) + c = 5*rotl27(..) + (5*seed + c)
+    h1 = rotl64c<27>(h1 ^ (rotl64c<31>(A0) * MM_C2));
+    h1 = times5(h1) + (5ULL * P.seed + 0x52dce729ULL);
+    h2 = rotl64c<31>(h2 ^ (rotl64c<33>(B0) * MM_C1)) + h1;
+    h2 = times5(h2) + 0x38495ab5ULL;
     t0 = A1; t1 = B1;
     if (k == 32) { mm_body(h1, h2, A1, B1); t0 = 0; t1 = 0; }
   }
@@ -258,9 +268,9 @@ __device__ __noinline__ MergeResult merge_block(lds_u64_ptr buf, lds_ctrl_ptr ct
   return MergeResult{c, newT};
 }
 
-// One lane's view of a tile: 96 consecutive bases = 36 warm-up + 60 owned k-mer end positions,
-// fetched straight from global memory as six 16-byte loads (no LDS staging: the 30 KiB tile would
-// cost a third of the occupancy, and each line is still read from HBM once -- neighbouring lanes
+// One lane's view of a tile: 160 consecutive bases = 36 warm-up + 124 owned k-mer end positions,
+// fetched straight from global memory as ten 16-byte loads (no LDS staging: the 62 KiB tile would
+// cost most of the occupancy, and each line is still read from HBM once -- neighbouring lanes
 // share lines through L2).
 __device__ __forceinline__ uint4 load_bases16(const uint8_t* __restrict__ seq, int64_t q, uint64_t g_begin,
                                               uint64_t g_end) {
@@ -335,18 +345,20 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
 
   uint32_t count_at_tile_start = 0;  // carried in registers: identical in every thread
   for (uint64_t T0 = sg.s_begin & ~15ULL; T0 < sg.s_end && s > 0; T0 += TILE_BASES) {
-    // owned positions of this lane relative to T0: [60t, 60t+60); hash window limits
+    // owned positions of this lane relative to T0: [OWN*t, OWN*t + OWN); hash window limits
     const int64_t lo64 = (int64_t)sg.s_begin - (int64_t)T0;
     const int64_t hi64 = (int64_t)sg.s_end - (int64_t)T0;
     const int rel_lo = lo64 < 0 ? 0 : (int)lo64;
     const int rel_hi = hi64 > TILE_BASES ? TILE_BASES : (int)hi64;
-    const int64_t p0 = (int64_t)T0 + 60 * t - 4 * WARM_DW;  // first base of this lane's window
+    const bool interior = rel_lo == 0 && rel_hi == TILE_BASES;  // every position of the tile is owned
+    const int64_t p0 = (int64_t)T0 + OWN * t - 4 * WARM_DW;  // first base of this lane's window
 
     bool redo;
     do {
       redo = false;
       uint64_t fwd = 0, rc = 0;
       int run = 0;
+      bool clean = true;  // wave-uniform: only valid bases in every lane of this wave so far in this pass
       uint4 nxt = load_bases16(seq, p0, sg.g_begin, sg.g_end);
       for (int grp = 0; grp < (WARM_DW + RUN_DW) / 4; grp++) {
         const uint4 cur = nxt;
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
           const int d = grp * 4 + qd;
           const uint32_t wv = wv4[qd];
           const bool hashing = d >= WARM_DW;  // wave-uniform
-          const int rel0 = 60 * t + 4 * (d - WARM_DW);
+          const int rel0 = OWN * t + 4 * (d - WARM_DW);
           if (safe_mode && hashing) {
             // bound the next dword's appends so the buffer cannot overflow
             __syncthreads();
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
             if ((uint32_t)cap - cn < (uint32_t)STEP_APPENDS) T = uniform64(merge_block(buf, ctrl, cap, s).T);
             __syncthreads();
           }
-          uint64_t canon[4];  // top-aligned (first base in bit 63)
+          uint64_t canon[4] = {0, 0, 0, 0};  // top-aligned (first base in bit 63); hashing dwords only
           bool ok[4] = {false, false, false, false};  // slow path only; the fast path derives it on demand
           bool allok = false;  // wave-uniform: all four k-mers of every lane are valid and owned
           // ---- decode four bases at once ----
@@ -373,6 +385,7 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
           const uint32_t codes4 = ((wv >> 1) ^ (wv >> 2)) & 0x03030303u;  // A,C,G,T (either case) -> 0..3 per byte
           const bool allvalid = __builtin_amdgcn_perm(0u, 0x54474341u, codes4) == up;
           const bool fast = fastroll && __all(allvalid);  // wave-uniform
+          clean = clean && fast;
           const int run_in = run;
           if (fast) {
             // pack = c0<<6|c1<<4|c2<<2|c3 ; rp = complement codes in reverse significance
@@ -380,15 +393,20 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
             const uint32_t rp = ((codes4 * 0x01041040u) >> 24) ^ 0xffu;
             const uint64_t F = (fwd << 8) | pack;
             const uint64_t R = rc | ((uint64_t)rp << (2 * P.k));
-            if (hashing) allok = __all(run + 1 >= P.k && rel0 >= rel_lo && rel0 + 3 < rel_hi);
-            // the four windows are cut out of F / R already top-aligned (one shift + one mask each):
-            // the order of two k-mers does not depend on the alignment, and the hash wants them there
-            const uint64_t topmask = P.kmask << P.lshift;
+            if (hashing) {
+              // Scalar ownership test for the steady state: in a tile interior to the segment, a wave
+              // that has seen only valid bases since the tile began has run = 4d >= 36 >= k-1 in every
+              // lane, and every position of the tile is owned.  Anything else takes the per-lane test.
+              allok = interior && clean;
+              // the four windows are cut out of F / R already top-aligned (one shift + one mask each):
+              // the order of two k-mers does not depend on the alignment, and the hash wants them there
+              const uint64_t topmask = P.kmask << P.lshift;
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-              const uint64_t f = (F << (P.lshift - 6 + 2 * b)) & topmask;   // lshift >= 8 in this path
-              const uint64_t r = (R << (P.lshift - 2 - 2 * b)) & topmask;
-              canon[b] = f < r ? f : r;
+              for (int b = 0; b < 4; b++) {
+                const uint64_t f = (F << (P.lshift - 6 + 2 * b)) & topmask;   // lshift >= 8 in this path
+                const uint64_t r = (R << (P.lshift - 2 - 2 * b)) & topmask;
+                canon[b] = f < r ? f : r;
+              }
             }
             fwd = F & P.kmask;
             rc = (R >> 8) & P.kmask;
@@ -579,7 +597,7 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   }
   const uint64_t target_segs = (uint64_t)ctx->num_cu * 12;
   uint64_t seg_len = total / target_segs;
-  const uint64_t min_seg = 8ull * TILE_BASES;
+  const uint64_t min_seg = 4ull * TILE_BASES;
   if (seg_len < min_seg) seg_len = min_seg;
 
   struct PassPlan { size_t direct0, ndirect, partial0, npartial, job0, njobs; };
