@@ -203,17 +203,34 @@ __device__ __forceinline__ uint64_t kmer_hash(uint64_t x, const KParams& P) {
   return P.use64 ? h1 : (h1 & 0xffffffffULL);
 }
 
-// ---- block-wide merge: sort buf[0..CAP), drop duplicates, keep the `s` smallest ----------------
-__device__ void bitonic_sort_lds(lds_u64_ptr buf, int cap) {
+// ---- block-wide merge: sort buf[0..n), drop duplicates, keep the `s` smallest -----------------
+// Normalised bitonic network (every compare-exchange ascending, first step of each merge mirrored)
+// over the next power of two >= n; positions >= n stand for +infinity, which an ascending exchange
+// never moves, so those exchanges are simply skipped and n may be any number.
+__device__ void bitonic_sort_lds(lds_u64_ptr buf, int n) {
   const int t = threadIdx.x;
-  for (int k = 2; k <= cap; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = t; i < (cap >> 1); i += WG) {
+  int n2 = 2;
+  while (n2 < n) n2 <<= 1;
+  for (int k = 2; k <= n2; k <<= 1) {
+    const int hk = k >> 1;
+    for (int i = t; i < (n2 >> 1); i += WG) {
+      const int off = i & (hk - 1);
+      const int a = ((i - off) << 1) | off;       // block base (i / hk) * k, plus off
+      const int b = (a - off) + (k - 1 - off);    // mirrored partner within the block
+      if (b < n) {
+        const uint64_t va = buf[a], vb = buf[b];
+        if (va > vb) { buf[a] = vb; buf[b] = va; }
+      }
+    }
+    __syncthreads();
+    for (int j = k >> 2; j > 0; j >>= 1) {
+      for (int i = t; i < (n2 >> 1); i += WG) {
         const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
         const int b = a | j;
-        const bool up = (a & k) == 0;
-        const uint64_t va = buf[a], vb = buf[b];
-        if ((va > vb) == up) { buf[a] = vb; buf[b] = va; }
+        if (b < n) {
+          const uint64_t va = buf[a], vb = buf[b];
+          if (va > vb) { buf[a] = vb; buf[b] = va; }
+        }
       }
       __syncthreads();
     }
@@ -229,16 +246,16 @@ __device__ __noinline__ MergeResult merge_block(lds_u64_ptr buf, lds_ctrl_ptr ct
   bool saw = false;  // a genuine hash equal to the padding value: remembered, re-appended at the end
   for (uint32_t i = t; i < n; i += WG) saw |= buf[i] == SENT;
   if (saw) ctrl->saw_max = 1;
-  for (int i = n + t; i < cap; i += WG) buf[i] = SENT;
   if (t == 0) ctrl->scan_base = 0;
   __syncthreads();
-  bitonic_sort_lds(buf, cap);
+  bitonic_sort_lds(buf, (int)n);
   // streaming compaction in rounds of WG elements (dest <= src always)
   const uint32_t lane = t & 63, wave = t >> 6;
-  for (int r = 0; r < cap; r += WG) {
+  for (int r = 0; r < (int)n; r += WG) {
     const int idx = r + t;
-    const uint64_t v = buf[idx];
-    const bool keep = v != SENT && (idx == 0 || v != buf[idx - 1]);
+    const bool in = idx < (int)n;
+    const uint64_t v = in ? buf[idx] : SENT;
+    const bool keep = in && v != SENT && (idx == 0 || v != buf[idx - 1]);
     const uint64_t bal = __ballot(keep);
     const uint32_t before = __popcll(bal & ((1ULL << lane) - 1ULL));
     if (lane == 0) ctrl->wave_tot[wave] = (uint32_t)__popcll(bal);
@@ -581,9 +598,24 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   const uint32_t CHUNK = 6144;
   const uint32_t chunk_max = std::min(smax, CHUNK);
   const uint32_t npass = smax == 0 ? 1 : (smax + CHUNK - 1) / CHUNK;
-  // candidate buffer of the sketch kernel: s + room; of the partial-merge kernel: two s-lists
-  const int cap = pow2ceil((int)(chunk_max + MIN_ROOM));
-  const int cap_merge = pow2ceil((int)std::max<uint32_t>(2 * chunk_max, 1024));
+  // Candidate buffer of the sketch kernel: s entries + room, as large as the LDS share of a workgroup
+  // allows at the best occupancy that still leaves MIN_ROOM (3, 2 or 1 workgroups per CU; the sort
+  // works on the live count, so the capacity need not be a power of two).  Partial-merge kernel:
+  // two s-lists.
+  int cap = 0;
+  int wgs_lo = 1, wgs_hi = 3;
+  if (const char* e = getenv("RTC_SKETCH_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 3) wgs_lo = wgs_hi = v; }  // tuning experiments
+  for (int wgs = wgs_hi; wgs >= wgs_lo && cap == 0; wgs--) {
+    // 52 / 78 / 156 KiB: measured on MI355X, a 53.3 KiB allocation no longer runs three workgroups per CU
+    const size_t share = ((size_t)156 * 1024 / wgs) & ~(size_t)2047;
+    const size_t fixed = lut_bytes(k) + sizeof(Ctrl);
+    // below ~3000 entries of room the merges (and safe-mode barriers) cost more than the lost occupancy
+    const size_t want_room = wgs > wgs_lo ? 3072 : MIN_ROOM;
+    if (share > fixed && (share - fixed) / 8 >= (size_t)chunk_max + want_room) cap = (int)((share - fixed) / 8);
+  }
+  if (cap == 0) return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "sketch chunk %u does not fit the LDS", chunk_max);
+  if (const char* e = getenv("RTC_SKETCH_CAP")) { const int v = atoi(e); if (v >= (int)(chunk_max + MIN_ROOM) && v <= cap) cap = v; }  // tuning experiments
+  const int cap_merge = (int)std::max<uint32_t>(2 * chunk_max, 1024);
   const size_t lds = (size_t)cap * 8 + lut_bytes(k) + sizeof(Ctrl);
   const size_t lds_m = (size_t)cap_merge * 8 + sizeof(Ctrl);
   if (lds > (size_t)160 * 1024 || lds_m > (size_t)160 * 1024)

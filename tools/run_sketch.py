@@ -6,6 +6,8 @@ from rabbittclust_amd import api
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 5_000_000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+size = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
+k = int(sys.argv[5]) if len(sys.argv) > 5 else 21
 ctx = api.Context(0)
 desc = api.synth_family_descs(max(1, n // 10), 10, global_seed=42)
 n = len(desc)
@@ -13,6 +15,6 @@ off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
 seq = ctx.synth_genomes(desc, off); ctx.sync()
 for r in range(reps):
     ctx.timer_start()
-    sk = ctx.sketch_minhash(seq, off, k=21, size=1000)
+    sk = ctx.sketch_minhash(seq, off, k=k, size=size)
     ms = ctx.timer_stop()
-    print(f"sketch {n} x {L}: {ms:.2f} ms  {n*L/ms/1e6:.1f} Gbp/s", flush=True)
+    print(f"sketch {n} x {L} k={k} s={size}: {ms:.2f} ms  {n*L/ms/1e6:.1f} Gbp/s", flush=True)
