@@ -694,7 +694,21 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     d_pcnt = (uint32_t*)((char*)ws1 + part_elems_max * 8);
   }
 
-  auto kern = k == 21 ? sketch_minhash_kernel<21> : sketch_minhash_kernel<0>;
+  // compile-time k for the values the reference's tune_parameters lands on for Mbp..Gbp genomes
+  // (recommended k = ceil(log4(maxSize * 9999)): 17..23) and its default 21; anything else takes
+  // the runtime-k kernel
+  auto kern = sketch_minhash_kernel<0>;
+  switch (k) {
+    case 16: kern = sketch_minhash_kernel<16>; break;
+    case 17: kern = sketch_minhash_kernel<17>; break;
+    case 18: kern = sketch_minhash_kernel<18>; break;
+    case 19: kern = sketch_minhash_kernel<19>; break;
+    case 20: kern = sketch_minhash_kernel<20>; break;
+    case 21: kern = sketch_minhash_kernel<21>; break;
+    case 22: kern = sketch_minhash_kernel<22>; break;
+    case 23: kern = sketch_minhash_kernel<23>; break;
+    default: break;
+  }
   RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   RTC_HIP(ctx, hipFuncSetAttribute((const void*)merge_partials_kernel,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
