@@ -22,8 +22,9 @@
 namespace {
 
 constexpr int WG = 512;
-constexpr int RUN_DW = 15;
-constexpr int WARM_DW = 9;   // 36 warm-up bases; 9 + 15 dwords = six 16-byte loads per lane and tile
+constexpr int RUN_DW = 31;   // 124 owned k-mer end positions per lane and tile
+constexpr int OWN = RUN_DW * 4;
+constexpr int WARM_DW = 9;   // 36 warm-up bases; 9 + 31 dwords = ten 16-byte loads per lane and tile
 constexpr int TILE_BASES = WG * RUN_DW * 4;
 constexpr int MAX_LDS_KEEP = 8192;
 constexpr uint32_t CK_EMPTY = 0xFFFFFFFFu;
@@ -66,8 +67,8 @@ __device__ __forceinline__ uint4 load_bases16(const uint8_t* __restrict__ seq, i
   return make_uint4(ww[0], ww[1], ww[2], ww[3]);
 }
 
-// Each lane walks 96 consecutive bases per tile (36 warm-up + 60 owned k-mer end positions) read
-// straight from global memory as six 16-byte loads; four bases are decoded at once (SWAR) and the
+// Each lane walks 160 consecutive bases per tile (36 warm-up + 124 owned k-mer end positions) read
+// straight from global memory as ten 16-byte loads; four bases are decoded at once (SWAR) and the
 // four k-mers of a dword are filtered back to back.
 template <typename OutT, bool LDS_INDEX>
 __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restrict__ seq,
@@ -100,10 +101,12 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
     const int64_t hi64 = (int64_t)sg.s_end - (int64_t)T0;
     const int rel_lo = lo64 < 0 ? 0 : (int)lo64;
     const int rel_hi = hi64 > TILE_BASES ? TILE_BASES : (int)hi64;
-    const int64_t p0 = (int64_t)T0 + 60 * t - 4 * WARM_DW;
+    const bool interior = rel_lo == 0 && rel_hi == TILE_BASES;  // every position of the tile is owned
+    const int64_t p0 = (int64_t)T0 + OWN * t - 4 * WARM_DW;
 
     uint64_t tuple = 0, rvs = 0;
     int run = 0;
+    bool clean = true;  // wave-uniform: only valid bases in every lane of this wave so far in this tile
     uint4 nxt = load_bases16(seq, p0, sg.g_begin, sg.g_end);
     for (int grp = 0; grp < (WARM_DW + RUN_DW) / 4; grp++) {
       const uint4 cur = nxt;
@@ -114,27 +117,42 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
         const int d = grp * 4 + qd;
         const uint32_t wv = wv4[qd];
         const bool emitting = d >= WARM_DW;  // wave-uniform
-        const int rel0 = 60 * t + 4 * (d - WARM_DW);
-        uint64_t uni[4];
-        bool ok[4];
+        const int rel0 = OWN * t + 4 * (d - WARM_DW);
+        uint64_t uni[4] = {0, 0, 0, 0};
+        bool ok[4] = {false, false, false, false};
         const uint32_t up = wv & 0xDFDFDFDFu;
         const uint32_t codes4 = ((wv >> 1) ^ (wv >> 2)) & 0x03030303u;  // BaseMap, src/SketchInfo.cpp:1007-1017
         const bool allvalid = __builtin_amdgcn_perm(0u, 0x54474341u, codes4) == up;
-        if (fastroll && __all(allvalid)) {
+        const bool fast = fastroll && __all(allvalid);  // wave-uniform
+        clean = clean && fast;
+        if (fast) {
           const uint32_t pack = (codes4 * 0x40100401u) >> 24;
           const uint32_t rp = ((codes4 * 0x01041040u) >> 24) ^ 0xffu;
           const uint64_t F = (tuple << 8) | pack;
           const uint64_t R = rvs | ((uint64_t)rp << (2 * P.K));
-          const bool allok = __all(run + 1 >= P.K && rel0 >= rel_lo && rel0 + 3 < rel_hi);
+          if (emitting) {
+            // scalar ownership test for the steady state (tile interior to the segment, only valid
+            // bases in this wave since the tile began => run = 4d >= 36 >= K-1 and every position owned)
+            const bool allok = interior && clean;
 #pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const uint64_t f = (F >> (6 - 2 * b)) & P.tupmask;                      // :1134 four times
-            const uint64_t r = (R >> (2 * b + 2)) & P.tupmask;                      // :1135 four times
-            const int rel = rel0 + b;
-            ok[b] = allok || (run + b + 1 >= P.K && rel >= rel_lo && rel < rel_hi);  // :1139
-            uni[b] = f < r ? f : r;                                                 // :1141
-            if (b == 3) { tuple = f; rvs = r; }
+            for (int b = 0; b < 4; b++) {
+              const uint64_t f = (F >> (6 - 2 * b)) & P.tupmask;                      // :1134 four times
+              const uint64_t r = (R >> (2 * b + 2)) & P.tupmask;                      // :1135 four times
+              uni[b] = f < r ? f : r;                                                 // :1141
+            }
+            if (allok) {
+#pragma unroll
+              for (int b = 0; b < 4; b++) ok[b] = true;
+            } else {
+#pragma unroll
+              for (int b = 0; b < 4; b++) {
+                const int rel = rel0 + b;
+                ok[b] = run + b + 1 >= P.K && rel >= rel_lo && rel < rel_hi;           // :1139
+              }
+            }
           }
+          tuple = F & P.tupmask;
+          rvs = (R >> 8) & P.tupmask;
           run += 4;
         } else {
 #pragma unroll
@@ -553,7 +571,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
     total += h_off[g + 1] - h_off[g];
   }
   uint64_t seg_len = total / ((uint64_t)ctx->num_cu * 12);
-  const uint64_t min_seg = 8ull * TILE_BASES;
+  const uint64_t min_seg = 4ull * TILE_BASES;
   if (seg_len < min_seg) seg_len = min_seg;
   std::vector<KSegment> segs;
   segs.reserve(n + 1024);
