@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def measured_traffic(kernel, args):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (request-size counters,
     profiles/r01_pmc_traffic.json), valid only for the workload they were collected on."""
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))

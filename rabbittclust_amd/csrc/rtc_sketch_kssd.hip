@@ -22,9 +22,9 @@
 namespace {
 
 constexpr int WG = 512;
-constexpr int RUN_DW = 31;   // 124 owned k-mer end positions per lane and tile
+constexpr int RUN_DW = 19;   // 76 owned k-mer end positions per lane and tile (live lines stay within L2, see rtc_sketch_minhash.hip)
 constexpr int OWN = RUN_DW * 4;
-constexpr int WARM_DW = 9;   // 36 warm-up bases; 9 + 31 dwords = ten 16-byte loads per lane and tile
+constexpr int WARM_DW = 9;   // 36 warm-up bases; 9 + 19 dwords = seven 16-byte loads per lane and tile
 constexpr int TILE_BASES = WG * RUN_DW * 4;
 constexpr int MAX_LDS_KEEP = 8192;
 constexpr uint32_t CK_EMPTY = 0xFFFFFFFFu;
@@ -67,8 +67,8 @@ __device__ __forceinline__ uint4 load_bases16(const uint8_t* __restrict__ seq, i
   return make_uint4(ww[0], ww[1], ww[2], ww[3]);
 }
 
-// Each lane walks 160 consecutive bases per tile (36 warm-up + 124 owned k-mer end positions) read
-// straight from global memory as ten 16-byte loads; four bases are decoded at once (SWAR) and the
+// Each lane walks 112 consecutive bases per tile (36 warm-up + 76 owned k-mer end positions) read
+// straight from global memory as seven 16-byte loads; four bases are decoded at once (SWAR) and the
 // four k-mers of a dword are filtered back to back.
 template <typename OutT, bool LDS_INDEX>
 __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restrict__ seq,

@@ -2,8 +2,8 @@
 //
 // Replaces Sketch::MinHash::{update,storeMinHashes} driven from src/SketchInfo.cpp:918-942,969
 // (reference tree paths).  One workgroup (512 lanes = 8 wave64) walks one *segment* of a genome:
-//   * every lane owns 124 consecutive k-mer end positions of a 62 KiB tile and reads its 160 bases
-//     (36 warm-up + 124 owned) straight from global memory as ten 16-byte loads, decoding four
+//   * every lane owns 76 consecutive k-mer end positions of a 38 KiB tile and reads its 112 bases
+//     (36 warm-up + 76 owned) straight from global memory as seven 16-byte loads, decoding four
 //     bases at once and rolling the 2-bit forward / reverse-complement words;
 //   * MurmurHash3_x64_128 of the canonical k-mer's ASCII bytes is evaluated from the 2-bit word:
 //     the first multiplication of every input word comes out of LDS product tables (linearity of
@@ -23,7 +23,10 @@ namespace {
 constexpr int WG = 512;                               // lanes per workgroup (8 waves)
 constexpr int NWAVE = WG / 64;
 #ifndef RTC_RUN_DW
-#define RTC_RUN_DW 31
+// 19 dwords = 76 owned positions per lane and tile: lane runs 76 B apart keep the set of live 128-B
+// lines (one or two lanes per line, ~1500 lanes per CU) inside the 4 MiB L2 of an XCD.  31 dwords is
+// 1 % faster but re-reads 80 % of the input from the fabric (measured: TCC_EA0_RDREQ_128B).
+#define RTC_RUN_DW 19
 #endif
 constexpr int RUN_DW = RTC_RUN_DW;                    // dwords of owned bases per lane per tile
 constexpr int OWN = RUN_DW * 4;                       // k-mer end positions a lane owns per tile
@@ -285,21 +288,25 @@ __device__ __noinline__ MergeResult merge_block(lds_u64_ptr buf, lds_ctrl_ptr ct
   return MergeResult{c, newT};
 }
 
-// One lane's view of a tile: 160 consecutive bases = 36 warm-up + 124 owned k-mer end positions,
-// fetched straight from global memory as ten 16-byte loads (no LDS staging: the 62 KiB tile would
+// One lane's view of a tile: 112 consecutive bases = 36 warm-up + 76 owned k-mer end positions,
+// fetched straight from global memory as seven 16-byte loads (no LDS staging: the 38 KiB tile would
 // cost most of the occupancy, and each line is still read from HBM once -- neighbouring lanes
 // share lines through L2).
-__device__ __forceinline__ uint4 load_bases16(const uint8_t* __restrict__ seq, int64_t q, uint64_t g_begin,
-                                              uint64_t g_end) {
-  if (q >= (int64_t)g_begin && q + 16 <= (int64_t)g_end) return *reinterpret_cast<const uint4*>(seq + q);
+// `tile` points at the tile's first base (wave-uniform, lives in SGPRs); rq is the lane's offset
+// relative to it and [gb, ge) the genome's extent in the same coordinates (clamped to +-2^30), so the
+// lane keeps 32-bit offsets only and the load is an SGPR-base + VGPR-offset global_load_dwordx4.
+constexpr int LOAD_BIAS = 64;  // offsets handed to the load are rq + LOAD_BIAS >= 0 (rq >= -4*WARM_DW)
+__device__ __forceinline__ uint4 load_bases16(const uint8_t* __restrict__ tile, int rq, int gb, int ge) {
+  if (rq >= gb && rq + 16 <= ge)
+    return *reinterpret_cast<const uint4*>((tile - LOAD_BIAS) + (uint32_t)(rq + LOAD_BIAS));
   uint32_t ww[4];
 #pragma unroll
   for (int d = 0; d < 4; d++) {
     uint32_t x = 0;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
-      const int64_t p = q + 4 * d + b;
-      const uint32_t ch = (p >= (int64_t)g_begin && p < (int64_t)g_end) ? seq[p] : (uint32_t)'N';
+      const int p = rq + 4 * d + b;
+      const uint32_t ch = (p >= gb && p < ge) ? (tile - LOAD_BIAS)[(uint32_t)(p + LOAD_BIAS)] : (uint32_t)'N';
       x |= ch << (8 * b);
     }
     ww[d] = x;
@@ -368,7 +375,11 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
     const int rel_lo = lo64 < 0 ? 0 : (int)lo64;
     const int rel_hi = hi64 > TILE_BASES ? TILE_BASES : (int)hi64;
     const bool interior = rel_lo == 0 && rel_hi == TILE_BASES;  // every position of the tile is owned
-    const int64_t p0 = (int64_t)T0 + OWN * t - 4 * WARM_DW;  // first base of this lane's window
+    const uint8_t* tile = seq + T0;                 // wave-uniform
+    const int rq0 = OWN * t - 4 * WARM_DW;          // first base of this lane's window, relative to the tile
+    const int64_t gb64 = (int64_t)sg.g_begin - (int64_t)T0, ge64 = (int64_t)sg.g_end - (int64_t)T0;
+    const int gb = gb64 < -(1 << 30) ? -(1 << 30) : (int)gb64;   // genome extent in tile coordinates
+    const int ge = ge64 > (1 << 30) ? (1 << 30) : (int)ge64;
 
     bool redo;
     do {
@@ -376,10 +387,10 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
       uint64_t fwd = 0, rc = 0;
       int run = 0;
       bool clean = true;  // wave-uniform: only valid bases in every lane of this wave so far in this pass
-      uint4 nxt = load_bases16(seq, p0, sg.g_begin, sg.g_end);
+      uint4 nxt = load_bases16(tile, rq0, gb, ge);
       for (int grp = 0; grp < (WARM_DW + RUN_DW) / 4; grp++) {
         const uint4 cur = nxt;
-        if (grp + 1 < (WARM_DW + RUN_DW) / 4) nxt = load_bases16(seq, p0 + 16 * (grp + 1), sg.g_begin, sg.g_end);
+        if (grp + 1 < (WARM_DW + RUN_DW) / 4) nxt = load_bases16(tile, rq0 + 16 * (grp + 1), gb, ge);
         const uint32_t wv4[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
