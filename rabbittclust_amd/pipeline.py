@@ -18,13 +18,18 @@ from .api import CEDGE_DT, EDGE_DT, SketchSet, _np_ptr, _t_ptr, mst_radio
 KEY_NONE = 0x7FFFFFFFFFFFFFFF
 
 
-def triangle_row_ranges(n, world):
-    """Contiguous row ranges [b_r, b_{r+1}) of the strict lower triangle with ~equal pair counts
-    (row i owns i pairs, so boundaries go like n*sqrt(r/world))."""
-    b = [int(round(n * math.sqrt(r / world))) for r in range(world + 1)]
+def triangle_row_ranges(n, world, fixed_cols=0.0):
+    """Contiguous row ranges [b_r, b_{r+1}) of the strict lower triangle with ~equal cost.
+    Row i costs (i + fixed_cols): i pairs plus the per-row-block work that does not depend on the
+    row's length (building the LDS tables of its 64-row block costs as much as ~8.8 columns per
+    sketch hash on MI355X: tools/sim_rank.py).  With fixed_cols = 0 the split is by pair count,
+    boundaries n*sqrt(r/world)."""
+    c = float(fixed_cols)
+    area = n * n / 2.0 + c * n
+    b = [int(round(-c + math.sqrt(c * c + 2.0 * area * r / world))) for r in range(world + 1)]
     b[0], b[-1] = 0, n
     for r in range(1, world + 1):
-        b[r] = max(b[r], b[r - 1])
+        b[r] = min(max(b[r], b[r - 1]), n)
     return b
 
 
@@ -177,7 +182,7 @@ class MstPipeline:
         ev[1].record()
         sk = self.gather_sketches(sk_local)
         ev[2].record()
-        b = triangle_row_ranges(sk.n, self.world)
+        b = triangle_row_ranges(sk.n, self.world, fixed_cols=8.8 * self.s if self.world > 1 else 0.0)
         row0, row1 = b[self.rank], b[self.rank + 1]
         edges, m = self.candidate_edges(sk, row0, row1)
         ev[3].record()

@@ -141,3 +141,17 @@ def test_triangle_row_ranges_balance():
         if n >= 1000:
             work = [(b[i + 1] ** 2 - b[i] ** 2) / 2 for i in range(w)]
             assert max(work) / (sum(work) / w) < 1.02
+
+
+def test_triangle_row_ranges_with_fixed_row_cost():
+    """Cost-aware split: row i weighs (i + fixed_cols); ranges stay contiguous, cover [0, n) and
+    balance that weight, so the rank that owns the short rows at the top gets fewer pairs."""
+    from rabbittclust_amd.pipeline import triangle_row_ranges
+    n, w, c = 80000, 8, 8800.0
+    b = triangle_row_ranges(n, w, fixed_cols=c)
+    assert b[0] == 0 and b[-1] == n and all(b[i] < b[i + 1] for i in range(w))
+    cost = [(b[i + 1] ** 2 - b[i] ** 2) / 2 + c * (b[i + 1] - b[i]) for i in range(w)]
+    assert max(cost) / (sum(cost) / w) < 1.01
+    pairs = [(b[i + 1] ** 2 - b[i] ** 2) / 2 for i in range(w)]
+    assert pairs[0] < pairs[-1]
+    assert triangle_row_ranges(n, w, fixed_cols=0.0) == triangle_row_ranges(n, w)
