@@ -112,6 +112,51 @@ __device__ __forceinline__ unsigned long long table_lookup(const uint32_t* keys,
   }
 }
 
+// First-bucket probe of four keys at once: all bucket reads are issued before any compare.
+// hit[j]: key j found, slot[j] its slot; slow[j]: undecided by the home bucket (bucket full without a
+// match, or the key is the EMPTY marker itself) -> the caller falls back to table_lookup.
+template <typename T>
+__device__ __forceinline__ void home_bucket_probe4(const T* keys, const T (&bq)[4], uint32_t e, uint32_t mylen,
+                                                   uint32_t (&slot)[4], bool (&hit)[4], bool (&slow)[4]) {
+  uint32_t b[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) b[j] = KeyTraits<T>::bucket(bq[j]) * BUCKET;
+  if constexpr (sizeof(T) == 8) {
+    ulonglong2 k01[4], k23[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      k01[j] = *reinterpret_cast<const ulonglong2*>(&keys[b[j]]);
+      k23[j] = *reinterpret_cast<const ulonglong2*>(&keys[b[j] + 2]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const bool valid = e + j < mylen;
+      const T key = bq[j];
+      const bool h0 = k01[j].x == key, h1 = k01[j].y == key, h2 = k23[j].x == key, h3 = k23[j].y == key;
+      const bool anyempty = k01[j].x == ~0ULL || k01[j].y == ~0ULL || k23[j].x == ~0ULL || k23[j].y == ~0ULL;
+      const bool marker = key == KeyTraits<T>::EMPTY;
+      hit[j] = valid && !marker && (h0 | h1 | h2 | h3);
+      slot[j] = b[j] + (h1 ? 1u : 0u) + (h2 ? 2u : 0u) + (h3 ? 3u : 0u);
+      slow[j] = valid && (marker || (!(h0 | h1 | h2 | h3) && !anyempty));
+    }
+  } else {
+    uint4 kk[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) kk[j] = *reinterpret_cast<const uint4*>(&keys[b[j]]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const bool valid = e + j < mylen;
+      const T key = bq[j];
+      const bool h0 = kk[j].x == key, h1 = kk[j].y == key, h2 = kk[j].z == key, h3 = kk[j].w == key;
+      const bool anyempty = kk[j].x == ~0u || kk[j].y == ~0u || kk[j].z == ~0u || kk[j].w == ~0u;
+      const bool marker = key == KeyTraits<T>::EMPTY;
+      hit[j] = valid && !marker && (h0 | h1 | h2 | h3);
+      slot[j] = b[j] + (h1 ? 1u : 0u) + (h2 ? 2u : 0u) + (h3 ? 3u : 0u);
+      slow[j] = valid && (marker || (!(h0 | h1 | h2 | h3) && !anyempty));
+    }
+  }
+}
+
 // so: [(P+1)][n] slice offsets (so[p][g] = lower_bound(sketch g, bound[p])), so[0]=0, so[P]=len.
 template <typename T, int NPL>
 __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ hashes,
@@ -191,26 +236,45 @@ __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ ha
       }
       __syncthreads();
       // ---- probe: this lane's column slice, read coalesced from the transposed copy ----
+      // Four keys per trip.  The next trip's global loads are issued before this trip's table work;
+      // the four home buckets are read back to back (no data-dependent loop in the common case),
+      // the row masks are fetched only by waves in which some lane hit, and the rare key whose home
+      // bucket is full without a match (or that equals the EMPTY marker) takes the looping lookup.
       {
         const T* tp = tcols + tbase[p] + c;
         const uint32_t mylen = chi - clo;
-        // four elements per trip: the global loads are issued together, then the four LDS lookups
+        T nq[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) nq[j] = (j < (int)mylen) ? tp[(size_t)j * n] : (T)0;
         for (uint32_t e = 0; e < mylen; e += 4) {
           T bq[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++) bq[j] = (e + j < mylen) ? tp[(size_t)(e + j) * n] : (T)0;
-          unsigned long long mq[4];
+          for (int j = 0; j < 4; j++) bq[j] = nq[j];
 #pragma unroll
-          for (int j = 0; j < 4; j++) mq[j] = (e + j < mylen) ? table_lookup(keys, masks, sh, bq[j]) : 0ULL;
+          for (int j = 0; j < 4; j++) nq[j] = (e + 4 + j < mylen) ? tp[(size_t)(e + 4 + j) * n] : (T)0;
+          uint32_t slot[4];
+          bool hit[4], slow[4];
+          home_bucket_probe4<T>(keys, bq, e, mylen, slot, hit, slow);
+          unsigned long long mq[4] = {0ULL, 0ULL, 0ULL, 0ULL};
+          if (__any(hit[0] | hit[1] | hit[2] | hit[3])) {
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            unsigned long long carry = mq[j];
+            for (int j = 0; j < 4; j++) if (hit[j]) mq[j] = masks[slot[j]];
+          }
+          if (__any(slow[0] | slow[1] | slow[2] | slow[3])) {
 #pragma unroll
-            for (int k = 0; k < NPL; k++) {
-              if (!__any(carry != 0ULL)) break;  // wave-uniform
-              const unsigned long long t = planes[k] & carry;
-              planes[k] ^= carry;
-              carry = t;
+            for (int j = 0; j < 4; j++) if (slow[j]) mq[j] = table_lookup(keys, masks, sh, bq[j]);
+          }
+          if (__any((mq[0] | mq[1] | mq[2] | mq[3]) != 0ULL)) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              unsigned long long carry = mq[j];
+#pragma unroll
+              for (int k = 0; k < NPL; k++) {
+                if (!__any(carry != 0ULL)) break;  // wave-uniform
+                const unsigned long long t = planes[k] & carry;
+                planes[k] ^= carry;
+                carry = t;
+              }
             }
           }
         }
