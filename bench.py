@@ -53,16 +53,29 @@ def parse():
     ap.add_argument("-s", type=int, default=1000)
     ap.add_argument("--threshold", type=float, default=0.05)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-genomes", type=int, default=0, help="0 = max(16, host cores)")
-    ap.add_argument("--cpu-sample-sketches", type=int, default=4000)
+    ap.add_argument("--cpu-sample-genomes", type=int, default=0, help="0 = 16 per usable core (>= 64)")
+    ap.add_argument("--cpu-sample-sketches", type=int, default=8000)
     return ap.parse_args()
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask and cgroup-v2 CPU quota, not the
+    machine's core count (the GPU boxes expose 256 CPUs under a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        pass
+    return max(n, 1)
 
 
 def cpu_baseline(args, ctx, seq, off, sketches_host):
     """Oracle ("port") timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import pyoracle as O
-    cores = os.cpu_count() or 1
-    ns = min(args.cpu_sample_genomes or max(16, cores), len(off) - 1)
+    cores = usable_cores()
+    ns = min(args.cpu_sample_genomes or max(64, 16 * cores), len(off) - 1)
     L = int(off[1] - off[0])
     sub = seq[: ns * L].cpu().numpy()
     suboff = np.ascontiguousarray(off[: ns + 1])

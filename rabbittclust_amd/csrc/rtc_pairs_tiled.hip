@@ -414,8 +414,10 @@ int tiled_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
   const uint32_t lmax = hst.lmax;
   if (tot == 0 || lmax >= (1u << 20) || nsamp == 0) return RTC_OK;  // nothing to gain / counters too wide: merge path
   const double avg = (double)tot / n;
+  uint32_t ktarget = KTARGET;
+  if (const char* e = getenv("RTC_PAIR_KTARGET")) { const int v = atoi(e); if (v >= 256 && v <= (int)KCAP_HARD) ktarget = (uint32_t)v; }  // tuning experiments
   int P = 1;
-  while (P < MAXP && (double)ROWS * avg / P > KTARGET) P <<= 1;
+  while (P < MAXP && (double)ROWS * avg / P > ktarget) P <<= 1;
   std::vector<T> sample((const T*)((const char*)hpin + sizeof(PlanStats) + 8),
                         (const T*)((const char*)hpin + sizeof(PlanStats) + 8) + nsamp);
   std::sort(sample.begin(), sample.end());
