@@ -457,7 +457,11 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
             // four independent hash chains: their LDS table reads and multiplies overlap
             uint64_t h[4];
 #pragma unroll
+            #ifdef RTC_ABLATE_HASH  // timing experiment only: everything but MurmurHash3
+            for (int b = 0; b < 4; b++) h[b] = canon[b] * 0x9E3779B97F4A7C15ULL;
+#else
             for (int b = 0; b < 4; b++) h[b] = kmer_hash(canon[b], P);
+#endif
             // lanes that append, as wave masks (T is scalar: compares write the masks directly)
             uint64_t m[4];
             if (allok && T != SENT) {  // the steady state: one 64-bit compare per k-mer

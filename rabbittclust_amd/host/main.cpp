@@ -386,7 +386,7 @@ static Options parse(int argc, char** argv) {
   return o;
 }
 
-static void cluster_from_mst(const vector<rtc_edge>& mst, const vector<GenomeInfo>& genomes, bool sketchByFile,
+[[maybe_unused]] static void cluster_from_mst(const vector<rtc_edge>& mst, const vector<GenomeInfo>& genomes, bool sketchByFile,
                              const string& outputFile, double threshold) {
   vector<rtc_edge> forest = generate_forest(mst, threshold);
   vector<vector<int>> cl = generate_cluster_with_bfs(forest, (int)genomes.size());
@@ -395,7 +395,7 @@ static void cluster_from_mst(const vector<rtc_edge>& mst, const vector<GenomeInf
   cerr << "-----the cluster number of: " << outputFile << " is: " << cl.size() << endl;
 }
 
-static vector<vector<int>> clusters_from_rep_of(const vector<int32_t>& rep_of) {
+[[maybe_unused]] static vector<vector<int>> clusters_from_rep_of(const vector<int32_t>& rep_of) {
   // cluster list in representative-creation order: [rep, members...] (src/greedy.cpp:1355-1367)
   vector<vector<int>> cl; vector<int> cid(rep_of.size(), -1);
   for (size_t i = 0; i < rep_of.size(); i++) if (rep_of[i] == (int32_t)i) { cid[i] = (int)cl.size(); cl.push_back({(int)i}); }
