@@ -264,3 +264,41 @@ def test_clust_mst_batching_gzip_retry_and_min_length_filter(oracle, tmp_path):
     flat, start, lens = oracle.to_csr(want_sk)
     want_cl = oracle.forest_clusters(oracle.mst(flat, start, lens, 21, 0, 0.05), 0.05, 6)
     assert _partition(_parse_clusters(out)) == _partition(want_cl)
+
+
+def test_cli_edge_cases(oracle, tmp_path):
+    """Degenerate inputs the command lines must take without crashing: one genome, identical
+    genomes (distance 0), blank lines in the list, every genome under -m, a missing file."""
+    tmp = str(tmp_path)
+    L = 2_000_000
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 1, 2, L, seed=21)
+    exe = os.path.join(BIN, "clust-mst")
+    base = ["-k", "21", "-s", "1000", "-d", "0.05", "-t", "2", "-e"]
+
+    def run(list_lines, extra=(), expect_ok=True):
+        open(lst, "w").write("\n".join(list_lines) + "\n")
+        out = os.path.join(tmp, "o.cluster")
+        if os.path.exists(out):
+            os.remove(out)
+        r = subprocess.run([exe, "-l", "-i", lst, "-o", out] + base + list(extra), cwd=tmp, capture_output=True, text=True, timeout=600)
+        assert (r.returncode == 0) == expect_ok, r.stderr[-2000:]
+        return (_parse_clusters(out) if expect_ok else None), r.stderr
+
+    # one genome -> one singleton cluster
+    cl, _ = run([paths[0]])
+    assert cl == [[0]]
+    # the same file twice (+ blank lines): distance 0, one cluster of two
+    cl, _ = run([paths[0], "", paths[0], ""])
+    assert _partition(cl) == [(0, 1)]
+    # greedy on the same input
+    out = os.path.join(tmp, "g.cluster")
+    r = subprocess.run([os.path.join(BIN, "clust-greedy"), "-l", "-i", lst, "-o", out, "-k", "21", "-d", "0.05", "-t", "2", "-e"],
+                       cwd=tmp, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _partition(_parse_clusters(out)) == [(0, 1)]
+    # everything below the minimum length: a clean error, no crash
+    _, err = run([paths[0], paths[1]], extra=["-m", "3000000"], expect_ok=False)
+    assert "ERROR" in err or "no genome" in err
+    # a missing file: the reference's message and exit(1)
+    _, err = run([paths[0], os.path.join(tmp, "does_not_exist.fna")], expect_ok=False)
+    assert "cannot open the genome file" in err
