@@ -617,7 +617,7 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   // allows at the best occupancy that still leaves MIN_ROOM (3, 2 or 1 workgroups per CU; the sort
   // works on the live count, so the capacity need not be a power of two).  Partial-merge kernel:
   // two s-lists.
-  int cap = 0;
+  int cap = 0, wgs_per_cu = 1;
   int wgs_lo = 1, wgs_hi = 3;
   if (const char* e = getenv("RTC_SKETCH_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 3) wgs_lo = wgs_hi = v; }  // tuning experiments
   for (int wgs = wgs_hi; wgs >= wgs_lo && cap == 0; wgs--) {
@@ -626,7 +626,7 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     const size_t fixed = lut_bytes(k) + sizeof(Ctrl);
     // below ~3000 entries of room the merges (and safe-mode barriers) cost more than the lost occupancy
     const size_t want_room = wgs > wgs_lo ? 3072 : MIN_ROOM;
-    if (share > fixed && (share - fixed) / 8 >= (size_t)chunk_max + want_room) cap = (int)((share - fixed) / 8);
+    if (share > fixed && (share - fixed) / 8 >= (size_t)chunk_max + want_room) { cap = (int)((share - fixed) / 8); wgs_per_cu = wgs; }
   }
   if (cap == 0) return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "sketch chunk %u does not fit the LDS", chunk_max);
   if (const char* e = getenv("RTC_SKETCH_CAP")) { const int v = atoi(e); if (v >= (int)(chunk_max + MIN_ROOM) && v <= cap) cap = v; }  // tuning experiments
@@ -647,6 +647,36 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   const uint64_t min_seg = 4ull * TILE_BASES;
   if (seg_len < min_seg) seg_len = min_seg;
 
+  // segments per genome: ~equal-length pieces of seg_len; 1 = the whole genome in one workgroup
+  std::vector<uint32_t> nsv(n);
+  uint32_t n_single = 0;
+  for (uint32_t g = 0; g < n; g++) {
+    const uint64_t len = h_off[g + 1] - h_off[g];
+    uint64_t ns = (len + seg_len / 2) / seg_len;
+    if (ns < 1) ns = 1;
+    if (ns > 4096) ns = 4096;
+    nsv[g] = (uint32_t)ns;
+    if (ns == 1) n_single++;
+  }
+  // Whole-genome workgroups run in rounds of `slots` at a time; n mod slots leftover genomes would
+  // occupy a nearly empty final round for a full round's duration (10 000 genomes on 768 slots:
+  // 16 workgroups alone for 7 % of the kernel).  Cut the last leftover genomes into enough segments
+  // to fill that round instead; they go through the partial path, launched after the full rounds.
+  const uint32_t slots = (uint32_t)ctx->num_cu * (uint32_t)wgs_per_cu;
+  if (n_single > slots) {
+    uint32_t q = n_single % slots;
+    if (q > 0 && q <= slots * 3 / 5) {
+      const uint32_t want = slots / q;
+      for (uint32_t g = n; g-- > 0 && q > 0;) {
+        if (nsv[g] != 1) continue;
+        const uint64_t len = h_off[g + 1] - h_off[g];
+        const uint64_t ns2 = std::min<uint64_t>(std::min<uint64_t>(want, len / min_seg), 64);
+        if (ns2 >= 2) nsv[g] = (uint32_t)ns2;
+        q--;
+      }
+    }
+  }
+
   struct PassPlan { size_t direct0, ndirect, partial0, npartial, job0, njobs; };
   std::vector<PassPlan> plans(npass);
   std::vector<Segment> direct, partial;
@@ -666,9 +696,7 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
       const uint32_t expect = ps * CHUNK;
       const uint64_t out_off = (uint64_t)g * stride + expect;
       const uint64_t lo_off = ps ? out_off - 1 : 0;
-      uint64_t ns = (len + seg_len / 2) / seg_len;
-      if (ns < 1) ns = 1;
-      if (ns > 4096) ns = 4096;
+      const uint64_t ns = nsv[g];
       if (ns == 1) {
         direct.push_back(Segment{b, e, b, e, out_off, lo_off, g, s, g, expect});
       } else {
