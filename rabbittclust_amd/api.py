@@ -94,6 +94,11 @@ class Context:
         if st != _lib.RTC_OK:
             raise RtcError(st, self.lib.rtc_last_error(self.h).decode(errors="replace"))
 
+    def num_cu(self):
+        info = (C.c_int * 3)()
+        self.check(self.lib.rtc_device_info(self.h, info))
+        return int(info[0])
+
     def use_torch_stream(self):
         s = torch.cuda.current_stream(self.device).cuda_stream
         self.check(self.lib.rtc_ctx_set_stream(self.h, C.c_void_p(s)))
@@ -143,6 +148,19 @@ class Context:
             _np_ptr(sizes) if sizes is not None else None, int(size), _t_ptr(out), stride, _t_ptr(cnt)))
         start = torch.arange(n, dtype=torch.int64, device=self.device) * stride
         return SketchSet(out.view(-1), start, cnt[:n], 8, k, "minhash")
+
+    def sketch_minhash_into(self, seq, off, out, cnt, k=21, size=1000, sizes=None, seed=42):
+        """Same as sketch_minhash, into caller-provided rows: `out` (len(off)-1, stride) int64 and `cnt`
+        int32 views (used by the multi-GPU step, which sketches in two parts so that the all-gather
+        of the first overlaps the sketching of the second).  `off` may start at any base offset."""
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        assert out.is_contiguous() and cnt.is_contiguous() and out.shape[0] == n and cnt.shape[0] == n
+        if sizes is not None:
+            sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        self.check(self.lib.rtc_sketch_minhash_dev(
+            self.h, _t_ptr(seq), _np_ptr(off), n, k, seed,
+            _np_ptr(sizes) if sizes is not None else None, int(size), _t_ptr(out), int(out.shape[1]), _t_ptr(cnt)))
 
     def sketch_kssd(self, seq, off, shuffled_dim, kmer_size=21, drlevel=3, stride=None):
         """sketchFileWithKssd's per-file body.  shuffled_dim: int32[2^(4*half_subk)] from the host."""

@@ -120,6 +120,64 @@ class MstPipeline:
         start = torch.arange(n, dtype=torch.int64, device=sk.hashes.device) * stride
         return SketchSet(hashes, start, lens, sk.width, sk.k, sk.kind)
 
+    @staticmethod
+    def split_point(n_local, slots=0):
+        """Genomes sketched before the first all-gather is started: ~3/4 of them, so that the gather
+        of the first part hides behind the sketching of the rest and only a quarter's gather is
+        exposed.  With `slots` (workgroups the GPU runs at once, one genome each) the first part is a
+        whole number of full rounds, so the extra launch boundary costs no idle tail."""
+        if n_local < 8:
+            return n_local
+        if slots > 0 and n_local >= 2 * slots:
+            return max(slots, int(0.8 * n_local) // slots * slots)
+        return (3 * n_local) // 4
+
+    def _gather_part(self, g_hashes, g_len, base, out_part, cnt_part):
+        """Start the all-gathers of one locally sketched row range into rows [base, base + W*m) of the
+        global buffers (rank r's rows land at base + r*m).  Returns the async work handles."""
+        m = out_part.shape[0]
+        rows = slice(base, base + self.world * m)
+        return [self.dist.all_gather_into_tensor(g_hashes[rows].view(-1), out_part.reshape(-1), async_op=True),
+                self.dist.all_gather_into_tensor(g_len[rows], cnt_part.contiguous(), async_op=True)]
+
+    def gather_parts(self, out, cnt, parts, k, kind="minhash", before_part=None):
+        """All-gather the local row ranges `parts` = [(a, b), ...] one after the other into the global
+        layout [part 0 of rank 0..W-1 | part 1 of rank 0..W-1 | ...]; `before_part(a, b)` (if given)
+        is called right before a part's collectives are started -- the multi-GPU step sketches the
+        part there, so the previous part's all-gather runs beside it.  Every rank passes the same
+        parts.  Returns (SketchSet over the global buffers, work handles to wait on)."""
+        n_local, stride = out.shape
+        n = self.world * n_local
+        g_hashes = torch.empty((n, stride), dtype=out.dtype, device=out.device)
+        g_len = torch.empty(n, dtype=cnt.dtype, device=cnt.device)
+        works, base = [], 0
+        for a, b in parts:
+            if b <= a:
+                continue
+            if before_part is not None:
+                before_part(a, b)
+            works += self._gather_part(g_hashes, g_len, base, out[a:b], cnt[a:b])
+            base += self.world * (b - a)
+        start = torch.arange(n, dtype=torch.int64, device=out.device) * stride
+        return SketchSet(g_hashes.view(-1), start, g_len, 8, k, kind), works
+
+    def sketch_and_gather(self, seq, off, sizes=None):
+        """Multi-GPU sketch phase: sketch part A, start its all-gather, sketch part B, start its
+        all-gather.  The collective of part A runs on RCCL's stream beside the sketch kernel of B."""
+        ctx = self.ctx
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n_local = len(off) - 1
+        stride = int(np.max(sizes)) if sizes is not None else int(self.s)
+        out = torch.empty((n_local, max(stride, 1)), dtype=torch.int64, device=ctx.device)
+        cnt = torch.zeros(n_local, dtype=torch.int32, device=ctx.device)
+        split = self.split_point(n_local, slots=3 * ctx.num_cu())
+
+        def sketch_part(a, b):
+            ctx.sketch_minhash_into(seq, off[a:b + 1], out[a:b], cnt[a:b], k=self.k, size=self.s,
+                                    sizes=None if sizes is None else sizes[a:b])
+
+        return self.gather_parts(out, cnt, [(0, split), (split, n_local)], self.k, before_part=sketch_part)
+
     def candidate_edges(self, sk, row0, row1):
         """Dense common counts for rows [row0,row1) x cols [0,row) in chunks, filtered into a
         compact (i, j, common) list on the device."""
@@ -178,9 +236,14 @@ class MstPipeline:
         ctx = self.ctx
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
-        sk_local = ctx.sketch_minhash(seq, off, k=self.k, size=self.s, sizes=sizes)
-        ev[1].record()
-        sk = self.gather_sketches(sk_local)
+        if self.dist is None:
+            sk = ctx.sketch_minhash(seq, off, k=self.k, size=self.s, sizes=sizes)
+            ev[1].record()
+        else:
+            sk, works = self.sketch_and_gather(seq, off, sizes)
+            ev[1].record()  # local sketching done; what follows is the exposed rest of the all-gathers
+            for w in works:
+                w.wait()
         ev[2].record()
         b = triangle_row_ranges(sk.n, self.world, fixed_cols=8.8 * self.s if self.world > 1 else 0.0)
         row0, row1 = b[self.rank], b[self.rank + 1]

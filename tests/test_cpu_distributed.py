@@ -86,6 +86,20 @@ def _worker(rank, world, port, n, containment, q):
     sk = pipe.gather_sketches(local)
     got = sk.to_host()
     assert all(np.array_equal(a, b) for a, b in zip(got, sk_all))
+    # two-part all-gather used by the overlapped multi-GPU sketch phase: global order is
+    # [part A of rank 0..W-1 | part B of rank 0..W-1]
+    split = pipeline.MstPipeline.split_point(n_local)
+    assert 0 < split < n_local
+    called = []
+    skp, works = pipe.gather_parts(torch.from_numpy(h.view(np.int64)), torch.from_numpy(ln), [(0, split), (split, n_local)], 21,
+                                   before_part=lambda a, b: called.append((a, b)))
+    for w in works:
+        w.wait()
+    assert called == [(0, split), (split, n_local)]
+    want_order = [r * n_local + i for r in range(world) for i in range(split)] + \
+                 [r * n_local + i for r in range(world) for i in range(split, n_local)]
+    gotp = skp.to_host()
+    assert len(gotp) == n and all(np.array_equal(gotp[q], sk_all[g]) for q, g in enumerate(want_order))
     # this rank's rows of the strict lower triangle
     b = pipeline.triangle_row_ranges(n, world)
     radio = api.mst_radio(0.05, 21)

@@ -170,6 +170,52 @@ def test_row_sharded_boruvka_equals_single_rank(ctx, oracle, world):
     assert _partition(oracle.forest_clusters(got, 0.05, n)) == _partition(oracle.forest_clusters(want, 0.05, n))
 
 
+class _LoopbackDist:
+    """world = 1 stand-in for torch.distributed: the collectives of the multi-GPU step degenerate to
+    copies, so pipeline.step runs its N>1 code path (two-part sketch + all-gathers) on one GPU."""
+
+    class _Done:
+        def wait(self):
+            return True
+
+    class ReduceOp:
+        MIN, MAX = "min", "max"
+
+    def all_gather_into_tensor(self, out, inp, async_op=False):
+        out.copy_(inp.reshape(-1))
+        return self._Done()
+
+    def all_reduce(self, t, op=None):
+        return None
+
+
+def test_pipeline_multi_gpu_code_path_on_one_gpu(ctx, oracle):
+    """The distributed branch of MstPipeline.step (sketch in two parts into caller-provided rows, an
+    all-gather per part, cost-aware row split) must give the same sketches and forest as the
+    single-GPU branch and the oracle."""
+    from rabbittclust_amd import api, pipeline
+    desc = api.synth_family_descs(12, 5, global_seed=31)
+    L = 120_000
+    off = np.arange(len(desc) + 1, dtype=np.uint64) * L
+    seq = ctx.synth_genomes(desc, off)
+    ref = pipeline.MstPipeline(ctx, k=21, sketch_size=600, threshold=0.05)
+    ref.step(seq, off)
+    want_sk = ref.last_sketches.to_host()
+    pipe = pipeline.MstPipeline(ctx, k=21, sketch_size=600, threshold=0.05, dist=_LoopbackDist(), rank=0, world=1)
+    stats = pipe.step(seq, off)
+    got_sk = pipe.last_sketches.to_host()
+    assert len(got_sk) == len(want_sk) and all(np.array_equal(a, b) for a, b in zip(got_sk, want_sk))
+    flat, start, lens = oracle.to_csr(got_sk)
+    want = oracle.mst(flat, start, lens, 21, 0, 0.05)
+    assert stats["mst_edges"] == len(want)
+    assert np.array_equal(np.sort(pipe.last_mst["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
+    # variable sketch sizes through the same path
+    sizes = np.array([300 + 10 * (g % 7) for g in range(len(desc))], dtype=np.uint32)
+    pipe.step(seq, off, sizes=sizes)
+    ref.step(seq, off, sizes=sizes)
+    assert all(np.array_equal(a, b) for a, b in zip(pipe.last_sketches.to_host(), ref.last_sketches.to_host()))
+
+
 def test_bench_rccl_path_single_rank(tmp_path):
     """bench.py under torch.distributed.run with one rank and RTC_FORCE_DIST=1: the all-gather and
     the per-round all-reduces go through RCCL (backend "nccl") exactly as in the multi-GPU run."""
