@@ -126,8 +126,8 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
         const bool fast = fastroll && __all(allvalid);  // wave-uniform
         clean = clean && fast;
         if (fast) {
-          const uint32_t pack = (codes4 * 0x40100401u) >> 24;
-          const uint32_t rp = ((codes4 * 0x01041040u) >> 24) ^ 0xffu;
+          const uint32_t pack = __builtin_amdgcn_udot4(codes4, 0x01041040u, 0u, false);  // c0<<6|c1<<4|c2<<2|c3
+          const uint32_t rp = __builtin_amdgcn_udot4(codes4, 0x40100401u, 0u, false) ^ 0xffu;
           const uint64_t F = (tuple << 8) | pack;
           const uint64_t R = rvs | ((uint64_t)rp << (2 * P.K));
           if (emitting) {
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
               }
             }
           }
-          tuple = F & P.tupmask;
-          rvs = (R >> 8) & P.tupmask;
+          tuple = F;      // bits above the window are masked where windows are cut / by the per-base path
+          rvs = R >> 8;   // R < 2^(2K+8) by construction
           run += 4;
         } else {
 #pragma unroll

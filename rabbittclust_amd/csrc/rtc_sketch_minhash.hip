@@ -416,9 +416,11 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
           clean = clean && fast;
           const int run_in = run;
           if (fast) {
-            // pack = c0<<6|c1<<4|c2<<2|c3 ; rp = complement codes in reverse significance
-            const uint32_t pack = (codes4 * 0x40100401u) >> 24;
-            const uint32_t rp = ((codes4 * 0x01041040u) >> 24) ^ 0xffu;
+            // pack = c0<<6|c1<<4|c2<<2|c3 ; rp = complement codes in reverse significance; both are
+            // byte dot products of the four codes (v_dot4_u32_u8)
+            const uint32_t pack = __builtin_amdgcn_udot4(codes4, 0x01041040u, 0u, false);
+            const uint32_t rp = __builtin_amdgcn_udot4(codes4, 0x40100401u, 0u, false) ^ 0xffu;
+            // bits of fwd above the window shift out when the windows are cut, so it carries unmasked
             const uint64_t F = (fwd << 8) | pack;
             const uint64_t R = rc | ((uint64_t)rp << (2 * P.k));
             if (hashing) {
@@ -436,8 +438,8 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
                 canon[b] = f < r ? f : r;
               }
             }
-            fwd = F & P.kmask;
-            rc = (R >> 8) & P.kmask;
+            fwd = F;        // masked by whoever needs exactly 2k bits (the per-base path below)
+            rc = R >> 8;    // R < 2^(2k+8) by construction, so this is already < 2^(2k)
             run += 4;
           } else {
 #pragma unroll
