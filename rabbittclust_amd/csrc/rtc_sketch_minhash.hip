@@ -136,8 +136,11 @@ __device__ __forceinline__ uint64_t rotl64c(uint64_t x) {
     nh = __builtin_amdgcn_alignbit(lo, hi, 64 - R);
     nl = __builtin_amdgcn_alignbit(hi, lo, 64 - R);
   }
-  // assembled as a register pair (a shift-or would be re-associated into the additions that follow)
-  return __builtin_bit_cast(uint64_t, make_uint2(nl, nh));
+  // assembled as a register pair and made opaque: otherwise the two halves are re-associated into
+  // the 64-bit additions that follow ((lo, 0) + x + (0, hi): one more add and a move)
+  uint64_t r = __builtin_bit_cast(uint64_t, make_uint2(nl, nh));
+  asm("" : "+v"(r));
+  return r;
 }
 
 // x*5 as one v_lshl_add_u64 ((x << 2) + x); the compiler's choice is two v_mad_u64_u32 plus moves
@@ -198,8 +201,16 @@ __device__ __forceinline__ uint64_t kmer_hash(uint64_t x, const KParams& P) {
   }
   const int tail = k & 15;
   if (tail > 8) { h2 ^= rotl64c<33>(t1) * MM_C1; }
-  if (tail > 0) { h1 ^= rotl64c<31>(t0) * MM_C2; }
-  h1 ^= (uint64_t)k; h2 ^= (uint64_t)k;
+  if (tail > 0) {
+    // h1 ^= k1; h1 ^= len: the low word as one three-input xor (v_bitop3_b32)
+    const uint64_t kt = rotl64c<31>(t0) * MM_C2;
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)h1, (uint32_t)kt, (uint32_t)k, 0x96);
+    const uint32_t hi = (uint32_t)(h1 >> 32) ^ (uint32_t)(kt >> 32);
+    h1 = __builtin_bit_cast(uint64_t, make_uint2(lo, hi));
+  } else {
+    h1 ^= (uint64_t)k;
+  }
+  h2 ^= (uint64_t)k;
   h1 += h2; h2 += h1;
   h1 = fmix64(h1); h2 = fmix64(h2);
   h1 += h2;
