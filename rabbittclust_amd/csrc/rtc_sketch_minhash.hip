@@ -416,7 +416,7 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
             if ((uint32_t)cap - cn < (uint32_t)STEP_APPENDS) T = uniform64(merge_block(buf, ctrl, cap, s).T);
             __syncthreads();
           }
-          uint64_t canon[4] = {0, 0, 0, 0};  // top-aligned (first base in bit 63); hashing dwords only
+          uint64_t canon[4];  // top-aligned (first base in bit 63); set and read in hashing dwords only
           bool ok[4] = {false, false, false, false};  // slow path only; the fast path derives it on demand
           bool allok = false;  // wave-uniform: all four k-mers of every lane are valid and owned
           // ---- decode four bases at once ----
