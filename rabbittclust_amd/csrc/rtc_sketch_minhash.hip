@@ -48,6 +48,8 @@ struct Segment {
   uint32_t sketch_size;     // hashes to select in this pass
   uint32_t final_slot;      // genome index in the final count buffer
   uint32_t expect;          // pass > 0: run only if the genome already holds exactly this many hashes
+  uint32_t partial;         // 1: one of several segments of a genome, writes a partial sketch for the merge kernel
+  uint32_t pad;
 };
 
 struct Ctrl {
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
                                                             int k_arg, uint32_t seed, int cap,
                                                             uint64_t* out,
                                                             uint32_t* cnt, int pass_no,
-                                                            const uint64_t* fin_out, const uint32_t* fin_cnt) {
+                                                            uint64_t* parts, uint32_t* pcnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int k = KT > 0 ? KT : k_arg;
   const lds_byte_ptr lds0 = (lds_byte_ptr)smem;
@@ -361,10 +363,10 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
   // admits hashes above the largest one kept so far (lo1 = that hash + 1; 0 in the first pass).
   uint64_t lo1 = 0;
   if (pass_no > 0) {  // workgroup-uniform
-    const bool live = fin_cnt[sg.final_slot] == sg.expect;  // genome not exhausted by earlier passes
-    const uint64_t lo = live ? fin_out[sg.lo_off] : SENT;
+    const bool live = cnt[sg.final_slot] == sg.expect;  // genome not exhausted by earlier passes
+    const uint64_t lo = live ? out[sg.lo_off] : SENT;
     if (!live || lo == SENT) {
-      if (t == 0 && cnt != fin_cnt) cnt[sg.cnt_slot] = 0;  // partial slot: nothing from this segment
+      if (t == 0 && sg.partial) pcnt[sg.cnt_slot] = 0;  // nothing from this segment
       return;
     }
     lo1 = lo + 1;
@@ -540,12 +542,13 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
 
   // ---- final fold and write-out ----
   uint32_t n = merge_block(buf, ctrl, cap, s).count;
-  uint64_t* o = out + sg.out_off;
+  uint64_t* o = (sg.partial ? parts : out) + sg.out_off;
   for (uint32_t i = t; i < n; i += WG) o[i] = buf[i];
   if (t == 0) {
     if (ctrl->saw_max && n < s) { o[n] = SENT; n++; }
     // direct segments accumulate over passes; partial slots hold this pass's count only
-    cnt[sg.cnt_slot] = (pass_no > 0 && cnt == fin_cnt) ? sg.expect + n : n;
+    if (sg.partial) pcnt[sg.cnt_slot] = n;
+    else cnt[sg.cnt_slot] = pass_no > 0 ? sg.expect + n : n;
   }
 }
 
@@ -711,12 +714,12 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
       const uint64_t lo_off = ps ? out_off - 1 : 0;
       const uint64_t ns = nsv[g];
       if (ns == 1) {
-        direct.push_back(Segment{b, e, b, e, out_off, lo_off, g, s, g, expect});
+        direct.push_back(Segment{b, e, b, e, out_off, lo_off, g, s, g, expect, 0, 0});
       } else {
         jobs.push_back(MergeJob{part_elems, part_slots, (uint32_t)ns, out_off, g, s, chunk_max, expect, ps, 0});
         for (uint64_t i = 0; i < ns; i++) {
           const uint64_t sb = b + len * i / ns, se = b + len * (i + 1) / ns;
-          partial.push_back(Segment{b, e, sb, se, part_elems, lo_off, part_slots, s, g, expect});
+          partial.push_back(Segment{b, e, sb, se, part_elems, lo_off, part_slots, s, g, expect, 1, 0});
           part_elems += chunk_max;
           part_slots++;
         }
@@ -726,20 +729,30 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     part_elems_max = std::max(part_elems_max, part_elems);
     part_slots_max = std::max(part_slots_max, part_slots);
   }
-  const size_t bdir = direct.size() * sizeof(Segment), bpar = partial.size() * sizeof(Segment);
+  // one segment table, pass by pass: [whole-genome segments | partial segments] -- a single launch per
+  // pass walks both (workgroups are dispatched in index order, so the partial segments fill the
+  // tail of the last whole-genome round)
+  std::vector<Segment> segs;
+  segs.reserve(direct.size() + partial.size());
+  std::vector<size_t> seg0(npass);
+  for (uint32_t ps = 0; ps < npass; ps++) {
+    const PassPlan& pl = plans[ps];
+    seg0[ps] = segs.size();
+    segs.insert(segs.end(), direct.begin() + pl.direct0, direct.begin() + pl.direct0 + pl.ndirect);
+    segs.insert(segs.end(), partial.begin() + pl.partial0, partial.begin() + pl.partial0 + pl.npartial);
+  }
+  const size_t bseg = segs.size() * sizeof(Segment);
   const size_t bjobs = jobs.size() * sizeof(MergeJob);
   void* ws0 = nullptr;
-  RTC_TRY(rtc_ws(ctx, 0, bdir + bpar + bjobs + 64, &ws0));
-  Segment* d_direct = (Segment*)ws0;
-  Segment* d_partial = (Segment*)((char*)ws0 + bdir);
-  MergeJob* d_jobs = (MergeJob*)((char*)ws0 + bdir + bpar);
+  RTC_TRY(rtc_ws(ctx, 0, bseg + bjobs + 64, &ws0));
+  Segment* d_segs = (Segment*)ws0;
+  MergeJob* d_jobs = (MergeJob*)((char*)ws0 + bseg);
   void* hp = nullptr;
-  RTC_TRY(rtc_pinned(ctx, bdir + bpar + bjobs + 64, &hp));
+  RTC_TRY(rtc_pinned(ctx, bseg + bjobs + 64, &hp));
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pinned staging may still be in flight
-  memcpy(hp, direct.data(), bdir);
-  memcpy((char*)hp + bdir, partial.data(), bpar);
-  memcpy((char*)hp + bdir + bpar, jobs.data(), bjobs);
-  RTC_HIP(ctx, hipMemcpyAsync(ws0, hp, bdir + bpar + bjobs, hipMemcpyHostToDevice, ctx->stream));
+  memcpy(hp, segs.data(), bseg);
+  memcpy((char*)hp + bseg, jobs.data(), bjobs);
+  RTC_HIP(ctx, hipMemcpyAsync(ws0, hp, bseg + bjobs, hipMemcpyHostToDevice, ctx->stream));
 
   uint64_t* d_parts = nullptr;
   uint32_t* d_pcnt = nullptr;
@@ -770,15 +783,12 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
   for (uint32_t ps = 0; ps < npass; ps++) {
     const PassPlan& pl = plans[ps];
-    if (pl.ndirect) {
-      hipLaunchKernelGGL(kern, dim3((uint32_t)pl.ndirect), dim3(WG), lds, ctx->stream, d_seq, d_direct + pl.direct0, k,
-                         seed, cap, d_out, d_cnt, (int)ps, (const uint64_t*)d_out, (const uint32_t*)d_cnt);
+    if (pl.ndirect + pl.npartial) {
+      hipLaunchKernelGGL(kern, dim3((uint32_t)(pl.ndirect + pl.npartial)), dim3(WG), lds, ctx->stream, d_seq,
+                         d_segs + seg0[ps], k, seed, cap, d_out, d_cnt, (int)ps, d_parts, d_pcnt);
       RTC_CHECK_LAUNCH(ctx);
     }
     if (pl.npartial) {
-      hipLaunchKernelGGL(kern, dim3((uint32_t)pl.npartial), dim3(WG), lds, ctx->stream, d_seq, d_partial + pl.partial0, k,
-                         seed, cap, d_parts, d_pcnt, (int)ps, (const uint64_t*)d_out, (const uint32_t*)d_cnt);
-      RTC_CHECK_LAUNCH(ctx);
       hipLaunchKernelGGL(merge_partials_kernel, dim3((uint32_t)pl.njobs), dim3(WG), lds_m, ctx->stream,
                          d_jobs + pl.job0, d_parts, d_pcnt, cap_merge, d_out, d_cnt);
       RTC_CHECK_LAUNCH(ctx);
