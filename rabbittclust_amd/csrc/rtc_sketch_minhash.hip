@@ -418,7 +418,9 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
             if ((uint32_t)cap - cn < (uint32_t)STEP_APPENDS) T = uniform64(merge_block(buf, ctrl, cap, s).T);
             __syncthreads();
           }
-          uint64_t canon[4];  // top-aligned (first base in bit 63); set and read in hashing dwords only
+          // (zero-initialised on purpose: left uninitialised, the generated code issues the tile loads in an
+          // order that re-reads 40 % more of the input from the fabric -- measured, tools/pmc_runlen.sh)
+          uint64_t canon[4] = {0, 0, 0, 0};  // top-aligned (first base in bit 63); hashing dwords only
           bool ok[4] = {false, false, false, false};  // slow path only; the fast path derives it on demand
           bool allok = false;  // wave-uniform: all four k-mers of every lane are valid and owned
           // ---- decode four bases at once ----
