@@ -175,7 +175,7 @@ def main():
                          "traffic": measured_traffic("sketch_minhash_kernel", args),
                          "note": "algorithmic bytes = 1 B/base + 8 B/hash out per launch; traffic = rocprofv3 PMC "
                                  "bytes per launch (profiles/r01_pmc_traffic.json); the kernel is integer-VALU-issue "
-                                 "bound (~98 VALU instructions per k-mer at 4.2 cycles each), see DESIGN.md 3.1"},
+                                 "bound (~95 VALU instructions per k-mer at ~4.1 cycles each), see DESIGN.md 3.1"},
             "roofline_dist": {"bound": "hbm", "kernel": "pair kernel", "achieved": dist_ach, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": dist_ach / HBM_PEAK_GBS,
                               "traffic": measured_traffic("pair_tiled_kernel", args),
