@@ -7,11 +7,11 @@
 //     bases at once and rolling the 2-bit forward / reverse-complement words;
 //   * MurmurHash3_x64_128 of the canonical k-mer's ASCII bytes is evaluated from the 2-bit word:
 //     the first multiplication of every input word comes out of LDS product tables (linearity of
-//     multiplication mod 2^64), leaving seven 64x64 multiplies per k-mer; four k-mers per lane
-//     are hashed back to back so their table reads and multiply chains overlap;
-//   * hashes below the running threshold T are appended to an LDS candidate buffer with a
-//     wave ballot + one LDS atomic per wave; when the buffer fills, an in-LDS bitonic sort +
-//     dedup keeps the s smallest distinct values and lowers T.
+//     multiplication mod 2^64), leaving seven 64x64 multiplies per k-mer (72 VALU instructions
+//     for k = 21, with hand-picked forms for rotates, x5 and the table offsets);
+//   * hashes below the running threshold T (kept in SGPRs) are appended to an LDS candidate buffer
+//     with one LDS atomic per wave; when the buffer fills, an in-LDS bitonic sort over the live
+//     count + dedup keeps the s smallest distinct values and lowers T.
 // Large genomes / small batches are split into several segments whose partial sketches are
 // merged by merge_partials_kernel (bottom-s is a mergeable summary).
 #include <algorithm>
@@ -25,13 +25,13 @@ constexpr int NWAVE = WG / 64;
 #ifndef RTC_RUN_DW
 // 19 dwords = 76 owned positions per lane and tile: lane runs 76 B apart keep the set of live 128-B
 // lines (one or two lanes per line, ~1500 lanes per CU) inside the 4 MiB L2 of an XCD.  31 dwords is
-// 1 % faster but re-reads 80 % of the input from the fabric (measured: TCC_EA0_RDREQ_128B).
+// 1 % faster but re-reads 56 % of the input from the fabric (measured: TCC_EA0_RDREQ_128B, 19 dwords: 11 %).
 #define RTC_RUN_DW 19
 #endif
 constexpr int RUN_DW = RTC_RUN_DW;                    // dwords of owned bases per lane per tile
 constexpr int OWN = RUN_DW * 4;                       // k-mer end positions a lane owns per tile
 static_assert((RUN_DW + 9) % 4 == 0, "a lane's window must be whole 16-byte loads");
-constexpr int WARM_DW = 9;                            // 36 warm-up bases (k-1 <= 31); 9+15 dwords = six 16-byte loads
+constexpr int WARM_DW = 9;                            // 36 warm-up bases (k-1 <= 31); 9+19 dwords = seven 16-byte loads
 constexpr int TILE_BASES = WG * RUN_DW * 4;           // bases per tile
 constexpr int STEP_APPENDS = WG * 4;                  // worst-case appends per dword iteration
 constexpr int MIN_ROOM = STEP_APPENDS;                // candidate room the buffer always offers
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
             // four independent hash chains: their LDS table reads and multiplies overlap
             uint64_t h[4];
 #pragma unroll
-            #ifdef RTC_ABLATE_HASH  // timing experiment only: everything but MurmurHash3
+#ifdef RTC_ABLATE_HASH  // timing experiment only: everything but MurmurHash3
             for (int b = 0; b < 4; b++) h[b] = canon[b] * 0x9E3779B97F4A7C15ULL;
 #else
             for (int b = 0; b < 4; b++) h[b] = kmer_hash(canon[b], P);
