@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <limits>
+#include <unordered_map>
 #include <vector>
 
 #include "rtc_internal.h"
@@ -72,18 +73,31 @@ extern "C" int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const u
   RTC_HIP(ctx, hipMemcpyAsync(h_start.data(), d_start, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
   RTC_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  uint64_t span = 0;
-  for (uint32_t g = 0; g < n; g++) span = std::max<uint64_t>(span, h_start[g] + h_len[g]);
-  std::vector<unsigned char> h_hashes((size_t)span * width);
-  if (span) {
-    RTC_HIP(ctx, hipMemcpyAsync(h_hashes.data(), d_hashes, (size_t)span * width, hipMemcpyDeviceToHost, ctx->stream));
-    RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
+  // Sketches are fetched on demand (two small copies per tie) and kept while they fit 256 MiB:
+  // ties are rare, and a host copy of every sketch would cost more than the clustering itself
+  // (2 GB for 50 000 containment sketches).
+  std::unordered_map<uint32_t, std::vector<unsigned char>> sketch_cache;
+  size_t cache_bytes = 0;
+  int fetch_status = RTC_OK;
+  auto fetch = [&](uint32_t g) -> const unsigned char* {
+    auto it = sketch_cache.find(g);
+    if (it != sketch_cache.end()) return it->second.data();
+    std::vector<unsigned char> v((size_t)h_len[g] * width + 8);
+    if (h_len[g]) {
+      hipError_t e = hipMemcpyAsync(v.data(), (const unsigned char*)d_hashes + h_start[g] * width, (size_t)h_len[g] * width,
+                                    hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) fetch_status = rtc_fail(ctx, RTC_ERR_HIP, "sketch fetch for the tie rule -> %s", hipGetErrorString(e));
+    }
+    cache_bytes += v.size();
+    return sketch_cache.emplace(g, std::move(v)).first->second.data();
+  };
   auto first_pos = [&](uint32_t q, uint32_t r) -> uint32_t {
-    if (width == 8) return first_shared_pos((const uint64_t*)h_hashes.data() + h_start[q], h_len[q],
-                                            (const uint64_t*)h_hashes.data() + h_start[r], h_len[r]);
-    return first_shared_pos((const uint32_t*)h_hashes.data() + h_start[q], h_len[q],
-                            (const uint32_t*)h_hashes.data() + h_start[r], h_len[r]);
+    if (cache_bytes > ((size_t)256 << 20)) { sketch_cache.clear(); cache_bytes = 0; }  // only between lookups
+    const unsigned char* pq = fetch(q);
+    const unsigned char* pr = fetch(r);  // pq stays valid: unordered_map does not move mapped values on insert
+    if (width == 8) return first_shared_pos((const uint64_t*)pq, h_len[q], (const uint64_t*)pr, h_len[r]);
+    return first_shared_pos((const uint32_t*)pq, h_len[q], (const uint32_t*)pr, h_len[r]);
   };
 
   // ---- reference constants ----
@@ -228,6 +242,7 @@ extern "C" int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const u
         reps.push_back(q);
       }
     }
+    if (fetch_status != RTC_OK) { cleanup(); return fetch_status; }
   }
   cleanup();
 #undef G_TRY
