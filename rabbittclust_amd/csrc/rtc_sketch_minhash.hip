@@ -765,9 +765,9 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     d_pcnt = (uint32_t*)((char*)ws1 + part_elems_max * 8);
   }
 
-  // compile-time k for the values the reference's tune_parameters lands on for Mbp..Gbp genomes
-  // (recommended k = ceil(log4(maxSize * 9999)): 17..23) and its default 21; anything else takes
-  // the runtime-k kernel
+  // compile-time k for 16..28: the values the reference's tune_parameters lands on for Mbp..Gbp
+  // genomes (recommended k = ceil(log4(maxSize * 9999)) = 17..23, accepted up to +3) and its
+  // default 21; anything else takes the runtime-k kernel (k >= 29 also leaves the 64-bit window path)
   auto kern = sketch_minhash_kernel<0>;
   switch (k) {
     case 16: kern = sketch_minhash_kernel<16>; break;
@@ -778,6 +778,11 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     case 21: kern = sketch_minhash_kernel<21>; break;
     case 22: kern = sketch_minhash_kernel<22>; break;
     case 23: kern = sketch_minhash_kernel<23>; break;
+    case 24: kern = sketch_minhash_kernel<24>; break;
+    case 25: kern = sketch_minhash_kernel<25>; break;
+    case 26: kern = sketch_minhash_kernel<26>; break;
+    case 27: kern = sketch_minhash_kernel<27>; break;
+    case 28: kern = sketch_minhash_kernel<28>; break;
     default: break;
   }
   RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
