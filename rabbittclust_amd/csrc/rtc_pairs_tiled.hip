@@ -173,9 +173,12 @@ __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ ha
   TileShared* sh = reinterpret_cast<TileShared*>(smem + (size_t)SLOTS * (sizeof(T) + 8));
 
   const int tid = threadIdx.x;
-  const uint32_t rb0 = row0 + blockIdx.y * ROWS;
+  // Row blocks vary fastest in the grid: the workgroups running at the same time (round-robin over
+  // the XCDs) then probe the same 1024-column slab, which each XCD's L2 fetches once instead of
+  // once per row block.
+  const uint32_t rb0 = row0 + blockIdx.x * ROWS;
   const uint32_t nrows = min((uint32_t)ROWS, row1 - rb0);
-  const uint32_t cb0 = col0 + blockIdx.x * TW;
+  const uint32_t cb0 = col0 + blockIdx.y * TW;
   if (lower_only && cb0 + 1 > rb0 + nrows - 1) return;  // no (row, col) with col < row in this block
   const uint32_t c = cb0 + tid;
   const bool col_active = c < col1;
@@ -381,7 +384,7 @@ int launch_tiled(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const
   const size_t lds = (size_t)SLOTS * (sizeof(T) + 8) + sizeof(TileShared);
   auto kern = pair_tiled_kernel<T, NPL>;
   RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  dim3 grid((col1 - col0 + TW - 1) / TW, (row1 - row0 + ROWS - 1) / ROWS);
+  dim3 grid((row1 - row0 + ROWS - 1) / ROWS, (col1 - col0 + TW - 1) / TW);
   hipLaunchKernelGGL(kern, grid, dim3(TW), lds, ctx->stream, d_hashes, d_start, d_tcols, d_tbase, d_so, P, n, row0, row1,
                      col0, col1, d_common, ld, lower_only);
   RTC_CHECK_LAUNCH(ctx);
