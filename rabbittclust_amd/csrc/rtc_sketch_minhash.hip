@@ -685,10 +685,12 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     uint32_t q = n_single % slots;
     if (q > 0 && q <= slots * 3 / 5) {
       const uint32_t want = slots / q;
+      uint64_t tail_max = 8;  // more pieces fill the round better but serialise in the per-genome merge (measured: 4-8 best)
+      if (const char* e = getenv("RTC_SKETCH_TAILMAX")) tail_max = (uint64_t)std::max(1, atoi(e));  // tuning experiments
       for (uint32_t g = n; g-- > 0 && q > 0;) {
         if (nsv[g] != 1) continue;
         const uint64_t len = h_off[g + 1] - h_off[g];
-        const uint64_t ns2 = std::min<uint64_t>(std::min<uint64_t>(want, len / min_seg), 64);
+        const uint64_t ns2 = std::min<uint64_t>(std::min<uint64_t>(want, len / min_seg), tail_max);
         if (ns2 >= 2) nsv[g] = (uint32_t)ns2;
         q--;
       }
