@@ -1,3 +1,4 @@
+"""Times rtc_extract_edges_dev alone on a 10 000 x 10 000 count matrix with ~150 000 survivors."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
