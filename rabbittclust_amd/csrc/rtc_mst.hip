@@ -28,38 +28,16 @@ __device__ __forceinline__ uint64_t weight_key(uint32_t common, uint32_t sa, uin
   return 0x4000000000000000ULL - (uint64_t)__double_as_longlong(J);
 }
 
-// Survivors are staged in LDS and flushed with ONE global atomic per flush: a single counter hit by
-// one atomic per wave and column (150 000 of them on the bench shape) serialises in L2 and took 1.4 ms.
-constexpr int EX_STAGE = 3072;  // staged edges per block (36 KiB); an iteration adds at most 1024
-
 __global__ __launch_bounds__(256) void extract_edges_kernel(const uint32_t* __restrict__ common, uint64_t ld,
                                                             uint32_t row0, uint32_t row1, uint32_t col0,
                                                             uint32_t col1, const uint32_t* __restrict__ len,
                                                             int radio, rtc_cedge* __restrict__ edges,
                                                             uint64_t cap, unsigned long long* __restrict__ count) {
-  __shared__ rtc_cedge stage[EX_STAGE];
-  __shared__ uint32_t staged;
-  __shared__ unsigned long long flush_base;
   // each lane covers 4 consecutive columns (one 16-byte load when aligned); a block covers 1024
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t cbase = col0 + blockIdx.x * 1024;
   const uint32_t c4 = cbase + threadIdx.x * 4;
   const bool vec_ok = (ld & 3) == 0 && (((uintptr_t)common) & 15) == 0;
-  if (threadIdx.x == 0) staged = 0;
-  __syncthreads();
-  auto flush = [&]() {  // called by all threads of the block
-    __syncthreads();
-    const uint32_t m = staged;
-    if (m == 0) return;  // uniform
-    if (threadIdx.x == 0) flush_base = atomicAdd(count, (unsigned long long)m);
-    __syncthreads();
-    const unsigned long long base = flush_base;
-    for (uint32_t i = threadIdx.x; i < m; i += 256)
-      if (base + i < cap) edges[base + i] = stage[i];
-    __syncthreads();
-    if (threadIdx.x == 0) staged = 0;
-    __syncthreads();
-  };
   for (uint32_t row = row0 + blockIdx.y; row < row1; row += gridDim.y) {
     if (cbase >= row) continue;  // whole block on/above the diagonal (uniform)
     const uint32_t* rp = common + (uint64_t)(row - row0) * ld;
@@ -73,37 +51,27 @@ __global__ __launch_bounds__(256) void extract_edges_kernel(const uint32_t* __re
       for (int j = 0; j < 4; j++) if (c4 + j < col1) v[j] = rp[off + j];
     }
     const uint32_t s0 = len[row];
-    bool keep[4];
-    uint32_t mine = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const uint32_t col = c4 + j;
-      keep[j] = false;
+      bool keep = false;
       if (col < col1 && col < row && v[j] > 0 && s0 > 0) {
         const uint32_t s1 = len[col];
         if (s1 > 0) {
           const uint32_t mn = s0 < s1 ? s0 : s1, mx = s0 > s1 ? s0 : s1;
-          keep[j] = !((uint64_t)mx > (uint64_t)(int64_t)radio * (uint64_t)mn);  // src/MST.cpp:1484
+          keep = !((uint64_t)mx > (uint64_t)(int64_t)radio * (uint64_t)mn);  // src/MST.cpp:1484
         }
       }
-      mine += keep[j] ? 1u : 0u;
+      const uint64_t bal = __ballot(keep);
+      if (bal) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(bal));
+        base = __shfl(base, 0);
+        const uint64_t idx = base + (uint64_t)__popcll(bal & ((1ULL << lane) - 1ULL));
+        if (keep && idx < cap) edges[idx] = rtc_cedge{row, col, v[j]};
+      }
     }
-    if (__any(mine != 0)) {  // wave-uniform: reserve this wave's slots with one LDS atomic
-      uint32_t incl = mine;  // inclusive prefix sum over the wave
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += t; }
-      const uint32_t total = __shfl(incl, 63);
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&staged, total);
-      base = __shfl(base, 0);
-      uint32_t pos = base + incl - mine;
-#pragma unroll
-      for (int j = 0; j < 4; j++) if (keep[j]) stage[pos++] = rtc_cedge{row, c4 + j, v[j]};
-    }
-    __syncthreads();
-    if (staged > EX_STAGE - 1024) flush();  // uniform: read after the barrier
   }
-  flush();
 }
 
 __global__ __launch_bounds__(256) void boruvka_minweight_kernel(const rtc_cedge* __restrict__ edges, uint64_t m,
@@ -199,9 +167,7 @@ int rtc_extract_edges_dev(rtc_ctx* ctx, const uint32_t* d_common, uint64_t ld, u
   if (!ctx || !d_common || !d_len || !d_count || (cap && !d_edges)) return RTC_ERR_ARG;
   if (row0 >= row1 || col0 >= col1) return RTC_OK;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
-  // few, long-lived blocks: each stages the survivors of many rows and flushes them together
-  const uint32_t gy = (uint32_t)std::max(1, ctx->num_cu * 8 / (int)std::max<uint32_t>(1, (col1 - col0 + 1023) / 1024));
-  dim3 grid((col1 - col0 + 1023) / 1024, std::min<uint32_t>(row1 - row0, gy));
+  dim3 grid((col1 - col0 + 1023) / 1024, std::min<uint32_t>(row1 - row0, 4096));
   hipLaunchKernelGGL(extract_edges_kernel, grid, dim3(256), 0, ctx->stream, d_common, ld, row0, row1, col0, col1,
                      d_len, radio, d_edges, cap, (unsigned long long*)d_count);
   RTC_CHECK_LAUNCH(ctx);
