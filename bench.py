@@ -1,44 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- MinHash sketch + all-pairs Mash distance (clust-mst hot path) on MI355X.
+"""bench.py -- sketch + all-pairs Mash distance (clust-mst hot path) on MI355X.
 
 One step = one pass of the hot path over one batch of synthetic genomes already resident in HBM:
-  sketch (k=21, s=1000) -> [N>1: all-gather sketches over RCCL] -> row-sharded N x N sorted-sketch
-  intersection -> candidate edges -> minimum spanning forest (Boruvka; N>1: all-reduce(min) per round).
-Workload at N=1: BASELINE.json configs[1] = 10k x 5 Mbp synthetic genomes (1 000 families of 10,
-substitution rate U[0,0.08]).  N>1: every rank brings its own 10k genomes (weak scaling), the pair
-space is (N*10k)^2/2 row-sharded across ranks.
+  sketch (MinHash k=21 s=1000, or KSSD with --mode kssd) -> [N>1: all-gather sketches over RCCL] ->
+  row-sharded N x N sorted-sketch intersection with fused candidate-edge emission -> minimum spanning
+  forest (device Boruvka; N>1: one all-reduce(MIN) per round in fixed-size mode).
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for field definitions).
+Workloads (BASELINE.json configs; 1 000-family synthetic genomes, substitution rate U[0,0.08]):
+  --mode minhash  N=1: configs[1] = 10 000 x 5 Mbp.  N>1: 12 500 genomes per GPU, i.e. configs[2]
+                  (100 000 x 5 Mbp) at N=8; the pair space is (N*12 500)^2/2, row-sharded.
+  --mode kssd     25 000 x 2 Mbp per GPU, i.e. configs[4] (200 000 x 2 Mbp) at N=8.
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment re-launches itself under
+torch.distributed.run with N ranks (one per GPU, backend nccl = RCCL); `n_gpus` in the output is the
+world size the process group reports.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from rabbittclust_amd import api  # noqa: E402
-from rabbittclust_amd import pipeline  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-
-
-def measured_traffic(kernel, args):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (request-size counters,
-    profiles/r01_pmc_traffic.json), valid only for the workload they were collected on."""
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        w = prof["workload"]
-        if (w["genomes"], w["length"], w["k"], w["s"]) != (args.genomes, args.length, args.k, args.s):
-            return None
-        return prof["kernels"][kernel]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+PROFILE_JSON = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def parse():
@@ -46,16 +35,48 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genomes", type=int, default=10000, help="genomes per GPU")
-    ap.add_argument("--length", type=int, default=5_000_000)
+    ap.add_argument("--mode", choices=("minhash", "kssd"), default="minhash")
+    ap.add_argument("--genomes", type=int, default=0, help="genomes per GPU (0 = the BASELINE shape for --gpus/--mode)")
+    ap.add_argument("--length", type=int, default=0, help="bases per genome (0 = 5 000 000 minhash / 2 000 000 kssd)")
     ap.add_argument("--family", type=int, default=10)
     ap.add_argument("-k", type=int, default=21)
     ap.add_argument("-s", type=int, default=1000)
+    ap.add_argument("--drlevel", type=int, default=3)
     ap.add_argument("--threshold", type=float, default=0.05)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-genomes", type=int, default=0, help="0 = 16 per usable core (>= 64)")
+    ap.add_argument("--cpu-sample-genomes", type=int, default=0, help="0 = 1024 (SURVEY 8d: >= 1k genomes)")
     ap.add_argument("--cpu-sample-sketches", type=int, default=8000)
     return ap.parse_args()
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: launch the N ranks ourselves."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} requested but {have} GPU(s) visible; refusing to run fewer ranks")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def measured_traffic(kernel, workload):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (request-size counters),
+    valid only for the workload they were collected on."""
+    for name in PROFILE_JSON:
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", name)))
+            w = prof["workload"]
+            if all(w.get(k) == v for k, v in workload.items()) and kernel in prof["kernels"]:
+                return prof["kernels"][kernel]["hbm_bytes_per_launch"], name
+        except Exception:
+            continue
+    return None, None
 
 
 def usable_cores():
@@ -71,37 +92,62 @@ def usable_cores():
     return max(n, 1)
 
 
-def cpu_baseline(args, ctx, seq, off, sketches_host):
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, mode, seq, off, sketches_host, shuffled):
     """Oracle ("port") timed on this box's host cores on a bounded sample of the same workload."""
+    import numpy as np
     from oracle import pyoracle as O
     cores = usable_cores()
-    ns = min(args.cpu_sample_genomes or max(64, 16 * cores), len(off) - 1)
+    n = len(off) - 1
+    ns = min(args.cpu_sample_genomes or 1024, n)
     L = int(off[1] - off[0])
     sub = seq[: ns * L].cpu().numpy()
     suboff = np.ascontiguousarray(off[: ns + 1])
     t0 = time.time()
-    sk = O.sketch_minhash_batch(sub, suboff, args.k, args.s, threads=cores)
+    if mode == "minhash":
+        sk = O.sketch_minhash_batch(sub, suboff, args.k, args.s, threads=cores)
+        impl = getattr(O, "MINHASH_IMPL", "scalar MurmurHash3 port")
+    else:
+        sk = O.sketch_kssd_batch(sub, suboff, shuffled, args.k, args.drlevel, threads=cores)
+        impl = "KSSD restatement of src/SketchInfo.cpp:994-1252"
     t_sk = time.time() - t0
     for g in range(min(ns, 4)):
         assert np.array_equal(sk[g], sketches_host[g]), "cpu baseline sketch differs from GPU sketch"
     npair = min(args.cpu_sample_sketches, len(sketches_host))
-    flat, start, lens = O.to_csr(sketches_host[:npair])
+    flat, start, lens = O.to_csr(sketches_host[:npair], dtype=sketches_host[0].dtype)
+    kk = args.k if mode == "minhash" else 2 * ((args.k + 1) // 2)
     t0 = time.time()
-    O.mst(flat, start, lens, args.k, 0, args.threshold, threads=cores)
+    O.mst(flat, start, lens, kk, 0, args.threshold, threads=cores)
     t_mst = time.time() - t0
     pairs = npair * (npair - 1) // 2
     return {
-        "value": pairs / t_mst, "unit": "genome-pairs/s", "cores": cores, "kind": "port",
+        "value": pairs / t_mst, "unit": "genome-pairs/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
         "sketch_gbp_per_sec": ns * L / t_sk / 1e9,
-        "sample": (f"sketch: {ns} x {L} bp genomes in {t_sk:.2f}s on {cores} threads (OpenMP over genomes, "
-                   f"scalar MurmurHash3 port; RabbitSketch's AVX2 kernel is absent from the reference tree); "
-                   f"distance: index-based compute_minhash_mst restatement on {npair} of the same sketches "
-                   f"({pairs} pairs, only pairs sharing a hash are touched) in {t_mst:.2f}s"),
+        "sample": (f"sketch: {ns} x {L} bp genomes in {t_sk:.2f}s on {cores} threads (OpenMP over genomes, {impl}; "
+                   f"ours -- RabbitSketch's AVX2 kernel is absent from the reference tree); "
+                   f"distance: index-based compute_{'minhash' if mode == 'minhash' else 'kssd'}_mst restatement on "
+                   f"{npair} of the same sketches ({pairs} pairs, only pairs sharing a hash are touched) in {t_mst:.2f}s"),
     }
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
+
+    import numpy as np
+    import torch
+    from rabbittclust_amd import api, pipeline
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -111,18 +157,34 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        world = dist.get_world_size()  # what RCCL actually sees
+        rank = dist.get_rank()
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s); reporting n_gpus={world}",
+              file=sys.stderr)
     ctx = api.Context(local)
 
-    n_local = args.genomes
+    mode = args.mode
+    if mode == "minhash":
+        n_local = args.genomes or (10000 if world == 1 else 12500)
+        length = args.length or 5_000_000
+    else:
+        n_local = args.genomes or 25000
+        length = args.length or 2_000_000
     n_fam = max(1, n_local // args.family)
     n_local = n_fam * args.family
     desc = api.synth_family_descs(n_fam, args.family, global_seed=42 + 1000 * rank)
-    off = np.arange(n_local + 1, dtype=np.uint64) * np.uint64(args.length)
+    off = np.arange(n_local + 1, dtype=np.uint64) * np.uint64(length)
     seq = ctx.synth_genomes(desc, off)
     ctx.sync()
 
+    shuffled = None
+    if mode == "kssd":
+        from rabbittclust_amd import host
+        shuffled = host.generate_shuffle_dim(6 if 6 - args.drlevel >= 2 else args.drlevel + 2)
     pipe = pipeline.MstPipeline(ctx, k=args.k, sketch_size=args.s, threshold=args.threshold,
-                                dist=dist, rank=rank, world=world)
+                                dist=dist, rank=rank, world=world, mode=mode, drlevel=args.drlevel,
+                                shuffled_dim=shuffled)
 
     def barrier():
         if dist is not None:
@@ -145,50 +207,68 @@ def main():
 
     n_total = n_local * world
     pairs = n_total * (n_total - 1) // 2
-    bases_total = float(n_local) * args.length * world
+    bases_total = float(n_local) * length * world
     ms_step = dt / args.steps * 1e3
     ph = {k: float(np.mean([p[k] for p in phases])) for k in phases[0]}
 
     if rank == 0:
         sk_ms = ph["sketch_ms"]
-        algo_bytes = float(n_local) * args.length + n_local * args.s * 8.0
+        sk_all = pipe.last_sketches
+        width = sk_all.width
+        hashes_local = float(sk_all.len.sum().item()) / world
+        algo_bytes = float(n_local) * length + hashes_local * width
         achieved = algo_bytes / (sk_ms * 1e-3) / 1e9
+        avg_len = float(sk_all.len.float().mean().item())
         dist_pairs_local = ph["pairs_local"]
-        dist_ach = dist_pairs_local * 2 * args.s * 8.0 / (ph["pair_ms"] * 1e-3) / 1e9
+        dist_algo = dist_pairs_local * 2 * avg_len * width / (ph["pair_ms"] * 1e-3) / 1e9
+        wl = {"genomes": n_local, "length": length, "k": args.k, "s": args.s, "mode": mode}
+        sk_kernel = "sketch_minhash_kernel" if mode == "minhash" else "sketch_kssd_kernel"
+        sk_traffic, sk_src = measured_traffic(sk_kernel, wl)
+        pr_traffic, pr_src = measured_traffic("pair_tiled_kernel", wl)
+        pr_ach = pr_traffic / (ph["pair_ms"] * 1e-3) / 1e9 if pr_traffic else None
+        what = "MinHash k=%d s=%d" % (args.k, args.s) if mode == "minhash" else "KSSD --fast k=%d drlevel=%d" % (args.k, args.drlevel)
         line = {
-            "metric": "genome_pairs_per_sec_end_to_end (sketch + all-pairs Mash distance + MST), k=21 s=1000",
+            "metric": ("genome_pairs_per_sec_end_to_end (sketch + all-pairs Mash distance + MST), k=21 s=1000"
+                       if mode == "minhash" else
+                       "genome_pairs_per_sec_end_to_end (KSSD sketch + all-pairs Mash distance + MST), --fast k=21"),
             "value": pairs / (dt / args.steps),
             "unit": "genome-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{n_total} x {args.length} bp synthetic genomes ({n_local}/GPU), MinHash k={args.k} "
-                                   f"s={args.s}, sketch + all-pairs + MST at d={args.threshold}",
-                       "genomes_per_gpu": n_local, "genome_length": args.length, "k": args.k,
-                       "sketch_size": args.s, "sharding": f"rows/{world}"},
+            "vs_baseline": None, "dtype": "u64" if width == 8 else "u32", "data": "synthetic",
+            "config": {"workload": f"{n_total} x {length} bp synthetic genomes ({n_local}/GPU), {what}, "
+                                   f"sketch + all-pairs + MST at d={args.threshold}",
+                       "genomes_per_gpu": n_local, "genome_length": length, "k": args.k,
+                       "sketch_size": args.s if mode == "minhash" else round(avg_len, 1), "sharding": f"rows/{world}",
+                       "scaling_note": "weak in genomes: per-GPU genomes (and sketch work) fixed as N grows; the pair "
+                                       "space is (N x genomes_per_gpu)^2/2, so pairs per GPU grow with N"},
             "sketch_gbp_per_sec": bases_total / (sk_ms * 1e-3) / 1e9,
             "dist_pairs_per_sec": pairs / (ph["dist_ms"] * 1e-3),
             "phase_ms": ph,
             "mst_edges": int(phases[-1]["mst_edges"]),
-            "roofline": {"bound": "hbm", "kernel": "sketch_minhash_kernel", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": sk_kernel, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("sketch_minhash_kernel", args),
-                         "note": "algorithmic bytes = 1 B/base + 8 B/hash out per launch; traffic = rocprofv3 PMC "
-                                 "bytes per launch (profiles/r01_pmc_traffic.json); the kernel is integer-VALU-issue "
-                                 "bound (~95 VALU instructions per k-mer at ~4.1 cycles each), see DESIGN.md 3.1"},
-            "roofline_dist": {"bound": "hbm", "kernel": "pair kernel", "achieved": dist_ach, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": dist_ach / HBM_PEAK_GBS,
-                              "traffic": measured_traffic("pair_tiled_kernel", args),
-                              "note": "algorithmic bytes = (|A|+|B|)*8 = 16000 B/pair; tiles are reused from "
-                                      "LDS/L2 so this may exceed 1"},
+                         "traffic": sk_traffic,
+                         "note": "algorithmic bytes = 1 B/base + %d B/hash out per launch; traffic = rocprofv3 PMC "
+                                 "bytes per launch (profiles/%s); the kernel is integer-VALU-issue bound, "
+                                 "see DESIGN.md 3.1" % (width, sk_src)},
+            "roofline_dist": {"bound": "hbm", "kernel": "pair_tiled_kernel", "achieved": pr_ach, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": (pr_ach / HBM_PEAK_GBS) if pr_ach else None,
+                              "traffic": pr_traffic, "algorithmic_achieved": dist_algo,
+                              "algorithmic_frac": dist_algo / HBM_PEAK_GBS,
+                              "note": "achieved/frac = PMC-measured HBM bytes per launch (profiles/%s) / pair-phase time: "
+                                      "the physical figure; algorithmic_* = (|A|+|B|)*%d B per pair / time, which "
+                                      "exceeds 1 because a tile's sketches are reused from LDS/L2 (one LDS probe serves "
+                                      "64 pairs)" % (pr_src, width)},
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                line["cpu_baseline"] = cpu_baseline(args, ctx, seq, off, pipe.last_sketches.to_host())
+                line["cpu_baseline"] = cpu_baseline(args, mode, seq, off, pipe.last_sketches.to_host(), shuffled)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(line))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

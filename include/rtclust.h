@@ -119,6 +119,14 @@ int rtc_extract_edges_dev(rtc_ctx* ctx, const uint32_t* d_common, uint64_t ld, u
                           uint32_t row1, uint32_t col0, uint32_t col1, const uint32_t* d_len,
                           int radio, rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count);
 
+/* Fused form of the two calls above for the tile rows [row0,row1) x cols [col0,col1): the pair
+ * kernel applies the same filters (src/MST.cpp:1468-1487) to its counters and appends the
+ * surviving (i, j, common), j < i, directly -- no dense matrix is written.  radio < 0 disables the
+ * size-ratio test (greedy clustering filters on the host).  d_count as above. */
+int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+                       const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0,
+                       uint32_t col1, int radio, rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count);
+
 /* ---- minimum spanning forest over candidate edges (Boruvka, order-exact integer weights) -- */
 /* One Boruvka round primitive for row-sharded multi-GPU use: for every current component c
  * (d_comp[v] = component label of vertex v) computes the minimum key over the local edges that
@@ -136,6 +144,26 @@ int rtc_boruvka_minedge_dev(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m,
  * into d_ecommon[component] (others leave 0; all-reduce(MAX) across ranks). */
 int rtc_boruvka_fetch_dev(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_comp,
                           uint32_t n, const uint64_t* d_ekey, uint32_t* d_ecommon);
+
+/* Fixed-size mode (every sketch holds exactly s hashes -- the -s configs): the distance
+ * (src/MST.cpp:1489-1503) is monotone in `common` alone, so ONE u64 key per component carries weight,
+ * edge and count:  key = (s - common) << 2B | i << B | j,  B = rtc_boruvka_key_bits(n, s) (0 when the
+ * key would not fit 63 bits -> use the three-pass form).  Across GPUs: one all-reduce(MIN) per round. */
+int rtc_boruvka_key_bits(uint32_t n, uint32_t s_fixed);
+int rtc_boruvka_minkey_dev(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_comp,
+                           uint32_t n, uint32_t s_fixed, uint64_t* d_key);
+
+/* Round state on the device: d_comp[v] = v, forest counter d_nsel[0] = 0 (d_nsel: two u64). */
+int rtc_boruvka_init_dev(rtc_ctx* ctx, uint32_t n, uint32_t* d_comp, uint64_t* d_nsel);
+/* Union step of a round on the device (kruskalAlgorithm's union-find work, src/MST.cpp:59-75):
+ * every component hooks onto the one its (all-reduced) minimum edge leads to, chosen edges are
+ * appended to d_sel (capacity n) and d_comp is relabelled.  s_fixed != 0: d_key holds fused keys;
+ * s_fixed == 0: d_key holds edge ids (i<<32|j, the d_ekey of the three-pass form) and d_ecommon the
+ * counts.  d_succ: n u32 of scratch.  *h_added = edges added this round (0: forest complete).
+ * Synchronises the stream (reads one counter back). */
+int rtc_boruvka_union_dev(rtc_ctx* ctx, uint32_t n, uint32_t s_fixed, const uint64_t* d_key,
+                          const uint32_t* d_ecommon, uint32_t* d_comp, uint32_t* d_succ, rtc_cedge* d_sel,
+                          uint64_t* d_nsel, uint32_t* h_added);
 
 /* Host helper closing one Boruvka round: unions the components joined by the winning edges
  * (h_ekey[c] = i<<32|j or 0x7FFF...F for none), appends them to h_sel (capacity n) and relabels

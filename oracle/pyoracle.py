@@ -149,6 +149,33 @@ def kssd_sketch(seq: np.ndarray, kmer_size=21, drlevel=3):
     return (o64[:n].copy() if p.use64 else o32[:n].copy())
 
 
+def sketch_kssd_batch(seq, off, shuffled_dim, kmer_size=21, drlevel=3, threads=1):
+    """KSSD sketches of concatenated genomes (one orc_kssd_sketch call per genome; the calls release
+    the GIL, so a thread pool spreads them over `threads` cores like the reference's OpenMP loop over
+    files, src/SketchInfo.cpp:1067)."""
+    from concurrent.futures import ThreadPoolExecutor
+    p = kssd_params(kmer_size, drlevel)
+    sd = np.ascontiguousarray(shuffled_dim, dtype=np.int32)
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    n = len(off) - 1
+    L = lib()
+
+    def one(g):
+        a, b = int(off[g]), int(off[g + 1])
+        cap = (b - a) // (16 ** drlevel) * 2 + 4096
+        while True:
+            o32 = np.empty(cap, dtype=np.uint32)
+            o64 = np.empty(cap if p.use64 else 1, dtype=np.uint64)
+            m = L.orc_kssd_sketch(C.byref(p), _p(sd), C.c_void_p(seq.ctypes.data + a), C.c_uint64(b - a), _p(o32), _p(o64),
+                                  C.c_uint64(cap))
+            if m <= cap:
+                return (o64[:m].copy() if p.use64 else o32[:m].copy())
+            cap = int(m)
+
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        return list(ex.map(one, range(n)))
+
+
 def to_csr(sketches, dtype=np.uint64):
     lens = np.array([len(s) for s in sketches], dtype=np.uint32)
     start = np.zeros(len(sketches), dtype=np.uint64)

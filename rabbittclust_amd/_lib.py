@@ -60,6 +60,11 @@ SIGNATURES = {
     "rtc_pair_common_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _u64,
                                  _i, _i]),
     "rtc_extract_edges_dev": (_i, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _vp, _i, _vp, _u64, _vp]),
+    "rtc_pair_edges_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _i, _vp, _u64, _vp]),
+    "rtc_boruvka_key_bits": (_i, [_u32, _u32]),
+    "rtc_boruvka_minkey_dev": (_i, [_vp, _vp, _u64, _vp, _u32, _u32, _vp]),
+    "rtc_boruvka_init_dev": (_i, [_vp, _u32, _vp, _vp]),
+    "rtc_boruvka_union_dev": (_i, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u32)]),
     "rtc_boruvka_minweight_dev": (_i, [_vp, _vp, _u64, _vp, _i, _vp, _u32, _vp]),
     "rtc_boruvka_minedge_dev": (_i, [_vp, _vp, _u64, _vp, _i, _vp, _u32, _vp, _vp]),
     "rtc_boruvka_fetch_dev": (_i, [_vp, _vp, _u64, _vp, _u32, _vp, _vp]),

@@ -211,6 +211,15 @@ class Context:
                                                   _t_ptr(count)))
         return edges, count
 
+    def pair_edges(self, sk, row0, row1, col0, col1, radio, cap):
+        """Fused form of pair_common + extract_edges (no dense matrix).  Returns (edges, count)."""
+        edges = torch.empty((max(cap, 1), 3), dtype=torch.int32, device=self.device)
+        count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.check(self.lib.rtc_pair_edges_dev(self.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start), _t_ptr(sk.len),
+                                               sk.n, row0, row1, col0, col1, int(radio), _t_ptr(edges), cap,
+                                               _t_ptr(count)))
+        return edges, int(count.item())
+
     def mst(self, sk, threshold, is_containment=False):
         """compute_minhash_mst / compute_kssd_mst: returns numpy EDGE_DT array (edge.mst records)."""
         n = sk.n

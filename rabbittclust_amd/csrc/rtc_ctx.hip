@@ -82,6 +82,8 @@ void rtc_ctx_destroy(rtc_ctx* ctx) {
   for (int i = 0; i < 6; i++)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->kssd.d_index) (void)hipFree(ctx->kssd.d_index);
+  if (ctx->kssd.d_table) (void)hipFree(ctx->kssd.d_table);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   delete ctx;

@@ -5,7 +5,7 @@
 // per query, probes a dynamic inverted index of the representatives' hashes.  Here a batch of
 // queries is intersected against every current representative AND against the earlier genomes of
 // the same batch in one tiled all-pairs launch (a virtual sketch set [reps..., batch...] built
-// from CSR offsets, no copy of hashes); the non-zero counts come back as a compact list and the
+// from CSR offsets, no copy of hashes); the pair kernel emits the non-zero counts as a compact list and the
 // host replays the reference's serial decisions -- common_min filter (:1205-1225), best match with
 // the reference's strict comparisons (:1233-1282), first-touched-wins tie rule of a -t 1 run --
 // so the clusters are identical to the reference at -t 1.
@@ -155,14 +155,13 @@ extern "C" int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const u
     }
     G_HIP(hipMemcpyAsync(dv_start, v_start.data(), (size_t)nv * 8, hipMemcpyHostToDevice, ctx->stream));
     G_HIP(hipMemcpyAsync(dv_len, v_len.data(), (size_t)nv * 4, hipMemcpyHostToDevice, ctx->stream));
-    uint32_t* d_common = nullptr;
-    G_TRY(rtc_ws(ctx, 2, (size_t)nb * nv * 4, (void**)&d_common));
-    G_TRY(rtc_pair_common_dev(ctx, d_hashes, width, dv_start, dv_len, nv, nr, nv, 0, nv - 1, d_common, nv, 1, 0));
+    // candidate (query, earlier genome, common) triples straight from the pair kernel (no dense matrix);
+    // the reference's filters need the configured sizes and run on the host below
     uint64_t m = 0;
     while (true) {
       G_HIP(hipMemsetAsync(d_count, 0, 8, ctx->stream));
-      G_TRY(rtc_extract_edges_dev(ctx, d_common, nv, nr, nv, 0, nv - 1, dv_len, std::numeric_limits<int>::max(), d_edges,
-                                  ecap, (uint64_t*)d_count));
+      G_TRY(rtc_pair_edges_dev(ctx, d_hashes, width, dv_start, dv_len, nv, nr, nv, 0, nv - 1, -1, d_edges, ecap,
+                               (uint64_t*)d_count));
       unsigned long long cnt = 0;
       G_HIP(hipMemcpyAsync(&cnt, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
       G_HIP(hipStreamSynchronize(ctx->stream));

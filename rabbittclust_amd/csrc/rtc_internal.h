@@ -24,12 +24,55 @@ struct rtc_ctx {
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // tiled pair kernel: the last plan (slice offsets + transposed column copy in scratch slots 1 / 4).
+  // Reused only while pair_plan_hold is set by a caller that guarantees unchanged sketches between
+  // launches (the row-chunk loop of the dense candidate-edge path).
+  int pair_plan_hold = 0, pair_plan_valid = 0;
+  uint32_t pair_plan_tc1_hint = 0;
+  struct {
+    const void *hashes, *start, *len;
+    uint32_t n, tc0, tc1;
+    int width, P, npl;
+    const uint32_t* d_so;
+    const uint64_t* d_tbase;
+    const void* d_tcols;
+  } pair_plan = {};
+  // KSSD filter tables of this context (cuckoo index or full table), keyed by (half_subk, drlevel, checksum)
+  struct {
+    int half_subk = -1, drlevel = -1;
+    uint64_t checksum = 0;
+    void* d_index = nullptr;
+    int ck1 = 13, ck2 = 13;
+    int32_t* d_table = nullptr;
+  } kssd;
 };
 
 int rtc_fail(rtc_ctx* ctx, int code, const char* fmt, ...);
 // returns device scratch slot `slot` grown to at least `bytes`
 int rtc_ws(rtc_ctx* ctx, int slot, size_t bytes, void** out);
 int rtc_pinned(rtc_ctx* ctx, size_t bytes, void** out);
+
+// ---- internal C++ interfaces shared by the translation units ----------------------------------
+// all-reduce of a per-round key array across the ranks of a multi-GPU run (rtc_comm.hip);
+// dtype 0 = int64, 1 = uint32; op 0 = MIN, 1 = MAX
+struct rtc_reduce_hook {
+  int (*all_reduce)(void* self, void* d_buf, size_t count, int dtype, int op);
+  void* self;
+};
+struct rtc_edge_list {  // device-resident candidate edges
+  rtc_cedge* d_edges = nullptr;
+  uint64_t cap = 0, m = 0;
+  unsigned long long* d_count = nullptr;
+  int contractions = 0;
+};
+int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+                               const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1, int kmer_size,
+                               int is_containment, double threshold, uint32_t s_fixed, rtc_edge_list* el);
+void rtc_edge_list_free(rtc_edge_list* el);
+int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_len, uint32_t n,
+                   int is_containment, uint32_t s_fixed, const rtc_reduce_hook* hook, rtc_cedge* d_sel,
+                   uint64_t* n_sel_out, int* rounds_out);
+uint32_t rtc_fixed_size_of(const uint32_t* h_len, uint32_t n);
 
 #define RTC_HIP(ctx, call)                                                                  \
   do {                                                                                      \

@@ -9,6 +9,14 @@
 //     compared as log() results on the device: the key is the IEEE-754 bit pattern of the
 //     similarity double J = common/denom (correctly rounded division, monotone in the exact
 //     rational), so the order is exact and identical on every rank; ties break on (i,j).
+//     When every sketch has the same size s (the fixed-size MinHash configs) the distance is
+//     monotone in `common` alone and one u64 key  (s - common) | i | j  carries weight, edge and
+//     count: one atomicMin pass and -- across GPUs -- ONE all-reduce(MIN) per round.
+//   * The union step runs on the device too: every component hooks onto the component its minimum
+//     edge leads to (the strict total order on keys leaves only 2-cycles, broken towards the smaller
+//     root), the hooked forest is flattened by following the successor chains, and the chosen edges
+//     are appended to the forest list.  A round is launch -> [all-reduce] -> launch, the host reads
+//     back one counter.
 //     Distances are evaluated on the host with the reference's expression order.
 #include <math.h>
 
@@ -122,6 +130,93 @@ __global__ void fill_u64_kernel(unsigned long long* p, uint64_t n, unsigned long
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// fixed-size mode: key = (s - common) << 2B | i << B | j   (B = index bits; smaller key = closer pair)
+__global__ __launch_bounds__(256) void boruvka_minkey_kernel(const rtc_cedge* __restrict__ edges, uint64_t m,
+                                                             const uint32_t* __restrict__ comp, uint32_t s_fixed,
+                                                             int idx_bits, unsigned long long* __restrict__ key) {
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += (uint64_t)gridDim.x * blockDim.x) {
+    const rtc_cedge ed = edges[e];
+    const uint32_t ci = comp[ed.i], cj = comp[ed.j];
+    if (ci == cj) continue;
+    const unsigned long long k = ((unsigned long long)(s_fixed - ed.common) << (2 * idx_bits)) |
+                                 ((unsigned long long)ed.i << idx_bits) | (unsigned long long)ed.j;
+    if (k < key[ci]) atomicMin(&key[ci], k);
+    if (k < key[cj]) atomicMin(&key[cj], k);
+  }
+}
+
+struct RoundKeys {
+  const unsigned long long* key;  // fixed mode: fused key; variable mode: edge id (i << 32 | j)
+  const uint32_t* ecommon;        // variable mode only
+  uint32_t s_fixed;               // 0: variable mode
+  int idx_bits;
+};
+
+__device__ __forceinline__ bool round_edge(const RoundKeys& K, uint32_t c, uint32_t& i, uint32_t& j, uint32_t& common) {
+  const unsigned long long k = K.key[c];
+  if (k == KEY_NONE) return false;
+  if (K.s_fixed) {
+    const unsigned long long mask = (1ULL << K.idx_bits) - 1ULL;
+    j = (uint32_t)(k & mask);
+    i = (uint32_t)((k >> K.idx_bits) & mask);
+    common = K.s_fixed - (uint32_t)(k >> (2 * K.idx_bits));
+  } else {
+    i = (uint32_t)(k >> 32);
+    j = (uint32_t)k;
+    common = K.ecommon[c];
+  }
+  return true;
+}
+
+// Every root v with a minimum edge hooks onto the component at the edge's other end.  Two roots that
+// picked each other picked the same edge (strict total order on keys): the smaller one stays a root
+// and records the edge, the larger one hooks without recording it.
+__global__ __launch_bounds__(256) void boruvka_hook_kernel(RoundKeys K, const uint32_t* __restrict__ comp, uint32_t n,
+                                                           uint32_t* __restrict__ succ, rtc_cedge* __restrict__ sel,
+                                                           unsigned long long* __restrict__ nsel,
+                                                           uint32_t* __restrict__ added) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t v0 = blockIdx.x * blockDim.x; v0 < n; v0 += gridDim.x * blockDim.x) {  // whole waves stay together
+    const uint32_t v = v0 + threadIdx.x;
+    uint32_t s = v, i = 0, j = 0, cm = 0;
+    bool append = false;
+    if (v < n && comp[v] == v && round_edge(K, v, i, j, cm)) {
+      const uint32_t ci = comp[i], cj = comp[j];
+      const uint32_t d = ci == v ? cj : ci;
+      uint32_t i2, j2, cm2;
+      bool mutual = false;
+      if (round_edge(K, d, i2, j2, cm2)) {
+        const uint32_t di = comp[i2], dj = comp[j2];
+        mutual = (di == d ? dj : di) == v;
+      }
+      if (mutual && v < d) { s = v; append = true; }
+      else { s = d; append = !mutual; }
+    }
+    if (v < n) succ[v] = s;
+    const uint64_t bal = __ballot(append);
+    if (bal) {
+      unsigned long long base = 0;
+      if (lane == 0) { base = atomicAdd(nsel, (unsigned long long)__popcll(bal)); atomicAdd(added, (uint32_t)__popcll(bal)); }
+      base = __shfl(base, 0);
+      if (append) sel[base + (uint64_t)__popcll(bal & ((1ULL << lane) - 1ULL))] = rtc_cedge{i, j, cm};
+    }
+  }
+}
+
+// comp[v] <- root of comp[v] in the hooked forest (successor chains end in a root with succ[r] == r)
+__global__ __launch_bounds__(256) void boruvka_relabel_kernel(uint32_t* __restrict__ comp, const uint32_t* __restrict__ succ,
+                                                              uint32_t n) {
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+    uint32_t r = comp[v];
+    while (true) { const uint32_t nx = succ[r]; if (nx == r) break; r = nx; }
+    comp[v] = r;
+  }
+}
+
+__global__ void iota_u32_kernel(uint32_t* p, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
+}
+
 inline uint32_t grid_for(uint64_t work, int num_cu) {
   uint64_t b = (work + 255) / 256;
   uint64_t mx = (uint64_t)num_cu * 8;
@@ -159,6 +254,151 @@ static double host_mst_distance(int common, int size0, int size1, int kmer_size,
   return -inv_kmer_size * log(containment);
 }
 
+// ---- minimum spanning forest of a device-resident candidate list (shared by rtc_mst and the
+// multi-GPU step; `hook` all-reduces the per-round key arrays across ranks, NULL on one GPU) ----
+int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_len, uint32_t n,
+                   int is_containment, uint32_t s_fixed, const rtc_reduce_hook* hook, rtc_cedge* d_sel,
+                   uint64_t* n_sel_out, int* rounds_out) {
+  *n_sel_out = 0;
+  if (rounds_out) *rounds_out = 0;
+  if (n < 2) return RTC_OK;
+  const int idx_bits = rtc_boruvka_key_bits(n, s_fixed);
+  if (s_fixed && !idx_bits) s_fixed = 0;
+  void* ws3 = nullptr;
+  RTC_TRY(rtc_ws(ctx, 3, (size_t)n * (8 + 8 + 4 + 4 + 4) + 256, &ws3));
+  uint64_t* d_wkey = (uint64_t*)ws3;
+  uint64_t* d_ekey = d_wkey + n;
+  uint32_t* d_ecommon = (uint32_t*)(d_ekey + n);
+  uint32_t* d_comp = d_ecommon + n;
+  uint32_t* d_succ = d_comp + n;
+  uint64_t* d_nsel = (uint64_t*)(((uintptr_t)(d_succ + n) + 63) & ~(uintptr_t)63);
+  RTC_TRY(rtc_boruvka_init_dev(ctx, n, d_comp, d_nsel));
+  int rounds = 0;
+  for (int round = 0; round < 64; round++) {
+    if (s_fixed) {
+      RTC_TRY(rtc_boruvka_minkey_dev(ctx, d_edges, m, d_comp, n, s_fixed, d_wkey));
+      if (hook) RTC_TRY(hook->all_reduce(hook->self, d_wkey, n, 0, 0));
+    } else {
+      RTC_TRY(rtc_boruvka_minweight_dev(ctx, d_edges, m, d_len, is_containment, d_comp, n, d_wkey));
+      if (hook) RTC_TRY(hook->all_reduce(hook->self, d_wkey, n, 0, 0));
+      RTC_TRY(rtc_boruvka_minedge_dev(ctx, d_edges, m, d_len, is_containment, d_comp, n, d_wkey, d_ekey));
+      if (hook) RTC_TRY(hook->all_reduce(hook->self, d_ekey, n, 0, 0));
+      RTC_TRY(rtc_boruvka_fetch_dev(ctx, d_edges, m, d_comp, n, d_ekey, d_ecommon));
+      if (hook) RTC_TRY(hook->all_reduce(hook->self, d_ecommon, n, 1, 1));
+    }
+    uint32_t added = 0;
+    RTC_TRY(rtc_boruvka_union_dev(ctx, n, s_fixed, s_fixed ? d_wkey : d_ekey, d_ecommon, d_comp, d_succ, d_sel, d_nsel, &added));
+    rounds++;
+    if (!added) break;
+  }
+  unsigned long long ns = 0;
+  RTC_HIP(ctx, hipMemcpyAsync(&ns, d_nsel, 8, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *n_sel_out = ns;
+  if (rounds_out) *rounds_out = rounds;
+  return RTC_OK;
+}
+
+// ---- candidate edges of rows [row0, row1) (columns j < i), device list with growth / contraction ----
+// The list is produced optimistically in one launch; if it would exceed the edge budget (dense
+// inputs: same-species collections) the rows are walked in chunks and the list is contracted to
+// its own minimum spanning forest whenever it passes half the budget -- the reference bounds its
+// memory the same way (sort + Kruskal per row block, src/MST.cpp:1543-1546); the forest of a union is the
+// forest of the parts' forests.
+int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+                               const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1, int kmer_size,
+                               int is_containment, double threshold, uint32_t s_fixed, rtc_edge_list* el) {
+  const int radio = (int)(2.0 * exp(threshold * (kmer_size - 1)) - 1.0);  // src/MST.cpp:26-37,1292
+  uint64_t budget = (uint64_t)256 << 20;  // edges (3 GiB)
+  if (const char* e = getenv("RTC_EDGE_BUDGET")) budget = std::max<uint64_t>(strtoull(e, nullptr, 10), 1024);  // tests of the dense path
+  budget = std::max<uint64_t>(budget, 66ull * n + 1024);  // a 64-row block on top of a contracted list always fits
+  el->m = 0;
+  if (row1 <= std::max<uint32_t>(row0, 1)) return RTC_OK;
+  row0 = std::max<uint32_t>(row0, 1);
+  if (!el->d_count) RTC_HIP(ctx, hipMalloc((void**)&el->d_count, 64));
+  auto ensure = [&](uint64_t want) -> int {
+    if (want <= el->cap) return RTC_OK;
+    rtc_cedge* nd = nullptr;
+    hipError_t e = hipMalloc((void**)&nd, want * sizeof(rtc_cedge));
+    if (e != hipSuccess) return rtc_fail(ctx, RTC_ERR_NOMEM, "candidate edge list of %llu edges (%.1f GB): %s",
+                                         (unsigned long long)want, want * 12e-9, hipGetErrorString(e));
+    if (el->m) RTC_HIP(ctx, hipMemcpyAsync(nd, el->d_edges, el->m * sizeof(rtc_cedge), hipMemcpyDeviceToDevice, ctx->stream));
+    RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (el->d_edges) (void)hipFree(el->d_edges);
+    el->d_edges = nd; el->cap = want;
+    return RTC_OK;
+  };
+  RTC_TRY(ensure(std::min<uint64_t>(budget, std::max<uint64_t>((uint64_t)1 << 20, (uint64_t)n * 16))));
+  auto run_rows = [&](uint32_t r0, uint32_t r1, unsigned long long* cnt_out) -> int {
+    unsigned long long mm = el->m;
+    RTC_HIP(ctx, hipMemcpyAsync(el->d_count, &mm, 8, hipMemcpyHostToDevice, ctx->stream));
+    RTC_TRY(rtc_pair_edges_dev(ctx, d_hashes, width, d_start, d_len, n, r0, r1, 0, r1 - 1, radio, el->d_edges, el->cap,
+                               (uint64_t*)el->d_count));
+    RTC_HIP(ctx, hipMemcpyAsync(cnt_out, el->d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RTC_OK;
+  };
+  unsigned long long cnt = 0;
+  RTC_TRY(run_rows(row0, row1, &cnt));
+  if (cnt <= el->cap) { el->m = cnt; return RTC_OK; }
+  if (cnt <= budget) {  // grow to the exact need and redo the launch
+    RTC_TRY(ensure(cnt));
+    RTC_TRY(run_rows(row0, row1, &cnt));
+    el->m = cnt;
+    return RTC_OK;
+  }
+  // ---- dense input: row chunks + contraction ----
+  RTC_TRY(ensure(budget));
+  rtc_cedge* d_sel = nullptr;
+  RTC_HIP(ctx, hipMalloc((void**)&d_sel, (size_t)n * sizeof(rtc_cedge)));
+  int st = RTC_OK;
+  ctx->pair_plan_hold = 1;  // the sketches do not change between the chunk launches: build the plan once
+  ctx->pair_plan_valid = 0;
+  ctx->pair_plan_tc1_hint = row1 - 1;
+  uint32_t r0 = row0;
+  uint32_t rows_per = (uint32_t)std::max<uint64_t>(64, (budget / 4) / std::max<uint32_t>(row1, 1) / 64 * 64);
+  auto contract = [&]() -> int {
+    uint64_t ns = 0;
+    RTC_TRY(rtc_msf_device(ctx, el->d_edges, el->m, d_len, n, is_containment, s_fixed, nullptr, d_sel, &ns, nullptr));
+    RTC_HIP(ctx, hipMemcpyAsync(el->d_edges, d_sel, ns * sizeof(rtc_cedge), hipMemcpyDeviceToDevice, ctx->stream));
+    el->m = ns;
+    el->contractions++;
+    return RTC_OK;
+  };
+  while (r0 < row1 && st == RTC_OK) {
+    const uint32_t r1 = std::min<uint32_t>(row1, r0 + rows_per);
+    st = run_rows(r0, r1, &cnt);
+    if (st != RTC_OK) break;
+    if (cnt > el->cap) {  // the chunk does not fit on top of the list: contract the list, then shrink the chunk
+      if (el->m >= n) { st = contract(); continue; }
+      if (rows_per > 64) { rows_per = std::max<uint32_t>(64, rows_per / 2 / 64 * 64); continue; }
+      st = rtc_fail(ctx, RTC_ERR_NOMEM, "edge budget %llu too small for a 64-row block", (unsigned long long)budget);
+      break;
+    }
+    el->m = cnt;
+    r0 = r1;
+    if (el->m > budget / 2 && r0 < row1) st = contract();
+  }
+  ctx->pair_plan_hold = 0;
+  ctx->pair_plan_valid = 0;
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_sel);
+  return st;
+}
+
+void rtc_edge_list_free(rtc_edge_list* el) {
+  if (el->d_edges) (void)hipFree(el->d_edges);
+  if (el->d_count) (void)hipFree(el->d_count);
+  *el = rtc_edge_list{};
+}
+
+// all sketches the same size (and the fused key fits)?  0 otherwise
+uint32_t rtc_fixed_size_of(const uint32_t* h_len, uint32_t n) {
+  if (!n || !h_len[0]) return 0;
+  for (uint32_t i = 1; i < n; i++) if (h_len[i] != h_len[0]) return 0;
+  return rtc_boruvka_key_bits(n, h_len[0]) ? h_len[0] : 0;
+}
+
 extern "C" {
 
 int rtc_extract_edges_dev(rtc_ctx* ctx, const uint32_t* d_common, uint64_t ld, uint32_t row0, uint32_t row1,
@@ -171,6 +411,66 @@ int rtc_extract_edges_dev(rtc_ctx* ctx, const uint32_t* d_common, uint64_t ld, u
   hipLaunchKernelGGL(extract_edges_kernel, grid, dim3(256), 0, ctx->stream, d_common, ld, row0, row1, col0, col1,
                      d_len, radio, d_edges, cap, (unsigned long long*)d_count);
   RTC_CHECK_LAUNCH(ctx);
+  return RTC_OK;
+}
+
+int rtc_boruvka_key_bits(uint32_t n, uint32_t s_fixed) {
+  if (!s_fixed || n < 2) return 0;
+  int b = 1;
+  while (b < 32 && (1ull << b) < (uint64_t)n) b++;
+  int w = 1;
+  while (w < 32 && (1ull << w) <= (uint64_t)s_fixed) w++;
+  return (w + 2 * b <= 63) ? b : 0;
+}
+
+int rtc_boruvka_init_dev(rtc_ctx* ctx, uint32_t n, uint32_t* d_comp, uint64_t* d_nsel) {
+  if (!ctx || !d_comp || !d_nsel) return RTC_ERR_ARG;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  if (n) {
+    hipLaunchKernelGGL(iota_u32_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(256), 0, ctx->stream, d_comp, n);
+    RTC_CHECK_LAUNCH(ctx);
+  }
+  RTC_HIP(ctx, hipMemsetAsync(d_nsel, 0, 16, ctx->stream));  // [0] = forest size, [1] = edges added by the last round
+  return RTC_OK;
+}
+
+int rtc_boruvka_minkey_dev(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_comp, uint32_t n,
+                           uint32_t s_fixed, uint64_t* d_key) {
+  if (!ctx || !d_comp || !d_key || (m && !d_edges)) return RTC_ERR_ARG;
+  const int idx_bits = rtc_boruvka_key_bits(n, s_fixed);
+  if (!idx_bits) return rtc_fail(ctx, RTC_ERR_ARG, "fused Boruvka key does not fit: n=%u s=%u", n, s_fixed);
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(256), 0, ctx->stream,
+                     (unsigned long long*)d_key, (uint64_t)n, (unsigned long long)KEY_NONE);
+  RTC_CHECK_LAUNCH(ctx);
+  if (m) {
+    hipLaunchKernelGGL(boruvka_minkey_kernel, dim3(grid_for(m, ctx->num_cu)), dim3(256), 0, ctx->stream, d_edges, m, d_comp,
+                       s_fixed, idx_bits, (unsigned long long*)d_key);
+    RTC_CHECK_LAUNCH(ctx);
+  }
+  return RTC_OK;
+}
+
+int rtc_boruvka_union_dev(rtc_ctx* ctx, uint32_t n, uint32_t s_fixed, const uint64_t* d_key, const uint32_t* d_ecommon,
+                          uint32_t* d_comp, uint32_t* d_succ, rtc_cedge* d_sel, uint64_t* d_nsel, uint32_t* h_added) {
+  if (!ctx || !d_key || !d_comp || !d_succ || !d_sel || !d_nsel || !h_added || (!s_fixed && !d_ecommon)) return RTC_ERR_ARG;
+  *h_added = 0;
+  if (!n) return RTC_OK;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  RoundKeys K{(const unsigned long long*)d_key, d_ecommon, s_fixed, rtc_boruvka_key_bits(n, s_fixed)};
+  if (s_fixed && !K.idx_bits) return rtc_fail(ctx, RTC_ERR_ARG, "fused Boruvka key does not fit: n=%u s=%u", n, s_fixed);
+  uint32_t* d_added = (uint32_t*)(d_nsel + 1);
+  RTC_HIP(ctx, hipMemsetAsync(d_added, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(boruvka_hook_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(256), 0, ctx->stream, K, d_comp, n, d_succ,
+                     d_sel, (unsigned long long*)d_nsel, d_added);
+  RTC_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(boruvka_relabel_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(256), 0, ctx->stream, d_comp, d_succ, n);
+  RTC_CHECK_LAUNCH(ctx);
+  void* hp = nullptr;
+  RTC_TRY(rtc_pinned(ctx, 64, &hp));
+  RTC_HIP(ctx, hipMemcpyAsync(hp, d_added, 4, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *h_added = *(const uint32_t*)hp;
   return RTC_OK;
 }
 
@@ -265,80 +565,29 @@ int rtc_mst(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_sta
   *h_n_edges = 0;
   if (n < 2) return RTC_OK;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
-  const int radio = (int)(2.0 * exp(threshold * (kmer_size - 1)) - 1.0);  // src/MST.cpp:26-37,1292
+  std::vector<uint32_t> h_len(n);
+  RTC_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t s_fixed = rtc_fixed_size_of(h_len.data(), n);
 
-  // ---- all-pairs in row chunks -> compacted candidate edges ----
-  const uint64_t budget = 2ull << 30;  // bytes of dense common matrix resident at a time
-  uint32_t rows_per = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(n, budget / ((uint64_t)n * 4)));
-  rows_per = ((rows_per + 63) / 64) * 64;
-  uint32_t* d_common = nullptr;
-  RTC_TRY(rtc_ws(ctx, 2, (size_t)rows_per * n * 4, (void**)&d_common));
-  uint64_t cap = std::max<uint64_t>(1u << 20, (uint64_t)n * 16);
-  rtc_cedge* d_edges = nullptr;
-  unsigned long long* d_count = nullptr;
-  RTC_HIP(ctx, hipMalloc(&d_edges, cap * sizeof(rtc_cedge)));
-  hipError_t e0 = hipMalloc(&d_count, 8);
-  if (e0 != hipSuccess) { (void)hipFree(d_edges); return rtc_fail(ctx, RTC_ERR_NOMEM, "hipMalloc count"); }
-  int st = RTC_OK;
-  uint64_t m = 0;
-  auto cleanup = [&]() { (void)hipFree(d_edges); (void)hipFree(d_count); };
-#define MST_TRY(x) do { st = (x); if (st != RTC_OK) { cleanup(); return st; } } while (0)
-#define MST_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { cleanup(); return rtc_fail(ctx, RTC_ERR_HIP, "%s -> %s", #x, hipGetErrorString(e__)); } } while (0)
-  MST_HIP(hipMemsetAsync(d_count, 0, 8, ctx->stream));
-  for (uint32_t r0 = 1; r0 < n; r0 += rows_per) {
-    const uint32_t r1 = std::min<uint32_t>(n, r0 + rows_per);
-    const uint32_t c1 = r1 - 1;  // columns < max row
-    MST_TRY(rtc_pair_common_dev(ctx, d_hashes, width, d_start, d_len, n, r0, r1, 0, c1, d_common, n, 1, 0));
-    while (true) {
-      MST_TRY(rtc_extract_edges_dev(ctx, d_common, n, r0, r1, 0, c1, d_len, radio, d_edges, cap, (uint64_t*)d_count));
-      unsigned long long cnt = 0;
-      MST_HIP(hipMemcpyAsync(&cnt, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
-      MST_HIP(hipStreamSynchronize(ctx->stream));
-      if (cnt <= cap) { m = cnt; break; }
-      // grow and redo this chunk's extraction from the previous fill level
-      uint64_t ncap = std::max<uint64_t>(cnt + cnt / 2, cap * 2);
-      rtc_cedge* nd = nullptr;
-      MST_HIP(hipMalloc(&nd, ncap * sizeof(rtc_cedge)));
-      MST_HIP(hipMemcpyAsync(nd, d_edges, m * sizeof(rtc_cedge), hipMemcpyDeviceToDevice, ctx->stream));
-      MST_HIP(hipStreamSynchronize(ctx->stream));
-      (void)hipFree(d_edges);
-      d_edges = nd; cap = ncap;
-      unsigned long long mm = m;
-      MST_HIP(hipMemcpyAsync(d_count, &mm, 8, hipMemcpyHostToDevice, ctx->stream));
-      MST_HIP(hipStreamSynchronize(ctx->stream));
-    }
-  }
-
-  // ---- Boruvka rounds ----
-  std::vector<uint32_t> h_len(n), h_comp(n);
-  MST_HIP(hipMemcpyAsync(h_len.data(), d_len, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  void* ws3 = nullptr;
-  MST_TRY(rtc_ws(ctx, 3, (size_t)n * (8 + 8 + 4 + 4) + 64, &ws3));
-  uint64_t* d_wkey = (uint64_t*)ws3;
-  uint64_t* d_ekey = d_wkey + n;
-  uint32_t* d_ecommon = (uint32_t*)(d_ekey + n);
-  uint32_t* d_comp = d_ecommon + n;
-  std::vector<uint64_t> h_ekey(n);
-  std::vector<uint32_t> h_ecommon(n);
-  std::vector<rtc_cedge> sel(n);
+  rtc_edge_list el{};
+  rtc_cedge* d_sel = nullptr;
+  int st = rtc_candidate_edges_device(ctx, d_hashes, width, d_start, d_len, n, 1, n, kmer_size, is_containment, threshold,
+                                      s_fixed, &el);
   uint64_t nsel = 0;
-  std::iota(h_comp.begin(), h_comp.end(), 0u);
-  for (int round = 0; round < 64 && m > 0; round++) {
-    MST_HIP(hipMemcpyAsync(d_comp, h_comp.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    MST_TRY(rtc_boruvka_minweight_dev(ctx, d_edges, m, d_len, is_containment, d_comp, n, d_wkey));
-    MST_TRY(rtc_boruvka_minedge_dev(ctx, d_edges, m, d_len, is_containment, d_comp, n, d_wkey, d_ekey));
-    MST_TRY(rtc_boruvka_fetch_dev(ctx, d_edges, m, d_comp, n, d_ekey, d_ecommon));
-    MST_HIP(hipMemcpyAsync(h_ekey.data(), d_ekey, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    MST_HIP(hipMemcpyAsync(h_ecommon.data(), d_ecommon, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MST_HIP(hipStreamSynchronize(ctx->stream));
-    uint64_t added = 0;
-    MST_TRY(rtc_boruvka_merge_host(n, h_ekey.data(), h_ecommon.data(), h_comp.data(), sel.data(), &nsel, &added));
-    if (!added) break;
+  std::vector<rtc_cedge> sel;
+  if (st == RTC_OK && hipMalloc((void**)&d_sel, (size_t)n * sizeof(rtc_cedge)) != hipSuccess)
+    st = rtc_fail(ctx, RTC_ERR_NOMEM, "hipMalloc forest list");
+  if (st == RTC_OK) st = rtc_msf_device(ctx, el.d_edges, el.m, d_len, n, is_containment, s_fixed, nullptr, d_sel, &nsel, nullptr);
+  if (st == RTC_OK && nsel) {
+    sel.resize(nsel);
+    hipError_t e = hipMemcpyAsync(sel.data(), d_sel, nsel * sizeof(rtc_cedge), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) st = rtc_fail(ctx, RTC_ERR_HIP, "forest read-back -> %s", hipGetErrorString(e));
   }
-  MST_HIP(hipStreamSynchronize(ctx->stream));
-  cleanup();
-#undef MST_TRY
-#undef MST_HIP
+  if (d_sel) (void)hipFree(d_sel);
+  rtc_edge_list_free(&el);
+  if (st != RTC_OK) return st;
   RTC_TRY(rtc_edges_to_mst_host(sel.data(), nsel, h_len.data(), kmer_size, is_containment, h_edges_out));
   *h_n_edges = nsel;
   return RTC_OK;

@@ -7,12 +7,19 @@
 //   algo 1  pair_merge_kernel : one lane per pair, two-pointer merge straight from global memory.
 //           Handles any sketch size / width; used as fallback and as on-device cross-check.
 //   algo 2  (rtc_pairs_tiled.hip) LDS mask-table tiles.
+#include <algorithm>
+
 #include "rtc_internal.h"
 
 int rtc_pair_common_tiled(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
                           const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1,
                           uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld,
                           int lower_only, int* handled);
+
+int rtc_pair_edges_tiled(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+                         const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0,
+                         uint32_t col1, int lower_only, int radio, rtc_cedge* d_edges, uint64_t cap,
+                         uint64_t* d_count, int* handled);
 
 namespace {
 
@@ -73,5 +80,36 @@ extern "C" int rtc_pair_common_dev(rtc_ctx* ctx, const void* d_hashes, int width
     hipLaunchKernelGGL(pair_merge_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream,
                        (const uint32_t*)d_hashes, d_start, d_len, row0, row1, col0, col1, d_common, ld, lower_only);
   RTC_CHECK_LAUNCH(ctx);
+  return RTC_OK;
+}
+
+// Candidate edges of a tile.  Tiled path: survivors are emitted by the pair kernel itself.  Inputs
+// the tiled scheme cannot take go through the per-pair merge kernel into a dense scratch matrix
+// (row chunks of <= 1 GiB) that rtc_extract_edges_dev filters.
+extern "C" int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+                                  const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0,
+                                  uint32_t col1, int radio, rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count) {
+  if (!ctx || !d_start || !d_len || !d_count || (cap && !d_edges)) return RTC_ERR_ARG;
+  if (width != 4 && width != 8) return rtc_fail(ctx, RTC_ERR_ARG, "width must be 4 or 8");
+  if (row1 > n || col1 > n || row0 > row1 || col0 > col1) return rtc_fail(ctx, RTC_ERR_ARG, "tile outside [0,n)");
+  if (row0 == row1 || col0 == col1) return RTC_OK;
+  if (!d_hashes) return RTC_ERR_ARG;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  int handled = 0;
+  if (!getenv("RTC_PAIR_FORCE_MERGE"))
+    RTC_TRY(rtc_pair_edges_tiled(ctx, d_hashes, width, d_start, d_len, n, row0, row1, col0, col1, 1, radio, d_edges, cap,
+                                 d_count, &handled));
+  if (handled) return RTC_OK;
+  const uint64_t ld = col1 - col0;
+  uint32_t rows_per = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(row1 - row0, ((uint64_t)1 << 30) / (ld * 4)));
+  rows_per = std::min<uint32_t>(rows_per, 262140);
+  uint32_t* d_common = nullptr;
+  RTC_TRY(rtc_ws(ctx, 2, (size_t)rows_per * ld * 4, (void**)&d_common));
+  for (uint32_t r0 = row0; r0 < row1; r0 += rows_per) {
+    const uint32_t r1 = std::min(row1, r0 + rows_per);
+    RTC_TRY(rtc_pair_common_dev(ctx, d_hashes, width, d_start, d_len, n, r0, r1, col0, col1, d_common, ld, 1, 1));
+    RTC_TRY(rtc_extract_edges_dev(ctx, d_common, ld, r0, r1, col0, col1, d_len, radio < 0 ? 0x7fffffff : radio, d_edges, cap,
+                                  d_count));
+  }
   return RTC_OK;
 }

@@ -17,6 +17,12 @@
 // lanes) to common[row][col].  Partition boundaries are data quantiles computed from a sample, so
 // the table load stays ~25 %; blocks whose slices would overflow the table are split into row
 // sub-blocks inside the kernel, and inputs the scheme cannot take fall back to the merge kernel.
+//
+// Two output forms of the same kernel: EMIT_DENSE stores the counts into common[row][col];
+// EMIT_EDGES applies the reference's pair filters (src/MST.cpp:1468-1487: j < i, common > 0, size
+// ratio "radio") to the 64 counters a lane holds and appends the survivors (i, j, common) straight
+// to the candidate-edge list -- one global atomic per workgroup reserves the range, no dense matrix
+// is written or re-read.
 #include <algorithm>
 #include <vector>
 
@@ -52,6 +58,19 @@ struct TileShared {
   unsigned long long special;  // rows containing the EMPTY sentinel value itself
   uint32_t nsub;
   uint32_t sub_end[ROWS + 1];
+  // edge emission
+  uint32_t rlen[ROWS];
+  uint32_t wave_tot[TW / 64];
+  unsigned long long gbase;
+};
+
+enum { EMIT_DENSE = 0, EMIT_EDGES = 1 };
+struct EdgeSink {                 // EMIT_EDGES only
+  const uint32_t* len;            // sketch lengths (radio test)
+  rtc_cedge* edges;
+  unsigned long long cap;
+  unsigned long long* count;
+  int radio;                      // < 0: no size-ratio test
 };
 
 __device__ __forceinline__ unsigned long long lds_cas(unsigned long long* p, unsigned long long cmp, unsigned long long v) {
@@ -158,15 +177,18 @@ __device__ __forceinline__ void home_bucket_probe4(const T* keys, const T (&bq)[
 }
 
 // so: [(P+1)][n] slice offsets (so[p][g] = lower_bound(sketch g, bound[p])), so[0]=0, so[P]=len.
-template <typename T, int NPL>
+// tcols covers the column range [tc0, tc0 + tnc): element e of column c's slice in partition p sits at
+// tcols[tbase[p] + e*tnc + (c - tc0)].
+template <typename T, int NPL, int EMIT>
 __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ hashes,
                                                         const uint64_t* __restrict__ start,
                                                         const T* __restrict__ tcols,          // transposed column slices
                                                         const uint64_t* __restrict__ tbase,   // [P] element offsets
                                                         const uint32_t* __restrict__ so, int P, uint32_t n,
+                                                        uint32_t tc0, uint32_t tnc,
                                                         uint32_t row0, uint32_t row1, uint32_t col0,
                                                         uint32_t col1, uint32_t* __restrict__ out, uint64_t ld,
-                                                        int lower_only) {
+                                                        int lower_only, EdgeSink sink) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* keys = reinterpret_cast<T*>(smem);
   unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem + (size_t)SLOTS * sizeof(T));
@@ -244,17 +266,17 @@ __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ ha
       // the row masks are fetched only by waves in which some lane hit, and the rare key whose home
       // bucket is full without a match (or that equals the EMPTY marker) takes the looping lookup.
       {
-        const T* tp = tcols + tbase[p] + c;
+        const T* tp = tcols + tbase[p] + (c - tc0);
         const uint32_t mylen = chi - clo;
         T nq[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) nq[j] = (j < (int)mylen) ? tp[(size_t)j * n] : (T)0;
+        for (int j = 0; j < 4; j++) nq[j] = (j < (int)mylen) ? tp[(size_t)j * tnc] : (T)0;
         for (uint32_t e = 0; e < mylen; e += 4) {
           T bq[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) bq[j] = nq[j];
 #pragma unroll
-          for (int j = 0; j < 4; j++) nq[j] = (e + 4 + j < mylen) ? tp[(size_t)(e + 4 + j) * n] : (T)0;
+          for (int j = 0; j < 4; j++) nq[j] = (e + 4 + j < mylen) ? tp[(size_t)(e + 4 + j) * tnc] : (T)0;
           uint32_t slot[4];
           bool hit[4], slow[4];
           home_bucket_probe4<T>(keys, bq, e, mylen, slot, hit, slow);
@@ -288,13 +310,72 @@ __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ ha
     clo = chi;
   }
 
-  // ---- unpack the 64 bit-sliced counters of this lane's column ----
-  for (uint32_t r = 0; r < nrows; r++) {
-    uint32_t cnt = 0;
+  if constexpr (EMIT == EMIT_DENSE) {
+    // ---- unpack the 64 bit-sliced counters of this lane's column ----
+    for (uint32_t r = 0; r < nrows; r++) {
+      uint32_t cnt = 0;
 #pragma unroll
-    for (int k = 0; k < NPL; k++) cnt |= (uint32_t)((planes[k] >> r) & 1ULL) << k;
-    const uint32_t row = rb0 + r;
-    if (col_active && (!lower_only || c < row)) out[(uint64_t)(row - row0) * ld + (c - col0)] = cnt;
+      for (int k = 0; k < NPL; k++) cnt |= (uint32_t)((planes[k] >> r) & 1ULL) << k;
+      const uint32_t row = rb0 + r;
+      if (col_active && (!lower_only || c < row)) out[(uint64_t)(row - row0) * ld + (c - col0)] = cnt;
+    }
+  } else {
+    // ---- candidate edges: filter the 64 counters as bit masks, reserve a range, write survivors ----
+    // bit r of `keep`: pair (row rb0 + r, column c) becomes an EdgeInfo in the reference
+    // (src/MST.cpp:1468-1487): common > 0 (which implies both sketches non-empty), j < i, and
+    // max(|A|,|B|) <= radio * min(|A|,|B|).
+    if (tid < ROWS) sh->rlen[tid] = tid < (int)nrows ? sink.len[rb0 + tid] : 0;
+    unsigned long long keep = 0ULL;
+#pragma unroll
+    for (int k = 0; k < NPL; k++) keep |= planes[k];
+    if (nrows < (uint32_t)ROWS) keep &= (1ULL << nrows) - 1ULL;
+    if (!col_active) keep = 0ULL;
+    if (lower_only && c >= rb0) {  // rows rb0 + r > c  <=>  r > c - rb0
+      const uint32_t d = c - rb0 + 1;
+      keep = d >= 64 ? 0ULL : (keep & (~0ULL << d));
+    }
+    __syncthreads();  // rlen visible
+    if (sink.radio >= 0 && keep) {
+      const uint32_t s1 = sink.len[c];
+      unsigned long long m = keep;
+      while (m) {
+        const int r = __builtin_ctzll(m);
+        m &= m - 1ULL;
+        const uint32_t s0 = sh->rlen[r];
+        const uint32_t mn = s0 < s1 ? s0 : s1, mx = s0 > s1 ? s0 : s1;
+        if ((uint64_t)mx > (uint64_t)(uint32_t)sink.radio * (uint64_t)mn) keep &= ~(1ULL << r);  // src/MST.cpp:1484
+      }
+    }
+    const uint32_t mine = (uint32_t)__popcll(keep);
+    // inclusive prefix sum within the wave
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+      if (lane >= (uint32_t)o) incl += v;
+    }
+    if (lane == 63) sh->wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < TW / 64; w++) {
+      const uint32_t wt = sh->wave_tot[w];
+      if ((uint32_t)w < wave) wbase += wt;
+      total += wt;
+    }
+    if (total == 0) return;  // workgroup-uniform
+    if (tid == 0) sh->gbase = atomicAdd(sink.count, (unsigned long long)total);
+    __syncthreads();
+    unsigned long long idx = sh->gbase + wbase + (incl - mine);
+    while (keep) {
+      const int r = __builtin_ctzll(keep);
+      keep &= keep - 1ULL;
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int k = 0; k < NPL; k++) cnt |= (uint32_t)((planes[k] >> r) & 1ULL) << k;
+      if (idx < sink.cap) sink.edges[idx] = rtc_cedge{rb0 + (uint32_t)r, c, cnt};
+      idx++;
+    }
   }
 }
 
@@ -319,29 +400,41 @@ __global__ void slice_offsets_kernel(const T* __restrict__ hashes, const uint64_
   so[(size_t)p * n + g] = r;
 }
 
-// per-partition maximum slice length (sizes the transposed copy) -- pmax[P]; grid.y = partition
+// per-partition maximum slice length: pmax[p] over the columns [c0, c1) (sizes the transposed copy),
+// amax[0] over every sketch and partition (a single slice must fit one table build); grid.y = partition
 __global__ __launch_bounds__(256) void partition_max_kernel(const uint32_t* __restrict__ so, int P, uint32_t n,
+                                                            uint32_t c0, uint32_t c1, uint32_t* __restrict__ amax,
                                                             uint32_t* __restrict__ pmax) {
   const uint32_t p = blockIdx.y;
-  uint32_t v = 0;
-  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x)
-    v = max(v, so[(size_t)(p + 1) * n + g] - so[(size_t)p * n + g]);
-  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
-  if ((threadIdx.x & 63) == 0 && v) atomicMax(&pmax[p], v);
+  uint32_t v = 0, a = 0;
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
+    const uint32_t d = so[(size_t)(p + 1) * n + g] - so[(size_t)p * n + g];
+    a = max(a, d);
+    if (g >= c0 && g < c1) v = max(v, d);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    v = max(v, (uint32_t)__shfl_xor((int)v, o));
+    a = max(a, (uint32_t)__shfl_xor((int)a, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (v) atomicMax(&pmax[p], v);
+    if (a) atomicMax(amax, a);
+  }
 }
 
-// tcols[tbase[p] + e*n + c] = element e of column c's slice in partition p
+// tcols[tbase[p] + e*tnc + (c - tc0)] = element e of column c's slice in partition p
 template <typename T>
 __global__ void transpose_slices_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
                                         const uint32_t* __restrict__ so, const uint64_t* __restrict__ tbase, int P,
-                                        uint32_t n, T* __restrict__ tcols) {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+                                        uint32_t n, uint32_t tc0, uint32_t tnc, T* __restrict__ tcols) {
+  const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t p = blockIdx.y;
-  if (c >= n) return;
+  if (ci >= tnc) return;
+  const uint32_t c = tc0 + ci;
   const uint32_t lo = so[(size_t)p * n + c], hi = so[(size_t)(p + 1) * n + c];
   const T* src = hashes + start[c] + lo;
-  T* dst = tcols + tbase[p] + c;
-  for (uint32_t e = 0; e < hi - lo; e++) dst[(size_t)e * n] = src[e];
+  T* dst = tcols + tbase[p] + ci;
+  for (uint32_t e = 0; e < hi - lo; e++) dst[(size_t)e * tnc] = src[e];
 }
 
 // planning inputs in one launch: sum / max of the sketch lengths and SAMPLE_PER evenly spaced
@@ -377,25 +470,51 @@ __global__ __launch_bounds__(256) void plan_stats_kernel(const T* __restrict__ h
   }
 }
 
-template <typename T, int NPL>
-int launch_tiled(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const T* d_tcols, const uint64_t* d_tbase,
-                 const uint32_t* d_so, int P, uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1,
-                 uint32_t* d_common, uint64_t ld, int lower_only) {
+// Everything a launch needs besides the tile itself: partition bounds -> slice offsets of every
+// sketch, and the transposed copy of the column range [tc0, tc0 + tnc).  Lives in the context's
+// scratch slots 1 (offsets) and 4 (transposed copy) until the next plan is built.
+struct PairPlan {
+  int P = 0, npl = 0;
+  uint32_t n = 0, tc0 = 0, tnc = 0;
+  const uint32_t* d_so = nullptr;
+  const uint64_t* d_tbase = nullptr;
+  const void* d_tcols = nullptr;
+};
+
+template <typename T, int NPL, int EMIT>
+int launch_tiled(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const PairPlan& pl, uint32_t row0,
+                 uint32_t row1, uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld, int lower_only,
+                 const EdgeSink& sink) {
   const size_t lds = (size_t)SLOTS * (sizeof(T) + 8) + sizeof(TileShared);
-  auto kern = pair_tiled_kernel<T, NPL>;
+  auto kern = pair_tiled_kernel<T, NPL, EMIT>;
   RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((row1 - row0 + ROWS - 1) / ROWS, (col1 - col0 + TW - 1) / TW);
-  hipLaunchKernelGGL(kern, grid, dim3(TW), lds, ctx->stream, d_hashes, d_start, d_tcols, d_tbase, d_so, P, n, row0, row1,
-                     col0, col1, d_common, ld, lower_only);
+  hipLaunchKernelGGL(kern, grid, dim3(TW), lds, ctx->stream, d_hashes, d_start, (const T*)pl.d_tcols, pl.d_tbase, pl.d_so,
+                     pl.P, pl.n, pl.tc0, pl.tnc, row0, row1, col0, col1, d_common, ld, lower_only, sink);
   RTC_CHECK_LAUNCH(ctx);
   return RTC_OK;
 }
 
+template <typename T, int EMIT>
+int run_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const PairPlan& pl, uint32_t row0, uint32_t row1,
+             uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld, int lower_only, const EdgeSink& sink) {
+#define LT(NPLV) launch_tiled<T, NPLV, EMIT>(ctx, d_hashes, d_start, pl, row0, row1, col0, col1, d_common, ld, lower_only, sink)
+  if (pl.npl <= 10) return LT(10);
+  if (pl.npl <= 13) return LT(13);
+  if (pl.npl <= 16) return LT(16);
+  return LT(20);
+#undef LT
+}
+
+// Builds the plan for columns [tc0, tc1).  *ok = 0 (and RTC_OK) when the tiled scheme cannot or should
+// not take the input: counters too wide, a slice that fits no table, or a transposed copy beyond the
+// memory budget (one huge sketch among many small ones inflates every partition's maximum) -- the
+// caller then runs the per-pair merge kernel, which takes anything.
 template <typename T>
-int tiled_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const uint32_t* d_len, uint32_t n,
-               uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld,
-               int lower_only, int* handled) {
-  *handled = 0;
+int build_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const uint32_t* d_len, uint32_t n,
+               uint32_t tc0, uint32_t tc1, PairPlan* pl, int* ok) {
+  *ok = 0;
+  if (n == 0 || tc1 <= tc0) return RTC_OK;
   // ---- planning inputs: one kernel, one small read-back ----
   void* wsp = nullptr;
   const size_t bsamp = (size_t)SAMPLE_SK * SAMPLE_PER * sizeof(T);
@@ -425,6 +544,15 @@ int tiled_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
                         (const T*)((const char*)hpin + sizeof(PlanStats) + 8) + nsamp);
   std::sort(sample.begin(), sample.end());
   T* h_bounds_pin = (T*)((char*)hpin + sizeof(PlanStats) + 8 + bsamp + 64 - ((sizeof(PlanStats) + 8 + bsamp + 64) % 8));
+  const uint32_t tnc = tc1 - tc0;
+
+  // Memory budget of the transposed copy: sum_p(pmax[p]) * tnc elements.  With even lengths it is
+  // ~1.8x the hashes themselves; it is allowed 16x (or 1 GiB) and never more than half of the free HBM.
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+  uint64_t budget = std::max<uint64_t>((uint64_t)1 << 30, 16ull * tot * sizeof(T));
+  budget = std::min<uint64_t>(budget, (uint64_t)(free_b + ctx->ws_bytes[4]) / 2);
+  if (const char* e = getenv("RTC_PAIR_TCOLS_BUDGET")) budget = strtoull(e, nullptr, 10);  // tests of the fallback
 
   for (int attempt = 0; attempt < 3; attempt++) {
     std::vector<T> bounds(P + 1);
@@ -437,7 +565,7 @@ int tiled_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
     RTC_TRY(rtc_ws(ctx, 1, bso + bb + 64 + (size_t)(P + 1) * 4, &ws));
     uint32_t* d_so = (uint32_t*)ws;
     T* d_bounds = (T*)((char*)ws + bso);
-    uint32_t* d_max = (uint32_t*)((char*)ws + bso + bb + (8 - bb % 8) % 8);  // [0] = max slice, [1..P] = per-partition max
+    uint32_t* d_max = (uint32_t*)((char*)ws + bso + bb + (8 - bb % 8) % 8);  // [0] = max slice of any sketch, [1..P] = per-partition max over the columns
     uint32_t* d_pmax = d_max + 1;
     memcpy(h_bounds_pin, bounds.data(), bb);
     RTC_HIP(ctx, hipMemcpyAsync(d_bounds, h_bounds_pin, bb, hipMemcpyHostToDevice, ctx->stream));
@@ -447,45 +575,72 @@ int tiled_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
                        d_hashes, d_start, d_len, d_bounds, P, n, d_so);
     RTC_CHECK_LAUNCH(ctx);
     hipLaunchKernelGGL(partition_max_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 64), (uint32_t)P), dim3(256), 0,
-                       ctx->stream, d_so, P, n, d_pmax);
+                       ctx->stream, d_so, P, n, tc0, tc1, d_max, d_pmax);
     RTC_CHECK_LAUNCH(ctx);
     std::vector<uint32_t> h_maxes(P + 1);
     RTC_HIP(ctx, hipMemcpyAsync(h_maxes.data(), d_max, (size_t)(P + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
     RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t* h_pmax = h_maxes.data() + 1;
-    uint32_t h_max = 0;  // largest single slice: must fit one table build
-    for (int p = 0; p < P; p++) h_max = std::max(h_max, h_pmax[p]);
-    if (h_max > KCAP_HARD) {  // some single slice does not fit a table: refine the partition
+    if (h_maxes[0] > KCAP_HARD) {  // some single slice does not fit a table: refine the partition
       if (P >= MAXP) return RTC_OK;
       P = std::min(MAXP, P * 4);
       continue;
     }
     // ---- partition-major transposed copy of the column slices ----
     std::vector<uint64_t> tbase(P + 1, 0);
-    for (int p = 0; p < P; p++) tbase[p + 1] = tbase[p] + (uint64_t)h_pmax[p] * n;
+    for (int p = 0; p < P; p++) tbase[p + 1] = tbase[p] + (uint64_t)h_pmax[p] * tnc;
+    if (tbase[P] * sizeof(T) > budget) return RTC_OK;  // merge path (skewed lengths)
     void* ws4 = nullptr;
     const size_t btb = (size_t)P * 8;
-    RTC_TRY(rtc_ws(ctx, 4, tbase[P] * sizeof(T) + btb + 256, &ws4));
+    {
+      const int st = rtc_ws(ctx, 4, tbase[P] * sizeof(T) + btb + 256, &ws4);
+      if (st == RTC_ERR_NOMEM) return RTC_OK;  // the merge kernel needs no scratch
+      if (st != RTC_OK) return st;
+    }
     uint64_t* d_tbase = (uint64_t*)ws4;
     T* d_tcols = (T*)((char*)ws4 + ((btb + 255) / 256) * 256);
     memcpy(h_bounds_pin, tbase.data(), btb);  // the bounds upload completed before the read-back above
     RTC_HIP(ctx, hipMemcpyAsync(d_tbase, h_bounds_pin, btb, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(transpose_slices_kernel<T>, dim3((n + 255) / 256, (uint32_t)P), dim3(256), 0, ctx->stream, d_hashes,
-                       d_start, d_so, d_tbase, P, n, d_tcols);
+    hipLaunchKernelGGL(transpose_slices_kernel<T>, dim3((tnc + 255) / 256, (uint32_t)P), dim3(256), 0, ctx->stream, d_hashes,
+                       d_start, d_so, d_tbase, P, n, tc0, tnc, d_tcols);
     RTC_CHECK_LAUNCH(ctx);
     int npl = 1;
     while ((1u << npl) <= lmax) npl++;
-    int st;
-#define LT(NPLV) launch_tiled<T, NPLV>(ctx, d_hashes, d_start, d_tcols, d_tbase, d_so, P, n, row0, row1, col0, col1, d_common, ld, lower_only)
-    if (npl <= 10) st = LT(10);
-    else if (npl <= 13) st = LT(13);
-    else if (npl <= 16) st = LT(16);
-    else st = LT(20);
-#undef LT
-    if (st != RTC_OK) return st;
-    *handled = 1;
+    pl->P = P; pl->npl = npl; pl->n = n; pl->tc0 = tc0; pl->tnc = tnc;
+    pl->d_so = d_so; pl->d_tbase = d_tbase; pl->d_tcols = d_tcols;
+    *ok = 1;
     return RTC_OK;
   }
+  return RTC_OK;
+}
+
+template <typename T>
+int tiled_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const uint32_t* d_len, uint32_t n,
+               uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld,
+               int lower_only, const EdgeSink* sink, int* handled) {
+  *handled = 0;
+  PairPlan pl;
+  int ok = 0;
+  auto& pc = ctx->pair_plan;
+  if (ctx->pair_plan_hold && ctx->pair_plan_valid && pc.hashes == (const void*)d_hashes && pc.start == (const void*)d_start &&
+      pc.len == (const void*)d_len && pc.n == n && pc.width == (int)sizeof(T) && pc.tc0 <= col0 && col1 <= pc.tc1) {
+    pl.P = pc.P; pl.npl = pc.npl; pl.n = n; pl.tc0 = pc.tc0; pl.tnc = pc.tc1 - pc.tc0;
+    pl.d_so = pc.d_so; pl.d_tbase = pc.d_tbase; pl.d_tcols = pc.d_tcols;
+    ok = 1;
+  } else {
+    const uint32_t tc1 = ctx->pair_plan_hold ? std::min(n, std::max(col1, ctx->pair_plan_tc1_hint)) : col1;
+    RTC_TRY(build_plan<T>(ctx, d_hashes, d_start, d_len, n, col0, tc1, &pl, &ok));
+    ctx->pair_plan_valid = 0;
+    if (ok && ctx->pair_plan_hold) {
+      pc.hashes = d_hashes; pc.start = d_start; pc.len = d_len; pc.n = n; pc.tc0 = col0; pc.tc1 = tc1;
+      pc.width = (int)sizeof(T); pc.P = pl.P; pc.npl = pl.npl; pc.d_so = pl.d_so; pc.d_tbase = pl.d_tbase; pc.d_tcols = pl.d_tcols;
+      ctx->pair_plan_valid = 1;
+    }
+  }
+  if (!ok) return RTC_OK;
+  if (sink) RTC_TRY((run_plan<T, EMIT_EDGES>(ctx, d_hashes, d_start, pl, row0, row1, col0, col1, nullptr, 0, lower_only, *sink)));
+  else RTC_TRY((run_plan<T, EMIT_DENSE>(ctx, d_hashes, d_start, pl, row0, row1, col0, col1, d_common, ld, lower_only, EdgeSink{})));
+  *handled = 1;
   return RTC_OK;
 }
 
@@ -498,7 +653,22 @@ int rtc_pair_common_tiled(rtc_ctx* ctx, const void* d_hashes, int width, const u
   if (n == 0) return RTC_OK;
   if (width == 8)
     return tiled_impl<uint64_t>(ctx, (const uint64_t*)d_hashes, d_start, d_len, n, row0, row1, col0, col1, d_common,
-                                ld, lower_only, handled);
+                                ld, lower_only, nullptr, handled);
   return tiled_impl<uint32_t>(ctx, (const uint32_t*)d_hashes, d_start, d_len, n, row0, row1, col0, col1, d_common, ld,
-                              lower_only, handled);
+                              lower_only, nullptr, handled);
+}
+
+// Candidate edges of the tile straight from the tiled kernel (no dense matrix).  radio < 0: no size test.
+int rtc_pair_edges_tiled(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+                         const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0,
+                         uint32_t col1, int lower_only, int radio, rtc_cedge* d_edges, uint64_t cap,
+                         uint64_t* d_count, int* handled) {
+  *handled = 0;
+  if (n == 0) return RTC_OK;
+  const EdgeSink sink{d_len, d_edges, (unsigned long long)cap, (unsigned long long*)d_count, radio};
+  if (width == 8)
+    return tiled_impl<uint64_t>(ctx, (const uint64_t*)d_hashes, d_start, d_len, n, row0, row1, col0, col1, nullptr, 0,
+                                lower_only, &sink, handled);
+  return tiled_impl<uint32_t>(ctx, (const uint32_t*)d_hashes, d_start, d_len, n, row0, row1, col0, col1, nullptr, 0,
+                              lower_only, &sink, handled);
 }

@@ -402,17 +402,6 @@ __global__ void max_u32_kernel(const uint32_t* __restrict__ a, uint32_t n, uint3
   if ((threadIdx.x & 63) == 0 && v) atomicMax(out_max, v);
 }
 
-// cached device copies of the filter structures (deterministic per half_subk/drlevel)
-struct KssdCache {
-  int half_subk = -1, drlevel = -1;
-  uint64_t checksum = 0;
-  void* d_index = nullptr;    // cuckoo table 1 then table 2 (u32 entries)
-  int ck1 = 13, ck2 = 13;
-  int32_t* d_table = nullptr;
-  size_t table_elems = 0;
-};
-KssdCache g_cache[8];  // per device ordinal
-
 uint64_t table_checksum(const int32_t* t, size_t n) {
   uint64_t h = 1469598103934665603ULL;
   const size_t step = n > 4096 ? n / 4096 : 1;
@@ -506,9 +495,9 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   if (((uintptr_t)d_seq & 15) != 0) return rtc_fail(ctx, RTC_ERR_ARG, "d_seq must be 16-byte aligned");
   RTC_HIP(ctx, hipSetDevice(ctx->device));
 
-  // ---- filter structures (cached per device) ----
+  // ---- filter structures (cached in the context: one host thread per context, freed with it) ----
   bool lds_index = dim_end <= MAX_LDS_KEEP;
-  KssdCache& kc = g_cache[ctx->device & 7];
+  auto& kc = ctx->kssd;
   const uint64_t cs = table_checksum(h_shuffled_dim, (size_t)dim_size);
   if (kc.half_subk != half_subk || kc.drlevel != drlevel || kc.checksum != cs) {
     RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));

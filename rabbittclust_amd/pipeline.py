@@ -1,10 +1,12 @@
 """clust-mst hot path as one step: sketch -> [all-gather] -> row-sharded all-pairs -> edges -> MSF.
 
 Mirrors clust_from_genomes -> compute_sketches -> compute_clusters of the reference
-(src/sub_command.cpp:2302-2315, :2858-2889, :2924-3053) from the sketching call down to the
-`vector<EdgeInfo> mst`.  Multi-GPU: one process per GPU; sketches are all-gathered once (RCCL),
-the strict lower triangle of the N x N pair space is split into contiguous row ranges of equal
-area, and every Boruvka round all-reduces (MIN) two u64 arrays (weight key, then edge id).
+(src/sub_command.cpp:2302-2315, :2858-2889, :2924-3053; --fast: :1934-1951, :1953-2152) from the
+sketching call down to the `vector<EdgeInfo> mst`.  Multi-GPU: one process per GPU; sketches are
+all-gathered once (RCCL) into the canonical order rank*n_local + i, the strict lower triangle of the
+N x N pair space is split into contiguous row ranges of equal cost, and every Boruvka round
+all-reduces (MIN) ONE u64 key array when all sketches have the same size (three small arrays
+otherwise); the union step runs on the device, identically on every rank.
 """
 import ctypes as C
 import math
@@ -33,89 +35,148 @@ def triangle_row_ranges(n, world, fixed_cols=0.0):
     return b
 
 
+class TorchComm:
+    """The collectives of the multi-GPU step over torch.distributed (backend "nccl" = RCCL over xGMI
+    on the GPUs, "gloo" in the CPU tests).  world == 1 without a process group: no-ops."""
+
+    def __init__(self, dist=None, rank=0, world=1):
+        self.dist, self.rank, self.world = dist, rank, world
+
+    @property
+    def active(self):
+        return self.dist is not None
+
+    def all_reduce_min(self, t):
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+
+    def all_reduce_max(self, t):
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+
+    def all_gather(self, out, inp, async_op=False):
+        return self.dist.all_gather_into_tensor(out, inp, async_op=async_op)
+
+
 class HipBoruvkaBackend:
     """Per-round primitives on this rank's candidate edges (device tensors, HIP kernels)."""
 
     def __init__(self, ctx, sk, edges, m, is_containment):
         self.ctx, self.sk, self.edges, self.m, self.ic = ctx, sk, edges, m, int(is_containment)
         self.device = ctx.device
+        n = sk.n
+        self.comp = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        self.succ = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        self.sel = torch.empty((max(n, 1), 3), dtype=torch.int32, device=self.device)
+        self.nsel = torch.zeros(2, dtype=torch.int64, device=self.device)
 
-    def minweight(self, comp, wkey):
+    def init(self):
+        c = self.ctx
+        c.check(c.lib.rtc_boruvka_init_dev(c.h, self.sk.n, _t_ptr(self.comp), _t_ptr(self.nsel)))
+
+    def minkey(self, s_fixed, key):
+        c = self.ctx
+        c.check(c.lib.rtc_boruvka_minkey_dev(c.h, _t_ptr(self.edges), self.m, _t_ptr(self.comp), self.sk.n,
+                                             int(s_fixed), _t_ptr(key)))
+
+    def minweight(self, wkey):
         c = self.ctx
         c.check(c.lib.rtc_boruvka_minweight_dev(c.h, _t_ptr(self.edges), self.m, _t_ptr(self.sk.len), self.ic,
-                                                _t_ptr(comp), self.sk.n, _t_ptr(wkey)))
+                                                _t_ptr(self.comp), self.sk.n, _t_ptr(wkey)))
 
-    def minedge(self, comp, wkey, ekey):
+    def minedge(self, wkey, ekey):
         c = self.ctx
         c.check(c.lib.rtc_boruvka_minedge_dev(c.h, _t_ptr(self.edges), self.m, _t_ptr(self.sk.len), self.ic,
-                                              _t_ptr(comp), self.sk.n, _t_ptr(wkey), _t_ptr(ekey)))
+                                              _t_ptr(self.comp), self.sk.n, _t_ptr(wkey), _t_ptr(ekey)))
 
-    def fetch(self, comp, ekey, ecommon):
+    def fetch(self, ekey, ecommon):
         c = self.ctx
-        c.check(c.lib.rtc_boruvka_fetch_dev(c.h, _t_ptr(self.edges), self.m, _t_ptr(comp), self.sk.n,
+        c.check(c.lib.rtc_boruvka_fetch_dev(c.h, _t_ptr(self.edges), self.m, _t_ptr(self.comp), self.sk.n,
                                             _t_ptr(ekey), _t_ptr(ecommon)))
 
+    def union(self, s_fixed, key, ecommon):
+        """Device union; returns the number of forest edges this round added (identical on every rank)."""
+        c = self.ctx
+        added = C.c_uint32(0)
+        c.check(c.lib.rtc_boruvka_union_dev(c.h, self.sk.n, int(s_fixed), _t_ptr(key),
+                                            _t_ptr(ecommon) if ecommon is not None else None, _t_ptr(self.comp),
+                                            _t_ptr(self.succ), _t_ptr(self.sel), _t_ptr(self.nsel), C.byref(added)))
+        return int(added.value)
 
-def boruvka_rounds(backend, n, lib, dist=None, world=1):
-    """Boruvka over row-sharded candidate edges.  Per round: local per-component minimum weight key
-    -> all-reduce(MIN) -> local minimum edge id among edges attaining it -> all-reduce(MIN) ->
-    owner publishes `common` -> all-reduce(MAX); then every rank applies the identical host-side
-    union (rtc_boruvka_merge_host).  `backend` supplies the three local primitives."""
+    def selected(self):
+        ns = int(self.nsel[0].item())
+        return np.ascontiguousarray(self.sel[:ns].cpu().numpy().view(np.uint32)).view(CEDGE_DT).reshape(-1)
+
+
+def boruvka_rounds(backend, n, comm=None, s_fixed=0):
+    """Boruvka over row-sharded candidate edges.  Fixed-size mode (s_fixed = the common sketch size,
+    fused key fits): per round ONE local pass -> ONE all-reduce(MIN) -> device union.  Otherwise:
+    minimum weight key -> all-reduce(MIN) -> minimum edge id among edges attaining it ->
+    all-reduce(MIN) -> owner publishes `common` -> all-reduce(MAX) -> device union.  Every rank
+    applies the identical union to the identical reduced arrays.  `backend` supplies the primitives."""
+    comm = comm or TorchComm()
     dev = backend.device
-    wkey = torch.empty(n, dtype=torch.int64, device=dev)
-    ekey = torch.empty(n, dtype=torch.int64, device=dev)
-    ecommon = torch.empty(n, dtype=torch.int32, device=dev)
-    comp_h = np.arange(n, dtype=np.uint32)
-    comp = torch.empty(n, dtype=torch.int32, device=dev)
-    sel = np.zeros(max(n, 1), dtype=CEDGE_DT)
-    nsel, added = C.c_uint64(0), C.c_uint64(0)
+    wkey = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    ekey = ecommon = None
+    if not s_fixed:
+        ekey = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        ecommon = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    backend.init()
     rounds = 0
     for _ in range(64):
-        comp.copy_(torch.from_numpy(comp_h.view(np.int32)))
-        backend.minweight(comp, wkey)
-        if world > 1:
-            dist.all_reduce(wkey, op=dist.ReduceOp.MIN)
-        backend.minedge(comp, wkey, ekey)
-        if world > 1:
-            dist.all_reduce(ekey, op=dist.ReduceOp.MIN)
-        backend.fetch(comp, ekey, ecommon)
-        if world > 1:
-            dist.all_reduce(ecommon, op=dist.ReduceOp.MAX)
-        ekey_h = np.ascontiguousarray(ekey.cpu().numpy().view(np.uint64))
-        ecommon_h = np.ascontiguousarray(ecommon.cpu().numpy().view(np.uint32))
-        st = lib.rtc_boruvka_merge_host(n, _np_ptr(ekey_h), _np_ptr(ecommon_h), _np_ptr(comp_h),
-                                        _np_ptr(sel), C.byref(nsel), C.byref(added))
-        if st != _lib.RTC_OK:
-            raise _lib.RtcError(st, "rtc_boruvka_merge_host")
+        if s_fixed:
+            backend.minkey(s_fixed, wkey)
+            comm.all_reduce_min(wkey)
+            added = backend.union(s_fixed, wkey, None)
+        else:
+            backend.minweight(wkey)
+            comm.all_reduce_min(wkey)
+            backend.minedge(wkey, ekey)
+            comm.all_reduce_min(ekey)
+            backend.fetch(ekey, ecommon)
+            comm.all_reduce_max(ecommon)
+            added = backend.union(0, ekey, ecommon)
         rounds += 1
-        if added.value == 0:
+        if added == 0:
             break
-    return sel[: nsel.value], rounds
+    return backend.selected(), rounds
 
 
 class MstPipeline:
+    """mode "minhash": rtc_sketch_minhash_dev; mode "kssd": rtc_sketch_kssd_dev (--fast, u32/u64 tuples)."""
+
     def __init__(self, ctx, k=21, sketch_size=1000, threshold=0.05, is_containment=False,
-                 dist=None, rank=0, world=1, row_chunk_bytes=2 << 30):
+                 dist=None, rank=0, world=1, mode="minhash", drlevel=3, shuffled_dim=None, comm=None):
         self.ctx, self.k, self.s, self.threshold = ctx, k, sketch_size, threshold
         self.is_containment = is_containment
-        self.dist, self.rank, self.world = dist, rank, world
-        self.row_chunk_bytes = row_chunk_bytes
+        self.comm = comm or TorchComm(dist, rank, world)
+        self.dist, self.rank, self.world = self.comm.dist, self.comm.rank, self.comm.world
+        self.mode, self.drlevel, self.shuffled_dim = mode, drlevel, shuffled_dim
         self.last_sketches = None
         self.last_mst = None
         self._edge_cap = 1 << 20
         self._edges = None
 
     # ---- pieces ---------------------------------------------------------------------------------
+    def _check_equal_counts(self, n_local):
+        """Every rank must bring the same number of genomes (the gathered order is rank*n_local + i)."""
+        t = torch.tensor([n_local, -n_local], dtype=torch.int64, device=self.ctx.device if self.ctx else "cpu")
+        self.comm.all_reduce_max(t)
+        if int(t[0].item()) != n_local or int(-t[1].item()) != n_local:
+            raise ValueError("multi-GPU step: ranks hold different genome counts "
+                             f"(this rank {n_local}, max {int(t[0].item())}, min {int(-t[1].item())})")
+
     def gather_sketches(self, sk):
-        """All ranks end up with every genome's sketch (strided layout, stride = sketch_size)."""
-        if self.world == 1:
+        """All ranks end up with every genome's sketch in canonical order (genome g of rank r at
+        r*n_local + g; strided layout)."""
+        if not self.comm.active:
             return sk
         n_local = sk.n
         stride = sk.hashes.numel() // max(n_local, 1)
         hashes = torch.empty(self.world * sk.hashes.numel(), dtype=sk.hashes.dtype, device=sk.hashes.device)
         lens = torch.empty(self.world * n_local, dtype=sk.len.dtype, device=sk.len.device)
-        self.dist.all_gather_into_tensor(hashes, sk.hashes.contiguous())
-        self.dist.all_gather_into_tensor(lens, sk.len.contiguous())
+        self.comm.all_gather(hashes, sk.hashes.contiguous())
+        self.comm.all_gather(lens, sk.len.contiguous())
         n = self.world * n_local
         start = torch.arange(n, dtype=torch.int64, device=sk.hashes.device) * stride
         return SketchSet(hashes, start, lens, sk.width, sk.k, sk.kind)
@@ -132,42 +193,55 @@ class MstPipeline:
             return max(slots, int(0.8 * n_local) // slots * slots)
         return (3 * n_local) // 4
 
-    def _gather_part(self, g_hashes, g_len, base, out_part, cnt_part):
-        """Start the all-gathers of one locally sketched row range into rows [base, base + W*m) of the
-        global buffers (rank r's rows land at base + r*m).  Returns the async work handles."""
-        m = out_part.shape[0]
-        rows = slice(base, base + self.world * m)
-        return [self.dist.all_gather_into_tensor(g_hashes[rows].view(-1), out_part.reshape(-1), async_op=True),
-                self.dist.all_gather_into_tensor(g_len[rows], cnt_part.contiguous(), async_op=True)]
-
-    def gather_parts(self, out, cnt, parts, k, kind="minhash", before_part=None):
-        """All-gather the local row ranges `parts` = [(a, b), ...] one after the other into the global
-        layout [part 0 of rank 0..W-1 | part 1 of rank 0..W-1 | ...]; `before_part(a, b)` (if given)
-        is called right before a part's collectives are started -- the multi-GPU step sketches the
-        part there, so the previous part's all-gather runs beside it.  Every rank passes the same
-        parts.  Returns (SketchSet over the global buffers, work handles to wait on)."""
+    def gather_parts(self, out, cnt, parts, k, kind="minhash", before_part=None, width=8):
+        """All-gather the local row ranges `parts` = [(a, b), ...] one after the other; `before_part(a, b)`
+        (if given) is called right before a part's collectives are started -- the multi-GPU step
+        sketches the part there, so the previous part's all-gather runs beside it.  Every rank passes
+        the same parts.  Returns (finish, works): wait on `works`, then finish() assembles the
+        canonical global order (genome g of rank r at r*n_local + g) and returns the SketchSet."""
         n_local, stride = out.shape
-        n = self.world * n_local
-        g_hashes = torch.empty((n, stride), dtype=out.dtype, device=out.device)
-        g_len = torch.empty(n, dtype=cnt.dtype, device=cnt.device)
-        works, base = [], 0
+        W = self.world
+        n = W * n_local
+        staged, works = [], []
         for a, b in parts:
             if b <= a:
                 continue
             if before_part is not None:
                 before_part(a, b)
-            works += self._gather_part(g_hashes, g_len, base, out[a:b], cnt[a:b])
-            base += self.world * (b - a)
-        start = torch.arange(n, dtype=torch.int64, device=out.device) * stride
-        return SketchSet(g_hashes.view(-1), start, g_len, 8, k, kind), works
+            m = b - a
+            th = torch.empty((W, m, stride), dtype=out.dtype, device=out.device)
+            tl = torch.empty((W, m), dtype=cnt.dtype, device=cnt.device)
+            works.append(self.comm.all_gather(th.view(-1), out[a:b].reshape(-1), async_op=True))
+            works.append(self.comm.all_gather(tl.view(-1), cnt[a:b].contiguous(), async_op=True))
+            staged.append((a, b, th, tl))
+
+        def finish():
+            if len(staged) == 1 and staged[0][0] == 0 and staged[0][1] == n_local:
+                g_hashes, g_len = staged[0][2].view(n, stride), staged[0][3].view(n)
+            else:
+                g_hashes = torch.empty((W, n_local, stride), dtype=out.dtype, device=out.device)
+                g_len = torch.empty((W, n_local), dtype=cnt.dtype, device=cnt.device)
+                for a, b, th, tl in staged:
+                    g_hashes[:, a:b] = th
+                    g_len[:, a:b] = tl
+                g_hashes, g_len = g_hashes.view(n, stride), g_len.view(n)
+            start = torch.arange(n, dtype=torch.int64, device=out.device) * stride
+            return SketchSet(g_hashes.view(-1), start, g_len, width, k, kind)
+
+        return finish, works
 
     def sketch_and_gather(self, seq, off, sizes=None):
-        """Multi-GPU sketch phase: sketch part A, start its all-gather, sketch part B, start its
+        """Multi-GPU MinHash sketch phase: sketch part A, start its all-gather, sketch part B, start its
         all-gather.  The collective of part A runs on RCCL's stream beside the sketch kernel of B."""
         ctx = self.ctx
         off = np.ascontiguousarray(off, dtype=np.uint64)
         n_local = len(off) - 1
+        self._check_equal_counts(n_local)
         stride = int(np.max(sizes)) if sizes is not None else int(self.s)
+        if sizes is not None:  # containment mode: per-rank sizes differ -> agree on the row stride
+            t = torch.tensor([stride], dtype=torch.int64, device=ctx.device)
+            self.comm.all_reduce_max(t)
+            stride = int(t.item())
         out = torch.empty((n_local, max(stride, 1)), dtype=torch.int64, device=ctx.device)
         cnt = torch.zeros(n_local, dtype=torch.int32, device=ctx.device)
         split = self.split_point(n_local, slots=3 * ctx.num_cu())
@@ -178,47 +252,61 @@ class MstPipeline:
 
         return self.gather_parts(out, cnt, [(0, split), (split, n_local)], self.k, before_part=sketch_part)
 
+    def sketch_kssd_and_gather(self, seq, off):
+        """Multi-GPU KSSD (--fast) sketch phase (sketchFileWithKssd on every rank's genomes, then one
+        all-gather): sketch sizes vary per genome, so the ranks first agree on the row stride."""
+        ctx = self.ctx
+        sk = ctx.sketch_kssd(seq, off, self.shuffled_dim, kmer_size=self.k, drlevel=self.drlevel)
+        if not self.comm.active:
+            return (lambda: sk), []
+        n_local = sk.n
+        self._check_equal_counts(n_local)
+        stride = sk.hashes.numel() // max(n_local, 1)
+        t = torch.tensor([stride], dtype=torch.int64, device=ctx.device)
+        self.comm.all_reduce_max(t)
+        gstride = int(t.item())
+        rows = sk.hashes.view(n_local, stride)
+        if gstride != stride:
+            wide = torch.zeros((n_local, gstride), dtype=rows.dtype, device=rows.device)
+            wide[:, :stride] = rows
+            rows = wide
+        return self.gather_parts(rows, sk.len.contiguous(), [(0, n_local)], sk.k, kind="kssd", width=sk.width)
+
     def candidate_edges(self, sk, row0, row1):
-        """Dense common counts for rows [row0,row1) x cols [0,row) in chunks, filtered into a
-        compact (i, j, common) list on the device."""
+        """Candidate (i, j, common) triples of rows [row0,row1) x cols [0,row): emitted by the pair
+        kernel itself (reference filters src/MST.cpp:1468-1487), compacted on the device."""
         ctx = self.ctx
         n = sk.n
         radio = mst_radio(self.threshold, sk.k)
         count = torch.zeros(1, dtype=torch.int64, device=ctx.device)
-        if self._edges is None or self._edges.shape[0] < self._edge_cap:
-            self._edges = torch.empty((self._edge_cap, 3), dtype=torch.int32, device=ctx.device)
-        rows_per = max(64, min(max(row1 - row0, 1), self.row_chunk_bytes // (max(n, 1) * 4)))
-        rows_per = ((rows_per + 63) // 64) * 64  # whole 64-row blocks, one launch when it fits
-        m = 0
         r0 = max(row0, 1)
-        common = None
-        while r0 < row1:
-            r1 = min(row1, r0 + rows_per)
-            c1 = r1 - 1
-            if common is None or common.shape[0] < (r1 - r0) or common.shape[1] < c1:
-                common = torch.empty((rows_per, max(n, 1)), dtype=torch.int32, device=ctx.device)
-            ctx.check(ctx.lib.rtc_pair_common_dev(ctx.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start),
-                                                  _t_ptr(sk.len), n, r0, r1, 0, c1, _t_ptr(common),
-                                                  common.stride(0), 1, 0))
-            while True:
-                ctx.check(ctx.lib.rtc_extract_edges_dev(ctx.h, _t_ptr(common), common.stride(0), r0, r1, 0, c1,
-                                                        _t_ptr(sk.len), radio, _t_ptr(self._edges),
-                                                        self._edges.shape[0], _t_ptr(count)))
-                cnt = int(count.item())
-                if cnt <= self._edges.shape[0]:
-                    m = cnt
-                    break
-                self._edge_cap = max(cnt + cnt // 2, self._edge_cap * 2)
-                bigger = torch.empty((self._edge_cap, 3), dtype=torch.int32, device=ctx.device)
-                bigger[:m] = self._edges[:m]
-                self._edges = bigger
-                count.fill_(m)
-            r0 = r1
-        return self._edges, m
+        while True:
+            if self._edges is None or self._edges.shape[0] < self._edge_cap:
+                self._edges = torch.empty((self._edge_cap, 3), dtype=torch.int32, device=ctx.device)
+            if r0 >= row1:
+                return self._edges, 0
+            count.zero_()
+            ctx.check(ctx.lib.rtc_pair_edges_dev(ctx.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start), _t_ptr(sk.len),
+                                                 n, r0, row1, 0, row1 - 1, radio, _t_ptr(self._edges),
+                                                 self._edges.shape[0], _t_ptr(count)))
+            cnt = int(count.item())
+            if cnt <= self._edges.shape[0]:
+                return self._edges, cnt
+            self._edge_cap = cnt + cnt // 8  # the kernel counted everything: exact need, one redo
+            self._edges = None
+
+    def fixed_size(self, sk):
+        """Common sketch size when every sketch has it and the fused Boruvka key fits, else 0."""
+        if sk.n < 2:
+            return 0
+        mm = torch.stack((sk.len.min(), sk.len.max())).cpu().numpy()
+        if int(mm[0]) != int(mm[1]) or int(mm[0]) <= 0:
+            return 0
+        return int(mm[0]) if self.ctx.lib.rtc_boruvka_key_bits(sk.n, int(mm[0])) else 0
 
     def boruvka(self, sk, edges, m):
         backend = HipBoruvkaBackend(self.ctx, sk, edges, m, self.is_containment)
-        return boruvka_rounds(backend, sk.n, self.ctx.lib, self.dist, self.world)
+        return boruvka_rounds(backend, sk.n, self.comm, self.fixed_size(sk))
 
     def finish(self, sk, sel):
         """(i, j, common) -> EdgeInfo records with the reference's double arithmetic, sorted."""
@@ -236,16 +324,20 @@ class MstPipeline:
         ctx = self.ctx
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
-        if self.dist is None:
-            sk = ctx.sketch_minhash(seq, off, k=self.k, size=self.s, sizes=sizes)
-            ev[1].record()
+        if self.mode == "kssd":
+            finish, works = self.sketch_kssd_and_gather(seq, off)
+        elif not self.comm.active:
+            sk0 = ctx.sketch_minhash(seq, off, k=self.k, size=self.s, sizes=sizes)
+            finish, works = (lambda: sk0), []
         else:
-            sk, works = self.sketch_and_gather(seq, off, sizes)
-            ev[1].record()  # local sketching done; what follows is the exposed rest of the all-gathers
-            for w in works:
-                w.wait()
+            finish, works = self.sketch_and_gather(seq, off, sizes)
+        ev[1].record()  # local sketching done; what follows is the exposed rest of the all-gathers
+        for w in works:
+            w.wait()
+        sk = finish()
         ev[2].record()
-        b = triangle_row_ranges(sk.n, self.world, fixed_cols=8.8 * self.s if self.world > 1 else 0.0)
+        fixed_cols = 8.8 * float(sk.len.float().mean().item()) if self.world > 1 else 0.0
+        b = triangle_row_ranges(sk.n, self.world, fixed_cols=fixed_cols)
         row0, row1 = b[self.rank], b[self.rank + 1]
         edges, m = self.candidate_edges(sk, row0, row1)
         ev[3].record()

@@ -89,6 +89,107 @@ def test_extract_edges_equals_oracle_candidates(ctx, oracle):
     got = sorted(map(tuple, got.tolist()))
     want = sorted((int(e["pre"]), int(e["suf"]), int(e["common"])) for e in cand)  # equal sizes -> radio passes
     assert got == want
+    # the fused form (pair kernel emits the edges itself) gives the same list
+    fused, m2 = ctx.pair_edges(sk, 0, n, 0, n, radio, cap=n * n)
+    assert sorted(map(tuple, fused[:m2].cpu().numpy().view(np.uint32).tolist())) == want
+    # a capacity that is too small: everything is still counted, nothing is written past the end
+    small, m3 = ctx.pair_edges(sk, 0, n, 0, n, radio, cap=7)
+    assert m3 == len(want) and set(map(tuple, small[:7].cpu().numpy().view(np.uint32).tolist())) <= set(want)
+    # row sub-range, merge-path fallback
+    import os
+    r0, r1 = 11, 29
+    sub = sorted(t for t in want if r0 <= t[0] < r1)
+    e1, m4 = ctx.pair_edges(sk, r0, r1, 0, r1 - 1, radio, cap=n * n)
+    assert sorted(map(tuple, e1[:m4].cpu().numpy().view(np.uint32).tolist())) == sub
+    os.environ["RTC_PAIR_FORCE_MERGE"] = "1"
+    try:
+        e2, m5 = ctx.pair_edges(sk, r0, r1, 0, r1 - 1, radio, cap=n * n)
+    finally:
+        del os.environ["RTC_PAIR_FORCE_MERGE"]
+    assert sorted(map(tuple, e2[:m5].cpu().numpy().view(np.uint32).tolist())) == sub
+
+
+def test_fused_edges_dense_stress_and_radio(ctx, oracle):
+    """Worst case for the edge emission: every pair of 1 500 mutually similar sketches is an edge
+    (1.1 M edges from 24 x 2 workgroups, every lane writes), plus variable sizes so that the radio
+    test (src/MST.cpp:1481-1484) actually rejects pairs."""
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(11)
+    core = np.unique(rng.integers(1, 1 << 62, size=400, dtype=np.uint64))
+    pool = np.unique(rng.integers(1, 1 << 62, size=6000, dtype=np.uint64))
+    sk = []
+    for g in range(1500):
+        extra = rng.choice(pool, size=int(rng.integers(0, 1400)), replace=False)
+        sk.append(np.unique(np.concatenate([core[: int(rng.integers(50, 400))], extra])))
+    dev = api.SketchSet.from_host(sk, ctx.device, k=21)
+    n = len(sk)
+    lens = np.array([len(x) for x in sk])
+    radio = api.mst_radio(0.05, 21)
+    dense = ctx.pair_common(dev, lower_only=True).cpu().numpy()
+    want = []
+    for i in range(n):
+        for j in range(i):
+            c = int(dense[i, j])
+            if c > 0 and max(lens[i], lens[j]) <= radio * min(lens[i], lens[j]):
+                want.append((i, j, c))
+    assert len(want) > 500_000 and len(want) < n * (n - 1) // 2  # dense, and the radio test rejected some
+    # spot check of the dense counts against the oracle
+    for (i, j) in ((5, 2), (700, 3), (1499, 1498), (900, 450)):
+        assert dense[i, j] == oracle.common(sk[i], sk[j])
+    for trial in range(3):  # atomics order varies run to run; the set must not
+        e, m = ctx.pair_edges(dev, 0, n, 0, n, radio, cap=n * n // 2)
+        assert m == len(want)
+        got = e[:m].cpu().numpy().view(np.uint32)
+        assert sorted(map(tuple, got.tolist())) == want
+    e, m = ctx.pair_edges(dev, 0, n, 0, n, -1, cap=n * n // 2)  # radio < 0: no size test (greedy)
+    assert m == int((np.tril(dense, -1) > 0).sum())
+
+
+def test_mst_dense_input_edge_budget_contraction(ctx, oracle):
+    """Dense inputs beyond the edge budget: rows are walked in chunks and the list is contracted to
+    its own spanning forest in between (RTC_EDGE_BUDGET shrinks the budget so 600 sketches trigger it);
+    the forest must equal the unbudgeted one."""
+    import os
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(13)
+    core = np.unique(rng.integers(1, 1 << 62, size=300, dtype=np.uint64))
+    pool = np.unique(rng.integers(1, 1 << 62, size=3000, dtype=np.uint64))
+    sk = [np.unique(np.concatenate([core[: int(rng.integers(100, 300))], rng.choice(pool, size=200, replace=False)]))
+          for _ in range(600)]
+    dev = api.SketchSet.from_host(sk, ctx.device, k=21)
+    flat, start, lens = oracle.to_csr(sk)
+    want = oracle.mst(flat, start, lens, 21, 0, 0.05, threads=1)
+    ref = ctx.mst(dev, 0.05)
+    os.environ["RTC_EDGE_BUDGET"] = "40000"
+    try:
+        got = ctx.mst(dev, 0.05)
+    finally:
+        del os.environ["RTC_EDGE_BUDGET"]
+    assert np.array_equal(got, ref)
+    assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
+
+
+def test_pair_tiled_falls_back_when_transposed_copy_exceeds_budget(ctx, oracle):
+    """one huge sketch among many small ones inflates the partition-major transposed copy.
+    With a tiny budget the tiled path must decline (handled = 0) and the merge kernel must give the
+    same counts; algo=2 (tiled only) must then report RTC_ERR_UNSUPPORTED."""
+    import os
+    from rabbittclust_amd import _lib, api
+    rng = np.random.default_rng(17)
+    sk = [np.unique(rng.integers(1, 1 << 40, size=60, dtype=np.uint64)) for _ in range(300)]
+    sk[7] = np.unique(rng.integers(1, 1 << 40, size=200_000, dtype=np.uint64))
+    dev = api.SketchSet.from_host(sk, ctx.device, k=21)
+    ref = ctx.pair_common(dev, algo=1).cpu().numpy()
+    os.environ["RTC_PAIR_TCOLS_BUDGET"] = "100000"
+    try:
+        got = ctx.pair_common(dev, algo=0).cpu().numpy()
+        with pytest.raises(_lib.RtcError) as ei:
+            ctx.pair_common(dev, algo=2)
+        assert ei.value.status == _lib.RTC_ERR_UNSUPPORTED
+    finally:
+        del os.environ["RTC_PAIR_TCOLS_BUDGET"]
+    assert np.array_equal(got, ref)
+    assert ref[7, 7] == len(sk[7]) and ref[3, 7] == oracle.common(sk[3], sk[7])
 
 
 def test_pipeline_step_single_gpu(ctx, oracle):
@@ -109,12 +210,18 @@ def test_pipeline_step_single_gpu(ctx, oracle):
 
 class _LockstepRanks:
     """`world` simulated ranks on one GPU: every rank owns the candidate edges of its triangle row
-    range; the three per-round primitives run on each rank's edge list and are reduced exactly as
-    the RCCL all-reduces would (MIN, MIN, MAX)."""
+    range and its own copy of the round state; the per-round key arrays are reduced exactly as the
+    RCCL all-reduces would (MIN, MIN, MAX) and every rank applies the device union to the reduced
+    arrays -- the states must stay identical."""
 
     def __init__(self, backends):
         self.b = backends
         self.device = backends[0].device
+        self.reduces = 0
+
+    def init(self):
+        for b in self.b:
+            b.init()
 
     def _reduce(self, call, out, op):
         import torch
@@ -124,32 +231,51 @@ class _LockstepRanks:
             call(b, tmp)
             acc = tmp if acc is None else op(acc, tmp)
         out.copy_(acc)
+        self.reduces += 1
 
-    def minweight(self, comp, wkey):
+    def minkey(self, s_fixed, key):
         import torch
-        self._reduce(lambda b, o: b.minweight(comp, o), wkey, torch.minimum)
+        self._reduce(lambda b, o: b.minkey(s_fixed, o), key, torch.minimum)
 
-    def minedge(self, comp, wkey, ekey):
+    def minweight(self, wkey):
         import torch
-        self._reduce(lambda b, o: b.minedge(comp, wkey, o), ekey, torch.minimum)
+        self._reduce(lambda b, o: b.minweight(o), wkey, torch.minimum)
 
-    def fetch(self, comp, ekey, ecommon):
+    def minedge(self, wkey, ekey):
         import torch
-        self._reduce(lambda b, o: b.fetch(comp, ekey, o), ecommon, torch.maximum)
+        self._reduce(lambda b, o: b.minedge(wkey, o), ekey, torch.minimum)
+
+    def fetch(self, ekey, ecommon):
+        import torch
+        self._reduce(lambda b, o: b.fetch(ekey, o), ecommon, torch.maximum)
+
+    def union(self, s_fixed, key, ecommon):
+        import torch
+        added = [b.union(s_fixed, key, ecommon) for b in self.b]
+        assert len(set(added)) == 1
+        for b in self.b[1:]:
+            assert torch.equal(b.comp, self.b[0].comp)
+        return added[0]
+
+    def selected(self):
+        return self.b[0].selected()
 
 
 @pytest.mark.parametrize("world", [2, 8])
-def test_row_sharded_boruvka_equals_single_rank(ctx, oracle, world):
+@pytest.mark.parametrize("fixed", [True, False])
+def test_row_sharded_boruvka_equals_single_rank(ctx, oracle, world, fixed):
     """The multi-GPU decomposition on real HIP kernels: triangle row ranges -> per-rank candidate
-    edges -> lockstep Boruvka rounds with MIN/MIN/MAX reductions -> same forest weights as the
-    oracle's Kruskal over all pairs."""
+    edges -> lockstep Boruvka rounds (fixed sizes: ONE reduction per round; else MIN/MIN/MAX) with
+    the device union -> same forest weights as the oracle's Kruskal over all pairs, and the SAME
+    forest edges as the single-rank run (canonical ids, total order on keys)."""
     import torch
     from rabbittclust_amd import api, pipeline
     desc = api.synth_family_descs(60, 7, global_seed=57)
     L = 60_000
     off = np.arange(len(desc) + 1, dtype=np.uint64) * L
     seq = ctx.synth_genomes(desc, off)
-    sk = ctx.sketch_minhash(seq, off, k=21, size=400)
+    sizes = None if fixed else np.array([300 + 20 * (g % 6) for g in range(len(desc))], dtype=np.uint32)
+    sk = ctx.sketch_minhash(seq, off, k=21, size=400, sizes=sizes)
     n = sk.n
     bounds = pipeline.triangle_row_ranges(n, world)
     assert bounds[0] == 0 and bounds[-1] == n
@@ -159,15 +285,22 @@ def test_row_sharded_boruvka_equals_single_rank(ctx, oracle, world):
         edges, m = pipe.candidate_edges(sk, bounds[r], bounds[r + 1])
         backends.append(pipeline.HipBoruvkaBackend(ctx, sk, edges[:m].clone(), m, False))
         total_edges += m
-    sel, rounds = pipeline.boruvka_rounds(_LockstepRanks(backends), n, ctx.lib)
     pipe = pipeline.MstPipeline(ctx, k=21, sketch_size=400, threshold=0.05)
+    s_fixed = pipe.fixed_size(sk)
+    assert (s_fixed == 400) == fixed
+    ranks = _LockstepRanks(backends)
+    sel, rounds = pipeline.boruvka_rounds(ranks, n, None, s_fixed)
+    assert ranks.reduces == (rounds if fixed else 3 * rounds)
     got = pipe.finish(sk, sel)
     flat, start, lens = oracle.to_csr(sk.to_host())
     want = oracle.mst(flat, start, lens, 21, 0, 0.05)
-    assert total_edges == len(oracle.candidate_pairs(flat, start, lens))  # equal sizes: the radio filter passes all
+    if fixed:
+        assert total_edges == len(oracle.candidate_pairs(flat, start, lens))  # equal sizes: the radio filter passes all
     assert len(got) == len(want) and rounds >= 2
     assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
     assert _partition(oracle.forest_clusters(got, 0.05, n)) == _partition(oracle.forest_clusters(want, 0.05, n))
+    single = ctx.mst(sk, 0.05)
+    assert np.array_equal(single, got), "sharded forest differs from the single-rank forest"
 
 
 class _LoopbackDist:
@@ -202,6 +335,7 @@ def test_pipeline_multi_gpu_code_path_on_one_gpu(ctx, oracle):
     ref.step(seq, off)
     want_sk = ref.last_sketches.to_host()
     pipe = pipeline.MstPipeline(ctx, k=21, sketch_size=600, threshold=0.05, dist=_LoopbackDist(), rank=0, world=1)
+    assert pipe.comm.active
     stats = pipe.step(seq, off)
     got_sk = pipe.last_sketches.to_host()
     assert len(got_sk) == len(want_sk) and all(np.array_equal(a, b) for a, b in zip(got_sk, want_sk))

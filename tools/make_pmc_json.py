@@ -3,7 +3,7 @@ per-launch counter sums plus the derived figures DESIGN.md quotes).  Usage: make
 import collections, csv, glob, json, os, sys
 root, tag = sys.argv[1], sys.argv[2]
 G, L, K, S = 10000, 5_000_000, 21, 1000   # bench.py defaults: the workload the passes ran on
-want = ("synth_kernel", "sketch_minhash_kernel", "transpose_slices_kernel", "pair_tiled_kernel", "extract_edges_kernel")
+want = ("synth_kernel", "sketch_minhash_kernel", "sketch_kssd_kernel", "transpose_slices_kernel", "pair_tiled_kernel")
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
 for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):

@@ -22,7 +22,7 @@ for it in range(3):
     torch.cuda.synchronize(); t0 = time.time()
     edges, m = pipe.candidate_edges(sk, b[rank], b[rank + 1])
     torch.cuda.synchronize(); t1 = time.time()
-    sel, rounds = pipeline.boruvka_rounds(pipeline.HipBoruvkaBackend(ctx, sk, edges, m, False), sk.n, ctx.lib)
+    sel, rounds = pipe.boruvka(sk, edges, m)
     torch.cuda.synchronize(); t2 = time.time()
     rows = b[rank + 1] - b[rank]
     pairs = (b[rank + 1] * (b[rank + 1] - 1) - b[rank] * (b[rank] - 1)) // 2
