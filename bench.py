@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("-s", type=int, default=1000)
     ap.add_argument("--drlevel", type=int, default=3)
     ap.add_argument("--threshold", type=float, default=0.05)
+    ap.add_argument("--comm", choices=("native", "torch"), default="native",
+                    help="N>1 collectives: the C ABI's own RCCL communicator (rtc_comm_*, what the C++ hosts use) "
+                         "or torch.distributed's; both are RCCL over xGMI")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-genomes", type=int, default=0, help="0 = 1024 (SURVEY 8d: >= 1k genomes)")
     ap.add_argument("--cpu-sample-sketches", type=int, default=8000)
@@ -182,9 +185,29 @@ def main():
     if mode == "kssd":
         from rabbittclust_amd import host
         shuffled = host.generate_shuffle_dim(6 if 6 - args.drlevel >= 2 else args.drlevel + 2)
+    comm, comm_kind = None, "none"
+    if dist is not None:
+        comm, comm_kind = pipeline.TorchComm(dist, rank, world), "torch.distributed nccl (RCCL)"
+        if args.comm == "native":
+            # the id is created on rank 0 and travels through the process group the launcher set up
+            ok, nat = 1, None
+            try:
+                uid = [api.Comm.unique_id(ctx.lib) if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                nat = api.Comm.init_rank(ctx, world, rank, uid[0])
+                t = torch.tensor([rank + 1], dtype=torch.int64, device=ctx.device)
+                nat.all_reduce(t, "max")
+                ok = int(int(t.item()) == world)
+            except Exception as e:  # stay on torch.distributed's communicator (also RCCL), say so
+                print(f"bench.py rank {rank}: native communicator unavailable ({e!r}); using torch.distributed", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int64, device=ctx.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks take the same path
+            if int(flag.item()) == 1:
+                comm, comm_kind = pipeline.NativeComm(nat), f"rtc_comm ({nat.backend}, C ABI)"
     pipe = pipeline.MstPipeline(ctx, k=args.k, sketch_size=args.s, threshold=args.threshold,
-                                dist=dist, rank=rank, world=world, mode=mode, drlevel=args.drlevel,
-                                shuffled_dim=shuffled)
+                                mode=mode, drlevel=args.drlevel, shuffled_dim=shuffled,
+                                comm=comm or pipeline.TorchComm(None, rank, world))
 
     def barrier():
         if dist is not None:
@@ -240,6 +263,7 @@ def main():
                                    f"sketch + all-pairs + MST at d={args.threshold}",
                        "genomes_per_gpu": n_local, "genome_length": length, "k": args.k,
                        "sketch_size": args.s if mode == "minhash" else round(avg_len, 1), "sharding": f"rows/{world}",
+                       "collectives": comm_kind,
                        "scaling_note": "weak in genomes: per-GPU genomes (and sketch work) fixed as N grows; the pair "
                                        "space is (N x genomes_per_gpu)^2/2, so pairs per GPU grow with N"},
             "sketch_gbp_per_sec": bases_total / (sk_ms * 1e-3) / 1e9,

@@ -30,6 +30,7 @@ typedef enum {
 typedef struct rtc_ctx rtc_ctx;
 
 /* ---- context ------------------------------------------------------------------------- */
+int rtc_device_count(void); /* visible GPUs (0 when there is none or the runtime fails) */
 int rtc_ctx_create(int device, rtc_ctx** out);
 void rtc_ctx_destroy(rtc_ctx* ctx);
 int rtc_ctx_set_stream(rtc_ctx* ctx, void* hip_stream); /* NULL = default stream */
@@ -186,6 +187,60 @@ int rtc_edges_to_mst_host(const rtc_cedge* h_sel, uint64_t m, const uint32_t* h_
 int rtc_mst(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
             const uint32_t* d_len, uint32_t n, int kmer_size, int is_containment, double threshold,
             rtc_edge* h_edges_out, uint64_t* h_n_edges);
+
+/* ---- multi-GPU: RCCL collectives over xGMI and the sharded clust-mst step ----------------- */
+/* The reference is one shared-memory process (OpenMP over 8-row blocks of the pair space,
+ * src/MST.cpp:1382, and over files, src/SketchInfo.cpp:878).  Here one rtc_comm per rtc_ctx (= per
+ * GPU); ranks are processes (one per GPU, the id travels through the launcher's own channel) or
+ * host threads of one process.  Every rank sketches its block of genomes; the sketches are gathered
+ * into the canonical order (genome g of rank r at row r*n_local + g); the strict lower triangle of
+ * the pair space is cut into contiguous row ranges of equal cost; each Boruvka round all-reduces
+ * (MIN) one u64 key per component (fixed sketch sizes) or three small arrays (variable sizes). */
+typedef struct rtc_comm rtc_comm;
+#define RTC_COMM_ID_BYTES 128
+int rtc_comm_unique_id(void* id_out /* RTC_COMM_ID_BYTES, created on one rank, passed to all */);
+int rtc_comm_init_rank(rtc_ctx* ctx, int nranks, int rank, const void* id, rtc_comm** out); /* collective */
+/* One process, one context per GPU, one host thread per context afterwards: communicators for
+ * ctxs[0..n).  Contexts that share a device (RCCL rejects duplicate GPUs) get an in-process
+ * exchange instead -- the way the protocol is exercised on a one-GPU box. */
+int rtc_comm_init_all(rtc_ctx** ctxs, int n, rtc_comm** comms_out);
+void rtc_comm_destroy(rtc_comm* comm);
+int rtc_comm_rank(const rtc_comm* comm);
+int rtc_comm_size(const rtc_comm* comm);
+const char* rtc_comm_backend(const rtc_comm* comm); /* "rccl" | "in-process" | "single" */
+/* in-place all-reduce on the context stream; dtype 0 = int64, 1 = uint32; op 0 = MIN, 1 = MAX */
+int rtc_comm_all_reduce(rtc_comm* comm, void* d_buf, size_t count, int dtype, int op);
+/* the same for up to 64 host values (agreeing on strides, counts); synchronises */
+int rtc_comm_all_reduce_host(rtc_comm* comm, int64_t* h_vals, size_t count, int op);
+/* Rows [a,b) of every rank's block of a canonical global buffer (rank r owns rows
+ * [r*n_local, (r+1)*n_local), row_bytes each) travel to all ranks, in place (grouped broadcasts).
+ * async != 0: on the communicator's side stream, ordered after the work enqueued so far on the
+ * context stream; rtc_comm_wait makes the context stream wait for it. */
+int rtc_comm_gather_rows(rtc_comm* comm, void* d_global, size_t row_bytes, uint32_t n_local, uint32_t a,
+                         uint32_t b, int async);
+int rtc_comm_wait(rtc_comm* comm);
+/* d_buf[0..bytes) of rank `root` replaces every other rank's copy (context stream) */
+int rtc_comm_broadcast(rtc_comm* comm, void* d_buf, size_t bytes, int root);
+/* h_bounds[world+1]: row ranges of the strict lower triangle of equal cost, row i costing
+ * (i + fixed_cols) columns (fixed_cols: the per-row-block table build, ~8.8 x mean sketch size). */
+int rtc_triangle_rows(uint32_t n, int world, double fixed_cols, uint32_t* h_bounds);
+/* sketchFiles' sketch loop (src/SketchInfo.cpp:878-976) for this rank's genomes, written into its
+ * block of the global buffers (d_out_global: size*n_local*stride u64, d_cnt_global: size*n_local)
+ * and gathered to all ranks; the gather of the first part overlaps the sketching of the rest. */
+int rtc_sketch_minhash_sharded(rtc_ctx* ctx, rtc_comm* comm, const uint8_t* d_seq, const uint64_t* h_off,
+                               uint32_t n_local, int k, uint32_t seed, const uint32_t* h_sizes, uint32_t size,
+                               uint64_t* d_out_global, uint32_t stride, uint32_t* d_cnt_global);
+typedef struct {
+  uint32_t row0, row1;  /* this rank's rows of the pair space */
+  uint64_t cand_edges;  /* candidate edges it produced */
+  uint32_t rounds, s_fixed, contractions, pad;
+  float pair_ms, mst_ms;
+} rtc_shard_stats;
+/* rtc_mst across the ranks of `comm` (sketches: the complete canonical set, on every rank).  Every
+ * rank receives the identical forest, identical to rtc_mst's on one GPU.  stats may be NULL. */
+int rtc_mst_sharded(rtc_ctx* ctx, rtc_comm* comm, const void* d_hashes, int width, const uint64_t* d_start,
+                    const uint32_t* d_len, uint32_t n, int kmer_size, int is_containment, double threshold,
+                    rtc_edge* h_edges_out, uint64_t* h_n_edges, rtc_shard_stats* stats);
 
 /* ---- greedy incremental clustering ------------------------------------------------------- */
 /* MinHashGreedyClusterWithInvertedIndex at -t 1 (src/greedy.cpp:986-1399) and

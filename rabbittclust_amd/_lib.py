@@ -30,6 +30,12 @@ class CEdge(C.Structure):
     _fields_ = [("i", C.c_uint32), ("j", C.c_uint32), ("common", C.c_uint32)]
 
 
+class ShardStats(C.Structure):
+    _fields_ = [("row0", C.c_uint32), ("row1", C.c_uint32), ("cand_edges", C.c_uint64), ("rounds", C.c_uint32),
+                ("s_fixed", C.c_uint32), ("contractions", C.c_uint32), ("pad", C.c_uint32),
+                ("pair_ms", C.c_float), ("mst_ms", C.c_float)]
+
+
 class Edge(C.Structure):
     _fields_ = [("preNode", C.c_int32), ("sufNode", C.c_int32), ("dist", C.c_double)]
 
@@ -37,6 +43,7 @@ class Edge(C.Structure):
 # every symbol include/rtclust.h declares, with its ctypes signature
 _vp, _u32, _u64, _i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
 SIGNATURES = {
+    "rtc_device_count": (_i, []),
     "rtc_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "rtc_ctx_destroy": (None, [_vp]),
     "rtc_ctx_set_stream": (_i, [_vp, _vp]),
@@ -70,6 +77,21 @@ SIGNATURES = {
     "rtc_boruvka_fetch_dev": (_i, [_vp, _vp, _u64, _vp, _u32, _vp, _vp]),
     "rtc_boruvka_merge_host": (_i, [_u32, _vp, _vp, _vp, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rtc_edges_to_mst_host": (_i, [_vp, _u64, _vp, _i, _i, _vp]),
+    "rtc_comm_unique_id": (_i, [_vp]),
+    "rtc_comm_init_rank": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
+    "rtc_comm_init_all": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp)]),
+    "rtc_comm_destroy": (None, [_vp]),
+    "rtc_comm_rank": (_i, [_vp]),
+    "rtc_comm_size": (_i, [_vp]),
+    "rtc_comm_backend": (C.c_char_p, [_vp]),
+    "rtc_comm_all_reduce": (_i, [_vp, _vp, C.c_size_t, _i, _i]),
+    "rtc_comm_all_reduce_host": (_i, [_vp, _vp, C.c_size_t, _i]),
+    "rtc_comm_gather_rows": (_i, [_vp, _vp, C.c_size_t, _u32, _u32, _u32, _i]),
+    "rtc_comm_wait": (_i, [_vp]),
+    "rtc_comm_broadcast": (_i, [_vp, _vp, C.c_size_t, _i]),
+    "rtc_triangle_rows": (_i, [_u32, _i, C.c_double, _vp]),
+    "rtc_sketch_minhash_sharded": (_i, [_vp, _vp, _vp, _vp, _u32, _i, _u32, _vp, _u32, _vp, _u32, _vp]),
+    "rtc_mst_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64), _vp]),
     "rtc_mst": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64)]),
     "rtc_greedy": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _vp, _i, _i, _i, C.c_double, _vp,
                         C.POINTER(_u32)]),

@@ -229,6 +229,38 @@ class Context:
                                     n, sk.k, int(is_containment), float(threshold), _np_ptr(out), C.byref(m)))
         return out[:m.value].copy()
 
+    def sketch_minhash_sharded(self, comm, seq, off, k=21, size=1000, sizes=None, stride=None, seed=42):
+        """Multi-GPU sketch phase behind the C ABI: this rank's genomes into its block of the canonical
+        global buffers, gathered to every rank (two parts, the first gather overlapping the second
+        sketch launch).  Returns the global SketchSet (comm.size * n_local genomes)."""
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n_local = len(off) - 1
+        if sizes is not None:
+            sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        if stride is None:
+            stride = int(sizes.max()) if sizes is not None else int(size)
+            if sizes is not None and comm.size > 1:  # per-rank maxima differ: agree
+                stride = int(comm.all_reduce_host([stride], "max")[0])
+        n = comm.size * n_local
+        out = torch.empty((max(n, 1), max(stride, 1)), dtype=torch.int64, device=self.device)
+        cnt = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+        self.check(self.lib.rtc_sketch_minhash_sharded(
+            self.h, comm.h, _t_ptr(seq), _np_ptr(off), n_local, k, seed,
+            _np_ptr(sizes) if sizes is not None else None, int(size), _t_ptr(out), max(stride, 1), _t_ptr(cnt)))
+        start = torch.arange(n, dtype=torch.int64, device=self.device) * max(stride, 1)
+        return SketchSet(out.view(-1), start, cnt[:n], 8, k, "minhash")
+
+    def mst_sharded(self, comm, sk, threshold, is_containment=False):
+        """rtc_mst across the ranks of `comm`; returns (edge.mst records, ShardStats)."""
+        n = sk.n
+        out = np.zeros(max(n, 1), dtype=EDGE_DT)
+        m = C.c_uint64()
+        stats = _lib.ShardStats()
+        self.check(self.lib.rtc_mst_sharded(self.h, comm.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start), _t_ptr(sk.len),
+                                            n, sk.k, int(is_containment), float(threshold), _np_ptr(out), C.byref(m),
+                                            C.byref(stats)))
+        return out[:m.value].copy(), stats
+
     def greedy(self, sk, threshold, size_cfg=None, is_containment=False):
         n = sk.n
         rep = np.zeros(max(n, 1), dtype=np.int32)
@@ -241,6 +273,64 @@ class Context:
                                        int(is_containment), int(sk.kind == "kssd"), float(threshold),
                                        _np_ptr(rep), C.byref(nc)))
         return int(nc.value), rep[:n].copy()
+
+
+class Comm:
+    """One rtc_comm (RCCL communicator of one GPU / context).  Ranks are processes (init_rank, the id
+    from rank 0 travels through the launcher's channel, e.g. torch.distributed) or threads of one
+    process (init_all)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+        lib = ctx.lib
+        self.rank, self.size = lib.rtc_comm_rank(handle), lib.rtc_comm_size(handle)
+        self.backend = lib.rtc_comm_backend(handle).decode()
+
+    @staticmethod
+    def unique_id(lib=None):
+        lib = lib or _lib.load()
+        buf = (C.c_char * 128)()
+        st = lib.rtc_comm_unique_id(buf)
+        if st != _lib.RTC_OK:
+            raise RtcError(st, "rtc_comm_unique_id: " + lib.rtc_last_error(None).decode(errors="replace"))
+        return bytes(buf)
+
+    @staticmethod
+    def init_rank(ctx, nranks, rank, uid):
+        h = C.c_void_p()
+        buf = (C.c_char * 128).from_buffer_copy(uid) if uid is not None else None
+        ctx.check(ctx.lib.rtc_comm_init_rank(ctx.h, nranks, rank, buf, C.byref(h)))
+        return Comm(ctx, h)
+
+    @staticmethod
+    def init_all(ctxs):
+        n = len(ctxs)
+        hs = (C.c_void_p * n)(*[c.h for c in ctxs])
+        out = (C.c_void_p * n)()
+        st = ctxs[0].lib.rtc_comm_init_all(hs, n, out)
+        ctxs[0].check(st)
+        return [Comm(c, C.c_void_p(out[i])) for i, c in enumerate(ctxs)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.rtc_comm_destroy(self.h)
+            self.h = None
+
+    def all_reduce(self, t, op="min"):
+        dtype = {torch.int64: 0, torch.int32: 1}[t.dtype]
+        self.ctx.check(self.ctx.lib.rtc_comm_all_reduce(self.h, _t_ptr(t), t.numel(), dtype, 0 if op == "min" else 1))
+
+    def all_reduce_host(self, vals, op="max"):
+        a = np.ascontiguousarray(vals, dtype=np.int64)
+        self.ctx.check(self.ctx.lib.rtc_comm_all_reduce_host(self.h, _np_ptr(a), len(a), 0 if op == "min" else 1))
+        return a
+
+    def gather_rows(self, t_global, n_local, a, b, async_=False):
+        row_bytes = t_global.numel() * t_global.element_size() // (self.size * n_local)
+        self.ctx.check(self.ctx.lib.rtc_comm_gather_rows(self.h, _t_ptr(t_global), row_bytes, n_local, a, b, int(async_)))
+
+    def wait(self):
+        self.ctx.check(self.ctx.lib.rtc_comm_wait(self.h))
 
 
 # ---- host-side arithmetic shared by CLI-equivalent flows (reference expression order) -------------

@@ -1,0 +1,400 @@
+// rtc_comm.hip -- the multi-GPU side of the path behind the C ABI: RCCL collectives over xGMI and
+// the sharded clust-mst step built on them.
+//
+// The reference is a single shared-memory process (OpenMP over 8-row blocks of the pair space,
+// src/MST.cpp:1382; over files, src/SketchInfo.cpp:878).  Here every GPU ("rank") sketches its own
+// block of genomes, the sketches are gathered once into the canonical order (genome g of rank r at
+// row r*n_local + g) and the strict lower triangle of the N x N pair space is cut into contiguous
+// row ranges of equal cost.  Two kinds of exchange exist and nothing else:
+//   * gather of sketch rows: W grouped ncclBroadcast calls, each in place on the owner's rows of the
+//     global buffer (an all-gather with arbitrary row ranges, so the first part of every rank's
+//     sketches travels on a side stream while the second part is still being sketched);
+//   * per Boruvka round one ncclAllReduce(MIN) over a u64[n] key array (fixed sketch sizes), or
+//     MIN, MIN, MAX over three small arrays (variable sizes).  The union step runs on every rank's
+//     device on the identical reduced arrays.
+// One rtc_comm belongs to one rtc_ctx (one GPU).  Ranks may be processes (bench.py under
+// torch.distributed.run: rtc_comm_init_rank with an id the caller distributed) or host threads of
+// one process (clust-mst: rtc_comm_init_all).  When two contexts of one process sit on the SAME
+// device -- RCCL refuses duplicate GPUs -- an in-process exchange (host barrier + device copies)
+// stands in, which is how the protocol is tested on a one-GPU box.
+#include <math.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <numeric>
+#include <vector>
+
+#include "rtc_internal.h"
+
+namespace {
+
+struct LocalGroup {  // in-process exchange for contexts sharing a device
+  std::mutex m;
+  std::condition_variable cv;
+  int n = 0, arrived = 0;
+  uint64_t gen = 0;
+  std::vector<const void*> ptr;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    const uint64_t g = gen;
+    if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); }
+    else cv.wait(lk, [&] { return gen != g; });
+  }
+};
+
+}  // namespace
+
+struct rtc_comm {
+  rtc_ctx* ctx = nullptr;
+  int rank = 0, size = 1;
+  ncclComm_t nccl = nullptr;
+  std::shared_ptr<LocalGroup> local;
+  hipStream_t side = nullptr;      // gathers overlap compute on the context stream
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  bool side_busy = false;
+};
+
+#define RTC_NCCL(ctx, call)                                                                     \
+  do {                                                                                          \
+    ncclResult_t r__ = (call);                                                                  \
+    if (r__ != ncclSuccess)                                                                     \
+      return rtc_fail((ctx), RTC_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r__)); \
+  } while (0)
+
+namespace {
+
+template <typename T>
+__global__ void local_reduce_kernel(const void* const* __restrict__ srcs, int nsrc, size_t count, int op, T* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    T v = ((const T*)srcs[0])[i];
+    for (int s = 1; s < nsrc; s++) {
+      const T w = ((const T*)srcs[s])[i];
+      v = op == 0 ? (w < v ? w : v) : (w > v ? w : v);
+    }
+    dst[i] = v;
+  }
+}
+
+int comm_finish_init(rtc_comm* c) {
+  rtc_ctx* ctx = c->ctx;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  RTC_HIP(ctx, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  RTC_HIP(ctx, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+  RTC_HIP(ctx, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  return RTC_OK;
+}
+
+// dtype 0 = int64, 1 = uint32; op 0 = MIN, 1 = MAX; on `stream`
+int comm_all_reduce_on(rtc_comm* c, void* d_buf, size_t count, int dtype, int op, hipStream_t stream) {
+  rtc_ctx* ctx = c->ctx;
+  if ((c->size == 1 && !c->nccl) || count == 0) return RTC_OK;
+  if (c->nccl) {
+    RTC_NCCL(ctx, ncclAllReduce(d_buf, d_buf, count, dtype == 0 ? ncclInt64 : ncclUint32, op == 0 ? ncclMin : ncclMax, c->nccl, stream));
+    return RTC_OK;
+  }
+  LocalGroup& g = *c->local;
+  const size_t esz = dtype == 0 ? 8 : 4;
+  void* ws = nullptr;
+  RTC_TRY(rtc_ws(ctx, 5, count * esz + (size_t)c->size * 8 + 64, &ws));
+  void* tmp = ws;
+  const void** d_ptrs = (const void**)((char*)ws + ((count * esz + 63) & ~(size_t)63));
+  RTC_HIP(ctx, hipStreamSynchronize(stream));
+  g.ptr[c->rank] = d_buf;
+  g.barrier();
+  std::vector<const void*> ptrs(g.ptr.begin(), g.ptr.begin() + c->size);
+  RTC_HIP(ctx, hipMemcpyAsync((void*)d_ptrs, ptrs.data(), (size_t)c->size * 8, hipMemcpyHostToDevice, stream));
+  const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 2048));
+  if (dtype == 0) hipLaunchKernelGGL(local_reduce_kernel<long long>, dim3(grid), dim3(256), 0, stream, (const void* const*)d_ptrs, c->size, count, op, (long long*)tmp);
+  else hipLaunchKernelGGL(local_reduce_kernel<uint32_t>, dim3(grid), dim3(256), 0, stream, (const void* const*)d_ptrs, c->size, count, op, (uint32_t*)tmp);
+  RTC_HIP(ctx, hipGetLastError());
+  RTC_HIP(ctx, hipStreamSynchronize(stream));
+  g.barrier();  // everybody has read everybody's input
+  RTC_HIP(ctx, hipMemcpyAsync(d_buf, tmp, count * esz, hipMemcpyDeviceToDevice, stream));
+  RTC_HIP(ctx, hipStreamSynchronize(stream));
+  g.barrier();
+  return RTC_OK;
+}
+
+// rows [a, b) of every rank's block of the canonical global buffer travel to all ranks, in place
+int comm_gather_rows_on(rtc_comm* c, void* d_global, size_t row_bytes, uint32_t n_local, uint32_t a, uint32_t b, hipStream_t stream) {
+  rtc_ctx* ctx = c->ctx;
+  if ((c->size == 1 && !c->nccl) || b <= a || row_bytes == 0) return RTC_OK;
+  const size_t bytes = (size_t)(b - a) * row_bytes;
+  if (c->nccl) {
+    RTC_NCCL(ctx, ncclGroupStart());
+    for (int r = 0; r < c->size; r++) {
+      char* p = (char*)d_global + ((size_t)r * n_local + a) * row_bytes;
+      ncclResult_t st = ncclBroadcast(p, p, bytes, ncclInt8, r, c->nccl, stream);
+      if (st != ncclSuccess) { (void)ncclGroupEnd(); return rtc_fail(ctx, RTC_ERR_HIP, "ncclBroadcast -> %s", ncclGetErrorString(st)); }
+    }
+    RTC_NCCL(ctx, ncclGroupEnd());
+    return RTC_OK;
+  }
+  LocalGroup& g = *c->local;
+  RTC_HIP(ctx, hipStreamSynchronize(stream));
+  g.ptr[c->rank] = d_global;
+  g.barrier();
+  for (int r = 0; r < c->size; r++) {
+    if (r == c->rank) continue;
+    const size_t off = ((size_t)r * n_local + a) * row_bytes;
+    RTC_HIP(ctx, hipMemcpyAsync((char*)d_global + off, (const char*)g.ptr[r] + off, bytes, hipMemcpyDefault, stream));
+  }
+  RTC_HIP(ctx, hipStreamSynchronize(stream));
+  g.barrier();
+  return RTC_OK;
+}
+
+int hook_all_reduce(void* self, void* d_buf, size_t count, int dtype, int op) {
+  rtc_comm* c = (rtc_comm*)self;
+  return comm_all_reduce_on(c, d_buf, count, dtype, op, c->ctx->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtc_comm_unique_id(void* id_out) {
+  if (!id_out) return RTC_ERR_ARG;
+  static_assert(sizeof(ncclUniqueId) == RTC_COMM_ID_BYTES, "rtclust.h: RTC_COMM_ID_BYTES");
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return rtc_fail(nullptr, RTC_ERR_HIP, "ncclGetUniqueId -> %s", ncclGetErrorString(r));
+  memcpy(id_out, &id, sizeof id);
+  return RTC_OK;
+}
+
+int rtc_comm_init_rank(rtc_ctx* ctx, int nranks, int rank, const void* id, rtc_comm** out) {
+  if (!ctx || !out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !id)) return RTC_ERR_ARG;
+  *out = nullptr;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  std::unique_ptr<rtc_comm> c(new rtc_comm());
+  c->ctx = ctx; c->rank = rank; c->size = nranks;
+  if (nranks > 1 || (id && getenv("RTC_COMM_FORCE_RCCL"))) {  // the env switch drives the RCCL calls on one GPU (tests)
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    RTC_NCCL(ctx, ncclCommInitRank(&c->nccl, nranks, uid, rank));
+  }
+  RTC_TRY(comm_finish_init(c.get()));
+  *out = c.release();
+  return RTC_OK;
+}
+
+int rtc_comm_init_all(rtc_ctx** ctxs, int n, rtc_comm** comms_out) {
+  if (!ctxs || !comms_out || n < 1) return RTC_ERR_ARG;
+  for (int i = 0; i < n; i++) { if (!ctxs[i]) return RTC_ERR_ARG; comms_out[i] = nullptr; }
+  bool distinct = true;
+  for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (ctxs[i]->device == ctxs[j]->device) distinct = false;
+  std::vector<std::unique_ptr<rtc_comm>> cs;
+  for (int i = 0; i < n; i++) { cs.emplace_back(new rtc_comm()); cs[i]->ctx = ctxs[i]; cs[i]->rank = i; cs[i]->size = n; }
+  if (n > 1 && distinct) {
+    std::vector<int> devs(n);
+    std::vector<ncclComm_t> nc(n);
+    for (int i = 0; i < n; i++) devs[i] = ctxs[i]->device;
+    RTC_NCCL(ctxs[0], ncclCommInitAll(nc.data(), n, devs.data()));
+    for (int i = 0; i < n; i++) cs[i]->nccl = nc[i];
+  } else if (n > 1) {  // shared device(s): RCCL rejects duplicate GPUs
+    auto g = std::make_shared<LocalGroup>();
+    g->n = n; g->ptr.assign(n, nullptr);
+    for (int i = 0; i < n; i++) cs[i]->local = g;
+  }
+  for (int i = 0; i < n; i++) RTC_TRY(comm_finish_init(cs[i].get()));
+  for (int i = 0; i < n; i++) comms_out[i] = cs[i].release();
+  return RTC_OK;
+}
+
+void rtc_comm_destroy(rtc_comm* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->ctx->device);
+  if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->nccl) (void)ncclCommDestroy(c->nccl);
+  delete c;
+}
+
+int rtc_comm_rank(const rtc_comm* c) { return c ? c->rank : -1; }
+int rtc_comm_size(const rtc_comm* c) { return c ? c->size : 0; }
+const char* rtc_comm_backend(const rtc_comm* c) { return !c ? "" : (c->nccl ? "rccl" : (c->local ? "in-process" : "single")); }
+
+int rtc_comm_all_reduce(rtc_comm* c, void* d_buf, size_t count, int dtype, int op) {
+  if (!c || (count && !d_buf) || dtype < 0 || dtype > 1 || op < 0 || op > 1) return RTC_ERR_ARG;
+  RTC_HIP(c->ctx, hipSetDevice(c->ctx->device));
+  return comm_all_reduce_on(c, d_buf, count, dtype, op, c->ctx->stream);
+}
+
+int rtc_comm_all_reduce_host(rtc_comm* c, int64_t* h_vals, size_t count, int op) {
+  if (!c || !h_vals || count == 0 || count > 64 || op < 0 || op > 1) return RTC_ERR_ARG;
+  if (c->size == 1 && !c->nccl) return RTC_OK;
+  rtc_ctx* ctx = c->ctx;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  void* ws = nullptr;
+  RTC_TRY(rtc_ws(ctx, 0, 4096, &ws));
+  RTC_HIP(ctx, hipMemcpyAsync(ws, h_vals, count * 8, hipMemcpyHostToDevice, ctx->stream));
+  RTC_TRY(comm_all_reduce_on(c, ws, count, 0, op, ctx->stream));
+  RTC_HIP(ctx, hipMemcpyAsync(h_vals, ws, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RTC_OK;
+}
+
+int rtc_comm_gather_rows(rtc_comm* c, void* d_global, size_t row_bytes, uint32_t n_local, uint32_t a, uint32_t b, int async) {
+  if (!c || !d_global || a > b || b > n_local) return RTC_ERR_ARG;
+  rtc_ctx* ctx = c->ctx;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  if (!async) return comm_gather_rows_on(c, d_global, row_bytes, n_local, a, b, ctx->stream);
+  // side stream: starts when the work enqueued so far on the context stream (the sketch kernel of
+  // these rows) is done; rtc_comm_wait joins it back
+  RTC_HIP(ctx, hipEventRecord(c->ev_ready, ctx->stream));
+  RTC_HIP(ctx, hipStreamWaitEvent(c->side, c->ev_ready, 0));
+  RTC_TRY(comm_gather_rows_on(c, d_global, row_bytes, n_local, a, b, c->side));
+  c->side_busy = true;
+  return RTC_OK;
+}
+
+// d_buf[0..bytes) of rank `root` replaces every other rank's d_buf (context stream)
+int rtc_comm_broadcast(rtc_comm* c, void* d_buf, size_t bytes, int root) {
+  if (!c || (bytes && !d_buf) || root < 0 || root >= c->size) return RTC_ERR_ARG;
+  rtc_ctx* ctx = c->ctx;
+  if ((c->size == 1 && !c->nccl) || bytes == 0) return RTC_OK;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  if (c->nccl) {
+    RTC_NCCL(ctx, ncclBroadcast(d_buf, d_buf, bytes, ncclInt8, root, c->nccl, ctx->stream));
+    return RTC_OK;
+  }
+  LocalGroup& g = *c->local;
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  g.ptr[c->rank] = d_buf;
+  g.barrier();
+  if (c->rank != root) RTC_HIP(ctx, hipMemcpyAsync(d_buf, g.ptr[root], bytes, hipMemcpyDefault, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  g.barrier();
+  return RTC_OK;
+}
+
+int rtc_comm_wait(rtc_comm* c) {
+  if (!c) return RTC_ERR_ARG;
+  if (!c->side_busy) return RTC_OK;
+  rtc_ctx* ctx = c->ctx;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  RTC_HIP(ctx, hipEventRecord(c->ev_done, c->side));
+  RTC_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done, 0));
+  c->side_busy = false;
+  return RTC_OK;
+}
+
+// Contiguous row ranges of the strict lower triangle with equal cost; row i costs (i + fixed_cols)
+// (fixed_cols: per-row-block table build that does not depend on the row length, ~8.8 columns per
+// sketch hash on MI355X).  h_bounds[world + 1].
+int rtc_triangle_rows(uint32_t n, int world, double fixed_cols, uint32_t* h_bounds) {
+  if (world < 1 || !h_bounds) return RTC_ERR_ARG;
+  const double c = fixed_cols, area = (double)n * n / 2.0 + c * n;
+  h_bounds[0] = 0;
+  for (int r = 1; r <= world; r++) {
+    double v = -c + sqrt(c * c + 2.0 * area * r / world);
+    long b = lround(v);
+    b = std::min<long>(std::max<long>(b, h_bounds[r - 1]), n);
+    h_bounds[r] = (uint32_t)b;
+  }
+  h_bounds[world] = n;
+  return RTC_OK;
+}
+
+// Multi-GPU MinHash sketch phase: this rank's genomes -> its block of the canonical global buffers
+// (d_out_global: size*n_local*stride u64, d_cnt_global: size*n_local u32), in two parts so that the
+// gather of the first part (side stream) runs beside the sketch kernel of the second.  Every rank
+// passes the same n_local / stride.  Returns with the gathers enqueued; the context stream already
+// waits for them (no host synchronisation here).
+int rtc_sketch_minhash_sharded(rtc_ctx* ctx, rtc_comm* c, const uint8_t* d_seq, const uint64_t* h_off, uint32_t n_local,
+                               int k, uint32_t seed, const uint32_t* h_sizes, uint32_t size, uint64_t* d_out_global,
+                               uint32_t stride, uint32_t* d_cnt_global) {
+  if (!ctx || !c || c->ctx != ctx || !h_off || (n_local && (!d_seq || !d_out_global || !d_cnt_global))) return RTC_ERR_ARG;
+  if (n_local == 0) return RTC_OK;
+  {  // the canonical order needs identical block shapes
+    int64_t v[4] = {(int64_t)n_local, -(int64_t)n_local, (int64_t)stride, -(int64_t)stride};
+    RTC_TRY(rtc_comm_all_reduce_host(c, v, 4, 1));
+    if (v[0] != (int64_t)n_local || -v[1] != (int64_t)n_local || v[2] != (int64_t)stride || -v[3] != (int64_t)stride)
+      return rtc_fail(ctx, RTC_ERR_ARG, "ranks disagree on genomes per rank (%u here, %lld..%lld) or stride (%u here, %lld..%lld)",
+                      n_local, (long long)-v[1], (long long)v[0], stride, (long long)-v[3], (long long)v[2]);
+  }
+  const uint32_t slots = 3u * (uint32_t)ctx->num_cu;
+  uint32_t split = n_local;
+  if (c->size > 1 && n_local >= 8) split = (n_local >= 2 * slots) ? std::max(slots, (uint32_t)(0.8 * n_local) / slots * slots) : (3 * n_local) / 4;
+  uint64_t* my_out = d_out_global + (size_t)c->rank * n_local * stride;
+  uint32_t* my_cnt = d_cnt_global + (size_t)c->rank * n_local;
+  const uint32_t parts[3] = {0, split, n_local};
+  for (int p = 0; p < 2; p++) {
+    const uint32_t a = parts[p], b = parts[p + 1];
+    if (b <= a) continue;
+    RTC_TRY(rtc_sketch_minhash_dev(ctx, d_seq, h_off + a, b - a, k, seed, h_sizes ? h_sizes + a : nullptr, size,
+                                   my_out + (size_t)a * stride, stride, my_cnt + a));
+    RTC_TRY(rtc_comm_gather_rows(c, d_out_global, (size_t)stride * 8, n_local, a, b, 1));
+    RTC_TRY(rtc_comm_gather_rows(c, d_cnt_global, 4, n_local, a, b, 1));
+  }
+  return rtc_comm_wait(c);
+}
+
+// compute_minhash_mst / compute_kssd_mst (src/MST.cpp:1290-1737, :216-807) across the ranks of `c`:
+// this rank evaluates its row range of the pair space, the Boruvka rounds all-reduce their key
+// arrays, every rank returns the identical forest (identical to rtc_mst on one GPU: the total order
+// on (weight, i, j) makes the minimum spanning forest unique).  Sketches: the complete, canonical set.
+int rtc_mst_sharded(rtc_ctx* ctx, rtc_comm* c, const void* d_hashes, int width, const uint64_t* d_start,
+                    const uint32_t* d_len, uint32_t n, int kmer_size, int is_containment, double threshold,
+                    rtc_edge* h_edges_out, uint64_t* h_n_edges, rtc_shard_stats* stats) {
+  if (!ctx || !c || c->ctx != ctx || !h_n_edges || (n && (!d_start || !d_len || !h_edges_out))) return RTC_ERR_ARG;
+  *h_n_edges = 0;
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (n < 2) return RTC_OK;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  RTC_TRY(rtc_comm_wait(c));
+  std::vector<uint32_t> h_len(n);
+  RTC_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t s_fixed = rtc_fixed_size_of(h_len.data(), n);
+  double mean = 0;
+  for (uint32_t g = 0; g < n; g++) mean += h_len[g];
+  mean /= n;
+  std::vector<uint32_t> bounds(c->size + 1);
+  RTC_TRY(rtc_triangle_rows(n, c->size, c->size > 1 ? 8.8 * mean : 0.0, bounds.data()));
+  const uint32_t row0 = bounds[c->rank], row1 = bounds[c->rank + 1];
+
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  RTC_HIP(ctx, hipEventCreate(&e0)); RTC_HIP(ctx, hipEventCreate(&e1)); RTC_HIP(ctx, hipEventCreate(&e2));
+  rtc_edge_list el{};
+  rtc_cedge* d_sel = nullptr;
+  (void)hipEventRecord(e0, ctx->stream);
+  int st = rtc_candidate_edges_device(ctx, d_hashes, width, d_start, d_len, n, row0, row1, kmer_size, is_containment,
+                                      threshold, s_fixed, &el);
+  (void)hipEventRecord(e1, ctx->stream);
+  uint64_t nsel = 0;
+  int rounds = 0;
+  std::vector<rtc_cedge> sel;
+  if (st == RTC_OK && hipMalloc((void**)&d_sel, (size_t)n * sizeof(rtc_cedge)) != hipSuccess)
+    st = rtc_fail(ctx, RTC_ERR_NOMEM, "hipMalloc forest list");
+  const rtc_reduce_hook hook{hook_all_reduce, c};
+  if (st == RTC_OK) st = rtc_msf_device(ctx, el.d_edges, el.m, d_len, n, is_containment, s_fixed, c->size > 1 ? &hook : nullptr, d_sel, &nsel, &rounds);
+  if (st == RTC_OK && nsel) {
+    sel.resize(nsel);
+    hipError_t e = hipMemcpyAsync(sel.data(), d_sel, nsel * sizeof(rtc_cedge), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) st = rtc_fail(ctx, RTC_ERR_HIP, "forest read-back -> %s", hipGetErrorString(e));
+  }
+  (void)hipEventRecord(e2, ctx->stream);
+  (void)hipEventSynchronize(e2);
+  if (stats && st == RTC_OK) {
+    (void)hipEventElapsedTime(&stats->pair_ms, e0, e1);
+    (void)hipEventElapsedTime(&stats->mst_ms, e1, e2);
+    stats->row0 = row0; stats->row1 = row1; stats->cand_edges = el.m; stats->rounds = (uint32_t)rounds;
+    stats->s_fixed = s_fixed; stats->contractions = (uint32_t)el.contractions;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+  if (d_sel) (void)hipFree(d_sel);
+  rtc_edge_list_free(&el);
+  if (st != RTC_OK) return st;
+  RTC_TRY(rtc_edges_to_mst_host(sel.data(), nsel, h_len.data(), kmer_size, is_containment, h_edges_out));
+  *h_n_edges = nsel;
+  return RTC_OK;
+}
+
+}  // extern "C"

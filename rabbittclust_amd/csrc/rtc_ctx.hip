@@ -50,6 +50,12 @@ extern "C" {
 
 const char* rtc_version(void) { return "rabbittclust_amd 0.1 (gfx950)"; }
 
+int rtc_device_count(void) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess) return 0;
+  return ndev;
+}
+
 int rtc_ctx_create(int device, rtc_ctx** out) {
   if (!out) return RTC_ERR_ARG;
   *out = nullptr;
@@ -97,6 +103,7 @@ int rtc_ctx_set_stream(rtc_ctx* ctx, void* hip_stream) {
 
 int rtc_ctx_sync(rtc_ctx* ctx) {
   if (!ctx) return RTC_ERR_ARG;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));  // the current device is per host thread; a NULL stream means ITS default stream
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RTC_OK;
 }
@@ -164,18 +171,21 @@ int rtc_copy_d2h(rtc_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
 int rtc_memset_dev(rtc_ctx* ctx, void* d_ptr, int value, size_t bytes) {
   if (!ctx || (bytes && !d_ptr)) return RTC_ERR_ARG;
   if (!bytes) return RTC_OK;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
   RTC_HIP(ctx, hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
   return RTC_OK;
 }
 
 int rtc_timer_start(rtc_ctx* ctx) {
   if (!ctx) return RTC_ERR_ARG;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
   RTC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   return RTC_OK;
 }
 
 int rtc_timer_stop(rtc_ctx* ctx, float* ms_out) {
   if (!ctx || !ms_out) return RTC_ERR_ARG;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
   RTC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   RTC_HIP(ctx, hipEventSynchronize(ctx->ev1));
   RTC_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));

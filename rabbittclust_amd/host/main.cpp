@@ -5,7 +5,11 @@
 // and KSSD (--fast) sketching, --presketched / --premsted resume, -e/--no-save, and the same
 // intermediate folder (info.sketch, hash.sketch, minhash.sketch.index, kssd.*, info.mst,
 // edge.mst).  Built twice: -DGREEDY_CLUST gives clust-greedy, otherwise clust-mst
-// (CMakeLists.txt:40-58 of the reference does the same).  Incremental (--append, --db, --save-rep),
+// (CMakeLists.txt:40-58 of the reference does the same).
+// GPUs: every visible MI355X is used (--gpus LIST / RTC_GPUS to choose): one context + one host thread
+// per GPU, file batches go round-robin to the GPUs, the sketches stay in HBM (copied to the host only
+// to write hash.sketch), are shared among the GPUs with RCCL broadcasts, and the MST runs
+// row-sharded with one all-reduce per Boruvka round (rtc_mst_sharded).  Incremental (--append, --db, --save-rep),
 // tree writers, --dense, --auto-threshold and single-FASTA mode are outside this path and exit
 // with a message.
 #include <math.h>
@@ -17,6 +21,7 @@
 #include <sys/time.h>
 
 #include <algorithm>
+#include <atomic>
 #include <fstream>
 #include <iostream>
 #include <numeric>
@@ -43,6 +48,30 @@ struct DeviceSketches {  // sketches resident in HBM in the CSR the pair kernels
   uint32_t n = 0; int width = 8;
 };
 
+struct Gpu {  // one per GPU in use: context, communicator, staging and the resident sketch rows
+  rtc_ctx* ctx = nullptr; rtc_comm* comm = nullptr;
+  void* d_seq = nullptr;        // staging for one batch of bases
+  void* d_sk = nullptr;         // resident sketches: row g (genome id g) at d_sk + g*stride*width
+  uint32_t* d_cnt = nullptr;    // hashes per genome
+  std::thread worker;
+};
+
+// Sketches produced by sketch_files and left in HBM (every GPU holds all rows after the share step)
+struct Resident {
+  bool ok = false;              // false: fall back to the host vectors (gzip retry round, KSSD row overflow)
+  uint32_t stride = 0; int width = 8;
+  std::vector<uint32_t> counts; // per genome id
+};
+
+// run fn(g) on one host thread per GPU and wait (a context is used by one thread at a time)
+template <typename F>
+static void on_all_gpus(std::vector<Gpu>& gpus, F fn) {
+  std::vector<std::thread> th;
+  for (size_t g = 1; g < gpus.size(); g++) th.emplace_back([&fn, g]() { fn(g); });
+  fn(0);
+  for (auto& t : th) t.join();
+}
+
 static void upload_sketches(rtc_ctx* ctx, const vector<vector<uint64_t>>* h64, const vector<vector<uint32_t>>* h32,
                             DeviceSketches& ds) {
   const uint32_t n = (uint32_t)(h64 ? h64->size() : h32->size());
@@ -60,6 +89,18 @@ static void upload_sketches(rtc_ctx* ctx, const vector<vector<uint64_t>>* h64, c
   CHECK(ctx, rtc_dev_alloc(ctx, (size_t)n * 8 + 64, (void**)&ds.d_start));
   CHECK(ctx, rtc_dev_alloc(ctx, (size_t)n * 4 + 64, (void**)&ds.d_len));
   CHECK(ctx, rtc_copy_h2d(ctx, ds.d_hashes, flat.data(), flat.size()));
+  CHECK(ctx, rtc_copy_h2d(ctx, ds.d_start, start.data(), (size_t)n * 8));
+  CHECK(ctx, rtc_copy_h2d(ctx, ds.d_len, len.data(), (size_t)n * 4));
+}
+
+// the CSR over the resident rows: start[g] = order[g]*stride (order: processing order -> genome id), len from the counts
+static void resident_sketches(rtc_ctx* ctx, const Gpu& gp, const Resident& rs, const vector<uint32_t>* order, DeviceSketches& ds) {
+  const uint32_t n = (uint32_t)rs.counts.size();
+  ds.n = n; ds.width = rs.width; ds.d_hashes = gp.d_sk;
+  vector<uint64_t> start(n); vector<uint32_t> len(n);
+  for (uint32_t g = 0; g < n; g++) { const uint32_t src = order ? (*order)[g] : g; start[g] = (uint64_t)src * rs.stride; len[g] = rs.counts[src]; }
+  CHECK(ctx, rtc_dev_alloc(ctx, (size_t)n * 8 + 64, (void**)&ds.d_start));
+  CHECK(ctx, rtc_dev_alloc(ctx, (size_t)n * 4 + 64, (void**)&ds.d_len));
   CHECK(ctx, rtc_copy_h2d(ctx, ds.d_start, start.data(), (size_t)n * 8));
   CHECK(ctx, rtc_copy_h2d(ctx, ds.d_len, len.data(), (size_t)n * 4));
 }
@@ -94,10 +135,13 @@ struct Batch { vector<size_t> files; vector<uint64_t> slot_off, slot_len; uint64
 struct FileResult {           // indexed by list position, so late (retried) files keep list order
   SequenceInfo first; uint64_t total = 0; int flen = 0; bool kept = false;
   vector<uint64_t> h64; vector<uint32_t> h32;
+  bool on_host = false;  // h64 / h32 hold the sketch (otherwise it lives in HBM only)
 };
 
-static void sketch_files(rtc_ctx* ctx, const string& inputFile, const SketchJob& job, vector<GenomeInfo>& genomes,
-                         MinHashSketchFile* mh, KssdSketchFile* ks) {
+static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const SketchJob& job, vector<GenomeInfo>& genomes,
+                         MinHashSketchFile* mh, KssdSketchFile* ks, Resident& rs, bool need_host_hashes) {
+  rtc_ctx* ctx = gpus[0].ctx;
+  const size_t G = gpus.size();
   const double tp00 = get_sec();
   const vector<string> fileList = read_list(inputFile);
   const size_t nfiles = fileList.size();
@@ -144,15 +188,15 @@ static void sketch_files(rtc_ctx* ctx, const string& inputFile, const SketchJob&
   iota(all.begin(), all.end(), 0);
   vector<Batch> batches = plan(all, slot);
 
-  // ---- staging: two page-locked host buffers and one device buffer, reused by every batch ----
+  // ---- staging: G+1 host buffers (one being parsed, one per GPU in flight) and one device buffer per GPU ----
+  const size_t NSTAGE = G + 1;
   uint64_t buf_bytes = 0;
-  char* stage[2] = {nullptr, nullptr};
-  void* d_seq = nullptr;
+  vector<char*> stage(NSTAGE, nullptr);
   // Pageable staging by default: page-locking costs ~0.15 s/GB up front while the pageable PCIe copy
   // already runs at > 30 GB/s on the MI355X hosts measured; RTC_STAGE_PINNED=1 page-locks instead.
   bool pinned = getenv("RTC_STAGE_PINNED") != nullptr;
   auto free_stage = [&]() {
-    for (int i = 0; i < 2; i++) {
+    for (size_t i = 0; i < NSTAGE; i++) {
       if (stage[i] && pinned) CHECK(ctx, rtc_host_free(ctx, stage[i]));
       else free(stage[i]);
       stage[i] = nullptr;
@@ -161,9 +205,9 @@ static void sketch_files(rtc_ctx* ctx, const string& inputFile, const SketchJob&
   auto ensure_buffers = [&](uint64_t need) {
     if (need <= buf_bytes) return;
     free_stage();
-    if (d_seq) CHECK(ctx, rtc_dev_free(ctx, d_seq));
+    for (Gpu& g : gpus) if (g.d_seq) { CHECK(g.ctx, rtc_dev_free(g.ctx, g.d_seq)); g.d_seq = nullptr; }
     buf_bytes = need;
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < (int)NSTAGE; i++) {
       if (pinned && rtc_host_alloc(ctx, buf_bytes + 64, (void**)&stage[i]) != RTC_OK) {
         // the host refuses to page-lock this much (ulimit -l): stage through pageable memory instead
         fprintf(stderr, "-----cannot page-lock %.2f GB (%s), staging through pageable memory\n", buf_bytes / 1e9, rtc_last_error(ctx));
@@ -173,15 +217,38 @@ static void sketch_files(rtc_ctx* ctx, const string& inputFile, const SketchJob&
       }
       if (!pinned && !(stage[i] = alloc_pageable(buf_bytes + 64))) { fprintf(stderr, "ERROR: cannot allocate %.2f GB of staging memory\n", buf_bytes / 1e9); exit(1); }
     }
-    CHECK(ctx, rtc_dev_alloc(ctx, buf_bytes + 64, &d_seq));
+    for (Gpu& g : gpus) CHECK(g.ctx, rtc_dev_alloc(g.ctx, buf_bytes + 64, &g.d_seq));
   };
   uint64_t maxb = 0;
   for (const Batch& b : batches) maxb = std::max(maxb, b.bytes);
   ensure_buffers(maxb);
-  if (verbose) fprintf(stderr, "[plan] %zu files, %zu batches, staging 2 x %.2f GB, %.3fs\n", nfiles, batches.size(), buf_bytes / 1e9, get_sec() - tp0);
+  if (verbose) fprintf(stderr, "[plan] %zu files, %zu batches, %zu GPU(s), staging %zu x %.2f GB, %.3fs\n", nfiles, batches.size(), G, NSTAGE, buf_bytes / 1e9, get_sec() - tp0);
 
-  // ---- GPU side of one batch (runs on its own host thread while the next batch is parsed) ----
-  auto gpu_batch = [&](const Batch& b, const char* h_seq) {
+  // ---- resident sketch rows: genome id g (list order among the kept files) owns row g on every GPU ----
+  auto size_of = [&](size_t file) -> uint32_t {
+    return job.isContainment ? (uint32_t)std::max(res[file].flen / job.containCompress, 100) : (uint32_t)job.sketchSize;  // :919-924
+  };
+  rs.width = job.kssd ? (use64 ? 8 : 4) : 8;
+  rs.stride = 1;
+  if (!job.kssd) for (size_t i = 0; i < nfiles; i++) rs.stride = std::max(rs.stride, size_of(i));
+  else { uint64_t ms = 0; for (size_t i = 0; i < nfiles; i++) ms = std::max(ms, slot[i]); rs.stride = (uint32_t)(ms / (1ull << (4 * job.drlevel)) * 3 / 2 + 256); }
+  rs.ok = getenv("RTC_HOST_SKETCHES") == nullptr;  // the switch forces the upload path (tests compare the two)
+  rs.counts.assign(nfiles, 0);
+  std::atomic<bool> resident_ok{rs.ok};
+  if (rs.ok)
+    for (Gpu& g : gpus) {
+      CHECK(g.ctx, rtc_dev_alloc(g.ctx, (size_t)nfiles * rs.stride * rs.width + 64, &g.d_sk));
+      CHECK(g.ctx, rtc_dev_alloc(g.ctx, (size_t)nfiles * 4 + 64, (void**)&g.d_cnt));
+      CHECK(g.ctx, rtc_memset_dev(g.ctx, g.d_cnt, 0, (size_t)nfiles * 4));
+    }
+  struct Placed { uint32_t row0, rows; int gpu; };  // where a batch's sketches live (share step)
+  vector<Placed> placed;
+  vector<size_t> row_file;  // row (= genome id) -> list position
+
+  // ---- GPU side of one batch (runs on that GPU's host thread while the next batch is parsed) ----
+  // row0 < 0: not resident (retry round), results only go to the host vectors.
+  auto gpu_batch = [&](Gpu& gp, const Batch& b, const char* h_seq, long row0) {
+    rtc_ctx* c = gp.ctx;
     const double t0 = get_sec();
     vector<uint64_t> off; vector<uint32_t> sizes; vector<size_t> kept;
     for (size_t q = 0; q < b.files.size(); q++) {
@@ -189,63 +256,78 @@ static void sketch_files(rtc_ctx* ctx, const string& inputFile, const SketchJob&
       if (!r.kept) continue;
       kept.push_back(b.files[q]);
       off.push_back(b.slot_off[q]);  // a genome extends to the next kept one: the gap holds only 'N'
-      sizes.push_back(job.isContainment ? (uint32_t)std::max(r.flen / job.containCompress, 100) : (uint32_t)job.sketchSize);  // :919-924
+      sizes.push_back(size_of(b.files[q]));
     }
     const uint32_t nb = (uint32_t)kept.size();
     if (!nb) return;
     off.push_back(b.bytes);
-    CHECK(ctx, rtc_copy_h2d(ctx, d_seq, h_seq, b.bytes + 64));
+    CHECK(c, rtc_copy_h2d(c, gp.d_seq, h_seq, b.bytes + 64));
     const double t1 = get_sec();
+    const bool resident = row0 >= 0 && resident_ok.load();
+    const bool to_host = need_host_hashes || !resident;
+    const int w = rs.width;
     uint32_t* d_cnt = nullptr;
-    CHECK(ctx, rtc_dev_alloc(ctx, (size_t)nb * 4, (void**)&d_cnt));
+    if (resident) d_cnt = gp.d_cnt + row0;
+    else CHECK(c, rtc_dev_alloc(c, (size_t)nb * 4, (void**)&d_cnt));
     vector<uint32_t> cnt(nb);
+    uint32_t stride = rs.stride;
+    void* d_out = nullptr;
+    if (resident) d_out = (char*)gp.d_sk + (size_t)row0 * rs.stride * w;
+    bool row_overflow = false;
     if (!job.kssd) {
-      const uint32_t stride = *std::max_element(sizes.begin(), sizes.end());
-      uint64_t* d_out = nullptr;
-      CHECK(ctx, rtc_dev_alloc(ctx, (size_t)nb * stride * 8, (void**)&d_out));
-      CHECK(ctx, rtc_sketch_minhash_dev(ctx, (const uint8_t*)d_seq, off.data(), nb, job.kmerSize, 42, sizes.data(), stride,
-                                        d_out, stride, d_cnt));
-      vector<uint64_t> out((size_t)nb * stride);
-      CHECK(ctx, rtc_copy_d2h(ctx, out.data(), d_out, out.size() * 8));
-      CHECK(ctx, rtc_copy_d2h(ctx, cnt.data(), d_cnt, (size_t)nb * 4));
-      for (uint32_t g = 0; g < nb; g++) res[kept[g]].h64.assign(out.begin() + (size_t)g * stride, out.begin() + (size_t)g * stride + cnt[g]);
-      CHECK(ctx, rtc_dev_free(ctx, d_out));
+      if (!resident) { stride = *std::max_element(sizes.begin(), sizes.end()); CHECK(c, rtc_dev_alloc(c, (size_t)nb * stride * 8, &d_out)); }
+      CHECK(c, rtc_sketch_minhash_dev(c, (const uint8_t*)gp.d_seq, off.data(), nb, job.kmerSize, 42, sizes.data(), stride,
+                                      (uint64_t*)d_out, stride, d_cnt));
     } else {
-      uint64_t maxlen = 0;
-      for (uint32_t g = 0; g < nb; g++) maxlen = std::max(maxlen, off[g + 1] - off[g]);
-      uint32_t stride = (uint32_t)(maxlen / (1ull << (4 * job.drlevel)) * 3 / 2 + 256);
-      const int w = use64 ? 8 : 4;
+      if (!resident) {
+        uint64_t maxlen = 0;
+        for (uint32_t g = 0; g < nb; g++) maxlen = std::max(maxlen, off[g + 1] - off[g]);
+        stride = (uint32_t)(maxlen / (1ull << (4 * job.drlevel)) * 3 / 2 + 256);
+        CHECK(c, rtc_dev_alloc(c, (size_t)nb * stride * w, &d_out));
+      }
       while (true) {
-        void* d_out = nullptr;
-        CHECK(ctx, rtc_dev_alloc(ctx, (size_t)nb * stride * w, &d_out));
         int width = 0; uint32_t need = 0;
-        int st = rtc_sketch_kssd_dev(ctx, (const uint8_t*)d_seq, off.data(), nb, job.kmerSize, job.drlevel, shuffled.data(),
+        int st = rtc_sketch_kssd_dev(c, (const uint8_t*)gp.d_seq, off.data(), nb, job.kmerSize, job.drlevel, shuffled.data(),
                                      d_out, stride, d_cnt, &width, &need);
-        if (st == RTC_ERR_OVERFLOW) { CHECK(ctx, rtc_dev_free(ctx, d_out)); stride = need + 64; continue; }
-        CHECK(ctx, st);
-        CHECK(ctx, rtc_copy_d2h(ctx, cnt.data(), d_cnt, (size_t)nb * 4));
-        vector<unsigned char> out((size_t)nb * stride * w);
-        CHECK(ctx, rtc_copy_d2h(ctx, out.data(), d_out, out.size()));
-        for (uint32_t g = 0; g < nb; g++) {
-          if (use64) { const uint64_t* p = (const uint64_t*)out.data() + (size_t)g * stride; res[kept[g]].h64.assign(p, p + cnt[g]); }
-          else { const uint32_t* p = (const uint32_t*)out.data() + (size_t)g * stride; res[kept[g]].h32.assign(p, p + cnt[g]); }
+        if (st == RTC_ERR_OVERFLOW) {
+          // a genome with more tuples than a resident row: this batch goes to a wider temporary buffer and
+          // the run falls back to the host vectors (the other batches are pulled from HBM at the end)
+          if (resident && !row_overflow) { row_overflow = true; resident_ok.store(false); CHECK(c, rtc_dev_alloc(c, (size_t)nb * 4, (void**)&d_cnt)); }
+          else CHECK(c, rtc_dev_free(c, d_out));
+          stride = need + 64;
+          CHECK(c, rtc_dev_alloc(c, (size_t)nb * stride * w, &d_out));
+          continue;
         }
-        CHECK(ctx, rtc_dev_free(ctx, d_out));
+        CHECK(c, st);
         break;
       }
     }
-    CHECK(ctx, rtc_dev_free(ctx, d_cnt));
-    if (verbose) fprintf(stderr, "[gpu]   %u genomes, %.2f GB: h2d %.3fs sketch+d2h %.3fs\n", nb, b.bytes / 1e9, t1 - t0, get_sec() - t1);
+    const bool temp = !resident || row_overflow;
+    CHECK(c, rtc_copy_d2h(c, cnt.data(), d_cnt, (size_t)nb * 4));
+    if (row0 >= 0) for (uint32_t g = 0; g < nb; g++) rs.counts[row0 + g] = cnt[g];
+    if (to_host || temp) {
+      vector<unsigned char> out((size_t)nb * stride * w);
+      CHECK(c, rtc_copy_d2h(c, out.data(), d_out, out.size()));
+      for (uint32_t g = 0; g < nb; g++) {
+        FileResult& r = res[kept[g]];
+        if (w == 8) { const uint64_t* p = (const uint64_t*)out.data() + (size_t)g * stride; r.h64.assign(p, p + cnt[g]); }
+        else { const uint32_t* p = (const uint32_t*)out.data() + (size_t)g * stride; r.h32.assign(p, p + cnt[g]); }
+        r.on_host = true;
+      }
+    }
+    if (temp) { CHECK(c, rtc_dev_free(c, d_out)); CHECK(c, rtc_dev_free(c, d_cnt)); }
+    if (verbose) fprintf(stderr, "[gpu %d] %u genomes, %.2f GB: h2d %.3fs sketch%s %.3fs\n", (int)(&gp - gpus.data()), nb, b.bytes / 1e9, t1 - t0,
+                         to_host || temp ? "+d2h" : "", get_sec() - t1);
   };
 
-  // ---- pipeline: parse batch i into stage[i&1] while the GPU thread works on batch i-1 ----
+  // ---- pipeline: parse batch i into stage[i % (G+1)] while the GPU threads work on batches i-1 .. i-G ----
   vector<size_t> retry_files; vector<uint64_t> retry_need;
-  std::thread worker;
   size_t done_files = 0, bi = 0;
+  uint32_t next_row = 0;
   for (int round = 0; round < 2; round++) {  // round 1: files whose slot guess was too small (gzip ISIZE)
     for (const Batch& b : batches) {
       const double t0 = get_sec();
-      char* buf = stage[bi & 1];
+      char* buf = stage[bi % NSTAGE];
       vector<uint64_t> need(b.files.size(), 0);
 #pragma omp parallel for num_threads(job.threads) schedule(dynamic)
       for (long q = 0; q < (long)b.files.size(); q++) {
@@ -260,16 +342,25 @@ static void sketch_files(rtc_ctx* ctx, const string& inputFile, const SketchJob&
         memset(dst + used, 'N', b.slot_len[q] - used);  // no k-mers in the gap, nor in dropped genomes
       }
       memset(buf + b.bytes, 'N', 64);
-      for (size_t q = 0; q < b.files.size(); q++) if (need[q]) { retry_files.push_back(b.files[q]); retry_need.push_back(need[q]); }
+      uint32_t nkept = 0;
+      for (size_t q = 0; q < b.files.size(); q++) {
+        if (need[q]) { retry_files.push_back(b.files[q]); retry_need.push_back(need[q]); }
+        if (res[b.files[q]].kept) { nkept++; if (round == 0) row_file.push_back(b.files[q]); }
+      }
+      if (!retry_files.empty()) resident_ok.store(false);  // retried files arrive out of list order: ids are no longer row numbers
       if (verbose) fprintf(stderr, "[parse] batch %zu: %zu files, %.2f GB in %.3fs\n", bi, b.files.size(), b.bytes / 1e9, get_sec() - t0);
-      if (worker.joinable()) worker.join();
+      Gpu& gp = gpus[bi % G];
+      if (gp.worker.joinable()) gp.worker.join();
       if (shuffle_thread.joinable()) shuffle_thread.join();
       const Batch* bp = &b;
-      worker = std::thread([&gpu_batch, bp, buf]() { gpu_batch(*bp, buf); });
+      const long row0 = round == 0 ? (long)next_row : -1;
+      if (round == 0) { placed.push_back(Placed{next_row, nkept, (int)(bi % G)}); next_row += nkept; }
+      Gpu* gpp = &gp;
+      gp.worker = std::thread([&gpu_batch, gpp, bp, buf, row0]() { gpu_batch(*gpp, *bp, buf, row0); });
       for (size_t q = 0; q < b.files.size(); q++, done_files++) if (done_files % 10000 == 0) cerr << "---finished sketching: " << done_files << " genomes" << endl;
       bi++;
     }
-    if (worker.joinable()) worker.join();
+    for (Gpu& g : gpus) if (g.worker.joinable()) g.worker.join();
     if (round == 1 || retry_files.empty()) break;
     batches = plan(retry_files, retry_need);
     maxb = 0;
@@ -282,14 +373,51 @@ static void sketch_files(rtc_ctx* ctx, const string& inputFile, const SketchJob&
   const double tf0 = get_sec();
   if (pinned) free_stage();
   else {  // returning GBs of touched pages to the kernel takes a while: do it beside the clustering
-    char* s0 = stage[0]; char* s1 = stage[1];
-    stage[0] = stage[1] = nullptr;
-    std::thread([s0, s1]() { free(s0); free(s1); }).detach();
+    vector<char*> old = stage;
+    for (auto& p : stage) p = nullptr;
+    std::thread([old]() { for (char* p : old) free(p); }).detach();
   }
-  // The device staging buffer stays allocated until the process ends: hipFree of a multi-GB buffer
+  // The device staging buffers stay allocated until the process ends: hipFree of a multi-GB buffer
   // costs ~0.4 s here and the clustering phase needs far less than the 288 GB that are there.
-  (void)d_seq;
   if (verbose) fprintf(stderr, "[free]  host staging %.3fs\n", get_sec() - tf0);
+
+  rs.ok = resident_ok.load();
+  if (!rs.ok) {
+    // fall back to the host vectors: pull the batches whose rows were left in HBM only
+    for (const Placed& pl : placed) {
+      if (!pl.rows || !gpus[pl.gpu].d_sk || res[row_file[pl.row0]].on_host) continue;
+      Gpu& gp = gpus[pl.gpu];
+      vector<unsigned char> out((size_t)pl.rows * rs.stride * rs.width);
+      CHECK(gp.ctx, rtc_copy_d2h(gp.ctx, out.data(), (char*)gp.d_sk + (size_t)pl.row0 * rs.stride * rs.width, out.size()));
+      for (uint32_t g = 0; g < pl.rows; g++) {
+        FileResult& r = res[row_file[pl.row0 + g]];
+        const uint32_t c = rs.counts[pl.row0 + g];
+        if (rs.width == 8) { const uint64_t* q = (const uint64_t*)out.data() + (size_t)g * rs.stride; r.h64.assign(q, q + c); }
+        else { const uint32_t* q = (const uint32_t*)out.data() + (size_t)g * rs.stride; r.h32.assign(q, q + c); }
+        r.on_host = true;
+      }
+    }
+    for (Gpu& g : gpus) {
+      if (g.d_sk) CHECK(g.ctx, rtc_dev_free(g.ctx, g.d_sk));
+      if (g.d_cnt) CHECK(g.ctx, rtc_dev_free(g.ctx, g.d_cnt));
+      g.d_sk = nullptr; g.d_cnt = nullptr;
+    }
+  } else if (G > 1) {
+    // ---- share: every batch's rows travel from the GPU that sketched them to all others (RCCL broadcast) ----
+    const double ts0 = get_sec();
+    on_all_gpus(gpus, [&](size_t g) {
+      Gpu& gp = gpus[g];
+      for (const Placed& pl : placed) {
+        if (!pl.rows) continue;
+        CHECK(gp.ctx, rtc_comm_broadcast(gp.comm, (char*)gp.d_sk + (size_t)pl.row0 * rs.stride * rs.width,
+                                         (size_t)pl.rows * rs.stride * rs.width, pl.gpu));
+        CHECK(gp.ctx, rtc_comm_broadcast(gp.comm, gp.d_cnt + pl.row0, (size_t)pl.rows * 4, pl.gpu));
+      }
+      CHECK(gp.ctx, rtc_ctx_sync(gp.ctx));
+    });
+    if (verbose) fprintf(stderr, "[share] %zu batches over %zu GPUs (%s) in %.3fs\n", placed.size(), G, rtc_comm_backend(gpus[0].comm), get_sec() - ts0);
+  }
+  rs.counts.resize(next_row);
 
   // ---- assemble in list order ----
   for (size_t i = 0; i < nfiles; i++) {
@@ -332,6 +460,7 @@ struct Options {
   double threshold = 0.05;
   int kmerSize = 19, sketchSize = 1000, containCompress = 1000, drlevel = 3;
   uint64_t minLen = 10000;
+  string gpus;  // --gpus / RTC_GPUS: "all" (default), a count, or a comma list of device ordinals
 };
 
 static void unsupported(const char* what) {
@@ -357,6 +486,7 @@ static Options parse(int argc, char** argv) {
     else if (a == "--presketched") { o.folder_path = need(i); o.has_presketched = true; }
     else if (a == "--fast") o.is_fast = true;
     else if (a == "--drlevel") o.drlevel = atoi(need(i));
+    else if (a == "--gpus") o.gpus = need(i);
     else if (a == "--inverted-index") { /* always on, as in the reference (src/main.cpp:104,129) */ }
 #ifndef GREEDY_CLUST
     else if (a == "--premsted") { o.folder_path = need(i); o.has_premsted = true; }
@@ -369,7 +499,7 @@ static Options parse(int argc, char** argv) {
 #endif
       puts("  -t,--threads N  -m,--min-length N  -c,--containment N  -k,--kmer-size N  -s,--sketch-size N\n"
            "  -l,--list  -e,--no-save  -d,--threshold X  -o,--output FILE  -i,--input FILE\n"
-           "  --presketched DIR  --fast  --drlevel N"
+           "  --presketched DIR  --fast  --drlevel N  --gpus all|N|i,j,.. (default all visible MI355X)"
 #ifndef GREEDY_CLUST
            "  --premsted DIR"
 #endif
@@ -421,8 +551,38 @@ int main(int argc, char** argv) {
   }
 #endif
 
-  rtc_ctx* ctx = nullptr;
-  { int st = rtc_ctx_create(0, &ctx); if (st != RTC_OK) { fprintf(stderr, "ERROR: no MI355X context: %s\n", rtc_last_error(nullptr)); return 1; } }
+  // ---- GPUs: one context (and one host thread when it works) per device; RCCL communicators among them ----
+  vector<Gpu> gpus;
+  {
+    string spec = o.gpus.empty() ? (getenv("RTC_GPUS") ? getenv("RTC_GPUS") : "all") : o.gpus;
+    const int ndev = rtc_device_count();
+    vector<int> devs;
+    if (spec == "all") for (int d = 0; d < ndev; d++) devs.push_back(d);
+    else if (spec.find(',') == string::npos && atoi(spec.c_str()) > 0 && spec.find_first_not_of("0123456789") == string::npos) {
+      const int want = atoi(spec.c_str());
+      if (want > ndev) { fprintf(stderr, "ERROR: --gpus %d but only %d GPU(s) are visible\n", want, ndev); return 1; }
+      for (int d = 0; d < want; d++) devs.push_back(d);
+    } else {
+      size_t p0 = 0;
+      while (p0 <= spec.size()) { size_t p1 = spec.find(',', p0); if (p1 == string::npos) p1 = spec.size(); if (p1 > p0) devs.push_back(atoi(spec.substr(p0, p1 - p0).c_str())); p0 = p1 + 1; }
+    }
+    if (devs.empty()) { fprintf(stderr, "ERROR: no MI355X context: %s (%d devices)\n", rtc_last_error(nullptr), ndev); return 1; }
+    gpus.resize(devs.size());
+    vector<rtc_ctx*> ctxs;
+    for (size_t g = 0; g < devs.size(); g++) {
+      int st = rtc_ctx_create(devs[g], &gpus[g].ctx);
+      if (st != RTC_OK) { fprintf(stderr, "ERROR: no MI355X context on device %d: %s\n", devs[g], rtc_last_error(nullptr)); return 1; }
+      ctxs.push_back(gpus[g].ctx);
+    }
+    if (gpus.size() > 1) {
+      vector<rtc_comm*> comms(gpus.size(), nullptr);
+      CHECK(ctxs[0], rtc_comm_init_all(ctxs.data(), (int)ctxs.size(), comms.data()));
+      for (size_t g = 0; g < gpus.size(); g++) gpus[g].comm = comms[g];
+      fprintf(stderr, "-----use %zu GPUs (%s exchange)\n", gpus.size(), rtc_comm_backend(comms[0]));
+    }
+  }
+  rtc_ctx* ctx = gpus[0].ctx;
+  Resident rs;
 
   vector<GenomeInfo> genomes;
   MinHashSketchFile mh; KssdSketchFile ks;
@@ -454,7 +614,7 @@ int main(int argc, char** argv) {
     job.kssd = o.is_fast; job.kmerSize = o.kmerSize; job.sketchSize = o.sketchSize; job.isContainment = o.isContainment;
     job.containCompress = o.containCompress; job.drlevel = o.drlevel; job.minLen = o.minLen; job.threads = o.threads;
     if (getenv("RTC_VERBOSE")) fprintf(stderr, "[tune]  cal_size + tune_parameters in %.3fs\n", get_sec() - t0);
-    sketch_files(ctx, o.inputFile, job, genomes, &mh, &ks);
+    sketch_files(gpus, o.inputFile, job, genomes, &mh, &ks, rs, !o.noSave);
     mh.kmerSize = o.kmerSize; mh.isContainment = o.isContainment; mh.containCompress = o.containCompress; mh.sketchSize = o.sketchSize;
     cerr << "-----the size of sketches (number of genomes or sequences) is: " << genomes.size() << endl;
     double t1 = get_sec();
@@ -474,18 +634,22 @@ int main(int argc, char** argv) {
   double t2 = get_sec();
 #ifdef GREEDY_CLUST
   // ---- clust-greedy: compute_clusters GREEDY branch (src/sub_command.cpp:2894-2922, :1963-1986) ----
-  vector<uint32_t> size_cfg;
+  vector<uint32_t> size_cfg, kssd_order;
   if (o.is_fast) {
     // src/greedy.cpp:594-597: sort by hash count, descending, comparator without tie-break
     vector<size_t> perm(genomes.size());
     iota(perm.begin(), perm.end(), 0);
-    auto cnt = [&](size_t i) { return ks.use64 ? ks.h64[i].size() : ks.h32[i].size(); };
+    auto cnt = [&](size_t i) { return rs.ok ? (size_t)rs.counts[i] : (ks.use64 ? ks.h64[i].size() : ks.h32[i].size()); };
     struct Item { size_t idx; size_t c; };
     vector<Item> items(genomes.size());
     for (size_t i = 0; i < items.size(); i++) items[i] = Item{i, cnt(i)};
     std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.c > b.c; });
     vector<GenomeInfo> g2; KssdSketchFile k2; k2.info = ks.info; k2.use64 = ks.use64;
-    for (const Item& it : items) { g2.push_back(genomes[it.idx]); if (ks.use64) k2.h64.push_back(ks.h64[it.idx]); else k2.h32.push_back(ks.h32[it.idx]); }
+    for (const Item& it : items) {
+      g2.push_back(genomes[it.idx]);
+      kssd_order.push_back((uint32_t)it.idx);  // resident rows are addressed through this order, not moved
+      if (!rs.ok) { if (ks.use64) k2.h64.push_back(ks.h64[it.idx]); else k2.h32.push_back(ks.h32[it.idx]); }
+    }
     genomes.swap(g2); ks = std::move(k2);
   } else {
     if (from_sketches) {
@@ -509,8 +673,10 @@ int main(int argc, char** argv) {
                                        : (uint32_t)mh.sketchSize;
     }
   }
+  // greedy has a serial dependency on the representative set: one GPU clusters (replicas only)
   DeviceSketches ds;
-  if (o.is_fast) upload_sketches(ctx, ks.use64 ? &ks.h64 : nullptr, ks.use64 ? nullptr : &ks.h32, ds);
+  if (rs.ok) resident_sketches(ctx, gpus[0], rs, o.is_fast ? &kssd_order : nullptr, ds);
+  else if (o.is_fast) upload_sketches(ctx, ks.use64 ? &ks.h64 : nullptr, ks.use64 ? nullptr : &ks.h32, ds);
   else upload_sketches(ctx, &mh.hashes, nullptr, ds);
   vector<int32_t> rep_of(genomes.size());
   uint32_t ncl = 0;
@@ -523,13 +689,38 @@ int main(int argc, char** argv) {
   cerr << "========time of greedyCluster is: " << get_sec() - t2 << "========" << endl;
 #else
   // ---- clust-mst: compute_clusters MST branch (src/sub_command.cpp:2924-3053, :1988-2152) ----
-  DeviceSketches ds;
-  if (o.is_fast) upload_sketches(ctx, ks.use64 ? &ks.h64 : nullptr, ks.use64 ? nullptr : &ks.h32, ds);
-  else upload_sketches(ctx, &mh.hashes, nullptr, ds);
   const int is_containment = o.is_fast ? (int)o.isContainment : (int)mh.isContainment;
   vector<rtc_edge> mst(genomes.size());
   uint64_t nedges = 0;
-  CHECK(ctx, rtc_mst(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, kmer_size, is_containment, o.threshold, mst.data(), &nedges));
+  const size_t G = gpus.size();
+  vector<DeviceSketches> dss(G);
+  on_all_gpus(gpus, [&](size_t g) {  // every GPU holds the complete sketch set (resident rows, or an upload of the loaded folder)
+    if (rs.ok) resident_sketches(gpus[g].ctx, gpus[g], rs, nullptr, dss[g]);
+    else if (o.is_fast) upload_sketches(gpus[g].ctx, ks.use64 ? &ks.h64 : nullptr, ks.use64 ? nullptr : &ks.h32, dss[g]);
+    else upload_sketches(gpus[g].ctx, &mh.hashes, nullptr, dss[g]);
+  });
+  if (G == 1) {
+    const DeviceSketches& ds = dss[0];
+    CHECK(ctx, rtc_mst(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, kmer_size, is_containment, o.threshold, mst.data(), &nedges));
+  } else {
+    // N x N row-sharded across the GPUs, one all-reduce per Boruvka round; every rank ends with the same forest
+    vector<vector<rtc_edge>> out(G, vector<rtc_edge>(genomes.size()));
+    vector<uint64_t> ne(G, 0);
+    vector<rtc_shard_stats> stt(G);
+    on_all_gpus(gpus, [&](size_t g) {
+      const DeviceSketches& ds = dss[g];
+      CHECK(gpus[g].ctx, rtc_mst_sharded(gpus[g].ctx, gpus[g].comm, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, kmer_size,
+                                         is_containment, o.threshold, out[g].data(), &ne[g], &stt[g]));
+    });
+    for (size_t g = 1; g < G; g++)
+      if (ne[g] != ne[0] || memcmp(out[g].data(), out[0].data(), ne[0] * sizeof(rtc_edge)) != 0) { fprintf(stderr, "ERROR: GPU %zu ended with a different forest\n", g); return 1; }
+    nedges = ne[0];
+    mst.swap(out[0]);
+    if (getenv("RTC_VERBOSE"))
+      for (size_t g = 0; g < G; g++)
+        fprintf(stderr, "[mst gpu %zu] rows %u..%u, %llu candidate edges, pair %.2f ms, boruvka %.2f ms (%u rounds)\n", g, stt[g].row0, stt[g].row1,
+                (unsigned long long)stt[g].cand_edges, stt[g].pair_ms, stt[g].mst_ms, stt[g].rounds);
+  }
   mst.resize(nedges);
   double t3 = get_sec();
   cerr << "========time of generateMST is: " << t3 - t2 << "========" << endl;
@@ -540,6 +731,7 @@ int main(int argc, char** argv) {
   }
   cluster_from_mst(mst, genomes, sketchByFile, o.outputFile, o.threshold);
 #endif
-  rtc_ctx_destroy(ctx);
+  for (Gpu& g : gpus) { if (g.comm) rtc_comm_destroy(g.comm); }
+  for (Gpu& g : gpus) rtc_ctx_destroy(g.ctx);
   return 0;
 }

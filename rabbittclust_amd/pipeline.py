@@ -58,6 +58,23 @@ class TorchComm:
         return self.dist.all_gather_into_tensor(out, inp, async_op=async_op)
 
 
+class NativeComm:
+    """The same collectives through the C ABI's own RCCL communicator (rtc_comm_*): what the C++ hosts
+    use.  With it MstPipeline.step runs the multi-GPU phases as two C calls
+    (rtc_sketch_minhash_sharded, rtc_mst_sharded)."""
+
+    def __init__(self, comm):
+        self.c, self.rank, self.world, self.dist = comm, comm.rank, comm.size, None
+
+    active = True
+
+    def all_reduce_min(self, t):
+        self.c.all_reduce(t, "min")
+
+    def all_reduce_max(self, t):
+        self.c.all_reduce(t, "max")
+
+
 class HipBoruvkaBackend:
     """Per-round primitives on this rank's candidate edges (device tensors, HIP kernels)."""
 
@@ -320,7 +337,53 @@ class MstPipeline:
         return out[: len(sel)]
 
     # ---- one step ---------------------------------------------------------------------------------
+    def step_native(self, seq, off, sizes=None):
+        """The step with both multi-GPU phases behind the C ABI (NativeComm)."""
+        ctx, comm = self.ctx, self.comm.c
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        if self.mode == "kssd":
+            loc = ctx.sketch_kssd(seq, off, self.shuffled_dim, kmer_size=self.k, drlevel=self.drlevel)
+            ev[1].record()
+            n_local = loc.n
+            stride = loc.hashes.numel() // max(n_local, 1)
+            v = comm.all_reduce_host([stride, n_local, -n_local], "max")
+            if int(v[1]) != n_local or int(-v[2]) != n_local:
+                raise ValueError("multi-GPU step: ranks hold different genome counts")
+            gstride, n = int(v[0]), comm.size * n_local
+            g_h = torch.zeros((n, gstride), dtype=loc.hashes.dtype, device=ctx.device)
+            g_l = torch.zeros(n, dtype=torch.int32, device=ctx.device)
+            g_h[comm.rank * n_local:(comm.rank + 1) * n_local, :stride] = loc.hashes.view(n_local, stride)
+            g_l[comm.rank * n_local:(comm.rank + 1) * n_local] = loc.len
+            comm.gather_rows(g_h, n_local, 0, n_local)
+            comm.gather_rows(g_l, n_local, 0, n_local)
+            start = torch.arange(n, dtype=torch.int64, device=ctx.device) * gstride
+            sk = SketchSet(g_h.view(-1), start, g_l, loc.width, loc.k, "kssd")
+        else:
+            sk = ctx.sketch_minhash_sharded(comm, seq, off, k=self.k, size=self.s, sizes=sizes)
+            ev[1].record()
+        ev[2].record()
+        mst, st = ctx.mst_sharded(comm, sk, self.threshold, self.is_containment)
+        ev[3].record()
+        torch.cuda.synchronize()
+        self.last_sketches, self.last_mst = sk, mst
+        row0, row1 = int(st.row0), int(st.row1)
+        pairs_local = (row1 * (row1 - 1) - row0 * (row0 - 1)) // 2 if row1 > 0 else 0
+        return {
+            "sketch_ms": ev[0].elapsed_time(ev[1]),
+            "gather_ms": ev[1].elapsed_time(ev[2]),
+            "pair_ms": float(st.pair_ms),
+            "mst_ms": float(st.mst_ms),
+            "dist_ms": ev[2].elapsed_time(ev[3]),
+            "pairs_local": float(pairs_local),
+            "cand_edges": float(st.cand_edges),
+            "boruvka_rounds": float(st.rounds),
+            "mst_edges": float(len(mst)),
+        }
+
     def step(self, seq, off, sizes=None):
+        if isinstance(self.comm, NativeComm):
+            return self.step_native(seq, off, sizes)
         ctx = self.ctx
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()

@@ -302,3 +302,30 @@ def test_cli_edge_cases(oracle, tmp_path):
     # a missing file: the reference's message and exit(1)
     _, err = run([paths[0], os.path.join(tmp, "does_not_exist.fna")], expect_ok=False)
     assert "cannot open the genome file" in err
+
+
+def test_clust_mst_config1_kmer_override_64_genomes(oracle, tmp_path):
+    """BASELINE config 1: 64 x 1 Mbp, `-k 21 -s 1000`.  tune_parameters replaces 21 by the recommended
+    17 (21 > 17 + 3, src/sub_command.cpp:2414-2430): the hash.sketch header must say k = 17 and sketches,
+    MST weights and clusters must equal the oracle's at k = 17."""
+    tmp = str(tmp_path)
+    L = 1_000_000
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 8, 8, L, seed=8)
+    out = os.path.join(tmp, "c1.out")
+    err = _run([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "1000", "-d", "0.05", "-t", "4", "-o", out], tmp)
+    assert "17" in err  # the override is announced
+    folder = [os.path.join(tmp, d) for d in os.listdir(tmp) if os.path.isdir(os.path.join(tmp, d)) and d[:2] == "20"][0]
+    hdr, got_sk = _read_hash_sketch(folder)
+    assert hdr == (0, 17, False, 1000)
+    off = np.arange(len(seqs) + 1, dtype=np.uint64) * L
+    want_sk = oracle.sketch_minhash_batch(np.concatenate(seqs), off, 17, 1000)
+    assert len(got_sk) == 64 and all(np.array_equal(a, b) for a, b in zip(got_sk, want_sk))
+    flat, start, lens = oracle.to_csr(want_sk)
+    want_mst = oracle.mst(flat, start, lens, 17, 0, 0.05)
+    got_mst = _read_edges(folder)
+    assert np.array_equal(np.sort(got_mst["dist"]).view(np.uint64), np.sort(want_mst["dist"]).view(np.uint64))
+    assert _partition(_parse_clusters(out)) == _partition(oracle.forest_clusters(want_mst, 0.05, 64))
+    # the tuner itself agrees with the oracle's restatement on this input
+    size = os.path.getsize(paths[0])
+    t = oracle.tune_parameters(0, 1, 0, 1, 21, 0.05, 1000, 1000, size, size, size)
+    assert t.ok and t.kmer_size == 17

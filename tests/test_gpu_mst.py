@@ -350,20 +350,38 @@ def test_pipeline_multi_gpu_code_path_on_one_gpu(ctx, oracle):
     assert all(np.array_equal(a, b) for a, b in zip(pipe.last_sketches.to_host(), ref.last_sketches.to_host()))
 
 
-def test_bench_rccl_path_single_rank(tmp_path):
-    """bench.py under torch.distributed.run with one rank and RTC_FORCE_DIST=1: the all-gather and
-    the per-round all-reduces go through RCCL (backend "nccl") exactly as in the multi-GPU run."""
+@pytest.mark.parametrize("comm", ["native", "torch"])
+def test_bench_rccl_path_single_rank(tmp_path, comm):
+    """bench.py under torch.distributed.run with one rank and RTC_FORCE_DIST=1: the sketch gather and
+    the per-round all-reduces go through RCCL exactly as in the multi-GPU run -- through the C ABI's
+    own communicator (--comm native, forced onto RCCL for one rank) or torch.distributed's."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RTC_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, RTC_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", RTC_COMM_FORCE_RCCL="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", "29611", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1",
-           "--warmup", "1", "--genomes", "200", "--length", "200000", "--no-cpu-baseline"]
+           "127.0.0.1", "--master-port", "29611" if comm == "native" else "29612", os.path.join(root, "bench.py"), "--gpus", "1",
+           "--steps", "1", "--warmup", "1", "--genomes", "200", "--length", "200000", "--no-cpu-baseline", "--comm", comm]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["mst_edges"] > 0 and line["value"] > 0
     assert line["roofline"]["frac"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["collectives"].startswith("rtc_comm (rccl" if comm == "native" else "torch.distributed")
+
+
+def test_bench_kssd_mode_small(tmp_path):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "kssd", "--steps", "1", "--warmup", "0",
+                        "--genomes", "300", "--length", "300000", "--cpu-sample-genomes", "32"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["dtype"] == "u32" and line["mst_edges"] > 0 and line["roofline"]["kernel"] == "sketch_kssd_kernel"
+    assert line["cpu_baseline"]["value"] > 0 and "KSSD" in line["cpu_baseline"]["sample"]

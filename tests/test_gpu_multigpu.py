@@ -1,0 +1,240 @@
+"""GPU: the multi-GPU path behind the C ABI on a one-GPU box.
+
+RCCL refuses two ranks on one device, so `rtc_comm_init_all` over two contexts of the same device
+uses its in-process exchange; everything above the exchange -- canonical sketch blocks, two-part
+gather, triangle row ranges, per-round all-reduce + device union (rtc_mst_sharded), the CLI's
+`--gpus 0,0` mode -- is the code that runs with RCCL on distinct GPUs.  The RCCL calls themselves are
+driven with one rank (RTC_COMM_FORCE_RCCL=1): ncclAllReduce and the grouped in-place ncclBroadcast."""
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "rabbittclust_amd", "bin")
+
+
+def _threads(fns):
+    err, out = [], [None] * len(fns)
+
+    def run(i):
+        try:
+            out[i] = fns[i]()
+        except BaseException as e:  # noqa: BLE001 -- reported to the main thread
+            err.append(e)
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(len(fns))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not any(t.is_alive() for t in ts), "a rank hung"
+    if err:
+        raise err[0]
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("fixed", [True, False])
+def test_sharded_step_in_process_ranks_equal_single_gpu(oracle, world, fixed):
+    """world contexts on device 0, one host thread each: sharded sketch + gather + sharded MST.  Every
+    rank must end with the global sketches in canonical order and the forest of the single-GPU run."""
+    import torch
+    from rabbittclust_amd import api
+    ctxs = [api.Context(0) for _ in range(world)]
+    comms = api.Comm.init_all(ctxs)
+    assert [c.rank for c in comms] == list(range(world)) and all(c.backend == "in-process" for c in comms)
+    n_local, L, s = 40, 50_000, 300
+    descs = [api.synth_family_descs(n_local // 5, 5, global_seed=100 + 7 * (r // 2)) for r in range(world)]  # ranks 0/1 share families
+    off = np.arange(n_local + 1, dtype=np.uint64) * L
+    seqs = [ctxs[r].synth_genomes(descs[r], off) for r in range(world)]
+    sizes = None if fixed else [np.array([200 + 25 * ((g + r) % 5) for g in range(n_local)], dtype=np.uint32) for r in range(world)]
+    torch.cuda.synchronize()
+
+    def rank_fn(r):
+        def f():
+            sk = ctxs[r].sketch_minhash_sharded(comms[r], seqs[r], off, k=21, size=s, sizes=None if fixed else sizes[r])
+            mst, st = ctxs[r].mst_sharded(comms[r], sk, 0.05)
+            ctxs[r].sync()
+            return sk.to_host(), mst, (st.row0, st.row1, st.cand_edges, st.rounds, st.s_fixed)
+        return f
+
+    res = _threads([rank_fn(r) for r in range(world)])
+    # reference: everything on one context
+    one = api.Context(0)
+    want_sk = []
+    for r in range(world):
+        want_sk += one.sketch_minhash(seqs[r], off, k=21, size=s, sizes=None if fixed else sizes[r]).to_host()
+    for r in range(world):
+        assert len(res[r][0]) == world * n_local
+        assert all(np.array_equal(a, b) for a, b in zip(res[r][0], want_sk)), f"rank {r}: gathered sketches differ"
+    dev = api.SketchSet.from_host(want_sk, one.device, k=21)
+    want_mst = one.mst(dev, 0.05)
+    flat, start, lens = oracle.to_csr(want_sk)
+    omst = oracle.mst(flat, start, lens, 21, 0, 0.05)
+    assert np.array_equal(np.sort(want_mst["dist"]).view(np.uint64), np.sort(omst["dist"]).view(np.uint64))
+    rows = []
+    for r in range(world):
+        assert np.array_equal(res[r][1], want_mst), f"rank {r}: forest differs from the single-GPU forest"
+        rows.append(res[r][2][:2])
+        assert (res[r][2][4] == s) == fixed
+    assert rows[0][0] == 0 and rows[-1][1] == world * n_local and all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+    assert sum(x[2][2] for x in res) > 0
+    for c in comms:
+        c.close()
+    for c in ctxs + [one]:
+        c.close()
+
+
+def test_rccl_calls_single_rank(oracle):
+    """One rank, communicator forced through RCCL: ncclCommInitRank, ncclAllReduce(MIN/MAX) and the
+    grouped in-place ncclBroadcast run on the GPU; the sharded step equals rtc_mst."""
+    import torch
+    from rabbittclust_amd import api, pipeline
+    os.environ["RTC_COMM_FORCE_RCCL"] = "1"
+    try:
+        ctx = api.Context(0)
+        comm = api.Comm.init_rank(ctx, 1, 0, api.Comm.unique_id(ctx.lib))
+    finally:
+        del os.environ["RTC_COMM_FORCE_RCCL"]
+    assert comm.backend == "rccl" and comm.size == 1
+    t = torch.tensor([5, -3, 1 << 40], dtype=torch.int64, device=ctx.device)
+    comm.all_reduce(t, "min"); comm.all_reduce(t, "max")
+    assert t.tolist() == [5, -3, 1 << 40]
+    assert comm.all_reduce_host([7, -2], "max").tolist() == [7, -2]
+    desc = api.synth_family_descs(8, 5, global_seed=3)
+    L = 60_000
+    off = np.arange(len(desc) + 1, dtype=np.uint64) * L
+    seq = ctx.synth_genomes(desc, off)
+    pipe = pipeline.MstPipeline(ctx, k=21, sketch_size=400, threshold=0.05, comm=pipeline.NativeComm(comm))
+    st = pipe.step(seq, off)
+    ref = pipeline.MstPipeline(ctx, k=21, sketch_size=400, threshold=0.05)
+    ref.step(seq, off)
+    assert all(np.array_equal(a, b) for a, b in zip(pipe.last_sketches.to_host(), ref.last_sketches.to_host()))
+    assert np.array_equal(pipe.last_mst, ref.last_mst) and st["mst_edges"] == len(ref.last_mst) > 0
+    comm.close()
+    ctx.close()
+
+
+def test_native_kssd_step_in_process_ranks(oracle):
+    """--fast (KSSD) multi-GPU step: local sketch, stride agreement, gather, sharded u32 MST."""
+    import torch
+    from rabbittclust_amd import api, host, pipeline
+    world = 2
+    ctxs = [api.Context(0) for _ in range(world)]
+    comms = api.Comm.init_all(ctxs)
+    sd = host.generate_shuffle_dim(6)
+    n_local = 20
+    Ls = [150_000, 260_000]  # different lengths -> different local strides
+    seqs, offs = [], []
+    for r in range(world):
+        desc = api.synth_family_descs(4, 5, global_seed=50)  # same families on both ranks, different lengths: prefixes overlap
+        off = np.arange(n_local + 1, dtype=np.uint64) * Ls[r]
+        seqs.append(ctxs[r].synth_genomes(desc, off)); offs.append(off)
+    torch.cuda.synchronize()
+
+    def rank_fn(r):
+        def f():
+            pipe = pipeline.MstPipeline(ctxs[r], k=21, threshold=0.05, mode="kssd", shuffled_dim=sd, comm=pipeline.NativeComm(comms[r]))
+            pipe.step(seqs[r], offs[r])
+            return pipe.last_sketches.to_host(), pipe.last_mst
+        return f
+
+    res = _threads([rank_fn(r) for r in range(world)])
+    one = api.Context(0)
+    want = []
+    for r in range(world):
+        want += one.sketch_kssd(seqs[r], offs[r], sd, kmer_size=21, drlevel=3).to_host()
+    assert want[0].dtype == np.uint32
+    g0 = seqs[0][: Ls[0]].cpu().numpy()
+    assert np.array_equal(want[0], oracle.kssd_sketch(g0, 21, 3))
+    for r in range(world):
+        assert all(np.array_equal(a, b) for a, b in zip(res[r][0], want))
+    dev = api.SketchSet.from_host(want, one.device, k=22, kind="kssd", width=4)
+    ref = one.mst(dev, 0.05)
+    assert len(ref) > 0 and np.array_equal(res[0][1], ref) and np.array_equal(res[1][1], ref)
+    flat, start, lens = oracle.to_csr(want, dtype=np.uint32)
+    omst = oracle.mst(flat, start, lens, 22, 0, 0.05)
+    assert np.array_equal(np.sort(ref["dist"]).view(np.uint64), np.sort(omst["dist"]).view(np.uint64))
+    for c in comms:
+        c.close()
+    for c in ctxs + [one]:
+        c.close()
+
+
+def test_mismatched_ranks_are_reported(oracle):
+    """ranks bringing different genome counts must fail with RTC_ERR_ARG on every rank, not hang"""
+    import torch
+    from rabbittclust_amd import _lib, api
+    ctxs = [api.Context(0) for _ in range(2)]
+    comms = api.Comm.init_all(ctxs)
+    L = 30_000
+    ns = [10, 15]
+    seqs, offs = [], []
+    for r in range(2):
+        desc = api.synth_family_descs(ns[r] // 5, 5, global_seed=9)
+        off = np.arange(ns[r] + 1, dtype=np.uint64) * L
+        seqs.append(ctxs[r].synth_genomes(desc, off)); offs.append(off)
+    torch.cuda.synchronize()
+
+    def rank_fn(r):
+        def f():
+            try:
+                ctxs[r].sketch_minhash_sharded(comms[r], seqs[r], offs[r], k=21, size=100)
+            except _lib.RtcError as e:
+                return e.status
+            return 0
+        return f
+    assert _threads([rank_fn(0), rank_fn(1)]) == [_lib.RTC_ERR_ARG, _lib.RTC_ERR_ARG]
+
+
+def _cli(args, cwd, env=None):
+    r = subprocess.run(args, cwd=cwd, capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r.stderr
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_clust_mst_two_gpu_mode_equals_one_gpu(oracle, tmp_path, fast):
+    """clust-mst --gpus 0,0 (two contexts, two host threads, batches round-robin, share step, sharded MST)
+    must write byte-identical hash.sketch / edge.mst / cluster text to the --gpus 1 run; RTC_HOST_SKETCHES=1
+    (sketches uploaded from the host vectors instead of staying in HBM) as well."""
+    from test_gpu_cli import _write_family_fastas
+    tmp = str(tmp_path)
+    L = 1_800_000
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 4, 4, L, seed=12)
+    outs = {}
+    for tag, gpus, env in (("one", "1", {}), ("two", "0,0", {}), ("host", "0,0", {"RTC_HOST_SKETCHES": "1"})):
+        d = os.path.join(tmp, tag)
+        os.makedirs(d)
+        out = os.path.join(d, "res.out")
+        cmd = [os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-d", "0.05", "-t", "4", "--gpus", gpus, "-o", out]
+        cmd += ["--fast"] if fast else ["-s", "600"]
+        err = _cli(cmd, d, dict(env, RTC_BATCH_BYTES=str(5 << 20), RTC_VERBOSE="1"))  # 5 MiB batches: several per GPU
+        if tag != "one":
+            assert "use 2 GPUs (in-process exchange)" in err
+        folder = [os.path.join(d, x) for x in os.listdir(d) if os.path.isdir(os.path.join(d, x))][0]
+        files = sorted(f for f in os.listdir(folder) if "info" not in f)
+        outs[tag] = (open(out).read(), {f: open(os.path.join(folder, f), "rb").read() for f in files})
+    assert outs["one"][0] == outs["two"][0] == outs["host"][0]
+    assert outs["one"][1].keys() == outs["two"][1].keys()
+    for f in outs["one"][1]:
+        assert outs["one"][1][f] == outs["two"][1][f] == outs["host"][1][f], f
+    assert ("kssd.hash.sketch" if fast else "hash.sketch") in outs["one"][1] and "edge.mst" in outs["one"][1]
+
+
+def test_clust_mst_no_save_keeps_sketches_on_device(oracle, tmp_path):
+    """-e: nothing is written and no sketch travels to the host; the clusters equal the saving run's"""
+    from test_gpu_cli import _write_family_fastas, _parse_clusters, _partition
+    tmp = str(tmp_path)
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 3, 3, 1_800_000, seed=14)
+    a, b = os.path.join(tmp, "a.out"), os.path.join(tmp, "b.out")
+    err = _cli([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "500", "-d", "0.05", "-e", "-o", a], tmp, {"RTC_VERBOSE": "1"})
+    assert "sketch+d2h" not in err and "[gpu 0]" in err
+    assert not [d for d in os.listdir(tmp) if os.path.isdir(os.path.join(tmp, d))]
+    _cli([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "500", "-d", "0.05", "-o", b], tmp)
+    assert _partition(_parse_clusters(a)) == _partition(_parse_clusters(b))
+    assert open(a).read() == open(b).read()
