@@ -2,8 +2,8 @@
 //
 // Replaces Sketch::MinHash::{update,storeMinHashes} driven from src/SketchInfo.cpp:918-942,969
 // (reference tree paths).  One workgroup (512 lanes = 8 wave64) walks one *segment* of a genome:
-//   * every lane owns 76 consecutive k-mer end positions of a 38 KiB tile and reads its 112 bases
-//     (36 warm-up + 76 owned) straight from global memory as seven 16-byte loads, decoding four
+//   * every lane owns 76 consecutive k-mer end positions of a 38 KiB tile and reads its 96 bases
+//     (20 warm-up + 76 owned; 112 = 36 + 76 for k > 21) straight from global memory as 16-byte loads, decoding four
 //     bases at once and rolling the 2-bit forward / reverse-complement words;
 //   * MurmurHash3_x64_128 of the canonical k-mer's ASCII bytes is evaluated from the 2-bit word:
 //     the first multiplication of every input word comes out of LDS product tables (linearity of
@@ -30,14 +30,24 @@ constexpr int NWAVE = WG / 64;
 #endif
 constexpr int RUN_DW = RTC_RUN_DW;                    // dwords of owned bases per lane per tile
 constexpr int OWN = RUN_DW * 4;                       // k-mer end positions a lane owns per tile
-static_assert((RUN_DW + 9) % 4 == 0, "a lane's window must be whole 16-byte loads");
-constexpr int WARM_DW = 9;                            // 36 warm-up bases (k-1 <= 31); 9+19 dwords = seven 16-byte loads
+// warm-up dwords in front of a lane's owned run (they only roll the windows): k-1 bases rounded up so
+// that warm-up + run are whole 16-byte loads -- 5 (20 bases, six loads per tile) for the compile-time
+// k <= 21, 9 (36 bases >= 31, seven loads) otherwise
+#ifndef RTC_WARM_SHORT
+#define RTC_WARM_SHORT 1
+#endif
+__host__ __device__ constexpr int warm_dw(int kt) { return (RTC_WARM_SHORT && kt > 0 && kt <= 21) ? 5 : 9; }
+static_assert((RUN_DW + warm_dw(21)) % 4 == 0 && (RUN_DW + warm_dw(0)) % 4 == 0, "a lane's window must be whole 16-byte loads");
 constexpr int TILE_BASES = WG * RUN_DW * 4;           // bases per tile
 constexpr int STEP_APPENDS = WG * 4;                  // worst-case appends per dword iteration
 constexpr int MIN_ROOM = STEP_APPENDS;                // candidate room the buffer always offers
 constexpr uint64_t SENT = ~0ULL;
-constexpr size_t LUT_TABLE_BYTES = 256 * 8;           // one 256-entry u64 product table per 4 bases of k
-__host__ __device__ constexpr size_t lut_bytes(int k) { return (size_t)((k + 3) / 4) * LUT_TABLE_BYTES; }
+// hash tables in LDS (see kmer_hash_parts): per 8 bases of k one 256-entry table of 16-byte entries
+// (first four bases of the word) and, where the word has more than four bases, one of 4-byte entries
+constexpr size_t LUT_LO_BYTES = 256 * 16, LUT_HI_BYTES = 256 * 4;
+__host__ __device__ constexpr int lut_words(int k) { return (k + 7) / 8; }
+__host__ __device__ constexpr int lut_his(int k) { return (k + 3) / 8; }   // word w has a second half iff k > 8w + 4
+__host__ __device__ constexpr size_t lut_bytes(int k) { return (size_t)lut_words(k) * LUT_LO_BYTES + (size_t)lut_his(k) * LUT_HI_BYTES; }
 
 struct Segment {
   uint64_t g_begin, g_end;  // genome byte range in d_seq
@@ -68,14 +78,22 @@ typedef RTC_LDS uint64_t* lds_u64_ptr;
 typedef RTC_LDS Ctrl* lds_ctrl_ptr;
 typedef RTC_LDS unsigned char* lds_byte_ptr;
 struct MergeResult { uint32_t count; uint64_t T; };
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // plain vector (HIP's uint4 is a class, unusable through LDS pointers)
 
 // ---- MurmurHash3_x64_128 (first output word) of the canonical k-mer's ASCII bytes ----------------
-// The first operation MurmurHash3 applies to every 64-bit input word is a multiplication by a
-// constant (c1 for the k1 words, c2 for the k2 words).  Multiplication mod 2^64 is linear, so
-//     (bytes 0-3 | bytes 4-7 << 32) * c  =  LUT[d][codes of bytes 0-3] + LUT[d+1][codes of bytes 4-7]
-// with LUT[d][e] = ((ascii4(e) & bytemask_d) << 32*(d&1)) * c.  Eight 256-entry tables (16 KiB of
-// LDS, built once per workgroup for the runtime k) replace both the 2-bit -> ASCII expansion and
-// three of the ten 64x64 multiplies per k-mer; the lookups run on the LDS pipe beside the VALU.
+// MurmurHash3 turns every 64-bit input word w into  rotl(w * c, r) * c'  (c, r, c' = c1, 31, c2 for the
+// k1 words, c2, 33, c1 for the k2 words) before mixing it into the state.  With w = a | b << 32
+// (a = bytes 0-3, b = bytes 4-7 of the word) multiplication mod 2^64 gives
+//     S = w * c :   S.lo = lo(a * c),   S.hi = hi(a * c) + lo(b * c)   (one 32-bit add, no other carry)
+// and the rotation by 31 / 33 moves the two halves of S to DISJOINT bit ranges, so
+//     rotl(S, r) * c' = X(S.lo) * c' + Y(S.hi) * c'
+// where the first term depends on the word's first four bases only: it comes out of an LDS table
+// together with hi(a * c) (16-byte entries, one ds_read_b128), lo(b * c) out of a second table
+// (4-byte entries), and the second term is a 32 x 64-bit product:
+//     r = 31:  Y = S.hi >> 1 | (S.hi & 1) << 63   ->  (S.hi >> 1) * c' + (S.hi << 31) in the top word
+//     r = 33:  Y = S.hi << 1 (33 bits)            ->  (S.hi * c') << 1
+// i.e. 6 / 5 VALU instructions per word instead of 7 (add, two-instruction rotate, 64 x 64 multiply),
+// and no 2-bit -> ASCII expansion at all.  The tables are built once per workgroup for the runtime k.
 __device__ __forceinline__ uint64_t fmix64(uint64_t x) {
   x ^= x >> 33;
   x *= 0xff51afd7ed558ccdULL;
@@ -84,6 +102,18 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t x) {
   x ^= x >> 33;
   return x;
 }
+
+// fmix64 without its last xorshift (which changes the low word only): the high words of the two
+// halves decide almost every threshold test, the low words are finished on demand (mm_finish)
+__device__ __forceinline__ uint64_t fmix64_open(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  return x;
+}
+struct HashParts { uint64_t f1, f2; };  // hash = (f1 ^ f1 >> 33) + (f2 ^ f2 >> 33)
+__device__ __forceinline__ uint64_t mm_finish(const HashParts& p) { return (p.f1 ^ (p.f1 >> 33)) + (p.f2 ^ (p.f2 >> 33)); }
 
 constexpr uint64_t MM_C1 = 0x87c37b91114253d5ULL, MM_C2 = 0x4cf5ad432745937fULL;
 
@@ -110,18 +140,32 @@ __device__ __forceinline__ KParams make_kparams(int k, uint32_t seed) {
   return P;
 }
 
-// lut: [ceil(k/4)][256] u64 in LDS.  Called by all WG threads; the first 256 fill one column each.
-__device__ __forceinline__ void build_kmer_lut(lds_u64_ptr lut, int k) {
+// Called by all WG threads; the first 256 fill one column each.  Layout: lut_words(k) tables of
+// {u64 P, u32 AH, pad} at w * LUT_LO_BYTES, then lut_his(k) tables of u32 BL.
+__device__ __forceinline__ void build_kmer_lut(lds_byte_ptr lut, int k) {
   const uint32_t e = threadIdx.x;
   if (e >= 256) return;
   const uint32_t a4 = codes_to_ascii(e);
+  const uint32_t hi_base = (uint32_t)(lut_words(k) * LUT_LO_BYTES);
 #pragma unroll
-  for (int d = 0; d < 8; d++) {
-    const int nb = k - 4 * d;
-    if (nb <= 0) break;  // only ceil(k/4) tables exist
-    const uint32_t bm = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
-    const uint64_t v = (uint64_t)(a4 & bm) << (32 * (d & 1));
-    lut[d * 256 + e] = v * ((d & 2) ? MM_C2 : MM_C1);
+  for (int w = 0; w < 4; w++) {
+    const int nb = k - 8 * w;  // bytes of this word
+    if (nb <= 0) break;
+    const uint64_t c = (w & 1) ? MM_C2 : MM_C1;
+    const uint32_t am = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+    const uint64_t A = (uint64_t)(a4 & am) * c;
+    const uint32_t AL = (uint32_t)A, AH = (uint32_t)(A >> 32);
+    uint64_t P;
+    if (w & 1) P = (((uint64_t)(uint32_t)(AL << 1) << 32) | (uint64_t)(AL >> 31)) * MM_C1;   // rotl33 part of S.lo, times c1
+    else P = (((uint64_t)(AL >> 1) << 32) | ((uint64_t)(AL & 1u) << 31)) * MM_C2;           // rotl31 part of S.lo, times c2
+    typedef RTC_LDS u32x4* lds_u4_ptr;
+    const u32x4 ent = {(uint32_t)P, (uint32_t)(P >> 32), AH, 0u};
+    *(lds_u4_ptr)(lut + (size_t)w * LUT_LO_BYTES + (size_t)e * 16) = ent;
+    if (nb > 4) {
+      const uint32_t bm = nb >= 8 ? 0xffffffffu : ((1u << (8 * (nb - 4))) - 1u);
+      typedef RTC_LDS uint32_t* lds_u32_ptr;
+      *(lds_u32_ptr)(lut + hi_base + (size_t)w * LUT_HI_BYTES + (size_t)e * 4) = (a4 & bm) * (uint32_t)c;  // lo(b * c)
+    }
   }
 }
 
@@ -152,7 +196,7 @@ __device__ __forceinline__ uint64_t times5(uint64_t x) {
   return r;
 }
 
-// byte B of w, times 8 (the byte offset of a u64 table entry), as one SDWA shift
+// byte B of w, shifted left by `three` (the byte offset of a table entry), as one SDWA shift
 template <int B>
 __device__ __forceinline__ uint32_t byte_x8(uint32_t w, uint32_t three) {
   uint32_t r;
@@ -163,60 +207,78 @@ __device__ __forceinline__ uint32_t byte_x8(uint32_t w, uint32_t three) {
   return r;
 }
 
-__device__ __forceinline__ void mm_body(uint64_t& h1, uint64_t& h2, uint64_t k1m, uint64_t k2m) {
-  uint64_t k1 = rotl64c<31>(k1m) * MM_C2; h1 ^= k1;
-  h1 = rotl64c<27>(h1); h1 += h2; h1 = times5(h1) + 0x52dce729;
-  uint64_t k2 = rotl64c<33>(k2m) * MM_C1; h2 ^= k2;
-  h2 = rotl64c<31>(h2); h2 += h1; h2 = times5(h2) + 0x38495ab5;
+// rotl(S, 31) * c2 for a k1 word: e = {P.lo, P.hi, AH, -}, BL = lo(b * c1)
+__device__ __forceinline__ uint64_t word_k1(const u32x4 e, uint32_t BL) {
+  const uint32_t SH = e.z + BL, v = SH >> 1;
+  const uint64_t R = (uint64_t)v * (uint32_t)MM_C2 + __builtin_bit_cast(uint64_t, make_uint2(e.x, e.y));  // v_mad_u64_u32
+  const uint32_t hi = (uint32_t)(R >> 32) + v * (uint32_t)(MM_C2 >> 32) + (SH << 31);
+  return __builtin_bit_cast(uint64_t, make_uint2((uint32_t)R, hi));
+}
+// rotl(S, 33) * c1 for a k2 word
+__device__ __forceinline__ uint64_t word_k2(const u32x4 e, uint32_t BL) {
+  const uint32_t SH = e.z + BL;
+  const uint64_t Z0 = (uint64_t)SH * (uint32_t)MM_C1;
+  uint32_t cross = SH * (uint32_t)(MM_C1 >> 32);
+  asm("" : "+v"(cross));  // keep it a v_mul_lo_u32 + v_add_u32: fused into a second v_mad_u64_u32 it costs two extra moves
+  const uint64_t Z = __builtin_bit_cast(uint64_t, make_uint2((uint32_t)Z0, (uint32_t)(Z0 >> 32) + cross));
+  uint64_t r;
+  const uint64_t Pv = __builtin_bit_cast(uint64_t, make_uint2(e.x, e.y));
+  asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(r) : "v"(Z), "v"(Pv));
+  return r;
 }
 
 // x: canonical k-mer, 2 bits per base, first base in the top bits (canon << (64 - 2k))
-__device__ __forceinline__ uint64_t kmer_hash(uint64_t x, const KParams& P) {
+__device__ __forceinline__ HashParts kmer_hash_parts(uint64_t x, const KParams& P) {
   const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
   const int k = P.k;
-  // table d sits at byte offset d*2048 of the LDS allocation (constant offsets fold into ds_read);
-  // the entry offset is (code byte)*8, one SDWA shift each
-  // (the tables start at LDS address 0 -- checked at kernel entry -- so the LDS address is the offset)
-  typedef const RTC_LDS uint64_t* lds_u64_cptr;
-  const uint32_t three = 3;
-#define RTC_LUT(d, off) (*(lds_u64_cptr)(uintptr_t)((off) + (uint32_t)((d) * LUT_TABLE_BYTES)))
-  uint64_t A0 = RTC_LUT(0, byte_x8<3>(hi, three));
-  uint64_t B0 = 0, A1 = 0, B1 = 0;
-  if (k > 4) A0 += RTC_LUT(1, byte_x8<2>(hi, three));
-  if (k > 8) B0 = RTC_LUT(2, byte_x8<1>(hi, three));
-  if (k > 12) B0 += RTC_LUT(3, byte_x8<0>(hi, three));
-  if (k > 16) A1 = RTC_LUT(4, byte_x8<3>(lo, three));
-  if (k > 20) A1 += RTC_LUT(5, byte_x8<2>(lo, three));
-  if (k > 24) B1 = RTC_LUT(6, byte_x8<1>(lo, three));
-  if (k > 28) B1 += RTC_LUT(7, byte_x8<0>(lo, three));
-#undef RTC_LUT
+  // the tables start at LDS address 0 (checked at kernel entry), so an LDS address is a table offset:
+  // entry offset = code byte << 4 (16-byte entries) or << 2 (4-byte entries), one SDWA shift each;
+  // the table bases fold into the ds_read immediates
+  typedef const RTC_LDS u32x4* lds_u4_cptr;
+  typedef const RTC_LDS uint32_t* lds_u32_cptr;
+  const uint32_t four = 4, two = 2;
+  const uint32_t hi_base = (uint32_t)(lut_words(k) * LUT_LO_BYTES);
+#define RTC_LO(w, off) (*(lds_u4_cptr)(uintptr_t)((off) + (uint32_t)((w) * LUT_LO_BYTES)))
+#define RTC_HI(w, off) (*(lds_u32_cptr)(uintptr_t)((off) + hi_base + (uint32_t)((w) * LUT_HI_BYTES)))
+  uint64_t K0 = 0, K1 = 0, K2 = 0, K3 = 0;  // the words' contributions, already rotl(w * c, r) * c'
+  K0 = word_k1(RTC_LO(0, byte_x8<3>(hi, four)), k > 4 ? RTC_HI(0, byte_x8<2>(hi, two)) : 0u);
+  if (k > 8) K1 = word_k2(RTC_LO(1, byte_x8<1>(hi, four)), k > 12 ? RTC_HI(1, byte_x8<0>(hi, two)) : 0u);
+  if (k > 16) K2 = word_k1(RTC_LO(2, byte_x8<3>(lo, four)), k > 20 ? RTC_HI(2, byte_x8<2>(lo, two)) : 0u);
+  if (k > 24) K3 = word_k2(RTC_LO(3, byte_x8<1>(lo, four)), k > 28 ? RTC_HI(3, byte_x8<0>(lo, two)) : 0u);
+#undef RTC_LO
+#undef RTC_HI
   uint64_t h1 = P.seed, h2 = P.seed;
-  uint64_t t0 = A0, t1 = B0;  // tail words (already multiplied by c1 / c2)
+  uint64_t t0 = K0, t1 = K1;  // tail contributions
   if (k >= 16) {
     // first block with h1 == h2 == seed folded in: 5*(rotl27(seed ^ k1) + seed) + c = 5*rotl27(..) + (5*seed + c)
-    h1 = rotl64c<27>(h1 ^ (rotl64c<31>(A0) * MM_C2));
+    h1 = rotl64c<27>(h1 ^ K0);
     h1 = times5(h1) + (5ULL * P.seed + 0x52dce729ULL);
-    h2 = rotl64c<31>(h2 ^ (rotl64c<33>(B0) * MM_C1)) + h1;
+    h2 = rotl64c<31>(h2 ^ K1) + h1;
     h2 = times5(h2) + 0x38495ab5ULL;
-    t0 = A1; t1 = B1;
-    if (k == 32) { mm_body(h1, h2, A1, B1); t0 = 0; t1 = 0; }
+    t0 = K2; t1 = K3;
+    if (k == 32) {
+      h1 ^= K2; h1 = rotl64c<27>(h1); h1 += h2; h1 = times5(h1) + 0x52dce729;
+      h2 ^= K3; h2 = rotl64c<31>(h2); h2 += h1; h2 = times5(h2) + 0x38495ab5;
+      t0 = 0; t1 = 0;
+    }
   }
   const int tail = k & 15;
-  if (tail > 8) { h2 ^= rotl64c<33>(t1) * MM_C1; }
+  if (tail > 8) { h2 ^= t1; }
   if (tail > 0) {
     // h1 ^= k1; h1 ^= len: the low word as one three-input xor (v_bitop3_b32)
-    const uint64_t kt = rotl64c<31>(t0) * MM_C2;
-    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)h1, (uint32_t)kt, (uint32_t)k, 0x96);
-    const uint32_t hi = (uint32_t)(h1 >> 32) ^ (uint32_t)(kt >> 32);
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)h1, (uint32_t)t0, (uint32_t)k, 0x96);
+    const uint32_t hi = (uint32_t)(h1 >> 32) ^ (uint32_t)(t0 >> 32);
     h1 = __builtin_bit_cast(uint64_t, make_uint2(lo, hi));
   } else {
     h1 ^= (uint64_t)k;
   }
   h2 ^= (uint64_t)k;
   h1 += h2; h2 += h1;
-  h1 = fmix64(h1); h2 = fmix64(h2);
-  h1 += h2;
-  return P.use64 ? h1 : (h1 & 0xffffffffULL);
+  return HashParts{fmix64_open(h1), fmix64_open(h2)};
+}
+__device__ __forceinline__ uint64_t kmer_hash(uint64_t x, const KParams& P) {
+  const uint64_t h = mm_finish(kmer_hash_parts(x, P));
+  return P.use64 ? h : (h & 0xffffffffULL);
 }
 
 // ---- block-wide merge: sort buf[0..n), drop duplicates, keep the `s` smallest -----------------
@@ -344,8 +406,9 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
                                                             uint64_t* parts, uint32_t* pcnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int k = KT > 0 ? KT : k_arg;
+  constexpr int WARM_DW = warm_dw(KT);
   const lds_byte_ptr lds0 = (lds_byte_ptr)smem;
-  const lds_u64_ptr lut = (lds_u64_ptr)lds0;  // at LDS offset 0: table offsets become ds_read immediates
+  const lds_byte_ptr lut = lds0;  // at LDS offset 0: table offsets become ds_read immediates
   // kmer_hash addresses the tables by absolute LDS address; this kernel has no static LDS, so the
   // dynamic allocation starts at 0 -- trap rather than hash with wrong tables if that ever changes
   if ((uint32_t)(uintptr_t)lds0 != 0u) __builtin_trap();
@@ -420,7 +483,11 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
           }
           // (zero-initialised on purpose: left uninitialised, the generated code issues the tile loads in an
           // order that re-reads 40 % more of the input from the fabric -- measured, tools/pmc_runlen.sh)
+#ifdef RTC_CANON_NOINIT
+          uint64_t canon[4];
+#else
           uint64_t canon[4] = {0, 0, 0, 0};  // top-aligned (first base in bit 63); hashing dwords only
+#endif
           bool ok[4] = {false, false, false, false};  // slow path only; the fast path derives it on demand
           bool allok = false;  // wave-uniform: all four k-mers of every lane are valid and owned
           // ---- decode four bases at once ----
@@ -440,7 +507,7 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
             const uint64_t R = rc | ((uint64_t)rp << (2 * P.k));
             if (hashing) {
               // Scalar ownership test for the steady state: in a tile interior to the segment, a wave
-              // that has seen only valid bases since the tile began has run = 4d >= 36 >= k-1 in every
+              // that has seen only valid bases since the tile began has run = 4d >= 4*WARM_DW >= k-1 in every
               // lane, and every position of the tile is owned.  Anything else takes the per-lane test.
               allok = interior && clean;
               // the four windows are cut out of F / R already top-aligned (one shift + one mask each):
@@ -471,33 +538,9 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
             }
           }
           if (hashing) {  // wave-uniform
-            // four independent hash chains: their LDS table reads and multiplies overlap
-            uint64_t h[4];
-#pragma unroll
-#ifdef RTC_ABLATE_HASH  // timing experiment only: everything but MurmurHash3
-            for (int b = 0; b < 4; b++) h[b] = canon[b] * 0x9E3779B97F4A7C15ULL;
-#else
-            for (int b = 0; b < 4; b++) h[b] = kmer_hash(canon[b], P);
-#endif
-            // lanes that append, as wave masks (T is scalar: compares write the masks directly)
-            uint64_t m[4];
-            if (allok && T != SENT) {  // the steady state: one 64-bit compare per k-mer
-#pragma unroll
-              for (int b = 0; b < 4; b++) m[b] = __ballot(h[b] < T);
-            } else {
-#pragma unroll
-              for (int b = 0; b < 4; b++) {
-                const int rel = rel0 + b;
-                const bool okb = fast ? (run_in + b + 1 >= P.k && rel >= rel_lo && rel < rel_hi) : ok[b];
-                // T == SENT means "sketch not full yet": everything passes (also a hash == SENT)
-                m[b] = __ballot(okb && (h[b] < T || T == SENT));
-              }
-            }
-            if (lo1) {  // workgroup-uniform: later passes of a large sketch
-#pragma unroll
-              for (int b = 0; b < 4; b++) m[b] &= __ballot(h[b] >= lo1);
-            }
-            if (m[0] | m[1] | m[2] | m[3]) {
+            // appends the k-mers selected by the wave masks m[] (T is scalar: compares write the masks directly)
+            auto append = [&](const uint64_t (&m)[4], const uint64_t (&h)[4]) __attribute__((always_inline)) {
+              if (!(m[0] | m[1] | m[2] | m[3])) return;
 #pragma unroll
               for (int b = 0; b < 4; b++) {
                 const uint64_t bal = m[b];
@@ -512,6 +555,64 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
                   }
                 }
               }
+            };
+#ifdef RTC_ABLATE_HASH  // timing experiment only: everything but MurmurHash3
+            constexpr bool ablate = true;
+#else
+            constexpr bool ablate = false;
+#endif
+            const uint32_t Thi = (uint32_t)(T >> 32);
+            if (!ablate && allok && P.use64 && !lo1 && Thi != 0xffffffffu) {
+              // The steady state: hash = fin(f1) + fin(f2) where fin() touches the low word only, so
+              // hi(hash) = hi(f1) + hi(f2) + carry.  u = hi(f1) + hi(f2) + 1 (one v_add3) is hi(hash) or
+              // hi(hash) + 1: with u > hi(T) + 1 the hash cannot be below T -- one 32-bit compare per k-mer
+              // and the low words are never finished (T != SENT here since hi(T) != 2^32 - 1).  The few
+              // waves holding a possible candidate (hi(hash) <= hi(T): ~64 s / N of them) finish exactly.
+              // four independent hash chains: their LDS table reads and multiplies overlap
+              HashParts hp[4];
+#pragma unroll
+              for (int b = 0; b < 4; b++) hp[b] = kmer_hash_parts(canon[b], P);
+              const uint32_t Thi1 = Thi + 1u;
+              uint64_t cm = 0;
+#pragma unroll
+              for (int b = 0; b < 4; b++) {
+                const uint32_t u = (uint32_t)(hp[b].f1 >> 32) + (uint32_t)(hp[b].f2 >> 32) + 1u;
+                cm |= __ballot(u <= Thi1);
+              }
+              if (cm) {  // wave-uniform, rare
+                uint64_t h[4], m[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                  // (volatile: keeps the finishing arithmetic inside this branch -- left to itself the
+                  // compiler computes it speculatively for every k-mer, which is the cost being avoided)
+                  HashParts q = hp[b];
+                  asm volatile("" : "+v"(q.f1), "+v"(q.f2));
+                  h[b] = mm_finish(q);
+                  m[b] = __ballot(h[b] < T);
+                }
+                append(m, h);
+              }
+            } else {
+              uint64_t h[4], m[4];
+#pragma unroll
+              for (int b = 0; b < 4; b++) h[b] = ablate ? canon[b] * 0x9E3779B97F4A7C15ULL : kmer_hash(canon[b], P);
+              if (allok && T != SENT) {  // one 64-bit compare per k-mer
+#pragma unroll
+                for (int b = 0; b < 4; b++) m[b] = __ballot(h[b] < T);
+              } else {
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                  const int rel = rel0 + b;
+                  const bool okb = fast ? (run_in + b + 1 >= P.k && rel >= rel_lo && rel < rel_hi) : ok[b];
+                  // T == SENT means "sketch not full yet": everything passes (also a hash == SENT)
+                  m[b] = __ballot(okb && (h[b] < T || T == SENT));
+                }
+              }
+              if (lo1) {  // workgroup-uniform: later passes of a large sketch
+#pragma unroll
+                for (int b = 0; b < 4; b++) m[b] &= __ballot(h[b] >= lo1);
+              }
+              append(m, h);
             }
           }
         }
