@@ -420,7 +420,7 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
   const int t = threadIdx.x;
   const uint32_t lane = t & 63;
   const uint32_t s = sg.sketch_size;
-  const bool fastroll = k <= 28;  // 2k+8 bits fit the 64-bit extended window
+  const bool fastroll = true;     // four bases per step: 64-bit extended windows for k <= 28, 128-bit ones above
 
   // Sketch sizes beyond one LDS buffer are selected in passes of ascending hash ranges: pass p only
   // admits hashes above the largest one kept so far (lo1 = that hash + 1; 0 in the first pass).
@@ -503,26 +503,45 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
             const uint32_t pack = __builtin_amdgcn_udot4(codes4, 0x01041040u, 0u, false);
             const uint32_t rp = __builtin_amdgcn_udot4(codes4, 0x40100401u, 0u, false) ^ 0xffu;
             // bits of fwd above the window shift out when the windows are cut, so it carries unmasked
-            const uint64_t F = (fwd << 8) | pack;
-            const uint64_t R = rc | ((uint64_t)rp << (2 * P.k));
-            if (hashing) {
-              // Scalar ownership test for the steady state: in a tile interior to the segment, a wave
-              // that has seen only valid bases since the tile began has run = 4d >= 4*WARM_DW >= k-1 in every
-              // lane, and every position of the tile is owned.  Anything else takes the per-lane test.
-              allok = interior && clean;
-              // the four windows are cut out of F / R already top-aligned (one shift + one mask each):
-              // the order of two k-mers does not depend on the alignment, and the hash wants them there
-              const uint64_t topmask = P.kmask << P.lshift;
+            if (k > 28) {
+              // 2k + 8 bits do not fit 64: the same cuts on 128-bit extended windows (k = 29..32)
+              typedef unsigned __int128 u128;
+              const u128 F = ((u128)fwd << 8) | pack;
+              const u128 R = (u128)rc | ((u128)rp << (2 * P.k));
+              if (hashing) {
+                allok = interior && clean;
 #pragma unroll
-              for (int b = 0; b < 4; b++) {
-                const uint64_t f = (F << (P.lshift - 6 + 2 * b)) & topmask;   // lshift >= 8 in this path
-                const uint64_t r = (R << (P.lshift - 2 - 2 * b)) & topmask;
-                canon[b] = f < r ? f : r;
+                for (int b = 0; b < 4; b++) {
+                  const uint64_t f = (uint64_t)(F >> (6 - 2 * b)) & P.kmask;
+                  const uint64_t r = (uint64_t)(R >> (2 * b + 2)) & P.kmask;
+                  canon[b] = (f < r ? f : r) << P.lshift;
+                }
               }
+              fwd = (uint64_t)F;
+              rc = (uint64_t)(R >> 8);
+              run += 4;
+            } else {
+              const uint64_t F = (fwd << 8) | pack;
+              const uint64_t R = rc | ((uint64_t)rp << (2 * P.k));
+              if (hashing) {
+                // Scalar ownership test for the steady state: in a tile interior to the segment, a wave
+                // that has seen only valid bases since the tile began has run = 4d >= 4*WARM_DW >= k-1 in every
+                // lane, and every position of the tile is owned.  Anything else takes the per-lane test.
+                allok = interior && clean;
+                // the four windows are cut out of F / R already top-aligned (one shift + one mask each):
+                // the order of two k-mers does not depend on the alignment, and the hash wants them there
+                const uint64_t topmask = P.kmask << P.lshift;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                  const uint64_t f = (F << (P.lshift - 6 + 2 * b)) & topmask;   // lshift >= 8 in this path
+                  const uint64_t r = (R << (P.lshift - 2 - 2 * b)) & topmask;
+                  canon[b] = f < r ? f : r;
+                }
+              }
+              fwd = F;        // masked by whoever needs exactly 2k bits (the per-base path below)
+              rc = R >> 8;    // R < 2^(2k+8) by construction, so this is already < 2^(2k)
+              run += 4;
             }
-            fwd = F;        // masked by whoever needs exactly 2k bits (the per-base path below)
-            rc = R >> 8;    // R < 2^(2k+8) by construction, so this is already < 2^(2k)
-            run += 4;
           } else {
 #pragma unroll
             for (int b = 0; b < 4; b++) {
@@ -868,9 +887,9 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     d_pcnt = (uint32_t*)((char*)ws1 + part_elems_max * 8);
   }
 
-  // compile-time k for 16..28: the values the reference's tune_parameters lands on for Mbp..Gbp
-  // genomes (recommended k = ceil(log4(maxSize * 9999)) = 17..23, accepted up to +3) and its
-  // default 21; anything else takes the runtime-k kernel (k >= 29 also leaves the 64-bit window path)
+  // compile-time k for 16..32: the values the reference's tune_parameters lands on for Mbp..Gbp
+  // genomes (recommended k = ceil(log4(maxSize * 9999)) = 17..23, accepted up to +3), its default 21
+  // and the customary 31/32; anything else takes the runtime-k kernel
   auto kern = sketch_minhash_kernel<0>;
   switch (k) {
     case 16: kern = sketch_minhash_kernel<16>; break;
@@ -886,6 +905,10 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     case 26: kern = sketch_minhash_kernel<26>; break;
     case 27: kern = sketch_minhash_kernel<27>; break;
     case 28: kern = sketch_minhash_kernel<28>; break;
+    case 29: kern = sketch_minhash_kernel<29>; break;
+    case 30: kern = sketch_minhash_kernel<30>; break;
+    case 31: kern = sketch_minhash_kernel<31>; break;
+    case 32: kern = sketch_minhash_kernel<32>; break;
     default: break;
   }
   RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
