@@ -7,9 +7,13 @@
 //
 // The reference probes a phmap of the kept (dim_id -> rank) pairs per k-mer.  Here the kept set
 // (dim_end of 2^(4*half_subk) ids; 4096 of 16 Mi at the default drlevel 3) is compiled on the
-// host into a two-table cuckoo index in 64 KiB of LDS: table 1 is addressed by the low 13 bits of
-// dim_id and stores the remaining high bits + rank, table 2 is addressed by the high 13 bits and
-// stores the low bits + rank.  A lookup is two ds_read_b32 and a few compares, no loop, exact.
+// host into a two-table cuckoo index in <= 64 KiB of LDS: table 1 is addressed by the low 13 bits of
+// dim_id, table 2 by the high 12-13 bits.  An entry keeps the key bits its slot does not imply AT
+// THEIR NATURAL POSITIONS (plus one bit the slot does imply, so that an unused slot can hold a
+// pattern nothing matches) and the rank beside them, so a probe is  ((entry ^ dim_id) & mask) == 0:
+// two ds_read_b32, two three-input boolean ops and two compares, no loop, exact.  The canonical
+// k-mer is selected on top-aligned windows whose low bits are never cleaned (one shift each); the
+// exact tuple and the rank are only computed for the ~1/4096 survivors.
 // Configurations that keep more than 8192 ids (drlevel <= 2), or a kept set the cuckoo build cannot
 // place, fall back to a table lookup in HBM.  Survivors are appended to the genome's
 // output row with wave-aggregated atomics; kssd_sort_unique_kernel then sorts and deduplicates
@@ -27,7 +31,6 @@ constexpr int OWN = RUN_DW * 4;
 constexpr int WARM_DW = 9;   // 36 warm-up bases; 9 + 19 dwords = seven 16-byte loads per lane and tile
 constexpr int TILE_BASES = WG * RUN_DW * 4;
 constexpr int MAX_LDS_KEEP = 8192;
-constexpr uint32_t CK_EMPTY = 0xFFFFFFFFu;
 
 struct KSegment {
   uint64_t g_begin, g_end;
@@ -46,6 +49,9 @@ struct KssdParams {
   int dimbits;       // 4*half_subk (24 or 28)
   int ck1, ck2;      // log2 slots of cuckoo table 1 (low bits of dim_id) / table 2 (high bits)
   int dim_end;
+  int lshift;        // 64 - 2K: top-aligned windows
+  uint32_t dimmask;  // low `dimbits` bits
+  uint32_t m1key, m2key;  // entry bits compared with dim_id in table 1 / table 2
   uint64_t tupmask, domask, undomask0, undomask1;
 };
 
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
   uint32_t* ocnt = cnt + sg.genome;
   const bool fastroll = P.K <= 28;  // 2K+8 bits fit the 64-bit extended window
   const int hishift = P.dimbits - P.ck2;  // table 2 is addressed by the high ck2 bits
-  const uint32_t m1mask = (1u << P.ck1) - 1u, m2mask = (1u << hishift) - 1u;
+  const uint32_t m1mask = (1u << P.ck1) - 1u;
 
   for (uint64_t T0 = sg.s_begin & ~15ULL; T0 < sg.s_end; T0 += TILE_BASES) {
     const int64_t lo64 = (int64_t)sg.s_begin - (int64_t)T0;
@@ -134,11 +140,14 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
             // scalar ownership test for the steady state (tile interior to the segment, only valid
             // bases in this wave since the tile began => run = 4d >= 36 >= K-1 and every position owned)
             const bool allok = interior && clean;
+            // the four windows top-aligned (tuple :1134 / rvs :1135 four times): bits below the window are
+            // not cleaned -- they cannot change which of two different k-mers is smaller (:1141), and of
+            // two equal ones either will do
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-              const uint64_t f = (F >> (6 - 2 * b)) & P.tupmask;                      // :1134 four times
-              const uint64_t r = (R >> (2 * b + 2)) & P.tupmask;                      // :1135 four times
-              uni[b] = f < r ? f : r;                                                 // :1141
+              const uint64_t f = F << (P.lshift - 6 + 2 * b);
+              const uint64_t r = R << (P.lshift - 2 - 2 * b);
+              uni[b] = f < r ? f : r;
             }
             if (allok) {
 #pragma unroll
@@ -165,23 +174,23 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
             run = valid ? run + 1 : 0;                                               // base counter :1136,1161
             const int rel = rel0 + b;
             ok[b] = run >= P.K && rel >= rel_lo && rel < rel_hi;
-            uni[b] = tuple < rvs ? tuple : rvs;
+            uni[b] = (tuple < rvs ? tuple : rvs) << P.lshift;
           }
         }
         if (!emitting) continue;
         uint32_t rank[4];
         bool keep[4];
+        const int top_dim = P.lshift + P.dim_shift;  // dim_id's position in a top-aligned window
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-          const uint32_t dim_id = (uint32_t)((uni[b] & P.domask) >> P.dim_shift);   // :1142
+          const uint32_t dim_id = (uint32_t)(uni[b] >> top_dim) & P.dimmask;          // :1142
           rank[b] = 0;
           if (LDS_INDEX) {
-            // entry = (remaining key bits << 13) | rank ; CK_EMPTY when unused
             const uint32_t e1 = l_t1[dim_id & m1mask];
             const uint32_t e2 = l_t2[dim_id >> hishift];
-            const bool m1 = (e1 >> 13) == (dim_id >> P.ck1) && e1 != CK_EMPTY;
-            const bool m2 = (e2 >> 13) == (dim_id & m2mask) && e2 != CK_EMPTY;
-            rank[b] = (m1 ? e1 : e2) & 8191u;
+            const bool m1 = ((e1 ^ dim_id) & P.m1key) == 0u;
+            const bool m2 = ((e2 ^ dim_id) & P.m2key) == 0u;
+            rank[b] = m1 ? (e1 & 0xfffu) : (e2 >> 20);
             keep[b] = ok[b] && (m1 || m2);
           } else {
             keep[b] = false;
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
         for (int b = 0; b < 4; b++) {
           const uint64_t bal = __ballot(keep[b]);
           if (bal) {  // wave-uniform
-            const uint64_t u = uni[b];
+            const uint64_t u = uni[b] >> P.lshift;  // the exact 2K-bit tuple
             const uint64_t dr = (((u & P.undomask0) | ((u & P.undomask1) << P.und1_shl)) >> (P.drlevel * 4)) |
                                 (uint64_t)rank[b];                                   // :1150-1152
             uint32_t base = 0;
@@ -496,7 +505,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   RTC_HIP(ctx, hipSetDevice(ctx->device));
 
   // ---- filter structures (cached in the context: one host thread per context, freed with it) ----
-  bool lds_index = dim_end <= MAX_LDS_KEEP;
+  bool lds_index = dim_end <= 4096 && 4 * half_subk <= 28;  // ranks fit 12 bits, entries 32
   auto& kc = ctx->kssd;
   const uint64_t cs = table_checksum(h_shuffled_dim, (size_t)dim_size);
   if (kc.half_subk != half_subk || kc.drlevel != drlevel || kc.checksum != cs) {
@@ -509,33 +518,40 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
       std::vector<uint32_t> t1, t2;
       bool placed_all = false;
       size_t nkept = 0;
-      const int tries[3][2] = {{12, 12}, {13, 12}, {13, 13}};
-      for (int tr = 0; tr < 3 && !placed_all; tr++) {
+      const int tries[2][2] = {{13, 12}, {13, 13}};
+      for (int tr = 0; tr < 2 && !placed_all; tr++) {
         const int b1 = tries[tr][0], b2 = tries[tr][1], hishift = dimbits - b2;
-        if ((size_t)dim_end * 10 > (((size_t)1 << b1) + ((size_t)1 << b2)) * 6 && tr < 2) continue;  // keep load <= 60 %
-        t1.assign((size_t)1 << b1, CK_EMPTY); t2.assign((size_t)1 << b2, CK_EMPTY);
-        auto enc1 = [&](uint32_t key, uint32_t rank) { return ((key >> b1) << 13) | rank; };
-        auto enc2 = [&](uint32_t key, uint32_t rank) { return ((key & ((1u << hishift) - 1u)) << 13) | rank; };
-        auto key1 = [&](uint32_t slot, uint32_t e) { return ((e >> 13) << b1) | slot; };
-        auto key2 = [&](uint32_t slot, uint32_t e) { return (slot << hishift) | (e >> 13); };
+        struct Slot { int64_t key; uint32_t rank; };
+        std::vector<Slot> a1((size_t)1 << b1, Slot{-1, 0}), a2((size_t)1 << b2, Slot{-1, 0});
         placed_all = true; nkept = 0;
         for (int t = 0; t < dim_size && placed_all; t++) {
           if (h_shuffled_dim[t] < 0 || h_shuffled_dim[t] >= dim_end) continue;
           nkept++;
-          uint32_t key = (uint32_t)t, rank = (uint32_t)h_shuffled_dim[t];
+          Slot cur{t, (uint32_t)h_shuffled_dim[t]};
           bool done = false;
           for (int kick = 0; kick < 512 && !done; kick++) {
-            const uint32_t s1 = key & ((1u << b1) - 1u);
-            if (t1[s1] == CK_EMPTY) { t1[s1] = enc1(key, rank); done = true; break; }
-            const uint32_t s2 = key >> hishift;
-            if (t2[s2] == CK_EMPTY) { t2[s2] = enc2(key, rank); done = true; break; }
+            const uint32_t s1 = (uint32_t)cur.key & ((1u << b1) - 1u);
+            if (a1[s1].key < 0) { a1[s1] = cur; done = true; break; }
+            const uint32_t s2 = (uint32_t)cur.key >> hishift;
+            if (a2[s2].key < 0) { a2[s2] = cur; done = true; break; }
             // evict alternately from table 1 / table 2
-            if (kick & 1) { const uint32_t e = t2[s2]; t2[s2] = enc2(key, rank); key = key2(s2, e); rank = e & 8191u; }
-            else { const uint32_t e = t1[s1]; t1[s1] = enc1(key, rank); key = key1(s1, e); rank = e & 8191u; }
+            if (kick & 1) std::swap(cur, a2[s2]); else std::swap(cur, a1[s1]);
           }
           if (!done) placed_all = false;
         }
-        if (placed_all) { kc.ck1 = b1; kc.ck2 = b2; }
+        if (!placed_all) continue;
+        // Encoding.  Table 1 (slot = low b1 bits of the key): key bits b1-1 .. dimbits-1 at their own
+        // positions, rank (< 4096) in bits 0..11.  Table 2 (slot = high b2 bits): key bits 0 .. hishift at
+        // their own positions, rank in bits 20..31.  Each keeps ONE bit its slot already implies: an
+        // unused slot holds that bit inverted, which no key of the slot can match.
+        const uint32_t m1key = (dimbits == 32 ? ~0u : ((1u << dimbits) - 1u)) & ~((1u << (b1 - 1)) - 1u);
+        const uint32_t m2key = (1u << (hishift + 1)) - 1u;
+        t1.resize(a1.size()); t2.resize(a2.size());
+        for (size_t q = 0; q < a1.size(); q++)
+          t1[q] = a1[q].key < 0 ? ((((uint32_t)~q >> (b1 - 1)) & 1u) << (b1 - 1)) : (((uint32_t)a1[q].key & m1key) | a1[q].rank);
+        for (size_t q = 0; q < a2.size(); q++)
+          t2[q] = a2[q].key < 0 ? (((uint32_t)~q & 1u) << hishift) : (((uint32_t)a2[q].key & m2key) | (a2[q].rank << 20));
+        kc.ck1 = b1; kc.ck2 = b2;
       }
       if (nkept > (size_t)MAX_LDS_KEEP) return rtc_fail(ctx, RTC_ERR_ARG, "shuffle table is not a permutation");
       if (placed_all) {
@@ -584,6 +600,10 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   lds_index = kc.d_index != nullptr;  // false when the cuckoo build fell back to the HBM table
   const uint32_t* d_t1 = (const uint32_t*)kc.d_index;
   P.ck1 = kc.ck1; P.ck2 = kc.ck2;
+  P.lshift = 64 - 2 * K;
+  P.dimmask = P.dimbits >= 32 ? ~0u : ((1u << P.dimbits) - 1u);
+  P.m1key = P.dimmask & ~((1u << (P.ck1 - 1)) - 1u);
+  P.m2key = (1u << (P.dimbits - P.ck2 + 1)) - 1u;
   const uint32_t* d_t2 = kc.d_index ? d_t1 + ((size_t)1 << kc.ck1) : nullptr;
   const size_t lds = lds_index ? (((size_t)1 << kc.ck1) + ((size_t)1 << kc.ck2)) * 4 : 16;
 #define LAUNCH_KSSD(OT, LI)                                                                                         \
