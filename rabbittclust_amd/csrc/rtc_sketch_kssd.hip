@@ -26,10 +26,12 @@
 namespace {
 
 constexpr int WG = 512;
-constexpr int RUN_DW = 19;   // 76 owned k-mer end positions per lane and tile (live lines stay within L2, see rtc_sketch_minhash.hip)
-constexpr int OWN = RUN_DW * 4;
-constexpr int WARM_DW = 9;   // 36 warm-up bases; 9 + 19 dwords = seven 16-byte loads per lane and tile
-constexpr int TILE_BASES = WG * RUN_DW * 4;
+// Lane geometry per tile (template parameters of the kernel): RUN_DW dwords of owned k-mer end positions
+// behind WARM_DW warm-up dwords that only roll the windows (>= K-1 bases), together whole 16-byte loads.
+//   K <= 25:  18 + 6 dwords (72 owned + 24 warm-up bases, six loads)
+//   else:     19 + 9 dwords (76 + 36, seven loads)
+// Lane runs of 72-76 B keep the live 128-B lines inside an XCD's L2 (see rtc_sketch_minhash.hip).
+constexpr int TILE_BASES_MAX = WG * 19 * 4;
 constexpr int MAX_LDS_KEEP = 8192;
 
 struct KSegment {
@@ -73,10 +75,10 @@ __device__ __forceinline__ uint4 load_bases16(const uint8_t* __restrict__ seq, i
   return make_uint4(ww[0], ww[1], ww[2], ww[3]);
 }
 
-// Each lane walks 112 consecutive bases per tile (36 warm-up + 76 owned k-mer end positions) read
-// straight from global memory as seven 16-byte loads; four bases are decoded at once (SWAR) and the
-// four k-mers of a dword are filtered back to back.
-template <typename OutT, bool LDS_INDEX>
+// Each lane walks 96 (K <= 25: 24 warm-up + 72 owned k-mer end positions) or 112 (36 + 76) consecutive
+// bases per tile, read straight from global memory as 16-byte loads; four bases are decoded at once
+// (SWAR) and the four k-mers of a dword are filtered back to back.
+template <typename OutT, bool LDS_INDEX, int RUN_DW, int WARM_DW>
 __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restrict__ seq,
                                                          const KSegment* __restrict__ segs, KssdParams P,
                                                          const uint32_t* __restrict__ g_t1,    // cuckoo table 1 [1 << ck1]
@@ -88,6 +90,9 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
   uint32_t* l_t1 = reinterpret_cast<uint32_t*>(smem);
   uint32_t* l_t2 = l_t1 + (1u << P.ck1);
 
+  static_assert((RUN_DW + WARM_DW) % 4 == 0, "a lane's window must be whole 16-byte loads");
+  constexpr int OWN = RUN_DW * 4;
+  constexpr int TILE_BASES = WG * RUN_DW * 4;
   const KSegment sg = segs[blockIdx.x];
   const int t = threadIdx.x;
   const uint32_t lane = t & 63;
@@ -99,7 +104,6 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
   OutT* orow = out + (uint64_t)sg.genome * stride;
   uint32_t* ocnt = cnt + sg.genome;
   const bool fastroll = P.K <= 28;  // 2K+8 bits fit the 64-bit extended window
-  const int hishift = P.dimbits - P.ck2;  // table 2 is addressed by the high ck2 bits
   const uint32_t m1mask = (1u << P.ck1) - 1u;
 
   for (uint64_t T0 = sg.s_begin & ~15ULL; T0 < sg.s_end; T0 += TILE_BASES) {
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
           const uint64_t R = rvs | ((uint64_t)rp << (2 * P.K));
           if (emitting) {
             // scalar ownership test for the steady state (tile interior to the segment, only valid
-            // bases in this wave since the tile began => run = 4d >= 36 >= K-1 and every position owned)
+            // bases in this wave since the tile began => run = 4d >= 4*WARM_DW >= K-1 and every position owned)
             const bool allok = interior && clean;
             // the four windows top-aligned (tuple :1134 / rvs :1135 four times): bits below the window are
             // not cleaned -- they cannot change which of two different k-mers is smaller (:1141), and of
@@ -180,14 +184,18 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
         if (!emitting) continue;
         uint32_t rank[4];
         bool keep[4];
-        const int top_dim = P.lshift + P.dim_shift;  // dim_id's position in a top-aligned window
+        // dim_id (:1142) sits at bit lshift + dim_shift of a top-aligned window: shifting the bits above it
+        // out leaves it at the top of a 32-bit word, from where the table-2 slot (its high ck2 bits) and
+        // the value itself are one 32-bit shift each -- no masks
+        const int drop = 64 - (P.lshift + P.dim_shift) - P.dimbits;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-          const uint32_t dim_id = (uint32_t)(uni[b] >> top_dim) & P.dimmask;          // :1142
+          const uint32_t xh = (uint32_t)((uni[b] << drop) >> 32);
+          const uint32_t dim_id = xh >> (32 - P.dimbits);
           rank[b] = 0;
           if (LDS_INDEX) {
             const uint32_t e1 = l_t1[dim_id & m1mask];
-            const uint32_t e2 = l_t2[dim_id >> hishift];
+            const uint32_t e2 = l_t2[xh >> (32 - P.ck2)];
             const bool m1 = ((e1 ^ dim_id) & P.m1key) == 0u;
             const bool m2 = ((e2 ^ dim_id) & P.m2key) == 0u;
             rank[b] = m1 ? (e1 & 0xfffu) : (e2 >> 20);
@@ -576,7 +584,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
     total += h_off[g + 1] - h_off[g];
   }
   uint64_t seg_len = total / ((uint64_t)ctx->num_cu * 12);
-  const uint64_t min_seg = 4ull * TILE_BASES;
+  const uint64_t min_seg = 4ull * TILE_BASES_MAX;
   if (seg_len < min_seg) seg_len = min_seg;
   std::vector<KSegment> segs;
   segs.reserve(n + 1024);
@@ -606,15 +614,17 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   P.m2key = (1u << (P.dimbits - P.ck2 + 1)) - 1u;
   const uint32_t* d_t2 = kc.d_index ? d_t1 + ((size_t)1 << kc.ck1) : nullptr;
   const size_t lds = lds_index ? (((size_t)1 << kc.ck1) + ((size_t)1 << kc.ck2)) * 4 : 16;
-#define LAUNCH_KSSD(OT, LI)                                                                                         \
+#define LAUNCH_KSSD2(OT, LI, RUN, WARM)                                                                               \
   do {                                                                                                               \
-    auto kern = sketch_kssd_kernel<OT, LI>;                                                                          \
+    auto kern = sketch_kssd_kernel<OT, LI, RUN, WARM>;                                                               \
     RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
     hipLaunchKernelGGL(kern, dim3((uint32_t)segs.size()), dim3(WG), lds, ctx->stream, d_seq, (const KSegment*)ws0, P, \
                        d_t1, d_t2, (const int32_t*)kc.d_table, (OT*)d_out, stride, d_cnt);                        \
   } while (0)
+#define LAUNCH_KSSD(OT, LI) do { if (K <= 25) LAUNCH_KSSD2(OT, LI, 18, 6); else LAUNCH_KSSD2(OT, LI, 19, 9); } while (0)
   if (use64) { if (lds_index) LAUNCH_KSSD(uint64_t, true); else LAUNCH_KSSD(uint64_t, false); }
   else       { if (lds_index) LAUNCH_KSSD(uint32_t, true); else LAUNCH_KSSD(uint32_t, false); }
+#undef LAUNCH_KSSD2
 #undef LAUNCH_KSSD
   RTC_CHECK_LAUNCH(ctx);
 
