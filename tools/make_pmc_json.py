@@ -1,8 +1,12 @@
 """Fold the rocprofv3 --pmc CSVs written by tools/collect_profiles.sh into one JSON (per-kernel,
-per-launch counter sums plus the derived figures DESIGN.md quotes).  Usage: make_pmc_json.py <dir> <tag>"""
+per-launch counter sums plus the derived figures DESIGN.md quotes).
+Usage: make_pmc_json.py <dir> <tag> [mode genomes length]   (defaults: the bench.py N=1 workload)"""
 import collections, csv, glob, json, os, sys
 root, tag = sys.argv[1], sys.argv[2]
-G, L, K, S = 10000, 5_000_000, 21, 1000   # bench.py defaults: the workload the passes ran on
+MODE = sys.argv[3] if len(sys.argv) > 3 else "minhash"
+G = int(sys.argv[4]) if len(sys.argv) > 4 else 10000
+L = int(sys.argv[5]) if len(sys.argv) > 5 else 5_000_000
+K, S = 21, 1000
 want = ("synth_kernel", "sketch_minhash_kernel", "sketch_kssd_kernel", "transpose_slices_kernel", "pair_tiled_kernel")
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
@@ -14,9 +18,9 @@ for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), 
         tot[name][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[name][r["Counter_Name"]].add(r["Dispatch_Id"])
 out = {
-    "command": "rocprofv3 --pmc <group> --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline "
-               "(one run per counter group, tools/collect_profiles.sh)",
-    "workload": {"genomes": G, "length": L, "k": K, "s": S},
+    "command": "rocprofv3 --pmc <group> --output-format csv -- python bench.py [--mode kssd] --steps 1 --warmup 0 "
+               "--no-cpu-baseline (one run per counter group, tools/collect_profiles.sh)",
+    "workload": {"genomes": G, "length": L, "k": K, "s": S, "mode": MODE},
     "units": "hbm_bytes_per_launch = fabric-side bytes = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B + 64*WRREQ_64B + "
              "32*(WRREQ - WRREQ_64B), Infinity-Cache hits included (MI355X_MICROARCH.md, HBM section).  FETCH_SIZE / "
              "WRITE_SIZE (1024-byte units) are kept beside them: FETCH_SIZE = RDREQ x 64 B, i.e. half the bytes of "
@@ -42,7 +46,7 @@ for name in want:
         k["hbm_bytes_per_launch"] = rd + wr
     elif "FETCH_SIZE_per_launch" in k and "WRITE_SIZE_per_launch" in k:
         k["hbm_bytes_per_launch"] = (2.0 * k["FETCH_SIZE_per_launch"] + k["WRITE_SIZE_per_launch"]) * 1024.0
-    if name == "sketch_minhash_kernel" and "SQ_INSTS_VALU_per_launch" in k:
+    if name in ("sketch_minhash_kernel", "sketch_kssd_kernel") and "SQ_INSTS_VALU_per_launch" in k:
         steps = G * L / 64.0
         k["derived"] = {
             "kmer_wave_steps": steps,
