@@ -118,7 +118,7 @@ def cpu_baseline(args, mode, seq, off, sketches_host, shuffled):
     t0 = time.time()
     if mode == "minhash":
         sk = O.sketch_minhash_batch(sub, suboff, args.k, args.s, threads=cores)
-        impl = getattr(O, "MINHASH_IMPL", "scalar MurmurHash3 port")
+        impl = O.minhash_impl()
     else:
         sk = O.sketch_kssd_batch(sub, suboff, shuffled, args.k, args.drlevel, threads=cores)
         impl = "KSSD restatement of src/SketchInfo.cpp:994-1252"

@@ -88,6 +88,12 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def minhash_impl():
+    """What the batch sketcher's inner loop is (reported with bench.py's cpu_baseline)."""
+    lanes = lib().orc_minhash_impl_avx2()
+    return {8: "8-lane AVX-512 (vpmullq) MurmurHash3 port", 4: "4-lane AVX2 MurmurHash3 port"}.get(lanes, "scalar MurmurHash3 port")
+
+
 def murmur3_x64_128(data: bytes, seed: int):
     out = (C.c_uint64 * 2)()
     lib().orc_murmur3_x64_128(data, C.c_int(len(data)), C.c_uint32(seed), out)

@@ -172,6 +172,140 @@ extern "C" uint64_t orc_mh_kmer_hash(const char* kmer, int k, uint32_t seed) {
   return kmer_hash_packed(f < r ? f : r, k, seed, k > 16);
 }
 
+// ---- four k-mers at a time with AVX2 (ours: RabbitSketch's own AVX2/AVX512 MurmurHash3 kernels are
+// not in the reference tree).  Same arithmetic as orc_murmur3_x64_128 on 64-bit lanes; the 64 x 64
+// multiplies are assembled from 32 x 32 -> 64 products (AVX2 has no vpmullq).  16 <= k <= 32.
+#if defined(__AVX2__)
+#include <immintrin.h>
+#define ORC_HAVE_AVX2 1
+static inline __m256i mul64c(__m256i a, uint64_t c) {
+  const __m256i cl = _mm256_set1_epi64x((long long)(c & 0xffffffffULL)), ch = _mm256_set1_epi64x((long long)(c >> 32));
+  const __m256i ah = _mm256_srli_epi64(a, 32);
+  const __m256i lo = _mm256_mul_epu32(a, cl);
+  const __m256i cross = _mm256_add_epi64(_mm256_mul_epu32(a, ch), _mm256_mul_epu32(ah, cl));
+  return _mm256_add_epi64(lo, _mm256_slli_epi64(cross, 32));
+}
+static inline __m256i rotl64v(__m256i x, int r) { return _mm256_or_si256(_mm256_slli_epi64(x, r), _mm256_srli_epi64(x, 64 - r)); }
+static inline __m256i fmix64v(__m256i k) {
+  k = _mm256_xor_si256(k, _mm256_srli_epi64(k, 33));
+  k = mul64c(k, 0xff51afd7ed558ccdULL);
+  k = _mm256_xor_si256(k, _mm256_srli_epi64(k, 33));
+  k = mul64c(k, 0xc4ceb9fe1a85ec53ULL);
+  return _mm256_xor_si256(k, _mm256_srli_epi64(k, 33));
+}
+static inline void kmer_hash_packed_x4(const uint64_t canon[4], int k, uint32_t seed, bool use64, uint64_t out[4]) {
+  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  const uint32_t* a4 = ascii4_lut();
+  alignas(32) uint64_t w[4][4];  // w[word][lane]: the k-mer's ASCII bytes as four little-endian u64 words
+  for (int l = 0; l < 4; l++) {
+    const uint64_t x = k == 32 ? canon[l] : canon[l] << (64 - 2 * k);
+    for (int d = 0; d < 4; d++)
+      w[d][l] = (uint64_t)a4[(x >> (56 - 16 * d)) & 0xff] | ((uint64_t)a4[(x >> (48 - 16 * d)) & 0xff] << 32);
+  }
+  auto bytemask = [](int nb) { return nb >= 8 ? ~0ULL : (nb <= 0 ? 0ULL : ((1ULL << (8 * nb)) - 1)); };
+  __m256i h1 = _mm256_set1_epi64x((long long)(uint64_t)seed), h2 = h1;
+  const __m256i W0 = _mm256_load_si256((const __m256i*)w[0]), W1 = _mm256_load_si256((const __m256i*)w[1]);
+  __m256i W2 = _mm256_load_si256((const __m256i*)w[2]), W3 = _mm256_load_si256((const __m256i*)w[3]);
+  auto body = [&](__m256i k1, __m256i k2) {
+    k1 = mul64c(rotl64v(mul64c(k1, c1), 31), c2); h1 = _mm256_xor_si256(h1, k1);
+    h1 = _mm256_add_epi64(rotl64v(h1, 27), h2);
+    h1 = _mm256_add_epi64(_mm256_add_epi64(_mm256_slli_epi64(h1, 2), h1), _mm256_set1_epi64x(0x52dce729));
+    k2 = mul64c(rotl64v(mul64c(k2, c2), 33), c1); h2 = _mm256_xor_si256(h2, k2);
+    h2 = _mm256_add_epi64(rotl64v(h2, 31), h1);
+    h2 = _mm256_add_epi64(_mm256_add_epi64(_mm256_slli_epi64(h2, 2), h2), _mm256_set1_epi64x(0x38495ab5));
+  };
+  body(W0, W1);
+  if (k == 32) body(W2, W3);
+  else {
+    const int tail = k - 16;  // 0..15 bytes: k2 from bytes 8.., k1 from bytes 0..7 (src: the switch in orc_murmur3_x64_128)
+    if (tail > 8) {
+      W3 = _mm256_and_si256(W3, _mm256_set1_epi64x((long long)bytemask(tail - 8)));
+      h2 = _mm256_xor_si256(h2, mul64c(rotl64v(mul64c(W3, c2), 33), c1));
+    }
+    if (tail > 0) {
+      W2 = _mm256_and_si256(W2, _mm256_set1_epi64x((long long)bytemask(tail)));
+      h1 = _mm256_xor_si256(h1, mul64c(rotl64v(mul64c(W2, c1), 31), c2));
+    }
+  }
+  const __m256i len = _mm256_set1_epi64x(k);
+  h1 = _mm256_xor_si256(h1, len); h2 = _mm256_xor_si256(h2, len);
+  h1 = _mm256_add_epi64(h1, h2); h2 = _mm256_add_epi64(h2, h1);
+  h1 = fmix64v(h1); h2 = fmix64v(h2);
+  h1 = _mm256_add_epi64(h1, h2);
+  _mm256_storeu_si256((__m256i*)out, h1);
+  if (!use64) for (int l = 0; l < 4; l++) out[l] &= 0xffffffffULL;
+}
+// eight k-mers at a time with AVX-512 (vpmullq is a native 64 x 64 multiply); compiled for that target
+// only and chosen at run time, the library itself stays x86-64-v3
+#define ORC_T512 __attribute__((target("avx512f,avx512dq")))
+ORC_T512 static inline __m512i rotl64w(__m512i x, int r) { return _mm512_rol_epi64(x, r); }
+ORC_T512 static inline __m512i fmix64w(__m512i k) {
+  k = _mm512_xor_si512(k, _mm512_srli_epi64(k, 33));
+  k = _mm512_mullo_epi64(k, _mm512_set1_epi64((long long)0xff51afd7ed558ccdULL));
+  k = _mm512_xor_si512(k, _mm512_srli_epi64(k, 33));
+  k = _mm512_mullo_epi64(k, _mm512_set1_epi64((long long)0xc4ceb9fe1a85ec53ULL));
+  return _mm512_xor_si512(k, _mm512_srli_epi64(k, 33));
+}
+ORC_T512 static void kmer_hash_packed_x8(const uint64_t canon[8], int k, uint32_t seed, bool use64, uint64_t out[8]) {
+  const __m512i c1 = _mm512_set1_epi64((long long)0x87c37b91114253d5ULL), c2 = _mm512_set1_epi64((long long)0x4cf5ad432745937fULL);
+  const uint32_t* a4 = ascii4_lut();
+  alignas(64) uint64_t w[4][8];
+  for (int l = 0; l < 8; l++) {
+    const uint64_t x = k == 32 ? canon[l] : canon[l] << (64 - 2 * k);
+    for (int d = 0; d < 4; d++)
+      w[d][l] = (uint64_t)a4[(x >> (56 - 16 * d)) & 0xff] | ((uint64_t)a4[(x >> (48 - 16 * d)) & 0xff] << 32);
+  }
+  auto bytemask = [](int nb) { return nb >= 8 ? ~0ULL : (nb <= 0 ? 0ULL : ((1ULL << (8 * nb)) - 1)); };
+  __m512i h1 = _mm512_set1_epi64((long long)(uint64_t)seed), h2 = h1;
+  const __m512i W0 = _mm512_load_si512(w[0]), W1 = _mm512_load_si512(w[1]);
+  __m512i W2 = _mm512_load_si512(w[2]), W3 = _mm512_load_si512(w[3]);
+#define ORC_BODY8(K1, K2)                                                                                         \
+  do {                                                                                                            \
+    __m512i k1 = _mm512_mullo_epi64(rotl64w(_mm512_mullo_epi64(K1, c1), 31), c2); h1 = _mm512_xor_si512(h1, k1);   \
+    h1 = _mm512_add_epi64(rotl64w(h1, 27), h2);                                                                   \
+    h1 = _mm512_add_epi64(_mm512_add_epi64(_mm512_slli_epi64(h1, 2), h1), _mm512_set1_epi64(0x52dce729));          \
+    __m512i k2 = _mm512_mullo_epi64(rotl64w(_mm512_mullo_epi64(K2, c2), 33), c1); h2 = _mm512_xor_si512(h2, k2);   \
+    h2 = _mm512_add_epi64(rotl64w(h2, 31), h1);                                                                   \
+    h2 = _mm512_add_epi64(_mm512_add_epi64(_mm512_slli_epi64(h2, 2), h2), _mm512_set1_epi64(0x38495ab5));          \
+  } while (0)
+  ORC_BODY8(W0, W1);
+  if (k == 32) ORC_BODY8(W2, W3);
+  else {
+    const int tail = k - 16;
+    if (tail > 8) {
+      W3 = _mm512_and_si512(W3, _mm512_set1_epi64((long long)bytemask(tail - 8)));
+      h2 = _mm512_xor_si512(h2, _mm512_mullo_epi64(rotl64w(_mm512_mullo_epi64(W3, c2), 33), c1));
+    }
+    if (tail > 0) {
+      W2 = _mm512_and_si512(W2, _mm512_set1_epi64((long long)bytemask(tail)));
+      h1 = _mm512_xor_si512(h1, _mm512_mullo_epi64(rotl64w(_mm512_mullo_epi64(W2, c1), 31), c2));
+    }
+  }
+#undef ORC_BODY8
+  const __m512i len = _mm512_set1_epi64(k);
+  h1 = _mm512_xor_si512(h1, len); h2 = _mm512_xor_si512(h2, len);
+  h1 = _mm512_add_epi64(h1, h2); h2 = _mm512_add_epi64(h2, h1);
+  h1 = fmix64w(h1); h2 = fmix64w(h2);
+  h1 = _mm512_add_epi64(h1, h2);
+  _mm512_storeu_si512(out, h1);
+  if (!use64) for (int l = 0; l < 8; l++) out[l] &= 0xffffffffULL;
+}
+static int orc_hash_lanes() {  // 8: AVX-512, 4: AVX2, 1: scalar (ORC_HASH_LANES overrides, for timing comparisons)
+  static const int lanes = []() {
+    int want = 8;
+    if (const char* e = getenv("ORC_HASH_LANES")) want = atoi(e);
+    __builtin_cpu_init();
+    if (want >= 8 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq")) return 8;
+    return want >= 4 ? 4 : 1;
+  }();
+  return lanes;
+}
+#else
+#define ORC_HAVE_AVX2 0
+static int orc_hash_lanes() { return 1; }
+#endif
+extern "C" int orc_minhash_impl_avx2(void) { return orc_hash_lanes(); }
+
 static inline void mh_try_insert(orc_minhash* m, uint64_t h) {
   if (m->heap.size() < m->s || h < m->heap.top()) {
     if (m->set.insert(h).second) {
@@ -191,6 +325,9 @@ extern "C" void orc_mh_update(orc_minhash* m, const char* seq, uint64_t len) {
   const uint64_t mask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
   uint64_t f = 0, r = 0;
   int run = 0;
+  const int lanes = k >= 16 ? orc_hash_lanes() : 1;  // k-mers per vector hash call (the order of insertion does not change the set)
+  uint64_t pend[8], hv[8];
+  int np = 0;
   for (uint64_t i = 0; i < len; i++) {
     int c = lut[(uint8_t)seq[i]];
     if (c > 3) { run = 0; continue; }
@@ -198,11 +335,23 @@ extern "C" void orc_mh_update(orc_minhash* m, const char* seq, uint64_t len) {
     r = (r >> 2) | ((uint64_t)(3 - c) << (2 * (k - 1)));
     if (++run >= k) {
       uint64_t canon = f < r ? f : r;
-      // cheap pre-test: once the heap is full only hashes below the current max matter
-      uint64_t h = kmer_hash_packed(canon, k, m->seed, m->use64);
-      mh_try_insert(m, h);
+      if (lanes > 1) {
+        pend[np++] = canon;
+        if (np == lanes) {
+#if ORC_HAVE_AVX2
+          if (lanes == 8) kmer_hash_packed_x8(pend, k, m->seed, m->use64, hv);
+          else kmer_hash_packed_x4(pend, k, m->seed, m->use64, hv);
+#endif
+          for (int q = 0; q < lanes; q++) mh_try_insert(m, hv[q]);
+          np = 0;
+        }
+      } else {
+        uint64_t h = kmer_hash_packed(canon, k, m->seed, m->use64);
+        mh_try_insert(m, h);
+      }
     }
   }
+  for (int q = 0; q < np; q++) mh_try_insert(m, kmer_hash_packed(pend[q], k, m->seed, m->use64));
 }
 
 extern "C" uint32_t orc_mh_store(const orc_minhash* m, uint64_t* out, uint32_t cap) {

@@ -43,6 +43,10 @@ void orc_mh_free(orc_minhash*);
 void orc_mh_update(orc_minhash*, const char* seq, uint64_t len);
 /* ascending distinct hashes; returns count (<= sketch_size) */
 uint32_t orc_mh_store(const orc_minhash*, uint64_t* out, uint32_t cap);
+/* k-mers hashed per call in orc_mh_update: 8 (AVX-512 vpmullq), 4 (AVX2) or 1 (scalar) -- our own
+ * vectorisations of the same arithmetic; RabbitSketch's AVX2/AVX-512 kernels are absent from the
+ * reference tree.  Chosen at run time from the CPU's features. */
+int orc_minhash_impl_avx2(void);
 /* hash of one canonical k-mer given as ASCII (must be k valid ACGT chars) */
 uint64_t orc_mh_kmer_hash(const char* kmer, int k, uint32_t seed);
 
