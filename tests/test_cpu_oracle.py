@@ -223,3 +223,122 @@ def test_greedy_oracle_basic_invariants(oracle):
     assert n == 8
     for i, r in enumerate(rep):
         assert rep[r] == r and r <= i and r // 4 == i // 4
+
+
+# ---- an independent pure-Python twin of the greedy restatement (dict-based inverted index, the
+# reference's own loop order) -- every other restated function has one; src/greedy.cpp:986-1399, :566-899
+def _py_greedy(sk, size_cfg, k, containment, thr, kssd=False):
+    import math
+    n = len(sk)
+    rep_of = list(range(n))
+    index = {}                                    # hash -> [rep ids in insertion order]
+    for h in sk[0].tolist():
+        index.setdefault(h, []).append(0)
+    x = math.exp(-thr * k)
+    jmin = x / (2.0 - x)
+    fast = False
+    fixed_min = 0
+    if not kssd:
+        fixed = int(size_cfg[0])
+        fast = (not containment) and all(int(size_cfg[i]) == fixed for i in range(1, min(100, n)))
+        if fast:
+            fixed_min = int(math.ceil(jmin * (2 * fixed) / (1.0 + jmin)))
+    for j in range(1, n):
+        q = sk[j].tolist()
+        size_ref = len(q)
+        cnt, touched = {}, []
+        for h in q:                               # first-touch order = the -t 1 visiting order
+            for r in index.get(h, ()):
+                if r not in cnt:
+                    cnt[r] = 1
+                    touched.append(r)
+                else:
+                    cnt[r] += 1
+        best_rep, best_common, best_dist, best_jac = -1, -1, float("inf"), -1.0
+        for r in touched:
+            common = cnt[r]
+            if kssd:
+                size_q = len(sk[r])
+                if common < int(math.ceil(jmin * (size_ref + size_q) / (1.0 + jmin))):
+                    continue
+                den = size_ref + size_q - common
+                jac = 1.0 if den == 0 else common / den
+                if jac > best_jac:
+                    best_jac, best_rep = jac, r
+                continue
+            size_q = int(size_cfg[r])
+            if fast:
+                cmin = fixed_min
+            elif containment:
+                cmin = int(math.ceil(jmin * min(size_ref, size_q)))
+            else:
+                cmin = int(math.ceil(jmin * (size_ref + size_q) / (1.0 + jmin)))
+            if common < cmin:
+                continue
+            if fast:
+                if common > best_common:
+                    best_common, best_rep = common, r
+            else:
+                den = min(size_ref, size_q) if containment else size_ref + size_q - common
+                if den == 0:
+                    dist = 1.0 if containment else 0.0
+                else:
+                    jac = common / den
+                    if jac >= 1.0:
+                        dist = 0.0
+                    elif jac <= 0.0:
+                        dist = 1.0
+                    else:
+                        dist = min(-math.log(2.0 * jac / (1.0 + jac)) / k, 1.0)
+                if dist <= thr and dist < best_dist:
+                    best_dist, best_rep = dist, r
+        if best_rep >= 0:
+            rep_of[j] = best_rep
+        else:
+            for h in q:
+                index.setdefault(h, []).append(j)
+    return sum(1 for i in range(n) if rep_of[i] == i), rep_of
+
+
+def _greedy_families(rng, n_fam, per, size, ragged, dtype=np.uint64, bits=50):
+    sk = []
+    for _ in range(n_fam):
+        anc = np.unique(rng.integers(0, 1 << bits, size=2 * size, dtype=np.uint64))[:size]
+        for m in range(per):
+            s = size if not ragged else int(size * rng.uniform(0.3, 1.0))
+            v = anc[:s].copy()
+            if m % 3:
+                idx = rng.choice(len(v), size=int(len(v) * 0.5 * rng.uniform(0, 1)), replace=False)
+                v[idx] = rng.integers(0, 1 << bits, size=len(idx), dtype=np.uint64)
+            sk.append(np.unique(v).astype(dtype))
+    order = rng.permutation(len(sk))
+    return [sk[i] for i in order]
+
+
+@pytest.mark.parametrize("mode", ["fixed", "containment", "variable", "kssd"])
+def test_greedy_oracle_equals_python_twin(oracle, mode):
+    rng = np.random.default_rng({"fixed": 71, "containment": 72, "variable": 73, "kssd": 74}[mode])
+    if mode == "fixed":
+        sk = _greedy_families(rng, 30, 6, 200, False)
+        cfg = np.full(len(sk), 200, dtype=np.uint32)
+        flat, start, lens = oracle.to_csr(sk)
+        for thr in (0.02, 0.05):
+            want_n, want = _py_greedy(sk, cfg, 21, False, thr)
+            got_n, got = oracle.greedy_minhash(flat, start, lens, cfg, 21, False, thr)
+            assert got_n == want_n and got.tolist() == want
+        assert 1 < got_n < len(sk)
+    elif mode in ("containment", "variable"):
+        sk = _greedy_families(rng, 25, 6, 300, True)
+        cfg = np.array([max(len(s), 100) for s in sk], dtype=np.uint32)
+        flat, start, lens = oracle.to_csr(sk)
+        cont = mode == "containment"
+        want_n, want = _py_greedy(sk, cfg, 21, cont, 0.05)
+        got_n, got = oracle.greedy_minhash(flat, start, lens, cfg, 21, cont, 0.05)
+        assert got_n == want_n and got.tolist() == want and 1 < got_n < len(sk)
+    else:
+        sk = _greedy_families(rng, 25, 6, 250, True, dtype=np.uint32, bits=30)
+        sk.sort(key=lambda a: -len(a))
+        flat, start, lens = oracle.to_csr(sk, dtype=np.uint32)
+        want_n, want = _py_greedy(sk, None, 22, False, 0.05, kssd=True)
+        got_n, got = oracle.greedy_kssd(flat, start, lens, 22, 0.05)
+        assert got_n == want_n and got.tolist() == want and 1 < got_n < len(sk)

@@ -89,3 +89,179 @@ def test_full_size_pairs_mst_properties(ctx, oracle, full):
     flat, start, lens = oracle.to_csr(sub.to_host())
     want = oracle.mst(flat, start, lens, 21, 0, 0.05)
     assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
+
+
+# ---- BASELINE config 4: clust-greedy, containment (-c 1000), 50 000 genomes of 0.4 .. 2 Mbp ----------
+def test_config4_greedy_containment_50k(ctx, oracle):
+    """Full rtc_greedy on 50 000 variable-size sketches (prefix genomes: families of 10 where member m
+    is a random-length prefix of the ancestor, sketch size = ~bytes/1000 like -c 1000).  Invariants at
+    full size; representative assignment identical to the oracle on the first 2 500 genomes (greedy
+    decisions only depend on earlier genomes, so a prefix of the run is a run on the prefix)."""
+    from rabbittclust_amd import api
+    free, _ = torch.cuda.mem_get_info()
+    if free < 90e9:
+        pytest.skip("needs ~70 GB of HBM")
+    n, L, fam = 50000, 2_000_000, 10
+    rng = np.random.default_rng(1)
+    desc = api.synth_family_descs(n // fam, fam, global_seed=43, max_rate=0.04)
+    for f in range(n // fam):  # members share the ancestor's mutation stream too: true prefixes of one genome
+        desc[f * fam:(f + 1) * fam] = desc[f * fam]
+    frac = rng.uniform(0.2, 1.0, size=n)
+    frac[::fam] = 1.0
+    lens = (frac * L).astype(np.uint64) // 16 * 16
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    seq = ctx.synth_genomes(desc, off)
+    sizes = np.maximum((lens.astype(np.float64) * 1.0125 / 1000).astype(np.uint32), 100)  # max(fileBytes / 1000, 100)
+    sk = ctx.sketch_minhash(seq, off, k=21, sizes=sizes)
+    ctx.sync()
+    lens_sk = sk.len.cpu().numpy()
+    assert np.array_equal(lens_sk, sizes) and int(sizes.max()) > 2000 and int(sizes.min()) < 450
+    ncl, rep = ctx.greedy(sk, 0.05, size_cfg=sizes, is_containment=True)
+    # invariants: representatives represent themselves, come earlier, clusters stay inside families
+    idx = np.arange(n)
+    assert np.all(rep[rep] == rep) and np.all(rep <= idx) and ncl == int((rep == idx).sum())
+    assert np.all(rep // fam == idx // fam), "a genome joined a representative of another family"
+    assert n // fam <= ncl < n // 2
+    # members are within the threshold of their representative (greedy's distance, oracle arithmetic)
+    stride = sk.hashes.numel() // n
+    rows = sk.hashes.view(n, stride)
+    for g in rng.choice(np.nonzero(rep != idx)[0], size=60, replace=False):
+        r = int(rep[g])
+        a = rows[g, :int(sizes[g])].cpu().numpy().view(np.uint64)
+        b = rows[r, :int(sizes[r])].cpu().numpy().view(np.uint64)
+        c = oracle.common(a, b)
+        d = oracle.lib().orc_greedy_distance(c, int(sizes[g]), int(sizes[r]), 21, 1)
+        assert d <= 0.05, (g, r, c, d)
+    # oracle on the prefix
+    m = 2500
+    host = [rows[g, :int(sizes[g])].cpu().numpy().view(np.uint64) for g in range(m)]
+    # spot-check the sketches themselves against the oracle sketcher
+    for g in (0, 7, 1234):
+        ref = oracle.synth_genome(int(desc[g]["fam_seed"]), int(desc[g]["mut_seed"]), int(desc[g]["mut_thr"]), int(lens[g]))
+        assert np.array_equal(oracle.sketch_minhash_batch(ref, np.array([0, lens[g]], dtype=np.uint64), 21, int(sizes[g]))[0], host[g])
+    flat, start, ln = oracle.to_csr(host)
+    want_n, want = oracle.greedy_minhash(flat, start, ln, sizes[:m], 21, True, 0.05)
+    assert np.array_equal(rep[:m], want) and want_n == int((rep[:m] == idx[:m]).sum())
+    del seq
+
+
+# ---- BASELINE config 5 per-GPU shape: --fast (KSSD), 25 000 x 2 Mbp --------------------------------
+def test_config5_kssd_per_gpu_shape_25k(ctx, oracle):
+    from rabbittclust_amd import api, host, pipeline
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80e9:
+        pytest.skip("needs ~55 GB of HBM")
+    n, L = 25000, 2_000_000
+    desc = api.synth_family_descs(n // 10, 10, global_seed=45)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    seq = ctx.synth_genomes(desc, off)
+    sd = host.generate_shuffle_dim(6)
+    sk = ctx.sketch_kssd(seq, off, sd, kmer_size=21, drlevel=3)
+    ctx.sync()
+    assert sk.width == 4 and sk.k == 22
+    stride = sk.hashes.numel() // n
+    rows = sk.hashes.view(n, stride)
+    ln = sk.len.to(torch.int64)
+    assert 380 < float(ln.float().mean()) < 600  # ~L / 4096
+    # rows ascending + distinct over their length (u32 compared through an order-preserving map)
+    u = rows.to(torch.int64) & 0xFFFFFFFF
+    pos = torch.arange(stride, device=rows.device)[None, :]
+    ok = (u[:, 1:] > u[:, :-1]) | (pos[:, 1:] >= ln[:, None])
+    assert bool(ok.all())
+    again = ctx.sketch_kssd(seq, off, sd, kmer_size=21, drlevel=3)
+    assert torch.equal(again.len, sk.len)
+    st2 = again.hashes.numel() // n
+    valid = pos < ln[:, None]
+    assert torch.equal(torch.where(valid, rows, 0), torch.where(valid[:, :st2] if st2 >= stride else valid, again.hashes.view(n, st2)[:, :stride], 0))
+    for g in (0, 11111, n - 1):
+        ref = oracle.synth_genome(int(desc[g]["fam_seed"]), int(desc[g]["mut_seed"]), int(desc[g]["mut_thr"]), L)
+        assert np.array_equal(rows[g, :int(ln[g])].cpu().numpy().view(np.uint32), oracle.kssd_sketch(ref, 21, 3)), g
+    # whole step at this shape: forest properties + oracle weights on a 300-genome prefix
+    pipe = pipeline.MstPipeline(ctx, k=21, threshold=0.05, mode="kssd", shuffled_dim=sd)
+    st = pipe.step(seq, off)
+    mst = pipe.last_mst
+    assert st["mst_edges"] == len(mst) and bool(np.all(np.diff(mst["dist"]) >= 0))
+    parent = np.arange(n)
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for e in mst:
+        ra, rb = find(int(e["preNode"])), find(int(e["sufNode"]))
+        assert ra != rb
+        parent[ra] = rb
+    sub = api.SketchSet(sk.hashes[: 300 * stride], sk.start[:300], sk.len[:300], 4, 22, "kssd")
+    got = ctx.mst(sub, 0.05)
+    flat, start, lens = oracle.to_csr(sub.to_host(), dtype=np.uint32)
+    want = oracle.mst(flat, start, lens, 22, 0, 0.05)
+    assert len(got) == len(want) and np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
+    del seq
+
+
+# ---- BASELINE config 3 per-rank shape: rank 7 of 8 over 50 000 real sketches ------------------------
+def test_config3_rank7_of_8_over_50k_sketches(ctx, oracle):
+    """50 000 sketches (s=1000) of synthetic genomes, the last of 8 triangle row ranges: candidate list
+    against the independent merge kernel + oracle on sampled rows, then all 8 ranks in lockstep (one
+    reduction per round) against the single-launch rtc_mst forest; the same machinery on a
+    3 000-genome prefix against the oracle's weights."""
+    from rabbittclust_amd import api, pipeline
+    from test_gpu_mst import _LockstepRanks
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40e9:
+        pytest.skip("needs ~15 GB of HBM")
+    n, L, chunk, s = 50000, 1_000_000, 10000, 1000
+    out = torch.empty((n, s), dtype=torch.int64, device=ctx.device)
+    cnt = torch.zeros(n, dtype=torch.int32, device=ctx.device)
+    off = np.arange(chunk + 1, dtype=np.uint64) * np.uint64(L)
+    for c0 in range(0, n, chunk):  # sketched in 10 000-genome chunks through one 10 GB staging buffer
+        desc = api.synth_family_descs(chunk // 10, 10, global_seed=500 + c0)
+        seq = ctx.synth_genomes(desc, off)
+        ctx.sketch_minhash_into(seq, off, out[c0:c0 + chunk], cnt[c0:c0 + chunk], k=21, size=s)
+        ctx.sync()
+        del seq
+    sk = api.SketchSet(out.view(-1), torch.arange(n, dtype=torch.int64, device=ctx.device) * s, cnt, 8, 21, "minhash")
+    assert int(cnt.min()) == s
+    world = 8
+    b = pipeline.triangle_row_ranges(n, world, fixed_cols=8.8 * s)
+    assert b[0] == 0 and b[-1] == n and all(b[i] < b[i + 1] for i in range(world))
+    pipes = [pipeline.MstPipeline(ctx, k=21, sketch_size=s, threshold=0.05, rank=r, world=world) for r in range(world)]
+    e7, m7 = pipes[7].candidate_edges(sk, b[7], b[8])
+    edges7 = e7[:m7].cpu().numpy().view(np.uint32)
+    assert m7 > 0 and np.all(edges7[:, 1] < edges7[:, 0]) and np.all(edges7[:, 0] >= b[7]) and np.all(edges7[:, 2] > 0)
+    assert len(np.unique(edges7[:, 0].astype(np.uint64) << np.uint64(32) | edges7[:, 1])) == m7
+    rng = np.random.default_rng(3)
+    for row in rng.integers(b[7], n, size=6):
+        dense = ctx.pair_common(sk, row0=int(row), row1=int(row) + 1, col0=0, col1=int(row), algo=1).cpu().numpy()[0]
+        mine = edges7[edges7[:, 0] == row]
+        want_cols = np.nonzero(dense)[0]
+        assert np.array_equal(np.sort(mine[:, 1]), want_cols) and np.array_equal(mine[np.argsort(mine[:, 1]), 2], dense[want_cols])
+        for col in want_cols[:3]:
+            assert oracle.common(out[row].cpu().numpy().view(np.uint64), out[int(col)].cpu().numpy().view(np.uint64)) == dense[col]
+    # all 8 ranks in lockstep == the single-launch forest
+    backends, total = [], 0
+    for r in range(world):
+        e, m = pipes[r].candidate_edges(sk, b[r], b[r + 1])
+        backends.append(pipeline.HipBoruvkaBackend(ctx, sk, e[:m].clone(), m, False))
+        total += m
+    ranks = _LockstepRanks(backends)
+    sel, rounds = pipeline.boruvka_rounds(ranks, n, None, s)
+    assert ranks.reduces == rounds
+    got = pipes[0].finish(sk, sel)
+    single = ctx.mst(sk, 0.05)
+    assert np.array_equal(got, single)
+    # prefix against the oracle
+    m = 3000
+    sub = api.SketchSet(out[:m].reshape(-1), sk.start[:m], cnt[:m], 8, 21, "minhash")
+    bb = pipeline.triangle_row_ranges(m, world, fixed_cols=8.8 * s)
+    be = []
+    for r in range(world):
+        e, mm = pipes[r].candidate_edges(sub, bb[r], bb[r + 1])
+        be.append(pipeline.HipBoruvkaBackend(ctx, sub, e[:mm].clone(), mm, False))
+    sel2, _ = pipeline.boruvka_rounds(_LockstepRanks(be), m, None, s)
+    got2 = pipes[0].finish(sub, sel2)
+    flat, start, lens = oracle.to_csr(sub.to_host())
+    want = oracle.mst(flat, start, lens, 21, 0, 0.05, threads=8)
+    assert np.array_equal(np.sort(got2["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
