@@ -188,6 +188,14 @@ int rtc_mst(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_sta
             const uint32_t* d_len, uint32_t n, int kmer_size, int is_containment, double threshold,
             rtc_edge* h_edges_out, uint64_t* h_n_edges);
 
+/* The start_index form of the same functions (src/MST.cpp:1375-1383, used by append_clust_mst,
+ * src/sub_command.cpp:1532-1759): only rows i >= start_index of the pair space (all columns j < i)
+ * are evaluated -- the pairs that involve an appended genome -- and the forest over those edges is
+ * returned; the caller merges it with the stored MST (sort + kruskalAlgorithm, :1693-1700). */
+int rtc_mst_append(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+                   const uint32_t* d_len, uint32_t n, uint32_t start_index, int kmer_size, int is_containment,
+                   double threshold, rtc_edge* h_edges_out, uint64_t* h_n_edges);
+
 /* ---- multi-GPU: RCCL collectives over xGMI and the sharded clust-mst step ----------------- */
 /* The reference is one shared-memory process (OpenMP over 8-row blocks of the pair space,
  * src/MST.cpp:1382, and over files, src/SketchInfo.cpp:878).  Here one rtc_comm per rtc_ctx (= per

@@ -93,6 +93,7 @@ SIGNATURES = {
     "rtc_sketch_minhash_sharded": (_i, [_vp, _vp, _vp, _vp, _u32, _i, _u32, _vp, _u32, _vp, _u32, _vp]),
     "rtc_mst_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64), _vp]),
     "rtc_mst": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64)]),
+    "rtc_mst_append": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64)]),
     "rtc_greedy": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _vp, _i, _i, _i, C.c_double, _vp,
                         C.POINTER(_u32)]),
 }

@@ -220,13 +220,15 @@ class Context:
                                                _t_ptr(count)))
         return edges, int(count.item())
 
-    def mst(self, sk, threshold, is_containment=False):
-        """compute_minhash_mst / compute_kssd_mst: returns numpy EDGE_DT array (edge.mst records)."""
+    def mst(self, sk, threshold, is_containment=False, start_index=0):
+        """compute_minhash_mst / compute_kssd_mst: returns numpy EDGE_DT array (edge.mst records).
+        start_index > 0: only rows >= start_index (the --append form, src/MST.cpp:1375-1383)."""
         n = sk.n
         out = np.zeros(max(n, 1), dtype=EDGE_DT)
         m = C.c_uint64()
-        self.check(self.lib.rtc_mst(self.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start), _t_ptr(sk.len),
-                                    n, sk.k, int(is_containment), float(threshold), _np_ptr(out), C.byref(m)))
+        self.check(self.lib.rtc_mst_append(self.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start), _t_ptr(sk.len),
+                                           n, int(start_index), sk.k, int(is_containment), float(threshold),
+                                           _np_ptr(out), C.byref(m)))
         return out[:m.value].copy()
 
     def sketch_minhash_sharded(self, comm, seq, off, k=21, size=1000, sizes=None, stride=None, seed=42):

@@ -561,9 +561,15 @@ int rtc_boruvka_merge_host(uint32_t n, const uint64_t* h_ekey, const uint32_t* h
 int rtc_mst(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start, const uint32_t* d_len,
             uint32_t n, int kmer_size, int is_containment, double threshold, rtc_edge* h_edges_out,
             uint64_t* h_n_edges) {
+  return rtc_mst_append(ctx, d_hashes, width, d_start, d_len, n, 0, kmer_size, is_containment, threshold, h_edges_out, h_n_edges);
+}
+
+int rtc_mst_append(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start, const uint32_t* d_len,
+                   uint32_t n, uint32_t start_index, int kmer_size, int is_containment, double threshold,
+                   rtc_edge* h_edges_out, uint64_t* h_n_edges) {
   if (!ctx || !h_n_edges || (n && (!d_start || !d_len || !h_edges_out))) return RTC_ERR_ARG;
   *h_n_edges = 0;
-  if (n < 2) return RTC_OK;
+  if (n < 2 || start_index >= n) return RTC_OK;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
   std::vector<uint32_t> h_len(n);
   RTC_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -572,8 +578,8 @@ int rtc_mst(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_sta
 
   rtc_edge_list el{};
   rtc_cedge* d_sel = nullptr;
-  int st = rtc_candidate_edges_device(ctx, d_hashes, width, d_start, d_len, n, 1, n, kmer_size, is_containment, threshold,
-                                      s_fixed, &el);
+  int st = rtc_candidate_edges_device(ctx, d_hashes, width, d_start, d_len, n, std::max<uint32_t>(start_index, 1), n, kmer_size,
+                                      is_containment, threshold, s_fixed, &el);
   uint64_t nsel = 0;
   std::vector<rtc_cedge> sel;
   if (st == RTC_OK && hipMalloc((void**)&d_sel, (size_t)n * sizeof(rtc_cedge)) != hipSuccess)

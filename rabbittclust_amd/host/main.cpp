@@ -454,6 +454,7 @@ static int default_threads() {
 
 struct Options {
   string inputFile, outputFile, folder_path, premsted;
+  bool has_append = false;  // --append LIST: inputFile holds the genomes to add to --presketched/--premsted DIR
   int threads = default_threads();
   bool sketchByFile = false, noSave = false, is_fast = false, isContainment = false, isJaccard = false, isSetKmer = false;
   bool has_threshold = false, has_input = false, has_presketched = false, has_premsted = false, has_output = false;
@@ -484,6 +485,9 @@ static Options parse(int argc, char** argv) {
     else if (a == "-o" || a == "--output") { o.outputFile = need(i); o.has_output = true; }
     else if (a == "-i" || a == "--input") { o.inputFile = need(i); o.has_input = true; }
     else if (a == "--presketched") { o.folder_path = need(i); o.has_presketched = true; }
+#ifndef GREEDY_CLUST
+    else if (a == "--append") { o.inputFile = need(i); o.has_append = true; }
+#endif
     else if (a == "--fast") o.is_fast = true;
     else if (a == "--drlevel") o.drlevel = atoi(need(i));
     else if (a == "--gpus") o.gpus = need(i);
@@ -501,12 +505,16 @@ static Options parse(int argc, char** argv) {
            "  -l,--list  -e,--no-save  -d,--threshold X  -o,--output FILE  -i,--input FILE\n"
            "  --presketched DIR  --fast  --drlevel N  --gpus all|N|i,j,.. (default all visible MI355X)"
 #ifndef GREEDY_CLUST
-           "  --premsted DIR"
+           "  --premsted DIR  --append LIST (with --presketched/--premsted DIR)"
 #endif
       );
       exit(0);
     }
-    else if (a == "--append" || a == "--db" || a == "--build" || a == "--query" || a == "--assign" || a == "--stats" ||
+    else if (
+#ifdef GREEDY_CLUST
+             a == "--append" ||
+#endif
+             a == "--db" || a == "--build" || a == "--query" || a == "--assign" || a == "--stats" ||
              a == "--save-rep" || a == "--top-k" || a == "--dense" || a == "--newick-tree" || a == "--phylip-tree" ||
              a == "--nexus-tree" || a == "--linkage-matrix" || a == "--auto-threshold" || a == "--stability" ||
              a == "--dedup-dist" || a == "--reps-per-cluster" || a == "--buildDB")
@@ -533,6 +541,81 @@ static Options parse(int argc, char** argv) {
   return cl;
 }
 
+#ifndef GREEDY_CLUST
+// append_clust_mst / append_clust_mst_fast (src/sub_command.cpp:1532-1759): sketch the new genomes with the
+// stored folder's parameters, evaluate only the pairs that involve a new genome (rows >= start_index,
+// src/MST.cpp:1375-1383 -- rtc_mst_append), merge that forest with the stored MST (sort + Kruskal,
+// :1693-1700), cut, print, and write the combined folder.
+static int append_clust_mst(const Options& o, vector<Gpu>& gpus) {
+  rtc_ctx* ctx = gpus[0].ctx;
+  vector<GenomeInfo> genomes; MinHashSketchFile mh; KssdSketchFile ks; bool byFile = true;
+  double t0 = get_sec();
+  if (o.is_fast) { if (!load_kssd_sketches(o.folder_path, genomes, ks, byFile)) return 1; }
+  else if (!load_minhash_sketches(o.folder_path, genomes, mh, byFile)) return 1;
+  vector<rtc_edge> pre_mst;
+  if (!load_mst(o.folder_path, pre_mst)) return 1;
+  const size_t n_pre = genomes.size();
+  if (byFile != o.sketchByFile) {
+    cerr << "Warning: append_clust_mst(), the input format of append genomes and pre-sketched genome is not same (single input genome vs. genome list)" << endl;
+    cerr << "the output cluster file may not have the genome file name" << endl;
+  }
+  if (!o.sketchByFile) unsupported("single-FASTA input (run with -l and a genome list)");
+  cerr << "-----use the same sketch parameters with pre-generated sketches" << endl;
+  SketchJob job;
+  job.kssd = o.is_fast; job.minLen = o.minLen; job.threads = o.threads;
+  if (o.is_fast) {
+    job.kmerSize = ks.info.half_k * 2; job.drlevel = ks.info.drlevel;
+    cerr << "---use the KSSD sketches" << endl << "---the half_k is: " << ks.info.half_k << endl
+         << "---the half_subk is: " << ks.info.half_subk << endl << "---the drlevel is: " << ks.info.drlevel << endl;
+  } else {
+    job.kmerSize = mh.kmerSize; job.sketchSize = mh.sketchSize; job.isContainment = mh.isContainment; job.containCompress = mh.containCompress;
+    cerr << "---the kmer size is: " << mh.kmerSize << endl;
+    if (mh.isContainment) cerr << "---use the AAF distance (variable-sketch-size), the sketch size is in proportion with 1/" << mh.containCompress << endl;
+    else cerr << "---use the Mash distance (fixed-sketch-size), the sketch size is: " << mh.sketchSize << endl;
+  }
+  cerr << "---the thread number is: " << o.threads << endl << "---the threshold is: " << o.threshold << endl;
+  vector<GenomeInfo> add; MinHashSketchFile mh2; KssdSketchFile ks2; Resident rs2;
+  sketch_files(gpus, o.inputFile, job, add, &mh2, &ks2, rs2, true);
+  for (size_t i = 0; i < add.size(); i++) {
+    add[i].id = (int)(n_pre + i);
+    genomes.push_back(add[i]);
+    if (!o.is_fast) mh.hashes.push_back(std::move(mh2.hashes[i]));
+    else if (ks.use64) ks.h64.push_back(std::move(ks2.h64[i]));
+    else ks.h32.push_back(std::move(ks2.h32[i]));
+  }
+  ks.info.genomeNumber = (int)genomes.size();
+  cerr << "-----the size of sketches (number of genomes or sequences) is: " << genomes.size() << endl;
+  cerr << "========time of computing sketch is: " << get_sec() - t0 << "========" << endl;
+  const string new_folder = current_date_time();
+  if (!o.noSave) {
+    string command = "mkdir -p " + new_folder;
+    if (system(command.c_str()) != 0) { cerr << "ERROR: cannot create " << new_folder << endl; return 1; }
+    if (o.is_fast) { save_kssd_sketches(genomes, ks, new_folder, true); save_kssd_index(ks, new_folder); }
+    else { save_minhash_sketches(genomes, mh, new_folder, true); save_minhash_index(mh, new_folder); }
+  }
+  double t2 = get_sec();
+  DeviceSketches ds;
+  if (o.is_fast) upload_sketches(ctx, ks.use64 ? &ks.h64 : nullptr, ks.use64 ? nullptr : &ks.h32, ds);
+  else upload_sketches(ctx, &mh.hashes, nullptr, ds);
+  const int kmer_size = o.is_fast ? ks.info.half_k * 2 : mh.kmerSize;
+  const int is_containment = o.is_fast ? (int)o.isContainment : (int)mh.isContainment;
+  vector<rtc_edge> append_mst(genomes.size());
+  uint64_t ne = 0;
+  cerr << "---the start_index is: " << n_pre << endl;
+  CHECK(ctx, rtc_mst_append(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, (uint32_t)n_pre, kmer_size, is_containment, o.threshold,
+                            append_mst.data(), &ne));
+  append_mst.resize(ne);
+  cerr << "========time of generateMST is: " << get_sec() - t2 << "========" << endl;
+  vector<rtc_edge> final_graph(pre_mst);
+  final_graph.insert(final_graph.end(), append_mst.begin(), append_mst.end());
+  std::sort(final_graph.begin(), final_graph.end(), [](const rtc_edge& a, const rtc_edge& b) { return a.dist < b.dist; });  // cmpEdge
+  vector<rtc_edge> final_mst = kruskal_algorithm(final_graph, (int)genomes.size());
+  cluster_from_mst(final_mst, genomes, byFile, o.outputFile, o.threshold);
+  if (!o.noSave) { save_genome_info(genomes, new_folder, "mst", true, o.is_fast); save_mst(final_mst, new_folder); }
+  return 0;
+}
+#endif
+
 int main(int argc, char** argv) {
   Options o = parse(argc, argv);
   if (!o.has_output) { cerr << "ERROR: option -o/--output is required (unless --buildDB or --stats is used)" << endl; return 1; }
@@ -542,7 +625,9 @@ int main(int argc, char** argv) {
 
 #ifndef GREEDY_CLUST
   // ---- --premsted: no sketching, no GPU (clust_from_mst[_fast], src/sub_command.cpp:1760-1934) ----
-  if (o.has_premsted) {
+  if (o.has_append && o.has_input) { cerr << "ERROR: --append and -i/--input exclude each other" << endl; return 1; }
+  if (o.has_append && !o.has_presketched && !o.has_premsted) { cerr << "ERROR option --append, option --presketched or --premsted needed" << endl; return 1; }
+  if (o.has_premsted && !o.has_append) {
     vector<GenomeInfo> genomes; vector<rtc_edge> mst; bool byFile = true;
     if (!load_genome_info(o.folder_path, "mst", genomes, o.is_fast, byFile)) return 1;
     if (!load_mst(o.folder_path, mst)) return 1;
@@ -583,6 +668,9 @@ int main(int argc, char** argv) {
   }
   rtc_ctx* ctx = gpus[0].ctx;
   Resident rs;
+#ifndef GREEDY_CLUST
+  if (o.has_append) return append_clust_mst(o, gpus);
+#endif
 
   vector<GenomeInfo> genomes;
   MinHashSketchFile mh; KssdSketchFile ks;

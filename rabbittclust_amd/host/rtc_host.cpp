@@ -662,6 +662,22 @@ bool load_mst(const std::string& folder, std::vector<rtc_edge>& mst) {
 // =================================================================================================
 // forest cut + BFS clusters + text output
 // =================================================================================================
+std::vector<rtc_edge> kruskal_algorithm(const std::vector<rtc_edge>& graph, int vertices) {  // src/MST.cpp:59-75
+  std::vector<int> parent(vertices), ranks(vertices, 0);             // UnionFind.h: union by rank, path compression
+  for (int v = 0; v < vertices; v++) parent[v] = v;
+  auto find = [&](int x) { int r = x; while (parent[r] != r) r = parent[r]; while (parent[x] != r) { int nx = parent[x]; parent[x] = r; x = nx; } return r; };
+  std::vector<rtc_edge> tree;
+  for (const rtc_edge& e : graph) {
+    int a = find(e.preNode), b = find(e.sufNode);
+    if (a == b) continue;
+    if (ranks[a] > ranks[b]) parent[b] = a;
+    else if (ranks[a] < ranks[b]) parent[a] = b;
+    else { parent[a] = b; ranks[b]++; }
+    tree.push_back(e);
+  }
+  return tree;
+}
+
 std::vector<rtc_edge> generate_forest(const std::vector<rtc_edge>& mst, double threshold) {  // src/MST.cpp:77-85
   std::vector<rtc_edge> forest;
   for (const rtc_edge& e : mst) if (e.dist <= threshold) forest.push_back(e);

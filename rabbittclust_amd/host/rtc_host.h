@@ -92,6 +92,9 @@ void save_mst(const std::vector<rtc_edge>& mst, const std::string& folder);   //
 bool load_mst(const std::string& folder, std::vector<rtc_edge>& mst);
 
 // ---- forest cut, BFS clusters, result text (src/MST.cpp:77-85,109-142; src/MST_IO.cpp:72-179) ----
+// kruskalAlgorithm over a list already sorted by distance (src/MST.cpp:59-75, UnionFind.h:5-90): used to
+// merge a stored MST with the forest of the appended rows (append_clust_mst, src/sub_command.cpp:1693-1700)
+std::vector<rtc_edge> kruskal_algorithm(const std::vector<rtc_edge>& sorted_graph, int vertices);
 std::vector<rtc_edge> generate_forest(const std::vector<rtc_edge>& mst, double threshold);
 std::vector<std::vector<int>> generate_cluster_with_bfs(const std::vector<rtc_edge>& forest, int vertices);
 void print_result(const std::vector<std::vector<int>>& cluster, const std::vector<GenomeInfo>& g, bool sketchByFile,

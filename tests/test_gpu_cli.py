@@ -329,3 +329,51 @@ def test_clust_mst_config1_kmer_override_64_genomes(oracle, tmp_path):
     size = os.path.getsize(paths[0])
     t = oracle.tune_parameters(0, 1, 0, 1, 21, 0.05, 1000, 1000, size, size, size)
     assert t.ok and t.kmer_size == 17
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_clust_mst_append_equals_full_run(oracle, tmp_path, fast):
+    """--append (append_clust_mst, src/sub_command.cpp:1532-1759): cluster 9 genomes, append 7 more to the
+    stored folder, compare with one run over all 16 -- same sketch file bytes, same MST weights
+    (bit-for-bit, also equal to the oracle's), same clusters; the appended folder can be resumed from."""
+    tmp = str(tmp_path)
+    L = 1_800_000
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 4, 4, L, seed=21)
+    perm = [0, 5, 10, 15, 1, 4, 8, 12, 13, 2, 3, 6, 7, 9, 11, 14]  # families straddle the split
+    first, second = [paths[i] for i in perm[:9]], [paths[i] for i in perm[9:]]
+    la, lb, lall = (os.path.join(tmp, x) for x in ("a.txt", "b.txt", "all.txt"))
+    open(la, "w").write("\n".join(first) + "\n")
+    open(lb, "w").write("\n".join(second) + "\n")
+    open(lall, "w").write("\n".join(first + second) + "\n")
+    mode = ["--fast"] if fast else ["-s", "800"]
+    skname = "kssd.hash.sketch" if fast else "hash.sketch"
+
+    def run(sub, args):
+        d = os.path.join(tmp, sub)
+        os.makedirs(d)
+        out = os.path.join(d, "res.out")
+        err = _run([os.path.join(BIN, "clust-mst")] + args + ["-d", "0.05", "-t", "4", "-o", out], d)
+        folders = sorted(os.path.join(d, x) for x in os.listdir(d) if os.path.isdir(os.path.join(d, x)))
+        return out, folders, err
+
+    out_all, f_all, _ = run("all", ["-l", "-i", lall, "-k", "21"] + mode)
+    out_a, f_a, _ = run("a", ["-l", "-i", la, "-k", "21"] + mode)
+    out_ab, f_ab, err = run("ab", ["-l", "--append", lb, "--presketched", f_a[0]] + mode[:1] * fast)
+    assert "---the start_index is: 9" in err
+    assert open(os.path.join(f_ab[0], skname), "rb").read() == open(os.path.join(f_all[0], skname), "rb").read()
+    got, want = _read_edges(f_ab[0]), _read_edges(f_all[0])
+    assert len(got) == len(want) and np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
+    assert _partition(_parse_clusters(out_ab)) == _partition(_parse_clusters(out_all))
+    assert len(_parse_clusters(out_ab)) < 16
+    if not fast:  # the oracle's MST over all 16 sketches has the same weights
+        _, sk = _read_hash_sketch(f_ab[0])
+        flat, start, lens = oracle.to_csr(sk)
+        omst = oracle.mst(flat, start, lens, 21, 0, 0.05)
+        assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(omst["dist"]).view(np.uint64))
+    # the combined folder resumes like any other
+    out_r = os.path.join(tmp, "resume.out")
+    _run([os.path.join(BIN, "clust-mst"), "--premsted", f_ab[0], "-d", "0.05", "-o", out_r] + mode[:1] * fast, tmp)
+    assert open(out_r).read() == open(out_ab).read()
+    # usage errors of the reference (src/main.cpp:643-646)
+    r = subprocess.run([os.path.join(BIN, "clust-mst"), "-l", "--append", lb, "-o", out_r], capture_output=True, text=True)
+    assert r.returncode != 0 and "--presketched or --premsted needed" in r.stderr
