@@ -196,6 +196,15 @@ int rtc_mst_append(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t
                    const uint32_t* d_len, uint32_t n, uint32_t start_index, int kmer_size, int is_containment,
                    double threshold, rtc_edge* h_edges_out, uint64_t* h_n_edges);
 
+/* The same with the --dense by-products (src/MST.cpp:1333-1352, :1517-1530, :1703-1713): for every
+ * candidate pair (the pairs that become EdgeInfo records) with distance d, both genomes are counted
+ * in every radius bucket t with t/dense_span >= d, and ANI bin (int)((1-d)*100) is incremented.
+ * h_dense: dense_span x n int32 row-major (mst.dense layout, src/MST_IO.cpp:219-233), h_ani: 101 u64
+ * (mst.ani).  dense_span = 0: plain rtc_mst_append.  Buckets use the host doubles of the edge weights. */
+int rtc_mst_dense(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start, const uint32_t* d_len,
+                  uint32_t n, uint32_t start_index, int kmer_size, int is_containment, double threshold,
+                  rtc_edge* h_edges_out, uint64_t* h_n_edges, int dense_span, int32_t* h_dense, uint64_t* h_ani);
+
 /* ---- multi-GPU: RCCL collectives over xGMI and the sharded clust-mst step ----------------- */
 /* The reference is one shared-memory process (OpenMP over 8-row blocks of the pair space,
  * src/MST.cpp:1382, and over files, src/SketchInfo.cpp:878).  Here one rtc_comm per rtc_ctx (= per

@@ -94,6 +94,7 @@ SIGNATURES = {
     "rtc_mst_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64), _vp]),
     "rtc_mst": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64)]),
     "rtc_mst_append": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64)]),
+    "rtc_mst_dense": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64), _i, _vp, _vp]),
     "rtc_greedy": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _vp, _i, _i, _i, C.c_double, _vp,
                         C.POINTER(_u32)]),
 }

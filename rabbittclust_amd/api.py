@@ -211,6 +211,18 @@ class Context:
                                                   _t_ptr(count)))
         return edges, count
 
+    def mst_dense(self, sk, threshold, is_containment=False, span=100, start_index=0):
+        """rtc_mst_dense: (edge.mst records, dense[span, n] int32, ani[101] u64) -- the --dense by-products."""
+        n = sk.n
+        out = np.zeros(max(n, 1), dtype=EDGE_DT)
+        dense = np.zeros((span, max(n, 1)), dtype=np.int32)
+        ani = np.zeros(101, dtype=np.uint64)
+        m = C.c_uint64()
+        self.check(self.lib.rtc_mst_dense(self.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start), _t_ptr(sk.len), n,
+                                          int(start_index), sk.k, int(is_containment), float(threshold), _np_ptr(out),
+                                          C.byref(m), span, _np_ptr(dense), _np_ptr(ani)))
+        return out[:m.value].copy(), dense[:, :n], ani
+
     def pair_edges(self, sk, row0, row1, col0, col1, radio, cap):
         """Fused form of pair_common + extract_edges (no dense matrix).  Returns (edges, count)."""
         edges = torch.empty((max(cap, 1), 3), dtype=torch.int32, device=self.device)

@@ -65,9 +65,16 @@ struct rtc_edge_list {  // device-resident candidate edges
   unsigned long long* d_count = nullptr;
   int contractions = 0;
 };
+// on_new (optional): called with every batch of freshly produced candidate edges (device pointer, count)
+// before the list may be contracted -- the --dense histograms see every candidate pair exactly once
+struct rtc_edge_observer {
+  int (*on_new)(void* self, const rtc_cedge* d_new, uint64_t count);
+  void* self;
+};
 int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
                                const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1, int kmer_size,
-                               int is_containment, double threshold, uint32_t s_fixed, rtc_edge_list* el);
+                               int is_containment, double threshold, uint32_t s_fixed, rtc_edge_list* el,
+                               const rtc_edge_observer* obs = nullptr);
 void rtc_edge_list_free(rtc_edge_list* el);
 int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_len, uint32_t n,
                    int is_containment, uint32_t s_fixed, const rtc_reduce_hook* hook, rtc_cedge* d_sel,

@@ -307,7 +307,8 @@ int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uin
 // forest of the parts' forests.
 int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
                                const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1, int kmer_size,
-                               int is_containment, double threshold, uint32_t s_fixed, rtc_edge_list* el) {
+                               int is_containment, double threshold, uint32_t s_fixed, rtc_edge_list* el,
+                               const rtc_edge_observer* obs) {
   const int radio = (int)(2.0 * exp(threshold * (kmer_size - 1)) - 1.0);  // src/MST.cpp:26-37,1292
   uint64_t budget = (uint64_t)256 << 20;  // edges (3 GiB)
   if (const char* e = getenv("RTC_EDGE_BUDGET")) budget = std::max<uint64_t>(strtoull(e, nullptr, 10), 1024);  // tests of the dense path
@@ -340,11 +341,16 @@ int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, co
   };
   unsigned long long cnt = 0;
   RTC_TRY(run_rows(row0, row1, &cnt));
-  if (cnt <= el->cap) { el->m = cnt; return RTC_OK; }
+  if (cnt <= el->cap) {
+    el->m = cnt;
+    if (obs && cnt) RTC_TRY(obs->on_new(obs->self, el->d_edges, cnt));
+    return RTC_OK;
+  }
   if (cnt <= budget) {  // grow to the exact need and redo the launch
     RTC_TRY(ensure(cnt));
     RTC_TRY(run_rows(row0, row1, &cnt));
     el->m = cnt;
+    if (obs && cnt) RTC_TRY(obs->on_new(obs->self, el->d_edges, cnt));
     return RTC_OK;
   }
   // ---- dense input: row chunks + contraction ----
@@ -375,6 +381,7 @@ int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, co
       st = rtc_fail(ctx, RTC_ERR_NOMEM, "edge budget %llu too small for a 64-row block", (unsigned long long)budget);
       break;
     }
+    if (obs && cnt > el->m) { st = obs->on_new(obs->self, el->d_edges + el->m, cnt - el->m); if (st != RTC_OK) break; }
     el->m = cnt;
     r0 = r1;
     if (el->m > budget / 2 && r0 < row1) st = contract();
@@ -567,8 +574,56 @@ int rtc_mst(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_sta
 int rtc_mst_append(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start, const uint32_t* d_len,
                    uint32_t n, uint32_t start_index, int kmer_size, int is_containment, double threshold,
                    rtc_edge* h_edges_out, uint64_t* h_n_edges) {
+  return rtc_mst_dense(ctx, d_hashes, width, d_start, d_len, n, start_index, kmer_size, is_containment, threshold, h_edges_out,
+                       h_n_edges, 0, nullptr, nullptr);
+}
+
+namespace {
+// --dense accumulation (src/MST.cpp:1517-1530): every candidate pair adds one to the start bucket
+// t0 = lower_bound(radius, dist) of both genomes and to its ANI bin.  Distances are the HOST doubles
+// (same libm expression as the edge weights), so the buckets are the reference's bit for bit; with a
+// common sketch size they come from a table indexed by `common`.
+struct DenseAcc {
+  rtc_ctx* ctx; const uint32_t* h_len; uint32_t n; int k, cont, span; uint32_t s_fixed;
+  int32_t* dense; uint64_t* ani;
+  std::vector<double> radius; std::vector<int16_t> t0_of, ani_of; std::vector<rtc_cedge> buf;
+  void classify(uint32_t common, uint32_t a, uint32_t b, int& t0, int& an) const {
+    const double d = host_mst_distance((int)common, (int)a, (int)b, k, cont);
+    t0 = (int)(std::lower_bound(radius.begin(), radius.end(), d) - radius.begin());
+    an = (int)((1.0 - d) * 100.0);
+    if (an >= 101) an = 100;
+    if (an < 0) an = 0;  // distances above 1 (no clamp in compute_minhash_mst); the reference would index out of range
+  }
+  static int on_new(void* self, const rtc_cedge* d_new, uint64_t count) {
+    DenseAcc* A = (DenseAcc*)self;
+    const uint64_t slab = 1u << 22;
+    A->buf.resize((size_t)std::min<uint64_t>(slab, count));
+    for (uint64_t p = 0; p < count; p += slab) {
+      const uint64_t c = std::min<uint64_t>(slab, count - p);
+      hipError_t e = hipMemcpyAsync(A->buf.data(), d_new + p, c * sizeof(rtc_cedge), hipMemcpyDeviceToHost, A->ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(A->ctx->stream);
+      if (e != hipSuccess) return rtc_fail(A->ctx, RTC_ERR_HIP, "dense: edge read-back -> %s", hipGetErrorString(e));
+      for (uint64_t q = 0; q < c; q++) {
+        const rtc_cedge& ed = A->buf[q];
+        int t0, an;
+        if (A->s_fixed) { t0 = A->t0_of[ed.common]; an = A->ani_of[ed.common]; }
+        else A->classify(ed.common, A->h_len[ed.i], A->h_len[ed.j], t0, an);
+        if (t0 < A->span) { A->dense[(size_t)t0 * A->n + ed.i]++; A->dense[(size_t)t0 * A->n + ed.j]++; }
+        A->ani[an]++;
+      }
+    }
+    return RTC_OK;
+  }
+};
+}  // namespace
+
+int rtc_mst_dense(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start, const uint32_t* d_len,
+                  uint32_t n, uint32_t start_index, int kmer_size, int is_containment, double threshold,
+                  rtc_edge* h_edges_out, uint64_t* h_n_edges, int dense_span, int32_t* h_dense, uint64_t* h_ani) {
   if (!ctx || !h_n_edges || (n && (!d_start || !d_len || !h_edges_out))) return RTC_ERR_ARG;
+  if (dense_span < 0 || (dense_span > 0 && (!h_dense || !h_ani))) return RTC_ERR_ARG;
   *h_n_edges = 0;
+  if (dense_span) { memset(h_dense, 0, (size_t)dense_span * n * sizeof(int32_t)); memset(h_ani, 0, 101 * sizeof(uint64_t)); }
   if (n < 2 || start_index >= n) return RTC_OK;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
   std::vector<uint32_t> h_len(n);
@@ -578,8 +633,24 @@ int rtc_mst_append(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t
 
   rtc_edge_list el{};
   rtc_cedge* d_sel = nullptr;
+  DenseAcc acc{ctx, h_len.data(), n, kmer_size, is_containment, dense_span, s_fixed, h_dense, h_ani, {}, {}, {}, {}};
+  rtc_edge_observer obs{DenseAcc::on_new, &acc};
+  if (dense_span) {
+    const double step = 1.0 / dense_span;                              // src/MST.cpp:1333-1340
+    for (int i = 0; i < dense_span; i++) acc.radius.push_back(step * (double)i);
+    if (s_fixed) {
+      acc.t0_of.resize(s_fixed + 1); acc.ani_of.resize(s_fixed + 1);
+      for (uint32_t c = 0; c <= s_fixed; c++) { int t0, an; acc.classify(c, s_fixed, s_fixed, t0, an); acc.t0_of[c] = (int16_t)t0; acc.ani_of[c] = (int16_t)an; }
+    }
+  }
   int st = rtc_candidate_edges_device(ctx, d_hashes, width, d_start, d_len, n, std::max<uint32_t>(start_index, 1), n, kmer_size,
-                                      is_containment, threshold, s_fixed, &el);
+                                      is_containment, threshold, s_fixed, &el, dense_span ? &obs : nullptr);
+  if (st == RTC_OK && dense_span) {  // start-bucket counts -> cumulative density counts (:1703-1713)
+    for (uint32_t g = 0; g < n; g++) {
+      int32_t a = 0;
+      for (int t = 0; t < dense_span; t++) { a += h_dense[(size_t)t * n + g]; h_dense[(size_t)t * n + g] = a; }
+    }
+  }
   uint64_t nsel = 0;
   std::vector<rtc_cedge> sel;
   if (st == RTC_OK && hipMalloc((void**)&d_sel, (size_t)n * sizeof(rtc_cedge)) != hipSuccess)

@@ -454,6 +454,7 @@ static int default_threads() {
 
 struct Options {
   string inputFile, outputFile, folder_path, premsted;
+  bool dense = false;       // --dense: density maps, ANI histogram and the MST noise-removal pass
   bool has_append = false;  // --append LIST: inputFile holds the genomes to add to --presketched/--premsted DIR
   int threads = default_threads();
   bool sketchByFile = false, noSave = false, is_fast = false, isContainment = false, isJaccard = false, isSetKmer = false;
@@ -491,6 +492,9 @@ static Options parse(int argc, char** argv) {
     else if (a == "--fast") o.is_fast = true;
     else if (a == "--drlevel") o.drlevel = atoi(need(i));
     else if (a == "--gpus") o.gpus = need(i);
+#ifndef GREEDY_CLUST
+    else if (a == "--dense") o.dense = true;
+#endif
     else if (a == "--inverted-index") { /* always on, as in the reference (src/main.cpp:104,129) */ }
 #ifndef GREEDY_CLUST
     else if (a == "--premsted") { o.folder_path = need(i); o.has_premsted = true; }
@@ -515,7 +519,11 @@ static Options parse(int argc, char** argv) {
              a == "--append" ||
 #endif
              a == "--db" || a == "--build" || a == "--query" || a == "--assign" || a == "--stats" ||
-             a == "--save-rep" || a == "--top-k" || a == "--dense" || a == "--newick-tree" || a == "--phylip-tree" ||
+             a == "--save-rep" || a == "--top-k" ||
+#ifdef GREEDY_CLUST
+             a == "--dense" ||
+#endif
+              a == "--newick-tree" || a == "--phylip-tree" ||
              a == "--nexus-tree" || a == "--linkage-matrix" || a == "--auto-threshold" || a == "--stability" ||
              a == "--dedup-dist" || a == "--reps-per-cluster" || a == "--buildDB")
       unsupported(a.c_str());
@@ -531,6 +539,21 @@ static Options parse(int argc, char** argv) {
   print_result(cl, genomes, sketchByFile, outputFile, threshold);
   cerr << "-----write the cluster result into: " << outputFile << endl;
   cerr << "-----the cluster number of: " << outputFile << " is: " << cl.size() << endl;
+}
+
+// --dense noise removal (src/sub_command.cpp:3071-3103): drop the forest edges of low-density nodes, cluster again
+[[maybe_unused]] static void remove_noise_and_print(const vector<rtc_edge>& mst, const vector<GenomeInfo>& genomes, bool sketchByFile,
+                                                    const string& outputFile, double threshold, const vector<int32_t>& dense, int span) {
+  vector<rtc_edge> forest = generate_forest(mst, threshold);
+  vector<vector<int>> cl = generate_cluster_with_bfs(forest, (int)genomes.size());
+  vector<int> noise = noise_nodes(cl, dense, span, (int)genomes.size(), threshold);
+  cerr << "-----the total noiseArr size is: " << noise.size() << endl;
+  forest = modify_forest(forest, noise);
+  vector<vector<int>> cluster = generate_cluster_with_bfs(forest, (int)genomes.size());
+  const string outputFileNew = outputFile + ".removeNoise";
+  print_result(cluster, genomes, sketchByFile, outputFileNew);
+  cerr << "-----write the cluster without noise into: " << outputFileNew << endl;
+  cerr << "-----the cluster number of: " << outputFileNew << " is: " << cluster.size() << endl;
 }
 
 [[maybe_unused]] static vector<vector<int>> clusters_from_rep_of(const vector<int32_t>& rep_of) {
@@ -632,6 +655,11 @@ int main(int argc, char** argv) {
     if (!load_genome_info(o.folder_path, "mst", genomes, o.is_fast, byFile)) return 1;
     if (!load_mst(o.folder_path, mst)) return 1;
     cluster_from_mst(mst, genomes, byFile, o.outputFile, o.threshold);
+    if (o.dense) {  // clust_from_mst with !no_dense: the stored mst.dense drives the noise pass (src/sub_command.cpp:1795-1822)
+      vector<int32_t> dense; int span = 0, gn = 0;
+      if (!load_dense(o.folder_path, dense, span, gn) || gn != (int)genomes.size()) return 1;
+      remove_noise_and_print(mst, genomes, byFile, o.outputFile, o.threshold, dense, span);
+    }
     return 0;
   }
 #endif
@@ -787,9 +815,12 @@ int main(int argc, char** argv) {
     else if (o.is_fast) upload_sketches(gpus[g].ctx, ks.use64 ? &ks.h64 : nullptr, ks.use64 ? nullptr : &ks.h32, dss[g]);
     else upload_sketches(gpus[g].ctx, &mh.hashes, nullptr, dss[g]);
   });
-  if (G == 1) {
+  vector<int32_t> dense; uint64_t ani[101];
+  if (G == 1 || o.dense) {  // --dense: the histograms are accumulated beside the single-GPU candidate list
     const DeviceSketches& ds = dss[0];
-    CHECK(ctx, rtc_mst(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, kmer_size, is_containment, o.threshold, mst.data(), &nedges));
+    if (o.dense) dense.resize((size_t)DENSE_SPAN * ds.n);
+    CHECK(ctx, rtc_mst_dense(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, 0, kmer_size, is_containment, o.threshold, mst.data(), &nedges,
+                             o.dense ? DENSE_SPAN : 0, o.dense ? dense.data() : nullptr, o.dense ? ani : nullptr));
   } else {
     // N x N row-sharded across the GPUs, one all-reduce per Boruvka round; every rank ends with the same forest
     vector<vector<rtc_edge>> out(G, vector<rtc_edge>(genomes.size()));
@@ -818,6 +849,10 @@ int main(int argc, char** argv) {
     cerr << "========time of saveMST is: " << get_sec() - t3 << "========" << endl;
   }
   cluster_from_mst(mst, genomes, sketchByFile, o.outputFile, o.threshold);
+  if (o.dense) {
+    if (!o.noSave && !from_sketches) { save_ani(folder_path, ani); save_dense(folder_path, dense, DENSE_SPAN, (int)genomes.size()); }
+    remove_noise_and_print(mst, genomes, sketchByFile, o.outputFile, o.threshold, dense, DENSE_SPAN);
+  }
 #endif
   for (Gpu& g : gpus) { if (g.comm) rtc_comm_destroy(g.comm); }
   for (Gpu& g : gpus) rtc_ctx_destroy(g.ctx);

@@ -662,6 +662,77 @@ bool load_mst(const std::string& folder, std::vector<rtc_edge>& mst) {
 // =================================================================================================
 // forest cut + BFS clusters + text output
 // =================================================================================================
+void save_dense(const std::string& folder, const std::vector<int32_t>& dense, int span, int genome_number) {  // src/MST_IO.cpp:219-233
+  const std::string file = folder + "/mst.dense";
+  FILE* fp = fopen(file.c_str(), "w+");
+  if (!fp) { std::cerr << "ERROR: saveDense(), cannot open the file: " << file; exit(1); }
+  fwrite(&genome_number, sizeof(int), 1, fp);
+  fwrite(&span, sizeof(int), 1, fp);
+  fwrite(dense.data(), sizeof(int32_t), (size_t)span * genome_number, fp);
+  fclose(fp);
+  std::cerr << "-----save the dense file into: " << folder << std::endl;
+}
+
+bool load_dense(const std::string& folder, std::vector<int32_t>& dense, int& span, int& genome_number) {  // src/MST_IO.cpp:12-28
+  const std::string file = folder + "/mst.dense";
+  FILE* fp = fopen(file.c_str(), "r");
+  if (!fp) { std::cerr << "ERROR: saveDense(), cannot open the file: " << file; return false; }
+  bool ok = fread(&genome_number, sizeof(int), 1, fp) == 1 && fread(&span, sizeof(int), 1, fp) == 1 && span >= 0 && genome_number >= 0;
+  if (ok) {
+    dense.resize((size_t)span * genome_number);
+    ok = fread(dense.data(), sizeof(int32_t), dense.size(), fp) == dense.size();
+  }
+  fclose(fp);
+  if (ok) std::cerr << "-----read the dense file from: " << file << std::endl;
+  return ok;
+}
+
+void save_ani(const std::string& folder, const uint64_t ani[101]) {  // src/MST_IO.cpp:235-250
+  const std::string file = folder + "/mst.ani";
+  FILE* fp = fopen(file.c_str(), "w+");
+  if (!fp) { std::cerr << "ERROR: saveANI(), cannot open file: " << file << std::endl; exit(1); }
+  fwrite(ani, sizeof(uint64_t), 101, fp);
+  fclose(fp);
+  std::cerr << "-----save the ani file into: " << file << std::endl;
+}
+
+bool load_ani(const std::string& folder, uint64_t ani[101]) {
+  FILE* fp = fopen((folder + "/mst.ani").c_str(), "r");
+  if (!fp) return false;
+  const bool ok = fread(ani, sizeof(uint64_t), 101, fp) == 101;
+  fclose(fp);
+  return ok;
+}
+
+std::vector<int> noise_nodes(const std::vector<std::vector<int>>& cluster, const std::vector<int32_t>& dense, int span,
+                             int genome_number, double threshold) {  // src/sub_command.cpp:3077-3092, src/MST.cpp:189-211
+  const int alpha = 2;
+  const int denseIndex = (int)(threshold / 0.01);
+  std::vector<int> total;
+  if (denseIndex < 0 || denseIndex >= span) return total;
+  for (const std::vector<int>& cl : cluster) {
+    if (cl.size() == 1) continue;
+    std::vector<std::pair<int, int>> arr;
+    for (int element : cl) arr.emplace_back(element, dense[(size_t)denseIndex * genome_number + element]);
+    std::sort(arr.begin(), arr.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.second < b.second; });  // cmpPair
+    const int denseQ1 = arr[arr.size() / 4].second;
+    int thr = std::max(std::min(denseQ1 - 1, alpha), 0);
+    for (const auto& p : arr) { if (p.second <= thr) total.push_back(p.first); else break; }
+  }
+  return total;
+}
+
+std::vector<rtc_edge> modify_forest(const std::vector<rtc_edge>& forest, const std::vector<int>& noise) {  // src/MST.cpp:86-107
+  std::vector<char> is_noise;
+  for (int v : noise) { if ((size_t)v >= is_noise.size()) is_noise.resize(v + 1, 0); is_noise[v] = 1; }
+  std::vector<rtc_edge> out;
+  for (const rtc_edge& e : forest) {
+    const bool rm = ((size_t)e.preNode < is_noise.size() && is_noise[e.preNode]) || ((size_t)e.sufNode < is_noise.size() && is_noise[e.sufNode]);
+    if (!rm) out.push_back(e);
+  }
+  return out;
+}
+
 std::vector<rtc_edge> kruskal_algorithm(const std::vector<rtc_edge>& graph, int vertices) {  // src/MST.cpp:59-75
   std::vector<int> parent(vertices), ranks(vertices, 0);             // UnionFind.h: union by rank, path compression
   for (int v = 0; v < vertices; v++) parent[v] = v;

@@ -91,6 +91,18 @@ void save_kssd_index(const KssdSketchFile& f, const std::string& folder);  // ks
 void save_mst(const std::vector<rtc_edge>& mst, const std::string& folder);   // edge.mst
 bool load_mst(const std::string& folder, std::vector<rtc_edge>& mst);
 
+// ---- --dense by-products: mst.dense / mst.ani (src/MST_IO.cpp:12-45, :219-250) and the noise-removal
+// pass of compute_clusters (src/sub_command.cpp:3071-3103; getNoiseNode / modifyForest, src/MST.cpp:86-107,189-211) ----
+constexpr int DENSE_SPAN = 100;  // src/common.hpp
+void save_dense(const std::string& folder, const std::vector<int32_t>& dense, int span, int genome_number);  // dense: span x n row-major
+bool load_dense(const std::string& folder, std::vector<int32_t>& dense, int& span, int& genome_number);
+void save_ani(const std::string& folder, const uint64_t ani[101]);
+bool load_ani(const std::string& folder, uint64_t ani[101]);
+// nodes of every multi-member cluster whose density at the threshold's bucket is <= min(Q1 - 1, alpha = 2)
+std::vector<int> noise_nodes(const std::vector<std::vector<int>>& cluster, const std::vector<int32_t>& dense, int span,
+                             int genome_number, double threshold);
+std::vector<rtc_edge> modify_forest(const std::vector<rtc_edge>& forest, const std::vector<int>& noise);
+
 // ---- forest cut, BFS clusters, result text (src/MST.cpp:77-85,109-142; src/MST_IO.cpp:72-179) ----
 // kruskalAlgorithm over a list already sorted by distance (src/MST.cpp:59-75, UnionFind.h:5-90): used to
 // merge a stored MST with the forest of the appended rows (append_clust_mst, src/sub_command.cpp:1693-1700)

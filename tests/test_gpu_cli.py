@@ -331,6 +331,43 @@ def test_clust_mst_config1_kmer_override_64_genomes(oracle, tmp_path):
     assert t.ok and t.kmer_size == 17
 
 
+def _check_index_files(folder, fast):
+    """The inverted-index files a run leaves behind (minhash.sketch.index: MHIDX001, src/SketchInfo.h:115-160;
+    kssd.sketch.index + .dict, src/SketchInfo.cpp:1379-1467) must invert exactly the sketches stored
+    beside them: rebuild the posting lists from the files and compare with the sketch file."""
+    if not fast:
+        _, sk = _read_hash_sketch(folder)
+        raw = open(os.path.join(folder, "minhash.sketch.index"), "rb").read()
+        assert raw[:8] == b"MHIDX001"
+        (H,) = struct.unpack_from("<Q", raw, 8)
+        pos, inv = 16, {}
+        for _ in range(H):
+            h, m = struct.unpack_from("<QI", raw, pos); pos += 12
+            inv[h] = sorted(struct.unpack_from(f"<{m}I", raw, pos)); pos += 4 * m
+        assert pos == len(raw)
+    else:
+        raw = open(os.path.join(folder, "kssd.hash.sketch"), "rb").read()
+        n = struct.unpack_from("<iiiii", raw, 0)[4]
+        pos, sk = 20, []
+        for _ in range(n):
+            (m,) = struct.unpack_from("<Q", raw, pos); pos += 8
+            sk.append(np.frombuffer(raw, dtype="<u4", count=m, offset=pos)); pos += 4 * m
+        idx = open(os.path.join(folder, "kssd.sketch.index"), "rb").read()
+        (H,) = struct.unpack_from("<Q", idx, 0)
+        keys = np.frombuffer(idx, dtype="<u4", count=H, offset=8)
+        counts = np.frombuffer(idx, dtype="<u4", count=H, offset=8 + 4 * H)
+        ids = np.frombuffer(open(os.path.join(folder, "kssd.sketch.dict"), "rb").read(), dtype="<u4")
+        assert len(idx) == 8 + 8 * H and counts.sum() == len(ids)
+        inv, p = {}, 0
+        for k_, c in zip(keys.tolist(), counts.tolist()):
+            inv[k_] = sorted(ids[p:p + c].tolist()); p += c
+    want = {}
+    for gi, h in enumerate(sk):
+        for x in h.tolist():
+            want.setdefault(x, []).append(gi)
+    assert inv == want and len(inv) > 0
+
+
 @pytest.mark.parametrize("fast", [False, True])
 def test_clust_mst_append_equals_full_run(oracle, tmp_path, fast):
     """--append (append_clust_mst, src/sub_command.cpp:1532-1759): cluster 9 genomes, append 7 more to the
@@ -360,6 +397,8 @@ def test_clust_mst_append_equals_full_run(oracle, tmp_path, fast):
     out_a, f_a, _ = run("a", ["-l", "-i", la, "-k", "21"] + mode)
     out_ab, f_ab, err = run("ab", ["-l", "--append", lb, "--presketched", f_a[0]] + mode[:1] * fast)
     assert "---the start_index is: 9" in err
+    for folder in (f_all[0], f_a[0], f_ab[0]):
+        _check_index_files(folder, fast)
     assert open(os.path.join(f_ab[0], skname), "rb").read() == open(os.path.join(f_all[0], skname), "rb").read()
     got, want = _read_edges(f_ab[0]), _read_edges(f_all[0])
     assert len(got) == len(want) and np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
@@ -377,3 +416,56 @@ def test_clust_mst_append_equals_full_run(oracle, tmp_path, fast):
     # usage errors of the reference (src/main.cpp:643-646)
     r = subprocess.run([os.path.join(BIN, "clust-mst"), "-l", "--append", lb, "-o", out_r], capture_output=True, text=True)
     assert r.returncode != 0 and "--presketched or --premsted needed" in r.stderr
+
+
+def test_clust_mst_dense_files_and_noise_removal(oracle, tmp_path):
+    """--dense (src/sub_command.cpp:3071-3103): mst.dense / mst.ani hold the brute-force histograms of the
+    candidate pairs, the .removeNoise file is the forest without the edges of low-density nodes; --premsted
+    --dense reproduces it from the stored files."""
+    from test_gpu_mst import _dense_brute_force
+    tmp = str(tmp_path)
+    L = 1_800_000
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 3, 6, L, seed=31)
+    out = os.path.join(tmp, "d.out")
+    _run([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "500", "-d", "0.05", "--dense", "-t", "4", "-o", out], tmp)
+    folder = [os.path.join(tmp, d) for d in os.listdir(tmp) if os.path.isdir(os.path.join(tmp, d)) and d[:2] == "20"][0]
+    _, sk = _read_hash_sketch(folder)
+    n = len(sk)
+    want_dense, want_ani = _dense_brute_force(oracle, sk, 21, False, 0.05)
+    raw = open(os.path.join(folder, "mst.dense"), "rb").read()
+    gn, span = struct.unpack_from("<ii", raw, 0)
+    assert (gn, span) == (n, 100) and len(raw) == 8 + 4 * n * 100
+    assert np.array_equal(np.frombuffer(raw, dtype="<i4", offset=8).reshape(100, n), want_dense)
+    assert np.array_equal(np.frombuffer(open(os.path.join(folder, "mst.ani"), "rb").read(), dtype="<u8"), want_ani)
+    # the noise pass restated: per multi-member cluster, nodes with density <= max(min(Q1 - 1, 2), 0) at bucket d / 0.01
+    mst = _read_edges(folder)
+    forest = [e for e in mst if e["dist"] <= 0.05]
+
+    def components(edges):
+        parent = list(range(n))
+
+        def find(x):
+            while parent[x] != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+        for e in edges:
+            parent[find(int(e["pre"]))] = find(int(e["suf"]))
+        groups = {}
+        for v in range(n):
+            groups.setdefault(find(v), []).append(v)
+        return list(groups.values())
+    noise = set()
+    idx = int(0.05 / 0.01)
+    for cl in components(forest):
+        if len(cl) == 1:
+            continue
+        dens = sorted(int(want_dense[idx, v]) for v in cl)
+        thr = max(min(dens[len(dens) // 4] - 1, 2), 0)
+        noise |= {v for v in cl if want_dense[idx, v] <= thr}
+    kept = [e for e in forest if int(e["pre"]) not in noise and int(e["suf"]) not in noise]
+    assert _partition(_parse_clusters(out + ".removeNoise")) == _partition(components(kept))
+    assert not open(out + ".removeNoise").read().startswith("#")  # printed without the threshold header
+    out2 = os.path.join(tmp, "d2.out")
+    _run([os.path.join(BIN, "clust-mst"), "--premsted", folder, "--dense", "-d", "0.05", "-o", out2], tmp)
+    assert open(out2 + ".removeNoise").read() == open(out + ".removeNoise").read()

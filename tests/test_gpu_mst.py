@@ -385,3 +385,57 @@ def test_bench_kssd_mode_small(tmp_path):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["dtype"] == "u32" and line["mst_edges"] > 0 and line["roofline"]["kernel"] == "sketch_kssd_kernel"
     assert line["cpu_baseline"]["value"] > 0 and "KSSD" in line["cpu_baseline"]["sample"]
+
+
+def _dense_brute_force(oracle, sk, k, containment, thr, span=100):
+    """--dense restated from src/MST.cpp:1333-1352,1468-1530,1703-1713 over the oracle's candidate pairs."""
+    flat, start, lens = oracle.to_csr(sk, dtype=sk[0].dtype)
+    n = len(sk)
+    radio = oracle.lib().orc_mst_radio(thr, k)
+    radius = np.array([(1.0 / span) * i for i in range(span)])
+    dense = np.zeros((span, n), dtype=np.int64)
+    ani = np.zeros(101, dtype=np.uint64)
+    for e in oracle.candidate_pairs(flat, start, lens):
+        i, j, c = int(e["pre"]), int(e["suf"]), int(e["common"])
+        a, b = int(lens[i]), int(lens[j])
+        if max(a, b) > radio * min(a, b):
+            continue
+        d = oracle.lib().orc_mst_distance(c, a, b, k, int(containment))
+        t0 = int(np.searchsorted(radius, d, side="left"))
+        if t0 < span:
+            dense[t0, i] += 1
+            dense[t0, j] += 1
+        ani[min(int((1.0 - d) * 100.0), 100)] += 1
+    return np.cumsum(dense, axis=0).astype(np.int32), ani
+
+
+@pytest.mark.parametrize("shape", ["fixed", "variable", "kssd"])
+def test_mst_dense_histograms_equal_brute_force(ctx, oracle, shape):
+    """rtc_mst_dense: density counts and ANI histogram over the candidate pairs, bucketed with the host
+    doubles (table per `common` for equal sizes, per-pair otherwise); also through the edge-budget chunk
+    path, where the list is contracted between chunks but every pair must still be counted once."""
+    import os
+    from rabbittclust_amd import api
+    rng = np.random.default_rng({"fixed": 41, "variable": 42, "kssd": 43}[shape])
+    dt = np.uint32 if shape == "kssd" else np.uint64
+    pool = np.unique(rng.integers(1, 1 << 30, size=5000, dtype=np.uint64))
+    core = [rng.choice(pool, size=260, replace=False) for _ in range(12)]
+    sk = []
+    for g in range(300):
+        size = 200 if shape == "fixed" else int(rng.integers(60, 260))
+        own = core[g % 12][: int(size * rng.uniform(0.3, 1.0))]
+        v = np.unique(np.concatenate([own, rng.choice(pool, size=size, replace=False)]))[:size]
+        sk.append(np.sort(v).astype(dt))
+    k = 22 if shape == "kssd" else 21
+    dev = api.SketchSet.from_host(sk, ctx.device, k=k, kind="kssd" if shape == "kssd" else "minhash", width=4 if shape == "kssd" else 8)
+    want_dense, want_ani = _dense_brute_force(oracle, sk, k, False, 0.05)
+    mst, dense, ani = ctx.mst_dense(dev, 0.05)
+    assert np.array_equal(dense, want_dense) and np.array_equal(ani, want_ani)
+    assert want_ani.sum() > 5000 and want_dense[-1].max() > 20
+    assert np.array_equal(mst, ctx.mst(dev, 0.05))
+    os.environ["RTC_EDGE_BUDGET"] = "21000"
+    try:
+        mst2, dense2, ani2 = ctx.mst_dense(dev, 0.05)
+    finally:
+        del os.environ["RTC_EDGE_BUDGET"]
+    assert np.array_equal(dense2, want_dense) and np.array_equal(ani2, want_ani) and np.array_equal(mst2, mst)
