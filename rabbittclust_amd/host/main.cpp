@@ -454,6 +454,7 @@ static int default_threads() {
 
 struct Options {
   string inputFile, outputFile, folder_path, premsted;
+  bool newick = false, phylip = false, nexus = false, linkage = false;  // --newick-tree / --phylip-tree / --nexus-tree / --linkage-matrix
   bool dense = false;       // --dense: density maps, ANI histogram and the MST noise-removal pass
   bool has_append = false;  // --append LIST: inputFile holds the genomes to add to --presketched/--premsted DIR
   int threads = default_threads();
@@ -494,6 +495,10 @@ static Options parse(int argc, char** argv) {
     else if (a == "--gpus") o.gpus = need(i);
 #ifndef GREEDY_CLUST
     else if (a == "--dense") o.dense = true;
+    else if (a == "--newick-tree") o.newick = true;
+    else if (a == "--phylip-tree") o.phylip = true;
+    else if (a == "--nexus-tree") o.nexus = true;
+    else if (a == "--linkage-matrix") o.linkage = true;
 #endif
     else if (a == "--inverted-index") { /* always on, as in the reference (src/main.cpp:104,129) */ }
 #ifndef GREEDY_CLUST
@@ -541,6 +546,9 @@ static Options parse(int argc, char** argv) {
   cerr << "-----the cluster number of: " << outputFile << " is: " << cl.size() << endl;
 }
 
+struct Options;
+static void write_trees(const Options& o, const vector<GenomeInfo>& genomes, const vector<rtc_edge>& mst, bool byFile);
+
 // --dense noise removal (src/sub_command.cpp:3071-3103): drop the forest edges of low-density nodes, cluster again
 [[maybe_unused]] static void remove_noise_and_print(const vector<rtc_edge>& mst, const vector<GenomeInfo>& genomes, bool sketchByFile,
                                                     const string& outputFile, double threshold, const vector<int32_t>& dense, int span) {
@@ -562,6 +570,14 @@ static Options parse(int argc, char** argv) {
   for (size_t i = 0; i < rep_of.size(); i++) if (rep_of[i] == (int32_t)i) { cid[i] = (int)cl.size(); cl.push_back({(int)i}); }
   for (size_t i = 0; i < rep_of.size(); i++) if (rep_of[i] != (int32_t)i) cl[cid[rep_of[i]]].push_back((int)i);
   return cl;
+}
+
+// src/sub_command.cpp:3010-3029 (and the same block in the --premsted / --append flows)
+[[maybe_unused]] static void write_trees(const Options& o, const vector<GenomeInfo>& genomes, const vector<rtc_edge>& mst, bool byFile) {
+  if (o.newick) { const string f = o.outputFile + ".newick.tree"; print_newick_tree(genomes, mst, byFile, f); cerr << "-----write the newick tree into: " << f << endl; }
+  if (o.phylip) { const string f = o.outputFile + ".phylip.tree"; print_phylip_tree(genomes, mst, byFile, f); cerr << "-----write the PHYLIP tree into: " << f << endl; }
+  if (o.nexus) { const string f = o.outputFile + ".nexus.tree"; print_nexus_tree(genomes, mst, byFile, f); cerr << "-----write the NEXUS tree into: " << f << endl; }
+  if (o.linkage) { const string f = o.outputFile + ".linkage.txt"; print_linkage_matrix((int)genomes.size(), mst, f); cerr << "-----write the linkage matrix into: " << f << endl; }
 }
 
 #ifndef GREEDY_CLUST
@@ -633,6 +649,7 @@ static int append_clust_mst(const Options& o, vector<Gpu>& gpus) {
   final_graph.insert(final_graph.end(), append_mst.begin(), append_mst.end());
   std::sort(final_graph.begin(), final_graph.end(), [](const rtc_edge& a, const rtc_edge& b) { return a.dist < b.dist; });  // cmpEdge
   vector<rtc_edge> final_mst = kruskal_algorithm(final_graph, (int)genomes.size());
+  write_trees(o, genomes, final_mst, byFile);
   cluster_from_mst(final_mst, genomes, byFile, o.outputFile, o.threshold);
   if (!o.noSave) { save_genome_info(genomes, new_folder, "mst", true, o.is_fast); save_mst(final_mst, new_folder); }
   return 0;
@@ -654,6 +671,7 @@ int main(int argc, char** argv) {
     vector<GenomeInfo> genomes; vector<rtc_edge> mst; bool byFile = true;
     if (!load_genome_info(o.folder_path, "mst", genomes, o.is_fast, byFile)) return 1;
     if (!load_mst(o.folder_path, mst)) return 1;
+    write_trees(o, genomes, mst, byFile);
     cluster_from_mst(mst, genomes, byFile, o.outputFile, o.threshold);
     if (o.dense) {  // clust_from_mst with !no_dense: the stored mst.dense drives the noise pass (src/sub_command.cpp:1795-1822)
       vector<int32_t> dense; int span = 0, gn = 0;
@@ -848,6 +866,7 @@ int main(int argc, char** argv) {
     save_mst(mst, folder_path);
     cerr << "========time of saveMST is: " << get_sec() - t3 << "========" << endl;
   }
+  write_trees(o, genomes, mst, sketchByFile);
   cluster_from_mst(mst, genomes, sketchByFile, o.outputFile, o.threshold);
   if (o.dense) {
     if (!o.noSave && !from_sketches) { save_ani(folder_path, ani); save_dense(folder_path, dense, DENSE_SPAN, (int)genomes.size()); }

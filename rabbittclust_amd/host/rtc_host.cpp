@@ -733,6 +733,129 @@ std::vector<rtc_edge> modify_forest(const std::vector<rtc_edge>& forest, const s
   return out;
 }
 
+namespace {
+struct DSU {  // src/MST.cpp:40-57
+  std::vector<int> p, r;
+  explicit DSU(int n) : p(n), r(n, 0) { for (int i = 0; i < n; i++) p[i] = i; }
+  int find(int x) { int root = x; while (p[root] != root) root = p[root]; while (p[x] != root) { int nx = p[x]; p[x] = root; x = nx; } return root; }
+  int unite(int a, int b) {
+    a = find(a); b = find(b);
+    if (a == b) return a;
+    if (r[a] < r[b]) std::swap(a, b);
+    p[b] = a;
+    if (r[a] == r[b]) r[a]++;
+    return a;
+  }
+};
+std::vector<rtc_edge> by_distance(const std::vector<rtc_edge>& mst) {
+  std::vector<rtc_edge> edges = mst;
+  std::sort(edges.begin(), edges.end(), [](const rtc_edge& a, const rtc_edge& b) { return a.dist < b.dist; });
+  return edges;
+}
+}  // namespace
+
+std::string get_newick_tree(const std::vector<GenomeInfo>& g, const std::vector<rtc_edge>& mst, bool sketchByFile) {  // src/MST.cpp:1090-1150
+  const int N = (int)g.size();
+  auto name = [&](int v) { return sketchByFile ? g[v].fileName : g[v].seq0.name; };
+  if (N == 0) return ";";
+  if (N == 1) return name(0) + ";";
+  const std::vector<rtc_edge> edges = by_distance(mst);
+  const int maxNodes = 2 * N - 1;
+  std::vector<std::vector<std::pair<int, double>>> children(maxNodes);
+  std::vector<double> height(maxNodes, 0.0);
+  std::vector<int> repNode(maxNodes, -1);
+  for (int i = 0; i < N; i++) repNode[i] = i;
+  DSU dsu(N);
+  int nextNode = N;
+  for (const rtc_edge& e : edges) {
+    const int ru = dsu.find(e.preNode), rv = dsu.find(e.sufNode);
+    if (ru == rv) continue;
+    const int nodeU = repNode[ru], nodeV = repNode[rv];
+    const double h = e.dist;
+    const int newNode = nextNode++;
+    children[newNode].push_back({nodeU, std::max(0.0, h - height[nodeU])});
+    children[newNode].push_back({nodeV, std::max(0.0, h - height[nodeV])});
+    height[newNode] = h;
+    repNode[dsu.unite(ru, rv)] = newNode;
+  }
+  const int root = repNode[dsu.find(0)];
+  // build_newick_tree_recursive (:1044-1066) without the recursion (a 100 000-leaf caterpillar would overflow the stack)
+  std::string s;
+  struct Frame { int node; size_t next; };
+  std::vector<Frame> st{{root, 0}};
+  while (!st.empty()) {
+    Frame& f = st.back();
+    const auto& ch = children[f.node];
+    if (ch.empty()) { s += name(f.node); st.pop_back(); }
+    else if (f.next == ch.size()) { s += ")"; st.pop_back(); }
+    else {
+      if (f.next == 0) s += "("; else s += ",";
+      const int child = ch[f.next].first;
+      f.next++;
+      st.push_back({child, 0});
+      continue;
+    }
+    if (!st.empty()) {  // the finished subtree was child number next-1 of the new top: its branch length follows
+      const Frame& up = st.back();
+      s += ":" + std::to_string(children[up.node][up.next - 1].second);
+    }
+  }
+  return s + ";";
+}
+
+static FILE* open_out(const std::string& output, const char* who) {
+  FILE* fp = fopen(output.c_str(), "w");
+  if (!fp) { std::cerr << "ERROR: " << who << "(), cannot write file: " << output << std::endl; exit(1); }
+  return fp;
+}
+
+void print_newick_tree(const std::vector<GenomeInfo>& g, const std::vector<rtc_edge>& mst, bool sketchByFile, const std::string& output) {
+  FILE* fp = open_out(output, "print_newick_tree");
+  fprintf(fp, "%s\n", get_newick_tree(g, mst, sketchByFile).c_str());
+  fclose(fp);
+}
+
+void print_phylip_tree(const std::vector<GenomeInfo>& g, const std::vector<rtc_edge>& mst, bool sketchByFile, const std::string& output) {
+  FILE* fp = open_out(output, "print_phylip_tree");
+  fprintf(fp, "1\n%s\n", get_newick_tree(g, mst, sketchByFile).c_str());
+  fclose(fp);
+}
+
+void print_nexus_tree(const std::vector<GenomeInfo>& g, const std::vector<rtc_edge>& mst, bool sketchByFile, const std::string& output) {  // src/MST_IO.cpp:296-335
+  const std::string tree = get_newick_tree(g, mst, sketchByFile);
+  FILE* fp = open_out(output, "print_nexus_tree");
+  fprintf(fp, "#NEXUS\nBEGIN TAXA;\n  DIMENSIONS NTAX=%zu;\n  TAXLABELS", g.size());
+  for (const GenomeInfo& gi : g) {
+    std::string lab = sketchByFile ? gi.fileName : gi.seq0.name;
+    size_t pos = 0;
+    while ((pos = lab.find('\'', pos)) != std::string::npos) { lab.insert(pos, "'"); pos += 2; }  // quotes are doubled
+    fprintf(fp, " '%s'", lab.c_str());
+  }
+  fprintf(fp, ";\nEND;\nBEGIN TREES;\n  TREE tree_1 = [&R] %s\nEND;\n", tree.c_str());
+  fclose(fp);
+}
+
+void print_linkage_matrix(int N, const std::vector<rtc_edge>& mst, const std::string& output) {  // src/MST.cpp:1246-1287, src/MST_IO.cpp:362-376
+  FILE* fp = open_out(output, "print_linkage_matrix");
+  if (N > 1) {
+    const std::vector<rtc_edge> edges = by_distance(mst);
+    DSU dsu(N);
+    int next_id = N;
+    std::vector<int> cluster_id(N), cluster_size(2 * N - 1);
+    for (int i = 0; i < N; i++) { cluster_id[i] = i; cluster_size[i] = 1; }
+    for (const rtc_edge& e : edges) {
+      const int ru = dsu.find(e.preNode), rv = dsu.find(e.sufNode);
+      if (ru == rv) continue;
+      const int id_u = cluster_id[ru], id_v = cluster_id[rv];
+      const int new_id = next_id++, new_size = cluster_size[id_u] + cluster_size[id_v];
+      fprintf(fp, "%d\t%d\t%.6f\t%d\n", id_u, id_v, e.dist, new_size);
+      cluster_id[dsu.unite(ru, rv)] = new_id;
+      cluster_size[new_id] = new_size;
+    }
+  }
+  fclose(fp);
+}
+
 std::vector<rtc_edge> kruskal_algorithm(const std::vector<rtc_edge>& graph, int vertices) {  // src/MST.cpp:59-75
   std::vector<int> parent(vertices), ranks(vertices, 0);             // UnionFind.h: union by rank, path compression
   for (int v = 0; v < vertices; v++) parent[v] = v;

@@ -112,6 +112,15 @@ std::vector<std::vector<int>> generate_cluster_with_bfs(const std::vector<rtc_ed
 void print_result(const std::vector<std::vector<int>>& cluster, const std::vector<GenomeInfo>& g, bool sketchByFile,
                   const std::string& outputFile, double threshold = -1.0);
 
+// ---- tree / linkage writers of clust-mst (src/MST.cpp:1044-1287, src/MST_IO.cpp:252-380): the single-linkage
+// dendrogram of the MST (edges by ascending distance, heights = merge distances).  As in the reference only
+// the component that contains genome 0 is written when the MST is a forest. ----
+std::string get_newick_tree(const std::vector<GenomeInfo>& g, const std::vector<rtc_edge>& mst, bool sketchByFile);
+void print_newick_tree(const std::vector<GenomeInfo>& g, const std::vector<rtc_edge>& mst, bool sketchByFile, const std::string& output);
+void print_phylip_tree(const std::vector<GenomeInfo>& g, const std::vector<rtc_edge>& mst, bool sketchByFile, const std::string& output);
+void print_nexus_tree(const std::vector<GenomeInfo>& g, const std::vector<rtc_edge>& mst, bool sketchByFile, const std::string& output);
+void print_linkage_matrix(int n, const std::vector<rtc_edge>& mst, const std::string& output);  // c1 \t c2 \t dist \t size
+
 std::string current_date_time();  // src/common.hpp:36-44
 
 }  // namespace rtc

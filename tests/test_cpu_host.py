@@ -253,3 +253,89 @@ def test_flat_genome_reader_matches_string_reader(host, tmp_path):
             assert n2 >= n0 and b2 == b0[: n0 - 3], path  # need is an upper bound (CRs past cap are counted)
     assert run(multi, 0, 1 << 21)[5] < run(multi, 0, 1 << 21)[0]  # exercises the CLI's retry round
     assert run("/nonexistent/x.fa", 1, 16)[0] == -1
+
+
+def _py_dendrogram(n, edges, names):
+    """get_newick_tree / get_linkage_from_mst restated (src/MST.cpp:1090-1150, :1246-1287): Kruskal-order
+    merges with the reference's union-by-rank DSU; distinct weights, so the sort order is unambiguous."""
+    edges = sorted(edges, key=lambda e: e[2])
+    p, r = list(range(n)), [0] * n
+
+    def find(x):
+        while p[x] != x:
+            x = p[x]
+        return x
+
+    def unite(a, b):
+        a, b = find(a), find(b)
+        if r[a] < r[b]:
+            a, b = b, a
+        p[b] = a
+        if r[a] == r[b]:
+            r[a] += 1
+        return a
+    children, height, rep = {}, {i: 0.0 for i in range(n)}, {i: i for i in range(n)}
+    cid, csize, link, nxt = {i: i for i in range(n)}, {i: 1 for i in range(n)}, [], n
+    for u, v, w in edges:
+        ru, rv = find(u), find(v)
+        if ru == rv:
+            continue
+        nu, nv = rep[ru], rep[rv]
+        children[nxt] = [(nu, max(0.0, w - height[nu])), (nv, max(0.0, w - height[nv]))]
+        height[nxt] = w
+        link.append("%d\t%d\t%.6f\t%d" % (cid[ru], cid[rv], w, csize[cid[ru]] + csize[cid[rv]]))
+        csize[nxt] = csize[cid[ru]] + csize[cid[rv]]
+        root = unite(ru, rv)
+        rep[root], cid[root] = nxt, nxt
+        nxt += 1
+
+    def build(node):
+        if node not in children:
+            return names[node]
+        return "(" + ",".join(build(c) + ":" + "%f" % bl for c, bl in children[node]) + ")"
+    return build(rep[find(0)]) + ";", link
+
+
+def test_tree_and_linkage_writers_from_premsted_folder(tmp_path):
+    """clust-mst --premsted DIR --newick-tree --phylip-tree --nexus-tree --linkage-matrix (no GPU involved):
+    the four files against a Python restatement of the reference's dendrogram construction."""
+    import subprocess
+    binp = os.path.join(ROOT, "rabbittclust_amd", "bin", "clust-mst")
+    if not os.path.exists(binp):
+        pytest.fail("clust-mst missing: run __graft_entry__.build()")
+    src = tmp_path / "src"
+    src.mkdir()
+    n = 40
+    g = [(f"/data/it's_{i}.fna", f"seq{i}", "noName", 1000 + i) for i in range(n)]
+    _write_info(src / "info.mst", g)
+    rng = np.random.default_rng(3)
+    w = rng.permutation(200)[: n - 1] / 997.0  # distinct weights
+    edges = [(i, int(rng.integers(0, i)), float(w[i - 1])) for i in range(1, n)]  # a random spanning tree
+    with open(src / "edge.mst", "wb") as f:
+        f.write(struct.pack("<Q", len(edges)))
+        for a, b, d in edges:
+            f.write(struct.pack("<iid", a, b, d))
+    out = tmp_path / "res.out"
+    r = subprocess.run([binp, "--premsted", str(src), "-d", "0.05", "-o", str(out), "--newick-tree", "--phylip-tree", "--nexus-tree",
+                        "--linkage-matrix"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = [x[0] for x in g]
+    tree, link = _py_dendrogram(n, edges, names)
+    assert (tmp_path / "res.out.newick.tree").read_text() == tree + "\n"
+    assert (tmp_path / "res.out.phylip.tree").read_text() == "1\n" + tree + "\n"
+    nexus = (tmp_path / "res.out.nexus.tree").read_text()
+    assert nexus.startswith("#NEXUS\nBEGIN TAXA;\n  DIMENSIONS NTAX=40;\n  TAXLABELS '/data/it''s_0.fna'")
+    assert nexus.endswith(";\nEND;\nBEGIN TREES;\n  TREE tree_1 = [&R] " + tree + "\nEND;\n")
+    assert (tmp_path / "res.out.linkage.txt").read_text().splitlines() == link and len(link) == n - 1
+    assert tree.count("(") == n - 1 and all(nm in tree for nm in names)
+    # a forest: only the component of genome 0 is written (reference behaviour), the linkage covers every merge
+    with open(src / "edge.mst", "wb") as f:
+        f.write(struct.pack("<Q", len(edges) - 1))
+        for a, b, d in edges[:-1]:
+            f.write(struct.pack("<iid", a, b, d))
+    r = subprocess.run([binp, "--premsted", str(src), "-d", "0.05", "-o", str(out), "--newick-tree", "--linkage-matrix"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    tree2, link2 = _py_dendrogram(n, edges[:-1], names)
+    assert (tmp_path / "res.out.newick.tree").read_text() == tree2 + "\n" and names[n - 1] not in tree2
+    assert (tmp_path / "res.out.linkage.txt").read_text().splitlines() == link2 and len(link2) == n - 2
