@@ -19,6 +19,7 @@
 //     back one counter.
 //     Distances are evaluated on the host with the reference's expression order.
 #include <math.h>
+#include <time.h>
 
 #include <algorithm>
 #include <numeric>
@@ -631,6 +632,9 @@ int rtc_mst_dense(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t*
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const uint32_t s_fixed = rtc_fixed_size_of(h_len.data(), n);
 
+  const bool verbose = getenv("RTC_VERBOSE") != nullptr;
+  auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+  const double tv0 = now();
   rtc_edge_list el{};
   rtc_cedge* d_sel = nullptr;
   DenseAcc acc{ctx, h_len.data(), n, kmer_size, is_containment, dense_span, s_fixed, h_dense, h_ani, {}, {}, {}, {}};
@@ -653,20 +657,27 @@ int rtc_mst_dense(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t*
   }
   uint64_t nsel = 0;
   std::vector<rtc_cedge> sel;
+  const double tv1 = now();
   if (st == RTC_OK && hipMalloc((void**)&d_sel, (size_t)n * sizeof(rtc_cedge)) != hipSuccess)
     st = rtc_fail(ctx, RTC_ERR_NOMEM, "hipMalloc forest list");
-  if (st == RTC_OK) st = rtc_msf_device(ctx, el.d_edges, el.m, d_len, n, is_containment, s_fixed, nullptr, d_sel, &nsel, nullptr);
+  int rounds = 0;
+  if (st == RTC_OK) st = rtc_msf_device(ctx, el.d_edges, el.m, d_len, n, is_containment, s_fixed, nullptr, d_sel, &nsel, &rounds);
+  const double tv2 = now();
   if (st == RTC_OK && nsel) {
     sel.resize(nsel);
     hipError_t e = hipMemcpyAsync(sel.data(), d_sel, nsel * sizeof(rtc_cedge), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) st = rtc_fail(ctx, RTC_ERR_HIP, "forest read-back -> %s", hipGetErrorString(e));
   }
+  const uint64_t m_edges = el.m;
   if (d_sel) (void)hipFree(d_sel);
   rtc_edge_list_free(&el);
   if (st != RTC_OK) return st;
   RTC_TRY(rtc_edges_to_mst_host(sel.data(), nsel, h_len.data(), kmer_size, is_containment, h_edges_out));
   *h_n_edges = nsel;
+  if (verbose)
+    fprintf(stderr, "[mst]   %u sketches: %llu candidate edges in %.4fs, forest (%d rounds, %llu edges) in %.4fs, finish %.4fs\n", n,
+            (unsigned long long)m_edges, tv1 - tv0, rounds, (unsigned long long)nsel, tv2 - tv1, now() - tv2);
   return RTC_OK;
 }
 

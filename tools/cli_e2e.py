@@ -25,12 +25,12 @@ for g in range(n):
 open(os.path.join(tmp, "list.txt"), "w").write("\n".join(paths) + "\n")
 print(f"wrote {n} FASTA files ({n * L / 1e9:.2f} Gbp) in {time.time() - t0:.1f}s", flush=True)
 del ctx
-for binname, extra in (("clust-mst", ["-s", "1000"]), ("clust-mst", ["--fast"])):
+for binname, extra in (("clust-mst", ["-s", "1000"]), ("clust-mst", ["--fast"]), ("clust-mst", ["-s", "1000"])):
     t0 = time.time()
     r = subprocess.run(["env", "RTC_VERBOSE=1", os.path.join(root, "rabbittclust_amd", "bin", binname), "-l", "-i", os.path.join(tmp, "list.txt"), "-k", "21",
                         "-d", "0.05", "-e", "-o", os.path.join(tmp, "out.cluster")] + extra, capture_output=True, text=True, cwd=tmp)
     dt = time.time() - t0
-    lines = [ln for ln in r.stderr.splitlines() if "time of" in ln or "cluster number" in ln or ln.startswith(("[parse]", "[gpu]", "[plan]", "[init]", "[free]", "[tune]"))]
+    lines = [ln for ln in r.stderr.splitlines() if "time of" in ln or "cluster number" in ln or ln.startswith(("[gpu", "[plan]", "[init]", "[free]", "[tune]", "[share]", "[mst"))]
     print(binname, " ".join(extra), f"rc={r.returncode} wall={dt:.2f}s  {n * L / dt / 1e9:.2f} Gbp/s end-to-end from files", flush=True)
     for ln in lines:
         print("   ", ln)
