@@ -110,6 +110,16 @@ int rtc_pair_common_dev(rtc_ctx* ctx, const void* d_hashes, int width, const uin
                         uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld,
                         int lower_only, int algo);
 
+/* The dense loop's estimator: what Sketch::MinHash::jaccard()/distance() hand to modifyMST
+ * (src/MST.cpp:851-866) is Mash's union-truncated Jaccard, NOT the set-Jaccard of the index path: merge
+ * the two ascending lists, stop after `sketch_size` elements of the union; d_common = shared elements
+ * among them, d_denom = union elements seen (sketch_size unless both lists run out); distance on the host
+ * = -ln(2j/(1+j))/k with j = common/denom.  RabbitSketch is absent from the reference tree: this restates
+ * the published Mash algorithm and is parity-unpinned like the k-mer hash. */
+int rtc_pair_mash_dev(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+                      const uint32_t* d_len, uint32_t n, uint32_t sketch_size, uint32_t row0, uint32_t row1,
+                      uint32_t col0, uint32_t col1, uint32_t* d_common, uint32_t* d_denom, uint64_t ld);
+
 /* ---- candidate edges ----------------------------------------------------------------------- */
 typedef struct { uint32_t i, j, common; } rtc_cedge; /* i > j */
 /* Scans the common matrix produced above and appends every pair the reference would turn into

@@ -474,6 +474,24 @@ static uint32_t common_sorted(const T* a, uint32_t na, const T* b, uint32_t nb) 
   }
   return c;
 }
+// Mash's union-truncated estimator (what MinHash::jaccard() is recalled to do, SURVEY.md Appendix B [U];
+// call site src/MST.cpp:862-866): denominator = union elements seen, at most sketch_size
+extern "C" void orc_mash_counts_u64(const uint64_t* a, uint32_t na, const uint64_t* b, uint32_t nb, uint32_t sketch_size,
+                                    uint32_t* common, uint32_t* denom) {
+  uint32_t i = 0, j = 0, c = 0, d = 0;
+  while (d < sketch_size && i < na && j < nb) {
+    if (a[i] < b[j]) i++;
+    else if (b[j] < a[i]) j++;
+    else { c++; i++; j++; }
+    d++;
+  }
+  if (d < sketch_size) {
+    uint32_t rest = (na - i) + (nb - j);
+    d += std::min(rest, sketch_size - d);
+  }
+  *common = c; *denom = d;
+}
+
 extern "C" uint32_t orc_common_u64(const uint64_t* a, uint32_t na, const uint64_t* b, uint32_t nb) {
   return common_sorted(a, na, b, nb);
 }

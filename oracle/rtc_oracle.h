@@ -74,6 +74,9 @@ uint64_t orc_kssd_sketch(const orc_kssd_params* p, const int* shuffled_dim, cons
                          uint64_t len, uint32_t* out32, uint64_t* out64, uint64_t cap);
 
 /* ---- pair intersection + distances ---- */
+/* Mash's union-truncated estimator (MinHash::jaccard(), dense loop src/MST.cpp:851-866; [U], unpinned) */
+void orc_mash_counts_u64(const uint64_t* a, uint32_t na, const uint64_t* b, uint32_t nb, uint32_t sketch_size,
+                         uint32_t* common, uint32_t* denom);
 uint32_t orc_common_u64(const uint64_t* a, uint32_t na, const uint64_t* b, uint32_t nb);
 uint32_t orc_common_u32(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb);
 /* src/MST.cpp:1489-1503 (Jaccard -> Mash) and :1504-1515 (containment -> AAF); no >1 clamp */

@@ -203,6 +203,19 @@ class Context:
                                                 out.stride(0), int(lower_only), algo))
         return out
 
+    def pair_mash(self, sk, sketch_size, row0=0, row1=None, col0=0, col1=None):
+        """Mash's union-truncated estimator per pair (modifyMST's distance(), D3): (common, denom) tensors."""
+        n = sk.n
+        row1 = n if row1 is None else row1
+        col1 = n if col1 is None else col1
+        shape = (max(row1 - row0, 1), max(col1 - col0, 1))
+        common = torch.zeros(shape, dtype=torch.int32, device=self.device)
+        denom = torch.zeros(shape, dtype=torch.int32, device=self.device)
+        self.check(self.lib.rtc_pair_mash_dev(self.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start), _t_ptr(sk.len), n,
+                                              int(sketch_size), row0, row1, col0, col1, _t_ptr(common), _t_ptr(denom),
+                                              common.stride(0)))
+        return common, denom
+
     def extract_edges(self, common, sk, row0, row1, col0, col1, radio, cap):
         edges = torch.empty((max(cap, 1), 3), dtype=torch.int32, device=self.device)
         count = torch.zeros(1, dtype=torch.int64, device=self.device)

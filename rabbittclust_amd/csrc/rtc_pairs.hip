@@ -49,7 +49,62 @@ __global__ __launch_bounds__(256) void pair_merge_kernel(const T* __restrict__ h
   out[(uint64_t)(row - row0) * ld + (col - col0)] = c;
 }
 
+// Mash's pairwise estimator, i.e. what Sketch::MinHash::jaccard()/distance() return to the dense loop
+// modifyMST (src/MST.cpp:851-866) -- RabbitSketch is absent from the reference tree, this restates the
+// published Mash algorithm ([U]): merge the two ascending lists, stop after
+// `sketch_size` elements of the UNION, common = shared elements among them, denom = union elements seen.
+template <typename T>
+__global__ __launch_bounds__(256) void pair_mash_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
+                                                        const uint32_t* __restrict__ len, uint32_t sketch_size,
+                                                        uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1,
+                                                        uint32_t* __restrict__ common_out, uint32_t* __restrict__ denom_out,
+                                                        uint64_t ld) {
+  const uint32_t col = col0 + blockIdx.x * 64 + (threadIdx.x & 63);
+  const uint32_t row = row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (row >= row1 || col >= col1) return;
+  const T* a = hashes + start[row];
+  const T* b = hashes + start[col];
+  const uint32_t na = len[row], nb = len[col];
+  uint32_t i = 0, j = 0, c = 0, d = 0;
+  while (d < sketch_size && i < na && j < nb) {
+    const T va = a[i], vb = b[j];
+    if (va < vb) i++;
+    else if (vb < va) j++;
+    else { c++; i++; j++; }
+    d++;
+  }
+  if (d < sketch_size) {  // one list exhausted: the rest of the other one still belongs to the union
+    const uint32_t rest = (i < na ? na - i : 0) + (j < nb ? nb - j : 0);
+    d += rest < sketch_size - d ? rest : sketch_size - d;
+  }
+  const uint64_t o = (uint64_t)(row - row0) * ld + (col - col0);
+  common_out[o] = c;
+  denom_out[o] = d;
+}
+
 }  // namespace
+
+extern "C" int rtc_pair_mash_dev(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+                                 const uint32_t* d_len, uint32_t n, uint32_t sketch_size, uint32_t row0, uint32_t row1,
+                                 uint32_t col0, uint32_t col1, uint32_t* d_common, uint32_t* d_denom, uint64_t ld) {
+  if (!ctx || !d_start || !d_len || !d_common || !d_denom) return RTC_ERR_ARG;
+  if (width != 4 && width != 8) return rtc_fail(ctx, RTC_ERR_ARG, "width must be 4 or 8");
+  if (row1 > n || col1 > n || row0 > row1 || col0 > col1) return rtc_fail(ctx, RTC_ERR_ARG, "tile outside [0,n)");
+  if (ld < (uint64_t)(col1 - col0)) return rtc_fail(ctx, RTC_ERR_ARG, "ld smaller than tile width");
+  if (row0 == row1 || col0 == col1) return RTC_OK;
+  if (!d_hashes) return RTC_ERR_ARG;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  dim3 grid((col1 - col0 + 63) / 64, (row1 - row0 + 3) / 4);
+  if (grid.y > 65535) return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "more than 262140 rows per call");
+  if (width == 8)
+    hipLaunchKernelGGL(pair_mash_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream, (const uint64_t*)d_hashes, d_start, d_len,
+                       sketch_size, row0, row1, col0, col1, d_common, d_denom, ld);
+  else
+    hipLaunchKernelGGL(pair_mash_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, (const uint32_t*)d_hashes, d_start, d_len,
+                       sketch_size, row0, row1, col0, col1, d_common, d_denom, ld);
+  RTC_CHECK_LAUNCH(ctx);
+  return RTC_OK;
+}
 
 extern "C" int rtc_pair_common_dev(rtc_ctx* ctx, const void* d_hashes, int width,
                                    const uint64_t* d_start, const uint32_t* d_len, uint32_t n,

@@ -174,3 +174,38 @@ def test_auto_dispatch_with_a_huge_sketch(ctx, oracle):
     for i in (0, 7, 8, 39):
         for j in range(40):
             assert got[i, j] == oracle.common(sk[i], sk[j]) == got[j, i], (i, j)
+
+
+def test_mash_union_truncated_estimator(ctx, oracle):
+    """D3 (modifyMST's MinHash::distance()): Mash's estimator stops after `s` union elements, so it differs
+    from the set-Jaccard counts of the index path; checked against the oracle restatement and two
+    hand-computed cases (RabbitSketch itself is absent: parity unpinned)."""
+    import ctypes as C
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(23)
+    pool = np.unique(rng.integers(1, 1 << 50, size=1200, dtype=np.uint64))
+    sk = [np.sort(rng.choice(pool, size=int(rng.integers(30, 300)), replace=False)) for _ in range(70)]
+    sk[3] = np.zeros(0, dtype=np.uint64)
+    sk[5] = sk[4].copy()
+    sk.append(np.array([1, 2, 3, 4, 5, 6], dtype=np.uint64))
+    sk.append(np.array([2, 4, 6, 8, 10, 12], dtype=np.uint64))
+    dev = api.SketchSet.from_host(sk, ctx.device, k=21)
+    n = len(sk)
+    L = oracle.lib()
+    for s in (6, 100, 1000):
+        common, denom = ctx.pair_mash(dev, s)
+        common, denom = common.cpu().numpy(), denom.cpu().numpy()
+        for i in range(n):
+            for j in range(0, n, 3):
+                c, d = C.c_uint32(), C.c_uint32()
+                L.orc_mash_counts_u64(sk[i].ctypes.data_as(C.c_void_p), len(sk[i]), sk[j].ctypes.data_as(C.c_void_p), len(sk[j]),
+                                      s, C.byref(c), C.byref(d))
+                assert (common[i, j], denom[i, j]) == (c.value, d.value), (s, i, j)
+    # union of {1..6} and {2,4,..,12} in order: 1 2 3 4 5 6 | 8 10 12 ; the first six hold 3 shared values
+    common, denom = ctx.pair_mash(dev, 6)
+    assert (int(common[n - 2, n - 1]), int(denom[n - 2, n - 1])) == (3, 6)
+    common, denom = ctx.pair_mash(dev, 1000)
+    assert (int(common[n - 2, n - 1]), int(denom[n - 2, n - 1])) == (3, 9)
+    assert int(common[4, 5]) == len(sk[4]) == int(denom[4, 5]) and int(denom[3, 3]) == 0
+    dense = ctx.pair_common(dev).cpu().numpy()
+    assert np.array_equal(common.cpu().numpy(), dense)  # with s beyond both lists the estimator counts every shared value
