@@ -34,6 +34,9 @@ int rtc_device_count(void); /* visible GPUs (0 when there is none or the runtime
 int rtc_ctx_create(int device, rtc_ctx** out);
 void rtc_ctx_destroy(rtc_ctx* ctx);
 int rtc_ctx_set_stream(rtc_ctx* ctx, void* hip_stream); /* NULL = default stream */
+/* Gives the context a non-blocking stream of its own: two contexts on one device, each driven by its
+ * own host thread, then overlap (the command lines copy batch i+1 while batch i is sketched). */
+int rtc_ctx_own_stream(rtc_ctx* ctx);
 int rtc_ctx_sync(rtc_ctx* ctx);
 const char* rtc_last_error(const rtc_ctx* ctx); /* ctx may be NULL: last context-less failure */
 const char* rtc_version(void);

@@ -92,7 +92,17 @@ void rtc_ctx_destroy(rtc_ctx* ctx) {
   if (ctx->kssd.d_table) (void)hipFree(ctx->kssd.d_table);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->owned_stream) (void)hipStreamDestroy(ctx->owned_stream);
   delete ctx;
+}
+
+int rtc_ctx_own_stream(rtc_ctx* ctx) {
+  if (!ctx) return RTC_ERR_ARG;
+  if (ctx->owned_stream) return RTC_OK;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  RTC_HIP(ctx, hipStreamCreateWithFlags(&ctx->owned_stream, hipStreamNonBlocking));
+  ctx->stream = ctx->owned_stream;
+  return RTC_OK;
 }
 
 int rtc_ctx_set_stream(rtc_ctx* ctx, void* hip_stream) {

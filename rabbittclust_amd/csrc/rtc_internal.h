@@ -14,6 +14,7 @@
 struct rtc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t owned_stream = nullptr;  // rtc_ctx_own_stream
   int num_cu = 256;
   int lds_per_wg = 65536;
   std::string err;

@@ -50,10 +50,9 @@ struct DeviceSketches {  // sketches resident in HBM in the CSR the pair kernels
 
 struct Gpu {  // one per GPU in use: context, communicator, staging and the resident sketch rows
   rtc_ctx* ctx = nullptr; rtc_comm* comm = nullptr;
-  void* d_seq = nullptr;        // staging for one batch of bases
+  int device = 0;
   void* d_sk = nullptr;         // resident sketches: row g (genome id g) at d_sk + g*stride*width
   uint32_t* d_cnt = nullptr;    // hashes per genome
-  std::thread worker;
 };
 
 // Sketches produced by sketch_files and left in HBM (every GPU holds all rows after the share step)
@@ -142,6 +141,20 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
                          MinHashSketchFile* mh, KssdSketchFile* ks, Resident& rs, bool need_host_hashes) {
   rtc_ctx* ctx = gpus[0].ctx;
   const size_t G = gpus.size();
+  // Two lanes per GPU: lane 0 is the GPU's own context, lane 1 a second context on the same device with a
+  // stream of its own, each driven by its own host thread -- the PCIe copy of one batch runs beside the
+  // sketch kernel of the previous one.  Both lanes write rows of the same resident sketch buffer.
+  struct Lane { rtc_ctx* ctx; void* d_seq; std::thread worker; size_t gpu; bool owned; };
+  const size_t LPG = getenv("RTC_SINGLE_LANE") ? 1 : 2;
+  vector<Lane> lanes(G * LPG);
+  for (size_t l = 0; l < lanes.size(); l++) {
+    lanes[l].gpu = l % G; lanes[l].d_seq = nullptr; lanes[l].owned = l >= G; lanes[l].ctx = gpus[l % G].ctx;
+    if (lanes[l].owned) {
+      CHECK(ctx, rtc_ctx_create(gpus[l % G].device, &lanes[l].ctx));
+      CHECK(lanes[l].ctx, rtc_ctx_own_stream(lanes[l].ctx));
+    }
+  }
+  const size_t NL = lanes.size();
   const double tp00 = get_sec();
   const vector<string> fileList = read_list(inputFile);
   const size_t nfiles = fileList.size();
@@ -189,7 +202,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   vector<Batch> batches = plan(all, slot);
 
   // ---- staging: G+1 host buffers (one being parsed, one per GPU in flight) and one device buffer per GPU ----
-  const size_t NSTAGE = G + 1;
+  const size_t NSTAGE = NL + 1;
   uint64_t buf_bytes = 0;
   vector<char*> stage(NSTAGE, nullptr);
   // Pageable staging by default: page-locking costs ~0.15 s/GB up front while the pageable PCIe copy
@@ -205,7 +218,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   auto ensure_buffers = [&](uint64_t need) {
     if (need <= buf_bytes) return;
     free_stage();
-    for (Gpu& g : gpus) if (g.d_seq) { CHECK(g.ctx, rtc_dev_free(g.ctx, g.d_seq)); g.d_seq = nullptr; }
+    for (Lane& l : lanes) if (l.d_seq) { CHECK(l.ctx, rtc_dev_free(l.ctx, l.d_seq)); l.d_seq = nullptr; }
     buf_bytes = need;
     for (int i = 0; i < (int)NSTAGE; i++) {
       if (pinned && rtc_host_alloc(ctx, buf_bytes + 64, (void**)&stage[i]) != RTC_OK) {
@@ -217,7 +230,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       }
       if (!pinned && !(stage[i] = alloc_pageable(buf_bytes + 64))) { fprintf(stderr, "ERROR: cannot allocate %.2f GB of staging memory\n", buf_bytes / 1e9); exit(1); }
     }
-    for (Gpu& g : gpus) CHECK(g.ctx, rtc_dev_alloc(g.ctx, buf_bytes + 64, &g.d_seq));
+    for (Lane& l : lanes) CHECK(l.ctx, rtc_dev_alloc(l.ctx, buf_bytes + 64, &l.d_seq));
   };
   uint64_t maxb = 0;
   for (const Batch& b : batches) maxb = std::max(maxb, b.bytes);
@@ -247,8 +260,9 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
 
   // ---- GPU side of one batch (runs on that GPU's host thread while the next batch is parsed) ----
   // row0 < 0: not resident (retry round), results only go to the host vectors.
-  auto gpu_batch = [&](Gpu& gp, const Batch& b, const char* h_seq, long row0) {
-    rtc_ctx* c = gp.ctx;
+  auto gpu_batch = [&](Lane& ln, const Batch& b, const char* h_seq, long row0) {
+    Gpu& gp = gpus[ln.gpu];
+    rtc_ctx* c = ln.ctx;
     const double t0 = get_sec();
     vector<uint64_t> off; vector<uint32_t> sizes; vector<size_t> kept;
     for (size_t q = 0; q < b.files.size(); q++) {
@@ -261,7 +275,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
     const uint32_t nb = (uint32_t)kept.size();
     if (!nb) return;
     off.push_back(b.bytes);
-    CHECK(c, rtc_copy_h2d(c, gp.d_seq, h_seq, b.bytes + 64));
+    CHECK(c, rtc_copy_h2d(c, ln.d_seq, h_seq, b.bytes + 64));
     const double t1 = get_sec();
     const bool resident = row0 >= 0 && resident_ok.load();
     const bool to_host = need_host_hashes || !resident;
@@ -276,7 +290,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
     bool row_overflow = false;
     if (!job.kssd) {
       if (!resident) { stride = *std::max_element(sizes.begin(), sizes.end()); CHECK(c, rtc_dev_alloc(c, (size_t)nb * stride * 8, &d_out)); }
-      CHECK(c, rtc_sketch_minhash_dev(c, (const uint8_t*)gp.d_seq, off.data(), nb, job.kmerSize, 42, sizes.data(), stride,
+      CHECK(c, rtc_sketch_minhash_dev(c, (const uint8_t*)ln.d_seq, off.data(), nb, job.kmerSize, 42, sizes.data(), stride,
                                       (uint64_t*)d_out, stride, d_cnt));
     } else {
       if (!resident) {
@@ -287,7 +301,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       }
       while (true) {
         int width = 0; uint32_t need = 0;
-        int st = rtc_sketch_kssd_dev(c, (const uint8_t*)gp.d_seq, off.data(), nb, job.kmerSize, job.drlevel, shuffled.data(),
+        int st = rtc_sketch_kssd_dev(c, (const uint8_t*)ln.d_seq, off.data(), nb, job.kmerSize, job.drlevel, shuffled.data(),
                                      d_out, stride, d_cnt, &width, &need);
         if (st == RTC_ERR_OVERFLOW) {
           // a genome with more tuples than a resident row: this batch goes to a wider temporary buffer and
@@ -316,7 +330,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       }
     }
     if (temp) { CHECK(c, rtc_dev_free(c, d_out)); CHECK(c, rtc_dev_free(c, d_cnt)); }
-    if (verbose) fprintf(stderr, "[gpu %d] %u genomes, %.2f GB: h2d %.3fs sketch%s %.3fs\n", (int)(&gp - gpus.data()), nb, b.bytes / 1e9, t1 - t0,
+    if (verbose) fprintf(stderr, "[gpu %d.%d] %u genomes, %.2f GB: h2d %.3fs sketch%s %.3fs\n", (int)ln.gpu, (int)ln.owned, nb, b.bytes / 1e9, t1 - t0,
                          to_host || temp ? "+d2h" : "", get_sec() - t1);
   };
 
@@ -349,18 +363,18 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       }
       if (!retry_files.empty()) resident_ok.store(false);  // retried files arrive out of list order: ids are no longer row numbers
       if (verbose) fprintf(stderr, "[parse] batch %zu: %zu files, %.2f GB in %.3fs\n", bi, b.files.size(), b.bytes / 1e9, get_sec() - t0);
-      Gpu& gp = gpus[bi % G];
-      if (gp.worker.joinable()) gp.worker.join();
+      Lane& ln = lanes[bi % NL];
+      if (ln.worker.joinable()) ln.worker.join();
       if (shuffle_thread.joinable()) shuffle_thread.join();
       const Batch* bp = &b;
       const long row0 = round == 0 ? (long)next_row : -1;
-      if (round == 0) { placed.push_back(Placed{next_row, nkept, (int)(bi % G)}); next_row += nkept; }
-      Gpu* gpp = &gp;
-      gp.worker = std::thread([&gpu_batch, gpp, bp, buf, row0]() { gpu_batch(*gpp, *bp, buf, row0); });
+      if (round == 0) { placed.push_back(Placed{next_row, nkept, (int)ln.gpu}); next_row += nkept; }
+      Lane* lnp = &ln;
+      ln.worker = std::thread([&gpu_batch, lnp, bp, buf, row0]() { gpu_batch(*lnp, *bp, buf, row0); });
       for (size_t q = 0; q < b.files.size(); q++, done_files++) if (done_files % 10000 == 0) cerr << "---finished sketching: " << done_files << " genomes" << endl;
       bi++;
     }
-    for (Gpu& g : gpus) if (g.worker.joinable()) g.worker.join();
+    for (Lane& l : lanes) if (l.worker.joinable()) l.worker.join();
     if (round == 1 || retry_files.empty()) break;
     batches = plan(retry_files, retry_need);
     maxb = 0;
@@ -371,6 +385,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   }
   if (shuffle_thread.joinable()) shuffle_thread.join();
   const double tf0 = get_sec();
+  // (the second lanes' contexts and every device staging buffer live until the process ends, see below)
   if (pinned) free_stage();
   // Pageable staging is NOT returned here: munmap of GBs of touched pages takes ~0.1 s and holds the
   // address-space lock, which stalls every hipMalloc of the clustering phase that follows (measured:
@@ -700,6 +715,7 @@ int main(int argc, char** argv) {
     gpus.resize(devs.size());
     vector<rtc_ctx*> ctxs;
     for (size_t g = 0; g < devs.size(); g++) {
+      gpus[g].device = devs[g];
       int st = rtc_ctx_create(devs[g], &gpus[g].ctx);
       if (st != RTC_OK) { fprintf(stderr, "ERROR: no MI355X context on device %d: %s\n", devs[g], rtc_last_error(nullptr)); return 1; }
       ctxs.push_back(gpus[g].ctx);

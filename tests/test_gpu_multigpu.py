@@ -233,7 +233,7 @@ def test_clust_mst_no_save_keeps_sketches_on_device(oracle, tmp_path):
     lst, paths, seqs = _write_family_fastas(oracle, tmp, 3, 3, 1_800_000, seed=14)
     a, b = os.path.join(tmp, "a.out"), os.path.join(tmp, "b.out")
     err = _cli([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "500", "-d", "0.05", "-e", "-o", a], tmp, {"RTC_VERBOSE": "1"})
-    assert "sketch+d2h" not in err and "[gpu 0]" in err
+    assert "sketch+d2h" not in err and "[gpu 0.0]" in err
     assert not [d for d in os.listdir(tmp) if os.path.isdir(os.path.join(tmp, d))]
     _cli([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "500", "-d", "0.05", "-o", b], tmp)
     assert _partition(_parse_clusters(a)) == _partition(_parse_clusters(b))
