@@ -42,6 +42,10 @@ constexpr int TILE_BASES = WG * RUN_DW * 4;           // bases per tile
 constexpr int STEP_APPENDS = WG * 4;                  // worst-case appends per dword iteration
 constexpr int MIN_ROOM = STEP_APPENDS;                // candidate room the buffer always offers
 constexpr uint64_t SENT = ~0ULL;
+// per-wave queue of possible candidates (unfinished hash halves) in LDS: see the steady state of the kernel
+constexpr int QCAP = 32;                              // entries per wave
+constexpr int QDRAIN = 16;                            // drained at a tile end once this many wait
+constexpr size_t QUEUE_BYTES = (size_t)NWAVE * QCAP * 16;
 // hash tables in LDS (see kmer_hash_parts): per 8 bases of k one 256-entry table of 16-byte entries
 // (first four bases of the word) and, where the word has more than four bases, one of 4-byte entries
 constexpr size_t LUT_LO_BYTES = 256 * 16, LUT_HI_BYTES = 256 * 4;
@@ -60,10 +64,14 @@ struct Segment {
   uint32_t expect;          // pass > 0: run only if the genome already holds exactly this many hashes
   uint32_t partial;         // 1: one of several segments of a genome, writes a partial sketch for the merge kernel
   uint32_t pad;
+  uint64_t t0;              // starting threshold (SENT: none), see the kernel
 };
 
 struct Ctrl {
   uint64_t T;
+  uint64_t T0;       // the threshold while fewer than s hashes are held (SENT, or the segment's starting threshold)
+  uint32_t sorted;   // buf[0..sorted) is ascending and distinct (what the last merge left); appends follow it
+  uint32_t pad0;
   uint32_t count;
   uint32_t overflow;
   uint32_t saw_max;
@@ -317,23 +325,62 @@ __device__ void bitonic_sort_lds(lds_u64_ptr buf, int n) {
 
 // On entry: buf[0..ctrl->count) holds candidates (unsorted, duplicates allowed), all threads
 // arrive.  On exit: buf[0..count) ascending distinct, count <= s, ctrl->T updated.
+// first index in the ascending run a[0..n) whose value is >= v (STRICT = false) or > v (STRICT = true)
+template <bool STRICT>
+__device__ __forceinline__ uint32_t lds_bound(lds_u64_ptr a, uint32_t n, uint64_t v) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    const uint64_t x = a[mid];
+    if (STRICT ? (x <= v) : (x < v)) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
 __device__ __noinline__ MergeResult merge_block(lds_u64_ptr buf, lds_ctrl_ptr ctrl, int cap, uint32_t s) {
   const int t = threadIdx.x;
   __syncthreads();
   const uint32_t n = ctrl->count < (uint32_t)cap ? ctrl->count : (uint32_t)cap;
+  uint32_t c0 = ctrl->sorted < n ? ctrl->sorted : n;  // sorted distinct prefix left by the previous merge
+  if (c0 == n && n <= s) {  // nothing was appended since: the prefix is the result (workgroup-uniform)
+    const uint64_t keepT = ctrl->T;
+    __syncthreads();
+    if (t == 0) ctrl->overflow = 0;
+    __syncthreads();
+    return MergeResult{n, keepT};
+  }
   bool saw = false;  // a genuine hash equal to the padding value: remembered, re-appended at the end
-  for (uint32_t i = t; i < n; i += WG) saw |= buf[i] == SENT;
+  for (uint32_t i = c0 + t; i < n; i += WG) saw |= buf[i] == SENT;
   if (saw) ctrl->saw_max = 1;
   if (t == 0) ctrl->scan_base = 0;
   __syncthreads();
-  bitonic_sort_lds(buf, (int)n);
-  // streaming compaction in rounds of WG elements (dest <= src always)
+  // Only the appended candidates buf[c0..n) are sorted; they are then merged with the sorted prefix by
+  // rank (every element finds its output position with one binary search in the other run: prefix
+  // elements go before equal new ones) into the free space behind them.  Sorting n log^2 n elements
+  // again at every merge cost 6.6 % of the kernel at s = 1000 and 25 % at s = 2000.  Falls back to
+  // sorting everything when the output does not fit (2n > cap) or there is no prefix yet.
+  lds_u64_ptr src = buf;
+#ifndef RTC_MERGE_FULLSORT
+  if (c0 > 0 && 2 * n <= (uint32_t)cap) {
+    const uint32_t m = n - c0;
+    bitonic_sort_lds(buf + c0, (int)m);  // ends with a barrier
+    for (uint32_t idx = t; idx < n; idx += WG) {
+      const uint64_t v = buf[idx];
+      const uint32_t pos = idx < c0 ? idx + lds_bound<false>(buf + c0, m, v) : (idx - c0) + lds_bound<true>(buf, c0, v);
+      buf[n + pos] = v;
+    }
+    __syncthreads();
+    src = buf + n;
+  } else
+#endif
+    bitonic_sort_lds(buf, (int)n);
+  // streaming compaction in rounds of WG elements (dest <= src index when in place; disjoint otherwise)
   const uint32_t lane = t & 63, wave = t >> 6;
   for (int r = 0; r < (int)n; r += WG) {
     const int idx = r + t;
     const bool in = idx < (int)n;
-    const uint64_t v = in ? buf[idx] : SENT;
-    const bool keep = in && v != SENT && (idx == 0 || v != buf[idx - 1]);
+    const uint64_t v = in ? src[idx] : SENT;
+    const bool keep = in && v != SENT && (idx == 0 || v != src[idx - 1]);
     const uint64_t bal = __ballot(keep);
     const uint32_t before = __popcll(bal & ((1ULL << lane) - 1ULL));
     if (lane == 0) ctrl->wave_tot[wave] = (uint32_t)__popcll(bal);
@@ -356,9 +403,9 @@ __device__ __noinline__ MergeResult merge_block(lds_u64_ptr buf, lds_ctrl_ptr ct
   // already be appending again by then)
   const uint32_t sbv = ctrl->scan_base;
   const uint32_t c = sbv < s ? sbv : s;
-  const uint64_t newT = (c == s && s > 0) ? buf[s - 1] : SENT;
+  const uint64_t newT = (c == s && s > 0) ? buf[s - 1] : ctrl->T0;
   __syncthreads();
-  if (t == 0) { ctrl->count = c; ctrl->T = newT; ctrl->overflow = 0; }
+  if (t == 0) { ctrl->count = c; ctrl->sorted = c; ctrl->T = newT; ctrl->overflow = 0; }
   __syncthreads();
   return MergeResult{c, newT};
 }
@@ -414,6 +461,10 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
   if ((uint32_t)(uintptr_t)lds0 != 0u) __builtin_trap();
   const lds_u64_ptr buf = (lds_u64_ptr)(lds0 + lut_bytes(k));
   const lds_ctrl_ptr ctrl = (lds_ctrl_ptr)(lds0 + lut_bytes(k) + (size_t)cap * 8);
+  // this wave's candidate queue: QCAP x {f1, f2}
+  const lds_u64_ptr wq = (lds_u64_ptr)(lds0 + lut_bytes(k) + (size_t)cap * 8 + ((sizeof(Ctrl) + 15) & ~(size_t)15)) +
+                         (size_t)(threadIdx.x >> 6) * QCAP * 2;
+  uint32_t qn = 0;  // entries waiting in it (wave-uniform)
 
   const Segment sg = segs[blockIdx.x];
   const KParams P = make_kparams(k, seed);
@@ -435,13 +486,59 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
     lo1 = lo + 1;
   }
 
-  if (t == 0) { ctrl->T = SENT; ctrl->count = 0; ctrl->overflow = 0; ctrl->saw_max = 0; ctrl->scan_base = 0; }
+  // Starting threshold.  A whole-genome workgroup knows how many k-mers are coming: the s-th smallest of N
+  // uniform hashes will be near 2^64 * s / N, so it starts at T0 = 8x that instead of "everything passes".
+  // This skips the first tiles' flood of candidates (a dozen merges under per-dword barriers: the cost that
+  // grew with s -- 6 % of the kernel at s = 1000, 20 % with 1 Mbp genomes) and changes nothing in the
+  // result as long as s distinct hashes below T0 exist (8 s expected); if fewer than s were found -- a
+  // genome with few distinct k-mers -- the workgroup simply runs again from T0 = "none".
+  uint64_t Tstart = (pass_no == 0 && !sg.partial) ? sg.t0 : SENT;
+restart:
+  if (t == 0) { ctrl->T = Tstart; ctrl->T0 = Tstart; ctrl->sorted = 0; ctrl->count = 0; ctrl->overflow = 0; ctrl->saw_max = 0; ctrl->scan_base = 0; }
   build_kmer_lut(lut, k);
   __syncthreads();
 
-  uint64_t T = SENT;
+  uint64_t T = Tstart;
+  qn = 0;
   bool safe_mode = true;
   const uint32_t room = (uint32_t)cap - s;  // >= MIN_ROOM by construction
+
+  // finishes the queued halves (one lane each), keeps those still below T and appends them with ONE LDS
+  // atomic for the whole batch; called where cap - count >= NWAVE * QCAP is guaranteed
+  auto drain_queue = [&]() {
+    if (qn == 0) return;
+    HashParts qp{0, 0};
+    uint64_t h = 0;
+    bool okq = false;
+    if (lane < qn) {
+      qp = HashParts{wq[2 * lane], wq[2 * lane + 1]};
+      h = mm_finish(qp);
+      okq = h < T || T == SENT;
+    }
+    const uint64_t bal = __ballot(okq);
+    uint32_t left = 0;
+    if (bal) {
+      uint32_t base = 0;
+      if (lane == 0) base = __hip_atomic_fetch_add(&ctrl->count, (uint32_t)__popcll(bal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      base = __shfl(base, 0);
+      const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
+      const bool fits = idx < (uint32_t)cap;
+      if (okq && fits) buf[idx] = h;
+      // No room (other waves filled the buffer meanwhile; cannot happen while the tile-end guarantee holds):
+      // the entry stays queued and the overflow flag forces a merge -- nothing is ever dropped here.
+      const uint64_t fbal = __ballot(okq && !fits);
+      if (fbal) {
+        if (okq && !fits) {
+          const uint32_t slot = (uint32_t)__popcll(fbal & ((1ULL << lane) - 1ULL));
+          wq[2 * slot] = qp.f1;
+          wq[2 * slot + 1] = qp.f2;
+          ctrl->overflow = 1;
+        }
+        left = (uint32_t)__popcll(fbal);
+      }
+    }
+    qn = left;
+  };
 
   uint32_t count_at_tile_start = 0;  // carried in registers: identical in every thread
   for (uint64_t T0 = sg.s_begin & ~15ULL; T0 < sg.s_end && s > 0; T0 += TILE_BASES) {
@@ -467,6 +564,9 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
       for (int grp = 0; grp < (WARM_DW + RUN_DW) / 4; grp++) {
         const uint4 cur = nxt;
         if (grp + 1 < (WARM_DW + RUN_DW) / 4) nxt = load_bases16(tile, rq0 + 16 * (grp + 1), gb, ge);
+#ifdef RTC_CANON_NOINIT
+        __builtin_amdgcn_sched_barrier(0);  // experiment: pin the prefetch here instead of relying on the zero-initialised canon[]
+#endif
         const uint32_t wv4[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
@@ -530,7 +630,15 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
                 allok = interior && clean;
                 // the four windows are cut out of F / R already top-aligned (one shift + one mask each):
                 // the order of two k-mers does not depend on the alignment, and the hash wants them there
+                // Bits below the window are NOT cleared: they cannot change which of two different k-mers
+                // is smaller (of two equal ones either will do), and the hash never sees them -- table
+                // offsets are taken from whole bytes and the tables of a partially filled byte are built
+                // from the k-mer's bases only (build_kmer_lut masks by byte count).
+#ifdef RTC_CANON_MASKED
                 const uint64_t topmask = P.kmask << P.lshift;
+#else
+                const uint64_t topmask = ~0ULL;
+#endif
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                   const uint64_t f = (F << (P.lshift - 6 + 2 * b)) & topmask;   // lshift >= 8 in this path
@@ -592,24 +700,46 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
 #pragma unroll
               for (int b = 0; b < 4; b++) hp[b] = kmer_hash_parts(canon[b], P);
               const uint32_t Thi1 = Thi + 1u;
-              uint64_t cm = 0;
+              uint64_t cm = 0, mq[4];
 #pragma unroll
               for (int b = 0; b < 4; b++) {
                 const uint32_t u = (uint32_t)(hp[b].f1 >> 32) + (uint32_t)(hp[b].f2 >> 32) + 1u;
-                cm |= __ballot(u <= Thi1);
+                mq[b] = __ballot(u <= Thi1);
+                cm |= mq[b];
               }
               if (cm) {  // wave-uniform, rare
-                uint64_t h[4], m[4];
+                // Possible candidates are not finished here (a wave would spend ~35 instructions on what is
+                // usually ONE lane's k-mer, ~5 % of the kernel at s = 1000): their two hash halves go to this
+                // wave's LDS queue -- slots from the wave masks, no atomics -- and are finished, tested exactly
+                // and appended a queue-full at a time (drain_queue, at tile ends where room is guaranteed).
+                const uint32_t add = (uint32_t)(__popcll(mq[0]) + __popcll(mq[1]) + __popcll(mq[2]) + __popcll(mq[3]));
+                if (qn + add <= (uint32_t)QCAP) {
+                  uint32_t qb = qn;
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
-                  // (volatile: keeps the finishing arithmetic inside this branch -- left to itself the
-                  // compiler computes it speculatively for every k-mer, which is the cost being avoided)
-                  HashParts q = hp[b];
-                  asm volatile("" : "+v"(q.f1), "+v"(q.f2));
-                  h[b] = mm_finish(q);
-                  m[b] = __ballot(h[b] < T);
+                  for (int b = 0; b < 4; b++) {
+                    if (mq[b]) {  // wave-uniform
+                      if ((mq[b] >> lane) & 1ULL) {
+                        const uint32_t slot = qb + (uint32_t)__popcll(mq[b] & ((1ULL << lane) - 1ULL));
+                        wq[2 * slot] = hp[b].f1;
+                        wq[2 * slot + 1] = hp[b].f2;
+                      }
+                      qb += (uint32_t)__popcll(mq[b]);
+                    }
+                  }
+                  qn = qb;
+                } else {  // queue full (early in a genome, T still high): finish and append on the spot
+                  uint64_t h[4], m[4];
+#pragma unroll
+                  for (int b = 0; b < 4; b++) {
+                    // (volatile: keeps the finishing arithmetic inside this branch -- left to itself the
+                    // compiler computes it speculatively for every k-mer, which is the cost being avoided)
+                    HashParts q = hp[b];
+                    asm volatile("" : "+v"(q.f1), "+v"(q.f2));
+                    h[b] = mm_finish(q);
+                    m[b] = __ballot(h[b] < T);
+                  }
+                  append(m, h);
                 }
-                append(m, h);
               }
             } else {
               uint64_t h[4], m[4];
@@ -651,7 +781,9 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
     // ---- end of tile: decide about merging and the next tile's mode ----
     const uint32_t cn = uniform32(ctrl->count);
     const uint32_t appended = cn - (count_at_tile_start < cn ? count_at_tile_start : cn);
-    const bool need_merge = cn > s + room / 2;
+    // merge early enough that the rank merge's output still fits behind the candidates (2n <= cap)
+    const uint32_t half = (uint32_t)cap / 2;
+    const bool need_merge = cn > ((half > s + 512 && half < s + room / 2) ? half : s + room / 2);
     safe_mode = appended > room / 4;
     __syncthreads();  // all reads of ctrl->count done before merge or the next tile's appends
     if (need_merge) {
@@ -660,10 +792,23 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
       T = uniform64(mr.T);
     }
     else count_at_tile_start = cn;
+    // room is guaranteed here (count <= s + room/2, so cap - count >= MIN_ROOM/2 >= NWAVE * QCAP)
+    if (qn >= (uint32_t)QDRAIN) drain_queue();
   }
 
   // ---- final fold and write-out ----
+  drain_queue();
+  {
+    const MergeResult mr = merge_block(buf, ctrl, cap, s);   // frees room should a queue still hold entries
+    T = uniform64(mr.T);
+  }
+  drain_queue();
   uint32_t n = merge_block(buf, ctrl, cap, s).count;
+  if (n < s && Tstart != SENT) {  // workgroup-uniform: the starting threshold was too optimistic for this genome
+    Tstart = SENT;
+    __syncthreads();
+    goto restart;
+  }
   uint64_t* o = (sg.partial ? parts : out) + sg.out_off;
   for (uint32_t i = t; i < n; i += WG) o[i] = buf[i];
   if (t == 0) {
@@ -700,7 +845,7 @@ __global__ __launch_bounds__(WG) void merge_partials_kernel(const MergeJob* __re
   const int t = threadIdx.x;
   const uint32_t s = jb.sketch_size;
   if (jb.pass > 0 && cnt[jb.cnt_slot] != jb.expect) return;  // genome exhausted by earlier passes
-  if (t == 0) { ctrl->T = SENT; ctrl->count = 0; ctrl->overflow = 0; ctrl->saw_max = 0; ctrl->scan_base = 0; }
+  if (t == 0) { ctrl->T = SENT; ctrl->T0 = SENT; ctrl->sorted = 0; ctrl->count = 0; ctrl->overflow = 0; ctrl->saw_max = 0; ctrl->scan_base = 0; }
   __syncthreads();
   uint32_t nmerged = 0;
   for (uint32_t p = 0; p < jb.nparts; p++) {
@@ -761,15 +906,18 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   for (int wgs = wgs_hi; wgs >= wgs_lo && cap == 0; wgs--) {
     // 52 / 78 / 156 KiB: measured on MI355X, a 53.3 KiB allocation no longer runs three workgroups per CU
     const size_t share = ((size_t)156 * 1024 / wgs) & ~(size_t)2047;
-    const size_t fixed = lut_bytes(k) + sizeof(Ctrl);
-    // below ~3000 entries of room the merges (and safe-mode barriers) cost more than the lost occupancy
-    const size_t want_room = wgs > wgs_lo ? 3072 : MIN_ROOM;
+    const size_t fixed = lut_bytes(k) + ((sizeof(Ctrl) + 15) & ~(size_t)15) + QUEUE_BYTES;
+    // (round 1 measured ~3000 entries as the break-even against lost occupancy; with the merge sorting only
+    // the new candidates a third workgroup per CU wins down to ~2300)
+    size_t want_room = wgs > wgs_lo ? 2304 : MIN_ROOM;
+    if (const char* e = getenv("RTC_SKETCH_WANT_ROOM")) want_room = (size_t)std::max(atoi(e), MIN_ROOM);  // tuning experiments
     if (share > fixed && (share - fixed) / 8 >= (size_t)chunk_max + want_room) { cap = (int)((share - fixed) / 8); wgs_per_cu = wgs; }
   }
   if (cap == 0) return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "sketch chunk %u does not fit the LDS", chunk_max);
   if (const char* e = getenv("RTC_SKETCH_CAP")) { const int v = atoi(e); if (v >= (int)(chunk_max + MIN_ROOM) && v <= cap) cap = v; }  // tuning experiments
-  const int cap_merge = (int)std::max<uint32_t>(2 * chunk_max, 1024);
-  const size_t lds = (size_t)cap * 8 + lut_bytes(k) + sizeof(Ctrl);
+  // partial-sketch merge: two lists fit 2*chunk_max; twice that lets the rank merge work out of place
+  const int cap_merge = (int)std::max<uint32_t>(std::max<uint32_t>(2 * chunk_max, std::min<uint32_t>(4 * chunk_max, 16384)), 1024);
+  const size_t lds = (size_t)cap * 8 + lut_bytes(k) + ((sizeof(Ctrl) + 15) & ~(size_t)15) + QUEUE_BYTES;
   const size_t lds_m = (size_t)cap_merge * 8 + sizeof(Ctrl);
   if (lds > (size_t)160 * 1024 || lds_m > (size_t)160 * 1024)
     return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "sketch chunk %u needs %zu B of LDS (> 160 KiB)", chunk_max, std::max(lds, lds_m));
@@ -817,6 +965,8 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     }
   }
 
+  uint32_t t0_factor = 8;  // starting threshold = t0_factor x the expected s-th smallest hash (0: start from "everything passes")
+  if (const char* e = getenv("RTC_SKETCH_T0_FACTOR")) t0_factor = (uint32_t)std::max(0, atoi(e));  // tests of the restart path / tuning
   struct PassPlan { size_t direct0, ndirect, partial0, npartial, job0, njobs; };
   std::vector<PassPlan> plans(npass);
   std::vector<Segment> direct, partial;
@@ -838,12 +988,15 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
       const uint64_t lo_off = ps ? out_off - 1 : 0;
       const uint64_t ns = nsv[g];
       if (ns == 1) {
-        direct.push_back(Segment{b, e, b, e, out_off, lo_off, g, s, g, expect, 0, 0});
+        uint64_t t0 = SENT;
+        if (ps == 0 && t0_factor > 0 && s > 0 && len > (uint64_t)t0_factor * s)
+          t0 = (uint64_t)((((unsigned __int128)1 << 64) * ((uint64_t)t0_factor * s)) / len);
+        direct.push_back(Segment{b, e, b, e, out_off, lo_off, g, s, g, expect, 0, 0, t0});
       } else {
         jobs.push_back(MergeJob{part_elems, part_slots, (uint32_t)ns, out_off, g, s, chunk_max, expect, ps, 0});
         for (uint64_t i = 0; i < ns; i++) {
           const uint64_t sb = b + len * i / ns, se = b + len * (i + 1) / ns;
-          partial.push_back(Segment{b, e, sb, se, part_elems, lo_off, part_slots, s, g, expect, 1, 0});
+          partial.push_back(Segment{b, e, sb, se, part_elems, lo_off, part_slots, s, g, expect, 1, 0, SENT});
           part_elems += chunk_max;
           part_slots++;
         }

@@ -163,3 +163,63 @@ def test_sketch_many_tiny_genomes_and_max_size(ctx, oracle):
     seq2, off2 = _random_genomes(rng, [4000, 250_000])
     _check(ctx, oracle, seq2, off2, 21, size=6144)
     _check(ctx, oracle, seq2, off2, 17, size=6144)
+
+
+def test_starting_threshold_restart_on_low_complexity(ctx, oracle):
+    """Whole-genome workgroups start from a threshold 8x the expected s-th smallest hash and must run
+    again from "none" when a genome has too few distinct k-mers below it: periodic genomes (period 3 000 and
+    40 -- fewer than s distinct k-mers in all), a poly-A run, and normal genomes beside them; enough
+    genomes in the batch that each is one workgroup (no partial segments)."""
+    rng = np.random.default_rng(61)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    parts = []
+    for g in range(3400):  # > 3 x 768 workgroup slots x ... -> whole-genome segments
+        if g % 850 == 0:
+            motif = rng.choice(acgt, size=3000)
+            parts.append(np.tile(motif, 70)[:200_000])
+        elif g % 850 == 1:
+            parts.append(np.tile(rng.choice(acgt, size=40), 5000))
+        elif g % 850 == 2:
+            parts.append(np.full(150_000, ord("A"), dtype=np.uint8))
+        else:
+            parts.append(rng.choice(acgt, size=int(rng.integers(40_000, 60_000))))
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(p) for p in parts])
+    seq = np.concatenate(parts)
+    d = ctx.upload_sequences(seq)
+    sk = ctx.sketch_minhash(d, off, k=21, size=1000)
+    ctx.sync()
+    got = sk.to_host()
+    check = [g for g in range(len(parts)) if g % 850 < 4] + [5, 77, 1234, 3399]
+    sub_off = np.zeros(len(check) + 1, dtype=np.uint64)
+    sub_off[1:] = np.cumsum([len(parts[g]) for g in check])
+    want = oracle.sketch_minhash_batch(np.concatenate([parts[g] for g in check]), sub_off, 21, 1000)
+    for g, w in zip(check, want):
+        assert np.array_equal(got[g], w), g
+    assert len(got[0]) == 1000 and len(got[1]) < 100 and len(got[2]) == 1
+
+
+def test_starting_threshold_factor_does_not_change_results(ctx, oracle):
+    """RTC_SKETCH_T0_FACTOR = 1 makes about half of the workgroups restart, 0 disables the starting
+    threshold: identical sketches either way (and equal to the oracle on a sample)."""
+    import os
+    from rabbittclust_amd import api
+    desc = api.synth_family_descs(350, 10, global_seed=9)
+    L = 60_000
+    off = np.arange(len(desc) + 1, dtype=np.uint64) * L
+    seq = ctx.synth_genomes(desc, off)
+    ref = ctx.sketch_minhash(seq, off, k=21, size=500)
+    ctx.sync()
+    for f in ("1", "0", "3"):
+        os.environ["RTC_SKETCH_T0_FACTOR"] = f
+        try:
+            alt = ctx.sketch_minhash(seq, off, k=21, size=500)
+            ctx.sync()
+        finally:
+            del os.environ["RTC_SKETCH_T0_FACTOR"]
+        import torch
+        assert torch.equal(alt.hashes, ref.hashes) and torch.equal(alt.len, ref.len), f
+    host = seq[: 3 * L].cpu().numpy()
+    want = oracle.sketch_minhash_batch(host, off[:4], 21, 500)
+    got = ref.to_host()
+    assert all(np.array_equal(a, b) for a, b in zip(got[:3], want))
