@@ -498,7 +498,7 @@ restart:
   build_kmer_lut(lut, k);
   __syncthreads();
 
-  uint64_t T = Tstart;
+  uint64_t T = uniform64(Tstart);  // scalar registers: the threshold compares write wave masks directly
   qn = 0;
   bool safe_mode = true;
   const uint32_t room = (uint32_t)cap - s;  // >= MIN_ROOM by construction
