@@ -45,6 +45,8 @@ struct rtc_ctx {
     void* d_index = nullptr;
     int ck1 = 13, ck2 = 13;
     int32_t* d_table = nullptr;
+    void* d_bucket = nullptr;  // bucket index (64 KiB of patterns) + ranks (64 KiB)
+    int bvar = -1;             // which bucket bits the index uses, -1: none
   } kssd;
 };
 

@@ -33,6 +33,7 @@ constexpr int WG = 512;
 // Lane runs of 72-76 B keep the live 128-B lines inside an XCD's L2 (see rtc_sketch_minhash.hip).
 constexpr int TILE_BASES_MAX = WG * 19 * 4;
 constexpr int MAX_LDS_KEEP = 8192;
+constexpr int BUCKET_BYTES = 65536;  // bucket index: 8192 buckets x four 16-bit patterns
 
 struct KSegment {
   uint64_t g_begin, g_end;
@@ -54,6 +55,11 @@ struct KssdParams {
   int lshift;        // 64 - 2K: top-aligned windows
   uint32_t dimmask;  // low `dimbits` bits
   uint32_t m1key, m2key;  // entry bits compared with dim_id in table 1 / table 2
+  int cf0, cr0;      // bucket kernel: forward window b = F << (cf0 + 2b), reverse = R << (cr0 - 2b)
+  int xs;            // bucket kernel: shift that brings dim_id to bits 0..23 (of the 64-bit pair / the high word)
+  int re;            // bucket kernel: the reverse extended window is kept << re (its new byte lands on a byte)
+  uint32_t rsel;     // bucket kernel: v_perm selector of the reverse window's high-word roll
+  int nofast;        // bucket kernel: RTC_KSSD_NOFAST=1 sends every tile through the general walk (tests)
   uint64_t tupmask, domask, undomask0, undomask1;
 };
 
@@ -75,158 +81,433 @@ __device__ __forceinline__ uint4 load_bases16(const uint8_t* __restrict__ seq, i
   return make_uint4(ww[0], ww[1], ww[2], ww[3]);
 }
 
-// Each lane walks 96 (K <= 25: 24 warm-up + 72 owned k-mer end positions) or 112 (36 + 76) consecutive
-// bases per tile, read straight from global memory as 16-byte loads; four bases are decoded at once
-// (SWAR) and the four k-mers of a dword are filtered back to back.
-template <typename OutT, bool LDS_INDEX, int RUN_DW, int WARM_DW>
+enum { IDX_HBM = 0, IDX_CUCKOO = 1, IDX_BUCKET = 2 };
+
+struct KssdTables {
+  const uint32_t* l_t1;         // cuckoo table 1 (LDS)
+  const uint32_t* l_t2;         // cuckoo table 2 (LDS)
+  const unsigned char* l_bk;    // bucket index (LDS): 8192 buckets of four 16-bit patterns
+  const uint16_t* g_rank;       // rank of bucket slot [bucket * 4 + slot] (HBM, read by survivors only)
+  const int32_t* g_table;       // full shuffle table (HBM path)
+};
+
+// ---- bucket index (the default --fast configuration) -------------------------------------------------
+// x carries dim_id in bits 0..23 (anything above).  VAR 0: bucket = dim_id[3..16), the pattern is bytes
+// 0 and 2 of x; VAR 1: bucket = dim_id[11..24), the pattern is the low half of x.  The 16-bit pattern
+// holds every key bit the bucket does not imply and five that it does, so a slot is matched by one
+// 16-bit compare and an unused slot holds a pattern no key of its bucket can produce: exact, no rank.
+// VAR 2 (K = 22, where dim_id[2..24) sits in the high word of the top-aligned window and dim_id[0..2) in the
+// low word): bucket as VAR 1, pattern = dim_id[2..18) -- the steady state tests 22 bits on the high word
+// alone and the two low bits are checked (they sit beside the rank, bits 12..13) when a candidate is drained.
+template <int VAR> __device__ __forceinline__ uint32_t bucket_addr(uint32_t x) {
+  return VAR ? ((x >> 8) & 0xfff8u) : (x & 0xfff8u);
+}
+template <int VAR> __device__ __forceinline__ uint32_t bucket_pattern(uint32_t x) {
+  return VAR == 2 ? ((x >> 2) & 0xffffu) : VAR == 1 ? (x & 0xffffu) : __builtin_amdgcn_perm(0u, x, 0x0c0c0200u);
+}
+// the bucket kernel's index starts at LDS address 0 (checked at kernel entry): a bucket's byte offset IS its
+// LDS address, read through an address_space(3) pointer (ds_read_b64, no base add)
+#define RTC_LDS __attribute__((address_space(3)))
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 bucket_read(uint32_t addr) {
+  const u32x2 v = *(const RTC_LDS u32x2*)(uintptr_t)addr;
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ bool bucket_match(uint2 e, uint32_t q) {
+  return (e.x & 0xffffu) == q || (e.x >> 16) == q || (e.y & 0xffffu) == q || (e.y >> 16) == q;
+}
+// exact membership of a clean dim_id: rank (bits 0..11) or 0xffffffff
+template <int VAR>
+__device__ __forceinline__ uint32_t bucket_lookup(uint32_t dim_id, const uint16_t* __restrict__ g_rank) {
+  const uint32_t addr = bucket_addr<VAR>(dim_id);
+  const uint32_t q = bucket_pattern<VAR>(dim_id);
+  const uint2 e = bucket_read(addr);
+  const uint32_t pat[4] = {e.x & 0xffffu, e.x >> 16, e.y & 0xffffu, e.y >> 16};
+  uint32_t found = 0xffffffffu;
+#pragma unroll
+  for (int sl = 0; sl < 4; sl++) {
+    if (pat[sl] == q) {
+      const uint32_t r = g_rank[(addr >> 1) + sl];
+      if (VAR != 2 || (r >> 12) == (dim_id & 3u)) found = r & 0xfffu;
+    }
+  }
+  return found;
+}
+
+__device__ __forceinline__ uint64_t reduced_tuple(const KssdParams& P, uint64_t u, uint32_t rank) {   // :1150-1152
+  return (((u & P.undomask0) | ((u & P.undomask1) << P.und1_shl)) >> (P.drlevel * 4)) | (uint64_t)rank;
+}
+
+// wave-aggregated append of the lanes in `bal` to the genome's output row
+__device__ __forceinline__ void append_tuples(uint64_t bal, bool keep, uint64_t dr, uint32_t lane, void* orow,
+                                              uint32_t* ocnt, uint32_t stride, int use64) {
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(ocnt, (uint32_t)__popcll(bal));
+  base = __shfl(base, 0);
+  const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
+  if (keep && idx < stride) {
+    if (use64) reinterpret_cast<uint64_t*>(orow)[idx] = dr;
+    else reinterpret_cast<uint32_t*>(orow)[idx] = (uint32_t)dr;
+  }
+}
+
+// The general walk over the 16-byte groups grp0.. of one lane's tile window: guarded loads, any
+// character, any segment / genome edge.  Each lane walks 96 (K <= 25: 24 warm-up + 72 owned k-mer end
+// positions) or 112 (36 + 76) consecutive bases per tile, read straight from global memory as 16-byte
+// loads; four bases are decoded at once (SWAR) while the wave holds only valid bases, one by one otherwise.
+template <int IDX, int VAR, int RUN_DW, int WARM_DW>
+__device__ __forceinline__ void generic_groups(const uint8_t* __restrict__ seq, const KSegment& sg, const KssdParams& P,
+                                               const KssdTables& TB, uint64_t T0, int rel_lo, int rel_hi, int t,
+                                               uint32_t lane, void* orow, uint32_t* ocnt, uint32_t stride, int grp0,
+                                               uint64_t tuple, uint64_t rvs, int run, bool clean) {
+  constexpr int OWN = RUN_DW * 4;
+  constexpr int TILE_BASES = WG * RUN_DW * 4;
+  const bool interior = rel_lo == 0 && rel_hi == TILE_BASES;  // every position of the tile is owned
+  const int64_t p0 = (int64_t)T0 + OWN * t - 4 * WARM_DW;
+  const bool fastroll = P.K <= 28;  // 2K+8 bits fit the 64-bit extended window
+  const uint32_t m1mask = (1u << P.ck1) - 1u;
+  uint4 nxt = load_bases16(seq, p0 + 16 * grp0, sg.g_begin, sg.g_end);
+  for (int grp = grp0; grp < (WARM_DW + RUN_DW) / 4; grp++) {
+    const uint4 cur = nxt;
+    if (grp + 1 < (WARM_DW + RUN_DW) / 4) nxt = load_bases16(seq, p0 + 16 * (grp + 1), sg.g_begin, sg.g_end);
+    const uint32_t wv4[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {
+      const int d = grp * 4 + qd;
+      const uint32_t wv = wv4[qd];
+      const bool emitting = d >= WARM_DW;  // wave-uniform
+      const int rel0 = OWN * t + 4 * (d - WARM_DW);
+      uint64_t uni[4] = {0, 0, 0, 0};
+      bool ok[4] = {false, false, false, false};
+      const uint32_t up = wv & 0xDFDFDFDFu;
+      const uint32_t codes4 = ((wv >> 1) ^ (wv >> 2)) & 0x03030303u;  // BaseMap, src/SketchInfo.cpp:1007-1017
+      const bool allvalid = __builtin_amdgcn_perm(0u, 0x54474341u, codes4) == up;
+      const bool fast = fastroll && __all(allvalid);  // wave-uniform
+      clean = clean && fast;
+      if (fast) {
+        const uint32_t pack = __builtin_amdgcn_udot4(codes4, 0x01041040u, 0u, false);  // c0<<6|c1<<4|c2<<2|c3
+        const uint32_t rp = __builtin_amdgcn_udot4(codes4, 0x40100401u, 0u, false) ^ 0xffu;
+        const uint64_t F = (tuple << 8) | pack;
+        const uint64_t R = rvs | ((uint64_t)rp << (2 * P.K));
+        if (emitting) {
+          // scalar ownership test for the steady state (tile interior to the segment, only valid
+          // bases in this wave since the tile began => run = 4d >= 4*WARM_DW >= K-1 and every position owned)
+          const bool allok = interior && clean;
+          // the four windows top-aligned (tuple :1134 / rvs :1135 four times): bits below the window are
+          // not cleaned -- they cannot change which of two different k-mers is smaller (:1141), and of
+          // two equal ones either will do
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            const uint64_t f = F << (P.lshift - 6 + 2 * b);
+            const uint64_t r = R << (P.lshift - 2 - 2 * b);
+            uni[b] = f < r ? f : r;
+          }
+          if (allok) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) ok[b] = true;
+          } else {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+              const int rel = rel0 + b;
+              ok[b] = run + b + 1 >= P.K && rel >= rel_lo && rel < rel_hi;           // :1139
+            }
+          }
+        }
+        tuple = F;      // bits above the window are masked where windows are cut / by the per-base path
+        rvs = R >> 8;   // R < 2^(2K+8) by construction
+        run += 4;
+      } else {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const uint32_t c = (wv >> (8 * b)) & 0xffu;
+          const uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;
+          const bool valid = ((c & 0xC0u) == 0x40u) && ((0x0010008Au >> (c & 31u)) & 1u);
+          tuple = ((tuple << 2) | code) & P.tupmask;                               // :1134
+          rvs = (rvs >> 2) + ((uint64_t)(code ^ 3u) << P.rev_add_move);            // :1135
+          run = valid ? run + 1 : 0;                                               // base counter :1136,1161
+          const int rel = rel0 + b;
+          ok[b] = run >= P.K && rel >= rel_lo && rel < rel_hi;
+          uni[b] = (tuple < rvs ? tuple : rvs) << P.lshift;
+        }
+      }
+      if (!emitting) continue;
+      uint32_t rank[4];
+      bool keep[4];
+      // dim_id (:1142) sits at bit lshift + dim_shift of a top-aligned window: shifting the bits above it
+      // out leaves it at the top of a 32-bit word, from where the table-2 slot (its high ck2 bits) and
+      // the value itself are one 32-bit shift each -- no masks
+      const int drop = 64 - (P.lshift + P.dim_shift) - P.dimbits;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const uint32_t xh = (uint32_t)((uni[b] << drop) >> 32);
+        const uint32_t dim_id = xh >> (32 - P.dimbits);
+        rank[b] = 0;
+        if (IDX == IDX_CUCKOO) {
+          const uint32_t e1 = TB.l_t1[dim_id & m1mask];
+          const uint32_t e2 = TB.l_t2[xh >> (32 - P.ck2)];
+          const bool m1 = ((e1 ^ dim_id) & P.m1key) == 0u;
+          const bool m2 = ((e2 ^ dim_id) & P.m2key) == 0u;
+          rank[b] = m1 ? (e1 & 0xfffu) : (e2 >> 20);
+          keep[b] = ok[b] && (m1 || m2);
+        } else if (IDX == IDX_BUCKET) {
+          keep[b] = false;
+          if (ok[b]) {
+            rank[b] = bucket_lookup<VAR>(dim_id, TB.g_rank);
+            keep[b] = rank[b] != 0xffffffffu;
+          }
+        } else {
+          keep[b] = false;
+          if (ok[b]) {
+            const int32_t sd = TB.g_table[dim_id];
+            keep[b] = sd >= 0 && sd < P.dim_end;                                   // :1054
+            rank[b] = (uint32_t)sd;
+          }
+        }
+      }
+      if (!__any(keep[0] | keep[1] | keep[2] | keep[3])) continue;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const uint64_t bal = __ballot(keep[b]);
+        if (bal) {  // wave-uniform
+          const uint64_t u = uni[b] >> P.lshift;  // the exact 2K-bit tuple
+          append_tuples(bal, keep[b], reduced_tuple(P, u, rank[b]), lane, orow, ocnt, stride, P.use64);
+        }
+      }
+    }
+  }
+}
+
+template <int IDX, int RUN_DW, int WARM_DW>
 __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restrict__ seq,
                                                          const KSegment* __restrict__ segs, KssdParams P,
                                                          const uint32_t* __restrict__ g_t1,    // cuckoo table 1 [1 << ck1]
                                                          const uint32_t* __restrict__ g_t2,    // cuckoo table 2 [1 << ck2]
                                                          const int32_t* __restrict__ g_table,  // full table (HBM path)
-                                                         OutT* __restrict__ out, uint32_t stride,
+                                                         void* __restrict__ out, uint32_t stride,
                                                          uint32_t* __restrict__ cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* l_t1 = reinterpret_cast<uint32_t*>(smem);
   uint32_t* l_t2 = l_t1 + (1u << P.ck1);
 
   static_assert((RUN_DW + WARM_DW) % 4 == 0, "a lane's window must be whole 16-byte loads");
-  constexpr int OWN = RUN_DW * 4;
   constexpr int TILE_BASES = WG * RUN_DW * 4;
   const KSegment sg = segs[blockIdx.x];
   const int t = threadIdx.x;
   const uint32_t lane = t & 63;
-  if (LDS_INDEX) {
+  if (IDX == IDX_CUCKOO) {
     for (int i = t; i < (1 << P.ck1); i += WG) l_t1[i] = g_t1[i];
     for (int i = t; i < (1 << P.ck2); i += WG) l_t2[i] = g_t2[i];
     __syncthreads();
   }
-  OutT* orow = out + (uint64_t)sg.genome * stride;
+  const KssdTables TB{l_t1, l_t2, nullptr, nullptr, g_table};
+  void* orow = reinterpret_cast<unsigned char*>(out) + (uint64_t)sg.genome * stride * (P.use64 ? 8 : 4);
   uint32_t* ocnt = cnt + sg.genome;
-  const bool fastroll = P.K <= 28;  // 2K+8 bits fit the 64-bit extended window
-  const uint32_t m1mask = (1u << P.ck1) - 1u;
 
   for (uint64_t T0 = sg.s_begin & ~15ULL; T0 < sg.s_end; T0 += TILE_BASES) {
     const int64_t lo64 = (int64_t)sg.s_begin - (int64_t)T0;
     const int64_t hi64 = (int64_t)sg.s_end - (int64_t)T0;
     const int rel_lo = lo64 < 0 ? 0 : (int)lo64;
     const int rel_hi = hi64 > TILE_BASES ? TILE_BASES : (int)hi64;
-    const bool interior = rel_lo == 0 && rel_hi == TILE_BASES;  // every position of the tile is owned
-    const int64_t p0 = (int64_t)T0 + OWN * t - 4 * WARM_DW;
+    generic_groups<IDX, 0, RUN_DW, WARM_DW>(seq, sg, P, TB, T0, rel_lo, rel_hi, t, lane, orow, ocnt, stride, 0, 0ULL, 0ULL,
+                                            0, true);
+  }
+}
 
-    uint64_t tuple = 0, rvs = 0;
-    int run = 0;
-    bool clean = true;  // wave-uniform: only valid bases in every lane of this wave so far in this tile
-    uint4 nxt = load_bases16(seq, p0, sg.g_begin, sg.g_end);
-    for (int grp = 0; grp < (WARM_DW + RUN_DW) / 4; grp++) {
-      const uint4 cur = nxt;
-      if (grp + 1 < (WARM_DW + RUN_DW) / 4) nxt = load_bases16(seq, p0 + 16 * (grp + 1), sg.g_begin, sg.g_end);
-      const uint32_t wv4[4] = {cur.x, cur.y, cur.z, cur.w};
+// ---- the default --fast configuration: bucket index, branch-free steady state ---------------------
+// Candidates of the steady state (top-aligned canonical windows whose dim_id passed the bucket test) wait in
+// a per-wave LDS queue and are finished 64 at a time: exact membership, rank, reduced tuple, append.
+constexpr int KQ_CAP = 128;                                  // entries per wave
+constexpr int KQ_BYTES = (WG / 64) * KQ_CAP * 8;
+typedef uint64_t RTC_LDS* lds_u64_ptr;
+
+template <int VAR>
+__device__ __forceinline__ void drain_queue(const KssdParams& P, const uint16_t* __restrict__ g_rank, lds_u64_ptr wq,
+                                            uint32_t& qn, uint32_t lane, void* orow, uint32_t* ocnt, uint32_t stride) {
+  for (uint32_t base = 0; base < qn; base += 64) {
+    const uint32_t i = base + lane;
+    const bool have = i < qn;
+    const uint64_t uni = have ? wq[i] : 0ULL;
+    const uint64_t u = uni >> P.lshift;                                            // the exact 2K-bit tuple
+    const uint32_t dim_id = (uint32_t)(u >> P.dim_shift) & 0xffffffu;              // :1142
+    uint32_t rank = 0xffffffffu;
+    if (have) rank = bucket_lookup<VAR>(dim_id, g_rank);
+    const bool keep = rank != 0xffffffffu;
+    const uint64_t bal = __ballot(keep);
+    if (bal) append_tuples(bal, keep, reduced_tuple(P, u, rank), lane, orow, ocnt, stride, P.use64);
+  }
+  qn = 0;
+}
+
+// One 16-byte group of a lane whose wave holds only valid, owned bases.  Per dword: SWAR decode, the
+// validity of the whole group in one wave vote, forward and reverse-complement byte by one v_dot4_u32_u8
+// each, both extended windows rolled by one byte (the reverse one is kept shifted so that its new byte
+// lands on a byte boundary: v_perm + v_alignbit).  Per k-mer: the two strands top-aligned, the canonical
+// one's dim_id brought to x
+//   XMODE 0/1: context + dim_id fit the high word, so  hi(min(f, r)) = min(hi f, hi r)  -- 3 (+1) VALU
+//   XMODE 2:   64-bit compare + select + v_alignbit                                       -- 6 VALU
+//   XMODE 3:   K = 22: min(hi f, hi r) holds dim_id[2..24); the test ignores dim_id[0..2) -- 3 VALU, and four
+//              times as many candidates reach the queue, where the exact test drops three of them
+// then ONE ds_read_b64 of the bucket and four 16-bit compares (2 + 4 VALU).  Returns false, state
+// untouched, when some lane of the wave holds a character outside ACGTacgt in this group or the queue cannot
+// take the group's candidates (the caller sends the rest of the tile through the general walk).
+// wave mask of the lanes whose bucket holds the 16-bit pattern q (four v_cmp_eq_u32_sdwa + three s_or_b64)
+__device__ __forceinline__ uint64_t bucket_match_mask(uint2 e, uint32_t q) {
+  return __ballot((e.x & 0xffffu) == q) | __ballot((e.x >> 16) == q) | __ballot((e.y & 0xffffu) == q) |
+         __ballot((e.y >> 16) == q);
+}
+
+template <int XMODE, int VAR, int QCAP>
+__device__ __forceinline__ bool fast_group(const uint4 cur, const int emit_mask, const KssdParams& P,
+                                           lds_u64_ptr wq, uint32_t& qn, uint32_t lane, uint32_t& Fhi, uint32_t& Flo,
+                                           uint32_t& Rhi, uint32_t& Rlo) {
+  const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+  uint32_t codes[4];
+  uint32_t bad = 0;
 #pragma unroll
-      for (int qd = 0; qd < 4; qd++) {
-        const int d = grp * 4 + qd;
-        const uint32_t wv = wv4[qd];
-        const bool emitting = d >= WARM_DW;  // wave-uniform
-        const int rel0 = OWN * t + 4 * (d - WARM_DW);
-        uint64_t uni[4] = {0, 0, 0, 0};
-        bool ok[4] = {false, false, false, false};
-        const uint32_t up = wv & 0xDFDFDFDFu;
-        const uint32_t codes4 = ((wv >> 1) ^ (wv >> 2)) & 0x03030303u;  // BaseMap, src/SketchInfo.cpp:1007-1017
-        const bool allvalid = __builtin_amdgcn_perm(0u, 0x54474341u, codes4) == up;
-        const bool fast = fastroll && __all(allvalid);  // wave-uniform
-        clean = clean && fast;
-        if (fast) {
-          const uint32_t pack = __builtin_amdgcn_udot4(codes4, 0x01041040u, 0u, false);  // c0<<6|c1<<4|c2<<2|c3
-          const uint32_t rp = __builtin_amdgcn_udot4(codes4, 0x40100401u, 0u, false) ^ 0xffu;
-          const uint64_t F = (tuple << 8) | pack;
-          const uint64_t R = rvs | ((uint64_t)rp << (2 * P.K));
-          if (emitting) {
-            // scalar ownership test for the steady state (tile interior to the segment, only valid
-            // bases in this wave since the tile began => run = 4d >= 4*WARM_DW >= K-1 and every position owned)
-            const bool allok = interior && clean;
-            // the four windows top-aligned (tuple :1134 / rvs :1135 four times): bits below the window are
-            // not cleaned -- they cannot change which of two different k-mers is smaller (:1141), and of
-            // two equal ones either will do
+  for (int qd = 0; qd < 4; qd++) {
+    codes[qd] = ((w[qd] >> 1) ^ (w[qd] >> 2)) & 0x03030303u;  // BaseMap, src/SketchInfo.cpp:1007-1017
+    bad |= __builtin_amdgcn_perm(0u, 0x54474341u, codes[qd]) ^ w[qd];
+  }
+  if (__ballot((bad & 0xDFDFDFDFu) != 0u)) return false;
+  const uint32_t Fhi0 = Fhi, Flo0 = Flo, Rhi0 = Rhi, Rlo0 = Rlo, qn0 = qn;
+  bool lost = false;  // wave-uniform
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-              const uint64_t f = F << (P.lshift - 6 + 2 * b);
-              const uint64_t r = R << (P.lshift - 2 - 2 * b);
-              uni[b] = f < r ? f : r;
-            }
-            if (allok) {
+  for (int qd = 0; qd < 4; qd++) {
+    const uint32_t pack = __builtin_amdgcn_udot4(codes[qd], 0x01041040u, 0u, false);  // c0<<6|c1<<4|c2<<2|c3
+    // reverse-complement byte 255 - (c0 + 4 c1 + 16 c2 + 64 c3) as the LOW BYTE of an unsigned dot product with
+    // the weights 256 - {1, 4, 16, 64} on top of 255 (only that byte is used: v_perm picks it)
+    const uint32_t rp = __builtin_amdgcn_udot4(codes[qd], 0xC0F0FCFFu, 255u, false);
+    Fhi = __builtin_amdgcn_alignbit(Fhi, Flo, 24);              // tuple :1134 four times
+    Flo = (Flo << 8) | pack;
+    const uint32_t nhi = __builtin_amdgcn_perm(Rhi, rp, P.rsel);  // rvs :1135 four times, kept << P.re
+    Rlo = __builtin_amdgcn_alignbit(Rhi, Rlo, 8);
+    Rhi = nhi;
+    if (!((emit_mask >> qd) & 1)) continue;
+    const uint64_t F = ((uint64_t)Fhi << 32) | Flo, R = ((uint64_t)Rhi << 32) | Rlo;
+    uint64_t mm[4];
+    uint32_t x[4];
+    uint2 e[4];
 #pragma unroll
-              for (int b = 0; b < 4; b++) ok[b] = true;
-            } else {
+    for (int b = 0; b < 4; b++) {
+      // the four windows top-aligned; bits below a window are not cleaned -- they cannot change which of
+      // two different k-mers is smaller (:1141), and of two equal ones either will do
+      if (XMODE == 2) {
+        const uint64_t f = F << (P.cf0 + 2 * b);
+        const uint64_t r = R << (P.cr0 - 2 * b);
+        const uint64_t u = f < r ? f : r;
+        x[b] = __builtin_amdgcn_alignbit((uint32_t)(u >> 32), (uint32_t)u, P.xs);
+      } else {  // high words only (shift counts 1..31 for 18 <= K <= 22)
+        const uint32_t fh = __builtin_amdgcn_alignbit(Fhi, Flo, 32 - (P.cf0 + 2 * b));
+        const uint32_t rh = __builtin_amdgcn_alignbit(Rhi, Rlo, 32 - (P.cr0 - 2 * b));
+        const uint32_t mh = min(fh, rh);
+        x[b] = XMODE == 1 ? mh >> P.xs : mh;
+      }
+    }
+    // the four bucket reads in flight together, then the sixteen compares
 #pragma unroll
-              for (int b = 0; b < 4; b++) {
-                const int rel = rel0 + b;
-                ok[b] = run + b + 1 >= P.K && rel >= rel_lo && rel < rel_hi;           // :1139
-              }
-            }
-          }
-          tuple = F;      // bits above the window are masked where windows are cut / by the per-base path
-          rvs = R >> 8;   // R < 2^(2K+8) by construction
-          run += 4;
-        } else {
+    for (int b = 0; b < 4; b++)  // XMODE 3: x = ctx(10) | dim_id[2..24): bucket = dim_id[11..24) = x[9..22)
+      e[b] = bucket_read(XMODE == 3 ? ((x[b] >> 6) & 0xfff8u) : bucket_addr<VAR>(x[b]));
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const uint32_t c = (wv >> (8 * b)) & 0xffu;
-            const uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;
-            const bool valid = ((c & 0xC0u) == 0x40u) && ((0x0010008Au >> (c & 31u)) & 1u);
-            tuple = ((tuple << 2) | code) & P.tupmask;                               // :1134
-            rvs = (rvs >> 2) + ((uint64_t)(code ^ 3u) << P.rev_add_move);            // :1135
-            run = valid ? run + 1 : 0;                                               // base counter :1136,1161
-            const int rel = rel0 + b;
-            ok[b] = run >= P.K && rel >= rel_lo && rel < rel_hi;
-            uni[b] = (tuple < rvs ? tuple : rvs) << P.lshift;
-          }
-        }
-        if (!emitting) continue;
-        uint32_t rank[4];
-        bool keep[4];
-        // dim_id (:1142) sits at bit lshift + dim_shift of a top-aligned window: shifting the bits above it
-        // out leaves it at the top of a 32-bit word, from where the table-2 slot (its high ck2 bits) and
-        // the value itself are one 32-bit shift each -- no masks
-        const int drop = 64 - (P.lshift + P.dim_shift) - P.dimbits;
+    for (int b = 0; b < 4; b++)  // XMODE 3: pattern = dim_id[2..18) = x[0..16)
+      mm[b] = bucket_match_mask(e[b], XMODE == 3 ? (x[b] & 0xffffu) : bucket_pattern<VAR>(x[b]));
+    if (!(mm[0] | mm[1] | mm[2] | mm[3])) continue;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-          const uint32_t xh = (uint32_t)((uni[b] << drop) >> 32);
-          const uint32_t dim_id = xh >> (32 - P.dimbits);
-          rank[b] = 0;
-          if (LDS_INDEX) {
-            const uint32_t e1 = l_t1[dim_id & m1mask];
-            const uint32_t e2 = l_t2[xh >> (32 - P.ck2)];
-            const bool m1 = ((e1 ^ dim_id) & P.m1key) == 0u;
-            const bool m2 = ((e2 ^ dim_id) & P.m2key) == 0u;
-            rank[b] = m1 ? (e1 & 0xfffu) : (e2 >> 20);
-            keep[b] = ok[b] && (m1 || m2);
-          } else {
-            keep[b] = false;
-            if (ok[b]) {
-              const int32_t sd = g_table[dim_id];
-              keep[b] = sd >= 0 && sd < P.dim_end;                                   // :1054
-              rank[b] = (uint32_t)sd;
-            }
-          }
-        }
-        if (!__any(keep[0] | keep[1] | keep[2] | keep[3])) continue;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          const uint64_t bal = __ballot(keep[b]);
-          if (bal) {  // wave-uniform
-            const uint64_t u = uni[b] >> P.lshift;  // the exact 2K-bit tuple
-            const uint64_t dr = (((u & P.undomask0) | ((u & P.undomask1) << P.und1_shl)) >> (P.drlevel * 4)) |
-                                (uint64_t)rank[b];                                   // :1150-1152
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(ocnt, (uint32_t)__popcll(bal));
-            base = __shfl(base, 0);
-            const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
-            if (keep[b] && idx < stride) orow[idx] = (OutT)dr;
-          }
+    for (int b = 0; b < 4; b++) {
+      const uint64_t bal = mm[b];
+      if (bal) {  // wave-uniform, ~1.5 % of the k-mer slots (XMODE 3: ~6 %)
+        const uint32_t cnt = (uint32_t)__popcll(bal);
+        const bool room = qn + cnt <= (uint32_t)QCAP;
+        lost |= !room;  // no room: the group is forgotten below and walked again by the general code
+        if (room) {
+          const uint64_t f = F << (P.cf0 + 2 * b);
+          const uint64_t r = R << (P.cr0 - 2 * b);
+          if (__builtin_amdgcn_inverse_ballot_w64(bal)) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = f < r ? f : r;
+          qn += cnt;
         }
       }
     }
   }
+  if (lost) {
+    Fhi = Fhi0; Flo = Flo0; Rhi = Rhi0; Rlo = Rlo0; qn = qn0;
+    return false;
+  }
+  return true;
+}
+
+template <int RUN_DW, int WARM_DW, int XMODE, int VAR>
+__global__ __launch_bounds__(WG) void sketch_kssd_bucket_kernel(const uint8_t* __restrict__ seq,
+                                                                const KSegment* __restrict__ segs, KssdParams P,
+                                                                const uint32_t* __restrict__ g_bk,    // 8192 x 8 B
+                                                                const uint16_t* __restrict__ g_rank,  // 32768
+                                                                void* __restrict__ out, uint32_t stride,
+                                                                uint32_t* __restrict__ cnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert((RUN_DW + WARM_DW) % 4 == 0, "a lane's window must be whole 16-byte loads");
+  constexpr int OWN = RUN_DW * 4;
+  constexpr int TILE_BASES = WG * RUN_DW * 4;
+  constexpr int NG = (RUN_DW + WARM_DW) / 4;
+  constexpr int NPEEL = (WARM_DW + 3) / 4;  // groups that hold warm-up dwords
+  const KSegment sg = segs[blockIdx.x];
+  const int t = threadIdx.x;
+  const uint32_t lane = t & 63;
+  {
+    uint4* l4 = reinterpret_cast<uint4*>(smem);
+    const uint4* g4 = reinterpret_cast<const uint4*>(g_bk);
+    for (int i = t; i < BUCKET_BYTES / 16; i += WG) l4[i] = g4[i];
+    __syncthreads();
+  }
+  if ((uint32_t)(uintptr_t)(RTC_LDS unsigned char*)smem != 0u) __builtin_trap();  // bucket_read addresses the index absolutely
+  const KssdTables TB{nullptr, nullptr, smem, g_rank, nullptr};
+  void* orow = reinterpret_cast<unsigned char*>(out) + (uint64_t)sg.genome * stride * (P.use64 ? 8 : 4);
+  uint32_t* ocnt = cnt + sg.genome;
+  const int w0 = __builtin_amdgcn_readfirstlane(t & ~63);
+  const lds_u64_ptr wq = (lds_u64_ptr)(uintptr_t)(BUCKET_BYTES + (w0 >> 6) * KQ_CAP * 8);  // this wave's queue
+  uint32_t qn = 0;                                                                         // wave-uniform
+
+  // the wave's bases [own_b - warm-up, own_e): all inside the genome (plain loads) and all owned positions
+  // inside the segment => every k-mer end position of the wave counts as long as the characters are valid
+  auto wave_fast = [&](uint64_t T0) {
+    const int64_t own_b = (int64_t)T0 + (int64_t)OWN * w0, own_e = own_b + (int64_t)OWN * 64;
+    return T0 < sg.s_end && own_b - 4 * WARM_DW >= (int64_t)sg.g_begin && own_e <= (int64_t)sg.g_end &&
+           own_b >= (int64_t)sg.s_begin && own_e <= (int64_t)sg.s_end && !P.nofast;
+  };
+  for (uint64_t T0 = sg.s_begin & ~15ULL; T0 < sg.s_end; T0 += TILE_BASES) {
+    const int64_t lo64 = (int64_t)sg.s_begin - (int64_t)T0;
+    const int64_t hi64 = (int64_t)sg.s_end - (int64_t)T0;
+    const int rel_lo = lo64 < 0 ? 0 : (int)lo64;
+    const int rel_hi = hi64 > TILE_BASES ? TILE_BASES : (int)hi64;
+    const int64_t own_b = (int64_t)T0 + (int64_t)OWN * w0, own_e = own_b + (int64_t)OWN * 64;
+    const bool wfast = wave_fast(T0);
+    if (own_b >= (int64_t)sg.s_end || own_e <= (int64_t)sg.s_begin) continue;  // nothing of this wave's run is owned
+    int grp = 0;
+    uint32_t Fhi = 0, Flo = 0, Rhi = 0, Rlo = 0;
+    if (qn > (uint32_t)KQ_CAP / 2) drain_queue<VAR>(P, g_rank, wq, qn, lane, orow, ocnt, stride);
+    if (wfast) {
+      const uint4* base = reinterpret_cast<const uint4*>(seq + ((int64_t)T0 + OWN * t - 4 * WARM_DW));
+      uint4 D[NG];  // the lane's whole window at once: the loads of the later groups fly while the first are walked
+#pragma unroll
+      for (int g = 0; g < NG; g++) D[g] = base[g];
+      bool good = true;
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        if (good) {
+          int mask = 0;
+          for (int qd = 0; qd < 4; qd++) mask |= (g * 4 + qd >= WARM_DW ? 1 : 0) << qd;
+          good = fast_group<XMODE, VAR, KQ_CAP>(D[g], mask, P, wq, qn, lane, Fhi, Flo, Rhi, Rlo);
+          if (good) grp = g + 1;
+        }
+      }
+    }
+    if (grp < NG) {
+      if (qn > (uint32_t)KQ_CAP / 2) drain_queue<VAR>(P, g_rank, wq, qn, lane, orow, ocnt, stride);
+      const uint64_t F = ((uint64_t)Fhi << 32) | Flo, R = ((uint64_t)Rhi << 32) | Rlo;
+      generic_groups<IDX_BUCKET, VAR, RUN_DW, WARM_DW>(seq, sg, P, TB, T0, rel_lo, rel_hi, t, lane, orow, ocnt, stride, grp, F,
+                                                       R >> (P.re + 8), 16 * grp, true);
+    }
+  }
+  drain_queue<VAR>(P, g_rank, wq, qn, lane, orow, ocnt, stride);
 }
 
 // one workgroup per genome: sort + dedup the appended tuples in LDS (hashArr sort :1185,:1192)
@@ -520,6 +801,49 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
     RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (kc.d_index) { (void)hipFree(kc.d_index); kc.d_index = nullptr; }
     if (kc.d_table) { (void)hipFree(kc.d_table); kc.d_table = nullptr; }
+    if (kc.d_bucket) { (void)hipFree(kc.d_bucket); kc.d_bucket = nullptr; }
+    kc.bvar = -1;
+    if (lds_index && 4 * half_subk == 24 && !getenv("RTC_KSSD_CUCKOO")) {
+      // bucket index: 8192 buckets of four 16-bit patterns (one ds_read_b64 per probe) when no bucket
+      // receives more than four kept ids; two choices of bucket bits (see bucket_addr)
+      std::vector<uint32_t> keys;
+      for (int t = 0; t < dim_size; t++)
+        if (h_shuffled_dim[t] >= 0 && h_shuffled_dim[t] < dim_end) keys.push_back((uint32_t)t);
+      if (keys.size() > (size_t)MAX_LDS_KEEP) return rtc_fail(ctx, RTC_ERR_ARG, "shuffle table is not a permutation");
+      // var 1 first: its bucket bits also serve the K = 22 variant (var 2: pattern without dim_id[0..2))
+      const int order[2] = {1, 0};
+      for (int oi = 0; oi < 2 && kc.bvar < 0; oi++) {
+        const int var = order[oi];
+        const size_t nsl = (size_t)BUCKET_BYTES / 2;
+        std::vector<uint16_t> pat(nsl), rnk(nsl, 0), pat2(nsl), rnk2(nsl, 0);
+        std::vector<uint8_t> fill(8192, 0);
+        for (uint32_t bk = 0; bk < 8192; bk++)  // unused slots: implied bits inverted
+          for (int sl = 0; sl < 4; sl++) {
+            pat[bk * 4 + sl] = (uint16_t)((~bk & 0x1fu) << (var ? 11 : 3));
+            pat2[bk * 4 + sl] = (uint16_t)((~bk & 0x7fu) << 9);
+          }
+        bool fits = true;
+        for (uint32_t key : keys) {
+          const uint32_t bk = var ? (key >> 11) & 0x1fffu : (key >> 3) & 0x1fffu;
+          const uint16_t q = var ? (uint16_t)(key & 0xffffu) : (uint16_t)((key & 0xffu) | (((key >> 16) & 0xffu) << 8));
+          if (fill[bk] == 4) { fits = false; break; }
+          pat[bk * 4 + fill[bk]] = q;
+          rnk[bk * 4 + fill[bk]] = (uint16_t)h_shuffled_dim[key];
+          pat2[bk * 4 + fill[bk]] = (uint16_t)((key >> 2) & 0xffffu);
+          rnk2[bk * 4 + fill[bk]] = (uint16_t)((uint32_t)h_shuffled_dim[key] | ((key & 3u) << 12));
+          fill[bk]++;
+        }
+        if (!fits) continue;
+        // [patterns | ranks] of the exact variant, then (var 1 only) [patterns | ranks] of variant 2
+        RTC_HIP(ctx, hipMalloc(&kc.d_bucket, (size_t)BUCKET_BYTES * 4));
+        RTC_HIP(ctx, hipMemcpy(kc.d_bucket, pat.data(), BUCKET_BYTES, hipMemcpyHostToDevice));
+        RTC_HIP(ctx, hipMemcpy((char*)kc.d_bucket + BUCKET_BYTES, rnk.data(), BUCKET_BYTES, hipMemcpyHostToDevice));
+        RTC_HIP(ctx, hipMemcpy((char*)kc.d_bucket + 2 * (size_t)BUCKET_BYTES, pat2.data(), BUCKET_BYTES, hipMemcpyHostToDevice));
+        RTC_HIP(ctx, hipMemcpy((char*)kc.d_bucket + 3 * (size_t)BUCKET_BYTES, rnk2.data(), BUCKET_BYTES, hipMemcpyHostToDevice));
+        kc.bvar = var;
+      }
+    }
+    // the cuckoo / HBM structures below serve the k-mer lengths the bucket kernel does not cover
     if (lds_index) {
       // two-table cuckoo placement of the kept (dim_id -> rank) pairs; smallest tables that work
       const int dimbits = 4 * half_subk;
@@ -583,6 +907,9 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
     if (h_off[g + 1] < h_off[g]) return rtc_fail(ctx, RTC_ERR_ARG, "offsets not monotone at genome %u", g);
     total += h_off[g + 1] - h_off[g];
   }
+  // bucket kernel: dim_id of 24 bits, extended windows of 2K+8 <= 64 bits, window shifts of 1..31 bits where only
+  // high words are cut (K <= 22)
+  const bool use_bucket = kc.bvar >= 0 && K >= 18 && K <= 28;
   uint64_t seg_len = total / ((uint64_t)ctx->num_cu * 12);
   const uint64_t min_seg = 4ull * TILE_BASES_MAX;
   if (seg_len < min_seg) seg_len = min_seg;
@@ -614,18 +941,51 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   P.m2key = (1u << (P.dimbits - P.ck2 + 1)) - 1u;
   const uint32_t* d_t2 = kc.d_index ? d_t1 + ((size_t)1 << kc.ck1) : nullptr;
   const size_t lds = lds_index ? (((size_t)1 << kc.ck1) + ((size_t)1 << kc.ck2)) * 4 : 16;
-#define LAUNCH_KSSD2(OT, LI, RUN, WARM)                                                                               \
+  if (use_bucket) {
+    P.cf0 = P.lshift - 6;
+    P.nofast = getenv("RTC_KSSD_NOFAST") ? atoi(getenv("RTC_KSSD_NOFAST")) : 0;
+    P.re = (8 - (2 * K) % 8) % 8;
+    P.cr0 = P.lshift - 2 - P.re;
+    const int nb = (2 * K + P.re) / 8;  // byte of the extended reverse window that receives the new dword
+    P.rsel = 0;
+    for (int j = 0; j < 4; j++) P.rsel |= (uint32_t)(j == nb - 4 ? 0x00 : (j < nb - 4 ? 4 + j + 1 : 0x0c)) << (8 * j);
+    const int xs_abs = P.lshift + P.dim_shift;  // bit of the top-aligned window pair where dim_id starts
+    const int xmode = xs_abs >= 32 ? (xs_abs == 32 ? 0 : 1) : 2;
+    P.xs = xs_abs >= 32 ? xs_abs - 32 : xs_abs;
+    // K = 22 (xs_abs == 30) with the var-1 buckets: the 22-bit test on the high word (XMODE 3, table variant 2)
+    const bool approx = xs_abs == 30 && kc.bvar == 1 && !getenv("RTC_KSSD_EXACT_FILTER");
+    const size_t tb = approx ? 2 * (size_t)BUCKET_BYTES : 0;
+    const uint32_t* d_bk = (const uint32_t*)((const char*)kc.d_bucket + tb);
+    const uint16_t* d_rk = (const uint16_t*)((const char*)kc.d_bucket + tb + BUCKET_BYTES);
+    const int lds_bk = BUCKET_BYTES + KQ_BYTES;
+#define LAUNCH_BK(RUN, WARM, XM, VR)                                                                                  \
   do {                                                                                                               \
-    auto kern = sketch_kssd_kernel<OT, LI, RUN, WARM>;                                                               \
+    auto kern = sketch_kssd_bucket_kernel<RUN, WARM, XM, VR>;                                                        \
+    RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bk));        \
+    hipLaunchKernelGGL(kern, dim3((uint32_t)segs.size()), dim3(WG), lds_bk, ctx->stream, d_seq,                      \
+                       (const KSegment*)ws0, P, d_bk, d_rk, d_out, stride, d_cnt);                                   \
+  } while (0)
+#define LAUNCH_BKV(RUN, WARM, XM) do { if (kc.bvar) LAUNCH_BK(RUN, WARM, XM, 1); else LAUNCH_BK(RUN, WARM, XM, 0); } while (0)
+    if (K > 25) LAUNCH_BKV(19, 9, 2);  // K >= 22 always straddles the two words
+    else if (approx) LAUNCH_BK(18, 6, 3, 2);
+    else if (xmode == 0) LAUNCH_BKV(18, 6, 0);
+    else if (xmode == 1) LAUNCH_BKV(18, 6, 1);
+    else LAUNCH_BKV(18, 6, 2);
+#undef LAUNCH_BKV
+#undef LAUNCH_BK
+  } else {
+#define LAUNCH_KSSD2(IX, RUN, WARM)                                                                                   \
+  do {                                                                                                               \
+    auto kern = sketch_kssd_kernel<IX, RUN, WARM>;                                                                   \
     RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
     hipLaunchKernelGGL(kern, dim3((uint32_t)segs.size()), dim3(WG), lds, ctx->stream, d_seq, (const KSegment*)ws0, P, \
-                       d_t1, d_t2, (const int32_t*)kc.d_table, (OT*)d_out, stride, d_cnt);                        \
+                       d_t1, d_t2, (const int32_t*)kc.d_table, d_out, stride, d_cnt);                               \
   } while (0)
-#define LAUNCH_KSSD(OT, LI) do { if (K <= 25) LAUNCH_KSSD2(OT, LI, 18, 6); else LAUNCH_KSSD2(OT, LI, 19, 9); } while (0)
-  if (use64) { if (lds_index) LAUNCH_KSSD(uint64_t, true); else LAUNCH_KSSD(uint64_t, false); }
-  else       { if (lds_index) LAUNCH_KSSD(uint32_t, true); else LAUNCH_KSSD(uint32_t, false); }
+#define LAUNCH_KSSD(IX) do { if (K <= 25) LAUNCH_KSSD2(IX, 18, 6); else LAUNCH_KSSD2(IX, 19, 9); } while (0)
+    if (lds_index) LAUNCH_KSSD(IDX_CUCKOO); else LAUNCH_KSSD(IDX_HBM);
 #undef LAUNCH_KSSD2
 #undef LAUNCH_KSSD
+  }
   RTC_CHECK_LAUNCH(ctx);
 
   // ---- capacity check, then per-genome sort + dedup ----
