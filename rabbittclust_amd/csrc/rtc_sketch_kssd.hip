@@ -6,18 +6,16 @@
 // sort (:1154-1157, :1180-1193).
 //
 // The reference probes a phmap of the kept (dim_id -> rank) pairs per k-mer.  Here the kept set
-// (dim_end of 2^(4*half_subk) ids; 4096 of 16 Mi at the default drlevel 3) is compiled on the
-// host into a two-table cuckoo index in <= 64 KiB of LDS: table 1 is addressed by the low 13 bits of
-// dim_id, table 2 by the high 12-13 bits.  An entry keeps the key bits its slot does not imply AT
-// THEIR NATURAL POSITIONS (plus one bit the slot does imply, so that an unused slot can hold a
-// pattern nothing matches) and the rank beside them, so a probe is  ((entry ^ dim_id) & mask) == 0:
-// two ds_read_b32, two three-input boolean ops and two compares, no loop, exact.  The canonical
-// k-mer is selected on top-aligned windows whose low bits are never cleaned (one shift each); the
-// exact tuple and the rank are only computed for the ~1/4096 survivors.
-// Configurations that keep more than 8192 ids (drlevel <= 2), or a kept set the cuckoo build cannot
-// place, fall back to a table lookup in HBM.  Survivors are appended to the genome's
-// output row with wave-aggregated atomics; kssd_sort_unique_kernel then sorts and deduplicates
-// each row in LDS.
+// (dim_end of 2^(4*half_subk) ids; 4096 of 16 Mi at the default drlevel 3) is compiled on the host
+// into an index that lives in LDS:
+//  * bucket index (24-bit dim_id, K = 18..28: every default configuration): 8192 buckets of four 16-bit
+//    patterns, so a probe is one ds_read_b64 and four 16-bit compares, exact (see bucket_addr).  Its
+//    kernel walks wave tiles without a branch per k-mer while the wave holds only ACGTacgt: candidates go
+//    to a per-wave LDS queue and are finished (rank, reduced tuple, append) 64 at a time.
+//  * two-table cuckoo index (other k-mer lengths, 28-bit dim_id): two ds_read_b32 per k-mer.
+//  * the full table in HBM when more than 8192 ids are kept (drlevel <= 2) or nothing else can be built.
+// Survivors are appended to the genome's output row with wave-aggregated atomics;
+// kssd_sort_unique_kernel then sorts and deduplicates each row in LDS.
 #include <algorithm>
 #include <vector>
 
@@ -81,13 +79,11 @@ __device__ __forceinline__ uint4 load_bases16(const uint8_t* __restrict__ seq, i
   return make_uint4(ww[0], ww[1], ww[2], ww[3]);
 }
 
-enum { IDX_HBM = 0, IDX_CUCKOO = 1, IDX_BUCKET = 2 };
+enum { IDX_HBM = 0, IDX_CUCKOO = 1 };
 
 struct KssdTables {
   const uint32_t* l_t1;         // cuckoo table 1 (LDS)
   const uint32_t* l_t2;         // cuckoo table 2 (LDS)
-  const unsigned char* l_bk;    // bucket index (LDS): 8192 buckets of four 16-bit patterns
-  const uint16_t* g_rank;       // rank of bucket slot [bucket * 4 + slot] (HBM, read by survivors only)
   const int32_t* g_table;       // full shuffle table (HBM path)
 };
 
@@ -156,7 +152,7 @@ __device__ __forceinline__ void append_tuples(uint64_t bal, bool keep, uint64_t 
 // character, any segment / genome edge.  Each lane walks 96 (K <= 25: 24 warm-up + 72 owned k-mer end
 // positions) or 112 (36 + 76) consecutive bases per tile, read straight from global memory as 16-byte
 // loads; four bases are decoded at once (SWAR) while the wave holds only valid bases, one by one otherwise.
-template <int IDX, int VAR, int RUN_DW, int WARM_DW>
+template <int IDX, int RUN_DW, int WARM_DW>
 __device__ __forceinline__ void generic_groups(const uint8_t* __restrict__ seq, const KSegment& sg, const KssdParams& P,
                                                const KssdTables& TB, uint64_t T0, int rel_lo, int rel_hi, int t,
                                                uint32_t lane, void* orow, uint32_t* ocnt, uint32_t stride, int grp0,
@@ -250,12 +246,6 @@ __device__ __forceinline__ void generic_groups(const uint8_t* __restrict__ seq, 
           const bool m2 = ((e2 ^ dim_id) & P.m2key) == 0u;
           rank[b] = m1 ? (e1 & 0xfffu) : (e2 >> 20);
           keep[b] = ok[b] && (m1 || m2);
-        } else if (IDX == IDX_BUCKET) {
-          keep[b] = false;
-          if (ok[b]) {
-            rank[b] = bucket_lookup<VAR>(dim_id, TB.g_rank);
-            keep[b] = rank[b] != 0xffffffffu;
-          }
         } else {
           keep[b] = false;
           if (ok[b]) {
@@ -300,7 +290,7 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
     for (int i = t; i < (1 << P.ck2); i += WG) l_t2[i] = g_t2[i];
     __syncthreads();
   }
-  const KssdTables TB{l_t1, l_t2, nullptr, nullptr, g_table};
+  const KssdTables TB{l_t1, l_t2, g_table};
   void* orow = reinterpret_cast<unsigned char*>(out) + (uint64_t)sg.genome * stride * (P.use64 ? 8 : 4);
   uint32_t* ocnt = cnt + sg.genome;
 
@@ -309,7 +299,7 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
     const int64_t hi64 = (int64_t)sg.s_end - (int64_t)T0;
     const int rel_lo = lo64 < 0 ? 0 : (int)lo64;
     const int rel_hi = hi64 > TILE_BASES ? TILE_BASES : (int)hi64;
-    generic_groups<IDX, 0, RUN_DW, WARM_DW>(seq, sg, P, TB, T0, rel_lo, rel_hi, t, lane, orow, ocnt, stride, 0, 0ULL, 0ULL,
+    generic_groups<IDX, RUN_DW, WARM_DW>(seq, sg, P, TB, T0, rel_lo, rel_hi, t, lane, orow, ocnt, stride, 0, 0ULL, 0ULL,
                                             0, true);
   }
 }
@@ -317,8 +307,11 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
 // ---- the default --fast configuration: bucket index, branch-free steady state ---------------------
 // Candidates of the steady state (top-aligned canonical windows whose dim_id passed the bucket test) wait in
 // a per-wave LDS queue and are finished 64 at a time: exact membership, rank, reduced tuple, append.
+// 768 lanes x 2 workgroups per CU (index 64 KiB + queues each) = 6 waves per SIMD at <= 80 VGPRs: measured best of
+// 512 / 640 / 768 / 896 / 1024 (the walk is VALU-issue bound; the steady state needs 64 registers)
+constexpr int WGB = 768;                                     // lanes per workgroup of the bucket kernel
 constexpr int KQ_CAP = 128;                                  // entries per wave
-constexpr int KQ_BYTES = (WG / 64) * KQ_CAP * 8;
+constexpr int KQ_BYTES = (WGB / 64) * KQ_CAP * 8;
 typedef uint64_t RTC_LDS* lds_u64_ptr;
 
 template <int VAR>
@@ -436,8 +429,63 @@ __device__ __forceinline__ bool fast_group(const uint4 cur, const int emit_mask,
   return true;
 }
 
+// The groups g0.. of a lane's tile window base by base (:1126-1161): any character, any segment / genome
+// edge, guarded loads, a few live registers, one instance in the kernel.  Candidates (valid, owned k-mer ends
+// whose dim_id passes the bucket's pattern test) join the same queue as the steady state's.  Used from the
+// group that holds a character outside ACGTacgt to the end of the tile, and for wave tiles at the edges of a
+// segment.
+template <int VAR, int RUN_DW, int WARM_DW>
+__device__ __forceinline__ void slow_groups(const uint8_t* __restrict__ seq, const KSegment& sg, const KssdParams& P,
+                                            const uint16_t* __restrict__ g_rank, int64_t p0, int rel00, int rel_lo,
+                                            int rel_hi, int g0, lds_u64_ptr wq, uint32_t& qn, uint32_t lane, void* orow,
+                                            uint32_t* ocnt, uint32_t stride, uint64_t tuple, uint64_t rvs, int run) {
+#pragma unroll 1
+  for (int g = g0; g < (RUN_DW + WARM_DW) / 4; g++) {
+    const int64_t q = p0 + 16 * g;
+    uint64_t lo = 0, hi = 0;
+    if (q >= (int64_t)sg.g_begin && q + 16 <= (int64_t)sg.g_end) {
+      const uint4 cur = *reinterpret_cast<const uint4*>(seq + q);
+      lo = ((uint64_t)cur.y << 32) | cur.x;
+      hi = ((uint64_t)cur.w << 32) | cur.z;
+    } else {  // across an end of the genome: byte by byte, 'N' outside
+#pragma unroll 1
+      for (int i = 15; i >= 0; i--) {
+        const int64_t pp = q + i;
+        const uint64_t ch = (pp >= (int64_t)sg.g_begin && pp < (int64_t)sg.g_end) ? seq[pp] : (uint64_t)'N';
+        hi = (hi << 8) | (lo >> 56);
+        lo = (lo << 8) | ch;
+      }
+    }
+#pragma unroll 1
+    for (int i = 0; i < 16; i++) {
+      const uint32_t c = (uint32_t)lo & 0xffu;
+      lo = (lo >> 8) | (hi << 56);
+      hi >>= 8;
+      const uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;                        // BaseMap, src/SketchInfo.cpp:1007-1017
+      const bool valid = ((c & 0xC0u) == 0x40u) && ((0x0010008Au >> (c & 31u)) & 1u);
+      tuple = ((tuple << 2) | code) & P.tupmask;                               // :1134
+      rvs = (rvs >> 2) + ((uint64_t)(code ^ 3u) << P.rev_add_move);            // :1135
+      run = valid ? run + 1 : 0;                                               // base counter :1136,1161
+      if (16 * g + i < 4 * WARM_DW) continue;                                  // warm-up: roll only
+      const int rel = rel00 + 16 * g + i;
+      const bool ok = run >= P.K && rel >= rel_lo && rel < rel_hi;            // :1139
+      const uint64_t u = tuple < rvs ? tuple : rvs;                            // :1141
+      const uint32_t dim_id = (uint32_t)(u >> P.dim_shift) & 0xffffffu;        // :1142
+      const uint2 e = bucket_read(bucket_addr<VAR>(dim_id));
+      const uint64_t bal = __ballot(ok && bucket_match(e, bucket_pattern<VAR>(dim_id)));
+      if (bal) {
+        const uint32_t cnt = (uint32_t)__popcll(bal);
+        if (qn + cnt > (uint32_t)KQ_CAP) drain_queue<VAR>(P, g_rank, wq, qn, lane, orow, ocnt, stride);
+        if (__builtin_amdgcn_inverse_ballot_w64(bal))
+          wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = u << P.lshift;
+        qn += cnt;
+      }
+    }
+  }
+}
+
 template <int RUN_DW, int WARM_DW, int XMODE, int VAR>
-__global__ __launch_bounds__(WG) void sketch_kssd_bucket_kernel(const uint8_t* __restrict__ seq,
+__global__ __launch_bounds__(WGB, 2) void sketch_kssd_bucket_kernel(const uint8_t* __restrict__ seq,
                                                                 const KSegment* __restrict__ segs, KssdParams P,
                                                                 const uint32_t* __restrict__ g_bk,    // 8192 x 8 B
                                                                 const uint16_t* __restrict__ g_rank,  // 32768
@@ -446,20 +494,18 @@ __global__ __launch_bounds__(WG) void sketch_kssd_bucket_kernel(const uint8_t* _
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert((RUN_DW + WARM_DW) % 4 == 0, "a lane's window must be whole 16-byte loads");
   constexpr int OWN = RUN_DW * 4;
-  constexpr int TILE_BASES = WG * RUN_DW * 4;
+  constexpr int TILE_BASES = WGB * RUN_DW * 4;
   constexpr int NG = (RUN_DW + WARM_DW) / 4;
-  constexpr int NPEEL = (WARM_DW + 3) / 4;  // groups that hold warm-up dwords
   const KSegment sg = segs[blockIdx.x];
   const int t = threadIdx.x;
   const uint32_t lane = t & 63;
   {
     uint4* l4 = reinterpret_cast<uint4*>(smem);
     const uint4* g4 = reinterpret_cast<const uint4*>(g_bk);
-    for (int i = t; i < BUCKET_BYTES / 16; i += WG) l4[i] = g4[i];
+    for (int i = t; i < BUCKET_BYTES / 16; i += WGB) l4[i] = g4[i];
     __syncthreads();
   }
   if ((uint32_t)(uintptr_t)(RTC_LDS unsigned char*)smem != 0u) __builtin_trap();  // bucket_read addresses the index absolutely
-  const KssdTables TB{nullptr, nullptr, smem, g_rank, nullptr};
   void* orow = reinterpret_cast<unsigned char*>(out) + (uint64_t)sg.genome * stride * (P.use64 ? 8 : 4);
   uint32_t* ocnt = cnt + sg.genome;
   const int w0 = __builtin_amdgcn_readfirstlane(t & ~63);
@@ -479,14 +525,16 @@ __global__ __launch_bounds__(WG) void sketch_kssd_bucket_kernel(const uint8_t* _
     const int rel_lo = lo64 < 0 ? 0 : (int)lo64;
     const int rel_hi = hi64 > TILE_BASES ? TILE_BASES : (int)hi64;
     const int64_t own_b = (int64_t)T0 + (int64_t)OWN * w0, own_e = own_b + (int64_t)OWN * 64;
-    const bool wfast = wave_fast(T0);
     if (own_b >= (int64_t)sg.s_end || own_e <= (int64_t)sg.s_begin) continue;  // nothing of this wave's run is owned
+    const bool wfast = wave_fast(T0);
+    if (qn > (uint32_t)KQ_CAP / 2) drain_queue<VAR>(P, g_rank, wq, qn, lane, orow, ocnt, stride);
+    const int64_t p0 = (int64_t)T0 + OWN * t - 4 * WARM_DW;
     int grp = 0;
     uint32_t Fhi = 0, Flo = 0, Rhi = 0, Rlo = 0;
-    if (qn > (uint32_t)KQ_CAP / 2) drain_queue<VAR>(P, g_rank, wq, qn, lane, orow, ocnt, stride);
     if (wfast) {
-      const uint4* base = reinterpret_cast<const uint4*>(seq + ((int64_t)T0 + OWN * t - 4 * WARM_DW));
-      uint4 D[NG];  // the lane's whole window at once: the loads of the later groups fly while the first are walked
+      // the lane's whole window at once: the loads of the later groups fly while the first are walked
+      uint4 D[NG];
+      const uint4* base = reinterpret_cast<const uint4*>(seq + p0);
 #pragma unroll
       for (int g = 0; g < NG; g++) D[g] = base[g];
       bool good = true;
@@ -500,11 +548,10 @@ __global__ __launch_bounds__(WG) void sketch_kssd_bucket_kernel(const uint8_t* _
         }
       }
     }
-    if (grp < NG) {
-      if (qn > (uint32_t)KQ_CAP / 2) drain_queue<VAR>(P, g_rank, wq, qn, lane, orow, ocnt, stride);
+    if (grp < NG) {  // from the group with a character outside ACGTacgt (or a full queue), or the whole edge tile
       const uint64_t F = ((uint64_t)Fhi << 32) | Flo, R = ((uint64_t)Rhi << 32) | Rlo;
-      generic_groups<IDX_BUCKET, VAR, RUN_DW, WARM_DW>(seq, sg, P, TB, T0, rel_lo, rel_hi, t, lane, orow, ocnt, stride, grp, F,
-                                                       R >> (P.re + 8), 16 * grp, true);
+      slow_groups<VAR, RUN_DW, WARM_DW>(seq, sg, P, g_rank, p0, OWN * t - 4 * WARM_DW, rel_lo, rel_hi, grp, wq, qn, lane, orow,
+                                        ocnt, stride, F, R >> (P.re + 8), 16 * grp);
     }
   }
   drain_queue<VAR>(P, g_rank, wq, qn, lane, orow, ocnt, stride);
@@ -911,7 +958,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   // high words are cut (K <= 22)
   const bool use_bucket = kc.bvar >= 0 && K >= 18 && K <= 28;
   uint64_t seg_len = total / ((uint64_t)ctx->num_cu * 12);
-  const uint64_t min_seg = 4ull * TILE_BASES_MAX;
+  const uint64_t min_seg = 4ull * (use_bucket ? WGB * 19 * 4 : TILE_BASES_MAX);
   if (seg_len < min_seg) seg_len = min_seg;
   std::vector<KSegment> segs;
   segs.reserve(n + 1024);
@@ -962,7 +1009,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   do {                                                                                                               \
     auto kern = sketch_kssd_bucket_kernel<RUN, WARM, XM, VR>;                                                        \
     RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bk));        \
-    hipLaunchKernelGGL(kern, dim3((uint32_t)segs.size()), dim3(WG), lds_bk, ctx->stream, d_seq,                      \
+    hipLaunchKernelGGL(kern, dim3((uint32_t)segs.size()), dim3(WGB), lds_bk, ctx->stream, d_seq,                      \
                        (const KSegment*)ws0, P, d_bk, d_rk, d_out, stride, d_cnt);                                   \
   } while (0)
 #define LAUNCH_BKV(RUN, WARM, XM) do { if (kc.bvar) LAUNCH_BK(RUN, WARM, XM, 1); else LAUNCH_BK(RUN, WARM, XM, 0); } while (0)
