@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_JSON = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PROFILE_JSON = ("r02_pmc_traffic.json", "r02_kssd_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def parse():
@@ -75,8 +75,9 @@ def measured_traffic(kernel, workload):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", name)))
             w = prof["workload"]
-            if all(w.get(k) == v for k, v in workload.items()) and kernel in prof["kernels"]:
-                return prof["kernels"][kernel]["hbm_bytes_per_launch"], name
+            key = next((k for k in prof["kernels"] if k in kernel), None)  # profile keys are kernel-name stems
+            if key is not None and all(w.get(k) == v for k, v in workload.items()):
+                return prof["kernels"][key]["hbm_bytes_per_launch"], name
         except Exception:
             continue
     return None, None
@@ -245,7 +246,7 @@ def main():
         dist_pairs_local = ph["pairs_local"]
         dist_algo = dist_pairs_local * 2 * avg_len * width / (ph["pair_ms"] * 1e-3) / 1e9
         wl = {"genomes": n_local, "length": length, "k": args.k, "s": args.s, "mode": mode}
-        sk_kernel = "sketch_minhash_kernel" if mode == "minhash" else "sketch_kssd_kernel"
+        sk_kernel = "sketch_minhash_kernel" if mode == "minhash" else "sketch_kssd_bucket_kernel"
         sk_traffic, sk_src = measured_traffic(sk_kernel, wl)
         pr_traffic, pr_src = measured_traffic("pair_tiled_kernel", wl)
         pr_ach = pr_traffic / (ph["pair_ms"] * 1e-3) / 1e9 if pr_traffic else None

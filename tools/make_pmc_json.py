@@ -7,7 +7,7 @@ MODE = sys.argv[3] if len(sys.argv) > 3 else "minhash"
 G = int(sys.argv[4]) if len(sys.argv) > 4 else 10000
 L = int(sys.argv[5]) if len(sys.argv) > 5 else 5_000_000
 K, S = 21, 1000
-want = ("synth_kernel", "sketch_minhash_kernel", "sketch_kssd_kernel", "transpose_slices_kernel", "pair_tiled_kernel")
+want = ("synth_kernel", "sketch_minhash_kernel", "sketch_kssd", "transpose_slices_kernel", "pair_tiled_kernel")
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
 for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
@@ -46,7 +46,7 @@ for name in want:
         k["hbm_bytes_per_launch"] = rd + wr
     elif "FETCH_SIZE_per_launch" in k and "WRITE_SIZE_per_launch" in k:
         k["hbm_bytes_per_launch"] = (2.0 * k["FETCH_SIZE_per_launch"] + k["WRITE_SIZE_per_launch"]) * 1024.0
-    if name in ("sketch_minhash_kernel", "sketch_kssd_kernel") and "SQ_INSTS_VALU_per_launch" in k:
+    if name in ("sketch_minhash_kernel", "sketch_kssd") and "SQ_INSTS_VALU_per_launch" in k:
         steps = G * L / 64.0
         k["derived"] = {
             "kmer_wave_steps": steps,
