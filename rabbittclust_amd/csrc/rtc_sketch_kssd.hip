@@ -1001,6 +1001,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
     P.xs = xs_abs >= 32 ? xs_abs - 32 : xs_abs;
     // K = 22 (xs_abs == 30) with the var-1 buckets: the 22-bit test on the high word (XMODE 3, table variant 2)
     const bool approx = xs_abs == 30 && kc.bvar == 1 && !getenv("RTC_KSSD_EXACT_FILTER");
+    if (getenv("RTC_VERBOSE")) fprintf(stderr, "[kssd] bucket index (bits %d, %s), K=%d, %zu segments\n", kc.bvar, approx ? "22-bit steady test" : "exact steady test", K, segs.size());
     const size_t tb = approx ? 2 * (size_t)BUCKET_BYTES : 0;
     const uint32_t* d_bk = (const uint32_t*)((const char*)kc.d_bucket + tb);
     const uint16_t* d_rk = (const uint16_t*)((const char*)kc.d_bucket + tb + BUCKET_BYTES);
@@ -1029,6 +1030,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
                        d_t1, d_t2, (const int32_t*)kc.d_table, d_out, stride, d_cnt);                               \
   } while (0)
 #define LAUNCH_KSSD(IX) do { if (K <= 25) LAUNCH_KSSD2(IX, 18, 6); else LAUNCH_KSSD2(IX, 19, 9); } while (0)
+    if (getenv("RTC_VERBOSE")) fprintf(stderr, "[kssd] %s index, K=%d, %zu segments\n", lds_index ? "cuckoo" : "HBM table", K, segs.size());
     if (lds_index) LAUNCH_KSSD(IDX_CUCKOO); else LAUNCH_KSSD(IDX_HBM);
 #undef LAUNCH_KSSD2
 #undef LAUNCH_KSSD

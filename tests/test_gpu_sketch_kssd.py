@@ -103,6 +103,41 @@ def test_kssd_big_row_with_heavy_duplication(ctx, oracle):
     assert np.array_equal(sk.to_host()[0], want)
 
 
+@pytest.mark.parametrize("k", [21, 19, 17, 27])
+def test_kssd_full_queue_contigs_and_edges(ctx, oracle, k):
+    """The steady-state walk's exits: (1) a shuffle table that keeps the dimension of the poly-A k-mer, so a
+    poly-A stretch makes every lane a candidate at every position (the per-wave queue overflows, the group is
+    forgotten and walked base by base with drains in between); (2) contigs separated by single characters
+    outside ACGTacgt every few hundred bases; (3) genomes shorter than a tile, a wave's run, a k-mer."""
+    rng = np.random.default_rng(100 + k)
+    p = oracle.kssd_params(k, 3)
+    sd = oracle.kssd_shuffle_dim(p.half_subk).copy()
+    j = int(np.nonzero(sd == 7)[0][0])
+    sd[0], sd[j] = sd[j], sd[0]  # dim_id 0 (AAAA...A / TTTT...T) is kept with rank 7
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def rnd(n):
+        return rng.choice(acgt, size=n)
+    g0 = np.concatenate([rnd(150_000), np.full(30_000, ord("A"), np.uint8), rnd(50_000), np.full(9_000, ord("t"), np.uint8),
+                         rnd(120_001)])
+    g1 = rnd(400_000)
+    cuts = np.sort(rng.choice(len(g1), size=900, replace=False))
+    g1[cuts] = rng.choice(np.frombuffer(b"N>\n-", dtype=np.uint8), size=len(cuts))
+    low = rng.random(len(g1)) < 0.3
+    g1[low & (g1 > 64)] |= 0x20
+    parts = [g0, g1, rnd(36_864 * 2), rnd(4_607), rnd(73), rnd(k), rnd(k - 2), np.zeros(0, np.uint8), rnd(250_000)]
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in parts])
+    seq = np.concatenate(parts)
+    sk = ctx.sketch_kssd(ctx.upload_sequences(seq), off, sd, kmer_size=k, drlevel=3)
+    ctx.sync()
+    got = sk.to_host()
+    want = oracle.sketch_kssd_batch(seq, off, sd, kmer_size=k, drlevel=3, threads=4)
+    for g in range(len(parts)):
+        assert np.array_equal(got[g], want[g]), f"genome {g} k={k}: got {len(got[g])} want {len(want[g])}"
+    assert len(got[0]) > 50
+
+
 @pytest.mark.skip(reason="covered by the CPU suite")
 def test_kssd_shuffle_table_fixture(oracle):
     """The 4096 surviving (dim_id, rank) pairs of generate_shuffle_dim(6) pin glibc rand()."""
