@@ -30,14 +30,19 @@
 
 namespace {
 
-constexpr int TW = 1024;                // lanes per workgroup = columns per block
+#ifndef RTC_PAIR_TW
+#define RTC_PAIR_TW 1024
+#endif
+constexpr int TW = RTC_PAIR_TW;         // lanes per workgroup = columns per block (1024 or 512)
 constexpr int ROWS = 64;                // rows per block = mask width
-constexpr int SLOTS = 8192;             // table slots
+constexpr int SLOTS = 8 * TW;           // table slots
 constexpr int BUCKET = 4;               // keys per bucket
-constexpr int NB = SLOTS / BUCKET;      // 2048 buckets
-constexpr int LOG2NB = 11;
-constexpr uint32_t KCAP_HARD = 5632;    // max keys per table build (~69 % load)
-constexpr uint32_t KTARGET = 2048;      // planned mean keys per table (25 % load)
+constexpr int NB = SLOTS / BUCKET;      // buckets
+constexpr int LOG2NB = TW == 1024 ? 11 : 10;
+constexpr uint32_t KCAP_HARD = SLOTS / 16 * 11;  // max keys per table build (~69 % load)
+constexpr uint32_t KTARGET = SLOTS / 4;          // planned mean keys per table (25 % load)
+constexpr int RPW = ROWS / (TW / 64);   // rows a wave builds at once
+constexpr int LPR = 64 / RPW;           // lanes per row in the build
 constexpr int MAXP = 512;
 
 template <typename T> struct KeyTraits;
@@ -78,8 +83,14 @@ __device__ __forceinline__ unsigned long long lds_cas(unsigned long long* p, uns
 }
 __device__ __forceinline__ uint32_t lds_cas(uint32_t* p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
 
+// Beside the keys, a bucket keeps four 15-bit fingerprints (low key bits) in 8 bytes and, in bit 31 of the
+// second word, an "overflowed" flag set by an insert that had to move past the full bucket: the probe's
+// straight line reads only those 8 bytes (one ds_read_b64) and goes to the keys when a fingerprint matches
+// or the bucket overflowed.
+template <typename T> __device__ __forceinline__ uint32_t fingerprint(T key) { return (uint32_t)key & 0x7fffu; }
+
 template <typename T>
-__device__ __forceinline__ void table_insert(T* keys, unsigned long long* masks, TileShared* sh, T key, int r) {
+__device__ __forceinline__ void table_insert(T* keys, unsigned long long* masks, uint32_t* fps, TileShared* sh, T key, int r) {
   const unsigned long long bit = 1ULL << r;
   if (key == KeyTraits<T>::EMPTY) { atomicOr(&sh->special, bit); return; }
   uint32_t b = KeyTraits<T>::bucket(key);
@@ -90,8 +101,13 @@ __device__ __forceinline__ void table_insert(T* keys, unsigned long long* masks,
       T old;
       if constexpr (sizeof(T) == 8) old = (T)lds_cas((unsigned long long*)&keys[slot], (unsigned long long)KeyTraits<T>::EMPTY, (unsigned long long)key);
       else old = (T)lds_cas((uint32_t*)&keys[slot], (uint32_t)KeyTraits<T>::EMPTY, (uint32_t)key);
-      if (old == KeyTraits<T>::EMPTY || old == key) { atomicOr(&masks[slot], bit); return; }
+      if (old == KeyTraits<T>::EMPTY || old == key) {
+        atomicOr(&masks[slot], bit);
+        if (old == KeyTraits<T>::EMPTY) atomicOr(&fps[b * 2 + (j >> 1)], fingerprint(key) << (16 * (j & 1)));
+        return;
+      }
     }
+    atomicOr(&fps[b * 2 + 1], 0x80000000u);  // overflowed
     b = (b + 1) & (NB - 1);
   }
 }
@@ -131,56 +147,11 @@ __device__ __forceinline__ unsigned long long table_lookup(const uint32_t* keys,
   }
 }
 
-// First-bucket probe of four keys at once: all bucket reads are issued before any compare.
-// hit[j]: key j found, slot[j] its slot; slow[j]: undecided by the home bucket (bucket full without a
-// match, or the key is the EMPTY marker itself) -> the caller falls back to table_lookup.
-template <typename T>
-__device__ __forceinline__ void home_bucket_probe4(const T* keys, const T (&bq)[4], uint32_t e, uint32_t mylen,
-                                                   uint32_t (&slot)[4], bool (&hit)[4], bool (&slow)[4]) {
-  uint32_t b[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) b[j] = KeyTraits<T>::bucket(bq[j]) * BUCKET;
-  if constexpr (sizeof(T) == 8) {
-    ulonglong2 k01[4], k23[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      k01[j] = *reinterpret_cast<const ulonglong2*>(&keys[b[j]]);
-      k23[j] = *reinterpret_cast<const ulonglong2*>(&keys[b[j] + 2]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const bool valid = e + j < mylen;
-      const T key = bq[j];
-      const bool h0 = k01[j].x == key, h1 = k01[j].y == key, h2 = k23[j].x == key, h3 = k23[j].y == key;
-      const bool anyempty = k01[j].x == ~0ULL || k01[j].y == ~0ULL || k23[j].x == ~0ULL || k23[j].y == ~0ULL;
-      const bool marker = key == KeyTraits<T>::EMPTY;
-      hit[j] = valid && !marker && (h0 | h1 | h2 | h3);
-      slot[j] = b[j] + (h1 ? 1u : 0u) + (h2 ? 2u : 0u) + (h3 ? 3u : 0u);
-      slow[j] = valid && (marker || (!(h0 | h1 | h2 | h3) && !anyempty));
-    }
-  } else {
-    uint4 kk[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) kk[j] = *reinterpret_cast<const uint4*>(&keys[b[j]]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const bool valid = e + j < mylen;
-      const T key = bq[j];
-      const bool h0 = kk[j].x == key, h1 = kk[j].y == key, h2 = kk[j].z == key, h3 = kk[j].w == key;
-      const bool anyempty = kk[j].x == ~0u || kk[j].y == ~0u || kk[j].z == ~0u || kk[j].w == ~0u;
-      const bool marker = key == KeyTraits<T>::EMPTY;
-      hit[j] = valid && !marker && (h0 | h1 | h2 | h3);
-      slot[j] = b[j] + (h1 ? 1u : 0u) + (h2 ? 2u : 0u) + (h3 ? 3u : 0u);
-      slow[j] = valid && (marker || (!(h0 | h1 | h2 | h3) && !anyempty));
-    }
-  }
-}
-
 // so: [(P+1)][n] slice offsets (so[p][g] = lower_bound(sketch g, bound[p])), so[0]=0, so[P]=len.
 // tcols covers the column range [tc0, tc0 + tnc): element e of column c's slice in partition p sits at
 // tcols[tbase[p] + e*tnc + (c - tc0)].
 template <typename T, int NPL, int EMIT>
-__global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ hashes,
+__global__ __launch_bounds__(TW, TW == 1024 ? 1 : 2) void pair_tiled_kernel(const T* __restrict__ hashes,
                                                         const uint64_t* __restrict__ start,
                                                         const T* __restrict__ tcols,          // transposed column slices
                                                         const uint64_t* __restrict__ tbase,   // [P] element offsets
@@ -192,7 +163,8 @@ __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ ha
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* keys = reinterpret_cast<T*>(smem);
   unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem + (size_t)SLOTS * sizeof(T));
-  TileShared* sh = reinterpret_cast<TileShared*>(smem + (size_t)SLOTS * (sizeof(T) + 8));
+  uint32_t* fps = reinterpret_cast<uint32_t*>(smem + (size_t)SLOTS * (sizeof(T) + 8));  // [NB][2]
+  TileShared* sh = reinterpret_cast<TileShared*>(smem + (size_t)SLOTS * (sizeof(T) + 8 + 2));
 
   const int tid = threadIdx.x;
   // Row blocks vary fastest in the grid: the workgroups running at the same time (round-robin over
@@ -212,15 +184,24 @@ __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ ha
 
   uint32_t clo = col_active ? so[c] : 0;  // so[0][c]
   if (tid < ROWS) sh->rstart[tid] = tid < (int)nrows ? start[rb0 + tid] : 0;
+  // Every global load a partition needs is requested one partition (or one phase) ahead: the column's next
+  // slice end, the rows' slice bounds (lanes 0..63), the first four probe keys (before the table is built).
+  const bool rowlane = tid < (int)nrows;
+  uint32_t chi_n = col_active ? so[(size_t)n + c] : 0;
+  uint32_t rlo_n = rowlane ? so[rb0 + tid] : 0, rhi_n = rowlane ? so[(size_t)n + rb0 + tid] : 0;
 
   for (int p = 0; p < P; p++) {
-    const uint32_t chi = col_active ? so[(size_t)(p + 1) * n + c] : 0;
+    const uint32_t chi = chi_n;
+    const T* tp = tcols + tbase[p] + (c - tc0);
+    T nq[4], nq2[4];  // rows past the slice's end hold other data (the copy is padded by eight rows): masked by `rem`
+#pragma unroll
+    for (int j = 0; j < 4; j++) nq[j] = col_active ? tp[(size_t)j * tnc] : (T)0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) nq2[j] = col_active ? tp[(size_t)(4 + j) * tnc] : (T)0;
+    if (p + 1 < P) chi_n = col_active ? so[(size_t)(p + 2) * n + c] : 0;
     __syncthreads();  // previous partition's probes are done (table and rlo/rhi reusable)
-    if (tid < ROWS) {
-      const bool rv = tid < (int)nrows;
-      sh->rlo[tid] = rv ? so[(size_t)p * n + rb0 + tid] : 0;
-      sh->rhi[tid] = rv ? so[(size_t)(p + 1) * n + rb0 + tid] : 0;
-    }
+    if (tid < ROWS) { sh->rlo[tid] = rlo_n; sh->rhi[tid] = rhi_n; }
+    if (p + 1 < P) { rlo_n = rhi_n; rhi_n = rowlane ? so[(size_t)(p + 2) * n + rb0 + tid] : 0; }
     __syncthreads();
     if (wave == 0) {  // split the row block only if its keys would overflow one table (rare)
       uint32_t sz = (lane < nrows) ? sh->rhi[lane] - sh->rlo[lane] : 0;
@@ -248,16 +229,25 @@ __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ ha
       {
         uint4* kq = reinterpret_cast<uint4*>(keys);
         for (int i = tid; i < (int)(SLOTS * sizeof(T) / 16); i += TW) kq[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-        uint4* mq = reinterpret_cast<uint4*>(masks);
-        for (int i = tid; i < SLOTS * 8 / 16; i += TW) mq[i] = make_uint4(0u, 0u, 0u, 0u);
+        uint4* mq = reinterpret_cast<uint4*>(masks);  // masks and fingerprints are adjacent
+        for (int i = tid; i < SLOTS * (8 + 2) / 16; i += TW) mq[i] = make_uint4(0u, 0u, 0u, 0u);
         if (tid == 0) sh->special = 0ULL;
       }
       __syncthreads();
-      // ---- build: wave w inserts rows ra+w, ra+w+16, ... ----
-      for (uint32_t r = ra + wave; r < rbnd; r += TW / 64) {
-        const T* rp = hashes + sh->rstart[r];
-        const uint32_t hi = sh->rhi[r];
-        for (uint32_t e = sh->rlo[r] + lane; e < hi; e += 64) table_insert<T>(keys, masks, sh, rp[e], (int)r);
+      // ---- build: LPR lanes per row, all (<= 64) rows at once, four loads in flight per lane ----
+      {
+        const uint32_t r = ra + wave * RPW + lane / LPR;
+        if (r < rbnd) {
+          const T* rp = hashes + sh->rstart[r];
+          const uint32_t hi = sh->rhi[r];
+          for (uint32_t e = sh->rlo[r] + (lane % LPR); e < hi; e += 4 * LPR) {
+            T kq[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) kq[j] = (e + LPR * j < hi) ? rp[e + LPR * j] : (T)0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (e + LPR * j < hi) table_insert<T>(keys, masks, fps, sh, kq[j], (int)r);
+          }
+        }
       }
       __syncthreads();
       // ---- probe: this lane's column slice, read coalesced from the transposed copy ----
@@ -266,40 +256,52 @@ __global__ __launch_bounds__(TW) void pair_tiled_kernel(const T* __restrict__ ha
       // the row masks are fetched only by waves in which some lane hit, and the rare key whose home
       // bucket is full without a match (or that equals the EMPTY marker) takes the looping lookup.
       {
-        const T* tp = tcols + tbase[p] + (c - tc0);
         const uint32_t mylen = chi - clo;
-        T nq[4];
+        if (sb > 0) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) nq[j] = (j < (int)mylen) ? tp[(size_t)j * tnc] : (T)0;
+          for (int j = 0; j < 4; j++) nq[j] = col_active ? tp[(size_t)j * tnc] : (T)0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) nq2[j] = col_active ? tp[(size_t)(4 + j) * tnc] : (T)0;
+        }
         for (uint32_t e = 0; e < mylen; e += 4) {
-          T bq[4];
+          T bq[4];  // two trips of keys are in flight: the walk is short, the memory far
 #pragma unroll
-          for (int j = 0; j < 4; j++) bq[j] = nq[j];
+          for (int j = 0; j < 4; j++) { bq[j] = nq[j]; nq[j] = nq2[j]; }
 #pragma unroll
-          for (int j = 0; j < 4; j++) nq[j] = (e + 4 + j < mylen) ? tp[(size_t)(e + 4 + j) * tnc] : (T)0;
-          uint32_t slot[4];
-          bool hit[4], slow[4];
-          home_bucket_probe4<T>(keys, bq, e, mylen, slot, hit, slow);
-          unsigned long long mq[4] = {0ULL, 0ULL, 0ULL, 0ULL};
-          if (__any(hit[0] | hit[1] | hit[2] | hit[3])) {
+          for (int j = 0; j < 4; j++) nq2[j] = (e + 8 + j < mylen) ? tp[(size_t)(e + 8 + j) * tnc] : (T)0;
+          // Fingerprint words of the four home buckets, read back to back; per key four 16-bit compares and
+          // the overflow bit, all as wave masks.  A lane whose fingerprint matches (its key may be in the
+          // home bucket) or whose bucket overflowed (it may sit further on) takes the looping lookup on the
+          // keys below -- a few waves of the column block whose family lies in this row block, and the ~0.4 %
+          // of the buckets that overflow; the others never leave this straight line.
+          const uint32_t rem = mylen - e;
+          uint64_t todo[4];
+          uint2 fw[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) if (hit[j]) mq[j] = masks[slot[j]];
+          for (int j = 0; j < 4; j++) fw[j] = *reinterpret_cast<const uint2*>(&fps[KeyTraits<T>::bucket(bq[j]) * 2]);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const uint32_t q = fingerprint(bq[j]);
+            const uint64_t m = __ballot((fw[j].x & 0xffffu) == q) | __ballot((fw[j].x >> 16) == q) |
+                               __ballot((fw[j].y & 0xffffu) == q) | __ballot(((fw[j].y >> 16) & 0x7fffu) == q);
+            todo[j] = (m | __ballot((int32_t)fw[j].y < 0)) & __ballot(rem > (uint32_t)j);
           }
-          if (__any(slow[0] | slow[1] | slow[2] | slow[3])) {
+          if (p == P - 1) {  // the EMPTY marker as a key (only the largest value of the last partition): sh->special
 #pragma unroll
-            for (int j = 0; j < 4; j++) if (slow[j]) mq[j] = table_lookup(keys, masks, sh, bq[j]);
+            for (int j = 0; j < 4; j++) todo[j] |= __ballot(bq[j] == KeyTraits<T>::EMPTY && rem > (uint32_t)j);
           }
-          if (__any((mq[0] | mq[1] | mq[2] | mq[3]) != 0ULL)) {
+          if (!(todo[0] | todo[1] | todo[2] | todo[3])) continue;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-              unsigned long long carry = mq[j];
+          for (int j = 0; j < 4; j++) {
+            if (!todo[j]) continue;  // wave-uniform
+            unsigned long long carry = 0ULL;
+            if (__builtin_amdgcn_inverse_ballot_w64(todo[j])) carry = table_lookup(keys, masks, sh, bq[j]);
 #pragma unroll
-              for (int k = 0; k < NPL; k++) {
-                if (!__any(carry != 0ULL)) break;  // wave-uniform
-                const unsigned long long t = planes[k] & carry;
-                planes[k] ^= carry;
-                carry = t;
-              }
+            for (int k = 0; k < NPL; k++) {
+              if (!__ballot(carry != 0ULL)) break;  // wave-uniform
+              const unsigned long long t = planes[k] & carry;
+              planes[k] ^= carry;
+              carry = t;
             }
           }
         }
@@ -485,7 +487,7 @@ template <typename T, int NPL, int EMIT>
 int launch_tiled(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const PairPlan& pl, uint32_t row0,
                  uint32_t row1, uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld, int lower_only,
                  const EdgeSink& sink) {
-  const size_t lds = (size_t)SLOTS * (sizeof(T) + 8) + sizeof(TileShared);
+  const size_t lds = (size_t)SLOTS * (sizeof(T) + 8 + 2) + sizeof(TileShared);
   auto kern = pair_tiled_kernel<T, NPL, EMIT>;
   RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((row1 - row0 + ROWS - 1) / ROWS, (col1 - col0 + TW - 1) / TW);
@@ -593,7 +595,7 @@ int build_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
     void* ws4 = nullptr;
     const size_t btb = (size_t)P * 8;
     {
-      const int st = rtc_ws(ctx, 4, tbase[P] * sizeof(T) + btb + 256, &ws4);
+      const int st = rtc_ws(ctx, 4, (tbase[P] + 8ull * tnc) * sizeof(T) + btb + 256, &ws4);  // + eight rows: unconditional first probe loads
       if (st == RTC_ERR_NOMEM) return RTC_OK;  // the merge kernel needs no scratch
       if (st != RTC_OK) return st;
     }
