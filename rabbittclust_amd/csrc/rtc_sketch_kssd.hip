@@ -360,7 +360,7 @@ __device__ __forceinline__ bool fast_group(const uint4 cur, const int emit_mask,
 #pragma unroll
   for (int qd = 0; qd < 4; qd++) {
     codes[qd] = ((w[qd] >> 1) ^ (w[qd] >> 2)) & 0x03030303u;  // BaseMap, src/SketchInfo.cpp:1007-1017
-    bad |= __builtin_amdgcn_perm(0u, 0x54474341u, codes[qd]) ^ w[qd];
+    bad = __builtin_amdgcn_bitop3_b32(bad, __builtin_amdgcn_perm(0u, 0x54474341u, codes[qd]), w[qd], 0xF6);  // bad | (perm ^ w)
   }
   if (__ballot((bad & 0xDFDFDFDFu) != 0u)) return false;
   const uint32_t Fhi0 = Fhi, Flo0 = Flo, Rhi0 = Rhi, Rlo0 = Rlo, qn0 = qn;
@@ -958,7 +958,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   // high words are cut (K <= 22)
   const bool use_bucket = kc.bvar >= 0 && K >= 18 && K <= 28;
   uint64_t seg_len = total / ((uint64_t)ctx->num_cu * 12);
-  const uint64_t min_seg = 4ull * (use_bucket ? WGB * 19 * 4 : TILE_BASES_MAX);
+  const uint64_t min_seg = 4ull * (use_bucket ? WGB * 26 * 4 : TILE_BASES_MAX);
   if (seg_len < min_seg) seg_len = min_seg;
   std::vector<KSegment> segs;
   segs.reserve(n + 1024);
@@ -1014,11 +1014,13 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
                        (const KSegment*)ws0, P, d_bk, d_rk, d_out, stride, d_cnt);                                   \
   } while (0)
 #define LAUNCH_BKV(RUN, WARM, XM) do { if (kc.bvar) LAUNCH_BK(RUN, WARM, XM, 1); else LAUNCH_BK(RUN, WARM, XM, 0); } while (0)
+    // lane runs: 104 owned + 24 warm-up bases (K <= 25; measured best of 72 / 88 / 104 / 120: the warm-up is
+    // 6 of 32 dwords instead of 6 of 24 and the kernel is not bandwidth bound), 76 + 36 otherwise
     if (K > 25) LAUNCH_BKV(19, 9, 2);  // K >= 22 always straddles the two words
-    else if (approx) LAUNCH_BK(18, 6, 3, 2);
-    else if (xmode == 0) LAUNCH_BKV(18, 6, 0);
-    else if (xmode == 1) LAUNCH_BKV(18, 6, 1);
-    else LAUNCH_BKV(18, 6, 2);
+    else if (approx) LAUNCH_BK(26, 6, 3, 2);
+    else if (xmode == 0) LAUNCH_BKV(26, 6, 0);
+    else if (xmode == 1) LAUNCH_BKV(26, 6, 1);
+    else LAUNCH_BKV(26, 6, 2);
 #undef LAUNCH_BKV
 #undef LAUNCH_BK
   } else {
