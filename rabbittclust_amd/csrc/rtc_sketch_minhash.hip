@@ -443,6 +443,10 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
   return ((uint64_t)uniform32((uint32_t)(v >> 32)) << 32) | uniform32((uint32_t)v);
 }
 
+#ifndef RTC_EXPRESS
+#define RTC_EXPRESS 1
+#endif
+constexpr bool EXPRESS = RTC_EXPRESS;
 template <int KT>  // KT > 0: k known at compile time (uniform branches fold away); 0: runtime k
 // second launch bound: 6 waves/SIMD = 3 workgroups per CU (caps the allocation at 80 VGPRs)
 __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __restrict__ seq,
@@ -560,8 +564,91 @@ restart:
       uint64_t fwd = 0, rc = 0;
       int run = 0;
       bool clean = true;  // wave-uniform: only valid bases in every lane of this wave so far in this pass
-      uint4 nxt = load_bases16(tile, rq0, gb, ge);
-      for (int grp = 0; grp < (WARM_DW + RUN_DW) / 4; grp++) {
+      int g0 = 0;
+      if constexpr (KT > 16 && KT <= 28 && EXPRESS) {
+        // The steady state without the general walk's per-dword decisions: a wave whose windows lie inside the
+        // genome, in a tile interior to the segment, outside safe mode, with a threshold whose high word
+        // decides (see below), walks whole 16-byte groups -- validity of the group in one vote, the windows,
+        // the hash halves, the high-word test, possible candidates to the queue -- until a group holds a
+        // character outside ACGTacgt or the queue is full; the general walk takes over from that group.
+        constexpr int NG = (WARM_DW + RUN_DW) / 4;
+        const int w0 = (int)uniform32((uint32_t)(t & ~63));
+        const int wlo = OWN * w0 - 4 * WARM_DW, whi = OWN * (w0 + 63) - 4 * WARM_DW + 16 * NG;
+        const uint32_t Thi_e = (uint32_t)(T >> 32);
+        if (!safe_mode && !lo1 && interior && Thi_e != 0xffffffffu && wlo >= gb && whi <= ge) {
+          const uint8_t* base = (tile - LOAD_BIAS) + (uint32_t)(rq0 + LOAD_BIAS);
+          const uint32_t Thi1 = Thi_e + 1u;
+          uint4 cur = *reinterpret_cast<const uint4*>(base), nxt1 = *reinterpret_cast<const uint4*>(base + 16);
+          g0 = NG;
+#pragma unroll
+          for (int g = 0; g < NG; g++) {
+            uint4 nxt2 = cur;
+            if (g + 2 < NG) nxt2 = *reinterpret_cast<const uint4*>(base + 16 * (g + 2));
+            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+            uint32_t codes[4], bad = 0;
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+              codes[qd] = ((w[qd] >> 1) ^ (w[qd] >> 2)) & 0x03030303u;
+              bad = __builtin_amdgcn_bitop3_b32(bad, __builtin_amdgcn_perm(0u, 0x54474341u, codes[qd]), w[qd], 0xF6);  // bad | (perm ^ w)
+            }
+            if (__ballot((bad & 0xDFDFDFDFu) != 0u)) { g0 = g; break; }
+            const uint64_t fwd0 = fwd, rc0 = rc;
+            const uint32_t qn0 = qn;
+            bool lost = false;  // wave-uniform: the queue could not take this group's candidates
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+              const uint32_t pack = __builtin_amdgcn_udot4(codes[qd], 0x01041040u, 0u, false);
+              const uint32_t rp = __builtin_amdgcn_udot4(codes[qd], 0x40100401u, 0u, false) ^ 0xffu;
+              const uint64_t F = (fwd << 8) | pack;
+              const uint64_t R = rc | ((uint64_t)rp << (2 * KT));
+              if (g * 4 + qd >= WARM_DW) {
+                HashParts hp[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                  const uint64_t f = F << (P.lshift - 6 + 2 * b);
+                  const uint64_t r = R << (P.lshift - 2 - 2 * b);
+                  hp[b] = kmer_hash_parts(f < r ? f : r, P);
+                }
+                uint64_t cm = 0, mq[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                  const uint32_t u = (uint32_t)(hp[b].f1 >> 32) + (uint32_t)(hp[b].f2 >> 32) + 1u;
+                  mq[b] = __ballot(u <= Thi1);
+                  cm |= mq[b];
+                }
+                if (cm) {  // wave-uniform, rare
+                  const uint32_t add = (uint32_t)(__popcll(mq[0]) + __popcll(mq[1]) + __popcll(mq[2]) + __popcll(mq[3]));
+                  if (qn + add <= (uint32_t)QCAP) {
+                    uint32_t qb = qn;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                      if (mq[b]) {  // wave-uniform
+                        if (__builtin_amdgcn_inverse_ballot_w64(mq[b])) {
+                          const uint32_t slot = qb + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq[b] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq[b], 0u));
+                          wq[2 * slot] = hp[b].f1;
+                          wq[2 * slot + 1] = hp[b].f2;
+                        }
+                        qb += (uint32_t)__popcll(mq[b]);
+                      }
+                    }
+                    qn = qb;
+                  } else {
+                    lost = true;
+                  }
+                }
+              }
+              fwd = F;
+              rc = R >> 8;
+            }
+            if (lost) { fwd = fwd0; rc = rc0; qn = qn0; g0 = g; break; }
+            cur = nxt1;
+            nxt1 = nxt2;
+          }
+          run = 16 * g0;
+        }
+      }
+      uint4 nxt = g0 < (WARM_DW + RUN_DW) / 4 ? load_bases16(tile, rq0 + 16 * g0, gb, ge) : make_uint4(0u, 0u, 0u, 0u);
+      for (int grp = g0; grp < (WARM_DW + RUN_DW) / 4; grp++) {
         const uint4 cur = nxt;
         if (grp + 1 < (WARM_DW + RUN_DW) / 4) nxt = load_bases16(tile, rq0 + 16 * (grp + 1), gb, ge);
 #ifdef RTC_CANON_NOINIT
