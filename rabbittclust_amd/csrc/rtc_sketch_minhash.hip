@@ -579,6 +579,14 @@ restart:
           const uint8_t* base = (tile - LOAD_BIAS) + (uint32_t)(rq0 + LOAD_BIAS);
           const uint32_t Thi1 = Thi_e + 1u;
           uint4 cur = *reinterpret_cast<const uint4*>(base), nxt1 = *reinterpret_cast<const uint4*>(base + 16);
+          // the reverse-complement extended window is kept shifted left by RE bits so that the byte of a new
+          // dword lands on a byte boundary: one v_perm (high word) + one v_alignbit (low word) roll it
+          constexpr int RE = (8 - (2 * KT) % 8) % 8, NBY = (2 * KT + RE) / 8;
+          constexpr uint32_t RSEL = (uint32_t)(0 == NBY - 4 ? 0x00 : (0 < NBY - 4 ? 5 : 0x0c)) |
+                                    (uint32_t)(1 == NBY - 4 ? 0x00 : (1 < NBY - 4 ? 6 : 0x0c)) << 8 |
+                                    (uint32_t)(2 == NBY - 4 ? 0x00 : (2 < NBY - 4 ? 7 : 0x0c)) << 16 |
+                                    (uint32_t)(3 == NBY - 4 ? 0x00 : 0x0c) << 24;
+          uint32_t Rhi = 0, Rlo = 0;
           g0 = NG;
 #pragma unroll
           for (int g = 0; g < NG; g++) {
@@ -592,21 +600,26 @@ restart:
               bad = __builtin_amdgcn_bitop3_b32(bad, __builtin_amdgcn_perm(0u, 0x54474341u, codes[qd]), w[qd], 0xF6);  // bad | (perm ^ w)
             }
             if (__ballot((bad & 0xDFDFDFDFu) != 0u)) { g0 = g; break; }
-            const uint64_t fwd0 = fwd, rc0 = rc;
-            const uint32_t qn0 = qn;
+            const uint64_t fwd0 = fwd;
+            const uint32_t Rhi0 = Rhi, Rlo0 = Rlo, qn0 = qn;
             bool lost = false;  // wave-uniform: the queue could not take this group's candidates
 #pragma unroll
             for (int qd = 0; qd < 4; qd++) {
               const uint32_t pack = __builtin_amdgcn_udot4(codes[qd], 0x01041040u, 0u, false);
-              const uint32_t rp = __builtin_amdgcn_udot4(codes[qd], 0x40100401u, 0u, false) ^ 0xffu;
+              // reverse-complement byte 255 - (c0 + 4 c1 + 16 c2 + 64 c3) as the LOW BYTE of a dot product with the
+              // weights 256 - {1, 4, 16, 64} on top of 255 (only that byte is used: v_perm picks it)
+              const uint32_t rp = __builtin_amdgcn_udot4(codes[qd], 0xC0F0FCFFu, 255u, false);
               const uint64_t F = (fwd << 8) | pack;
-              const uint64_t R = rc | ((uint64_t)rp << (2 * KT));
+              const uint32_t nhi = __builtin_amdgcn_perm(Rhi, rp, RSEL);
+              Rlo = __builtin_amdgcn_alignbit(Rhi, Rlo, 8);
+              Rhi = nhi;
+              const uint64_t R = ((uint64_t)Rhi << 32) | Rlo;  // = (general walk's R) << RE
               if (g * 4 + qd >= WARM_DW) {
                 HashParts hp[4];
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                   const uint64_t f = F << (P.lshift - 6 + 2 * b);
-                  const uint64_t r = R << (P.lshift - 2 - 2 * b);
+                  const uint64_t r = R << (P.lshift - 2 - 2 * b - RE);
                   hp[b] = kmer_hash_parts(f < r ? f : r, P);
                 }
                 uint64_t cm = 0, mq[4];
@@ -638,12 +651,12 @@ restart:
                 }
               }
               fwd = F;
-              rc = R >> 8;
             }
-            if (lost) { fwd = fwd0; rc = rc0; qn = qn0; g0 = g; break; }
+            if (lost) { fwd = fwd0; Rhi = Rhi0; Rlo = Rlo0; qn = qn0; g0 = g; break; }
             cur = nxt1;
             nxt1 = nxt2;
           }
+          rc = (((uint64_t)Rhi << 32) | Rlo) >> (RE + 8);  // the general walk's form
           run = 16 * g0;
         }
       }
