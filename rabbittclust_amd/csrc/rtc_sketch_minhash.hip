@@ -1007,9 +1007,10 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     // 52 / 78 / 156 KiB: measured on MI355X, a 53.3 KiB allocation no longer runs three workgroups per CU
     const size_t share = ((size_t)156 * 1024 / wgs) & ~(size_t)2047;
     const size_t fixed = lut_bytes(k) + ((sizeof(Ctrl) + 15) & ~(size_t)15) + QUEUE_BYTES;
-    // (round 1 measured ~3000 entries as the break-even against lost occupancy; with the merge sorting only
-    // the new candidates a third workgroup per CU wins down to ~2300)
-    size_t want_room = wgs > wgs_lo ? 2304 : MIN_ROOM;
+    // (round 1 measured ~3000 entries of room as the break-even against lost occupancy; with the merge sorting
+    // only the new candidates and the express walk a third workgroup per CU wins down to the minimum room:
+    // s = 2000 at 10 000 x 5 Mbp 114.5 -> 102.1 ms, the containment sketches of config 4 190 -> 164 ms)
+    size_t want_room = MIN_ROOM;
     if (const char* e = getenv("RTC_SKETCH_WANT_ROOM")) want_room = (size_t)std::max(atoi(e), MIN_ROOM);  // tuning experiments
     if (share > fixed && (share - fixed) / 8 >= (size_t)chunk_max + want_room) { cap = (int)((share - fixed) / 8); wgs_per_cu = wgs; }
   }
