@@ -105,6 +105,27 @@ def test_tiled_u32_sentinel(ctx, oracle):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("width", [8, 4])
+def test_tiled_fingerprint_collisions(ctx, oracle, width):
+    """Every hash shares its low 15 bits (the table's bucket fingerprints are those bits): each probe that
+    finds an occupied home bucket is a fingerprint match, so all decisions fall to the key comparison; the
+    sketches also overlap heavily (ripple of the bit-sliced counters) and fill buckets to overflowing."""
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(23 + width)
+    hi_bits = 48 if width == 8 else 16
+    pool = (np.unique(rng.integers(0, 1 << hi_bits, size=9000, dtype=np.uint64)) << np.uint64(15)) | np.uint64(0x1234)
+    sk = []
+    for g in range(150):
+        size = int(rng.integers(200, 3000))
+        v = np.sort(rng.choice(pool, size=size, replace=False))
+        sk.append(v.astype(np.uint64 if width == 8 else np.uint32))
+    dev = api.SketchSet.from_host(sk, ctx.device, width=width)
+    want = _oracle_matrix(oracle, sk)
+    got = ctx.pair_common(dev, algo=2).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert want[3, 2] > 10
+
+
 def test_tiled_skewed_slices_force_row_subblocks(ctx, oracle):
     """All sketches crowd into a narrow value range except a few outliers that drag the sampled
     quantile boundaries: some (row block, partition) then holds far more keys than one table."""
