@@ -201,16 +201,18 @@ def test_starting_threshold_restart_on_low_complexity(ctx, oracle):
 
 def test_starting_threshold_factor_does_not_change_results(ctx, oracle):
     """RTC_SKETCH_T0_FACTOR = 1 makes about half of the workgroups restart, 0 disables the starting
-    threshold: identical sketches either way (and equal to the oracle on a sample)."""
+    threshold, 40 / 2000 let so many k-mers through that the express walk's per-wave queue fills up (the
+    group is forgotten and the general walk takes over, then safe mode): identical sketches every way
+    (and equal to the oracle on a sample)."""
     import os
     from rabbittclust_amd import api
-    desc = api.synth_family_descs(350, 10, global_seed=9)
-    L = 60_000
+    desc = api.synth_family_descs(120, 10, global_seed=9)
+    L = 230_000  # six tiles: the inner four take the express walk
     off = np.arange(len(desc) + 1, dtype=np.uint64) * L
     seq = ctx.synth_genomes(desc, off)
     ref = ctx.sketch_minhash(seq, off, k=21, size=500)
     ctx.sync()
-    for f in ("1", "0", "3"):
+    for f in ("1", "0", "8", "40", "2000"):
         os.environ["RTC_SKETCH_T0_FACTOR"] = f
         try:
             alt = ctx.sketch_minhash(seq, off, k=21, size=500)
