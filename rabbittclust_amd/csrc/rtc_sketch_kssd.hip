@@ -570,7 +570,7 @@ __global__ __launch_bounds__(WG) void kssd_sort_unique_kernel(OutT* __restrict__
   const uint32_t m = min(cnt[g], stride);
   if (m == 0 || m > (uint32_t)cap) return;  // rows beyond one LDS buffer go through kssd_big_* below
   OutT* row = out + (uint64_t)g * stride;
-  int n2 = 1024;
+  int n2 = 64;  // bitonic network over the next power of two (a 2 Mbp genome at drlevel 3: ~490 tuples -> 512)
   while (n2 < (int)m) n2 <<= 1;
   for (int i = t; i < n2; i += WG) buf[i] = i < (int)m ? row[i] : (OutT)~(OutT)0;
   if (t == 0) scan_base = 0;
