@@ -13,6 +13,7 @@
 // tree writers, --dense, --auto-threshold and single-FASTA mode are outside this path and exit
 // with a message.
 #include <math.h>
+#include <limits>
 #include <omp.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -501,9 +502,7 @@ static Options parse(int argc, char** argv) {
     else if (a == "-o" || a == "--output") { o.outputFile = need(i); o.has_output = true; }
     else if (a == "-i" || a == "--input") { o.inputFile = need(i); o.has_input = true; }
     else if (a == "--presketched") { o.folder_path = need(i); o.has_presketched = true; }
-#ifndef GREEDY_CLUST
     else if (a == "--append") { o.inputFile = need(i); o.has_append = true; }
-#endif
     else if (a == "--fast") o.is_fast = true;
     else if (a == "--drlevel") o.drlevel = atoi(need(i));
     else if (a == "--gpus") o.gpus = need(i);
@@ -529,15 +528,13 @@ static Options parse(int argc, char** argv) {
            "  --presketched DIR  --fast  --drlevel N  --gpus all|N|i,j,.. (default all visible MI355X)"
 #ifndef GREEDY_CLUST
            "  --premsted DIR  --append LIST (with --presketched/--premsted DIR)"
+#else
+           "  --append LIST (with --fast --presketched DIR)"
 #endif
       );
       exit(0);
     }
-    else if (
-#ifdef GREEDY_CLUST
-             a == "--append" ||
-#endif
-             a == "--db" || a == "--build" || a == "--query" || a == "--assign" || a == "--stats" ||
+    else if (a == "--db" || a == "--build" || a == "--query" || a == "--assign" || a == "--stats" ||
              a == "--save-rep" || a == "--top-k" ||
 #ifdef GREEDY_CLUST
              a == "--dense" ||
@@ -670,6 +667,121 @@ static int append_clust_mst(const Options& o, vector<Gpu>& gpus) {
 }
 #endif
 
+#ifdef GREEDY_CLUST
+// append_clust_greedy_fast without a stored cluster state (src/sub_command.cpp, "Initial State Building Mode"):
+// the stored KSSD sketches are clustered as clust-greedy --fast would (KssdInitialClusterWithState =
+// KssdGreedyClusterWithInvertedIndex on the size-sorted sketches, src/greedy.cpp:902-915), then every new genome,
+// in input order, joins the representative at the smallest Mash distance <= threshold among those that share a
+// hash with it and pass the size-ratio and minimum-common filters, or becomes a representative itself
+// (KssdIncrementalCluster, src/greedy.cpp:1736-1900).  The GPU supplies |A ∩ B| of each new genome against
+// everything before it; the rule runs on the host.  Ties in distance go to the earliest representative (the
+// reference's choice depends on hash-map iteration and thread order).
+static int append_clust_greedy_fast(const Options& o, vector<Gpu>& gpus) {
+  rtc_ctx* ctx = gpus[0].ctx;
+  vector<GenomeInfo> pre; KssdSketchFile ks; bool byFile = true;
+  double t0 = get_sec();
+  if (!load_kssd_sketches(o.folder_path, pre, ks, byFile)) return 1;
+  if (byFile != o.sketchByFile) cerr << "Warning: the input format of append genomes and pre-sketched genome is not same" << endl;
+  if (!o.sketchByFile) unsupported("single-FASTA input (run with -l and a genome list)");
+  const int kmer_size = ks.info.half_k * 2;
+  cerr << "===== Initial State Building Mode (KSSD) =====" << endl;
+  cerr << "No existing state found, building state from pre-sketched genomes..." << endl;
+  cerr << "-----use the same sketch parameters with pre-generated sketches" << endl << "---use the KSSD sketches" << endl
+       << "---the half_k is: " << ks.info.half_k << endl << "---the half_subk is: " << ks.info.half_subk << endl
+       << "---the drlevel is: " << ks.info.drlevel << endl << "---the threshold is: " << o.threshold << endl;
+  SketchJob job;
+  job.kssd = true; job.kmerSize = kmer_size; job.drlevel = ks.info.drlevel; job.minLen = o.minLen; job.threads = o.threads;
+  vector<GenomeInfo> add; MinHashSketchFile mh2; KssdSketchFile ks2; Resident rs2;
+  sketch_files(gpus, o.inputFile, job, add, &mh2, &ks2, rs2, true);
+  if (ks2.use64 != ks.use64) { cerr << "ERROR: appended sketches and stored sketches differ in hash width" << endl; return 1; }
+  cerr << "========time of computing sketch is: " << get_sec() - t0 << "========" << endl;
+  if (!o.noSave) {  // compute_kssd_sketches(isSave): the appended sketches get a folder of their own
+    const string folder = current_date_time();
+    string command = "mkdir -p " + folder;
+    if (system(command.c_str()) != 0) { cerr << "ERROR: cannot create " << folder << endl; return 1; }
+    save_kssd_sketches(add, ks2, folder, true);
+  }
+  double t2 = get_sec();
+  // src/greedy.cpp:594-597: the stored sketches sorted by hash count, descending (comparator without tie-break)
+  const size_t n_pre = pre.size(), n_all = n_pre + add.size();
+  auto cnt_pre = [&](size_t i) { return ks.use64 ? ks.h64[i].size() : ks.h32[i].size(); };
+  struct Item { size_t idx; size_t c; };
+  vector<Item> items(n_pre);
+  for (size_t i = 0; i < n_pre; i++) items[i] = Item{i, cnt_pre(i)};
+  std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.c > b.c; });
+  vector<GenomeInfo> genomes; KssdSketchFile all; all.info = ks.info; all.use64 = ks.use64;
+  for (const Item& it : items) {
+    genomes.push_back(pre[it.idx]);
+    if (ks.use64) all.h64.push_back(std::move(ks.h64[it.idx])); else all.h32.push_back(std::move(ks.h32[it.idx]));
+  }
+  for (size_t i = 0; i < add.size(); i++) {
+    genomes.push_back(add[i]);
+    if (ks.use64) all.h64.push_back(std::move(ks2.h64[i])); else all.h32.push_back(std::move(ks2.h32[i]));
+  }
+  for (size_t i = 0; i < genomes.size(); i++) genomes[i].id = (int)i;
+  vector<uint32_t> len(n_all);
+  for (size_t i = 0; i < n_all; i++) len[i] = (uint32_t)(all.use64 ? all.h64[i].size() : all.h32[i].size());
+  DeviceSketches ds;
+  upload_sketches(ctx, all.use64 ? &all.h64 : nullptr, all.use64 ? nullptr : &all.h32, ds);
+  vector<int32_t> rep_of(n_all, -1);
+  uint32_t ncl = 0;
+  if (n_pre) CHECK(ctx, rtc_greedy(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, (uint32_t)n_pre, nullptr, kmer_size, 0, 1, o.threshold,
+                                   rep_of.data(), &ncl));
+  vector<vector<int>> cluster;
+  {
+    vector<int32_t> pre_rep(rep_of.begin(), rep_of.begin() + n_pre);
+    cluster = clusters_from_rep_of(pre_rep);
+  }
+  vector<int> cid(n_all, -1);  // cluster index of a representative
+  for (size_t c = 0; c < cluster.size(); c++) cid[cluster[c][0]] = (int)c;
+  cerr << "Existing clusters: " << cluster.size() << endl << "New genomes: " << add.size() << endl;
+  // ---- incremental part ----
+  const double radio = 2.0 * exp(o.threshold * kmer_size) - 1.0;                 // calculateMaxSizeRatio, src/greedy.cpp:162-173
+  const double x = exp(-o.threshold * kmer_size), jaccard_min = x / (2.0 - x);   // :1751-1753
+  const size_t max_block_bytes = (size_t)256 << 20;
+  size_t B = std::max<size_t>(1, std::min<size_t>(add.size(), max_block_bytes / (n_all * 4)));
+  uint32_t* d_common = nullptr;
+  if (!add.empty()) CHECK(ctx, rtc_dev_alloc(ctx, B * n_all * 4 + 64, (void**)&d_common));
+  vector<uint32_t> common(B * n_all);
+  int new_clusters = 0, assigned = 0;
+  for (size_t r0 = n_pre; r0 < n_all; r0 += B) {
+    const size_t r1 = std::min(n_all, r0 + B);
+    CHECK(ctx, rtc_pair_common_dev(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, (uint32_t)n_all, (uint32_t)r0, (uint32_t)r1, 0,
+                                   (uint32_t)n_all, d_common, (uint64_t)n_all, 1, 0));
+    CHECK(ctx, rtc_copy_d2h(ctx, common.data(), d_common, (r1 - r0) * n_all * 4));
+    for (size_t q = r0; q < r1; q++) {
+      const uint32_t* row = common.data() + (q - r0) * n_all;
+      const int sizeQry = (int)len[q];
+      double best_dist = std::numeric_limits<double>::max();
+      int best = -1;
+      for (size_t r = 0; r < q; r++) {
+        if (cid[r] < 0 || row[r] == 0) continue;  // candidates: representatives sharing a hash (:1768-1790)
+        const int sizeRef = (int)len[r], cm = (int)row[r];
+        const double ratio = (double)sizeQry / sizeRef;
+        if (ratio > radio || ratio < 1.0 / radio) continue;                                              // :1822-1825
+        const int min_common_needed = (int)(jaccard_min * (sizeQry + sizeRef) / (1.0 + jaccard_min));    // :1829
+        if (cm < min_common_needed) continue;
+        const uint64_t uni = (uint64_t)sizeRef + (uint64_t)sizeQry - (uint64_t)cm;                       // calculate_mash_distance, :103-160
+        const double jac = uni == 0 ? 0.0 : (double)cm / (double)uni;
+        double dist = 0.0;
+        if (jac != 1.0) { dist = -log(2 * jac / (1.0 + jac)) / (double)kmer_size; if (dist > 1.0) dist = 1.0; }
+        if (dist <= o.threshold && dist < best_dist) { best_dist = dist; best = (int)r; }
+      }
+      if (best >= 0) { cluster[cid[best]].push_back((int)q); assigned++; }
+      else { cid[q] = (int)cluster.size(); cluster.push_back({(int)q}); new_clusters++; }
+    }
+  }
+  if (d_common) CHECK(ctx, rtc_dev_free(ctx, d_common));
+  cerr << "===== Incremental Clustering Results =====" << endl << "Assigned to existing clusters: " << assigned << endl
+       << "New clusters created: " << new_clusters << endl << "Total clusters now: " << cluster.size() << endl;
+  print_result(cluster, genomes, byFile, o.outputFile);
+  cerr << "-----write the cluster result into: " << o.outputFile << endl;
+  cerr << "-----the cluster number of " << o.outputFile << " is: " << cluster.size() << endl;
+  cerr << "========time of greedyCluster is: " << get_sec() - t2 << "========" << endl;
+  return 0;
+}
+#endif
+
 int main(int argc, char** argv) {
   Options o = parse(argc, argv);
   if (!o.has_output) { cerr << "ERROR: option -o/--output is required (unless --buildDB or --stats is used)" << endl; return 1; }
@@ -677,6 +789,10 @@ int main(int argc, char** argv) {
   fprintf(stderr, "-----set the thread number %d\n", o.threads);
   if (!o.has_threshold) { o.threshold = 0.05; cerr << "-----use default threshold: " << o.threshold << endl; }
 
+#ifdef GREEDY_CLUST
+  if (o.has_append && o.has_input) { cerr << "ERROR: --append and -i/--input exclude each other" << endl; return 1; }
+  if (o.has_append && !o.has_presketched) { cerr << "ERROR option --append, option --presketched needed" << endl; return 1; }  // src/main.cpp:378-381
+#endif
 #ifndef GREEDY_CLUST
   // ---- --premsted: no sketching, no GPU (clust_from_mst[_fast], src/sub_command.cpp:1760-1934) ----
   if (o.has_append && o.has_input) { cerr << "ERROR: --append and -i/--input exclude each other" << endl; return 1; }
@@ -731,6 +847,14 @@ int main(int argc, char** argv) {
   Resident rs;
 #ifndef GREEDY_CLUST
   if (o.has_append) return append_clust_mst(o, gpus);
+#else
+  if (o.has_append) {  // src/main.cpp:378-387
+    if (!o.is_fast) unsupported("clust-greedy --append on MinHash sketches (Sketch::MinHash::distance() of the absent RabbitSketch decides there); --fast");
+    const int rc = append_clust_greedy_fast(o, gpus);
+    for (Gpu& g : gpus) { if (g.comm) rtc_comm_destroy(g.comm); }
+    for (Gpu& g : gpus) rtc_ctx_destroy(g.ctx);
+    return rc;
+  }
 #endif
 
   vector<GenomeInfo> genomes;

@@ -227,6 +227,82 @@ def test_clust_greedy_fast_and_presketched(oracle, tmp_path):
     assert got == [[r] + [m for m in ms if m != r] for r, ms in sorted(want.items())]
 
 
+def test_clust_greedy_fast_append(oracle, tmp_path):
+    """clust-greedy --fast --presketched DIR --append LIST without a stored cluster state
+    (append_clust_greedy_fast, "Initial State Building Mode"): the stored sketches are clustered as
+    clust-greedy --fast clusters them (size-sorted), then every new genome in input order joins the nearest
+    representative that passes KssdIncrementalCluster's filters (src/greedy.cpp:1736-1900) or opens a cluster.
+    Checked against a Python restatement on the oracle's KSSD sketches."""
+    import math
+    tmp = str(tmp_path)
+    L = 2_000_000  # (shorter genomes make tune_parameters replace -k 21, src/sub_command.cpp:2414-2430)
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 4, 4, L, seed=34)
+    perm = [0, 5, 10, 1, 4, 8, 9, 2, 3, 6, 7, 13, 11, 12, 14, 15]  # family 3 arrives with the appended genomes only
+    first, second = perm[:7], perm[7:]
+    la, lb = os.path.join(tmp, "a.txt"), os.path.join(tmp, "b.txt")
+    open(la, "w").write("\n".join(paths[i] for i in first) + "\n")
+    open(lb, "w").write("\n".join(paths[i] for i in second) + "\n")
+    da = os.path.join(tmp, "a"); os.makedirs(da)
+    _run([os.path.join(BIN, "clust-greedy"), "--fast", "-l", "-i", la, "-k", "21", "-d", "0.05", "-t", "4", "-o", os.path.join(da, "a.out")], da)
+    folder = [os.path.join(da, d) for d in os.listdir(da) if os.path.isdir(os.path.join(da, d))][0]
+    out = os.path.join(tmp, "ab.out")
+    err = _run([os.path.join(BIN, "clust-greedy"), "--fast", "-l", "--presketched", folder, "--append", lb, "-d", "0.05", "-t", "4", "-e",
+                "-o", out], tmp)
+    assert "Initial State Building Mode (KSSD)" in err and "---the half_k is: 11" in err
+    # ---- restatement ----
+    ks = {i: oracle.kssd_sketch(seqs[i], 21, 3) for i in perm}
+    pre = sorted(first, key=lambda i: -len(ks[i]))
+    assert len({len(ks[i]) for i in pre}) == len(pre), "test data must not tie on sketch size (unstable sort order)"
+    order = pre + second
+    flat, start, lens = oracle.to_csr([ks[i] for i in pre], dtype=np.uint32)
+    ncl, rep = oracle.greedy_kssd(flat, start, lens, 22, 0.05)
+    clusters, cid = [], {}
+    for pos, r in enumerate(rep):
+        if int(r) == pos:
+            cid[pos] = len(clusters); clusters.append([pos])
+    for pos, r in enumerate(rep):
+        if int(r) != pos:
+            clusters[cid[int(r)]].append(pos)
+    kmer, thr = 22, 0.05
+    radio = 2.0 * math.exp(thr * kmer) - 1.0
+    x = math.exp(-thr * kmer); jmin = x / (2.0 - x)
+    sets = [set(ks[i].tolist()) for i in order]
+    for q in range(len(pre), len(order)):
+        best, best_d = -1, float("inf")
+        for r in sorted(cid):
+            cm = len(sets[q] & sets[r])
+            if cm == 0:
+                continue
+            sq, sr = len(sets[q]), len(sets[r])
+            ratio = sq / sr
+            if ratio > radio or ratio < 1.0 / radio:
+                continue
+            if cm < int(jmin * (sq + sr) / (1.0 + jmin)):
+                continue
+            jac = cm / (sq + sr - cm)
+            d = 0.0 if jac == 1.0 else min(1.0, -math.log(2 * jac / (1.0 + jac)) / kmer)
+            if d <= thr and d < best_d:
+                best, best_d = r, d
+        if best >= 0:
+            clusters[cid[best]].append(q)
+        else:
+            cid[q] = len(clusters); clusters.append([q])
+    got = _parse_clusters(out)
+    assert got == clusters
+    assert len(clusters) < 16 and any(c[0] >= len(pre) for c in clusters)  # the appended list opened a cluster of its own
+    names = {}
+    for ln in open(out):
+        if ln.startswith("\t"):
+            f = ln.rstrip("\n").split("\t")
+            names[int(f[2])] = f[4].strip()
+    assert [names[i] for i in range(len(order))] == [paths[i] for i in order]
+    # usage errors (src/main.cpp:378-381) and the MinHash flow, which is not offered
+    r = subprocess.run([os.path.join(BIN, "clust-greedy"), "--fast", "-l", "--append", lb, "-o", out], capture_output=True, text=True)
+    assert r.returncode != 0 and "--presketched needed" in r.stderr
+    r = subprocess.run([os.path.join(BIN, "clust-greedy"), "-l", "--presketched", folder, "--append", lb, "-o", out], capture_output=True, text=True)
+    assert r.returncode != 0 and "MinHash" in r.stderr
+
+
 def test_clust_mst_batching_gzip_retry_and_min_length_filter(oracle, tmp_path):
     """Several small staging batches, a multi-member gzip input whose ISIZE trailer under-reports
     its content (re-parsed in the retry round), and a too-short genome in the middle of the list
