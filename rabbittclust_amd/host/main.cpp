@@ -9,9 +9,10 @@
 // GPUs: every visible MI355X is used (--gpus LIST / RTC_GPUS to choose): one context + one host thread
 // per GPU, file batches go round-robin to the GPUs, the sketches stay in HBM (copied to the host only
 // to write hash.sketch), are shared among the GPUs with RCCL broadcasts, and the MST runs
-// row-sharded with one all-reduce per Boruvka round (rtc_mst_sharded).  Incremental (--append, --db, --save-rep),
-// tree writers, --dense, --auto-threshold and single-FASTA mode are outside this path and exit
-// with a message.
+// row-sharded with one all-reduce per Boruvka round (rtc_mst_sharded).  Also here: --append (clust-mst, and
+// clust-greedy --fast without a stored state), --dense, the tree / linkage writers.  The representative
+// database (--db ...), --save-rep cluster states, --auto-threshold and its companions and single-FASTA mode
+// are outside this path and exit with a message.
 #include <math.h>
 #include <limits>
 #include <omp.h>
