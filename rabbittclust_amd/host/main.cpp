@@ -15,6 +15,7 @@
 // are outside this path and exit with a message.
 #include <math.h>
 #include <limits>
+#include <sys/stat.h>
 #include <omp.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -473,6 +474,7 @@ struct Options {
   bool newick = false, phylip = false, nexus = false, linkage = false;  // --newick-tree / --phylip-tree / --nexus-tree / --linkage-matrix
   bool dense = false;       // --dense: density maps, ANI histogram and the MST noise-removal pass
   bool has_append = false;  // --append LIST: inputFile holds the genomes to add to --presketched/--premsted DIR
+  bool saveRep = false;     // clust-greedy --fast --save-rep: cluster_state.bin beside the sketches
   int threads = default_threads();
   bool sketchByFile = false, noSave = false, is_fast = false, isContainment = false, isJaccard = false, isSetKmer = false;
   bool has_threshold = false, has_input = false, has_presketched = false, has_premsted = false, has_output = false;
@@ -505,6 +507,9 @@ static Options parse(int argc, char** argv) {
     else if (a == "--presketched") { o.folder_path = need(i); o.has_presketched = true; }
     else if (a == "--append") { o.inputFile = need(i); o.has_append = true; }
     else if (a == "--fast") o.is_fast = true;
+#ifdef GREEDY_CLUST
+    else if (a == "--save-rep") o.saveRep = true;
+#endif
     else if (a == "--drlevel") o.drlevel = atoi(need(i));
     else if (a == "--gpus") o.gpus = need(i);
 #ifndef GREEDY_CLUST
@@ -536,7 +541,10 @@ static Options parse(int argc, char** argv) {
       exit(0);
     }
     else if (a == "--db" || a == "--build" || a == "--query" || a == "--assign" || a == "--stats" ||
-             a == "--save-rep" || a == "--top-k" ||
+#ifndef GREEDY_CLUST
+             a == "--save-rep" ||
+#endif
+             a == "--top-k" ||
 #ifdef GREEDY_CLUST
              a == "--dense" ||
 #endif
@@ -669,83 +677,31 @@ static int append_clust_mst(const Options& o, vector<Gpu>& gpus) {
 #endif
 
 #ifdef GREEDY_CLUST
-// append_clust_greedy_fast without a stored cluster state (src/sub_command.cpp, "Initial State Building Mode"):
-// the stored KSSD sketches are clustered as clust-greedy --fast would (KssdInitialClusterWithState =
-// KssdGreedyClusterWithInvertedIndex on the size-sorted sketches, src/greedy.cpp:902-915), then every new genome,
-// in input order, joins the representative at the smallest Mash distance <= threshold among those that share a
-// hash with it and pass the size-ratio and minimum-common filters, or becomes a representative itself
-// (KssdIncrementalCluster, src/greedy.cpp:1736-1900).  The GPU supplies |A ∩ B| of each new genome against
-// everything before it; the rule runs on the host.  Ties in distance go to the earliest representative (the
-// reference's choice depends on hash-map iteration and thread order).
-static int append_clust_greedy_fast(const Options& o, vector<Gpu>& gpus) {
-  rtc_ctx* ctx = gpus[0].ctx;
-  vector<GenomeInfo> pre; KssdSketchFile ks; bool byFile = true;
-  double t0 = get_sec();
-  if (!load_kssd_sketches(o.folder_path, pre, ks, byFile)) return 1;
-  if (byFile != o.sketchByFile) cerr << "Warning: the input format of append genomes and pre-sketched genome is not same" << endl;
-  if (!o.sketchByFile) unsupported("single-FASTA input (run with -l and a genome list)");
-  const int kmer_size = ks.info.half_k * 2;
-  cerr << "===== Initial State Building Mode (KSSD) =====" << endl;
-  cerr << "No existing state found, building state from pre-sketched genomes..." << endl;
-  cerr << "-----use the same sketch parameters with pre-generated sketches" << endl << "---use the KSSD sketches" << endl
-       << "---the half_k is: " << ks.info.half_k << endl << "---the half_subk is: " << ks.info.half_subk << endl
-       << "---the drlevel is: " << ks.info.drlevel << endl << "---the threshold is: " << o.threshold << endl;
-  SketchJob job;
-  job.kssd = true; job.kmerSize = kmer_size; job.drlevel = ks.info.drlevel; job.minLen = o.minLen; job.threads = o.threads;
-  vector<GenomeInfo> add; MinHashSketchFile mh2; KssdSketchFile ks2; Resident rs2;
-  sketch_files(gpus, o.inputFile, job, add, &mh2, &ks2, rs2, true);
-  if (ks2.use64 != ks.use64) { cerr << "ERROR: appended sketches and stored sketches differ in hash width" << endl; return 1; }
-  cerr << "========time of computing sketch is: " << get_sec() - t0 << "========" << endl;
-  if (!o.noSave) {  // compute_kssd_sketches(isSave): the appended sketches get a folder of their own
-    const string folder = current_date_time();
-    string command = "mkdir -p " + folder;
-    if (system(command.c_str()) != 0) { cerr << "ERROR: cannot create " << folder << endl; return 1; }
-    save_kssd_sketches(add, ks2, folder, true);
-  }
-  double t2 = get_sec();
-  // src/greedy.cpp:594-597: the stored sketches sorted by hash count, descending (comparator without tie-break)
-  const size_t n_pre = pre.size(), n_all = n_pre + add.size();
-  auto cnt_pre = [&](size_t i) { return ks.use64 ? ks.h64[i].size() : ks.h32[i].size(); };
-  struct Item { size_t idx; size_t c; };
-  vector<Item> items(n_pre);
-  for (size_t i = 0; i < n_pre; i++) items[i] = Item{i, cnt_pre(i)};
-  std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.c > b.c; });
-  vector<GenomeInfo> genomes; KssdSketchFile all; all.info = ks.info; all.use64 = ks.use64;
-  for (const Item& it : items) {
-    genomes.push_back(pre[it.idx]);
-    if (ks.use64) all.h64.push_back(std::move(ks.h64[it.idx])); else all.h32.push_back(std::move(ks.h32[it.idx]));
-  }
-  for (size_t i = 0; i < add.size(); i++) {
-    genomes.push_back(add[i]);
-    if (ks.use64) all.h64.push_back(std::move(ks2.h64[i])); else all.h32.push_back(std::move(ks2.h32[i]));
-  }
-  for (size_t i = 0; i < genomes.size(); i++) genomes[i].id = (int)i;
+// KssdIncrementalCluster (src/greedy.cpp:1736-1900): every genome from n_old on, in order, joins the
+// representative at the smallest Mash distance <= threshold among those that share a hash with it and pass the
+// size-ratio and minimum-common filters, or becomes a representative itself.  The GPU supplies |A ∩ B| of each new
+// genome against everything before it; the rule runs on the host.  Ties in distance go to the earliest
+// representative (the reference's choice depends on hash-map iteration and thread order).
+static int kssd_incremental_cluster(rtc_ctx* ctx, const KssdSketchFile& all, size_t n_old, double threshold, int kmer_size,
+                                    vector<vector<int>>& cluster) {
+  const size_t n_all = all.use64 ? all.h64.size() : all.h32.size();
   vector<uint32_t> len(n_all);
   for (size_t i = 0; i < n_all; i++) len[i] = (uint32_t)(all.use64 ? all.h64[i].size() : all.h32[i].size());
+  vector<int> cid(n_all, -1);  // cluster index of a representative
+  for (size_t c = 0; c < cluster.size(); c++) if (!cluster[c].empty()) cid[cluster[c][0]] = (int)c;
+  cerr << "Existing clusters: " << cluster.size() << endl << "New genomes: " << n_all - n_old << endl;
+  if (n_all == n_old) return 0;
   DeviceSketches ds;
   upload_sketches(ctx, all.use64 ? &all.h64 : nullptr, all.use64 ? nullptr : &all.h32, ds);
-  vector<int32_t> rep_of(n_all, -1);
-  uint32_t ncl = 0;
-  if (n_pre) CHECK(ctx, rtc_greedy(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, (uint32_t)n_pre, nullptr, kmer_size, 0, 1, o.threshold,
-                                   rep_of.data(), &ncl));
-  vector<vector<int>> cluster;
-  {
-    vector<int32_t> pre_rep(rep_of.begin(), rep_of.begin() + n_pre);
-    cluster = clusters_from_rep_of(pre_rep);
-  }
-  vector<int> cid(n_all, -1);  // cluster index of a representative
-  for (size_t c = 0; c < cluster.size(); c++) cid[cluster[c][0]] = (int)c;
-  cerr << "Existing clusters: " << cluster.size() << endl << "New genomes: " << add.size() << endl;
-  // ---- incremental part ----
-  const double radio = 2.0 * exp(o.threshold * kmer_size) - 1.0;                 // calculateMaxSizeRatio, src/greedy.cpp:162-173
-  const double x = exp(-o.threshold * kmer_size), jaccard_min = x / (2.0 - x);   // :1751-1753
+  const double radio = 2.0 * exp(threshold * kmer_size) - 1.0;                 // calculateMaxSizeRatio, src/greedy.cpp:162-173
+  const double x = exp(-threshold * kmer_size), jaccard_min = x / (2.0 - x);   // :1751-1753
   const size_t max_block_bytes = (size_t)256 << 20;
-  size_t B = std::max<size_t>(1, std::min<size_t>(add.size(), max_block_bytes / (n_all * 4)));
+  const size_t B = std::max<size_t>(1, std::min<size_t>(n_all - n_old, max_block_bytes / (n_all * 4)));
   uint32_t* d_common = nullptr;
-  if (!add.empty()) CHECK(ctx, rtc_dev_alloc(ctx, B * n_all * 4 + 64, (void**)&d_common));
+  CHECK(ctx, rtc_dev_alloc(ctx, B * n_all * 4 + 64, (void**)&d_common));
   vector<uint32_t> common(B * n_all);
   int new_clusters = 0, assigned = 0;
-  for (size_t r0 = n_pre; r0 < n_all; r0 += B) {
+  for (size_t r0 = n_old; r0 < n_all; r0 += B) {
     const size_t r1 = std::min(n_all, r0 + B);
     CHECK(ctx, rtc_pair_common_dev(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, (uint32_t)n_all, (uint32_t)r0, (uint32_t)r1, 0,
                                    (uint32_t)n_all, d_common, (uint64_t)n_all, 1, 0));
@@ -766,15 +722,117 @@ static int append_clust_greedy_fast(const Options& o, vector<Gpu>& gpus) {
         const double jac = uni == 0 ? 0.0 : (double)cm / (double)uni;
         double dist = 0.0;
         if (jac != 1.0) { dist = -log(2 * jac / (1.0 + jac)) / (double)kmer_size; if (dist > 1.0) dist = 1.0; }
-        if (dist <= o.threshold && dist < best_dist) { best_dist = dist; best = (int)r; }
+        if (dist <= threshold && dist < best_dist) { best_dist = dist; best = (int)r; }
       }
       if (best >= 0) { cluster[cid[best]].push_back((int)q); assigned++; }
       else { cid[q] = (int)cluster.size(); cluster.push_back({(int)q}); new_clusters++; }
     }
   }
-  if (d_common) CHECK(ctx, rtc_dev_free(ctx, d_common));
+  CHECK(ctx, rtc_dev_free(ctx, d_common));
+  CHECK(ctx, rtc_dev_free(ctx, ds.d_hashes)); CHECK(ctx, rtc_dev_free(ctx, ds.d_start)); CHECK(ctx, rtc_dev_free(ctx, ds.d_len));
   cerr << "===== Incremental Clustering Results =====" << endl << "Assigned to existing clusters: " << assigned << endl
        << "New clusters created: " << new_clusters << endl << "Total clusters now: " << cluster.size() << endl;
+  return 0;
+}
+
+static void fill_cluster_state(KssdClusterState& st, double threshold, int kmer_size, const KssdParameters& info,
+                               const vector<GenomeInfo>& genomes, const KssdSketchFile& sk, const vector<vector<int>>& cluster) {
+  st.threshold = threshold; st.kmer_size = kmer_size; st.info = info; st.genomes = genomes; st.sk = sk; st.clusters = cluster;
+  st.rep_ids.clear();
+  for (const auto& c : cluster) if (!c.empty()) st.rep_ids.push_back(c[0]);  // src/greedy.cpp:928-934
+}
+
+// append_clust_greedy_fast (src/sub_command.cpp:192-270).  With DIR/cluster_state.bin ("Incremental Update Mode"):
+// the stored state's sketches, clusters, threshold and k; the new genomes are clustered against its
+// representatives.  Without it ("Initial State Building Mode"): the stored KSSD sketches are clustered as
+// clust-greedy --fast would (KssdInitialClusterWithState = KssdGreedyClusterWithInvertedIndex on the size-sorted
+// sketches, src/greedy.cpp:902-915), then the new genomes as above.  --save-rep (and no -e) writes the state back.
+static int append_clust_greedy_fast(const Options& o, vector<Gpu>& gpus) {
+  rtc_ctx* ctx = gpus[0].ctx;
+  const string state_file = o.folder_path + "/cluster_state.bin";
+  double t0 = get_sec();
+  if (!o.sketchByFile) unsupported("single-FASTA input (run with -l and a genome list)");
+  KssdClusterState st;
+  struct stat sb;
+  bool has_state = stat(state_file.c_str(), &sb) == 0;
+  if (has_state) {
+    cerr << "===== Incremental Update Mode (KSSD) =====" << endl << "Found existing cluster state, loading..." << endl;
+    has_state = load_kssd_cluster_state(state_file, st);
+  }
+  vector<GenomeInfo> genomes; KssdSketchFile all; vector<vector<int>> cluster; bool byFile = true;
+  KssdParameters info{};
+  double threshold = o.threshold;
+  int kmer_size = 0;
+  size_t n_old = 0;
+  if (has_state) {
+    cerr << "---the threshold is: " << o.threshold << endl << "---the thread number is: " << o.threads << endl;
+    genomes = std::move(st.genomes); all = std::move(st.sk); cluster = std::move(st.clusters); info = st.info;
+    threshold = st.threshold; kmer_size = st.kmer_size;  // KssdIncrementalCluster works with the state's values
+    n_old = genomes.size();
+  } else {
+    vector<GenomeInfo> pre; KssdSketchFile ks;
+    if (!load_kssd_sketches(o.folder_path, pre, ks, byFile)) return 1;
+    if (byFile != o.sketchByFile) cerr << "Warning: the input format of append genomes and pre-sketched genome is not same" << endl;
+    info = ks.info;
+    kmer_size = ks.info.half_k * 2;
+    cerr << "===== Initial State Building Mode (KSSD) =====" << endl;
+    cerr << "No existing state found, building state from pre-sketched genomes..." << endl;
+    cerr << "-----use the same sketch parameters with pre-generated sketches" << endl << "---use the KSSD sketches" << endl
+         << "---the half_k is: " << ks.info.half_k << endl << "---the half_subk is: " << ks.info.half_subk << endl
+         << "---the drlevel is: " << ks.info.drlevel << endl << "---the threshold is: " << o.threshold << endl;
+    // src/greedy.cpp:594-597: the stored sketches sorted by hash count, descending (comparator without tie-break)
+    const size_t n_pre = pre.size();
+    auto cnt_pre = [&](size_t i) { return ks.use64 ? ks.h64[i].size() : ks.h32[i].size(); };
+    struct Item { size_t idx; size_t c; };
+    vector<Item> items(n_pre);
+    for (size_t i = 0; i < n_pre; i++) items[i] = Item{i, cnt_pre(i)};
+    std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.c > b.c; });
+    all.info = ks.info; all.use64 = ks.use64;
+    for (const Item& it : items) {
+      genomes.push_back(pre[it.idx]);
+      if (ks.use64) all.h64.push_back(std::move(ks.h64[it.idx])); else all.h32.push_back(std::move(ks.h32[it.idx]));
+    }
+    n_old = n_pre;
+    if (n_pre) {
+      DeviceSketches ds;
+      upload_sketches(ctx, all.use64 ? &all.h64 : nullptr, all.use64 ? nullptr : &all.h32, ds);
+      vector<int32_t> rep_of(n_pre, -1);
+      uint32_t ncl = 0;
+      CHECK(ctx, rtc_greedy(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, (uint32_t)n_pre, nullptr, kmer_size, 0, 1, o.threshold,
+                            rep_of.data(), &ncl));
+      CHECK(ctx, rtc_dev_free(ctx, ds.d_hashes)); CHECK(ctx, rtc_dev_free(ctx, ds.d_start)); CHECK(ctx, rtc_dev_free(ctx, ds.d_len));
+      cluster = clusters_from_rep_of(rep_of);
+    }
+  }
+  // ---- the new genomes, with the stored parameters ----
+  SketchJob job;
+  job.kssd = true; job.kmerSize = kmer_size; job.drlevel = info.drlevel; job.minLen = o.minLen; job.threads = o.threads;
+  vector<GenomeInfo> add; MinHashSketchFile mh2; KssdSketchFile ks2; Resident rs2;
+  sketch_files(gpus, o.inputFile, job, add, &mh2, &ks2, rs2, true);
+  if (!add.empty() && n_old && ks2.use64 != all.use64) { cerr << "ERROR: appended sketches and stored sketches differ in hash width" << endl; return 1; }
+  if (n_old == 0) all.use64 = ks2.use64;
+  cerr << "New genomes sketched: " << add.size() << endl;
+  cerr << "========time of computing sketch is: " << get_sec() - t0 << "========" << endl;
+  if (!o.noSave) {  // compute_kssd_sketches(isSave): the appended sketches get a folder of their own
+    const string folder = current_date_time();
+    string command = "mkdir -p " + folder;
+    if (system(command.c_str()) != 0) { cerr << "ERROR: cannot create " << folder << endl; return 1; }
+    save_kssd_sketches(add, ks2, folder, true);
+  }
+  double t2 = get_sec();
+  for (size_t i = 0; i < add.size(); i++) {
+    genomes.push_back(add[i]);
+    if (all.use64) all.h64.push_back(std::move(ks2.h64[i])); else all.h32.push_back(std::move(ks2.h32[i]));
+  }
+  if (!has_state) for (size_t i = 0; i < genomes.size(); i++) genomes[i].id = (int)i;  // (a stored state keeps the ids it holds)
+  if (kssd_incremental_cluster(ctx, all, n_old, threshold, kmer_size, cluster) != 0) return 1;
+  if (!o.noSave && o.saveRep) {
+    KssdClusterState out;
+    info.genomeNumber = (int)genomes.size();
+    fill_cluster_state(out, threshold, kmer_size, info, genomes, all, cluster);
+    if (!save_kssd_cluster_state(state_file, out)) return 1;
+    cerr << "-----saved cluster state (with inverted index) for future incremental updates" << endl;
+  }
   print_result(cluster, genomes, byFile, o.outputFile);
   cerr << "-----write the cluster result into: " << o.outputFile << endl;
   cerr << "-----the cluster number of " << o.outputFile << " is: " << cluster.size() << endl;
@@ -788,6 +846,9 @@ int main(int argc, char** argv) {
   if (!o.has_output) { cerr << "ERROR: option -o/--output is required (unless --buildDB or --stats is used)" << endl; return 1; }
   if (o.threads < 1) { fprintf(stderr, "-----Invalid thread number %d\n", o.threads); return 1; }
   fprintf(stderr, "-----set the thread number %d\n", o.threads);
+#ifdef GREEDY_CLUST
+  if (o.saveRep && !o.is_fast) unsupported("--save-rep on MinHash sketches (the MinHash cluster state); --fast");
+#endif
   if (!o.has_threshold) { o.threshold = 0.05; cerr << "-----use default threshold: " << o.threshold << endl; }
 
 #ifdef GREEDY_CLUST
@@ -922,7 +983,7 @@ int main(int argc, char** argv) {
     for (const Item& it : items) {
       g2.push_back(genomes[it.idx]);
       kssd_order.push_back((uint32_t)it.idx);  // resident rows are addressed through this order, not moved
-      if (!rs.ok) { if (ks.use64) k2.h64.push_back(ks.h64[it.idx]); else k2.h32.push_back(ks.h32[it.idx]); }
+      if (!rs.ok || (o.saveRep && !o.noSave)) { if (ks.use64) k2.h64.push_back(ks.h64[it.idx]); else k2.h32.push_back(ks.h32[it.idx]); }
     }
     genomes.swap(g2); ks = std::move(k2);
   } else {
@@ -957,6 +1018,15 @@ int main(int argc, char** argv) {
   CHECK(ctx, rtc_greedy(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, o.is_fast ? nullptr : size_cfg.data(), kmer_size,
                         o.is_fast ? 0 : (int)mh.isContainment, o.is_fast ? 1 : 0, o.threshold, rep_of.data(), &ncl));
   vector<vector<int>> cluster = clusters_from_rep_of(rep_of);
+  if (o.is_fast && o.saveRep && !o.noSave && !from_sketches) {  // compute_kssd_clusters, src/sub_command.cpp:1962-1967
+    KssdClusterState st;
+    KssdParameters info = ks.info;
+    info.genomeNumber = (int)genomes.size();
+    fill_cluster_state(st, o.threshold, kmer_size, info, genomes, ks, cluster);
+    const string state_file = folder_path + "/cluster_state.bin";
+    if (!save_kssd_cluster_state(state_file, st)) return 1;
+    cerr << "-----saved cluster state (with inverted index) to: " << state_file << endl;
+  }
   print_result(cluster, genomes, sketchByFile, o.outputFile);
   cerr << "-----write the cluster result into: " << o.outputFile << endl;
   cerr << "-----the cluster number of " << o.outputFile << " is: " << cluster.size() << endl;

@@ -897,6 +897,116 @@ std::vector<std::vector<int>> generate_cluster_with_bfs(const std::vector<rtc_ed
 }
 
 // src/MST_IO.cpp:72-179 (printResult / printKssdResult share the layout)
+// src/greedy.cpp:1545-1625
+bool save_kssd_cluster_state(const std::string& path, const KssdClusterState& st) {
+  FILE* fp = fopen(path.c_str(), "wb");
+  if (!fp) { std::cerr << "ERROR: Cannot open file for writing: " << path << std::endl; return false; }
+  wr(fp, st.threshold); wr(fp, st.kmer_size);
+  wr(fp, st.info.half_k); wr(fp, st.info.half_subk); wr(fp, st.info.drlevel); wr(fp, st.info.genomeNumber);
+  const size_t rep_count = st.rep_ids.size();
+  wr(fp, rep_count);
+  fwrite(st.rep_ids.data(), sizeof(int), rep_count, fp);
+  const size_t sketch_count = st.genomes.size();
+  wr(fp, sketch_count);
+  for (size_t i = 0; i < sketch_count; i++) {
+    const GenomeInfo& g = st.genomes[i];
+    const bool use64 = st.sk.use64;
+    const size_t n32 = use64 ? 0 : st.sk.h32[i].size(), n64 = use64 ? st.sk.h64[i].size() : 0;
+    const uint32_t sketchsize = (uint32_t)(n32 + n64);
+    wr(fp, g.id); wr(fp, g.totalSeqLength); wr(fp, use64); wr(fp, sketchsize);
+    wr(fp, n32); wr(fp, n64);
+    if (n32) fwrite(st.sk.h32[i].data(), 4, n32, fp);
+    if (n64) fwrite(st.sk.h64[i].data(), 8, n64, fp);
+    const size_t name_len = g.fileName.size();
+    wr(fp, name_len);
+    fwrite(g.fileName.data(), 1, name_len, fp);
+  }
+  const size_t cluster_count = st.clusters.size();
+  wr(fp, cluster_count);
+  for (const auto& c : st.clusters) {
+    const size_t m = c.size();
+    wr(fp, m);
+    fwrite(c.data(), sizeof(int), m, fp);
+  }
+  // representatives' inverted index: marker + 64-bit keys
+  const char magic[8] = {'K', 'S', 'S', 'I', '0', '2', '\0', '\0'};
+  fwrite(magic, 1, 8, fp);
+  std::vector<std::pair<uint64_t, int>> post;
+  for (size_t r = 0; r < rep_count; r++) {
+    const int g = st.rep_ids[r];
+    if (st.sk.use64) for (uint64_t h : st.sk.h64[g]) post.emplace_back(h, (int)r);
+    else for (uint32_t h : st.sk.h32[g]) post.emplace_back((uint64_t)h, (int)r);
+  }
+  std::sort(post.begin(), post.end());
+  size_t index_size = 0;
+  for (size_t i = 0; i < post.size(); i++) if (i == 0 || post[i].first != post[i - 1].first) index_size++;
+  wr(fp, index_size);
+  for (size_t i = 0; i < post.size();) {
+    size_t j = i;
+    while (j < post.size() && post[j].first == post[i].first) j++;
+    wr(fp, post[i].first);
+    const size_t list_size = j - i;
+    wr(fp, list_size);
+    for (size_t q = i; q < j; q++) wr(fp, post[q].second);
+    i = j;
+  }
+  fclose(fp);
+  std::cerr << "Saved clustering state to: " << path << std::endl
+            << "  - " << sketch_count << " genomes" << std::endl
+            << "  - " << rep_count << " clusters (representatives)" << std::endl
+            << "  - " << index_size << " unique hashes in inverted index" << std::endl;
+  return true;
+}
+
+// src/greedy.cpp:1627-1734 (the inverted index that follows the clusters is not read: it is a function of the
+// representatives' sketches)
+bool load_kssd_cluster_state(const std::string& path, KssdClusterState& st) {
+  FILE* fp = fopen(path.c_str(), "rb");
+  if (!fp) { std::cerr << "ERROR: Cannot open file for reading: " << path << std::endl; return false; }
+  bool ok = rd(fp, st.threshold) && rd(fp, st.kmer_size) && rd(fp, st.info.half_k) && rd(fp, st.info.half_subk) &&
+            rd(fp, st.info.drlevel) && rd(fp, st.info.genomeNumber);
+  size_t rep_count = 0, sketch_count = 0, cluster_count = 0;
+  ok = ok && rd(fp, rep_count) && rep_count < ((size_t)1 << 31);
+  if (ok) { st.rep_ids.resize(rep_count); ok = fread(st.rep_ids.data(), sizeof(int), rep_count, fp) == rep_count; }
+  ok = ok && rd(fp, sketch_count) && sketch_count < ((size_t)1 << 31);
+  st.genomes.clear(); st.sk.h32.clear(); st.sk.h64.clear(); st.sk.info = st.info;
+  for (size_t i = 0; ok && i < sketch_count; i++) {
+    GenomeInfo g; bool use64 = false; uint32_t sketchsize = 0; size_t n32 = 0, n64 = 0, name_len = 0;
+    ok = rd(fp, g.id) && rd(fp, g.totalSeqLength) && rd(fp, use64) && rd(fp, sketchsize) && rd(fp, n32) && rd(fp, n64) &&
+         n32 < ((size_t)1 << 32) && n64 < ((size_t)1 << 32);
+    if (!ok) break;
+    if (i == 0) st.sk.use64 = use64;
+    std::vector<uint32_t> h32(n32); std::vector<uint64_t> h64(n64);
+    if (n32) ok = ok && fread(h32.data(), 4, n32, fp) == n32;
+    if (n64) ok = ok && fread(h64.data(), 8, n64, fp) == n64;
+    ok = ok && rd(fp, name_len) && name_len < ((size_t)1 << 20);
+    if (!ok) break;
+    g.fileName.resize(name_len);
+    if (name_len) ok = fread(&g.fileName[0], 1, name_len, fp) == name_len;
+    g.use64 = use64;
+    g.seq0.name = "N/A"; g.seq0.comment = "N/A";   // printKssdResult's text for sketches without record infos (src/MST_IO.cpp:99-104)
+    st.genomes.push_back(g);
+    if (st.sk.use64) st.sk.h64.push_back(std::move(h64)); else st.sk.h32.push_back(std::move(h32));
+  }
+  ok = ok && rd(fp, cluster_count) && cluster_count < ((size_t)1 << 31);
+  st.clusters.clear();
+  for (size_t c = 0; ok && c < cluster_count; c++) {
+    size_t m = 0;
+    ok = rd(fp, m) && m < ((size_t)1 << 31);
+    if (!ok) break;
+    std::vector<int> cl(m);
+    if (m) ok = fread(cl.data(), sizeof(int), m, fp) == m;
+    st.clusters.push_back(std::move(cl));
+  }
+  fclose(fp);
+  if (!ok) { std::cerr << "ERROR: truncated or malformed cluster state: " << path << std::endl; return false; }
+  for (int r : st.rep_ids) if (r < 0 || (size_t)r >= st.genomes.size()) { std::cerr << "ERROR: Representative ID " << r << " out of range" << std::endl; return false; }
+  std::cerr << "Loaded clustering state from: " << path << std::endl
+            << "  - " << sketch_count << " genomes" << std::endl
+            << "  - " << rep_count << " clusters (representatives)" << std::endl;
+  return true;
+}
+
 void print_result(const std::vector<std::vector<int>>& cluster, const std::vector<GenomeInfo>& g, bool sketchByFile,
                   const std::string& outputFile, double threshold) {
   FILE* fp = fopen(outputFile.c_str(), "w");

@@ -88,6 +88,22 @@ void save_kssd_sketches(const std::vector<GenomeInfo>& g, const KssdSketchFile& 
 bool load_kssd_sketches(const std::string& folder, std::vector<GenomeInfo>& g, KssdSketchFile& f, bool& sketchByFile);
 void save_kssd_index(const KssdSketchFile& f, const std::string& folder);  // kssd.sketch.index + .dict
 
+// cluster_state.bin of clust-greedy --fast --save-rep (KssdClusterState::save / ::load, src/greedy.cpp:1545-1734):
+// threshold, k, KSSD parameters, representative ids, every sketch in clustering order (id, length, hashes,
+// file name), the clusters, and the representatives' inverted index (hash -> positions in rep_ids; written from
+// the sketches, skipped when read -- it is rebuilt from them wherever it is needed).
+struct KssdClusterState {
+  double threshold = 0.05;
+  int kmer_size = 0;
+  KssdParameters info{};
+  std::vector<int> rep_ids;
+  std::vector<GenomeInfo> genomes;   // state order: genome i has id i
+  KssdSketchFile sk;                 // hashes in the same order
+  std::vector<std::vector<int>> clusters;
+};
+bool save_kssd_cluster_state(const std::string& path, const KssdClusterState& st);
+bool load_kssd_cluster_state(const std::string& path, KssdClusterState& st);
+
 void save_mst(const std::vector<rtc_edge>& mst, const std::string& folder);   // edge.mst
 bool load_mst(const std::string& folder, std::vector<rtc_edge>& mst);
 

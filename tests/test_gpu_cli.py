@@ -263,6 +263,7 @@ def test_clust_greedy_fast_append(oracle, tmp_path):
     for pos, r in enumerate(rep):
         if int(r) != pos:
             clusters[cid[int(r)]].append(pos)
+    clusters_pre = [list(c) for c in clusters]
     kmer, thr = 22, 0.05
     radio = 2.0 * math.exp(thr * kmer) - 1.0
     x = math.exp(-thr * kmer); jmin = x / (2.0 - x)
@@ -296,6 +297,77 @@ def test_clust_greedy_fast_append(oracle, tmp_path):
             f = ln.rstrip("\n").split("\t")
             names[int(f[2])] = f[4].strip()
     assert [names[i] for i in range(len(order))] == [paths[i] for i in order]
+    # ---- the same through a stored cluster state: --save-rep writes DIR/cluster_state.bin, --append finds it ----
+    import struct
+    ds_ = os.path.join(tmp, "s"); os.makedirs(ds_)
+    _run([os.path.join(BIN, "clust-greedy"), "--fast", "-l", "-i", la, "-k", "21", "-d", "0.05", "-t", "4", "--save-rep", "-o",
+          os.path.join(ds_, "a.out")], ds_)
+    sfolder = [os.path.join(ds_, d) for d in os.listdir(ds_) if os.path.isdir(os.path.join(ds_, d))][0]
+    state = os.path.join(sfolder, "cluster_state.bin")
+
+    def read_state(path):  # KssdClusterState::save, src/greedy.cpp:1545-1625
+        b = open(path, "rb").read()
+        thr_, k_, hk, hs, dr, gn = struct.unpack_from("<diiiii", b, 0)
+        p_ = 28
+        (nrep,) = struct.unpack_from("<Q", b, p_); p_ += 8
+        reps = list(struct.unpack_from("<%di" % nrep, b, p_)); p_ += 4 * nrep
+        (nsk,) = struct.unpack_from("<Q", b, p_); p_ += 8
+        names_, sks = [], []
+        for _ in range(nsk):
+            gid, tot, u64, ssz = struct.unpack_from("<iQ?I", b, p_); p_ += 4 + 8 + 1 + 4
+            n32, n64 = struct.unpack_from("<QQ", b, p_); p_ += 16
+            sks.append(np.frombuffer(b, dtype=np.uint32, count=n32, offset=p_).copy()); p_ += 4 * n32 + 8 * n64
+            (nl,) = struct.unpack_from("<Q", b, p_); p_ += 8
+            names_.append(b[p_:p_ + nl].decode()); p_ += nl
+            assert ssz == n32 and n64 == 0 and not u64
+        (ncl_,) = struct.unpack_from("<Q", b, p_); p_ += 8
+        cls = []
+        for _ in range(ncl_):
+            (m,) = struct.unpack_from("<Q", b, p_); p_ += 8
+            cls.append(list(struct.unpack_from("<%di" % m, b, p_))); p_ += 4 * m
+        assert b[p_:p_ + 8] == b"KSSI02\0\0"; p_ += 8
+        (nidx,) = struct.unpack_from("<Q", b, p_); p_ += 8
+        index = {}
+        for _ in range(nidx):
+            h, ls = struct.unpack_from("<QQ", b, p_); p_ += 16
+            index[h] = list(struct.unpack_from("<%di" % ls, b, p_)); p_ += 4 * ls
+        assert p_ == len(b)
+        return dict(thr=thr_, k=k_, half_k=hk, drlevel=dr, n=gn, reps=reps, names=names_, sk=sks, clusters=cls, index=index)
+
+    st = read_state(state)
+    pre_clusters = [c for c in (clusters_pre)]
+    assert (st["thr"], st["k"], st["half_k"], st["drlevel"], st["n"]) == (0.05, 22, 11, 3, len(pre))
+    assert st["clusters"] == pre_clusters and st["reps"] == [c[0] for c in pre_clusters]
+    assert st["names"] == [paths[i] for i in pre] and all(np.array_equal(a, ks[i]) for a, i in zip(st["sk"], pre))
+    want_index = {}
+    for ridx, g in enumerate(st["reps"]):
+        for h in ks[pre[g]].tolist():
+            want_index.setdefault(h, []).append(ridx)
+    assert st["index"] == want_index
+    half = len(second) // 2
+    lb1, lb2 = os.path.join(tmp, "b1.txt"), os.path.join(tmp, "b2.txt")
+    open(lb1, "w").write("\n".join(paths[i] for i in second[:half]) + "\n")
+    open(lb2, "w").write("\n".join(paths[i] for i in second[half:]) + "\n")
+    out1, out2 = os.path.join(tmp, "s1.out"), os.path.join(tmp, "s2.out")
+    d1 = os.path.join(tmp, "s1"); os.makedirs(d1)
+    err = _run([os.path.join(BIN, "clust-greedy"), "--fast", "-l", "--presketched", sfolder, "--append", lb1, "-d", "0.2", "-t", "4",
+                "--save-rep", "-o", out1], d1)
+    assert "Incremental Update Mode (KSSD)" in err  # (-d 0.2 is ignored: the state's threshold decides)
+    st1 = read_state(state)
+    assert st1["n"] == len(pre) + half and st1["names"] == [paths[i] for i in order[:len(pre) + half]]
+    err = _run([os.path.join(BIN, "clust-greedy"), "--fast", "-l", "--presketched", sfolder, "--append", lb2, "-d", "0.05", "-t", "4", "-e",
+                "-o", out2], tmp)
+    assert "Incremental Update Mode (KSSD)" in err
+    assert _parse_clusters(out2) == clusters          # two appends through the state = one stateless append of everything
+    assert read_state(state)["n"] == len(pre) + half  # -e: the state stays as it was
+    seqnames = {}
+    for ln in open(out2):
+        if ln.startswith("\t"):
+            f = ln.rstrip("\n").split("\t")
+            seqnames[int(f[2])] = (f[4].strip(), f[5].strip())
+    assert all(seqnames[i][1] == "N/A" for i in range(len(pre) + half))          # src/MST_IO.cpp:99-104
+    assert all(seqnames[i][1] != "N/A" for i in range(len(pre) + half, len(order)))
+    assert [seqnames[i][0] for i in range(len(order))] == [paths[i] for i in order]
     # usage errors (src/main.cpp:378-381) and the MinHash flow, which is not offered
     r = subprocess.run([os.path.join(BIN, "clust-greedy"), "--fast", "-l", "--append", lb, "-o", out], capture_output=True, text=True)
     assert r.returncode != 0 and "--presketched needed" in r.stderr
