@@ -14,6 +14,7 @@
 // database (--db ...), --save-rep cluster states, --auto-threshold and its companions and single-FASTA mode
 // are outside this path and exit with a message.
 #include <math.h>
+#include <iomanip>
 #include <limits>
 #include <sys/stat.h>
 #include <omp.h>
@@ -475,6 +476,9 @@ struct Options {
   bool dense = false;       // --dense: density maps, ANI histogram and the MST noise-removal pass
   bool has_append = false;  // --append LIST: inputFile holds the genomes to add to --presketched/--premsted DIR
   bool saveRep = false;     // clust-greedy --fast --save-rep: cluster_state.bin beside the sketches
+  string repdb_path;        // clust-greedy --fast --db FILE with one of --build / --query / --assign / --append / --stats
+  bool db_build = false, db_query = false, db_assign = false, db_stats = false;
+  int topk = 5;             // --top-k of --query
   int threads = default_threads();
   bool sketchByFile = false, noSave = false, is_fast = false, isContainment = false, isJaccard = false, isSetKmer = false;
   bool has_threshold = false, has_input = false, has_presketched = false, has_premsted = false, has_output = false;
@@ -509,6 +513,12 @@ static Options parse(int argc, char** argv) {
     else if (a == "--fast") o.is_fast = true;
 #ifdef GREEDY_CLUST
     else if (a == "--save-rep") o.saveRep = true;
+    else if (a == "--db") o.repdb_path = need(i);
+    else if (a == "--build") o.db_build = true;
+    else if (a == "--query") o.db_query = true;
+    else if (a == "--assign") o.db_assign = true;
+    else if (a == "--stats") o.db_stats = true;
+    else if (a == "--top-k") o.topk = atoi(need(i));
 #endif
     else if (a == "--drlevel") o.drlevel = atoi(need(i));
     else if (a == "--gpus") o.gpus = need(i);
@@ -535,17 +545,16 @@ static Options parse(int argc, char** argv) {
 #ifndef GREEDY_CLUST
            "  --premsted DIR  --append LIST (with --presketched/--premsted DIR)"
 #else
-           "  --append LIST (with --fast --presketched DIR)"
+           "  --append LIST (with --fast --presketched DIR)  --save-rep (with --fast: cluster_state.bin)\n"
+           "  --fast --db FILE --build|--query|--assign|--append LIST|--stats [--top-k N] (representative database)"
 #endif
       );
       exit(0);
     }
-    else if (a == "--db" || a == "--build" || a == "--query" || a == "--assign" || a == "--stats" ||
+    else if (
 #ifndef GREEDY_CLUST
-             a == "--save-rep" ||
-#endif
-             a == "--top-k" ||
-#ifdef GREEDY_CLUST
+             a == "--db" || a == "--build" || a == "--query" || a == "--assign" || a == "--stats" || a == "--top-k" || a == "--save-rep" ||
+#else
              a == "--dense" ||
 #endif
               a == "--newick-tree" || a == "--phylip-tree" ||
@@ -677,76 +686,165 @@ static int append_clust_mst(const Options& o, vector<Gpu>& gpus) {
 #endif
 
 #ifdef GREEDY_CLUST
-// KssdIncrementalCluster (src/greedy.cpp:1736-1900): every genome from n_old on, in order, joins the
-// representative at the smallest Mash distance <= threshold among those that share a hash with it and pass the
-// size-ratio and minimum-common filters, or becomes a representative itself.  The GPU supplies |A ∩ B| of each new
-// genome against everything before it; the rule runs on the host.  Ties in distance go to the earliest
-// representative (the reference's choice depends on hash-map iteration and thread order).
-static int kssd_incremental_cluster(rtc_ctx* ctx, const KssdSketchFile& all, size_t n_old, double threshold, int kmer_size,
-                                    vector<vector<int>>& cluster) {
-  const size_t n_all = all.use64 ? all.h64.size() : all.h32.size();
-  vector<uint32_t> len(n_all);
-  for (size_t i = 0; i < n_all; i++) len[i] = (uint32_t)(all.use64 ? all.h64[i].size() : all.h32[i].size());
-  vector<int> cid(n_all, -1);  // cluster index of a representative
-  for (size_t c = 0; c < cluster.size(); c++) if (!cluster[c].empty()) cid[cluster[c][0]] = (int)c;
-  cerr << "Existing clusters: " << cluster.size() << endl << "New genomes: " << n_all - n_old << endl;
-  if (n_all == n_old) return 0;
+// calculate_mash_distance over a known intersection (src/greedy.cpp:103-160)
+static double kssd_mash_distance(int cm, int sizeRef, int sizeQry, int kmer_size) {
+  const uint64_t uni = (uint64_t)sizeRef + (uint64_t)sizeQry - (uint64_t)cm;
+  const double jac = uni == 0 ? 0.0 : (double)cm / (double)uni;
+  double dist = 0.0;
+  if (jac != 1.0) { dist = -log(2 * jac / (1.0 + jac)) / (double)kmer_size; if (dist > 1.0) dist = 1.0; }
+  return dist;
+}
+
+static size_t sketch_count(const KssdSketchFile& f) { return f.use64 ? f.h64.size() : f.h32.size(); }
+static size_t sketch_len(const KssdSketchFile& f, size_t i) { return f.use64 ? f.h64[i].size() : f.h32[i].size(); }
+static void push_sketch(KssdSketchFile& dst, const KssdSketchFile& src, size_t i) {
+  if (dst.use64) dst.h64.push_back(src.h64[i]); else dst.h32.push_back(src.h32[i]);
+}
+
+// the representatives' sketches followed by `tail`'s: the set one rectangular intersection launch works on
+static void reps_then(const KssdClusterState& st, const KssdSketchFile& tail, KssdSketchFile& work) {
+  work = st.reps;
+  if (sketch_count(work) == 0) work.use64 = tail.use64;
+  for (size_t i = 0; i < sketch_count(tail); i++) push_sketch(work, tail, i);
+}
+
+// KssdIncrementalCluster (src/greedy.cpp:1736-1900): every new genome, in order, joins the representative at the
+// smallest Mash distance <= threshold among those that share a hash with it and pass the size-ratio and
+// minimum-common filters, or becomes a representative itself.  The GPU supplies |A ∩ B| of each new genome against
+// the stored representatives and the new genomes before it; the rule runs on the host.  Ties in distance go to the
+// earliest representative (the reference's choice depends on hash-map iteration and thread order).  As in the
+// reference (:1861-1864) a genome that opens a cluster is recorded as its representative but is not listed among
+// the cluster's members -- the cluster starts empty.
+static int kssd_incremental_cluster(rtc_ctx* ctx, KssdClusterState& st, const vector<GenomeInfo>& add, const KssdSketchFile& ks2,
+                                    bool keep_sketches) {
+  const size_t R0 = st.rep_ids.size(), m = add.size(), n_old = st.genomes.size(), n_work = R0 + m;
+  const double threshold = st.threshold; const int kmer_size = st.kmer_size;
+  cerr << "Existing clusters: " << R0 << endl << "New genomes: " << m << endl;
+  if (m == 0) return 0;
+  if (R0 && ks2.use64 != st.reps.use64) { cerr << "ERROR: appended sketches and stored sketches differ in hash width" << endl; return 1; }
+  KssdSketchFile work;
+  reps_then(st, ks2, work);
+  st.reps.use64 = work.use64; if (keep_sketches && n_old == 0) st.sk.use64 = work.use64;
   DeviceSketches ds;
-  upload_sketches(ctx, all.use64 ? &all.h64 : nullptr, all.use64 ? nullptr : &all.h32, ds);
+  upload_sketches(ctx, work.use64 ? &work.h64 : nullptr, work.use64 ? nullptr : &work.h32, ds);
   const double radio = 2.0 * exp(threshold * kmer_size) - 1.0;                 // calculateMaxSizeRatio, src/greedy.cpp:162-173
   const double x = exp(-threshold * kmer_size), jaccard_min = x / (2.0 - x);   // :1751-1753
   const size_t max_block_bytes = (size_t)256 << 20;
-  const size_t B = std::max<size_t>(1, std::min<size_t>(n_all - n_old, max_block_bytes / (n_all * 4)));
+  const size_t B = std::max<size_t>(1, std::min<size_t>(m, max_block_bytes / (n_work * 4)));
   uint32_t* d_common = nullptr;
-  CHECK(ctx, rtc_dev_alloc(ctx, B * n_all * 4 + 64, (void**)&d_common));
-  vector<uint32_t> common(B * n_all);
+  CHECK(ctx, rtc_dev_alloc(ctx, B * n_work * 4 + 64, (void**)&d_common));
+  vector<uint32_t> common(B * n_work);
+  vector<int> rep_of_col(n_work, -1);  // column of `work` -> representative index (new genomes: once they open a cluster)
+  for (size_t r = 0; r < R0; r++) rep_of_col[r] = (int)r;
   int new_clusters = 0, assigned = 0;
-  for (size_t r0 = n_old; r0 < n_all; r0 += B) {
-    const size_t r1 = std::min(n_all, r0 + B);
-    CHECK(ctx, rtc_pair_common_dev(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, (uint32_t)n_all, (uint32_t)r0, (uint32_t)r1, 0,
-                                   (uint32_t)n_all, d_common, (uint64_t)n_all, 1, 0));
-    CHECK(ctx, rtc_copy_d2h(ctx, common.data(), d_common, (r1 - r0) * n_all * 4));
+  for (size_t r0 = R0; r0 < n_work; r0 += B) {
+    const size_t r1 = std::min(n_work, r0 + B);
+    CHECK(ctx, rtc_pair_common_dev(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, (uint32_t)n_work, (uint32_t)r0, (uint32_t)r1, 0,
+                                   (uint32_t)n_work, d_common, (uint64_t)n_work, 1, 0));
+    CHECK(ctx, rtc_copy_d2h(ctx, common.data(), d_common, (r1 - r0) * n_work * 4));
     for (size_t q = r0; q < r1; q++) {
-      const uint32_t* row = common.data() + (q - r0) * n_all;
-      const int sizeQry = (int)len[q];
+      const uint32_t* row = common.data() + (q - r0) * n_work;
+      const int genome_idx = (int)(n_old + (q - R0));
+      const int sizeQry = (int)sketch_len(work, q);
       double best_dist = std::numeric_limits<double>::max();
       int best = -1;
-      for (size_t r = 0; r < q; r++) {
-        if (cid[r] < 0 || row[r] == 0) continue;  // candidates: representatives sharing a hash (:1768-1790)
-        const int sizeRef = (int)len[r], cm = (int)row[r];
+      for (size_t c = 0; c < q; c++) {
+        if (rep_of_col[c] < 0 || row[c] == 0) continue;  // candidates: representatives sharing a hash (:1768-1790)
+        const int sizeRef = (int)sketch_len(work, c), cm = (int)row[c];
         const double ratio = (double)sizeQry / sizeRef;
         if (ratio > radio || ratio < 1.0 / radio) continue;                                              // :1822-1825
         const int min_common_needed = (int)(jaccard_min * (sizeQry + sizeRef) / (1.0 + jaccard_min));    // :1829
         if (cm < min_common_needed) continue;
-        const uint64_t uni = (uint64_t)sizeRef + (uint64_t)sizeQry - (uint64_t)cm;                       // calculate_mash_distance, :103-160
-        const double jac = uni == 0 ? 0.0 : (double)cm / (double)uni;
-        double dist = 0.0;
-        if (jac != 1.0) { dist = -log(2 * jac / (1.0 + jac)) / (double)kmer_size; if (dist > 1.0) dist = 1.0; }
-        if (dist <= threshold && dist < best_dist) { best_dist = dist; best = (int)r; }
+        const double dist = kssd_mash_distance(cm, sizeRef, sizeQry, kmer_size);
+        if (dist <= threshold && dist < best_dist) { best_dist = dist; best = rep_of_col[c]; }
       }
-      if (best >= 0) { cluster[cid[best]].push_back((int)q); assigned++; }
-      else { cid[q] = (int)cluster.size(); cluster.push_back({(int)q}); new_clusters++; }
+      if (best >= 0) { st.clusters[best].push_back(genome_idx); assigned++; }
+      else {
+        rep_of_col[q] = (int)st.rep_ids.size();
+        st.rep_ids.push_back(genome_idx);
+        st.rep_genomes.push_back(add[q - R0]);
+        push_sketch(st.reps, work, q);
+        st.clusters.push_back(vector<int>());
+        new_clusters++;
+      }
     }
   }
+  for (size_t i = 0; i < m; i++) {
+    st.genomes.push_back(add[i]);
+    if (keep_sketches) push_sketch(st.sk, ks2, i);
+  }
+  st.info.genomeNumber = (int)st.genomes.size();
   CHECK(ctx, rtc_dev_free(ctx, d_common));
   CHECK(ctx, rtc_dev_free(ctx, ds.d_hashes)); CHECK(ctx, rtc_dev_free(ctx, ds.d_start)); CHECK(ctx, rtc_dev_free(ctx, ds.d_len));
   cerr << "===== Incremental Clustering Results =====" << endl << "Assigned to existing clusters: " << assigned << endl
-       << "New clusters created: " << new_clusters << endl << "Total clusters now: " << cluster.size() << endl;
+       << "New clusters created: " << new_clusters << endl << "Total clusters now: " << st.clusters.size() << endl;
   return 0;
 }
 
+// the representative part of a state, from clusters whose first member is the representative (src/greedy.cpp:924-934)
 static void fill_cluster_state(KssdClusterState& st, double threshold, int kmer_size, const KssdParameters& info,
                                const vector<GenomeInfo>& genomes, const KssdSketchFile& sk, const vector<vector<int>>& cluster) {
   st.threshold = threshold; st.kmer_size = kmer_size; st.info = info; st.genomes = genomes; st.sk = sk; st.clusters = cluster;
-  st.rep_ids.clear();
-  for (const auto& c : cluster) if (!c.empty()) st.rep_ids.push_back(c[0]);  // src/greedy.cpp:928-934
+  st.rep_ids.clear(); st.rep_genomes.clear();
+  st.reps = KssdSketchFile(); st.reps.info = info; st.reps.use64 = sk.use64;
+  for (const auto& c : cluster) if (!c.empty()) {
+    st.rep_ids.push_back(c[0]);
+    st.rep_genomes.push_back(genomes[c[0]]);
+    push_sketch(st.reps, sk, c[0]);
+  }
+}
+
+// KssdInitialClusterWithState (src/greedy.cpp:900-958): the stored sketches sorted by hash count, descending
+// (comparator without tie-break, :594-597), clustered as clust-greedy --fast does, kept as a state
+static int kssd_initial_state(rtc_ctx* ctx, vector<GenomeInfo>& pre, KssdSketchFile& ks, double threshold, KssdClusterState& st) {
+  const size_t n_pre = pre.size();
+  struct Item { size_t idx; size_t c; };
+  vector<Item> items(n_pre);
+  for (size_t i = 0; i < n_pre; i++) items[i] = Item{i, sketch_len(ks, i)};
+  std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.c > b.c; });
+  vector<GenomeInfo> genomes; KssdSketchFile all; all.info = ks.info; all.use64 = ks.use64;
+  for (const Item& it : items) {
+    genomes.push_back(pre[it.idx]);
+    if (ks.use64) all.h64.push_back(std::move(ks.h64[it.idx])); else all.h32.push_back(std::move(ks.h32[it.idx]));
+  }
+  const int kmer_size = ks.info.half_k * 2;
+  vector<vector<int>> cluster;
+  if (n_pre) {
+    DeviceSketches ds;
+    upload_sketches(ctx, all.use64 ? &all.h64 : nullptr, all.use64 ? nullptr : &all.h32, ds);
+    vector<int32_t> rep_of(n_pre, -1);
+    uint32_t ncl = 0;
+    CHECK(ctx, rtc_greedy(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, (uint32_t)n_pre, nullptr, kmer_size, 0, 1, threshold,
+                          rep_of.data(), &ncl));
+    CHECK(ctx, rtc_dev_free(ctx, ds.d_hashes)); CHECK(ctx, rtc_dev_free(ctx, ds.d_start)); CHECK(ctx, rtc_dev_free(ctx, ds.d_len));
+    cluster = clusters_from_rep_of(rep_of);
+  }
+  fill_cluster_state(st, threshold, kmer_size, ks.info, genomes, all, cluster);
+  return 0;
+}
+
+// compute_kssd_sketches with a state's parameters: the genomes of `list` on the GPU sketcher
+static void sketch_for_state(vector<Gpu>& gpus, const Options& o, const string& list, int kmer_size, int drlevel,
+                             vector<GenomeInfo>& add, KssdSketchFile& ks2) {
+  SketchJob job;
+  job.kssd = true; job.kmerSize = kmer_size; job.drlevel = drlevel; job.minLen = o.minLen; job.threads = o.threads;
+  MinHashSketchFile mh2; Resident rs2;
+  sketch_files(gpus, list, job, add, &mh2, &ks2, rs2, true);
+}
+
+static int save_sketch_folder(const vector<GenomeInfo>& g, const KssdSketchFile& ks, string& folder) {
+  folder = current_date_time();
+  string command = "mkdir -p " + folder;
+  if (system(command.c_str()) != 0) { cerr << "ERROR: cannot create " << folder << endl; return 1; }
+  save_kssd_sketches(g, ks, folder, true);
+  return 0;
 }
 
 // append_clust_greedy_fast (src/sub_command.cpp:192-270).  With DIR/cluster_state.bin ("Incremental Update Mode"):
 // the stored state's sketches, clusters, threshold and k; the new genomes are clustered against its
 // representatives.  Without it ("Initial State Building Mode"): the stored KSSD sketches are clustered as
-// clust-greedy --fast would (KssdInitialClusterWithState = KssdGreedyClusterWithInvertedIndex on the size-sorted
-// sketches, src/greedy.cpp:902-915), then the new genomes as above.  --save-rep (and no -e) writes the state back.
+// clust-greedy --fast would (KssdInitialClusterWithState), then the new genomes as above.  --save-rep (and no -e)
+// writes the state back.
 static int append_clust_greedy_fast(const Options& o, vector<Gpu>& gpus) {
   rtc_ctx* ctx = gpus[0].ctx;
   const string state_file = o.folder_path + "/cluster_state.bin";
@@ -755,95 +853,220 @@ static int append_clust_greedy_fast(const Options& o, vector<Gpu>& gpus) {
   KssdClusterState st;
   struct stat sb;
   bool has_state = stat(state_file.c_str(), &sb) == 0;
+  bool byFile = true;
   if (has_state) {
     cerr << "===== Incremental Update Mode (KSSD) =====" << endl << "Found existing cluster state, loading..." << endl;
     has_state = load_kssd_cluster_state(state_file, st);
   }
-  vector<GenomeInfo> genomes; KssdSketchFile all; vector<vector<int>> cluster; bool byFile = true;
-  KssdParameters info{};
-  double threshold = o.threshold;
-  int kmer_size = 0;
-  size_t n_old = 0;
   if (has_state) {
     cerr << "---the threshold is: " << o.threshold << endl << "---the thread number is: " << o.threads << endl;
-    genomes = std::move(st.genomes); all = std::move(st.sk); cluster = std::move(st.clusters); info = st.info;
-    threshold = st.threshold; kmer_size = st.kmer_size;  // KssdIncrementalCluster works with the state's values
-    n_old = genomes.size();
   } else {
     vector<GenomeInfo> pre; KssdSketchFile ks;
     if (!load_kssd_sketches(o.folder_path, pre, ks, byFile)) return 1;
     if (byFile != o.sketchByFile) cerr << "Warning: the input format of append genomes and pre-sketched genome is not same" << endl;
-    info = ks.info;
-    kmer_size = ks.info.half_k * 2;
     cerr << "===== Initial State Building Mode (KSSD) =====" << endl;
     cerr << "No existing state found, building state from pre-sketched genomes..." << endl;
     cerr << "-----use the same sketch parameters with pre-generated sketches" << endl << "---use the KSSD sketches" << endl
          << "---the half_k is: " << ks.info.half_k << endl << "---the half_subk is: " << ks.info.half_subk << endl
          << "---the drlevel is: " << ks.info.drlevel << endl << "---the threshold is: " << o.threshold << endl;
-    // src/greedy.cpp:594-597: the stored sketches sorted by hash count, descending (comparator without tie-break)
-    const size_t n_pre = pre.size();
-    auto cnt_pre = [&](size_t i) { return ks.use64 ? ks.h64[i].size() : ks.h32[i].size(); };
-    struct Item { size_t idx; size_t c; };
-    vector<Item> items(n_pre);
-    for (size_t i = 0; i < n_pre; i++) items[i] = Item{i, cnt_pre(i)};
-    std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.c > b.c; });
-    all.info = ks.info; all.use64 = ks.use64;
-    for (const Item& it : items) {
-      genomes.push_back(pre[it.idx]);
-      if (ks.use64) all.h64.push_back(std::move(ks.h64[it.idx])); else all.h32.push_back(std::move(ks.h32[it.idx]));
-    }
-    n_old = n_pre;
-    if (n_pre) {
-      DeviceSketches ds;
-      upload_sketches(ctx, all.use64 ? &all.h64 : nullptr, all.use64 ? nullptr : &all.h32, ds);
-      vector<int32_t> rep_of(n_pre, -1);
-      uint32_t ncl = 0;
-      CHECK(ctx, rtc_greedy(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, (uint32_t)n_pre, nullptr, kmer_size, 0, 1, o.threshold,
-                            rep_of.data(), &ncl));
-      CHECK(ctx, rtc_dev_free(ctx, ds.d_hashes)); CHECK(ctx, rtc_dev_free(ctx, ds.d_start)); CHECK(ctx, rtc_dev_free(ctx, ds.d_len));
-      cluster = clusters_from_rep_of(rep_of);
-    }
+    if (kssd_initial_state(ctx, pre, ks, o.threshold, st) != 0) return 1;
   }
-  // ---- the new genomes, with the stored parameters ----
-  SketchJob job;
-  job.kssd = true; job.kmerSize = kmer_size; job.drlevel = info.drlevel; job.minLen = o.minLen; job.threads = o.threads;
-  vector<GenomeInfo> add; MinHashSketchFile mh2; KssdSketchFile ks2; Resident rs2;
-  sketch_files(gpus, o.inputFile, job, add, &mh2, &ks2, rs2, true);
-  if (!add.empty() && n_old && ks2.use64 != all.use64) { cerr << "ERROR: appended sketches and stored sketches differ in hash width" << endl; return 1; }
-  if (n_old == 0) all.use64 = ks2.use64;
+  // ---- the new genomes, with the stored parameters (KssdIncrementalCluster works with the state's threshold and k) ----
+  vector<GenomeInfo> add; KssdSketchFile ks2;
+  sketch_for_state(gpus, o, o.inputFile, st.kmer_size, st.info.drlevel, add, ks2);
   cerr << "New genomes sketched: " << add.size() << endl;
   cerr << "========time of computing sketch is: " << get_sec() - t0 << "========" << endl;
   if (!o.noSave) {  // compute_kssd_sketches(isSave): the appended sketches get a folder of their own
-    const string folder = current_date_time();
-    string command = "mkdir -p " + folder;
-    if (system(command.c_str()) != 0) { cerr << "ERROR: cannot create " << folder << endl; return 1; }
-    save_kssd_sketches(add, ks2, folder, true);
+    string folder;
+    if (save_sketch_folder(add, ks2, folder) != 0) return 1;
   }
   double t2 = get_sec();
-  for (size_t i = 0; i < add.size(); i++) {
-    genomes.push_back(add[i]);
-    if (all.use64) all.h64.push_back(std::move(ks2.h64[i])); else all.h32.push_back(std::move(ks2.h32[i]));
-  }
-  if (!has_state) for (size_t i = 0; i < genomes.size(); i++) genomes[i].id = (int)i;  // (a stored state keeps the ids it holds)
-  if (kssd_incremental_cluster(ctx, all, n_old, threshold, kmer_size, cluster) != 0) return 1;
+  if (kssd_incremental_cluster(ctx, st, add, ks2, true) != 0) return 1;
   if (!o.noSave && o.saveRep) {
-    KssdClusterState out;
-    info.genomeNumber = (int)genomes.size();
-    fill_cluster_state(out, threshold, kmer_size, info, genomes, all, cluster);
-    if (!save_kssd_cluster_state(state_file, out)) return 1;
+    if (!save_kssd_cluster_state(state_file, st)) return 1;
     cerr << "-----saved cluster state (with inverted index) for future incremental updates" << endl;
   }
-  print_result(cluster, genomes, byFile, o.outputFile);
+  print_result(st.clusters, st.genomes, byFile, o.outputFile);
   cerr << "-----write the cluster result into: " << o.outputFile << endl;
-  cerr << "-----the cluster number of " << o.outputFile << " is: " << cluster.size() << endl;
+  cerr << "-----the cluster number of " << o.outputFile << " is: " << st.clusters.size() << endl;
   cerr << "========time of greedyCluster is: " << get_sec() - t2 << "========" << endl;
+  return 0;
+}
+
+// ---- RepDB of clust-greedy --fast --db (src/sub_command.cpp:276-475, src/main.cpp:300-334) ----
+static void repdb_build_summary(size_t total, size_t reps, const string& db) {
+  cerr << "\n===== RepDB Build Summary =====" << endl << "  Total genomes:    " << total << endl << "  Representatives:  " << reps << endl
+       << "  Compression:      " << std::fixed << std::setprecision(2) << (1.0 - (double)reps / total) * 100.0 << "%" << endl
+       << "  RepDB saved to:   " << db << endl << "===============================" << endl;
+}
+
+// repdb_build_from_sketch / repdb_build_from_genome (src/sub_command.cpp:278-334)
+static int repdb_build(const Options& o, vector<Gpu>& gpus) {
+  rtc_ctx* ctx = gpus[0].ctx;
+  vector<GenomeInfo> pre; KssdSketchFile ks; bool byFile = true;
+  if (o.has_presketched) {
+    if (!load_kssd_sketches(o.folder_path, pre, ks, byFile)) return 1;
+    cerr << "===== RepDB Build (from pre-sketched) =====" << endl;
+  } else {
+    if (!o.sketchByFile) unsupported("single-FASTA input (run with -l and a genome list)");
+    int kmerSize = o.kmerSize;
+    if (!o.isSetKmer) { kmerSize = 19; cerr << "-----use default kmerSize: " << kmerSize << endl; }
+    sketch_for_state(gpus, o, o.inputFile, kmerSize, o.drlevel, pre, ks);
+    string folder;
+    if (save_sketch_folder(pre, ks, folder) != 0) return 1;   // compute_kssd_sketches(isSave = true)
+    cerr << "===== RepDB Build (from genomes) =====" << endl;
+  }
+  cerr << "  Genomes:    " << pre.size() << endl << "  Threshold:  " << o.threshold << endl << "  Kmer size:  " << ks.info.half_k * 2 << endl;
+  if (pre.empty()) { cerr << "ERROR: no genome to cluster" << endl; return 1; }
+  KssdClusterState st;
+  if (kssd_initial_state(ctx, pre, ks, o.threshold, st) != 0) return 1;
+  if (!save_kssd_repdb(o.repdb_path, st)) return 1;
+  if (!o.outputFile.empty()) {
+    print_result(st.clusters, st.genomes, byFile, o.outputFile, o.threshold);
+    cerr << "-----write the cluster result into: " << o.outputFile << endl;
+  }
+  repdb_build_summary(st.genomes.size(), st.rep_ids.size(), o.repdb_path);
+  return 0;
+}
+
+struct RepHit { int rep_idx; double distance; };
+
+// KssdClusterState::query_topk for every query (src/greedy.cpp:2539-2637): the representatives that share a hash
+// with the query and pass the size-ratio and minimum-common filters, ordered by Mash distance (ties: earlier
+// representative first -- the reference's std::sort leaves them in hash-map order), the first `topk` kept.  One
+// rectangular intersection launch (rows = queries, columns = representatives) stands in for the index walk.
+static int repdb_query_topk(rtc_ctx* ctx, const KssdClusterState& st, const KssdSketchFile& qs, int topk, vector<vector<RepHit>>& out) {
+  const size_t R = st.rep_ids.size(), Q = sketch_count(qs);
+  out.assign(Q, vector<RepHit>());
+  if (R == 0 || Q == 0) return 0;
+  if (qs.use64 != st.reps.use64) { cerr << "ERROR: query sketches and the RepDB differ in hash width" << endl; return 1; }
+  KssdSketchFile work;
+  reps_then(st, qs, work);
+  DeviceSketches ds;
+  upload_sketches(ctx, work.use64 ? &work.h64 : nullptr, work.use64 ? nullptr : &work.h32, ds);
+  const double radio = 2.0 * exp(st.threshold * st.kmer_size) - 1.0;
+  const double x = exp(-st.threshold * st.kmer_size), jaccard_min = x / (2.0 - x);
+  const size_t B = std::max<size_t>(1, std::min<size_t>(Q, ((size_t)256 << 20) / (R * 4)));
+  uint32_t* d_common = nullptr;
+  CHECK(ctx, rtc_dev_alloc(ctx, B * R * 4 + 64, (void**)&d_common));
+  vector<uint32_t> common(B * R);
+  for (size_t q0 = 0; q0 < Q; q0 += B) {
+    const size_t q1 = std::min(Q, q0 + B);
+    CHECK(ctx, rtc_pair_common_dev(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, (uint32_t)(R + Q), (uint32_t)(R + q0), (uint32_t)(R + q1), 0,
+                                   (uint32_t)R, d_common, (uint64_t)R, 0, 0));
+    CHECK(ctx, rtc_copy_d2h(ctx, common.data(), d_common, (q1 - q0) * R * 4));
+    for (size_t q = q0; q < q1; q++) {
+      const uint32_t* row = common.data() + (q - q0) * R;
+      const int sizeQry = (int)sketch_len(qs, q);
+      vector<RepHit> scored;
+      for (size_t r = 0; r < R; r++) {
+        if (row[r] == 0) continue;
+        const int sizeRef = (int)sketch_len(st.reps, r), cm = (int)row[r];
+        const double ratio = (double)sizeQry / sizeRef;
+        if (ratio > radio || ratio < 1.0 / radio) continue;
+        const int min_common = (int)(jaccard_min * (sizeQry + sizeRef) / (1.0 + jaccard_min));
+        if (cm < min_common) continue;
+        scored.push_back(RepHit{(int)r, kssd_mash_distance(cm, sizeRef, sizeQry, st.kmer_size)});
+      }
+      std::stable_sort(scored.begin(), scored.end(), [](const RepHit& a, const RepHit& b) { return a.distance < b.distance; });
+      if ((int)scored.size() > topk) scored.resize(std::max(topk, 0));
+      out[q] = std::move(scored);
+    }
+  }
+  CHECK(ctx, rtc_dev_free(ctx, d_common));
+  CHECK(ctx, rtc_dev_free(ctx, ds.d_hashes)); CHECK(ctx, rtc_dev_free(ctx, ds.d_start)); CHECK(ctx, rtc_dev_free(ctx, ds.d_len));
+  return 0;
+}
+
+static int repdb_load_and_sketch(const Options& o, vector<Gpu>& gpus, KssdClusterState& st, vector<GenomeInfo>& q, KssdSketchFile& qs) {
+  if (!load_kssd_repdb(o.repdb_path, st)) { cerr << "ERROR: Failed to load RepDB from: " << o.repdb_path << endl; return 1; }
+  if (!o.sketchByFile) unsupported("single-FASTA input (run with -l and a genome list)");
+  sketch_for_state(gpus, o, o.inputFile, st.kmer_size, st.info.drlevel, q, qs);
+  return 0;
+}
+
+// repdb_query (src/sub_command.cpp:337-393)
+static int repdb_query(const Options& o, vector<Gpu>& gpus) {
+  KssdClusterState st; vector<GenomeInfo> q; KssdSketchFile qs;
+  if (repdb_load_and_sketch(o, gpus, st, q, qs) != 0) return 1;
+  cerr << "===== RepDB Query =====" << endl << "  Query genomes:  " << q.size() << endl << "  Top-k:          " << o.topk << endl
+       << "  DB reps:        " << st.rep_ids.size() << endl;
+  vector<vector<RepHit>> hits;
+  if (repdb_query_topk(gpus[0].ctx, st, qs, o.topk, hits) != 0) return 1;
+  FILE* fp = fopen(o.outputFile.c_str(), "w");
+  if (!fp) { cerr << "ERROR: Cannot open output file: " << o.outputFile << endl; return 1; }
+  fprintf(fp, "#query\trank\trep_name\tdistance\tcluster_id\tcluster_size\n");
+  for (size_t i = 0; i < q.size(); i++) {
+    string qname = q[i].fileName;
+    if (qname.empty()) qname = "query_" + std::to_string(i);
+    if (hits[i].empty()) fprintf(fp, "%s\t0\tno_match\t-1\t-1\t0\n", qname.c_str());
+    else for (size_t r = 0; r < hits[i].size(); r++) {
+      const int ri = hits[i][r].rep_idx;
+      fprintf(fp, "%s\t%d\t%s\t%.6f\t%d\t%d\n", qname.c_str(), (int)r + 1, st.rep_genomes[ri].fileName.c_str(), hits[i][r].distance, ri,
+              (int)st.clusters[ri].size());
+    }
+  }
+  fclose(fp);
+  cerr << "===== Query Results =====" << endl << "  Output: " << o.outputFile << endl << "=========================" << endl;
+  return 0;
+}
+
+// repdb_assign (src/sub_command.cpp:395-452; KssdClusterState::assign, src/greedy.cpp:2639-2654)
+static int repdb_assign(const Options& o, vector<Gpu>& gpus) {
+  KssdClusterState st; vector<GenomeInfo> q; KssdSketchFile qs;
+  if (repdb_load_and_sketch(o, gpus, st, q, qs) != 0) return 1;
+  cerr << "===== RepDB Assignment =====" << endl << "  Query genomes:  " << q.size() << endl << "  DB reps:        " << st.rep_ids.size() << endl
+       << "  Threshold:      " << st.threshold << endl;
+  vector<vector<RepHit>> hits;
+  if (repdb_query_topk(gpus[0].ctx, st, qs, 1, hits) != 0) return 1;
+  FILE* fp = fopen(o.outputFile.c_str(), "w");
+  if (!fp) { cerr << "ERROR: Cannot open output file: " << o.outputFile << endl; return 1; }
+  fprintf(fp, "#query\tassigned_cluster\trep_name\tdistance\tcluster_size\tstatus\n");
+  int assigned = 0, unassigned = 0;
+  for (size_t i = 0; i < q.size(); i++) {
+    string qname = q[i].fileName;
+    if (qname.empty()) qname = "query_" + std::to_string(i);
+    if (!hits[i].empty() && hits[i][0].distance <= st.threshold) {
+      const int ri = hits[i][0].rep_idx;
+      fprintf(fp, "%s\t%d\t%s\t%.6f\t%d\tassigned\n", qname.c_str(), ri, st.rep_genomes[ri].fileName.c_str(), hits[i][0].distance,
+              (int)st.clusters[ri].size());
+      assigned++;
+    } else {
+      fprintf(fp, "%s\t-1\tunassigned\t-1\t0\tnovel\n", qname.c_str());
+      unassigned++;
+    }
+  }
+  fclose(fp);
+  cerr << "===== Assignment Results =====" << endl
+       << "  Assigned:    " << assigned << " (" << std::fixed << std::setprecision(1) << (100.0 * assigned / q.size()) << "%)" << endl
+       << "  Novel:       " << unassigned << " (" << std::fixed << std::setprecision(1) << (100.0 * unassigned / q.size()) << "%)" << endl
+       << "  Output:      " << o.outputFile << endl << "==============================" << endl;
+  return 0;
+}
+
+// repdb_append (src/sub_command.cpp:454-500)
+static int repdb_append(const Options& o, vector<Gpu>& gpus) {
+  KssdClusterState st; vector<GenomeInfo> add; KssdSketchFile ks2;
+  if (repdb_load_and_sketch(o, gpus, st, add, ks2) != 0) return 1;
+  const size_t old_reps = st.rep_ids.size(), old_total = st.genomes.size();
+  cerr << "===== RepDB Append =====" << endl << "  Existing reps:    " << old_reps << endl << "  Existing genomes: " << old_total << endl
+       << "  New genomes:      " << add.size() << endl;
+  if (kssd_incremental_cluster(gpus[0].ctx, st, add, ks2, false) != 0) return 1;
+  if (!save_kssd_repdb(o.repdb_path, st)) return 1;
+  if (!o.outputFile.empty()) {
+    print_result(st.clusters, st.genomes, true, o.outputFile, st.threshold);
+    cerr << "-----write the cluster result into: " << o.outputFile << endl;
+  }
+  cerr << "\n===== Append Summary =====" << endl << "  New reps added:   " << st.rep_ids.size() - old_reps << endl
+       << "  Total reps now:   " << st.rep_ids.size() << endl << "  Total genomes:    " << st.genomes.size() << endl
+       << "  RepDB updated:    " << o.repdb_path << endl << "==========================" << endl;
   return 0;
 }
 #endif
 
 int main(int argc, char** argv) {
   Options o = parse(argc, argv);
-  if (!o.has_output) { cerr << "ERROR: option -o/--output is required (unless --buildDB or --stats is used)" << endl; return 1; }
+  if (!o.has_output && !o.db_stats) { cerr << "ERROR: option -o/--output is required (unless --buildDB or --stats is used)" << endl; return 1; }
   if (o.threads < 1) { fprintf(stderr, "-----Invalid thread number %d\n", o.threads); return 1; }
   fprintf(stderr, "-----set the thread number %d\n", o.threads);
 #ifdef GREEDY_CLUST
@@ -852,8 +1075,25 @@ int main(int argc, char** argv) {
   if (!o.has_threshold) { o.threshold = 0.05; cerr << "-----use default threshold: " << o.threshold << endl; }
 
 #ifdef GREEDY_CLUST
+  // ---- RepDB mode (src/main.cpp:160-170, :300-370) ----
+  const bool db_action = o.db_build || o.db_query || o.db_assign || o.db_stats;
+  if (db_action && o.repdb_path.empty()) { cerr << "ERROR: --build / --query / --assign / --stats require --db" << endl; return 1; }
+  if ((int)o.db_build + (int)o.db_query + (int)o.db_assign + (int)o.db_stats > 1) { cerr << "ERROR: --build, --query, --assign and --stats exclude each other" << endl; return 1; }
+  if (!o.repdb_path.empty()) {
+    if (!o.is_fast) unsupported("--db on MinHash sketches (the MinHash RepDB); --fast");
+    if (o.db_stats) {
+      KssdClusterState st;
+      if (!load_kssd_repdb(o.repdb_path, st)) { cerr << "ERROR: Failed to load RepDB from: " << o.repdb_path << endl; return 1; }
+      print_kssd_repdb_stats(st, std::cout);
+      return 0;
+    }
+    if (o.db_build && !o.has_presketched && !o.has_input) { cerr << "ERROR: --build requires --presketched <folder> or -i <genome_list> -l" << endl; return 1; }
+    if (o.db_query && !o.has_input) { cerr << "ERROR: --query requires -i <input_file>" << endl; return 1; }
+    if (o.db_assign && !o.has_input) { cerr << "ERROR: --assign requires -i <input_file>" << endl; return 1; }
+    if (!db_action && !o.has_append) { cerr << "ERROR: --db requires one of: --build, --query, --assign, --append, --stats" << endl; return 1; }
+  }
   if (o.has_append && o.has_input) { cerr << "ERROR: --append and -i/--input exclude each other" << endl; return 1; }
-  if (o.has_append && !o.has_presketched) { cerr << "ERROR option --append, option --presketched needed" << endl; return 1; }  // src/main.cpp:378-381
+  if (o.has_append && !o.has_presketched && o.repdb_path.empty()) { cerr << "ERROR option --append, option --presketched needed" << endl; return 1; }  // src/main.cpp:378-381
 #endif
 #ifndef GREEDY_CLUST
   // ---- --premsted: no sketching, no GPU (clust_from_mst[_fast], src/sub_command.cpp:1760-1934) ----
@@ -910,6 +1150,12 @@ int main(int argc, char** argv) {
 #ifndef GREEDY_CLUST
   if (o.has_append) return append_clust_mst(o, gpus);
 #else
+  if (!o.repdb_path.empty()) {
+    const int rc = o.db_build ? repdb_build(o, gpus) : o.db_query ? repdb_query(o, gpus) : o.db_assign ? repdb_assign(o, gpus) : repdb_append(o, gpus);
+    for (Gpu& g : gpus) { if (g.comm) rtc_comm_destroy(g.comm); }
+    for (Gpu& g : gpus) rtc_ctx_destroy(g.ctx);
+    return rc;
+  }
   if (o.has_append) {  // src/main.cpp:378-387
     if (!o.is_fast) unsupported("clust-greedy --append on MinHash sketches (Sketch::MinHash::distance() of the absent RabbitSketch decides there); --fast");
     const int rc = append_clust_greedy_fast(o, gpus);

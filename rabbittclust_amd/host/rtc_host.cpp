@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <fstream>
+#include <iomanip>
 #include <iostream>
 #include <queue>
 
@@ -896,46 +897,14 @@ std::vector<std::vector<int>> generate_cluster_with_bfs(const std::vector<rtc_ed
   return res;
 }
 
-// src/MST_IO.cpp:72-179 (printResult / printKssdResult share the layout)
-// src/greedy.cpp:1545-1625
-bool save_kssd_cluster_state(const std::string& path, const KssdClusterState& st) {
-  FILE* fp = fopen(path.c_str(), "wb");
-  if (!fp) { std::cerr << "ERROR: Cannot open file for writing: " << path << std::endl; return false; }
-  wr(fp, st.threshold); wr(fp, st.kmer_size);
-  wr(fp, st.info.half_k); wr(fp, st.info.half_subk); wr(fp, st.info.drlevel); wr(fp, st.info.genomeNumber);
-  const size_t rep_count = st.rep_ids.size();
-  wr(fp, rep_count);
-  fwrite(st.rep_ids.data(), sizeof(int), rep_count, fp);
-  const size_t sketch_count = st.genomes.size();
-  wr(fp, sketch_count);
-  for (size_t i = 0; i < sketch_count; i++) {
-    const GenomeInfo& g = st.genomes[i];
-    const bool use64 = st.sk.use64;
-    const size_t n32 = use64 ? 0 : st.sk.h32[i].size(), n64 = use64 ? st.sk.h64[i].size() : 0;
-    const uint32_t sketchsize = (uint32_t)(n32 + n64);
-    wr(fp, g.id); wr(fp, g.totalSeqLength); wr(fp, use64); wr(fp, sketchsize);
-    wr(fp, n32); wr(fp, n64);
-    if (n32) fwrite(st.sk.h32[i].data(), 4, n32, fp);
-    if (n64) fwrite(st.sk.h64[i].data(), 8, n64, fp);
-    const size_t name_len = g.fileName.size();
-    wr(fp, name_len);
-    fwrite(g.fileName.data(), 1, name_len, fp);
-  }
-  const size_t cluster_count = st.clusters.size();
-  wr(fp, cluster_count);
-  for (const auto& c : st.clusters) {
-    const size_t m = c.size();
-    wr(fp, m);
-    fwrite(c.data(), sizeof(int), m, fp);
-  }
-  // representatives' inverted index: marker + 64-bit keys
-  const char magic[8] = {'K', 'S', 'S', 'I', '0', '2', '\0', '\0'};
-  fwrite(magic, 1, 8, fp);
+// the representatives' inverted index as the reference's writers lay it out (hash, list length, positions in
+// rep_ids); keys ascending here (the reference walks a hash map)
+static size_t write_rep_index(FILE* fp, const KssdClusterState& st) {
   std::vector<std::pair<uint64_t, int>> post;
+  const size_t rep_count = st.reps.use64 ? st.reps.h64.size() : st.reps.h32.size();
   for (size_t r = 0; r < rep_count; r++) {
-    const int g = st.rep_ids[r];
-    if (st.sk.use64) for (uint64_t h : st.sk.h64[g]) post.emplace_back(h, (int)r);
-    else for (uint32_t h : st.sk.h32[g]) post.emplace_back((uint64_t)h, (int)r);
+    if (st.reps.use64) for (uint64_t h : st.reps.h64[r]) post.emplace_back(h, (int)r);
+    else for (uint32_t h : st.reps.h32[r]) post.emplace_back((uint64_t)h, (int)r);
   }
   std::sort(post.begin(), post.end());
   size_t index_size = 0;
@@ -950,6 +919,65 @@ bool save_kssd_cluster_state(const std::string& path, const KssdClusterState& st
     for (size_t q = i; q < j; q++) wr(fp, post[q].second);
     i = j;
   }
+  return index_size;
+}
+
+static void write_state_sketch(FILE* fp, const GenomeInfo& g, const KssdSketchFile& sk, size_t i) {
+  const bool use64 = sk.use64;
+  const size_t n32 = use64 ? 0 : sk.h32[i].size(), n64 = use64 ? sk.h64[i].size() : 0;
+  const uint32_t sketchsize = (uint32_t)(n32 + n64);
+  wr(fp, g.id); wr(fp, g.totalSeqLength); wr(fp, use64); wr(fp, sketchsize);
+  wr(fp, n32); wr(fp, n64);
+  if (n32) fwrite(sk.h32[i].data(), 4, n32, fp);
+  if (n64) fwrite(sk.h64[i].data(), 8, n64, fp);
+  const size_t name_len = g.fileName.size();
+  wr(fp, name_len);
+  fwrite(g.fileName.data(), 1, name_len, fp);
+}
+
+static bool read_state_sketch(FILE* fp, GenomeInfo& g, KssdSketchFile& sk, bool first) {
+  bool use64 = false; uint32_t sketchsize = 0; size_t n32 = 0, n64 = 0, name_len = 0;
+  bool ok = rd(fp, g.id) && rd(fp, g.totalSeqLength) && rd(fp, use64) && rd(fp, sketchsize) && rd(fp, n32) && rd(fp, n64) &&
+            n32 < ((size_t)1 << 32) && n64 < ((size_t)1 << 32);
+  if (!ok) return false;
+  if (first) sk.use64 = use64;
+  std::vector<uint32_t> h32(n32); std::vector<uint64_t> h64(n64);
+  if (n32) ok = ok && fread(h32.data(), 4, n32, fp) == n32;
+  if (n64) ok = ok && fread(h64.data(), 8, n64, fp) == n64;
+  ok = ok && rd(fp, name_len) && name_len < ((size_t)1 << 20);
+  if (!ok) return false;
+  g.fileName.resize(name_len);
+  if (name_len) ok = fread(&g.fileName[0], 1, name_len, fp) == name_len;
+  g.use64 = use64;
+  g.seq0.name = "N/A"; g.seq0.comment = "N/A";   // printKssdResult's text for sketches without record infos (src/MST_IO.cpp:99-104)
+  if (sk.use64) sk.h64.push_back(std::move(h64)); else sk.h32.push_back(std::move(h32));
+  return ok;
+}
+
+// src/MST_IO.cpp:72-179 (printResult / printKssdResult share the layout)
+// src/greedy.cpp:1545-1625
+bool save_kssd_cluster_state(const std::string& path, const KssdClusterState& st) {
+  FILE* fp = fopen(path.c_str(), "wb");
+  if (!fp) { std::cerr << "ERROR: Cannot open file for writing: " << path << std::endl; return false; }
+  wr(fp, st.threshold); wr(fp, st.kmer_size);
+  wr(fp, st.info.half_k); wr(fp, st.info.half_subk); wr(fp, st.info.drlevel); wr(fp, st.info.genomeNumber);
+  const size_t rep_count = st.rep_ids.size();
+  wr(fp, rep_count);
+  fwrite(st.rep_ids.data(), sizeof(int), rep_count, fp);
+  const size_t sketch_count = st.genomes.size();
+  wr(fp, sketch_count);
+  for (size_t i = 0; i < sketch_count; i++) write_state_sketch(fp, st.genomes[i], st.sk, i);
+  const size_t cluster_count = st.clusters.size();
+  wr(fp, cluster_count);
+  for (const auto& c : st.clusters) {
+    const size_t m = c.size();
+    wr(fp, m);
+    fwrite(c.data(), sizeof(int), m, fp);
+  }
+  // representatives' inverted index: marker + 64-bit keys
+  const char magic[8] = {'K', 'S', 'S', 'I', '0', '2', '\0', '\0'};
+  fwrite(magic, 1, 8, fp);
+  const size_t index_size = write_rep_index(fp, st);
   fclose(fp);
   std::cerr << "Saved clustering state to: " << path << std::endl
             << "  - " << sketch_count << " genomes" << std::endl
@@ -971,22 +999,9 @@ bool load_kssd_cluster_state(const std::string& path, KssdClusterState& st) {
   ok = ok && rd(fp, sketch_count) && sketch_count < ((size_t)1 << 31);
   st.genomes.clear(); st.sk.h32.clear(); st.sk.h64.clear(); st.sk.info = st.info;
   for (size_t i = 0; ok && i < sketch_count; i++) {
-    GenomeInfo g; bool use64 = false; uint32_t sketchsize = 0; size_t n32 = 0, n64 = 0, name_len = 0;
-    ok = rd(fp, g.id) && rd(fp, g.totalSeqLength) && rd(fp, use64) && rd(fp, sketchsize) && rd(fp, n32) && rd(fp, n64) &&
-         n32 < ((size_t)1 << 32) && n64 < ((size_t)1 << 32);
-    if (!ok) break;
-    if (i == 0) st.sk.use64 = use64;
-    std::vector<uint32_t> h32(n32); std::vector<uint64_t> h64(n64);
-    if (n32) ok = ok && fread(h32.data(), 4, n32, fp) == n32;
-    if (n64) ok = ok && fread(h64.data(), 8, n64, fp) == n64;
-    ok = ok && rd(fp, name_len) && name_len < ((size_t)1 << 20);
-    if (!ok) break;
-    g.fileName.resize(name_len);
-    if (name_len) ok = fread(&g.fileName[0], 1, name_len, fp) == name_len;
-    g.use64 = use64;
-    g.seq0.name = "N/A"; g.seq0.comment = "N/A";   // printKssdResult's text for sketches without record infos (src/MST_IO.cpp:99-104)
-    st.genomes.push_back(g);
-    if (st.sk.use64) st.sk.h64.push_back(std::move(h64)); else st.sk.h32.push_back(std::move(h32));
+    GenomeInfo g;
+    ok = read_state_sketch(fp, g, st.sk, i == 0);
+    if (ok) st.genomes.push_back(g);
   }
   ok = ok && rd(fp, cluster_count) && cluster_count < ((size_t)1 << 31);
   st.clusters.clear();
@@ -1001,10 +1016,191 @@ bool load_kssd_cluster_state(const std::string& path, KssdClusterState& st) {
   fclose(fp);
   if (!ok) { std::cerr << "ERROR: truncated or malformed cluster state: " << path << std::endl; return false; }
   for (int r : st.rep_ids) if (r < 0 || (size_t)r >= st.genomes.size()) { std::cerr << "ERROR: Representative ID " << r << " out of range" << std::endl; return false; }
+  if (st.clusters.size() != rep_count) { std::cerr << "ERROR: " << st.clusters.size() << " clusters for " << rep_count << " representatives" << std::endl; return false; }
+  st.reps = KssdSketchFile(); st.reps.info = st.info; st.reps.use64 = st.sk.use64; st.rep_genomes.clear();
+  for (int r : st.rep_ids) {   // representatives = all_sketches[representative_ids] (src/greedy.cpp:1676-1685)
+    st.rep_genomes.push_back(st.genomes[r]);
+    if (st.sk.use64) st.reps.h64.push_back(st.sk.h64[r]); else st.reps.h32.push_back(st.sk.h32[r]);
+  }
   std::cerr << "Loaded clustering state from: " << path << std::endl
             << "  - " << sketch_count << " genomes" << std::endl
             << "  - " << rep_count << " clusters (representatives)" << std::endl;
   return true;
+}
+
+// src/greedy.cpp:2351-2428
+bool save_kssd_repdb(const std::string& path, const KssdClusterState& st) {
+  FILE* fp = fopen(path.c_str(), "wb");
+  if (!fp) { std::cerr << "ERROR: Cannot open RepDB file for writing: " << path << std::endl; return false; }
+  fwrite("REPDB002", 1, 8, fp);
+  wr(fp, st.threshold); wr(fp, st.kmer_size);
+  wr(fp, st.info.half_k); wr(fp, st.info.half_subk); wr(fp, st.info.drlevel); wr(fp, st.info.genomeNumber);
+  const size_t rep_count = st.rep_ids.size();
+  wr(fp, rep_count);
+  for (size_t r = 0; r < rep_count; r++) {
+    wr(fp, st.rep_ids[r]);
+    write_state_sketch(fp, st.rep_genomes[r], st.reps, r);
+  }
+  const size_t cluster_count = st.clusters.size();
+  wr(fp, cluster_count);
+  for (const auto& c : st.clusters) {
+    const size_t m = c.size();
+    wr(fp, m);
+    fwrite(c.data(), sizeof(int), m, fp);
+  }
+  const size_t all_count = st.genomes.size();
+  wr(fp, all_count);
+  for (const GenomeInfo& g : st.genomes) {
+    const size_t name_len = g.fileName.size();
+    wr(fp, name_len);
+    fwrite(g.fileName.data(), 1, name_len, fp);
+    wr(fp, g.totalSeqLength);
+  }
+  const size_t index_size = write_rep_index(fp, st);
+  fclose(fp);
+  std::cerr << "RepDB saved to: " << path << std::endl
+            << "  Representatives: " << rep_count << std::endl
+            << "  Total genomes:   " << all_count << std::endl
+            << "  Inverted index:  " << index_size << " unique hashes" << std::endl;
+  return true;
+}
+
+// src/greedy.cpp:2430-2537
+bool load_kssd_repdb(const std::string& path, KssdClusterState& st) {
+  FILE* fp = fopen(path.c_str(), "rb");
+  if (!fp) { std::cerr << "ERROR: Cannot open RepDB file for reading: " << path << std::endl; return false; }
+  char magic[8] = {0};
+  if (fread(magic, 1, 8, fp) != 8 || (memcmp(magic, "REPDB002", 8) != 0 && memcmp(magic, "REPDB001", 8) != 0)) {
+    std::cerr << "ERROR: Invalid RepDB file (bad magic): " << path << std::endl;
+    fclose(fp);
+    return false;
+  }
+  const bool v2 = memcmp(magic, "REPDB002", 8) == 0;
+  bool ok = rd(fp, st.threshold) && rd(fp, st.kmer_size) && rd(fp, st.info.half_k) && rd(fp, st.info.half_subk) &&
+            rd(fp, st.info.drlevel) && rd(fp, st.info.genomeNumber);
+  size_t rep_count = 0, cluster_count = 0, all_count = 0, index_size = 0;
+  ok = ok && rd(fp, rep_count) && rep_count < ((size_t)1 << 31);
+  st.rep_ids.clear(); st.rep_genomes.clear(); st.genomes.clear(); st.clusters.clear();
+  st.sk = KssdSketchFile(); st.reps = KssdSketchFile(); st.reps.info = st.info; st.sk.info = st.info;
+  for (size_t r = 0; ok && r < rep_count; r++) {
+    int rid = 0; GenomeInfo g;
+    ok = rd(fp, rid) && read_state_sketch(fp, g, st.reps, r == 0);
+    if (ok) { st.rep_ids.push_back(rid); st.rep_genomes.push_back(g); }
+  }
+  st.sk.use64 = st.reps.use64;
+  ok = ok && rd(fp, cluster_count) && cluster_count < ((size_t)1 << 31);
+  for (size_t c = 0; ok && c < cluster_count; c++) {
+    size_t m = 0;
+    ok = rd(fp, m) && m < ((size_t)1 << 31);
+    if (!ok) break;
+    std::vector<int> cl(m);
+    if (m) ok = fread(cl.data(), sizeof(int), m, fp) == m;
+    st.clusters.push_back(std::move(cl));
+  }
+  ok = ok && rd(fp, all_count) && all_count < ((size_t)1 << 31);
+  for (size_t i = 0; ok && i < all_count; i++) {
+    GenomeInfo g; size_t name_len = 0;
+    ok = rd(fp, name_len) && name_len < ((size_t)1 << 20);
+    if (!ok) break;
+    g.fileName.resize(name_len);
+    if (name_len) ok = fread(&g.fileName[0], 1, name_len, fp) == name_len;
+    ok = ok && rd(fp, g.totalSeqLength);
+    g.id = 0; g.use64 = st.reps.use64;   // load_repdb fills only the name and the length of all_sketches
+    g.seq0.name = "N/A"; g.seq0.comment = "N/A";
+    st.genomes.push_back(g);
+  }
+  ok = ok && rd(fp, index_size);
+  for (size_t i = 0; ok && i < index_size; i++) {   // walked for the truncation check only
+    uint64_t h64 = 0; uint32_t h32 = 0; size_t ls = 0;
+    ok = (v2 ? rd(fp, h64) : rd(fp, h32)) && rd(fp, ls) && ls < ((size_t)1 << 31) && fseek(fp, (long)(ls * sizeof(int)), SEEK_CUR) == 0;
+  }
+  fclose(fp);
+  if (!ok) { std::cerr << "ERROR: truncated or malformed RepDB: " << path << std::endl; return false; }
+  if (st.clusters.size() != rep_count) { std::cerr << "ERROR: " << st.clusters.size() << " clusters for " << rep_count << " representatives" << std::endl; return false; }
+  std::cerr << "RepDB loaded from: " << path << std::endl
+            << "  Representatives: " << rep_count << std::endl
+            << "  Total genomes:   " << all_count << std::endl
+            << "  Inverted index:  " << index_size << " unique hashes" << std::endl
+            << "  Threshold:       " << st.threshold << std::endl
+            << "  Kmer size:       " << st.kmer_size << std::endl;
+  return true;
+}
+
+// src/greedy.cpp:2656-2765
+void print_kssd_repdb_stats(const KssdClusterState& st, std::ostream& out) {
+  size_t total_genomes = 0;
+  for (const auto& cl : st.clusters) total_genomes += cl.size();
+  const size_t nrep = st.rep_ids.size();
+  auto rep_size = [&](size_t r) { return st.reps.use64 ? st.reps.h64[r].size() : st.reps.h32[r].size(); };
+  out << "========================================" << std::endl;
+  out << "        RepDB Statistics Report" << std::endl;
+  out << "========================================" << std::endl << std::endl;
+  out << "[Basic Info]" << std::endl;
+  out << "  Threshold:              " << st.threshold << std::endl;
+  out << "  Kmer size:              " << st.kmer_size << std::endl;
+  out << "  KSSD half_k:            " << st.info.half_k << std::endl;
+  out << "  KSSD half_subk:         " << st.info.half_subk << std::endl;
+  out << "  KSSD drlevel:           " << st.info.drlevel << std::endl << std::endl;
+  out << "[Scale]" << std::endl;
+  out << "  Total genomes:          " << total_genomes << std::endl;
+  out << "  Representatives:        " << nrep << std::endl;
+  out << "  Clusters:               " << st.clusters.size() << std::endl;
+  const double compression = total_genomes > 0 ? (1.0 - (double)nrep / total_genomes) * 100.0 : 0.0;
+  out << "  Compression ratio:      " << std::fixed << std::setprecision(2) << compression << "%" << std::endl << std::endl;
+  // the inverted index, from the representatives' sketches
+  std::vector<uint64_t> keys;
+  for (size_t r = 0; r < nrep; r++) {
+    if (st.reps.use64) keys.insert(keys.end(), st.reps.h64[r].begin(), st.reps.h64[r].end());
+    else keys.insert(keys.end(), st.reps.h32[r].begin(), st.reps.h32[r].end());
+  }
+  std::sort(keys.begin(), keys.end());
+  size_t unique = 0, max_posting = 0;
+  for (size_t i = 0; i < keys.size();) {
+    size_t j = i;
+    while (j < keys.size() && keys[j] == keys[i]) j++;
+    unique++; max_posting = std::max(max_posting, j - i);
+    i = j;
+  }
+  out << "[Inverted Index]" << std::endl;
+  out << "  Unique hashes:          " << unique << std::endl;
+  out << "  Total postings:         " << keys.size() << std::endl;
+  out << "  Avg posting length:     " << std::fixed << std::setprecision(2) << (unique ? (double)keys.size() / unique : 0.0) << std::endl;
+  out << "  Max posting length:     " << max_posting << std::endl << std::endl;
+  out << "[Cluster Size Distribution]" << std::endl;
+  if (!st.clusters.empty()) {
+    std::vector<int> sizes;
+    size_t singleton = 0;
+    for (const auto& cl : st.clusters) { sizes.push_back((int)cl.size()); if (cl.size() <= 1) singleton++; }
+    std::sort(sizes.begin(), sizes.end());
+    out << "  Min cluster size:       " << sizes.front() << std::endl;
+    out << "  Max cluster size:       " << sizes.back() << std::endl;
+    out << "  Mean cluster size:      " << std::fixed << std::setprecision(2) << (double)total_genomes / st.clusters.size() << std::endl;
+    out << "  Median cluster size:    " << sizes[sizes.size() / 2] << std::endl;
+    out << "  Singletons:             " << singleton << " (" << std::fixed << std::setprecision(1)
+        << (100.0 * singleton / st.clusters.size()) << "%)" << std::endl;
+    out << "  P90 cluster size:       " << sizes[(size_t)(sizes.size() * 0.9)] << std::endl;
+    out << "  P95 cluster size:       " << sizes[(size_t)(sizes.size() * 0.95)] << std::endl;
+    out << "  P99 cluster size:       " << sizes[(size_t)(sizes.size() * 0.99)] << std::endl;
+  }
+  out << std::endl;
+  out << "[Representative Sketch Sizes]" << std::endl;
+  if (nrep) {
+    size_t min_sk = SIZE_MAX, max_sk = 0, sum_sk = 0;
+    for (size_t r = 0; r < nrep; r++) { const size_t z = rep_size(r); min_sk = std::min(min_sk, z); max_sk = std::max(max_sk, z); sum_sk += z; }
+    out << "  Min sketch size:        " << min_sk << std::endl;
+    out << "  Max sketch size:        " << max_sk << std::endl;
+    out << "  Mean sketch size:       " << std::fixed << std::setprecision(1) << (double)sum_sk / nrep << std::endl;
+  }
+  uint64_t total_seq_len = 0, rep_seq_len = 0;
+  for (const GenomeInfo& g : st.genomes) total_seq_len += g.totalSeqLength;
+  if (total_seq_len > 0) {
+    for (const GenomeInfo& g : st.rep_genomes) rep_seq_len += g.totalSeqLength;
+    out << std::endl << "[Genome Coverage]" << std::endl;
+    out << "  Total sequence length:  " << total_seq_len << " bp" << std::endl;
+    out << "  Representative seq len: " << rep_seq_len << " bp" << std::endl;
+    out << "  Coverage ratio:         " << std::fixed << std::setprecision(2) << (100.0 * rep_seq_len / total_seq_len) << "%" << std::endl;
+  }
+  out << "========================================" << std::endl;
 }
 
 void print_result(const std::vector<std::vector<int>>& cluster, const std::vector<GenomeInfo>& g, bool sketchByFile,

@@ -4,6 +4,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <ostream>
 #include <string>
 #include <vector>
 
@@ -97,12 +98,21 @@ struct KssdClusterState {
   int kmer_size = 0;
   KssdParameters info{};
   std::vector<int> rep_ids;
-  std::vector<GenomeInfo> genomes;   // state order: genome i has id i
-  KssdSketchFile sk;                 // hashes in the same order
-  std::vector<std::vector<int>> clusters;
+  std::vector<GenomeInfo> genomes;   // state order: genome i has id i (RepDB: file name and length only)
+  KssdSketchFile sk;                 // hashes in the same order (cluster_state.bin; empty in a RepDB)
+  std::vector<GenomeInfo> rep_genomes;  // representative r: id, length, file name ...
+  KssdSketchFile reps;                  // ... and hashes, r = position in rep_ids
+  std::vector<std::vector<int>> clusters;  // clusters[r] belongs to representative r
 };
 bool save_kssd_cluster_state(const std::string& path, const KssdClusterState& st);
 bool load_kssd_cluster_state(const std::string& path, KssdClusterState& st);
+// RepDB of clust-greedy --fast --db (KssdClusterState::save_repdb / ::load_repdb / ::print_stats,
+// src/greedy.cpp:2351-2537, :2656-2765): "REPDB002", parameters, the representatives with their sketches, the
+// clusters, every genome's file name and length, the representatives' inverted index (64-bit keys; "REPDB001"
+// files with 32-bit keys are read too).  The index is written from the sketches and not kept when read.
+bool save_kssd_repdb(const std::string& path, const KssdClusterState& st);
+bool load_kssd_repdb(const std::string& path, KssdClusterState& st);
+void print_kssd_repdb_stats(const KssdClusterState& st, std::ostream& out);
 
 void save_mst(const std::vector<rtc_edge>& mst, const std::string& folder);   // edge.mst
 bool load_mst(const std::string& folder, std::vector<rtc_edge>& mst);

@@ -1,5 +1,6 @@
 """GPU end-to-end: the clust-mst / clust-greedy command lines on FASTA files, checked against the
 oracle run on the same bytes (sketch file contents, MST weights, cluster partition, resume flows)."""
+import math
 import os
 import struct
 import subprocess
@@ -227,6 +228,42 @@ def test_clust_greedy_fast_and_presketched(oracle, tmp_path):
     assert got == [[r] + [m for m in ms if m != r] for r, ms in sorted(want.items())]
 
 
+def _kssd_dist(cm, sr, sq, kmer):
+    jac = cm / (sq + sr - cm)
+    return 0.0 if jac == 1.0 else min(1.0, -math.log(2 * jac / (1.0 + jac)) / kmer)
+
+
+def _rep_candidates(q, rep_sets, kmer, thr):
+    """(distance, representative position) of every representative that survives the walk and the filters of
+    KssdIncrementalCluster / query_topk (src/greedy.cpp:1768-1835, :2545-2600)."""
+    radio = 2.0 * math.exp(thr * kmer) - 1.0
+    x = math.exp(-thr * kmer); jmin = x / (2.0 - x)
+    out = []
+    for r, rs in enumerate(rep_sets):
+        cm = len(q & rs)
+        if cm == 0:
+            continue
+        sq, sr = len(q), len(rs)
+        ratio = sq / sr
+        if ratio > radio or ratio < 1.0 / radio:
+            continue
+        if cm < int(jmin * (sq + sr) / (1.0 + jmin)):
+            continue
+        out.append((_kssd_dist(cm, sr, sq, kmer), r))
+    return sorted(out)
+
+
+def _incremental_twin(sets, n_old, cid, clusters, kmer, thr):
+    """KssdIncrementalCluster (src/greedy.cpp:1736-1900) over sets[n_old:]; cid: representative genome -> cluster."""
+    for q in range(n_old, len(sets)):
+        reps = sorted(cid, key=lambda g: cid[g])
+        cand = [c for c in _rep_candidates(sets[q], [sets[g] for g in reps], kmer, thr) if c[0] <= thr]
+        if cand:
+            clusters[cand[0][1]].append(q)
+        else:
+            cid[q] = len(clusters); clusters.append([])
+
+
 def test_clust_greedy_fast_append(oracle, tmp_path):
     """clust-greedy --fast --presketched DIR --append LIST without a stored cluster state
     (append_clust_greedy_fast, "Initial State Building Mode"): the stored sketches are clustered as
@@ -264,39 +301,22 @@ def test_clust_greedy_fast_append(oracle, tmp_path):
         if int(r) != pos:
             clusters[cid[int(r)]].append(pos)
     clusters_pre = [list(c) for c in clusters]
-    kmer, thr = 22, 0.05
-    radio = 2.0 * math.exp(thr * kmer) - 1.0
-    x = math.exp(-thr * kmer); jmin = x / (2.0 - x)
     sets = [set(ks[i].tolist()) for i in order]
-    for q in range(len(pre), len(order)):
-        best, best_d = -1, float("inf")
-        for r in sorted(cid):
-            cm = len(sets[q] & sets[r])
-            if cm == 0:
-                continue
-            sq, sr = len(sets[q]), len(sets[r])
-            ratio = sq / sr
-            if ratio > radio or ratio < 1.0 / radio:
-                continue
-            if cm < int(jmin * (sq + sr) / (1.0 + jmin)):
-                continue
-            jac = cm / (sq + sr - cm)
-            d = 0.0 if jac == 1.0 else min(1.0, -math.log(2 * jac / (1.0 + jac)) / kmer)
-            if d <= thr and d < best_d:
-                best, best_d = r, d
-        if best >= 0:
-            clusters[cid[best]].append(q)
-        else:
-            cid[q] = len(clusters); clusters.append([q])
+    _incremental_twin(sets, len(pre), cid, clusters, 22, 0.05)
     got = _parse_clusters(out)
     assert got == clusters
-    assert len(clusters) < 16 and any(c[0] >= len(pre) for c in clusters)  # the appended list opened a cluster of its own
+    # the appended list opened clusters of its own; a genome that opens one is its representative but is not listed
+    # among the members (src/greedy.cpp:1861-1864)
+    new_reps = [g for g in cid if g >= len(pre)]
+    assert len(clusters) < 16 and new_reps and any(clusters[cid[g]] for g in new_reps)
+    listed = sorted(m for c in clusters for m in c)
+    assert listed == [g for g in range(len(order)) if g not in new_reps]
     names = {}
     for ln in open(out):
         if ln.startswith("\t"):
             f = ln.rstrip("\n").split("\t")
             names[int(f[2])] = f[4].strip()
-    assert [names[i] for i in range(len(order))] == [paths[i] for i in order]
+    assert [names[i] for i in listed] == [paths[order[i]] for i in listed]
     # ---- the same through a stored cluster state: --save-rep writes DIR/cluster_state.bin, --append finds it ----
     import struct
     ds_ = os.path.join(tmp, "s"); os.makedirs(ds_)
@@ -355,6 +375,9 @@ def test_clust_greedy_fast_append(oracle, tmp_path):
     assert "Incremental Update Mode (KSSD)" in err  # (-d 0.2 is ignored: the state's threshold decides)
     st1 = read_state(state)
     assert st1["n"] == len(pre) + half and st1["names"] == [paths[i] for i in order[:len(pre) + half]]
+    reps_now = sorted((g for g in cid if g < len(pre) + half), key=lambda g: cid[g])
+    assert st1["reps"] == reps_now and len(st1["clusters"]) == len(reps_now)
+    assert st1["clusters"] == [[m for m in clusters[cid[g]] if m < len(pre) + half] for g in reps_now]
     err = _run([os.path.join(BIN, "clust-greedy"), "--fast", "-l", "--presketched", sfolder, "--append", lb2, "-d", "0.05", "-t", "4", "-e",
                 "-o", out2], tmp)
     assert "Incremental Update Mode (KSSD)" in err
@@ -365,14 +388,172 @@ def test_clust_greedy_fast_append(oracle, tmp_path):
         if ln.startswith("\t"):
             f = ln.rstrip("\n").split("\t")
             seqnames[int(f[2])] = (f[4].strip(), f[5].strip())
-    assert all(seqnames[i][1] == "N/A" for i in range(len(pre) + half))          # src/MST_IO.cpp:99-104
-    assert all(seqnames[i][1] != "N/A" for i in range(len(pre) + half, len(order)))
-    assert [seqnames[i][0] for i in range(len(order))] == [paths[i] for i in order]
+    assert all(seqnames[i][1] == "N/A" for i in listed if i < len(pre) + half)          # src/MST_IO.cpp:99-104
+    assert all(seqnames[i][1] != "N/A" for i in listed if i >= len(pre) + half)
+    assert [seqnames[i][0] for i in listed] == [paths[order[i]] for i in listed]
     # usage errors (src/main.cpp:378-381) and the MinHash flow, which is not offered
     r = subprocess.run([os.path.join(BIN, "clust-greedy"), "--fast", "-l", "--append", lb, "-o", out], capture_output=True, text=True)
     assert r.returncode != 0 and "--presketched needed" in r.stderr
     r = subprocess.run([os.path.join(BIN, "clust-greedy"), "-l", "--presketched", folder, "--append", lb, "-o", out], capture_output=True, text=True)
     assert r.returncode != 0 and "MinHash" in r.stderr
+
+
+def _read_repdb(path):
+    """KssdClusterState::save_repdb (src/greedy.cpp:2351-2428), field by field."""
+    import struct
+    b = open(path, "rb").read()
+    assert b[:8] == b"REPDB002"
+    thr, k, hk, hs, dr, gn = struct.unpack_from("<diiiii", b, 8)
+    p = 36
+    (nrep,) = struct.unpack_from("<Q", b, p); p += 8
+    rep_ids, rep_names, rep_len, rep_sk = [], [], [], []
+    for _ in range(nrep):
+        rid, gid, tot, u64, ssz = struct.unpack_from("<iiQ?I", b, p); p += 4 + 4 + 8 + 1 + 4
+        n32, n64 = struct.unpack_from("<QQ", b, p); p += 16
+        assert not u64 and n64 == 0 and ssz == n32
+        rep_sk.append(np.frombuffer(b, dtype=np.uint32, count=n32, offset=p).copy()); p += 4 * n32
+        (nl,) = struct.unpack_from("<Q", b, p); p += 8
+        rep_names.append(b[p:p + nl].decode()); p += nl
+        rep_ids.append(rid); rep_len.append(tot)
+    (ncl,) = struct.unpack_from("<Q", b, p); p += 8
+    cls = []
+    for _ in range(ncl):
+        (m,) = struct.unpack_from("<Q", b, p); p += 8
+        cls.append(list(struct.unpack_from("<%di" % m, b, p))); p += 4 * m
+    (nall,) = struct.unpack_from("<Q", b, p); p += 8
+    names, lens = [], []
+    for _ in range(nall):
+        (nl,) = struct.unpack_from("<Q", b, p); p += 8
+        names.append(b[p:p + nl].decode()); p += nl
+        (tot,) = struct.unpack_from("<Q", b, p); p += 8
+        lens.append(tot)
+    (nidx,) = struct.unpack_from("<Q", b, p); p += 8
+    index = {}
+    for _ in range(nidx):
+        h, ls = struct.unpack_from("<QQ", b, p); p += 16
+        index[h] = list(struct.unpack_from("<%di" % ls, b, p)); p += 4 * ls
+    assert p == len(b)
+    return dict(thr=thr, k=k, half_k=hk, half_subk=hs, drlevel=dr, n=gn, rep_ids=rep_ids, rep_names=rep_names, rep_len=rep_len,
+                rep_sk=rep_sk, clusters=cls, names=names, lens=lens, index=index)
+
+
+def test_clust_greedy_fast_repdb(oracle, tmp_path):
+    """clust-greedy --fast --db FILE: --build (from a sketch folder and from genomes), --stats, --query --top-k,
+    --assign and --append (src/sub_command.cpp:276-496, src/greedy.cpp:2351-2765) against a Python restatement on
+    the oracle's KSSD sketches; the RepDB file is parsed field by field."""
+    tmp = str(tmp_path)
+    L = 2_000_000
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 4, 4, L, seed=34)
+    perm = [0, 5, 10, 1, 4, 8, 9, 2, 3, 6, 7, 13, 11, 12, 14, 15]  # family 3 is absent from the database
+    first, second = perm[:7], perm[7:]
+    la, lb = os.path.join(tmp, "a.txt"), os.path.join(tmp, "b.txt")
+    open(la, "w").write("\n".join(paths[i] for i in first) + "\n")
+    open(lb, "w").write("\n".join(paths[i] for i in second) + "\n")
+    G = os.path.join(BIN, "clust-greedy")
+    da = os.path.join(tmp, "a"); os.makedirs(da)
+    db, db2 = os.path.join(tmp, "rep.db"), os.path.join(tmp, "rep2.db")
+    # --build from genomes: sketches with -k as given (no tuning), writes the sketch folder, clusters, saves the RepDB
+    err = _run([G, "--fast", "--db", db, "--build", "-l", "-i", la, "-k", "21", "-d", "0.05", "-t", "4", "-o", os.path.join(da, "a.out")], da)
+    assert "===== RepDB Build (from genomes) =====" in err and "RepDB saved to: " + db in err
+    folder = [os.path.join(da, d) for d in os.listdir(da) if os.path.isdir(os.path.join(da, d))][0]
+    # --build from the folder: the same database
+    err = _run([G, "--fast", "--db", db2, "--build", "--presketched", folder, "-d", "0.05", "-o", os.path.join(da, "a2.out")], da)
+    assert "===== RepDB Build (from pre-sketched) =====" in err
+    assert open(db, "rb").read() == open(db2, "rb").read()
+    assert open(os.path.join(da, "a.out")).read() == open(os.path.join(da, "a2.out")).read()
+    assert open(os.path.join(da, "a.out")).read().startswith("# Clustering threshold: 0.050000\n# Total clusters: ")
+    # ---- restatement of the build ----
+    ks = {i: oracle.kssd_sketch(seqs[i], 21, 3) for i in perm}
+    pre = sorted(first, key=lambda i: -len(ks[i]))
+    assert len({len(ks[i]) for i in pre}) == len(pre)
+    flat, start, lens = oracle.to_csr([ks[i] for i in pre], dtype=np.uint32)
+    ncl, rep = oracle.greedy_kssd(flat, start, lens, 22, 0.05)
+    clusters, cid = [], {}
+    for pos, r in enumerate(rep):
+        if int(r) == pos:
+            cid[pos] = len(clusters); clusters.append([pos])
+    for pos, r in enumerate(rep):
+        if int(r) != pos:
+            clusters[cid[int(r)]].append(pos)
+    assert _parse_clusters(os.path.join(da, "a.out")) == clusters
+    d = _read_repdb(db)
+    reps = sorted(cid, key=lambda g: cid[g])
+    assert (d["thr"], d["k"], d["half_k"], d["drlevel"]) == (0.05, 22, 11, 3)
+    assert d["rep_ids"] == reps and d["clusters"] == clusters
+    assert d["rep_names"] == [paths[pre[g]] for g in reps] and d["names"] == [paths[i] for i in pre]
+    assert d["lens"] == [L] * len(pre) and d["rep_len"] == [L] * len(reps)
+    assert all(np.array_equal(a, ks[pre[g]]) for a, g in zip(d["rep_sk"], reps))
+    want_index = {}
+    for ridx, g in enumerate(reps):
+        for h in ks[pre[g]].tolist():
+            want_index.setdefault(h, []).append(ridx)
+    assert d["index"] == want_index
+    # ---- --stats ----
+    r = subprocess.run([G, "--fast", "--db", db, "--stats"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    txt = r.stdout
+    assert "        RepDB Statistics Report" in txt
+    assert "  Total genomes:          %d\n" % len(pre) in txt and "  Representatives:        %d\n" % len(reps) in txt
+    assert "  Compression ratio:      %.2f%%\n" % ((1.0 - len(reps) / len(pre)) * 100.0) in txt
+    assert "  Unique hashes:          %d\n" % len(want_index) in txt
+    assert "  Total postings:         %d\n" % sum(len(v) for v in want_index.values()) in txt
+    assert "  Max posting length:     %d\n" % max(len(v) for v in want_index.values()) in txt
+    sizes = sorted(len(c) for c in clusters)
+    assert "  Median cluster size:    %d\n" % sizes[len(sizes) // 2] in txt
+    assert "  Max sketch size:        %d\n" % max(len(ks[pre[g]]) for g in reps) in txt
+    assert "  Total sequence length:  %d bp\n" % (L * len(pre)) in txt and "  Coverage ratio:         %.2f%%\n" % (100.0 * len(reps) / len(pre)) in txt
+    # ---- --query / --assign ----
+    rep_sets = [set(ks[pre[g]].tolist()) for g in reps]
+    qout, aout = os.path.join(tmp, "q.tsv"), os.path.join(tmp, "as.tsv")
+    _run([G, "--fast", "--db", db, "--query", "-l", "-i", lb, "--top-k", "2", "-t", "4", "-o", qout], tmp)
+    _run([G, "--fast", "--db", db, "--assign", "-l", "-i", lb, "-t", "4", "-o", aout], tmp)
+    want_q = ["#query\trank\trep_name\tdistance\tcluster_id\tcluster_size\n"]
+    want_a = ["#query\tassigned_cluster\trep_name\tdistance\tcluster_size\tstatus\n"]
+    n_match = n_none = 0
+    for i in second:
+        cand = _rep_candidates(set(ks[i].tolist()), rep_sets, 22, 0.05)
+        assert len({c[0] for c in cand}) == len(cand)  # no distance ties in the test data
+        if not cand:
+            want_q.append("%s\t0\tno_match\t-1\t-1\t0\n" % paths[i]); n_none += 1
+        for rank, (dist, r) in enumerate(cand[:2]):
+            want_q.append("%s\t%d\t%s\t%.6f\t%d\t%d\n" % (paths[i], rank + 1, paths[pre[reps[r]]], dist, r, len(clusters[r])))
+        if cand and cand[0][0] <= 0.05:
+            want_a.append("%s\t%d\t%s\t%.6f\t%d\tassigned\n" % (paths[i], cand[0][1], paths[pre[reps[cand[0][1]]]], cand[0][0], len(clusters[cand[0][1]])))
+            n_match += 1
+        else:
+            want_a.append("%s\t-1\tunassigned\t-1\t0\tnovel\n" % paths[i])
+    assert n_match >= 4 and n_none >= 3
+    assert open(qout).readlines() == want_q
+    assert open(aout).readlines() == want_a
+    assert open(db, "rb").read() == open(db2, "rb").read()  # read-only actions
+    # ---- --append: KssdIncrementalCluster on the database, which is rewritten ----
+    apout = os.path.join(tmp, "ap.out")
+    err = _run([G, "--fast", "--db", db, "--append", lb, "-l", "-t", "4", "-o", apout], tmp)
+    assert "===== RepDB Append =====" in err and "  RepDB updated:    " + db in err
+    order = pre + second
+    sets = [set(ks[i].tolist()) for i in order]
+    _incremental_twin(sets, len(pre), cid, clusters, 22, 0.05)
+    assert _parse_clusters(apout) == clusters
+    assert open(apout).read().startswith("# Clustering threshold: 0.050000\n# Total clusters: %d\n#\n" % len(clusters))
+    d = _read_repdb(db)
+    reps = sorted(cid, key=lambda g: cid[g])
+    assert d["rep_ids"] == reps and d["clusters"] == clusters and d["n"] == len(order)
+    assert d["names"] == [paths[i] for i in order] and d["rep_names"] == [paths[order[g]] for g in reps]
+    assert all(np.array_equal(a, ks[order[g]]) for a, g in zip(d["rep_sk"], reps))
+    # a second append works from the stored representatives alone (the RepDB keeps no other sketches)
+    lc = os.path.join(tmp, "c.txt")
+    open(lc, "w").write("\n".join(paths[i] for i in (13, 2)) + "\n")
+    _run([G, "--fast", "--db", db, "--append", lc, "-l", "-t", "4", "-o", apout], tmp)
+    sets += [set(ks[13].tolist()), set(ks[2].tolist())]
+    _incremental_twin(sets, len(order), cid, clusters, 22, 0.05)
+    assert _parse_clusters(apout) == clusters and cid == {g: c for c, g in enumerate(reps)}  # both joined existing clusters
+    # usage errors
+    r = subprocess.run([G, "--fast", "--db", db, "-o", apout], capture_output=True, text=True)
+    assert r.returncode != 0 and "--db requires one of: --build, --query, --assign, --append, --stats" in r.stderr
+    r = subprocess.run([G, "--fast", "--db", db, "--query", "-o", apout], capture_output=True, text=True)
+    assert r.returncode != 0 and "--query requires -i <input_file>" in r.stderr
+    r = subprocess.run([G, "--db", db, "--stats"], capture_output=True, text=True)
+    assert r.returncode != 0 and "outside the sketch + all-pairs path" in r.stderr
 
 
 def test_clust_mst_batching_gzip_retry_and_min_length_filter(oracle, tmp_path):
