@@ -546,7 +546,7 @@ static Options parse(int argc, char** argv) {
            "  --premsted DIR  --append LIST (with --presketched/--premsted DIR)"
 #else
            "  --append LIST (with --fast --presketched DIR)  --save-rep (with --fast: cluster_state.bin)\n"
-           "  --fast --db FILE --build|--query|--assign|--append LIST|--stats [--top-k N] (representative database)"
+           "  [--fast] --db FILE --build|--query|--assign|--append LIST|--stats [--top-k N] (representative database)"
 #endif
       );
       exit(0);
@@ -695,6 +695,49 @@ static double kssd_mash_distance(int cm, int sizeRef, int sizeQry, int kmer_size
   return dist;
 }
 
+// minhash_mash_distance (src/greedy.cpp:2771-2787)
+static double minhash_mash_distance(int common, int sizeQry, int sizeRef, int kmer_size, bool is_containment) {
+  if (common <= 0) return 1.0;
+  double jaccard;
+  if (is_containment) {
+    const int minSize = std::min(sizeQry, sizeRef);
+    if (minSize == 0) return 1.0;
+    jaccard = (double)common / minSize;
+  } else {
+    const int denom = sizeQry + sizeRef - common;
+    if (denom == 0) return 0.0;
+    jaccard = (double)common / denom;
+  }
+  if (jaccard >= 1.0) return 0.0;
+  if (jaccard <= 0.0) return 1.0;
+  const double dist = -log(2.0 * jaccard / (1.0 + jaccard)) / kmer_size;
+  return dist > 1.0 ? 1.0 : dist;
+}
+
+// one (new genome or query, representative) pair with cm > 0 shared hashes: is it a candidate, and at which distance?
+// KSSD: size-ratio and minimum-common filters, then calculate_mash_distance (src/greedy.cpp:1815-1843, :2583-2606).
+// MinHash, incremental step: minimum-common filter only (:2040-2076); MinHash query: no filter (:3003-3012).
+static bool rep_candidate(const KssdClusterState& st, bool query, int cm, int sizeQry, int sizeRef, double radio, double jaccard_min,
+                          double& dist) {
+  if (!st.minhash) {
+    const double ratio = (double)sizeQry / sizeRef;
+    if (ratio > radio || ratio < 1.0 / radio) return false;
+    const int min_common_needed = (int)(jaccard_min * (sizeQry + sizeRef) / (1.0 + jaccard_min));
+    if (cm < min_common_needed) return false;
+    dist = kssd_mash_distance(cm, sizeRef, sizeQry, st.kmer_size);
+    return true;
+  }
+  if (!query) {
+    if (sizeRef == 0) return false;
+    const int min_common_needed = st.is_containment ? (int)(jaccard_min * std::min(sizeQry, sizeRef))
+                                                    : (int)(jaccard_min * (sizeQry + sizeRef) / (1.0 + jaccard_min));
+    if (cm < min_common_needed) return false;
+    if (!st.is_containment && sizeQry + sizeRef - cm == 0) return false;
+  }
+  dist = minhash_mash_distance(cm, sizeQry, sizeRef, st.kmer_size, st.is_containment);
+  return true;
+}
+
 static size_t sketch_count(const KssdSketchFile& f) { return f.use64 ? f.h64.size() : f.h32.size(); }
 static size_t sketch_len(const KssdSketchFile& f, size_t i) { return f.use64 ? f.h64[i].size() : f.h32[i].size(); }
 static void push_sketch(KssdSketchFile& dst, const KssdSketchFile& src, size_t i) {
@@ -718,8 +761,10 @@ static void reps_then(const KssdClusterState& st, const KssdSketchFile& tail, Ks
 static int kssd_incremental_cluster(rtc_ctx* ctx, KssdClusterState& st, const vector<GenomeInfo>& add, const KssdSketchFile& ks2,
                                     bool keep_sketches) {
   const size_t R0 = st.rep_ids.size(), m = add.size(), n_old = st.genomes.size(), n_work = R0 + m;
-  const double threshold = st.threshold; const int kmer_size = st.kmer_size;
+  const double threshold = st.threshold;
   cerr << "Existing clusters: " << R0 << endl << "New genomes: " << m << endl;
+  if (st.minhash && m == 0) { cerr << "ERROR: No new sketches to process" << endl; return 0; }       // src/greedy.cpp:1973-1981
+  if (st.minhash && R0 == 0) { cerr << "ERROR: No existing representatives" << endl; return 0; }
   if (m == 0) return 0;
   if (R0 && ks2.use64 != st.reps.use64) { cerr << "ERROR: appended sketches and stored sketches differ in hash width" << endl; return 1; }
   KssdSketchFile work;
@@ -727,8 +772,8 @@ static int kssd_incremental_cluster(rtc_ctx* ctx, KssdClusterState& st, const ve
   st.reps.use64 = work.use64; if (keep_sketches && n_old == 0) st.sk.use64 = work.use64;
   DeviceSketches ds;
   upload_sketches(ctx, work.use64 ? &work.h64 : nullptr, work.use64 ? nullptr : &work.h32, ds);
-  const double radio = 2.0 * exp(threshold * kmer_size) - 1.0;                 // calculateMaxSizeRatio, src/greedy.cpp:162-173
-  const double x = exp(-threshold * kmer_size), jaccard_min = x / (2.0 - x);   // :1751-1753
+  const double radio = 2.0 * exp(threshold * st.kmer_size) - 1.0;                 // calculateMaxSizeRatio, src/greedy.cpp:162-173
+  const double x = exp(-threshold * st.kmer_size), jaccard_min = x / (2.0 - x);   // :1751-1753
   const size_t max_block_bytes = (size_t)256 << 20;
   const size_t B = std::max<size_t>(1, std::min<size_t>(m, max_block_bytes / (n_work * 4)));
   uint32_t* d_common = nullptr;
@@ -750,12 +795,8 @@ static int kssd_incremental_cluster(rtc_ctx* ctx, KssdClusterState& st, const ve
       int best = -1;
       for (size_t c = 0; c < q; c++) {
         if (rep_of_col[c] < 0 || row[c] == 0) continue;  // candidates: representatives sharing a hash (:1768-1790)
-        const int sizeRef = (int)sketch_len(work, c), cm = (int)row[c];
-        const double ratio = (double)sizeQry / sizeRef;
-        if (ratio > radio || ratio < 1.0 / radio) continue;                                              // :1822-1825
-        const int min_common_needed = (int)(jaccard_min * (sizeQry + sizeRef) / (1.0 + jaccard_min));    // :1829
-        if (cm < min_common_needed) continue;
-        const double dist = kssd_mash_distance(cm, sizeRef, sizeQry, kmer_size);
+        double dist;
+        if (!rep_candidate(st, false, (int)row[c], sizeQry, (int)sketch_len(work, c), radio, jaccard_min, dist)) continue;
         if (dist <= threshold && dist < best_dist) { best_dist = dist; best = rep_of_col[c]; }
       }
       if (best >= 0) { st.clusters[best].push_back(genome_idx); assigned++; }
@@ -830,6 +871,18 @@ static void sketch_for_state(vector<Gpu>& gpus, const Options& o, const string& 
   job.kssd = true; job.kmerSize = kmer_size; job.drlevel = drlevel; job.minLen = o.minLen; job.threads = o.threads;
   MinHashSketchFile mh2; Resident rs2;
   sketch_files(gpus, list, job, add, &mh2, &ks2, rs2, true);
+}
+
+// compute_sketches with a MinHash RepDB's parameters (contain_compress is the literal 1000 of mh_repdb_query / _assign /
+// _append, src/sub_command.cpp:609,657,717); the sketches come back in the u64 arm of a KssdSketchFile
+static void sketch_for_mh_state(vector<Gpu>& gpus, const Options& o, const string& list, const KssdClusterState& st,
+                                vector<GenomeInfo>& add, KssdSketchFile& out) {
+  SketchJob job;
+  job.kssd = false; job.kmerSize = st.kmer_size; job.sketchSize = st.sketch_size; job.isContainment = st.is_containment;
+  job.containCompress = 1000; job.minLen = o.minLen; job.threads = o.threads;
+  MinHashSketchFile mh2; KssdSketchFile unused; Resident rs2;
+  sketch_files(gpus, list, job, add, &mh2, &unused, rs2, true);
+  out = KssdSketchFile(); out.use64 = true; out.h64 = std::move(mh2.hashes);
 }
 
 static int save_sketch_folder(const vector<GenomeInfo>& g, const KssdSketchFile& ks, string& folder) {
@@ -961,12 +1014,9 @@ static int repdb_query_topk(rtc_ctx* ctx, const KssdClusterState& st, const Kssd
       vector<RepHit> scored;
       for (size_t r = 0; r < R; r++) {
         if (row[r] == 0) continue;
-        const int sizeRef = (int)sketch_len(st.reps, r), cm = (int)row[r];
-        const double ratio = (double)sizeQry / sizeRef;
-        if (ratio > radio || ratio < 1.0 / radio) continue;
-        const int min_common = (int)(jaccard_min * (sizeQry + sizeRef) / (1.0 + jaccard_min));
-        if (cm < min_common) continue;
-        scored.push_back(RepHit{(int)r, kssd_mash_distance(cm, sizeRef, sizeQry, st.kmer_size)});
+        double dist;
+        if (!rep_candidate(st, true, (int)row[r], sizeQry, (int)sketch_len(st.reps, r), radio, jaccard_min, dist)) continue;
+        scored.push_back(RepHit{(int)r, dist});
       }
       std::stable_sort(scored.begin(), scored.end(), [](const RepHit& a, const RepHit& b) { return a.distance < b.distance; });
       if ((int)scored.size() > topk) scored.resize(std::max(topk, 0));
@@ -979,9 +1029,76 @@ static int repdb_query_topk(rtc_ctx* ctx, const KssdClusterState& st, const Kssd
 }
 
 static int repdb_load_and_sketch(const Options& o, vector<Gpu>& gpus, KssdClusterState& st, vector<GenomeInfo>& q, KssdSketchFile& qs) {
-  if (!load_kssd_repdb(o.repdb_path, st)) { cerr << "ERROR: Failed to load RepDB from: " << o.repdb_path << endl; return 1; }
+  if (o.is_fast) { if (!load_kssd_repdb(o.repdb_path, st)) { cerr << "ERROR: Failed to load RepDB from: " << o.repdb_path << endl; return 1; } }
+  else if (!load_minhash_repdb(o.repdb_path, st)) { cerr << "ERROR: Failed to load MinHash RepDB from: " << o.repdb_path << endl; return 1; }
   if (!o.sketchByFile) unsupported("single-FASTA input (run with -l and a genome list)");
-  sketch_for_state(gpus, o, o.inputFile, st.kmer_size, st.info.drlevel, q, qs);
+  if (o.is_fast) sketch_for_state(gpus, o, o.inputFile, st.kmer_size, st.info.drlevel, q, qs);
+  else sketch_for_mh_state(gpus, o, o.inputFile, st, q, qs);
+  return 0;
+}
+
+// mh_repdb_build_from_sketch / mh_repdb_build_from_genome (src/sub_command.cpp:502-586): the sketches in stored /
+// list order (no size sort here), MinHashInitialClusterWithState = the MinHash greedy pass, saved as MHREPDB1
+static int mh_repdb_build(const Options& o, vector<Gpu>& gpus) {
+  rtc_ctx* ctx = gpus[0].ctx;
+  vector<GenomeInfo> genomes; MinHashSketchFile mh; bool byFile = true;
+  vector<uint32_t> size_cfg;
+  if (o.has_presketched) {
+    if (!load_minhash_sketches(o.folder_path, genomes, mh, byFile)) return 1;
+    if (genomes.empty()) { cerr << "ERROR: no genome to cluster" << endl; return 1; }
+    // loadSketches builds MinHash(k, containCompress) in containment mode (src/Sketch_IO.cpp:334): getSketchSize() reports that
+    size_cfg.assign(genomes.size(), mh.isContainment ? (uint32_t)mh.containCompress : (uint32_t)mh.sketchSize);
+    cerr << "===== MinHash RepDB Build (from pre-sketched) =====" << endl;
+  } else {
+    if (!o.sketchByFile) unsupported("single-FASTA input (run with -l and a genome list)");
+    mh.kmerSize = o.kmerSize; mh.sketchSize = o.sketchSize; mh.isContainment = o.isContainment; mh.containCompress = o.containCompress;
+    if (!o.isSetKmer) { mh.kmerSize = 21; cerr << "-----use default kmerSize: " << mh.kmerSize << endl; }
+    if (!o.isJaccard) mh.sketchSize = 1000;
+    SketchJob job;
+    job.kssd = false; job.kmerSize = mh.kmerSize; job.sketchSize = mh.sketchSize; job.isContainment = mh.isContainment;
+    job.containCompress = mh.containCompress; job.minLen = o.minLen; job.threads = o.threads;
+    KssdSketchFile unused; Resident rs;
+    sketch_files(gpus, o.inputFile, job, genomes, &mh, &unused, rs, true);
+    cerr << "-----the size of sketches (number of genomes or sequences) is: " << genomes.size() << endl;
+    if (genomes.empty()) { cerr << "ERROR: no genome to cluster" << endl; return 1; }
+    const string folder = current_date_time();   // compute_sketches(isSave = true)
+    string command = "mkdir -p " + folder;
+    if (system(command.c_str()) != 0) { cerr << "ERROR: cannot create " << folder << endl; return 1; }
+    save_minhash_sketches(genomes, mh, folder, true);
+    size_cfg.resize(genomes.size());
+    for (size_t i = 0; i < genomes.size(); i++)
+      size_cfg[i] = mh.isContainment ? (uint32_t)std::max(file_length_for_containment(genomes[i].fileName) / mh.containCompress, 100)
+                                     : (uint32_t)mh.sketchSize;
+    cerr << "===== MinHash RepDB Build (from genomes) =====" << endl;
+  }
+  KssdClusterState st;
+  st.minhash = true; st.threshold = o.threshold; st.kmer_size = mh.kmerSize; st.sketch_size = (int)size_cfg[0]; st.is_containment = mh.isContainment;
+  cerr << "  Genomes:       " << genomes.size() << endl << "  Threshold:     " << o.threshold << endl << "  Kmer size:     " << st.kmer_size << endl
+       << "  Sketch size:   " << st.sketch_size << endl;
+  if (o.has_presketched) cerr << "  Containment:   " << (st.is_containment ? "yes" : "no") << endl;
+  DeviceSketches ds;
+  upload_sketches(ctx, &mh.hashes, nullptr, ds);
+  vector<int32_t> rep_of(genomes.size(), -1);
+  uint32_t ncl = 0;
+  CHECK(ctx, rtc_greedy(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, size_cfg.data(), st.kmer_size, (int)st.is_containment, 0,
+                        o.threshold, rep_of.data(), &ncl));
+  CHECK(ctx, rtc_dev_free(ctx, ds.d_hashes)); CHECK(ctx, rtc_dev_free(ctx, ds.d_start)); CHECK(ctx, rtc_dev_free(ctx, ds.d_len));
+  st.clusters = clusters_from_rep_of(rep_of);
+  st.genomes = genomes; st.reps.use64 = true;
+  for (const auto& c : st.clusters) if (!c.empty()) {
+    st.rep_ids.push_back(c[0]);
+    st.rep_genomes.push_back(genomes[c[0]]);
+    st.reps.h64.push_back(mh.hashes[c[0]]);
+  }
+  if (!save_minhash_repdb(o.repdb_path, st)) return 1;
+  if (!o.outputFile.empty()) {
+    print_result(st.clusters, st.genomes, byFile, o.outputFile);
+    cerr << "-----write the cluster result into: " << o.outputFile << endl;
+  }
+  cerr << "\n===== MinHash RepDB Build Summary =====" << endl << "  Total genomes:    " << genomes.size() << endl
+       << "  Representatives:  " << st.rep_ids.size() << endl
+       << "  Compression:      " << std::fixed << std::setprecision(2) << (1.0 - (double)st.rep_ids.size() / genomes.size()) * 100.0 << "%" << endl
+       << "  RepDB saved to:   " << o.repdb_path << endl << "===============================" << endl;
   return 0;
 }
 
@@ -989,7 +1106,7 @@ static int repdb_load_and_sketch(const Options& o, vector<Gpu>& gpus, KssdCluste
 static int repdb_query(const Options& o, vector<Gpu>& gpus) {
   KssdClusterState st; vector<GenomeInfo> q; KssdSketchFile qs;
   if (repdb_load_and_sketch(o, gpus, st, q, qs) != 0) return 1;
-  cerr << "===== RepDB Query =====" << endl << "  Query genomes:  " << q.size() << endl << "  Top-k:          " << o.topk << endl
+  cerr << (o.is_fast ? "===== RepDB Query =====" : "===== MinHash RepDB Query =====") << endl << "  Query genomes:  " << q.size() << endl << "  Top-k:          " << o.topk << endl
        << "  DB reps:        " << st.rep_ids.size() << endl;
   vector<vector<RepHit>> hits;
   if (repdb_query_topk(gpus[0].ctx, st, qs, o.topk, hits) != 0) return 1;
@@ -1015,7 +1132,7 @@ static int repdb_query(const Options& o, vector<Gpu>& gpus) {
 static int repdb_assign(const Options& o, vector<Gpu>& gpus) {
   KssdClusterState st; vector<GenomeInfo> q; KssdSketchFile qs;
   if (repdb_load_and_sketch(o, gpus, st, q, qs) != 0) return 1;
-  cerr << "===== RepDB Assignment =====" << endl << "  Query genomes:  " << q.size() << endl << "  DB reps:        " << st.rep_ids.size() << endl
+  cerr << (o.is_fast ? "===== RepDB Assignment =====" : "===== MinHash RepDB Assignment =====") << endl << "  Query genomes:  " << q.size() << endl << "  DB reps:        " << st.rep_ids.size() << endl
        << "  Threshold:      " << st.threshold << endl;
   vector<vector<RepHit>> hits;
   if (repdb_query_topk(gpus[0].ctx, st, qs, 1, hits) != 0) return 1;
@@ -1049,11 +1166,11 @@ static int repdb_append(const Options& o, vector<Gpu>& gpus) {
   KssdClusterState st; vector<GenomeInfo> add; KssdSketchFile ks2;
   if (repdb_load_and_sketch(o, gpus, st, add, ks2) != 0) return 1;
   const size_t old_reps = st.rep_ids.size(), old_total = st.genomes.size();
-  cerr << "===== RepDB Append =====" << endl << "  Existing reps:    " << old_reps << endl << "  Existing genomes: " << old_total << endl
+  cerr << (o.is_fast ? "===== RepDB Append =====" : "===== MinHash RepDB Append =====") << endl << "  Existing reps:    " << old_reps << endl << "  Existing genomes: " << old_total << endl
        << "  New genomes:      " << add.size() << endl;
   if (kssd_incremental_cluster(gpus[0].ctx, st, add, ks2, false) != 0) return 1;
-  if (!save_kssd_repdb(o.repdb_path, st)) return 1;
-  if (!o.outputFile.empty()) {
+  if (!(st.minhash ? save_minhash_repdb(o.repdb_path, st) : save_kssd_repdb(o.repdb_path, st))) return 1;
+  if (!o.outputFile.empty()) {   // printKssdResult / printRepDBClusterResult (src/sub_command.cpp:672-702): the same layout
     print_result(st.clusters, st.genomes, true, o.outputFile, st.threshold);
     cerr << "-----write the cluster result into: " << o.outputFile << endl;
   }
@@ -1080,10 +1197,10 @@ int main(int argc, char** argv) {
   if (db_action && o.repdb_path.empty()) { cerr << "ERROR: --build / --query / --assign / --stats require --db" << endl; return 1; }
   if ((int)o.db_build + (int)o.db_query + (int)o.db_assign + (int)o.db_stats > 1) { cerr << "ERROR: --build, --query, --assign and --stats exclude each other" << endl; return 1; }
   if (!o.repdb_path.empty()) {
-    if (!o.is_fast) unsupported("--db on MinHash sketches (the MinHash RepDB); --fast");
     if (o.db_stats) {
       KssdClusterState st;
-      if (!load_kssd_repdb(o.repdb_path, st)) { cerr << "ERROR: Failed to load RepDB from: " << o.repdb_path << endl; return 1; }
+      if (o.is_fast) { if (!load_kssd_repdb(o.repdb_path, st)) { cerr << "ERROR: Failed to load RepDB from: " << o.repdb_path << endl; return 1; } }
+      else if (!load_minhash_repdb(o.repdb_path, st)) { cerr << "ERROR: Failed to load MinHash RepDB from: " << o.repdb_path << endl; return 1; }
       print_kssd_repdb_stats(st, std::cout);
       return 0;
     }
@@ -1151,7 +1268,7 @@ int main(int argc, char** argv) {
   if (o.has_append) return append_clust_mst(o, gpus);
 #else
   if (!o.repdb_path.empty()) {
-    const int rc = o.db_build ? repdb_build(o, gpus) : o.db_query ? repdb_query(o, gpus) : o.db_assign ? repdb_assign(o, gpus) : repdb_append(o, gpus);
+    const int rc = o.db_build ? (o.is_fast ? repdb_build(o, gpus) : mh_repdb_build(o, gpus)) : o.db_query ? repdb_query(o, gpus) : o.db_assign ? repdb_assign(o, gpus) : repdb_append(o, gpus);
     for (Gpu& g : gpus) { if (g.comm) rtc_comm_destroy(g.comm); }
     for (Gpu& g : gpus) rtc_ctx_destroy(g.ctx);
     return rc;

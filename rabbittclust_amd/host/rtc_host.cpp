@@ -1126,6 +1126,115 @@ bool load_kssd_repdb(const std::string& path, KssdClusterState& st) {
   return true;
 }
 
+// src/greedy.cpp:2789-2862
+bool save_minhash_repdb(const std::string& path, const KssdClusterState& st) {
+  FILE* fp = fopen(path.c_str(), "wb");
+  if (!fp) { std::cerr << "ERROR: Cannot open RepDB file for writing: " << path << std::endl; return false; }
+  fwrite("MHREPDB1", 1, 8, fp);
+  wr(fp, st.threshold); wr(fp, st.kmer_size); wr(fp, st.sketch_size); wr(fp, st.is_containment);
+  const size_t rep_count = st.rep_ids.size();
+  wr(fp, rep_count);
+  for (size_t r = 0; r < rep_count; r++) {
+    const GenomeInfo& g = st.rep_genomes[r];
+    wr(fp, st.rep_ids[r]); wr(fp, g.id); wr(fp, g.totalSeqLength); wr(fp, st.is_containment);
+    const size_t hash_count = st.reps.h64[r].size();
+    wr(fp, hash_count);
+    if (hash_count) fwrite(st.reps.h64[r].data(), 8, hash_count, fp);
+    const size_t name_len = g.fileName.size();
+    wr(fp, name_len);
+    fwrite(g.fileName.data(), 1, name_len, fp);
+  }
+  const size_t cluster_count = st.clusters.size();
+  wr(fp, cluster_count);
+  for (const auto& c : st.clusters) {
+    const size_t m = c.size();
+    wr(fp, m);
+    fwrite(c.data(), sizeof(int), m, fp);
+  }
+  const size_t all_count = st.genomes.size();
+  wr(fp, all_count);
+  for (const GenomeInfo& g : st.genomes) {
+    const size_t name_len = g.fileName.size();
+    wr(fp, name_len);
+    fwrite(g.fileName.data(), 1, name_len, fp);
+    wr(fp, g.totalSeqLength);
+  }
+  const size_t index_size = write_rep_index(fp, st);
+  fclose(fp);
+  std::cerr << "MinHash RepDB saved to: " << path << std::endl
+            << "  Representatives: " << rep_count << std::endl
+            << "  Total genomes:   " << all_count << std::endl
+            << "  Inverted index:  " << index_size << " unique hashes" << std::endl;
+  return true;
+}
+
+// src/greedy.cpp:2864-2956
+bool load_minhash_repdb(const std::string& path, KssdClusterState& st) {
+  FILE* fp = fopen(path.c_str(), "rb");
+  if (!fp) { std::cerr << "ERROR: Cannot open RepDB file for reading: " << path << std::endl; return false; }
+  char magic[8] = {0};
+  if (fread(magic, 1, 8, fp) != 8 || memcmp(magic, "MHREPDB1", 8) != 0) {
+    std::cerr << "ERROR: Invalid MinHash RepDB file (bad magic): " << path << std::endl;
+    fclose(fp);
+    return false;
+  }
+  st = KssdClusterState();
+  st.minhash = true; st.reps.use64 = true; st.sk.use64 = true;
+  bool ok = rd(fp, st.threshold) && rd(fp, st.kmer_size) && rd(fp, st.sketch_size) && rd(fp, st.is_containment);
+  size_t rep_count = 0, cluster_count = 0, all_count = 0, index_size = 0;
+  ok = ok && rd(fp, rep_count) && rep_count < ((size_t)1 << 31);
+  for (size_t r = 0; ok && r < rep_count; r++) {
+    int rid = 0; GenomeInfo g; bool cont = false; size_t hash_count = 0, name_len = 0;
+    ok = rd(fp, rid) && rd(fp, g.id) && rd(fp, g.totalSeqLength) && rd(fp, cont) && rd(fp, hash_count) && hash_count < ((size_t)1 << 32);
+    if (!ok) break;
+    std::vector<uint64_t> h(hash_count);
+    if (hash_count) ok = fread(h.data(), 8, hash_count, fp) == hash_count;
+    ok = ok && rd(fp, name_len) && name_len < ((size_t)1 << 20);
+    if (!ok) break;
+    g.fileName.resize(name_len);
+    if (name_len) ok = fread(&g.fileName[0], 1, name_len, fp) == name_len;
+    g.seq0.name = "N/A"; g.seq0.comment = "";
+    st.rep_ids.push_back(rid); st.rep_genomes.push_back(g); st.reps.h64.push_back(std::move(h));
+  }
+  ok = ok && rd(fp, cluster_count) && cluster_count < ((size_t)1 << 31);
+  for (size_t c = 0; ok && c < cluster_count; c++) {
+    size_t m = 0;
+    ok = rd(fp, m) && m < ((size_t)1 << 31);
+    if (!ok) break;
+    std::vector<int> cl(m);
+    if (m) ok = fread(cl.data(), sizeof(int), m, fp) == m;
+    st.clusters.push_back(std::move(cl));
+  }
+  ok = ok && rd(fp, all_count) && all_count < ((size_t)1 << 31);
+  for (size_t i = 0; ok && i < all_count; i++) {
+    GenomeInfo g; size_t name_len = 0;
+    ok = rd(fp, name_len) && name_len < ((size_t)1 << 20);
+    if (!ok) break;
+    g.fileName.resize(name_len);
+    if (name_len) ok = fread(&g.fileName[0], 1, name_len, fp) == name_len;
+    ok = ok && rd(fp, g.totalSeqLength);
+    g.seq0.name = "N/A"; g.seq0.comment = "";   // printRepDBClusterResult's text for genomes without record infos (src/sub_command.cpp:688-693)
+    st.genomes.push_back(g);
+  }
+  ok = ok && rd(fp, index_size);
+  for (size_t i = 0; ok && i < index_size; i++) {
+    uint64_t h = 0; size_t ls = 0;
+    ok = rd(fp, h) && rd(fp, ls) && ls < ((size_t)1 << 31) && fseek(fp, (long)(ls * sizeof(int)), SEEK_CUR) == 0;
+  }
+  fclose(fp);
+  if (!ok) { std::cerr << "ERROR: truncated or malformed RepDB: " << path << std::endl; return false; }
+  if (st.clusters.size() != rep_count) { std::cerr << "ERROR: " << st.clusters.size() << " clusters for " << rep_count << " representatives" << std::endl; return false; }
+  std::cerr << "MinHash RepDB loaded from: " << path << std::endl
+            << "  Representatives: " << rep_count << std::endl
+            << "  Total genomes:   " << all_count << std::endl
+            << "  Inverted index:  " << index_size << " unique hashes" << std::endl
+            << "  Threshold:       " << st.threshold << std::endl
+            << "  Kmer size:       " << st.kmer_size << std::endl
+            << "  Sketch size:     " << st.sketch_size << std::endl
+            << "  Containment:     " << (st.is_containment ? "yes" : "no") << std::endl;
+  return true;
+}
+
 // src/greedy.cpp:2656-2765
 void print_kssd_repdb_stats(const KssdClusterState& st, std::ostream& out) {
   size_t total_genomes = 0;
@@ -1133,14 +1242,19 @@ void print_kssd_repdb_stats(const KssdClusterState& st, std::ostream& out) {
   const size_t nrep = st.rep_ids.size();
   auto rep_size = [&](size_t r) { return st.reps.use64 ? st.reps.h64[r].size() : st.reps.h32[r].size(); };
   out << "========================================" << std::endl;
-  out << "        RepDB Statistics Report" << std::endl;
+  out << (st.minhash ? "    MinHash RepDB Statistics Report" : "        RepDB Statistics Report") << std::endl;
   out << "========================================" << std::endl << std::endl;
   out << "[Basic Info]" << std::endl;
   out << "  Threshold:              " << st.threshold << std::endl;
   out << "  Kmer size:              " << st.kmer_size << std::endl;
-  out << "  KSSD half_k:            " << st.info.half_k << std::endl;
-  out << "  KSSD half_subk:         " << st.info.half_subk << std::endl;
-  out << "  KSSD drlevel:           " << st.info.drlevel << std::endl << std::endl;
+  if (st.minhash) {
+    out << "  Sketch size:            " << st.sketch_size << std::endl;
+    out << "  Containment mode:       " << (st.is_containment ? "yes" : "no") << std::endl << std::endl;
+  } else {
+    out << "  KSSD half_k:            " << st.info.half_k << std::endl;
+    out << "  KSSD half_subk:         " << st.info.half_subk << std::endl;
+    out << "  KSSD drlevel:           " << st.info.drlevel << std::endl << std::endl;
+  }
   out << "[Scale]" << std::endl;
   out << "  Total genomes:          " << total_genomes << std::endl;
   out << "  Representatives:        " << nrep << std::endl;
@@ -1182,9 +1296,8 @@ void print_kssd_repdb_stats(const KssdClusterState& st, std::ostream& out) {
     out << "  P95 cluster size:       " << sizes[(size_t)(sizes.size() * 0.95)] << std::endl;
     out << "  P99 cluster size:       " << sizes[(size_t)(sizes.size() * 0.99)] << std::endl;
   }
-  out << std::endl;
-  out << "[Representative Sketch Sizes]" << std::endl;
-  if (nrep) {
+  if (!st.minhash) out << std::endl << "[Representative Sketch Sizes]" << std::endl;   // (the MinHash report has no such section)
+  if (nrep && !st.minhash) {
     size_t min_sk = SIZE_MAX, max_sk = 0, sum_sk = 0;
     for (size_t r = 0; r < nrep; r++) { const size_t z = rep_size(r); min_sk = std::min(min_sk, z); max_sk = std::max(max_sk, z); sum_sk += z; }
     out << "  Min sketch size:        " << min_sk << std::endl;

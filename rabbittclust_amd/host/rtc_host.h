@@ -103,6 +103,10 @@ struct KssdClusterState {
   std::vector<GenomeInfo> rep_genomes;  // representative r: id, length, file name ...
   KssdSketchFile reps;                  // ... and hashes, r = position in rep_ids
   std::vector<std::vector<int>> clusters;  // clusters[r] belongs to representative r
+  // MinHash RepDB (MinHashClusterState, src/greedy.h): u64 hashes in reps.h64, these instead of the KSSD parameters
+  bool minhash = false;
+  int sketch_size = 0;
+  bool is_containment = false;
 };
 bool save_kssd_cluster_state(const std::string& path, const KssdClusterState& st);
 bool load_kssd_cluster_state(const std::string& path, KssdClusterState& st);
@@ -113,6 +117,9 @@ bool load_kssd_cluster_state(const std::string& path, KssdClusterState& st);
 bool save_kssd_repdb(const std::string& path, const KssdClusterState& st);
 bool load_kssd_repdb(const std::string& path, KssdClusterState& st);
 void print_kssd_repdb_stats(const KssdClusterState& st, std::ostream& out);
+// MinHash twin (MinHashClusterState::save_repdb / ::load_repdb / ::print_stats, src/greedy.cpp:2789-3147): "MHREPDB1"
+bool save_minhash_repdb(const std::string& path, const KssdClusterState& st);
+bool load_minhash_repdb(const std::string& path, KssdClusterState& st);
 
 void save_mst(const std::vector<rtc_edge>& mst, const std::string& folder);   // edge.mst
 bool load_mst(const std::string& folder, std::vector<rtc_edge>& mst);

@@ -552,8 +552,172 @@ def test_clust_greedy_fast_repdb(oracle, tmp_path):
     assert r.returncode != 0 and "--db requires one of: --build, --query, --assign, --append, --stats" in r.stderr
     r = subprocess.run([G, "--fast", "--db", db, "--query", "-o", apout], capture_output=True, text=True)
     assert r.returncode != 0 and "--query requires -i <input_file>" in r.stderr
-    r = subprocess.run([G, "--db", db, "--stats"], capture_output=True, text=True)
-    assert r.returncode != 0 and "outside the sketch + all-pairs path" in r.stderr
+    r = subprocess.run([G, "--db", db, "--stats"], capture_output=True, text=True)  # without --fast: read as a MinHash RepDB
+    assert r.returncode != 0 and "Invalid MinHash RepDB file (bad magic)" in r.stderr
+
+
+def _read_mh_repdb(path):
+    """MinHashClusterState::save_repdb (src/greedy.cpp:2789-2862), field by field."""
+    import struct
+    b = open(path, "rb").read()
+    assert b[:8] == b"MHREPDB1"
+    thr, k, ssz, cont = struct.unpack_from("<dii?", b, 8)
+    p = 8 + 8 + 4 + 4 + 1
+    (nrep,) = struct.unpack_from("<Q", b, p); p += 8
+    rep_ids, rep_names, rep_len, rep_sk = [], [], [], []
+    for _ in range(nrep):
+        rid, gid, tot, c2 = struct.unpack_from("<iiQ?", b, p); p += 4 + 4 + 8 + 1
+        assert c2 == cont
+        (nh,) = struct.unpack_from("<Q", b, p); p += 8
+        rep_sk.append(np.frombuffer(b, dtype=np.uint64, count=nh, offset=p).copy()); p += 8 * nh
+        (nl,) = struct.unpack_from("<Q", b, p); p += 8
+        rep_names.append(b[p:p + nl].decode()); p += nl
+        rep_ids.append(rid); rep_len.append(tot)
+    (ncl,) = struct.unpack_from("<Q", b, p); p += 8
+    cls = []
+    for _ in range(ncl):
+        (m,) = struct.unpack_from("<Q", b, p); p += 8
+        cls.append(list(struct.unpack_from("<%di" % m, b, p))); p += 4 * m
+    (nall,) = struct.unpack_from("<Q", b, p); p += 8
+    names, lens = [], []
+    for _ in range(nall):
+        (nl,) = struct.unpack_from("<Q", b, p); p += 8
+        names.append(b[p:p + nl].decode()); p += nl
+        (tot,) = struct.unpack_from("<Q", b, p); p += 8
+        lens.append(tot)
+    (nidx,) = struct.unpack_from("<Q", b, p); p += 8
+    index = {}
+    for _ in range(nidx):
+        h, ls = struct.unpack_from("<QQ", b, p); p += 16
+        index[h] = list(struct.unpack_from("<%di" % ls, b, p)); p += 4 * ls
+    assert p == len(b)
+    return dict(thr=thr, k=k, sketch_size=ssz, cont=cont, rep_ids=rep_ids, rep_names=rep_names, rep_len=rep_len, rep_sk=rep_sk,
+                clusters=cls, names=names, lens=lens, index=index)
+
+
+def _mh_dist(cm, sq, sr, kmer):
+    """minhash_mash_distance, fixed-size mode (src/greedy.cpp:2771-2787)."""
+    if cm <= 0:
+        return 1.0
+    den = sq + sr - cm
+    if den == 0:
+        return 0.0
+    jac = cm / den
+    if jac >= 1.0:
+        return 0.0
+    return min(1.0, -math.log(2.0 * jac / (1.0 + jac)) / kmer)
+
+
+def test_clust_greedy_minhash_repdb(oracle, tmp_path):
+    """clust-greedy --db FILE on MinHash sketches (mh_repdb_*, src/sub_command.cpp:502-758; MinHashClusterState,
+    src/greedy.cpp:1903-2130, :2771-3147): --build from genomes and from a folder (list order, no size sort), --stats,
+    --query, --assign, --append, against a Python restatement on the oracle's sketches."""
+    tmp = str(tmp_path)
+    L = 2_000_000
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 4, 4, L, seed=34)
+    perm = [0, 5, 10, 1, 4, 8, 9, 2, 3, 6, 7, 13, 11, 12, 14, 15]  # family 3 is absent from the database
+    first, second = perm[:7], perm[7:]
+    la, lb = os.path.join(tmp, "a.txt"), os.path.join(tmp, "b.txt")
+    open(la, "w").write("\n".join(paths[i] for i in first) + "\n")
+    open(lb, "w").write("\n".join(paths[i] for i in second) + "\n")
+    G = os.path.join(BIN, "clust-greedy")
+    da = os.path.join(tmp, "a"); os.makedirs(da)
+    db, db2 = os.path.join(tmp, "rep.db"), os.path.join(tmp, "rep2.db")
+    err = _run([G, "--db", db, "--build", "-l", "-i", la, "-k", "21", "-s", "1000", "-d", "0.05", "-t", "4", "-o", os.path.join(da, "a.out")], da)
+    assert "===== MinHash RepDB Build (from genomes) =====" in err and "MinHash RepDB saved to: " + db in err
+    folder = [os.path.join(da, d) for d in os.listdir(da) if os.path.isdir(os.path.join(da, d))][0]
+    err = _run([G, "--db", db2, "--build", "--presketched", folder, "-d", "0.05", "-o", os.path.join(da, "a2.out")], da)
+    assert "===== MinHash RepDB Build (from pre-sketched) =====" in err
+    assert open(db, "rb").read() == open(db2, "rb").read()
+    assert open(os.path.join(da, "a.out")).read() == open(os.path.join(da, "a2.out")).read()
+    # ---- restatement of the build: the MinHash greedy pass in list order ----
+    off = np.arange(len(seqs) + 1, dtype=np.uint64) * L
+    sk_all = oracle.sketch_minhash_batch(np.concatenate(seqs), off, 21, 1000)
+    sk = {i: sk_all[i] for i in perm}
+    flat, start, lens = oracle.to_csr([sk[i] for i in first])
+    ncl, rep = oracle.greedy_minhash(flat, start, lens, 1000, 21, False, 0.05)
+    clusters, cid = [], {}
+    for pos, r in enumerate(rep):
+        if int(r) == pos:
+            cid[pos] = len(clusters); clusters.append([pos])
+    for pos, r in enumerate(rep):
+        if int(r) != pos:
+            clusters[cid[int(r)]].append(pos)
+    assert _parse_clusters(os.path.join(da, "a.out")) == clusters and 1 < len(clusters) < len(first)
+    d = _read_mh_repdb(db)
+    reps = sorted(cid, key=lambda g: cid[g])
+    assert (d["thr"], d["k"], d["sketch_size"], d["cont"]) == (0.05, 21, 1000, False)
+    assert d["rep_ids"] == reps and d["clusters"] == clusters
+    assert d["rep_names"] == [paths[first[g]] for g in reps] and d["names"] == [paths[i] for i in first]
+    assert d["lens"] == [L] * len(first) and d["rep_len"] == [L] * len(reps)
+    assert all(np.array_equal(a, sk[first[g]]) for a, g in zip(d["rep_sk"], reps))
+    want_index = {}
+    for ridx, g in enumerate(reps):
+        for h in sk[first[g]].tolist():
+            want_index.setdefault(h, []).append(ridx)
+    assert d["index"] == want_index
+    # ---- --stats ----
+    r = subprocess.run([G, "--db", db, "--stats"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    txt = r.stdout
+    assert "    MinHash RepDB Statistics Report" in txt and "  Sketch size:            1000\n" in txt
+    assert "  Containment mode:       no\n" in txt and "[Representative Sketch Sizes]" not in txt
+    assert "  Total genomes:          %d\n" % len(first) in txt and "  Representatives:        %d\n" % len(reps) in txt
+    assert "  Unique hashes:          %d\n" % len(want_index) in txt
+    assert "  Total sequence length:  %d bp\n" % (L * len(first)) in txt
+    # ---- --query / --assign: every representative sharing a hash, by distance, no filter ----
+    rep_sets = [set(sk[first[g]].tolist()) for g in reps]
+    qout, aout = os.path.join(tmp, "q.tsv"), os.path.join(tmp, "as.tsv")
+    _run([G, "--db", db, "--query", "-l", "-i", lb, "--top-k", "2", "-t", "4", "-o", qout], tmp)
+    _run([G, "--db", db, "--assign", "-l", "-i", lb, "-t", "4", "-o", aout], tmp)
+    want_q = ["#query\trank\trep_name\tdistance\tcluster_id\tcluster_size\n"]
+    want_a = ["#query\tassigned_cluster\trep_name\tdistance\tcluster_size\tstatus\n"]
+    n_match = n_none = 0
+    for i in second:
+        q = set(sk[i].tolist())
+        cand = sorted((_mh_dist(len(q & rs), len(q), len(rs), 21), r) for r, rs in enumerate(rep_sets) if q & rs)
+        assert len({c[0] for c in cand}) == len(cand)  # no distance ties in the test data
+        if not cand:
+            want_q.append("%s\t0\tno_match\t-1\t-1\t0\n" % paths[i]); n_none += 1
+        for rank, (dist, r) in enumerate(cand[:2]):
+            want_q.append("%s\t%d\t%s\t%.6f\t%d\t%d\n" % (paths[i], rank + 1, paths[first[reps[r]]], dist, r, len(clusters[r])))
+        if cand and cand[0][0] <= 0.05:
+            want_a.append("%s\t%d\t%s\t%.6f\t%d\tassigned\n" % (paths[i], cand[0][1], paths[first[reps[cand[0][1]]]], cand[0][0], len(clusters[cand[0][1]])))
+            n_match += 1
+        else:
+            want_a.append("%s\t-1\tunassigned\t-1\t0\tnovel\n" % paths[i])
+    assert n_match >= 2 and n_match + n_none < len(second) and n_none >= 3
+    assert open(qout).readlines() == want_q
+    assert open(aout).readlines() == want_a
+    # ---- --append: MinHashIncrementalCluster (minimum-common filter, no size-ratio filter) ----
+    apout = os.path.join(tmp, "ap.out")
+    err = _run([G, "--db", db, "--append", lb, "-l", "-t", "4", "-o", apout], tmp)
+    assert "===== MinHash RepDB Append =====" in err
+    order = first + second
+    sets = [set(sk[i].tolist()) for i in order]
+    x = math.exp(-0.05 * 21); jmin = x / (2.0 - x)
+    for q in range(len(first), len(order)):
+        rl = sorted(cid, key=lambda g: cid[g])
+        cand = []
+        for r, g in enumerate(rl):
+            cm = len(sets[q] & sets[g])
+            if cm == 0 or cm < int(jmin * (len(sets[q]) + len(sets[g])) / (1.0 + jmin)):
+                continue
+            dist = _mh_dist(cm, len(sets[q]), len(sets[g]), 21)
+            if dist <= 0.05:
+                cand.append((dist, r))
+        if cand:
+            clusters[min(cand)[1]].append(q)
+        else:
+            cid[q] = len(clusters); clusters.append([])
+    assert _parse_clusters(apout) == clusters
+    assert open(apout).read().startswith("# Clustering threshold: 0.050000\n# Total clusters: %d\n#\n" % len(clusters))
+    d = _read_mh_repdb(db)
+    reps = sorted(cid, key=lambda g: cid[g])
+    assert any(g >= len(first) for g in reps)
+    assert d["rep_ids"] == reps and d["clusters"] == clusters
+    assert d["names"] == [paths[i] for i in order] and d["rep_names"] == [paths[order[g]] for g in reps]
+    assert all(np.array_equal(a, sk[order[g]]) for a, g in zip(d["rep_sk"], reps))
 
 
 def test_clust_mst_batching_gzip_retry_and_min_length_filter(oracle, tmp_path):
