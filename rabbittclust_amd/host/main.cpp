@@ -10,8 +10,9 @@
 // per GPU, file batches go round-robin to the GPUs, the sketches stay in HBM (copied to the host only
 // to write hash.sketch), are shared among the GPUs with RCCL broadcasts, and the MST runs
 // row-sharded with one all-reduce per Boruvka round (rtc_mst_sharded).  Also here: --append (clust-mst, and
-// clust-greedy --fast without a stored state), --dense, the tree / linkage writers.  The representative
-// database (--db ...), --save-rep cluster states, --auto-threshold and its companions and single-FASTA mode
+// clust-greedy --fast with or without a stored state), --dense, the tree / linkage writers, clust-greedy's
+// --save-rep cluster state (--fast) and representative database (--db ..., KSSD and MinHash).  clust-mst's
+// --db / --save-rep, the MinHash cluster state, --auto-threshold and its companions and single-FASTA mode
 // are outside this path and exit with a message.
 #include <math.h>
 #include <iomanip>
