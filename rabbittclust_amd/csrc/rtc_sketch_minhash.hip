@@ -49,9 +49,21 @@ constexpr size_t QUEUE_BYTES = (size_t)NWAVE * QCAP * 16;
 // hash tables in LDS (see kmer_hash_parts): per 8 bases of k one 256-entry table of 16-byte entries
 // (first four bases of the word) and, where the word has more than four bases, one of 4-byte entries
 constexpr size_t LUT_LO_BYTES = 256 * 16, LUT_HI_BYTES = 256 * 4;
+// A last word of at most five bases has a table of its own instead: 4^bases entries of 8 bytes holding the
+// finished contribution (at most 8 KiB), one ds_read_b64 and two VALU instructions for the word.
 __host__ __device__ constexpr int lut_words(int k) { return (k + 7) / 8; }
-__host__ __device__ constexpr int lut_his(int k) { return (k + 3) / 8; }   // word w has a second half iff k > 8w + 4
-__host__ __device__ constexpr size_t lut_bytes(int k) { return (size_t)lut_words(k) * LUT_LO_BYTES + (size_t)lut_his(k) * LUT_HI_BYTES; }
+__host__ __device__ constexpr int lut_last_nb(int k) { return k - 8 * (lut_words(k) - 1); }   // bases of the last word, 1..8
+#ifdef RTC_NO_DIRECT_LUT
+__host__ __device__ constexpr bool lut_direct(int k) { return false; }
+#else
+__host__ __device__ constexpr bool lut_direct(int k) { return lut_last_nb(k) <= 5; }
+#endif
+__host__ __device__ constexpr int lut_los(int k) { return lut_words(k) - (lut_direct(k) ? 1 : 0); }  // words with the table pair
+__host__ __device__ constexpr int lut_his(int k) { return lut_direct(k) ? lut_los(k) : (k + 3) / 8; }  // word w has a second half iff k > 8w + 4
+__host__ __device__ constexpr size_t lut_direct_bytes(int k) { return lut_direct(k) ? ((size_t)8 << (2 * lut_last_nb(k))) : 0; }
+__host__ __device__ constexpr size_t lut_bytes(int k) {
+  return (size_t)lut_los(k) * LUT_LO_BYTES + (size_t)lut_his(k) * LUT_HI_BYTES + lut_direct_bytes(k);
+}
 
 struct Segment {
   uint64_t g_begin, g_end;  // genome byte range in d_seq
@@ -148,17 +160,33 @@ __device__ __forceinline__ KParams make_kparams(int k, uint32_t seed) {
   return P;
 }
 
-// Called by all WG threads; the first 256 fill one column each.  Layout: lut_words(k) tables of
-// {u64 P, u32 AH, pad} at w * LUT_LO_BYTES, then lut_his(k) tables of u32 BL.
+// Called by all WG threads; the first 256 fill one column each.  Layout: lut_los(k) tables of
+// {u64 P, u32 AH, pad} at w * LUT_LO_BYTES, then lut_his(k) tables of u32 BL, then the last word's own table
+// (lut_direct(k)): entry i = rotl(w * c, r) * c' of the word whose bases are the 2-bit codes of i.
 __device__ __forceinline__ void build_kmer_lut(lds_byte_ptr lut, int k) {
   const uint32_t e = threadIdx.x;
   if (e >= 256) return;
   const uint32_t a4 = codes_to_ascii(e);
-  const uint32_t hi_base = (uint32_t)(lut_words(k) * LUT_LO_BYTES);
+  const uint32_t hi_base = (uint32_t)(lut_los(k) * LUT_LO_BYTES);
+  if (lut_direct(k)) {
+    const int wl = lut_words(k) - 1, nb = lut_last_nb(k);
+    typedef RTC_LDS uint64_t* lds_u64w_ptr;
+    const lds_u64w_ptr dt = (lds_u64w_ptr)(lut + hi_base + (size_t)lut_his(k) * LUT_HI_BYTES);
+    for (uint32_t i = e; i < (1u << (2 * nb)); i += 256) {
+      const uint32_t e4 = nb >= 4 ? ((i >> (2 * nb - 8)) & 0xffu) : ((i << (8 - 2 * nb)) & 0xffu);   // first four bases, first on top
+      const uint32_t am = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+      uint64_t wd = (uint64_t)(codes_to_ascii(e4) & am);
+      if (nb == 5) wd |= (uint64_t)(codes_to_ascii((i & 3u) << 6) & 0xffu) << 32;
+      uint64_t S, K;
+      if (wl & 1) { S = wd * MM_C2; K = ((S << 33) | (S >> 31)) * MM_C1; }
+      else { S = wd * MM_C1; K = ((S << 31) | (S >> 33)) * MM_C2; }
+      dt[i] = K;
+    }
+  }
 #pragma unroll
   for (int w = 0; w < 4; w++) {
     const int nb = k - 8 * w;  // bytes of this word
-    if (nb <= 0) break;
+    if (nb <= 0 || w >= lut_los(k)) break;
     const uint64_t c = (w & 1) ? MM_C2 : MM_C1;
     const uint32_t am = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
     const uint64_t A = (uint64_t)(a4 & am) * c;
@@ -245,16 +273,29 @@ __device__ __forceinline__ HashParts kmer_hash_parts(uint64_t x, const KParams& 
   typedef const RTC_LDS u32x4* lds_u4_cptr;
   typedef const RTC_LDS uint32_t* lds_u32_cptr;
   const uint32_t four = 4, two = 2;
-  const uint32_t hi_base = (uint32_t)(lut_words(k) * LUT_LO_BYTES);
+  const uint32_t hi_base = (uint32_t)(lut_los(k) * LUT_LO_BYTES);
+  const uint32_t dt_base = hi_base + (uint32_t)(lut_his(k) * LUT_HI_BYTES);
+  // the last word's own table: its 2nb bits sit at the top of the word's 16-bit slot (whatever lies below them is
+  // not part of the k-mer and is cut off), entry offset = field << 3
+  typedef const RTC_LDS uint64_t* lds_u64_cptr;
+  const int dnb = lut_last_nb(k);
+#define RTC_DT(H, odd) (*(lds_u64_cptr)(uintptr_t)(dt_base + ((odd) ? (__builtin_amdgcn_ubfe((H), 16 - 2 * dnb, 2 * dnb) << 3) \
+                                                                     : (((H) >> (32 - 2 * dnb)) << 3))))
 #define RTC_LO(w, off) (*(lds_u4_cptr)(uintptr_t)((off) + (uint32_t)((w) * LUT_LO_BYTES)))
 #define RTC_HI(w, off) (*(lds_u32_cptr)(uintptr_t)((off) + hi_base + (uint32_t)((w) * LUT_HI_BYTES)))
   uint64_t K0 = 0, K1 = 0, K2 = 0, K3 = 0;  // the words' contributions, already rotl(w * c, r) * c'
-  K0 = word_k1(RTC_LO(0, byte_x8<3>(hi, four)), k > 4 ? RTC_HI(0, byte_x8<2>(hi, two)) : 0u);
-  if (k > 8) K1 = word_k2(RTC_LO(1, byte_x8<1>(hi, four)), k > 12 ? RTC_HI(1, byte_x8<0>(hi, two)) : 0u);
-  if (k > 16) K2 = word_k1(RTC_LO(2, byte_x8<3>(lo, four)), k > 20 ? RTC_HI(2, byte_x8<2>(lo, two)) : 0u);
-  if (k > 24) K3 = word_k2(RTC_LO(3, byte_x8<1>(lo, four)), k > 28 ? RTC_HI(3, byte_x8<0>(lo, two)) : 0u);
+  const int dw = lut_direct(k) ? lut_words(k) - 1 : -1;  // the word that has a table of its own
+  if (dw == 0) K0 = RTC_DT(hi, false);
+  else K0 = word_k1(RTC_LO(0, byte_x8<3>(hi, four)), k > 4 ? RTC_HI(0, byte_x8<2>(hi, two)) : 0u);
+  if (dw == 1) K1 = RTC_DT(hi, true);
+  else if (k > 8) K1 = word_k2(RTC_LO(1, byte_x8<1>(hi, four)), k > 12 ? RTC_HI(1, byte_x8<0>(hi, two)) : 0u);
+  if (dw == 2) K2 = RTC_DT(lo, false);
+  else if (k > 16) K2 = word_k1(RTC_LO(2, byte_x8<3>(lo, four)), k > 20 ? RTC_HI(2, byte_x8<2>(lo, two)) : 0u);
+  if (dw == 3) K3 = RTC_DT(lo, true);
+  else if (k > 24) K3 = word_k2(RTC_LO(3, byte_x8<1>(lo, four)), k > 28 ? RTC_HI(3, byte_x8<0>(lo, two)) : 0u);
 #undef RTC_LO
 #undef RTC_HI
+#undef RTC_DT
   uint64_t h1 = P.seed, h2 = P.seed;
   uint64_t t0 = K0, t1 = K1;  // tail contributions
   if (k >= 16) {
