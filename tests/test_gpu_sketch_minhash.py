@@ -32,7 +32,7 @@ def _check(ctx, oracle, seq, off, k, size=None, sizes=None):
         assert np.array_equal(a, b), f"genome {g}: k={k} got {len(a)} want {len(b)}"
 
 
-@pytest.mark.parametrize("k", [21, 17, 16, 11, 32, 5, 18, 19, 20, 22, 23, 24, 28, 29])
+@pytest.mark.parametrize("k", [21, 17, 16, 11, 32, 5, 18, 19, 20, 22, 23, 24, 28, 29, 1, 3, 9, 13, 25, 27, 31])
 def test_sketch_matches_oracle_various_k(ctx, oracle, k):
     rng = np.random.default_rng(100 + k)
     seq, off = _random_genomes(rng, [50_000, 123_457, 80_001, 15_359, 15_361, 30_720])
