@@ -897,6 +897,15 @@ std::vector<std::vector<int>> generate_cluster_with_bfs(const std::vector<rtc_ed
   return res;
 }
 
+// skips n bytes of fp; false when the file ends before them
+static bool skip_bytes(FILE* fp, size_t n) {
+  const long at = ftell(fp);
+  if (at < 0 || fseek(fp, 0, SEEK_END) != 0) return false;
+  const long end = ftell(fp);
+  if (end < 0 || (size_t)(end - at) < n) return false;
+  return fseek(fp, at + (long)n, SEEK_SET) == 0;
+}
+
 // the representatives' inverted index as the reference's writers lay it out (hash, list length, positions in
 // rep_ids); keys ascending here (the reference walks a hash map)
 static size_t write_rep_index(FILE* fp, const KssdClusterState& st) {
@@ -1112,7 +1121,7 @@ bool load_kssd_repdb(const std::string& path, KssdClusterState& st) {
   ok = ok && rd(fp, index_size);
   for (size_t i = 0; ok && i < index_size; i++) {   // walked for the truncation check only
     uint64_t h64 = 0; uint32_t h32 = 0; size_t ls = 0;
-    ok = (v2 ? rd(fp, h64) : rd(fp, h32)) && rd(fp, ls) && ls < ((size_t)1 << 31) && fseek(fp, (long)(ls * sizeof(int)), SEEK_CUR) == 0;
+    ok = (v2 ? rd(fp, h64) : rd(fp, h32)) && rd(fp, ls) && ls < ((size_t)1 << 31) && skip_bytes(fp, ls * sizeof(int));
   }
   fclose(fp);
   if (!ok) { std::cerr << "ERROR: truncated or malformed RepDB: " << path << std::endl; return false; }
@@ -1219,7 +1228,7 @@ bool load_minhash_repdb(const std::string& path, KssdClusterState& st) {
   ok = ok && rd(fp, index_size);
   for (size_t i = 0; ok && i < index_size; i++) {
     uint64_t h = 0; size_t ls = 0;
-    ok = rd(fp, h) && rd(fp, ls) && ls < ((size_t)1 << 31) && fseek(fp, (long)(ls * sizeof(int)), SEEK_CUR) == 0;
+    ok = rd(fp, h) && rd(fp, ls) && ls < ((size_t)1 << 31) && skip_bytes(fp, ls * sizeof(int));
   }
   fclose(fp);
   if (!ok) { std::cerr << "ERROR: truncated or malformed RepDB: " << path << std::endl; return false; }

@@ -339,3 +339,103 @@ def test_tree_and_linkage_writers_from_premsted_folder(tmp_path):
     tree2, link2 = _py_dendrogram(n, edges[:-1], names)
     assert (tmp_path / "res.out.newick.tree").read_text() == tree2 + "\n" and names[n - 1] not in tree2
     assert (tmp_path / "res.out.linkage.txt").read_text().splitlines() == link2 and len(link2) == n - 2
+
+
+def _write_kssd_repdb(path, thr, k, half_k, half_subk, drlevel, reps, clusters, genomes):
+    """reps: [(genome id, name, length, u32 hashes)], genomes: [(name, length)] -- KssdClusterState::save_repdb
+    (src/greedy.cpp:2351-2428)."""
+    index = {}
+    with open(path, "wb") as f:
+        f.write(b"REPDB002" + struct.pack("<diiiii", thr, k, half_k, half_subk, drlevel, len(genomes)))
+        f.write(struct.pack("<Q", len(reps)))
+        for r, (gid, name, length, hashes) in enumerate(reps):
+            f.write(struct.pack("<iiQ?I", gid, gid, length, False, len(hashes)) + struct.pack("<QQ", len(hashes), 0))
+            f.write(np.asarray(hashes, dtype=np.uint32).tobytes())
+            f.write(struct.pack("<Q", len(name)) + name.encode())
+            for h in hashes:
+                index.setdefault(int(h), []).append(r)
+        f.write(struct.pack("<Q", len(clusters)))
+        for c in clusters:
+            f.write(struct.pack("<Q", len(c)) + struct.pack("<%di" % len(c), *c))
+        f.write(struct.pack("<Q", len(genomes)))
+        for name, length in genomes:
+            f.write(struct.pack("<Q", len(name)) + name.encode() + struct.pack("<Q", length))
+        f.write(struct.pack("<Q", len(index)))
+        for h, lst in index.items():
+            f.write(struct.pack("<QQ", h, len(lst)) + struct.pack("<%di" % len(lst), *lst))
+    return index
+
+
+def test_repdb_stats_reads_reference_layout(tmp_path):
+    """clust-greedy [--fast] --db FILE --stats needs no GPU: a REPDB002 / MHREPDB1 file laid out by this test as the
+    reference's save_repdb lays it out (src/greedy.cpp:2351-2428, :2789-2862) is read and reported as print_stats
+    reports it (:2656-2765, :3057-3147); truncated files and wrong magics are refused."""
+    import subprocess
+    binp = os.path.join(ROOT, "rabbittclust_amd", "bin", "clust-greedy")
+    if not os.path.exists(binp):
+        pytest.fail("clust-greedy missing: run __graft_entry__.build()")
+    rng = np.random.default_rng(11)
+    genomes = [("/g/%d.fna" % i, 1_000_000 + 1000 * i) for i in range(9)]
+    clusters = [[0, 3, 4, 7], [1], [2, 5, 6, 8]]
+    reps = []
+    for c in clusters:
+        n = int(rng.integers(300, 600))
+        hashes = np.unique(rng.integers(0, 5000, size=n).astype(np.uint32))  # small range: shared hashes between representatives
+        reps.append((c[0], genomes[c[0]][0], genomes[c[0]][1], hashes))
+    db = str(tmp_path / "rep.db")
+    index = _write_kssd_repdb(db, 0.05, 20, 10, 6, 3, reps, clusters, genomes)
+    r = subprocess.run([binp, "--fast", "--db", db, "--stats"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-2000:]
+    postings = sum(len(v) for v in index.values())
+    rep_len = sum(x[2] for x in reps)
+    tot_len = sum(x[1] for x in genomes)
+    want = "\n".join([
+        "========================================", "        RepDB Statistics Report", "========================================", "",
+        "[Basic Info]", "  Threshold:              0.05", "  Kmer size:              20", "  KSSD half_k:            10",
+        "  KSSD half_subk:         6", "  KSSD drlevel:           3", "",
+        "[Scale]", "  Total genomes:          9", "  Representatives:        3", "  Clusters:               3",
+        "  Compression ratio:      66.67%", "",
+        "[Inverted Index]", "  Unique hashes:          %d" % len(index), "  Total postings:         %d" % postings,
+        "  Avg posting length:     %.2f" % (postings / len(index)), "  Max posting length:     %d" % max(len(v) for v in index.values()), "",
+        "[Cluster Size Distribution]", "  Min cluster size:       1", "  Max cluster size:       4", "  Mean cluster size:      3.00",
+        "  Median cluster size:    4", "  Singletons:             1 (33.3%)", "  P90 cluster size:       4", "  P95 cluster size:       4",
+        "  P99 cluster size:       4", "",
+        "[Representative Sketch Sizes]", "  Min sketch size:        %d" % min(len(x[3]) for x in reps),
+        "  Max sketch size:        %d" % max(len(x[3]) for x in reps), "  Mean sketch size:       %.1f" % (sum(len(x[3]) for x in reps) / 3), "",
+        "[Genome Coverage]", "  Total sequence length:  %d bp" % tot_len, "  Representative seq len: %d bp" % rep_len,
+        "  Coverage ratio:         %.2f%%" % (100.0 * rep_len / tot_len), "========================================", ""])
+    assert r.stdout == want
+    assert "RepDB loaded from: " + db in r.stderr and "  Inverted index:  %d unique hashes" % len(index) in r.stderr
+    raw = open(db, "rb").read()
+    for cut in (4, 30, 60, len(raw) // 2, len(raw) - 3):
+        bad = str(tmp_path / ("cut%d.db" % cut))
+        open(bad, "wb").write(raw[:cut])
+        r = subprocess.run([binp, "--fast", "--db", bad, "--stats"], capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and "ERROR" in r.stderr and r.stdout == ""
+    r = subprocess.run([binp, "--db", db, "--stats"], capture_output=True, text=True, timeout=60)  # KSSD file read as MinHash RepDB
+    assert r.returncode != 0 and "Invalid MinHash RepDB file (bad magic)" in r.stderr
+    # MHREPDB1 (src/greedy.cpp:2789-2862)
+    mh = str(tmp_path / "mh.db")
+    with open(mh, "wb") as f:
+        f.write(b"MHREPDB1" + struct.pack("<dii?", 0.03, 21, 1000, False) + struct.pack("<Q", len(reps)))
+        for gid, name, length, hashes in reps:
+            f.write(struct.pack("<iiQ?", gid, gid, length, False) + struct.pack("<Q", len(hashes)))
+            f.write(np.asarray(hashes, dtype=np.uint64).tobytes() + struct.pack("<Q", len(name)) + name.encode())
+        f.write(struct.pack("<Q", len(clusters)))
+        for c in clusters:
+            f.write(struct.pack("<Q", len(c)) + struct.pack("<%di" % len(c), *c))
+        f.write(struct.pack("<Q", len(genomes)))
+        for name, length in genomes:
+            f.write(struct.pack("<Q", len(name)) + name.encode() + struct.pack("<Q", length))
+        f.write(struct.pack("<Q", len(index)))
+        for h, lst in index.items():
+            f.write(struct.pack("<QQ", h, len(lst)) + struct.pack("<%di" % len(lst), *lst))
+    r = subprocess.run([binp, "--db", mh, "--stats"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.startswith("========================================\n    MinHash RepDB Statistics Report\n")
+    assert "  Threshold:              0.03\n  Kmer size:              21\n  Sketch size:            1000\n  Containment mode:       no\n\n[Scale]" in r.stdout
+    assert "[Representative Sketch Sizes]" not in r.stdout
+    assert "  P99 cluster size:       4\n\n[Genome Coverage]\n" in r.stdout
+    assert "  Unique hashes:          %d\n" % len(index) in r.stdout
+    r = subprocess.run([binp, "--fast", "--db", mh, "--stats"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "Invalid RepDB file (bad magic)" in r.stderr
