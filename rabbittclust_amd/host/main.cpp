@@ -1,7 +1,8 @@
 // main.cpp -- clust-mst / clust-greedy command lines on top of the MI355X C ABI.
 //
 // Mirrors the flag surface and workflow dispatch of the reference's src/main.cpp:113-254,291-671
-// for the sketch + all-pairs + cluster path: list-mode input (-l), MinHash
+// for the sketch + all-pairs + cluster path: list-mode input (-l) or one FASTA file whose
+// records are the genomes (no -l), MinHash
 // and KSSD (--fast) sketching, --presketched / --premsted resume, -e/--no-save, and the same
 // intermediate folder (info.sketch, hash.sketch, minhash.sketch.index, kssd.*, info.mst,
 // edge.mst).  Built twice: -DGREEDY_CLUST gives clust-greedy, otherwise clust-mst
@@ -12,8 +13,8 @@
 // row-sharded with one all-reduce per Boruvka round (rtc_mst_sharded).  Also here: --append (clust-mst, and
 // clust-greedy --fast with or without a stored state), --dense, the tree / linkage writers, clust-greedy's
 // --save-rep cluster state (--fast) and representative database (--db ..., KSSD and MinHash).  clust-mst's
-// --db / --save-rep, the MinHash cluster state, --auto-threshold and its companions and single-FASTA mode
-// are outside this path and exit with a message.
+// --db / --save-rep, the MinHash cluster state, --auto-threshold and its companions and single-FASTA input to
+// --append / --db are outside this path and exit with a message.
 #include <math.h>
 #include <iomanip>
 #include <limits>
@@ -458,6 +459,126 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
 // "all CPUs of the platform" (src/main.cpp:75-76,113), bounded by what this process may actually
 // use: the affinity mask (omp_get_num_procs) and a cgroup-v2 CPU quota.  Oversubscribing a quota
 // makes the parser threads time-slice against each other.
+// sketchSequences / sketchSequencesWithKssd (src/SketchInfo.cpp:554-862, consumers :205-272, :274-436): without -l the
+// input is ONE FASTA file and every record of at least minLen bases is a genome of its own (SequenceInfo{name, comment,
+// strand 0, length}).  Records keep their file order (the reference's RabbitFX consumers merge per-thread vectors, so
+// its order depends on the thread count; one consumer gives file order).  The records travel to the GPU back to back
+// -- the offsets are the genome boundaries -- in batches; the sketches come back to the host vectors.
+struct SeqModeSizes { uint64_t maxSize = 1, minSize = 1u << 31, totalSize = 0; int number = 0, badNumber = 0; };
+
+static bool read_sequences(const string& inputFile, uint64_t minLen, vector<FastaRecord>& kept, SeqModeSizes& sz) {
+  const size_t dot = inputFile.find_last_of('.');
+  const string suf = dot == string::npos ? string() : inputFile.substr(dot + 1);
+  if (suf != "fasta" && suf != "fna" && suf != "fa") {
+    cerr << "error input format file: " << inputFile << endl << "Only support FASTA files" << endl;
+    exit(1);
+  }
+  vector<FastaRecord> recs;
+  if (!read_fasta(inputFile, recs)) { fprintf(stderr, "ERROR: sketchSequences(), cannot open the genome file, %s\n", inputFile.c_str()); return false; }
+  for (FastaRecord& r : recs) {   // calSize, sequence branch (src/SketchInfo.cpp:484-535)
+    const uint64_t len = r.seq.size();
+    if (len < minLen) { sz.badNumber++; continue; }
+    sz.maxSize = std::max(sz.maxSize, len); sz.minSize = std::min(sz.minSize, len); sz.totalSize += len; sz.number++;
+    kept.push_back(std::move(r));
+  }
+  if (sz.number == 0) { cerr << "ERROR: calSize(), no sequence passes the minimum length filter" << endl; return false; }
+  const int totalNumber = sz.number + sz.badNumber;
+  cerr << "\t===the genome number for clustering is: " << sz.number << endl
+       << "\t===the genome number below the minimum genome length threshold is: " << sz.badNumber << endl
+       << "\t===the total genome number is: " << totalNumber << endl;
+  if ((double)sz.badNumber / totalNumber >= 0.2)
+    fprintf(stderr, "Warning: there are %d poor quality (length < %ld) genome assemblies in the total %d genome assemblied.\n", sz.badNumber, (long)minLen, totalNumber);
+  cerr << "\t===the totalSize is: " << sz.totalSize << endl << "\t===the maxSize is: " << sz.maxSize << endl
+       << "\t===the minSize is: " << sz.minSize << endl << "\t===the averageSize is: " << sz.totalSize / sz.number << endl;
+  return true;
+}
+
+static void sketch_sequences(vector<Gpu>& gpus, vector<FastaRecord>& recs, const SketchJob& job, vector<GenomeInfo>& genomes,
+                             MinHashSketchFile* mh, KssdSketchFile* ks) {
+  rtc_ctx* c = gpus[0].ctx;
+  const size_t n = recs.size();
+  vector<int32_t> shuffled;
+  int half_subk = 0;
+  if (job.kssd) {
+    half_subk = 6 - job.drlevel >= 2 ? 6 : job.drlevel + 2;
+    shuffled = generate_shuffle_dim(half_subk);
+    const int half_k = (job.kmerSize + 1) / 2;
+    ks->info.half_k = half_k; ks->info.half_subk = half_subk; ks->info.drlevel = job.drlevel;
+    ks->info.id = (half_k << 8) + (half_subk << 4) + job.drlevel; ks->info.genomeNumber = (int)n;
+    ks->use64 = half_k - job.drlevel > 8;
+  }
+  genomes.resize(n);
+  for (size_t i = 0; i < n; i++) {
+    GenomeInfo& g = genomes[i];
+    g.id = (int)i; g.totalSeqLength = recs[i].seq.size(); g.use64 = job.kssd && ks->use64;
+    g.seq0.name = recs[i].name; g.seq0.comment = recs[i].has_comment ? recs[i].comment : string();
+    g.seq0.strand = 0; g.seq0.length = (int)recs[i].seq.size();
+  }
+  if (job.kssd) { if (ks->use64) ks->h64.resize(n); else ks->h32.resize(n); } else mh->hashes.resize(n);
+  const uint64_t BATCH = (uint64_t)1 << 30;
+  void* d_seq = nullptr; uint64_t d_seq_bytes = 0;
+  for (size_t i0 = 0; i0 < n;) {
+    size_t i1 = i0; uint64_t bytes = 0;
+    while (i1 < n && (i1 == i0 || bytes + recs[i1].seq.size() <= BATCH)) bytes += recs[i1++].seq.size();
+    const uint32_t nb = (uint32_t)(i1 - i0);
+    if (bytes + 64 > d_seq_bytes) { if (d_seq) CHECK(c, rtc_dev_free(c, d_seq)); d_seq_bytes = bytes + 64; CHECK(c, rtc_dev_alloc(c, d_seq_bytes, &d_seq)); }
+    vector<char> h_seq(bytes + 64, 'N');
+    vector<uint64_t> off(nb + 1, 0);
+    vector<uint32_t> sizes(nb);
+    for (uint32_t q = 0; q < nb; q++) {
+      const string& sq = recs[i0 + q].seq;
+      memcpy(h_seq.data() + off[q], sq.data(), sq.size());
+      off[q + 1] = off[q] + sq.size();
+      sizes[q] = job.isContainment ? (uint32_t)std::max((int)sq.size() / job.containCompress, 100) : (uint32_t)job.sketchSize;   // :224-231
+    }
+    CHECK(c, rtc_copy_h2d(c, d_seq, h_seq.data(), bytes + 64));
+    uint32_t* d_cnt = nullptr; void* d_out = nullptr;
+    CHECK(c, rtc_dev_alloc(c, (size_t)nb * 4 + 64, (void**)&d_cnt));
+    uint32_t stride = 0; int w = 8;
+    if (!job.kssd) {
+      stride = *std::max_element(sizes.begin(), sizes.end());
+      CHECK(c, rtc_dev_alloc(c, (size_t)nb * stride * 8 + 64, &d_out));
+      CHECK(c, rtc_sketch_minhash_dev(c, (const uint8_t*)d_seq, off.data(), nb, job.kmerSize, 42, sizes.data(), stride, (uint64_t*)d_out, stride, d_cnt));
+    } else {
+      w = ks->use64 ? 8 : 4;
+      uint64_t maxlen = 0;
+      for (uint32_t q = 0; q < nb; q++) maxlen = std::max(maxlen, off[q + 1] - off[q]);
+      stride = (uint32_t)(maxlen / (1ull << (4 * job.drlevel)) * 3 / 2 + 256);
+      CHECK(c, rtc_dev_alloc(c, (size_t)nb * stride * w + 64, &d_out));
+      while (true) {
+        int width = 0; uint32_t need = 0;
+        const int st = rtc_sketch_kssd_dev(c, (const uint8_t*)d_seq, off.data(), nb, job.kmerSize, job.drlevel, shuffled.data(), d_out, stride, d_cnt,
+                                           &width, &need);
+        if (st == RTC_ERR_OVERFLOW) {
+          CHECK(c, rtc_dev_free(c, d_out));
+          stride = need + 64;
+          CHECK(c, rtc_dev_alloc(c, (size_t)nb * stride * w + 64, &d_out));
+          continue;
+        }
+        CHECK(c, st);
+        break;
+      }
+    }
+    vector<uint32_t> cnt(nb);
+    CHECK(c, rtc_copy_d2h(c, cnt.data(), d_cnt, (size_t)nb * 4));
+    vector<unsigned char> out((size_t)nb * stride * w);
+    CHECK(c, rtc_copy_d2h(c, out.data(), d_out, out.size()));
+    for (uint32_t q = 0; q < nb; q++) {
+      if (w == 8) {
+        const uint64_t* p = (const uint64_t*)out.data() + (size_t)q * stride;
+        if (job.kssd) ks->h64[i0 + q].assign(p, p + cnt[q]); else mh->hashes[i0 + q].assign(p, p + cnt[q]);
+      } else {
+        const uint32_t* p = (const uint32_t*)out.data() + (size_t)q * stride;
+        ks->h32[i0 + q].assign(p, p + cnt[q]);
+      }
+    }
+    CHECK(c, rtc_dev_free(c, d_out)); CHECK(c, rtc_dev_free(c, d_cnt));
+    for (size_t i = i0; i < i1; i++) { string().swap(recs[i].seq); }
+    i0 = i1;
+  }
+  if (d_seq) CHECK(c, rtc_dev_free(c, d_seq));
+}
+
 static int default_threads() {
   int n = omp_get_num_procs();
   if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -1303,9 +1424,15 @@ int main(int argc, char** argv) {
     cerr << "========time of load genome Infos and sketch Infos is: " << get_sec() - t0 << endl;
   } else {
     if (!o.has_input) { cerr << "ERROR: -i/--input is required" << endl; return 1; }
-    if (!o.sketchByFile) unsupported("single-FASTA input (run with -l and a genome list)");
+    sketchByFile = o.sketchByFile;
     uint64_t maxSize, minSize, averageSize;
-    if (!cal_size(o.inputFile, o.minLen, maxSize, minSize, averageSize)) return 1;
+    vector<FastaRecord> seq_recs;
+    if (o.sketchByFile) { if (!cal_size(o.inputFile, o.minLen, maxSize, minSize, averageSize)) return 1; }
+    else {
+      SeqModeSizes sz;
+      if (!read_sequences(o.inputFile, o.minLen, seq_recs, sz)) return 1;
+      maxSize = sz.maxSize; minSize = sz.minSize; averageSize = sz.totalSize / sz.number;
+    }
     // main.cpp:632 (clust-mst --fast uses the kssd tuner) / :659 (everything else)
     if (o.is_fast && !greedy) { if (!tune_kssd_parameters(o.isSetKmer, maxSize, minSize, averageSize, o.isContainment, o.kmerSize, o.threshold, o.drlevel)) return 1; }
     else if (!tune_parameters(greedy, o.isSetKmer, maxSize, minSize, averageSize, o.isContainment, o.isJaccard, o.kmerSize, o.threshold, o.containCompress, o.sketchSize)) return 1;
@@ -1313,7 +1440,8 @@ int main(int argc, char** argv) {
     job.kssd = o.is_fast; job.kmerSize = o.kmerSize; job.sketchSize = o.sketchSize; job.isContainment = o.isContainment;
     job.containCompress = o.containCompress; job.drlevel = o.drlevel; job.minLen = o.minLen; job.threads = o.threads;
     if (getenv("RTC_VERBOSE")) fprintf(stderr, "[tune]  cal_size + tune_parameters in %.3fs\n", get_sec() - t0);
-    sketch_files(gpus, o.inputFile, job, genomes, &mh, &ks, rs, !o.noSave);
+    if (o.sketchByFile) sketch_files(gpus, o.inputFile, job, genomes, &mh, &ks, rs, !o.noSave);
+    else sketch_sequences(gpus, seq_recs, job, genomes, &mh, &ks);
     mh.kmerSize = o.kmerSize; mh.isContainment = o.isContainment; mh.containCompress = o.containCompress; mh.sketchSize = o.sketchSize;
     cerr << "-----the size of sketches (number of genomes or sequences) is: " << genomes.size() << endl;
     double t1 = get_sec();
@@ -1322,8 +1450,8 @@ int main(int argc, char** argv) {
     if (!o.noSave) {
       string command = "mkdir -p " + folder_path;
       if (system(command.c_str()) != 0) { cerr << "ERROR: cannot create " << folder_path << endl; return 1; }
-      if (o.is_fast) { save_kssd_sketches(genomes, ks, folder_path, true); if (!greedy) save_kssd_index(ks, folder_path); }
-      else { save_minhash_sketches(genomes, mh, folder_path, true); save_minhash_index(mh, folder_path); }
+      if (o.is_fast) { save_kssd_sketches(genomes, ks, folder_path, sketchByFile); if (!greedy) save_kssd_index(ks, folder_path); }
+      else { save_minhash_sketches(genomes, mh, folder_path, sketchByFile); save_minhash_index(mh, folder_path); }
       cerr << "========time of saveSketches is: " << get_sec() - t1 << "========" << endl;
     }
   }
@@ -1356,6 +1484,10 @@ int main(int argc, char** argv) {
       vector<size_t> perm(genomes.size());
       iota(perm.begin(), perm.end(), 0);
       std::sort(perm.begin(), perm.end(), [&](size_t a, size_t b) {
+        if (!sketchByFile) {  // cmpSeqSize (src/SketchInfo.cpp:54-58)
+          if (genomes[a].seq0.length != genomes[b].seq0.length) return genomes[a].seq0.length > genomes[b].seq0.length;
+          return genomes[a].id < genomes[b].id;
+        }
         if (genomes[a].totalSeqLength != genomes[b].totalSeqLength) return genomes[a].totalSeqLength > genomes[b].totalSeqLength;
         return genomes[a].id < genomes[b].id;
       });
@@ -1368,8 +1500,9 @@ int main(int argc, char** argv) {
     } else {
       size_cfg.resize(genomes.size());
       for (size_t i = 0; i < genomes.size(); i++)
-        size_cfg[i] = mh.isContainment ? (uint32_t)std::max(file_length_for_containment(genomes[i].fileName) / mh.containCompress, 100)
-                                       : (uint32_t)mh.sketchSize;
+        size_cfg[i] = !mh.isContainment ? (uint32_t)mh.sketchSize
+                      : sketchByFile ? (uint32_t)std::max(file_length_for_containment(genomes[i].fileName) / mh.containCompress, 100)
+                                     : (uint32_t)std::max(genomes[i].seq0.length / mh.containCompress, 100);
     }
   }
   // greedy has a serial dependency on the representative set: one GPU clusters (replicas only)
@@ -1436,7 +1569,7 @@ int main(int argc, char** argv) {
   double t3 = get_sec();
   cerr << "========time of generateMST is: " << t3 - t2 << "========" << endl;
   if (!o.noSave && !from_sketches) {
-    save_genome_info(genomes, folder_path, "mst", true, o.is_fast);
+    save_genome_info(genomes, folder_path, "mst", sketchByFile, o.is_fast);
     save_mst(mst, folder_path);
     cerr << "========time of saveMST is: " << get_sec() - t3 << "========" << endl;
   }

@@ -962,3 +962,105 @@ def test_clust_mst_dense_files_and_noise_removal(oracle, tmp_path):
     out2 = os.path.join(tmp, "d2.out")
     _run([os.path.join(BIN, "clust-mst"), "--premsted", folder, "--dense", "-d", "0.05", "-o", out2], tmp)
     assert open(out2 + ".removeNoise").read() == open(out + ".removeNoise").read()
+
+
+def test_single_fasta_sequence_mode(oracle, tmp_path):
+    """Without -l the input is one FASTA file and every record of at least -m bases is a genome (sketchSequences /
+    sketchSequencesWithKssd, src/SketchInfo.cpp:554-862; calSize's sequence branch :484-535): records below the
+    minimum are dropped, the rest keep file order; info.sketch in its sequence layout (src/Sketch_IO.cpp:88-134),
+    sketches equal to the oracle's, clusters printed in the sequence format (src/MST_IO.cpp:136-160).  clust-mst,
+    clust-greedy, MinHash and --fast, plus the --presketched flow of the folder."""
+    from rabbittclust_amd import api
+    tmp = str(tmp_path)
+    L = 2_000_000
+    desc = api.synth_family_descs(3, 3, global_seed=77)
+    seqs = [oracle.synth_genome(int(d["fam_seed"]), int(d["mut_seed"]), int(d["mut_thr"]), L) for d in desc]
+    lens = [L, L - 1234, L - 77, L - 50000, L, L - 9, L - 300000, L - 1, L - 4321]   # distinct but for two: ties keep file order
+    fa = os.path.join(tmp, "all.fna")
+    recs = []
+    with open(fa, "wb") as f:
+        for g, s in enumerate(seqs):
+            body = s.tobytes()[:lens[g]]
+            if g == 4:
+                body = body.lower()
+            name, comment = "seq%d" % g, ("family %d member" % (g // 3) if g % 2 == 0 else None)
+            f.write((">" + name + (" " + comment if comment else "") + "\n").encode())
+            w = 60 if g % 2 else 100
+            for i in range(0, len(body), w):
+                f.write(body[i:i + w] + b"\n")
+            recs.append((name, comment or "", body))
+            if g in (1, 5):   # short records between the genomes: dropped by -m
+                f.write((">short%d tiny\n" % g).encode() + body[:5000] + b"\n")
+    M = os.path.join(BIN, "clust-mst")
+    out = os.path.join(tmp, "mst.out")
+    dm = os.path.join(tmp, "m"); os.makedirs(dm)
+    err = _run([M, "-i", fa, "-k", "21", "-s", "1000", "-d", "0.05", "-m", "10000", "-t", "4", "-o", out], dm)
+    assert "\t===the genome number for clustering is: 9" in err and "threshold is: 2\n" in err
+    assert "\t===the maxSize is: %d" % L in err and "\t===the minSize is: %d" % (L - 300000) in err
+    folder = [os.path.join(dm, d) for d in os.listdir(dm) if os.path.isdir(os.path.join(dm, d))][0]
+    # info.sketch, sequence layout
+    raw = open(os.path.join(folder, "info.sketch"), "rb").read()
+    by_file, n = struct.unpack_from("<?Q", raw, 0)
+    assert (by_file, n) == (False, 9)
+    p = 9
+    for name, comment, body in recs:
+        nl, cl, strand, length = struct.unpack_from("<iiii", raw, p); p += 16
+        assert (nl, cl, strand, length) == (len(name), len(comment), 0, len(body))
+        assert raw[p:p + nl].decode() == name and raw[p + nl:p + nl + cl].decode() == comment
+        p += nl + cl
+    assert p == len(raw)
+    off = np.zeros(10, dtype=np.uint64); off[1:] = np.cumsum([len(r[2]) for r in recs])
+    allb = np.frombuffer(b"".join(r[2] for r in recs), dtype=np.uint8)
+    want_sk = oracle.sketch_minhash_batch(allb, off, 21, 1000)
+    hdr, got_sk = _read_hash_sketch(folder)
+    assert hdr == (0, 21, False, 1000)
+    assert len(got_sk) == 9 and all(np.array_equal(a, b) for a, b in zip(got_sk, want_sk))
+    flat, start, slens = oracle.to_csr(want_sk)
+    want_mst = oracle.mst(flat, start, slens, 21, 0, 0.05)
+    got_cl = _parse_seq_clusters(out)
+    assert _partition(got_cl) == _partition(oracle.forest_clusters(want_mst, 0.05, 9)) and 1 < len(got_cl) < 9
+    text = open(out).read()
+    assert ("\t%6d\t%6d\t%12dnt\t%20s\t%s\n" % (0, 0, lens[0], "seq0", "family 0 member")) in text
+    assert ("\t%6d\t%12dnt\t%20s\t%s\n" % (1, lens[1], "seq1", "")) in text   # no comment: an empty field
+    out2 = os.path.join(tmp, "mst2.out")
+    _run([M, "--presketched", folder, "-d", "0.05", "-o", out2], tmp)
+    assert open(out2).read() == text
+    # clust-greedy on the same file: greedy pass in file order
+    G = os.path.join(BIN, "clust-greedy")
+    og = os.path.join(tmp, "g.out")
+    dg = os.path.join(tmp, "g"); os.makedirs(dg)
+    _run([G, "-i", fa, "-k", "21", "-s", "1000", "-d", "0.05", "-t", "4", "-o", og], dg)
+    ncl, rep = oracle.greedy_minhash(flat, start, slens, 1000, 21, False, 0.05)
+    want = {}
+    for i, r in enumerate(rep):
+        want.setdefault(int(r), []).append(i)
+    assert _parse_seq_clusters(og) == [[r] + [m for m in ms if m != r] for r, ms in sorted(want.items())]
+    # --fast: KSSD sketches per record
+    of = os.path.join(tmp, "f.out")
+    df = os.path.join(tmp, "f"); os.makedirs(df)
+    _run([M, "--fast", "-i", fa, "-k", "21", "-d", "0.05", "-t", "4", "-o", of], df)
+    ffolder = [os.path.join(df, d) for d in os.listdir(df) if os.path.isdir(os.path.join(df, d))][0]
+    want_ks = [oracle.kssd_sketch(np.frombuffer(r[2], dtype=np.uint8), 21, 3) for r in recs]
+    rawk = open(os.path.join(ffolder, "kssd.hash.sketch"), "rb").read()
+    assert struct.unpack_from("<iiiii", rawk, 0) == ((11 << 8) + (6 << 4) + 3, 11, 6, 3, 9)
+    pos = 20
+    for w in want_ks:
+        (m,) = struct.unpack_from("<Q", rawk, pos); pos += 8
+        assert np.array_equal(np.frombuffer(rawk, dtype="<u4", count=m, offset=pos), w); pos += 4 * m
+    assert pos == len(rawk)
+    kflat, kstart, klens = oracle.to_csr(want_ks, dtype=np.uint32)
+    assert _partition(_parse_seq_clusters(of)) == _partition(oracle.forest_clusters(oracle.mst(kflat, kstart, klens, 22, 0, 0.05), 0.05, 9))
+    # a list file given without -l is refused like any non-FASTA name
+    r = subprocess.run([M, "-i", os.path.join(tmp, "list.txt"), "-o", out2], capture_output=True, text=True)
+    assert r.returncode != 0 and "Only support FASTA files" in r.stderr
+
+
+def _parse_seq_clusters(path):
+    clusters, cur = [], None
+    for ln in open(path):
+        if ln.startswith("the cluster"):
+            cur = []
+            clusters.append(cur)
+        elif ln.startswith("\t"):
+            cur.append(int(ln.split("\t")[2]))
+    return clusters
