@@ -285,7 +285,7 @@ int rtc_comm_wait(rtc_comm* c) {
 }
 
 // Contiguous row ranges of the strict lower triangle with equal cost; row i costs (i + fixed_cols)
-// (fixed_cols: per-row-block table build that does not depend on the row length, ~8.8 columns per
+// (fixed_cols: per-row-block table build that does not depend on the row length, ~1.84 columns per
 // sketch hash on MI355X).  h_bounds[world + 1].
 int rtc_triangle_rows(uint32_t n, int world, double fixed_cols, uint32_t* h_bounds) {
   if (world < 1 || !h_bounds) return RTC_ERR_ARG;
@@ -356,7 +356,7 @@ int rtc_mst_sharded(rtc_ctx* ctx, rtc_comm* c, const void* d_hashes, int width, 
   for (uint32_t g = 0; g < n; g++) mean += h_len[g];
   mean /= n;
   std::vector<uint32_t> bounds(c->size + 1);
-  RTC_TRY(rtc_triangle_rows(n, c->size, c->size > 1 ? 8.8 * mean : 0.0, bounds.data()));
+  RTC_TRY(rtc_triangle_rows(n, c->size, c->size > 1 ? 1.84 * mean : 0.0, bounds.data()));
   const uint32_t row0 = bounds[c->rank], row1 = bounds[c->rank + 1];
 
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;

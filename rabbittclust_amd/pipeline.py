@@ -23,7 +23,7 @@ KEY_NONE = 0x7FFFFFFFFFFFFFFF
 def triangle_row_ranges(n, world, fixed_cols=0.0):
     """Contiguous row ranges [b_r, b_{r+1}) of the strict lower triangle with ~equal cost.
     Row i costs (i + fixed_cols): i pairs plus the per-row-block work that does not depend on the
-    row's length (building the LDS tables of its 64-row block costs as much as ~8.8 columns per
+    row's length (building the LDS tables of its 64-row block costs as much as ~1.84 columns per
     sketch hash on MI355X: tools/sim_rank.py).  With fixed_cols = 0 the split is by pair count,
     boundaries n*sqrt(r/world)."""
     c = float(fixed_cols)
@@ -399,7 +399,7 @@ class MstPipeline:
             w.wait()
         sk = finish()
         ev[2].record()
-        fixed_cols = 8.8 * float(sk.len.float().mean().item()) if self.world > 1 else 0.0
+        fixed_cols = 1.84 * float(sk.len.float().mean().item()) if self.world > 1 else 0.0
         b = triangle_row_ranges(sk.n, self.world, fixed_cols=fixed_cols)
         row0, row1 = b[self.rank], b[self.rank + 1]
         edges, m = self.candidate_edges(sk, row0, row1)

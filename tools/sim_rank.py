@@ -15,7 +15,7 @@ seq = ctx.synth_genomes(desc, off)
 sk = ctx.sketch_minhash(seq, off, k=21, size=1000)
 ctx.sync()
 del seq
-fixed = float(sys.argv[5]) if len(sys.argv) > 5 else 8800.0
+fixed = float(sys.argv[5]) if len(sys.argv) > 5 else 1840.0
 b = pipeline.triangle_row_ranges(sk.n, world, fixed_cols=fixed)
 pipe = pipeline.MstPipeline(ctx, k=21, sketch_size=1000, threshold=0.05, rank=rank, world=world)
 for it in range(3):
