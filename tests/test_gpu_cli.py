@@ -1035,6 +1035,18 @@ def test_single_fasta_sequence_mode(oracle, tmp_path):
     for i, r in enumerate(rep):
         want.setdefault(int(r), []).append(i)
     assert _parse_seq_clusters(og) == [[r] + [m for m in ms if m != r] for r, ms in sorted(want.items())]
+    # clust-greedy's default: containment sketches, size = record length / (average length / 1000) (tune_parameters)
+    oc = os.path.join(tmp, "gc.out")
+    _run([G, "-i", fa, "-k", "21", "-d", "0.05", "-t", "4", "-e", "-o", oc], tmp)
+    compress = (sum(lens) // len(lens)) // 1000
+    cfg = np.array([max(x // compress, 100) for x in lens], dtype=np.uint32)
+    csk = oracle.sketch_minhash_batch(allb, off, 21, cfg)
+    cflat, cstart, clens = oracle.to_csr(csk)
+    ncl, rep = oracle.greedy_minhash(cflat, cstart, clens, cfg, 21, True, 0.05)
+    want = {}
+    for i, r in enumerate(rep):
+        want.setdefault(int(r), []).append(i)
+    assert _parse_seq_clusters(oc) == [[r] + [m for m in ms if m != r] for r, ms in sorted(want.items())]
     # --fast: KSSD sketches per record
     of = os.path.join(tmp, "f.out")
     df = os.path.join(tmp, "f"); os.makedirs(df)
