@@ -123,17 +123,31 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t x) {
   return x;
 }
 
-// fmix64 without its last xorshift (which changes the low word only): the high words of the two
-// halves decide almost every threshold test, the low words are finished on demand (mm_finish)
+// fmix64 without its last multiply and xorshift.  With f = x * FMIX_C2 for the two halves the hash is
+// (f1 ^ f1 >> 33) + (f2 ^ f2 >> 33); the last xorshift changes the low words only, so the high words of f1 and
+// f2 decide almost every threshold test -- and their SUM is all the test needs:
+//   hi(a * C) + hi(b * C) = mulhi(a.lo, C.lo) + mulhi(b.lo, C.lo) + (a.lo + b.lo) * C.hi + (a.hi + b.hi) * C.lo  (mod 2^32)
+// (two cross products instead of four, no 64-bit products at all): hash_test_word.  The full halves are
+// formed on demand, for the few k-mers that pass (mm_finish).
+constexpr uint64_t FMIX_C2 = 0xc4ceb9fe1a85ec53ULL;
 __device__ __forceinline__ uint64_t fmix64_open(uint64_t x) {
   x ^= x >> 33;
   x *= 0xff51afd7ed558ccdULL;
   x ^= x >> 33;
-  x *= 0xc4ceb9fe1a85ec53ULL;
   return x;
 }
-struct HashParts { uint64_t f1, f2; };  // hash = (f1 ^ f1 >> 33) + (f2 ^ f2 >> 33)
-__device__ __forceinline__ uint64_t mm_finish(const HashParts& p) { return (p.f1 ^ (p.f1 >> 33)) + (p.f2 ^ (p.f2 >> 33)); }
+struct HashParts { uint64_t f1, f2; };  // the two halves before their last multiply
+__device__ __forceinline__ uint64_t mm_finish(const HashParts& p) {
+  const uint64_t f1 = p.f1 * FMIX_C2, f2 = p.f2 * FMIX_C2;
+  return (f1 ^ (f1 >> 33)) + (f2 ^ (f2 >> 33));
+}
+// hi(f1) + hi(f2) + 1 (mod 2^32) of the halves p stands for
+__device__ __forceinline__ uint32_t hash_test_word(const HashParts& p) {
+  const uint32_t alo = (uint32_t)p.f1, ahi = (uint32_t)(p.f1 >> 32), blo = (uint32_t)p.f2, bhi = (uint32_t)(p.f2 >> 32);
+  const uint32_t cl = (uint32_t)FMIX_C2, ch = (uint32_t)(FMIX_C2 >> 32);
+  const uint32_t m = __umulhi(alo, cl) + __umulhi(blo, cl) + (alo + blo) * ch;
+  return m + (ahi + bhi) * cl + 1u;
+}
 
 constexpr uint64_t MM_C1 = 0x87c37b91114253d5ULL, MM_C2 = 0x4cf5ad432745937fULL;
 
@@ -666,7 +680,7 @@ restart:
                 uint64_t cm = 0, mq[4];
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
-                  const uint32_t u = (uint32_t)(hp[b].f1 >> 32) + (uint32_t)(hp[b].f2 >> 32) + 1u;
+                  const uint32_t u = hash_test_word(hp[b]);
                   mq[b] = __ballot(u <= Thi1);
                   cm |= mq[b];
                 }
@@ -844,7 +858,7 @@ restart:
               uint64_t cm = 0, mq[4];
 #pragma unroll
               for (int b = 0; b < 4; b++) {
-                const uint32_t u = (uint32_t)(hp[b].f1 >> 32) + (uint32_t)(hp[b].f2 >> 32) + 1u;
+                const uint32_t u = hash_test_word(hp[b]);
                 mq[b] = __ballot(u <= Thi1);
                 cm |= mq[b];
               }
