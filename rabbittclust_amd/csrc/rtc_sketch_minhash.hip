@@ -264,17 +264,15 @@ __device__ __forceinline__ uint64_t word_k1(const u32x4 e, uint32_t BL) {
   const uint32_t hi = (uint32_t)(R >> 32) + v * (uint32_t)(MM_C2 >> 32) + (SH << 31);
   return __builtin_bit_cast(uint64_t, make_uint2((uint32_t)R, hi));
 }
-// rotl(S, 33) * c1 for a k2 word
+// rotl(S, 33) * c1 for a k2 word: (S.hi * c1) << 1 + P = S.hi * (2 c1 mod 2^64) + P, the table value as the
+// addend of the v_mad_u64_u32 and the constant's high word as one cross product
 __device__ __forceinline__ uint64_t word_k2(const u32x4 e, uint32_t BL) {
+  constexpr uint64_t C1X2 = MM_C1 << 1;
   const uint32_t SH = e.z + BL;
-  const uint64_t Z0 = (uint64_t)SH * (uint32_t)MM_C1;
-  uint32_t cross = SH * (uint32_t)(MM_C1 >> 32);
+  const uint64_t R = (uint64_t)SH * (uint32_t)C1X2 + __builtin_bit_cast(uint64_t, make_uint2(e.x, e.y));  // v_mad_u64_u32
+  uint32_t cross = SH * (uint32_t)(C1X2 >> 32);
   asm("" : "+v"(cross));  // keep it a v_mul_lo_u32 + v_add_u32: fused into a second v_mad_u64_u32 it costs two extra moves
-  const uint64_t Z = __builtin_bit_cast(uint64_t, make_uint2((uint32_t)Z0, (uint32_t)(Z0 >> 32) + cross));
-  uint64_t r;
-  const uint64_t Pv = __builtin_bit_cast(uint64_t, make_uint2(e.x, e.y));
-  asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(r) : "v"(Z), "v"(Pv));
-  return r;
+  return __builtin_bit_cast(uint64_t, make_uint2((uint32_t)R, (uint32_t)(R >> 32) + cross));
 }
 
 // x: canonical k-mer, 2 bits per base, first base in the top bits (canon << (64 - 2k))
