@@ -261,7 +261,12 @@ __device__ __forceinline__ uint32_t byte_x8(uint32_t w, uint32_t three) {
 __device__ __forceinline__ uint64_t word_k1(const u32x4 e, uint32_t BL) {
   const uint32_t SH = e.z + BL, v = SH >> 1;
   const uint64_t R = (uint64_t)v * (uint32_t)MM_C2 + __builtin_bit_cast(uint64_t, make_uint2(e.x, e.y));  // v_mad_u64_u32
-  const uint32_t hi = (uint32_t)(R >> 32) + v * (uint32_t)(MM_C2 >> 32) + (SH << 31);
+  // the high word takes v * hi(c2) + (SH & 1) << 31: with hi(c2) odd that is rotr32(SH, 1) * hi(c2) -- one rotate, one
+  // product, one two-input add instead of a shift, a product and a three-input add
+  static_assert(((MM_C2 >> 32) & 1) == 1, "hi(c2) must be odd");
+  uint32_t cross = __builtin_amdgcn_alignbit(SH, SH, 1) * (uint32_t)(MM_C2 >> 32);
+  asm("" : "+v"(cross));
+  const uint32_t hi = (uint32_t)(R >> 32) + cross;
   return __builtin_bit_cast(uint64_t, make_uint2((uint32_t)R, hi));
 }
 // rotl(S, 33) * c1 for a k2 word: (S.hi * c1) << 1 + P = S.hi * (2 c1 mod 2^64) + P, the table value as the
