@@ -141,13 +141,27 @@ __device__ __forceinline__ uint64_t mm_finish(const HashParts& p) {
   const uint64_t f1 = p.f1 * FMIX_C2, f2 = p.f2 * FMIX_C2;
   return (f1 ^ (f1 >> 33)) + (f2 ^ (f2 >> 33));
 }
-// hi(f1) + hi(f2) + 1 (mod 2^32) of the halves p stands for
+// The test word.  (f1 + f2) mod 2^64 = (a + b) * C for the halves a, b before their last multiply, and its high
+// word is hi(f1) + hi(f2) + c1 (c1: the carry of the two low words), while hi(hash) = hi(f1) + hi(f2) + c2 (c2: the
+// carry of the low words AFTER their xorshift).  So w = hi((a + b) * C) + 1 lies in {hi(hash), hi(hash) + 1,
+// hi(hash) + 2} (mod 2^32): a hash below T has w <= hi(T) + 2, also when hi(f1) + hi(f2) wraps (w = 0 or 1 then).
+// One 64-bit add and the high word of ONE 64 x 64 product (mulhi + two cross products + add3) instead of two.
+constexpr uint32_t TEST_SLACK = 2;  // callers compare with hi(T) + TEST_SLACK and need hi(T) + TEST_SLACK < 2^32
+#ifdef RTC_TEST_TWO_HALVES   // A/B: the former form, hi(f1) + hi(f2) + 1 from the two halves separately (slack 1 suffices)
 __device__ __forceinline__ uint32_t hash_test_word(const HashParts& p) {
   const uint32_t alo = (uint32_t)p.f1, ahi = (uint32_t)(p.f1 >> 32), blo = (uint32_t)p.f2, bhi = (uint32_t)(p.f2 >> 32);
   const uint32_t cl = (uint32_t)FMIX_C2, ch = (uint32_t)(FMIX_C2 >> 32);
   const uint32_t m = __umulhi(alo, cl) + __umulhi(blo, cl) + (alo + blo) * ch;
   return m + (ahi + bhi) * cl + 1u;
 }
+#else
+__device__ __forceinline__ uint32_t hash_test_word(const HashParts& p) {
+  const uint64_t S = p.f1 + p.f2;
+  const uint32_t slo = (uint32_t)S, shi = (uint32_t)(S >> 32);
+  const uint32_t cl = (uint32_t)FMIX_C2, ch = (uint32_t)(FMIX_C2 >> 32);
+  return __umulhi(slo, cl) + slo * ch + shi * cl + 1u;
+}
+#endif
 
 constexpr uint64_t MM_C1 = 0x87c37b91114253d5ULL, MM_C2 = 0x4cf5ad432745937fULL;
 
@@ -633,9 +647,9 @@ restart:
         const int w0 = (int)uniform32((uint32_t)(t & ~63));
         const int wlo = OWN * w0 - 4 * WARM_DW, whi = OWN * (w0 + 63) - 4 * WARM_DW + 16 * NG;
         const uint32_t Thi_e = (uint32_t)(T >> 32);
-        if (!safe_mode && !lo1 && interior && Thi_e != 0xffffffffu && wlo >= gb && whi <= ge) {
+        if (!safe_mode && !lo1 && interior && Thi_e < 0xffffffffu - TEST_SLACK && wlo >= gb && whi <= ge) {
           const uint8_t* base = (tile - LOAD_BIAS) + (uint32_t)(rq0 + LOAD_BIAS);
-          const uint32_t Thi1 = Thi_e + 1u;
+          const uint32_t Thi1 = Thi_e + TEST_SLACK;
           uint4 cur = *reinterpret_cast<const uint4*>(base), nxt1 = *reinterpret_cast<const uint4*>(base + 16);
           // the reverse-complement extended window is kept shifted left by RE bits so that the byte of a new
           // dword lands on a byte boundary: one v_perm (high word) + one v_alignbit (low word) roll it
@@ -847,17 +861,17 @@ restart:
             constexpr bool ablate = false;
 #endif
             const uint32_t Thi = (uint32_t)(T >> 32);
-            if (!ablate && allok && P.use64 && !lo1 && Thi != 0xffffffffu) {
+            if (!ablate && allok && P.use64 && !lo1 && Thi < 0xffffffffu - TEST_SLACK) {
               // The steady state: hash = fin(f1) + fin(f2) where fin() touches the low word only, so
-              // hi(hash) = hi(f1) + hi(f2) + carry.  u = hi(f1) + hi(f2) + 1 (one v_add3) is hi(hash) or
-              // hi(hash) + 1: with u > hi(T) + 1 the hash cannot be below T -- one 32-bit compare per k-mer
-              // and the low words are never finished (T != SENT here since hi(T) != 2^32 - 1).  The few
-              // waves holding a possible candidate (hi(hash) <= hi(T): ~64 s / N of them) finish exactly.
+              // hi(hash) = hi(f1) + hi(f2) + carry.  The test word w (hash_test_word) is hi(hash) + {0, 1, 2}: with
+              // w > hi(T) + TEST_SLACK the hash cannot be below T -- one 32-bit compare per k-mer and the halves'
+              // last multiply is never formed (T != SENT here since hi(T) < 2^32 - 1 - TEST_SLACK).  The few
+              // waves holding a possible candidate (~64 s / N of them) finish exactly.
               // four independent hash chains: their LDS table reads and multiplies overlap
               HashParts hp[4];
 #pragma unroll
               for (int b = 0; b < 4; b++) hp[b] = kmer_hash_parts(canon[b], P);
-              const uint32_t Thi1 = Thi + 1u;
+              const uint32_t Thi1 = Thi + TEST_SLACK;
               uint64_t cm = 0, mq[4];
 #pragma unroll
               for (int b = 0; b < 4; b++) {

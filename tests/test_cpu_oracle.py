@@ -342,3 +342,34 @@ def test_greedy_oracle_equals_python_twin(oracle, mode):
         want_n, want = _py_greedy(sk, None, 22, False, 0.05, kssd=True)
         got_n, got = oracle.greedy_kssd(flat, start, lens, 22, 0.05)
         assert got_n == want_n and got.tolist() == want and 1 < got_n < len(sk)
+
+
+def test_sketch_threshold_test_word_bounds():
+    """The sketch kernel's one-compare threshold test (csrc/rtc_sketch_minhash.hip, hash_test_word): with a, b the two
+    fmix64 halves before their last multiply by C, w = hi32((a + b) * C mod 2^64) + 1 must equal hi32(hash) + {0, 1, 2}
+    (mod 2^32) for hash = fin(a * C) + fin(b * C), fin(f) = f ^ f >> 33 -- random halves and halves built so that
+    hi(f1) + hi(f2) wraps or sits at 2^32 - 1 / 2^32 - 2 (the cases the slack of 2 exists for)."""
+    M64, M32 = (1 << 64) - 1, (1 << 32) - 1
+    Cm = 0xc4ceb9fe1a85ec53
+    Cinv = pow(Cm, -1, 1 << 64)
+    rng = np.random.default_rng(7)
+
+    def check(a, b):
+        f1, f2 = a * Cm & M64, b * Cm & M64
+        h = ((f1 ^ f1 >> 33) + (f2 ^ f2 >> 33)) & M64
+        w = ((((a + b) & M64) * Cm & M64) >> 32) + 1 & M32
+        d = (w - (h >> 32)) & M32
+        assert d in (0, 1, 2), (hex(a), hex(b), d)
+        return d
+
+    seen = set()
+    for a, b in rng.integers(0, 1 << 64, size=(20000, 2), dtype=np.uint64).tolist():
+        seen.add(check(a, b))
+    # products with chosen high words: f1 = x, f2 = y  =>  a = x * C^-1, b = y * C^-1
+    for hi_sum in (M32, M32 - 1, 0, 1, (1 << 32), (1 << 32) + 1):
+        for _ in range(2000):
+            h1 = int(rng.integers(0, 1 << 32))
+            h2 = (hi_sum - h1) & M32
+            for lo1, lo2 in ((int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 32))), (M32, M32), (0, 0), (M32, 1)):
+                seen.add(check((h1 << 32 | lo1) * Cinv & M64, (h2 << 32 | lo2) * Cinv & M64))
+    assert seen == {0, 1, 2}
