@@ -125,10 +125,9 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t x) {
 
 // fmix64 without its last multiply and xorshift.  With f = x * FMIX_C2 for the two halves the hash is
 // (f1 ^ f1 >> 33) + (f2 ^ f2 >> 33); the last xorshift changes the low words only, so the high words of f1 and
-// f2 decide almost every threshold test -- and their SUM is all the test needs:
-//   hi(a * C) + hi(b * C) = mulhi(a.lo, C.lo) + mulhi(b.lo, C.lo) + (a.lo + b.lo) * C.hi + (a.hi + b.hi) * C.lo  (mod 2^32)
-// (two cross products instead of four, no 64-bit products at all): hash_test_word.  The full halves are
-// formed on demand, for the few k-mers that pass (mm_finish).
+// f2 decide almost every threshold test -- and their SUM is all the test needs, which is the high word of ONE
+// product, (a + b) * C, up to a carry: hash_test_word.  The full halves are formed on demand, for the few k-mers
+// that pass (mm_finish).
 constexpr uint64_t FMIX_C2 = 0xc4ceb9fe1a85ec53ULL;
 __device__ __forceinline__ uint64_t fmix64_open(uint64_t x) {
   x ^= x >> 33;
