@@ -60,9 +60,12 @@ __host__ __device__ constexpr bool lut_direct(int k) { return lut_last_nb(k) <= 
 #endif
 __host__ __device__ constexpr int lut_los(int k) { return lut_words(k) - (lut_direct(k) ? 1 : 0); }  // words with the table pair
 __host__ __device__ constexpr int lut_his(int k) { return lut_direct(k) ? lut_los(k) : (k + 3) / 8; }  // word w has a second half iff k > 8w + 4
+// Packed layout (pk): lo(b * c) of the 4-byte tables sits in the spare fourth dword of the 16-byte entries instead --
+// lut_his(k) KiB less LDS, stride-16 reads (more bank conflicts: the headline shape loses 1.9 %, k = 23 6.5 %).  The
+// launch picks it only where it buys a workgroup per CU (k = 21: 1778 < s <= 2034, BASELINE config 4's sketches).
 __host__ __device__ constexpr size_t lut_direct_bytes(int k) { return lut_direct(k) ? ((size_t)8 << (2 * lut_last_nb(k))) : 0; }
-__host__ __device__ constexpr size_t lut_bytes(int k) {
-  return (size_t)lut_los(k) * LUT_LO_BYTES + (size_t)lut_his(k) * LUT_HI_BYTES + lut_direct_bytes(k);
+__host__ __device__ constexpr size_t lut_bytes(int k, bool pk) {
+  return (size_t)lut_los(k) * LUT_LO_BYTES + (pk ? 0 : (size_t)lut_his(k) * LUT_HI_BYTES) + lut_direct_bytes(k);
 }
 
 struct Segment {
@@ -177,11 +180,12 @@ struct KParams {
   int lshift;          // 64 - 2k
   int rc_shift;        // 2k - 2
   uint64_t kmask;      // low 2k bits
+  bool packed;         // table layout, see lut_bytes
 };
 
-__device__ __forceinline__ KParams make_kparams(int k, uint32_t seed) {
+__device__ __forceinline__ KParams make_kparams(int k, uint32_t seed, bool packed) {
   KParams P;
-  P.k = k; P.seed = seed; P.use64 = k > 16 ? 1u : 0u;
+  P.k = k; P.seed = seed; P.use64 = k > 16 ? 1u : 0u; P.packed = packed;
   P.lshift = 64 - 2 * k; P.rc_shift = 2 * k - 2;
   P.kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
   return P;
@@ -190,7 +194,7 @@ __device__ __forceinline__ KParams make_kparams(int k, uint32_t seed) {
 // Called by all WG threads; the first 256 fill one column each.  Layout: lut_los(k) tables of
 // {u64 P, u32 AH, pad} at w * LUT_LO_BYTES, then lut_his(k) tables of u32 BL, then the last word's own table
 // (lut_direct(k)): entry i = rotl(w * c, r) * c' of the word whose bases are the 2-bit codes of i.
-__device__ __forceinline__ void build_kmer_lut(lds_byte_ptr lut, int k) {
+__device__ __forceinline__ void build_kmer_lut(lds_byte_ptr lut, int k, bool pk) {
   const uint32_t e = threadIdx.x;
   if (e >= 256) return;
   const uint32_t a4 = codes_to_ascii(e);
@@ -198,7 +202,7 @@ __device__ __forceinline__ void build_kmer_lut(lds_byte_ptr lut, int k) {
   if (lut_direct(k)) {
     const int wl = lut_words(k) - 1, nb = lut_last_nb(k);
     typedef RTC_LDS uint64_t* lds_u64w_ptr;
-    const lds_u64w_ptr dt = (lds_u64w_ptr)(lut + hi_base + (size_t)lut_his(k) * LUT_HI_BYTES);
+    const lds_u64w_ptr dt = (lds_u64w_ptr)(lut + hi_base + (pk ? 0 : (size_t)lut_his(k) * LUT_HI_BYTES));
     for (uint32_t i = e; i < (1u << (2 * nb)); i += 256) {
       const uint32_t e4 = nb >= 4 ? ((i >> (2 * nb - 8)) & 0xffu) : ((i << (8 - 2 * nb)) & 0xffu);   // first four bases, first on top
       const uint32_t am = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
@@ -222,12 +226,13 @@ __device__ __forceinline__ void build_kmer_lut(lds_byte_ptr lut, int k) {
     if (w & 1) P = (((uint64_t)(uint32_t)(AL << 1) << 32) | (uint64_t)(AL >> 31)) * MM_C1;   // rotl33 part of S.lo, times c1
     else P = (((uint64_t)(AL >> 1) << 32) | ((uint64_t)(AL & 1u) << 31)) * MM_C2;           // rotl31 part of S.lo, times c2
     typedef RTC_LDS u32x4* lds_u4_ptr;
-    const u32x4 ent = {(uint32_t)P, (uint32_t)(P >> 32), AH, 0u};
+    const uint32_t bm = nb >= 8 ? 0xffffffffu : (nb > 4 ? ((1u << (8 * (nb - 4))) - 1u) : 0u);
+    const uint32_t BL = (a4 & bm) * (uint32_t)c;  // lo(b * c) of the word whose SECOND four bases are e's codes
+    const u32x4 ent = {(uint32_t)P, (uint32_t)(P >> 32), AH, pk ? BL : 0u};
     *(lds_u4_ptr)(lut + (size_t)w * LUT_LO_BYTES + (size_t)e * 16) = ent;
-    if (nb > 4) {
-      const uint32_t bm = nb >= 8 ? 0xffffffffu : ((1u << (8 * (nb - 4))) - 1u);
+    if (nb > 4 && !pk) {
       typedef RTC_LDS uint32_t* lds_u32_ptr;
-      *(lds_u32_ptr)(lut + hi_base + (size_t)w * LUT_HI_BYTES + (size_t)e * 4) = (a4 & bm) * (uint32_t)c;  // lo(b * c)
+      *(lds_u32_ptr)(lut + hi_base + (size_t)w * LUT_HI_BYTES + (size_t)e * 4) = BL;
     }
   }
 }
@@ -304,7 +309,9 @@ __device__ __forceinline__ HashParts kmer_hash_parts(uint64_t x, const KParams& 
   typedef const RTC_LDS uint32_t* lds_u32_cptr;
   const uint32_t four = 4, two = 2;
   const uint32_t hi_base = (uint32_t)(lut_los(k) * LUT_LO_BYTES);
-  const uint32_t dt_base = hi_base + (uint32_t)(lut_his(k) * LUT_HI_BYTES);
+  const bool pk = P.packed;
+  const uint32_t dt_base = hi_base + (pk ? 0u : (uint32_t)(lut_his(k) * LUT_HI_BYTES));
+  const uint32_t hsh = pk ? four : two;  // shift of the second-half offsets
   // the last word's own table: its 2nb bits sit at the top of the word's 16-bit slot (whatever lies below them is
   // not part of the k-mer and is cut off), entry offset = field << 3
   typedef const RTC_LDS uint64_t* lds_u64_cptr;
@@ -312,17 +319,17 @@ __device__ __forceinline__ HashParts kmer_hash_parts(uint64_t x, const KParams& 
 #define RTC_DT(H, odd) (*(lds_u64_cptr)(uintptr_t)(dt_base + ((odd) ? (__builtin_amdgcn_ubfe((H), 16 - 2 * dnb, 2 * dnb) << 3) \
                                                                      : (((H) >> (32 - 2 * dnb)) << 3))))
 #define RTC_LO(w, off) (*(lds_u4_cptr)(uintptr_t)((off) + (uint32_t)((w) * LUT_LO_BYTES)))
-#define RTC_HI(w, off) (*(lds_u32_cptr)(uintptr_t)((off) + hi_base + (uint32_t)((w) * LUT_HI_BYTES)))
+#define RTC_HI(w, off) (*(lds_u32_cptr)(uintptr_t)((off) + (pk ? (uint32_t)((w) * LUT_LO_BYTES) + 12u : hi_base + (uint32_t)((w) * LUT_HI_BYTES))))
   uint64_t K0 = 0, K1 = 0, K2 = 0, K3 = 0;  // the words' contributions, already rotl(w * c, r) * c'
   const int dw = lut_direct(k) ? lut_words(k) - 1 : -1;  // the word that has a table of its own
   if (dw == 0) K0 = RTC_DT(hi, false);
-  else K0 = word_k1(RTC_LO(0, byte_x8<3>(hi, four)), k > 4 ? RTC_HI(0, byte_x8<2>(hi, two)) : 0u);
+  else K0 = word_k1(RTC_LO(0, byte_x8<3>(hi, four)), k > 4 ? RTC_HI(0, byte_x8<2>(hi, hsh)) : 0u);
   if (dw == 1) K1 = RTC_DT(hi, true);
-  else if (k > 8) K1 = word_k2(RTC_LO(1, byte_x8<1>(hi, four)), k > 12 ? RTC_HI(1, byte_x8<0>(hi, two)) : 0u);
+  else if (k > 8) K1 = word_k2(RTC_LO(1, byte_x8<1>(hi, four)), k > 12 ? RTC_HI(1, byte_x8<0>(hi, hsh)) : 0u);
   if (dw == 2) K2 = RTC_DT(lo, false);
-  else if (k > 16) K2 = word_k1(RTC_LO(2, byte_x8<3>(lo, four)), k > 20 ? RTC_HI(2, byte_x8<2>(lo, two)) : 0u);
+  else if (k > 16) K2 = word_k1(RTC_LO(2, byte_x8<3>(lo, four)), k > 20 ? RTC_HI(2, byte_x8<2>(lo, hsh)) : 0u);
   if (dw == 3) K3 = RTC_DT(lo, true);
-  else if (k > 24) K3 = word_k2(RTC_LO(3, byte_x8<1>(lo, four)), k > 28 ? RTC_HI(3, byte_x8<0>(lo, two)) : 0u);
+  else if (k > 24) K3 = word_k2(RTC_LO(3, byte_x8<1>(lo, four)), k > 28 ? RTC_HI(3, byte_x8<0>(lo, hsh)) : 0u);
 #undef RTC_LO
 #undef RTC_HI
 #undef RTC_DT
@@ -518,7 +525,7 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 #define RTC_EXPRESS 1
 #endif
 constexpr bool EXPRESS = RTC_EXPRESS;
-template <int KT>  // KT > 0: k known at compile time (uniform branches fold away); 0: runtime k
+template <int KT, bool PK>  // KT > 0: k known at compile time (uniform branches fold away); 0: runtime k.  PK: packed tables
 // second launch bound: 6 waves/SIMD = 3 workgroups per CU (caps the allocation at 80 VGPRs)
 __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __restrict__ seq,
                                                             const Segment* __restrict__ segs,
@@ -534,15 +541,15 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
   // kmer_hash addresses the tables by absolute LDS address; this kernel has no static LDS, so the
   // dynamic allocation starts at 0 -- trap rather than hash with wrong tables if that ever changes
   if ((uint32_t)(uintptr_t)lds0 != 0u) __builtin_trap();
-  const lds_u64_ptr buf = (lds_u64_ptr)(lds0 + lut_bytes(k));
-  const lds_ctrl_ptr ctrl = (lds_ctrl_ptr)(lds0 + lut_bytes(k) + (size_t)cap * 8);
+  const lds_u64_ptr buf = (lds_u64_ptr)(lds0 + lut_bytes(k, PK));
+  const lds_ctrl_ptr ctrl = (lds_ctrl_ptr)(lds0 + lut_bytes(k, PK) + (size_t)cap * 8);
   // this wave's candidate queue: QCAP x {f1, f2}
-  const lds_u64_ptr wq = (lds_u64_ptr)(lds0 + lut_bytes(k) + (size_t)cap * 8 + ((sizeof(Ctrl) + 15) & ~(size_t)15)) +
+  const lds_u64_ptr wq = (lds_u64_ptr)(lds0 + lut_bytes(k, PK) + (size_t)cap * 8 + ((sizeof(Ctrl) + 15) & ~(size_t)15)) +
                          (size_t)(threadIdx.x >> 6) * QCAP * 2;
   uint32_t qn = 0;  // entries waiting in it (wave-uniform)
 
   const Segment sg = segs[blockIdx.x];
-  const KParams P = make_kparams(k, seed);
+  const KParams P = make_kparams(k, seed, PK);
   const int t = threadIdx.x;
   const uint32_t lane = t & 63;
   const uint32_t s = sg.sketch_size;
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
   uint64_t Tstart = (pass_no == 0 && !sg.partial) ? sg.t0 : SENT;
 restart:
   if (t == 0) { ctrl->T = Tstart; ctrl->T0 = Tstart; ctrl->sorted = 0; ctrl->count = 0; ctrl->overflow = 0; ctrl->saw_max = 0; ctrl->scan_base = 0; }
-  build_kmer_lut(lut, k);
+  build_kmer_lut(lut, k, PK);
   __syncthreads();
 
   uint64_t T = uniform64(Tstart);  // scalar registers: the threshold compares write wave masks directly
@@ -1072,24 +1079,29 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   // works on the live count, so the capacity need not be a power of two).  Partial-merge kernel:
   // two s-lists.
   int cap = 0, wgs_per_cu = 1;
+  bool packed = false;  // table layout (lut_bytes): packed only where it buys a workgroup per CU
   int wgs_lo = 1, wgs_hi = 3;
   if (const char* e = getenv("RTC_SKETCH_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 3) wgs_lo = wgs_hi = v; }  // tuning experiments
   for (int wgs = wgs_hi; wgs >= wgs_lo && cap == 0; wgs--) {
     // 52 / 78 / 156 KiB: measured on MI355X, a 53.3 KiB allocation no longer runs three workgroups per CU
     const size_t share = ((size_t)156 * 1024 / wgs) & ~(size_t)2047;
-    const size_t fixed = lut_bytes(k) + ((sizeof(Ctrl) + 15) & ~(size_t)15) + QUEUE_BYTES;
+    for (int pk = 0; pk < 2 && cap == 0; pk++) {
+    if (pk && (lut_his(k) == 0 || getenv("RTC_SKETCH_NO_PACKED"))) break;
+    if (!pk && getenv("RTC_SKETCH_PACKED") && lut_his(k) > 0) continue;  // A/B: the packed layout wherever it exists
+    const size_t fixed = lut_bytes(k, pk != 0) + ((sizeof(Ctrl) + 15) & ~(size_t)15) + QUEUE_BYTES;
     // (round 1 measured ~3000 entries of room as the break-even against lost occupancy; with the merge sorting
     // only the new candidates and the express walk a third workgroup per CU wins down to the minimum room:
     // s = 2000 at 10 000 x 5 Mbp 114.5 -> 102.1 ms, the containment sketches of config 4 190 -> 164 ms)
     size_t want_room = MIN_ROOM;
     if (const char* e = getenv("RTC_SKETCH_WANT_ROOM")) want_room = (size_t)std::max(atoi(e), MIN_ROOM);  // tuning experiments
-    if (share > fixed && (share - fixed) / 8 >= (size_t)chunk_max + want_room) { cap = (int)((share - fixed) / 8); wgs_per_cu = wgs; }
+    if (share > fixed && (share - fixed) / 8 >= (size_t)chunk_max + want_room) { cap = (int)((share - fixed) / 8); wgs_per_cu = wgs; packed = pk != 0; }
+    }
   }
   if (cap == 0) return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "sketch chunk %u does not fit the LDS", chunk_max);
   if (const char* e = getenv("RTC_SKETCH_CAP")) { const int v = atoi(e); if (v >= (int)(chunk_max + MIN_ROOM) && v <= cap) cap = v; }  // tuning experiments
   // partial-sketch merge: two lists fit 2*chunk_max; twice that lets the rank merge work out of place
   const int cap_merge = (int)std::max<uint32_t>(std::max<uint32_t>(2 * chunk_max, std::min<uint32_t>(4 * chunk_max, 16384)), 1024);
-  const size_t lds = (size_t)cap * 8 + lut_bytes(k) + ((sizeof(Ctrl) + 15) & ~(size_t)15) + QUEUE_BYTES;
+  const size_t lds = (size_t)cap * 8 + lut_bytes(k, packed) + ((sizeof(Ctrl) + 15) & ~(size_t)15) + QUEUE_BYTES;
   const size_t lds_m = (size_t)cap_merge * 8 + sizeof(Ctrl);
   if (lds > (size_t)160 * 1024 || lds_m > (size_t)160 * 1024)
     return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "sketch chunk %u needs %zu B of LDS (> 160 KiB)", chunk_max, std::max(lds, lds_m));
@@ -1218,25 +1230,12 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   // compile-time k for 16..32: the values the reference's tune_parameters lands on for Mbp..Gbp
   // genomes (recommended k = ceil(log4(maxSize * 9999)) = 17..23, accepted up to +3), its default 21
   // and the customary 31/32; anything else takes the runtime-k kernel
-  auto kern = sketch_minhash_kernel<0>;
+  auto kern = packed ? sketch_minhash_kernel<0, true> : sketch_minhash_kernel<0, false>;
   switch (k) {
-    case 16: kern = sketch_minhash_kernel<16>; break;
-    case 17: kern = sketch_minhash_kernel<17>; break;
-    case 18: kern = sketch_minhash_kernel<18>; break;
-    case 19: kern = sketch_minhash_kernel<19>; break;
-    case 20: kern = sketch_minhash_kernel<20>; break;
-    case 21: kern = sketch_minhash_kernel<21>; break;
-    case 22: kern = sketch_minhash_kernel<22>; break;
-    case 23: kern = sketch_minhash_kernel<23>; break;
-    case 24: kern = sketch_minhash_kernel<24>; break;
-    case 25: kern = sketch_minhash_kernel<25>; break;
-    case 26: kern = sketch_minhash_kernel<26>; break;
-    case 27: kern = sketch_minhash_kernel<27>; break;
-    case 28: kern = sketch_minhash_kernel<28>; break;
-    case 29: kern = sketch_minhash_kernel<29>; break;
-    case 30: kern = sketch_minhash_kernel<30>; break;
-    case 31: kern = sketch_minhash_kernel<31>; break;
-    case 32: kern = sketch_minhash_kernel<32>; break;
+#define RTC_K(K) case K: kern = packed ? sketch_minhash_kernel<K, true> : sketch_minhash_kernel<K, false>; break;
+    RTC_K(16) RTC_K(17) RTC_K(18) RTC_K(19) RTC_K(20) RTC_K(21) RTC_K(22) RTC_K(23) RTC_K(24)
+    RTC_K(25) RTC_K(26) RTC_K(27) RTC_K(28) RTC_K(29) RTC_K(30) RTC_K(31) RTC_K(32)
+#undef RTC_K
     default: break;
   }
   RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

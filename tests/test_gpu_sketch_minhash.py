@@ -225,3 +225,24 @@ def test_starting_threshold_factor_does_not_change_results(ctx, oracle):
     want = oracle.sketch_minhash_batch(host, off[:4], 21, 500)
     got = ref.to_host()
     assert all(np.array_equal(a, b) for a, b in zip(got[:3], want))
+
+
+@pytest.mark.parametrize("k", [21, 17, 19, 23, 12, 28, 31, 32, 9])
+def test_packed_table_layout_matches_oracle(ctx, oracle, k):
+    """The packed LDS table layout (lo(b*c) in the entries' fourth dword): forced everywhere by RTC_SKETCH_PACKED, and
+    picked by the launch on its own for sketch sizes it buys a third workgroup per CU for (k = 21: s = 1900)."""
+    import os
+    rng = np.random.default_rng(300 + k)
+    seq, off = _random_genomes(rng, [260_000, 123_457, 15_361, 700_001], n_rate=0.0005, lower_rate=0.01)
+    os.environ["RTC_SKETCH_PACKED"] = "1"
+    try:
+        _check(ctx, oracle, seq, off, k, size=1000)
+    finally:
+        del os.environ["RTC_SKETCH_PACKED"]
+    if k == 21:
+        _check(ctx, oracle, seq, off, k, size=1900)
+        os.environ["RTC_SKETCH_NO_PACKED"] = "1"
+        try:
+            _check(ctx, oracle, seq, off, k, size=1900)
+        finally:
+            del os.environ["RTC_SKETCH_NO_PACKED"]
