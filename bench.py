@@ -83,6 +83,28 @@ def measured_traffic(kernel, workload):
     return None, None
 
 
+def measured_valu(kernel, workload, n_xcd=8, n_simd=1024):
+    """VALU issue figures of the dominant kernel from the same committed PMC passes: wave64 VALU instructions per
+    launch, busy cycles per launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs) and the cycles one SIMD had per
+    VALU instruction it issued.  Against the issue cost of the kernel's instruction mix (profiles/
+    r02_valu_issue_cost.txt: ~2.5 cycles for xor / and / add / right shift / v_bitop3, ~4.2-4.7 for multiplies,
+    64-bit and three-operand forms; ~3.9 for the sketch kernels' mix) this says how busy the VALU pipe is."""
+    for name in PROFILE_JSON:
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", name)))
+            key = next((k for k in prof["kernels"] if k in kernel), None)
+            if key is None or not all(prof["workload"].get(k) == v for k, v in workload.items()):
+                continue
+            kd = prof["kernels"][key]
+            insts, cyc = kd["SQ_INSTS_VALU_per_launch"], kd["GRBM_GUI_ACTIVE_per_launch"] / n_xcd
+            return {"wave_insts_per_launch": insts, "gpu_cycles_per_launch": cyc,
+                    "insts_per_kmer_wave_step": kd.get("derived", {}).get("valu_insts_per_step"),
+                    "simd_cycles_per_wave_inst": cyc * n_simd / insts, "source": "profiles/" + name}
+        except Exception:
+            continue
+    return None
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask and cgroup-v2 CPU quota, not the
     machine's core count (the GPU boxes expose 256 CPUs under a 16-CPU quota)."""
@@ -273,7 +295,7 @@ def main():
             "mst_edges": int(phases[-1]["mst_edges"]),
             "roofline": {"bound": "hbm", "kernel": sk_kernel, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": sk_traffic,
+                         "traffic": sk_traffic, "valu_issue": measured_valu(sk_kernel, wl),
                          "note": "algorithmic bytes = 1 B/base + %d B/hash out per launch; traffic = rocprofv3 PMC "
                                  "bytes per launch (profiles/%s); the kernel is integer-VALU-issue bound, "
                                  "see DESIGN.md 3.1" % (width, sk_src)},
