@@ -292,9 +292,17 @@ __device__ __forceinline__ uint64_t word_k1(const u32x4 e, uint32_t BL) {
   // the high word takes v * hi(c2) + (SH & 1) << 31: with hi(c2) odd that is rotr32(SH, 1) * hi(c2) -- one rotate, one
   // product, one two-input add instead of a shift, a product and a three-input add
   static_assert(((MM_C2 >> 32) & 1) == 1, "hi(c2) must be odd");
+#ifdef RTC_K1_ROTR   // A/B: the former form
   uint32_t cross = __builtin_amdgcn_alignbit(SH, SH, 1) * (uint32_t)(MM_C2 >> 32);
   asm("" : "+v"(cross));
   const uint32_t hi = (uint32_t)(R >> 32) + cross;
+#else
+  // ... or, two issue cycles cheaper: t = hi(R) + (SH << 31) as one v_lshl_add_u32 (a fresh register, so it can be the
+  // low half of an addend pair) and v * hi(c2) + t as a 32-bit mad (v_mad_u64_u32, low word)
+  uint32_t t = (SH << 31) + (uint32_t)(R >> 32);
+  asm("" : "+v"(t));
+  const uint32_t hi = v * (uint32_t)(MM_C2 >> 32) + t;
+#endif
   return __builtin_bit_cast(uint64_t, make_uint2((uint32_t)R, hi));
 }
 // rotl(S, 33) * c1 for a k2 word: (S.hi * c1) << 1 + P = S.hi * (2 c1 mod 2^64) + P, the table value as the
