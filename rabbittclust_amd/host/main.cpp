@@ -1304,6 +1304,7 @@ static int repdb_append(const Options& o, vector<Gpu>& gpus) {
 #endif
 
 int main(int argc, char** argv) {
+  const double t_main = get_sec();
   Options o = parse(argc, argv);
   if (!o.has_output && !o.db_stats) { cerr << "ERROR: option -o/--output is required (unless --buildDB or --stats is used)" << endl; return 1; }
   if (o.threads < 1) { fprintf(stderr, "-----Invalid thread number %d\n", o.threads); return 1; }
@@ -1385,6 +1386,7 @@ int main(int argc, char** argv) {
     }
   }
   rtc_ctx* ctx = gpus[0].ctx;
+  if (getenv("RTC_VERBOSE")) fprintf(stderr, "[ctx]   HIP runtime + %zu GPU context(s) in %.3fs\n", gpus.size(), get_sec() - t_main);
   Resident rs;
 #ifndef GREEDY_CLUST
   if (o.has_append) return append_clust_mst(o, gpus);
@@ -1580,7 +1582,9 @@ int main(int argc, char** argv) {
     remove_noise_and_print(mst, genomes, sketchByFile, o.outputFile, o.threshold, dense, DENSE_SPAN);
   }
 #endif
+  const double t_end = get_sec();
   for (Gpu& g : gpus) { if (g.comm) rtc_comm_destroy(g.comm); }
   for (Gpu& g : gpus) rtc_ctx_destroy(g.ctx);
+  if (getenv("RTC_VERBOSE")) fprintf(stderr, "[exit]  output written at t+%.3fs, contexts released in %.3fs\n", t_end - t_main, get_sec() - t_end);
   return 0;
 }
