@@ -18,7 +18,9 @@
 // device -- RCCL refuses duplicate GPUs -- an in-process exchange (host barrier + device copies)
 // stands in, which is how the protocol is tested on a one-GPU box.
 #include <math.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types and enums only: the library itself is loaded on first use (below)
+#include <dlfcn.h>
+#include <mutex>
 
 #include <algorithm>
 #include <condition_variable>
@@ -30,6 +32,52 @@
 #include "rtc_internal.h"
 
 namespace {
+
+// librccl.so is 570 MB of code objects for every architecture; a single-GPU run (the common command line) never needs
+// it, so it is not a link-time dependency: the nine entry points used here are resolved on the first communicator call.
+// Inside a process that already holds RCCL (torch.distributed) dlopen by soname returns that copy.
+struct Rccl {
+  void* h = nullptr;
+  const char* err = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+const Rccl* rccl() {  // nullptr when the library or one of its symbols is missing (g_rccl.err says which)
+  std::call_once(g_rccl_once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (g_rccl.h) break;
+    }
+    if (!g_rccl.h) { g_rccl.err = "librccl.so.1 not found"; return; }
+#define RTC_SYM(field, sym)                                                      \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.h, sym)); \
+    if (!g_rccl.field && !g_rccl.err) g_rccl.err = sym " missing from librccl"
+    RTC_SYM(GetUniqueId, "ncclGetUniqueId");
+    RTC_SYM(CommInitRank, "ncclCommInitRank");
+    RTC_SYM(CommInitAll, "ncclCommInitAll");
+    RTC_SYM(CommDestroy, "ncclCommDestroy");
+    RTC_SYM(AllReduce, "ncclAllReduce");
+    RTC_SYM(Broadcast, "ncclBroadcast");
+    RTC_SYM(GroupStart, "ncclGroupStart");
+    RTC_SYM(GroupEnd, "ncclGroupEnd");
+    RTC_SYM(GetErrorString, "ncclGetErrorString");
+#undef RTC_SYM
+  });
+  return g_rccl.err ? nullptr : &g_rccl;
+}
+#define RTC_NEED_RCCL(ctx)                                                                             \
+  const Rccl* nc__ = rccl();                                                                           \
+  if (!nc__) return rtc_fail((ctx), RTC_ERR_UNSUPPORTED, "RCCL is not available: %s", g_rccl.err)
 
 struct LocalGroup {  // in-process exchange for contexts sharing a device
   std::mutex m;
@@ -61,7 +109,7 @@ struct rtc_comm {
   do {                                                                                          \
     ncclResult_t r__ = (call);                                                                  \
     if (r__ != ncclSuccess)                                                                     \
-      return rtc_fail((ctx), RTC_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r__)); \
+      return rtc_fail((ctx), RTC_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, nc__->GetErrorString(r__)); \
   } while (0)
 
 namespace {
@@ -92,7 +140,8 @@ int comm_all_reduce_on(rtc_comm* c, void* d_buf, size_t count, int dtype, int op
   rtc_ctx* ctx = c->ctx;
   if ((c->size == 1 && !c->nccl) || count == 0) return RTC_OK;
   if (c->nccl) {
-    RTC_NCCL(ctx, ncclAllReduce(d_buf, d_buf, count, dtype == 0 ? ncclInt64 : ncclUint32, op == 0 ? ncclMin : ncclMax, c->nccl, stream));
+    RTC_NEED_RCCL(ctx);
+    RTC_NCCL(ctx, nc__->AllReduce(d_buf, d_buf, count, dtype == 0 ? ncclInt64 : ncclUint32, op == 0 ? ncclMin : ncclMax, c->nccl, stream));
     return RTC_OK;
   }
   LocalGroup& g = *c->local;
@@ -124,13 +173,14 @@ int comm_gather_rows_on(rtc_comm* c, void* d_global, size_t row_bytes, uint32_t 
   if ((c->size == 1 && !c->nccl) || b <= a || row_bytes == 0) return RTC_OK;
   const size_t bytes = (size_t)(b - a) * row_bytes;
   if (c->nccl) {
-    RTC_NCCL(ctx, ncclGroupStart());
+    RTC_NEED_RCCL(ctx);
+    RTC_NCCL(ctx, nc__->GroupStart());
     for (int r = 0; r < c->size; r++) {
       char* p = (char*)d_global + ((size_t)r * n_local + a) * row_bytes;
-      ncclResult_t st = ncclBroadcast(p, p, bytes, ncclInt8, r, c->nccl, stream);
-      if (st != ncclSuccess) { (void)ncclGroupEnd(); return rtc_fail(ctx, RTC_ERR_HIP, "ncclBroadcast -> %s", ncclGetErrorString(st)); }
+      ncclResult_t st = nc__->Broadcast(p, p, bytes, ncclInt8, r, c->nccl, stream);
+      if (st != ncclSuccess) { (void)nc__->GroupEnd(); return rtc_fail(ctx, RTC_ERR_HIP, "ncclBroadcast -> %s", nc__->GetErrorString(st)); }
     }
-    RTC_NCCL(ctx, ncclGroupEnd());
+    RTC_NCCL(ctx, nc__->GroupEnd());
     return RTC_OK;
   }
   LocalGroup& g = *c->local;
@@ -159,9 +209,10 @@ extern "C" {
 int rtc_comm_unique_id(void* id_out) {
   if (!id_out) return RTC_ERR_ARG;
   static_assert(sizeof(ncclUniqueId) == RTC_COMM_ID_BYTES, "rtclust.h: RTC_COMM_ID_BYTES");
+  RTC_NEED_RCCL(nullptr);
   ncclUniqueId id;
-  ncclResult_t r = ncclGetUniqueId(&id);
-  if (r != ncclSuccess) return rtc_fail(nullptr, RTC_ERR_HIP, "ncclGetUniqueId -> %s", ncclGetErrorString(r));
+  ncclResult_t r = nc__->GetUniqueId(&id);
+  if (r != ncclSuccess) return rtc_fail(nullptr, RTC_ERR_HIP, "ncclGetUniqueId -> %s", nc__->GetErrorString(r));
   memcpy(id_out, &id, sizeof id);
   return RTC_OK;
 }
@@ -175,7 +226,8 @@ int rtc_comm_init_rank(rtc_ctx* ctx, int nranks, int rank, const void* id, rtc_c
   if (nranks > 1 || (id && getenv("RTC_COMM_FORCE_RCCL"))) {  // the env switch drives the RCCL calls on one GPU (tests)
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
-    RTC_NCCL(ctx, ncclCommInitRank(&c->nccl, nranks, uid, rank));
+    RTC_NEED_RCCL(ctx);
+    RTC_NCCL(ctx, nc__->CommInitRank(&c->nccl, nranks, uid, rank));
   }
   RTC_TRY(comm_finish_init(c.get()));
   *out = c.release();
@@ -193,7 +245,8 @@ int rtc_comm_init_all(rtc_ctx** ctxs, int n, rtc_comm** comms_out) {
     std::vector<int> devs(n);
     std::vector<ncclComm_t> nc(n);
     for (int i = 0; i < n; i++) devs[i] = ctxs[i]->device;
-    RTC_NCCL(ctxs[0], ncclCommInitAll(nc.data(), n, devs.data()));
+    RTC_NEED_RCCL(ctxs[0]);
+    RTC_NCCL(ctxs[0], nc__->CommInitAll(nc.data(), n, devs.data()));
     for (int i = 0; i < n; i++) cs[i]->nccl = nc[i];
   } else if (n > 1) {  // shared device(s): RCCL rejects duplicate GPUs
     auto g = std::make_shared<LocalGroup>();
@@ -211,7 +264,7 @@ void rtc_comm_destroy(rtc_comm* c) {
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
-  if (c->nccl) (void)ncclCommDestroy(c->nccl);
+  if (c->nccl && rccl()) (void)rccl()->CommDestroy(c->nccl);
   delete c;
 }
 
@@ -260,7 +313,8 @@ int rtc_comm_broadcast(rtc_comm* c, void* d_buf, size_t bytes, int root) {
   if ((c->size == 1 && !c->nccl) || bytes == 0) return RTC_OK;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
   if (c->nccl) {
-    RTC_NCCL(ctx, ncclBroadcast(d_buf, d_buf, bytes, ncclInt8, root, c->nccl, ctx->stream));
+    RTC_NEED_RCCL(ctx);
+    RTC_NCCL(ctx, nc__->Broadcast(d_buf, d_buf, bytes, ncclInt8, root, c->nccl, ctx->stream));
     return RTC_OK;
   }
   LocalGroup& g = *c->local;
