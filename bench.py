@@ -27,7 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_JSON = ("r02_pmc_traffic.json", "r02_kssd_pmc_traffic.json", "r01_pmc_traffic.json")
+PROFILE_JSON = ("r03_pmc_traffic.json", "r03_kssd_pmc_traffic.json", "r02_pmc_traffic.json", "r02_kssd_pmc_traffic.json",
+                "r01_pmc_traffic.json")
 
 
 def parse():
@@ -47,6 +48,10 @@ def parse():
                     help="N>1 collectives: the C ABI's own RCCL communicator (rtc_comm_*, what the C++ hosts use) "
                          "or torch.distributed's; both are RCCL over xGMI")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="N=1 only: skip the extra workloads timed after the headline region (KSSD 25 000 x 2 Mbp, "
+                         "greedy config 4, the 12 500-genome first point of the weak-scaling curve)")
+    ap.add_argument("--extra-steps", type=int, default=3)
     ap.add_argument("--cpu-sample-genomes", type=int, default=0, help="0 = 1024 (SURVEY 8d: >= 1k genomes)")
     ap.add_argument("--cpu-sample-sketches", type=int, default=8000)
     return ap.parse_args()
@@ -163,6 +168,132 @@ def cpu_baseline(args, mode, seq, off, sketches_host, shuffled):
                    f"distance: index-based compute_{'minhash' if mode == 'minhash' else 'kssd'}_mst restatement on "
                    f"{npair} of the same sketches ({pairs} pairs, only pairs sharing a hash are touched) in {t_mst:.2f}s"),
     }
+
+
+def _mean_phases(phases):
+    import numpy as np
+    return {k: float(np.mean([p[k] for p in phases])) for k in phases[0]}
+
+
+def extra_workloads(args, ctx, api, pipeline):
+    """N=1 only, AFTER the timed headline region: the other single-GPU shapes of BASELINE.json on the same clock.
+      kssd    configs[4] per-GPU shape: 25 000 x 2 Mbp, --fast k=21 drlevel=3, sketch + all-pairs + MST
+      greedy  configs[3]: 50 000 prefix genomes of 0.4 .. 2 Mbp, -c 1000 containment sketches + rtc_greedy
+      weak_first_point  12 500 x 5 Mbp MinHash: the per-GPU load of the N>1 runs, so the 1 -> 8 curve has a first point
+                        with the same per-GPU work
+    Each gets `--extra-steps` timed steps after one warm-up."""
+    import numpy as np
+    import torch
+    out = {}
+    steps = max(1, args.extra_steps)
+
+    # ---- KSSD (--fast) ----
+    try:
+        from rabbittclust_amd import host
+        n, L = 25000, 2_000_000
+        shuffled = host.generate_shuffle_dim(6 if 6 - args.drlevel >= 2 else args.drlevel + 2)
+        desc = api.synth_family_descs(n // 10, 10, global_seed=42)
+        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+        seq = ctx.synth_genomes(desc, off)
+        ctx.sync()
+        pipe = pipeline.MstPipeline(ctx, k=args.k, threshold=args.threshold, mode="kssd", drlevel=args.drlevel, shuffled_dim=shuffled)
+        pipe.step(seq, off)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ph = _mean_phases([pipe.step(seq, off) for _ in range(steps)])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        sk = pipe.last_sketches
+        algo = float(n) * L + float(sk.len.sum().item()) * sk.width
+        ach = algo / (ph["sketch_ms"] * 1e-3) / 1e9
+        wl = {"genomes": n, "length": L, "k": args.k, "s": args.s, "mode": "kssd"}
+        traffic, src = measured_traffic("sketch_kssd_bucket_kernel", wl)
+        pairs = n * (n - 1) // 2
+        out["kssd"] = {
+            "workload": f"{n} x {L} bp synthetic genomes, KSSD --fast k={args.k} drlevel={args.drlevel}, sketch + all-pairs + MST",
+            "steps": steps, "ms_per_step": dt * 1e3, "genome_pairs_per_sec": pairs / dt, "dtype": "u64" if sk.width == 8 else "u32",
+            "sketch_gbp_per_sec": float(n) * L / (ph["sketch_ms"] * 1e-3) / 1e9, "mean_sketch_size": float(sk.len.float().mean().item()),
+            "phase_ms": ph, "mst_edges": int(ph["mst_edges"]),
+            "roofline": {"bound": "hbm", "kernel": "sketch_kssd_bucket_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": "1 B/base + %d B/hash out over the whole sketch phase (bucket kernel + sort/dedup + capacity read-back); "
+                                 "traffic from profiles/%s" % (sk.width, src)},
+        }
+        del seq, pipe, sk
+        torch.cuda.empty_cache()
+    except Exception as e:  # an extra never costs the headline line
+        out["kssd"] = {"error": repr(e)}
+
+    # ---- greedy, containment (config 4) ----
+    try:
+        n, L, fam = 50000, 2_000_000, 10
+        rng = np.random.default_rng(1)
+        desc = api.synth_family_descs(n // fam, fam, global_seed=43, max_rate=0.04)
+        for f in range(n // fam):  # true prefixes of one genome
+            desc[f * fam:(f + 1) * fam] = desc[f * fam]
+        frac = rng.uniform(0.2, 1.0, size=n)
+        frac[::fam] = 1.0
+        lens = (frac * L).astype(np.uint64) // 16 * 16
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(lens)
+        seq = ctx.synth_genomes(desc, off)
+        sizes = np.maximum((lens.astype(np.float64) * 1.0125 / 1000).astype(np.uint32), 100)  # max(fileBytes / 1000, 100)
+        ctx.sync()
+        sk_ms, gr_s, ncl = [], [], 0
+        for it in range(steps + 1):
+            ctx.timer_start()
+            sk = ctx.sketch_minhash(seq, off, k=args.k, sizes=sizes)
+            ms = ctx.timer_stop()
+            t0 = time.perf_counter()
+            ncl, rep = ctx.greedy(sk, args.threshold, size_cfg=sizes, is_containment=True)
+            g = time.perf_counter() - t0
+            if it:
+                sk_ms.append(ms)
+                gr_s.append(g)
+        bases = float(off[-1])
+        algo = bases + float(sizes.sum()) * 8
+        ach = algo / (float(np.mean(sk_ms)) * 1e-3) / 1e9
+        out["greedy"] = {
+            "workload": f"{n} prefix genomes of {int(lens.min())} .. {int(lens.max())} bp ({bases / 1e9:.1f} Gbp), clust-greedy -c 1000 "
+                        f"(containment sketches of {int(sizes.min())} .. {int(sizes.max())} hashes), d={args.threshold}",
+            "steps": steps, "sketch_ms": float(np.mean(sk_ms)), "sketch_gbp_per_sec": bases / (float(np.mean(sk_ms)) * 1e-3) / 1e9,
+            "greedy_s": float(np.mean(gr_s)), "genomes_per_sec": n / (float(np.mean(sk_ms)) * 1e-3 + float(np.mean(gr_s))),
+            "clusters": int(ncl), "dtype": "u64",
+            "roofline": {"bound": "hbm", "kernel": "sketch_minhash_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None},
+        }
+        del seq, sk
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["greedy"] = {"error": repr(e)}
+
+    # ---- the N>1 per-GPU load on one GPU ----
+    try:
+        n, L = 12500, 5_000_000
+        free, _ = torch.cuda.mem_get_info()
+        if free < n * L * 1.2:
+            raise MemoryError(f"{free / 1e9:.0f} GB free")
+        desc = api.synth_family_descs(n // args.family, args.family, global_seed=42)
+        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+        seq = ctx.synth_genomes(desc, off)
+        ctx.sync()
+        pipe = pipeline.MstPipeline(ctx, k=args.k, sketch_size=args.s, threshold=args.threshold)
+        pipe.step(seq, off)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ph = _mean_phases([pipe.step(seq, off) for _ in range(steps)])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out["weak_first_point"] = {
+            "workload": f"{n} x {L} bp, MinHash k={args.k} s={args.s}: the per-GPU load of the N>1 runs on one GPU",
+            "steps": steps, "ms_per_step": dt * 1e3, "genome_pairs_per_sec": n * (n - 1) // 2 / dt,
+            "sketch_gbp_per_sec": float(n) * L / (ph["sketch_ms"] * 1e-3) / 1e9, "phase_ms": ph,
+        }
+        del seq, pipe
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["weak_first_point"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -291,6 +422,11 @@ def main():
                                        "space is (N x genomes_per_gpu)^2/2, so pairs per GPU grow with N"},
             "sketch_gbp_per_sec": bases_total / (sk_ms * 1e-3) / 1e9,
             "dist_pairs_per_sec": pairs / (ph["dist_ms"] * 1e-3),
+            "per_gpu": {"sketch_gbp_per_sec": float(n_local) * length / (sk_ms * 1e-3) / 1e9,
+                        "genome_pairs_per_sec": pairs / (dt / args.steps) / world,
+                        "dist_pairs_per_sec_rank0": dist_pairs_local / (ph["dist_ms"] * 1e-3),
+                        "note": "rank 0's phases; N=1 runs 10 000 genomes (configs[1]), N>1 12 500 per GPU (configs[2] at N=8): "
+                                "extra.weak_first_point of the N=1 line is the 12 500-genome load on one GPU"},
             "phase_ms": ph,
             "mst_edges": int(phases[-1]["mst_edges"]),
             "roofline": {"bound": "hbm", "kernel": sk_kernel, "achieved": achieved,
@@ -313,6 +449,11 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(args, mode, seq, off, pipe.last_sketches.to_host(), shuffled)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
+        if world == 1 and not args.no_extra and mode == "minhash" and not args.genomes and not args.length:
+            del seq
+            pipe.last_sketches = None
+            torch.cuda.empty_cache()
+            line["extra"] = extra_workloads(args, ctx, api, pipeline)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -46,6 +46,8 @@ int rtc_device_info(rtc_ctx* ctx, int out[3]);
 /* device memory for hosts that do not link a HIP runtime themselves (the C++ CLI) */
 int rtc_dev_alloc(rtc_ctx* ctx, size_t bytes, void** d_ptr);
 int rtc_dev_free(rtc_ctx* ctx, void* d_ptr);
+/* free / total HBM of the context's GPU in bytes (the command lines size their resident sketch rows against it) */
+int rtc_dev_mem_info(rtc_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 int rtc_copy_h2d(rtc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* synchronous */
 int rtc_copy_d2h(rtc_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* synchronous */
 int rtc_memset_dev(rtc_ctx* ctx, void* d_ptr, int value, size_t bytes);
@@ -238,7 +240,8 @@ void rtc_comm_destroy(rtc_comm* comm);
 int rtc_comm_rank(const rtc_comm* comm);
 int rtc_comm_size(const rtc_comm* comm);
 const char* rtc_comm_backend(const rtc_comm* comm); /* "rccl" | "in-process" | "single" */
-/* in-place all-reduce on the context stream; dtype 0 = int64, 1 = uint32; op 0 = MIN, 1 = MAX */
+/* in-place all-reduce on the context stream; dtype 0 = int64, 1 = uint32, 2 = uint64 (the Boruvka key arrays);
+ * op 0 = MIN, 1 = MAX */
 int rtc_comm_all_reduce(rtc_comm* comm, void* d_buf, size_t count, int dtype, int op);
 /* the same for up to 64 host values (agreeing on strides, counts); synchronises */
 int rtc_comm_all_reduce_host(rtc_comm* comm, int64_t* h_vals, size_t count, int op);
@@ -252,7 +255,8 @@ int rtc_comm_wait(rtc_comm* comm);
 /* d_buf[0..bytes) of rank `root` replaces every other rank's copy (context stream) */
 int rtc_comm_broadcast(rtc_comm* comm, void* d_buf, size_t bytes, int root);
 /* h_bounds[world+1]: row ranges of the strict lower triangle of equal cost, row i costing
- * (i + fixed_cols) columns (fixed_cols: the per-row-block table build, ~8.8 x mean sketch size). */
+ * (i + fixed_cols) columns (fixed_cols: the per-row-block table build; rtc_mst_sharded uses the measured
+ * 1.84 x mean sketch size). */
 int rtc_triangle_rows(uint32_t n, int world, double fixed_cols, uint32_t* h_bounds);
 /* sketchFiles' sketch loop (src/SketchInfo.cpp:878-976) for this rank's genomes, written into its
  * block of the global buffers (d_out_global: size*n_local*stride u64, d_cnt_global: size*n_local)

@@ -54,6 +54,7 @@ SIGNATURES = {
     "rtc_device_info": (_i, [_vp, C.POINTER(_i)]),
     "rtc_dev_alloc": (_i, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "rtc_dev_free": (_i, [_vp, _vp]),
+    "rtc_dev_mem_info": (_i, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rtc_copy_h2d": (_i, [_vp, _vp, _vp, C.c_size_t]),
     "rtc_copy_d2h": (_i, [_vp, _vp, _vp, C.c_size_t]),
     "rtc_memset_dev": (_i, [_vp, _vp, _i, C.c_size_t]),

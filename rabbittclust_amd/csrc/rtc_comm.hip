@@ -34,8 +34,7 @@
 namespace {
 
 // librccl.so is 570 MB of code objects for every architecture; a single-GPU run (the common command line) never needs
-// it, so it is not a link-time dependency: the nine entry points used here are resolved on the first communicator call.
-// Inside a process that already holds RCCL (torch.distributed) dlopen by soname returns that copy.
+// it, so it is not a link-time dependency: the ten entry points used here are resolved on the first communicator call.
 struct Rccl {
   void* h = nullptr;
   const char* err = nullptr;
@@ -43,6 +42,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -52,13 +52,46 @@ struct Rccl {
 Rccl g_rccl;
 std::once_flag g_rccl_once;
 
+// Where RCCL is looked for, in this order: $RTC_RCCL_LIB (a file), a copy this process already holds (a host that
+// imported torch: its wheel ships librccl.so beside its own libamdhip64), the directory of the HIP runtime this
+// library itself resolved against, $ROCM_PATH/lib, /opt/rocm/lib, and last the loader's own search by soname.
+// RTLD_LOCAL: only the function pointers below are used, nothing of RCCL goes into the global namespace.
+std::string g_rccl_err, g_rccl_path;
+void* rccl_open() {
+  auto try_open = [](const std::string& path, int extra) -> void* {
+    if (path.empty()) return nullptr;
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL | extra);
+    if (h) g_rccl_path = path;
+    else if (!extra) { const char* e = dlerror(); g_rccl_err += "  " + path + ": " + (e ? e : "?") + "\n"; }
+    return h;
+  };
+  if (const char* e = getenv("RTC_RCCL_LIB")) {
+    if (void* h = try_open(e, 0)) return h;
+    return nullptr;  // an explicit choice that does not load is an error, not a hint
+  }
+  for (const char* name : {"librccl.so.1", "librccl.so"})
+    if (void* h = try_open(name, RTLD_NOLOAD)) return h;
+  std::vector<std::string> dirs;
+  Dl_info info;
+  if (dladdr((const void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+    std::string f = info.dli_fname;
+    const size_t slash = f.rfind('/');
+    if (slash != std::string::npos) dirs.push_back(f.substr(0, slash));
+  }
+  if (const char* e = getenv("ROCM_PATH")) dirs.push_back(std::string(e) + "/lib");
+  dirs.push_back("/opt/rocm/lib");
+  for (const std::string& d : dirs)
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+      if (void* h = try_open(d + "/" + name, 0)) return h;
+  for (const char* name : {"librccl.so.1", "librccl.so"})
+    if (void* h = try_open(name, 0)) return h;
+  return nullptr;
+}
+
 const Rccl* rccl() {  // nullptr when the library or one of its symbols is missing (g_rccl.err says which)
   std::call_once(g_rccl_once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (g_rccl.h) break;
-    }
-    if (!g_rccl.h) { g_rccl.err = "librccl.so.1 not found"; return; }
+    g_rccl.h = rccl_open();
+    if (!g_rccl.h) { g_rccl_err = "librccl not found; tried\n" + g_rccl_err; g_rccl.err = g_rccl_err.c_str(); return; }
 #define RTC_SYM(field, sym)                                                      \
     g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.h, sym)); \
     if (!g_rccl.field && !g_rccl.err) g_rccl.err = sym " missing from librccl"
@@ -66,12 +99,14 @@ const Rccl* rccl() {  // nullptr when the library or one of its symbols is missi
     RTC_SYM(CommInitRank, "ncclCommInitRank");
     RTC_SYM(CommInitAll, "ncclCommInitAll");
     RTC_SYM(CommDestroy, "ncclCommDestroy");
+    RTC_SYM(CommAbort, "ncclCommAbort");
     RTC_SYM(AllReduce, "ncclAllReduce");
     RTC_SYM(Broadcast, "ncclBroadcast");
     RTC_SYM(GroupStart, "ncclGroupStart");
     RTC_SYM(GroupEnd, "ncclGroupEnd");
     RTC_SYM(GetErrorString, "ncclGetErrorString");
 #undef RTC_SYM
+    if (getenv("RTC_VERBOSE")) fprintf(stderr, "[comm]  RCCL from %s\n", g_rccl_path.c_str());
   });
   return g_rccl.err ? nullptr : &g_rccl;
 }
@@ -135,17 +170,17 @@ int comm_finish_init(rtc_comm* c) {
   return RTC_OK;
 }
 
-// dtype 0 = int64, 1 = uint32; op 0 = MIN, 1 = MAX; on `stream`
+// dtype 0 = int64, 1 = uint32, 2 = uint64; op 0 = MIN, 1 = MAX; on `stream`
 int comm_all_reduce_on(rtc_comm* c, void* d_buf, size_t count, int dtype, int op, hipStream_t stream) {
   rtc_ctx* ctx = c->ctx;
   if ((c->size == 1 && !c->nccl) || count == 0) return RTC_OK;
   if (c->nccl) {
     RTC_NEED_RCCL(ctx);
-    RTC_NCCL(ctx, nc__->AllReduce(d_buf, d_buf, count, dtype == 0 ? ncclInt64 : ncclUint32, op == 0 ? ncclMin : ncclMax, c->nccl, stream));
+    RTC_NCCL(ctx, nc__->AllReduce(d_buf, d_buf, count, dtype == 0 ? ncclInt64 : dtype == 1 ? ncclUint32 : ncclUint64, op == 0 ? ncclMin : ncclMax, c->nccl, stream));
     return RTC_OK;
   }
   LocalGroup& g = *c->local;
-  const size_t esz = dtype == 0 ? 8 : 4;
+  const size_t esz = dtype == 1 ? 4 : 8;
   void* ws = nullptr;
   RTC_TRY(rtc_ws(ctx, 5, count * esz + (size_t)c->size * 8 + 64, &ws));
   void* tmp = ws;
@@ -157,6 +192,7 @@ int comm_all_reduce_on(rtc_comm* c, void* d_buf, size_t count, int dtype, int op
   RTC_HIP(ctx, hipMemcpyAsync((void*)d_ptrs, ptrs.data(), (size_t)c->size * 8, hipMemcpyHostToDevice, stream));
   const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 2048));
   if (dtype == 0) hipLaunchKernelGGL(local_reduce_kernel<long long>, dim3(grid), dim3(256), 0, stream, (const void* const*)d_ptrs, c->size, count, op, (long long*)tmp);
+  else if (dtype == 2) hipLaunchKernelGGL(local_reduce_kernel<unsigned long long>, dim3(grid), dim3(256), 0, stream, (const void* const*)d_ptrs, c->size, count, op, (unsigned long long*)tmp);
   else hipLaunchKernelGGL(local_reduce_kernel<uint32_t>, dim3(grid), dim3(256), 0, stream, (const void* const*)d_ptrs, c->size, count, op, (uint32_t*)tmp);
   RTC_HIP(ctx, hipGetLastError());
   RTC_HIP(ctx, hipStreamSynchronize(stream));
@@ -241,7 +277,7 @@ int rtc_comm_init_all(rtc_ctx** ctxs, int n, rtc_comm** comms_out) {
   for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (ctxs[i]->device == ctxs[j]->device) distinct = false;
   std::vector<std::unique_ptr<rtc_comm>> cs;
   for (int i = 0; i < n; i++) { cs.emplace_back(new rtc_comm()); cs[i]->ctx = ctxs[i]; cs[i]->rank = i; cs[i]->size = n; }
-  if (n > 1 && distinct) {
+  if ((n > 1 && distinct) || (n == 1 && getenv("RTC_COMM_FORCE_RCCL"))) {  // the env switch: RCCL on one GPU (tests)
     std::vector<int> devs(n);
     std::vector<ncclComm_t> nc(n);
     for (int i = 0; i < n; i++) devs[i] = ctxs[i]->device;
@@ -273,7 +309,7 @@ int rtc_comm_size(const rtc_comm* c) { return c ? c->size : 0; }
 const char* rtc_comm_backend(const rtc_comm* c) { return !c ? "" : (c->nccl ? "rccl" : (c->local ? "in-process" : "single")); }
 
 int rtc_comm_all_reduce(rtc_comm* c, void* d_buf, size_t count, int dtype, int op) {
-  if (!c || (count && !d_buf) || dtype < 0 || dtype > 1 || op < 0 || op > 1) return RTC_ERR_ARG;
+  if (!c || (count && !d_buf) || dtype < 0 || dtype > 2 || op < 0 || op > 1) return RTC_ERR_ARG;
   RTC_HIP(c->ctx, hipSetDevice(c->ctx->device));
   return comm_all_reduce_on(c, d_buf, count, dtype, op, c->ctx->stream);
 }
@@ -413,36 +449,53 @@ int rtc_mst_sharded(rtc_ctx* ctx, rtc_comm* c, const void* d_hashes, int width, 
   RTC_TRY(rtc_triangle_rows(n, c->size, c->size > 1 ? 1.84 * mean : 0.0, bounds.data()));
   const uint32_t row0 = bounds[c->rank], row1 = bounds[c->rank + 1];
 
+  // A failure that only one rank sees (its candidate list does not fit, an allocation fails) must not leave the
+  // others waiting inside the next collective: the ranks agree on the status (one small all-reduce(MAX)) before the
+  // Boruvka rounds start and return the error together.  (A HIP fault inside the rounds is not recoverable either way.)
+  auto agree = [&](int local) -> int {
+    if (c->size == 1 && !c->nccl) return local;
+    int64_t v = local;
+    const int r = rtc_comm_all_reduce_host(c, &v, 1, 1);
+    if (r != RTC_OK) return r;
+    if (local == RTC_OK && v != RTC_OK) return rtc_fail(ctx, (int)v, "another rank of the sharded MST step failed (status %d)", (int)v);
+    return local != RTC_OK ? local : (int)v;
+  };
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-  RTC_HIP(ctx, hipEventCreate(&e0)); RTC_HIP(ctx, hipEventCreate(&e1)); RTC_HIP(ctx, hipEventCreate(&e2));
+  int st = RTC_OK;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess)
+    st = rtc_fail(ctx, RTC_ERR_HIP, "hipEventCreate failed");
   rtc_edge_list el{};
   rtc_cedge* d_sel = nullptr;
-  (void)hipEventRecord(e0, ctx->stream);
-  int st = rtc_candidate_edges_device(ctx, d_hashes, width, d_start, d_len, n, row0, row1, kmer_size, is_containment,
-                                      threshold, s_fixed, &el);
-  (void)hipEventRecord(e1, ctx->stream);
+  if (st == RTC_OK) {
+    (void)hipEventRecord(e0, ctx->stream);
+    st = rtc_candidate_edges_device(ctx, d_hashes, width, d_start, d_len, n, row0, row1, kmer_size, is_containment,
+                                    threshold, s_fixed, &el);
+    (void)hipEventRecord(e1, ctx->stream);
+  }
   uint64_t nsel = 0;
   int rounds = 0;
   std::vector<rtc_cedge> sel;
   if (st == RTC_OK && hipMalloc((void**)&d_sel, (size_t)n * sizeof(rtc_cedge)) != hipSuccess)
     st = rtc_fail(ctx, RTC_ERR_NOMEM, "hipMalloc forest list");
+  st = agree(st);
   const rtc_reduce_hook hook{hook_all_reduce, c};
-  if (st == RTC_OK) st = rtc_msf_device(ctx, el.d_edges, el.m, d_len, n, is_containment, s_fixed, c->size > 1 ? &hook : nullptr, d_sel, &nsel, &rounds);
+  if (st == RTC_OK) st = rtc_msf_device(ctx, el.d_edges, el.m, d_len, n, is_containment, s_fixed, (c->size > 1 || c->nccl) ? &hook : nullptr, d_sel, &nsel, &rounds);
   if (st == RTC_OK && nsel) {
     sel.resize(nsel);
     hipError_t e = hipMemcpyAsync(sel.data(), d_sel, nsel * sizeof(rtc_cedge), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) st = rtc_fail(ctx, RTC_ERR_HIP, "forest read-back -> %s", hipGetErrorString(e));
   }
-  (void)hipEventRecord(e2, ctx->stream);
-  (void)hipEventSynchronize(e2);
+  if (e2) { (void)hipEventRecord(e2, ctx->stream); (void)hipEventSynchronize(e2); }
   if (stats && st == RTC_OK) {
     (void)hipEventElapsedTime(&stats->pair_ms, e0, e1);
     (void)hipEventElapsedTime(&stats->mst_ms, e1, e2);
     stats->row0 = row0; stats->row1 = row1; stats->cand_edges = el.m; stats->rounds = (uint32_t)rounds;
     stats->s_fixed = s_fixed; stats->contractions = (uint32_t)el.contractions;
   }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (e2) (void)hipEventDestroy(e2);
   if (d_sel) (void)hipFree(d_sel);
   rtc_edge_list_free(&el);
   if (st != RTC_OK) return st;

@@ -145,6 +145,13 @@ int rtc_dev_free(rtc_ctx* ctx, void* d_ptr) {
   return RTC_OK;
 }
 
+int rtc_dev_mem_info(rtc_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+  if (!ctx || !free_bytes || !total_bytes) return RTC_ERR_ARG;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  RTC_HIP(ctx, hipMemGetInfo(free_bytes, total_bytes));
+  return RTC_OK;
+}
+
 int rtc_host_alloc(rtc_ctx* ctx, size_t bytes, void** h_ptr) {
   if (!ctx || !h_ptr) return RTC_ERR_ARG;
   *h_ptr = nullptr;

@@ -57,7 +57,7 @@ int rtc_pinned(rtc_ctx* ctx, size_t bytes, void** out);
 
 // ---- internal C++ interfaces shared by the translation units ----------------------------------
 // all-reduce of a per-round key array across the ranks of a multi-GPU run (rtc_comm.hip);
-// dtype 0 = int64, 1 = uint32; op 0 = MIN, 1 = MAX
+// dtype 0 = int64, 1 = uint32, 2 = uint64; op 0 = MIN, 1 = MAX
 struct rtc_reduce_hook {
   int (*all_reduce)(void* self, void* d_buf, size_t count, int dtype, int op);
   void* self;

@@ -28,7 +28,7 @@
 
 namespace {
 
-constexpr uint64_t KEY_NONE = 0x7FFFFFFFFFFFFFFFULL;  // fits int64 for all-reduce(MIN)
+constexpr uint64_t KEY_NONE = 0x7FFFFFFFFFFFFFFFULL;  // above every key (fused keys use 63 bits, edge ids need n < 2^31); also a valid int64
 
 // similarity key: smaller key == more similar == smaller distance
 __device__ __forceinline__ uint64_t weight_key(uint32_t common, uint32_t sa, uint32_t sb, int is_containment) {
@@ -263,6 +263,7 @@ int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uin
   *n_sel_out = 0;
   if (rounds_out) *rounds_out = 0;
   if (n < 2) return RTC_OK;
+  if (n >= (1u << 31)) return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "%u sketches: edge ids (i << 32 | j) must stay below the empty key 2^63 - 1", n);
   const int idx_bits = rtc_boruvka_key_bits(n, s_fixed);
   if (s_fixed && !idx_bits) s_fixed = 0;
   void* ws3 = nullptr;
@@ -278,12 +279,12 @@ int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uin
   for (int round = 0; round < 64; round++) {
     if (s_fixed) {
       RTC_TRY(rtc_boruvka_minkey_dev(ctx, d_edges, m, d_comp, n, s_fixed, d_wkey));
-      if (hook) RTC_TRY(hook->all_reduce(hook->self, d_wkey, n, 0, 0));
+      if (hook) RTC_TRY(hook->all_reduce(hook->self, d_wkey, n, 2, 0));
     } else {
       RTC_TRY(rtc_boruvka_minweight_dev(ctx, d_edges, m, d_len, is_containment, d_comp, n, d_wkey));
-      if (hook) RTC_TRY(hook->all_reduce(hook->self, d_wkey, n, 0, 0));
+      if (hook) RTC_TRY(hook->all_reduce(hook->self, d_wkey, n, 2, 0));
       RTC_TRY(rtc_boruvka_minedge_dev(ctx, d_edges, m, d_len, is_containment, d_comp, n, d_wkey, d_ekey));
-      if (hook) RTC_TRY(hook->all_reduce(hook->self, d_ekey, n, 0, 0));
+      if (hook) RTC_TRY(hook->all_reduce(hook->self, d_ekey, n, 2, 0));
       RTC_TRY(rtc_boruvka_fetch_dev(ctx, d_edges, m, d_comp, n, d_ekey, d_ecommon));
       if (hook) RTC_TRY(hook->all_reduce(hook->self, d_ecommon, n, 1, 1));
     }

@@ -253,13 +253,43 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   else { uint64_t ms = 0; for (size_t i = 0; i < nfiles; i++) ms = std::max(ms, slot[i]); rs.stride = (uint32_t)(ms / (1ull << (4 * job.drlevel)) * 3 / 2 + 256); }
   rs.ok = getenv("RTC_HOST_SKETCHES") == nullptr;  // the switch forces the upload path (tests compare the two)
   rs.counts.assign(nfiles, 0);
-  std::atomic<bool> resident_ok{rs.ok};
+  // The rows share ONE stride (the largest sketch any file can yield), so a single outlier -- one 3 Gbp assembly among
+  // 100 000 bacterial genomes -- inflates every row.  The buffer has to fit beside the staging buffers with room left
+  // for the clustering phase; when it does not (or the allocation fails) the run keeps per-batch temporary buffers
+  // and clusters from the host vectors instead of stopping.
+  if (rs.ok) {
+    const size_t want = (size_t)nfiles * rs.stride * rs.width + (size_t)nfiles * 4 + 128;
+    size_t budget = 0;
+    if (const char* e = getenv("RTC_RESIDENT_BUDGET")) budget = strtoull(e, nullptr, 10);  // bytes (tests of the fallback)
+    for (Gpu& g : gpus) {
+      size_t fr = 0, tot = 0;
+      CHECK(g.ctx, rtc_dev_mem_info(g.ctx, &fr, &tot));
+      const size_t lim = budget ? budget : fr / 2;
+      if (want > lim) {
+        fprintf(stderr, "-----resident sketch rows would take %.2f GB (%zu genomes x %u hashes, the largest genome sets the row) of %.2f GB free: "
+                        "sketches go through host memory instead\n", want / 1e9, nfiles, rs.stride, fr / 1e9);
+        rs.ok = false;
+        break;
+      }
+    }
+  }
   if (rs.ok)
     for (Gpu& g : gpus) {
-      CHECK(g.ctx, rtc_dev_alloc(g.ctx, (size_t)nfiles * rs.stride * rs.width + 64, &g.d_sk));
-      CHECK(g.ctx, rtc_dev_alloc(g.ctx, (size_t)nfiles * 4 + 64, (void**)&g.d_cnt));
-      CHECK(g.ctx, rtc_memset_dev(g.ctx, g.d_cnt, 0, (size_t)nfiles * 4));
+      if (rtc_dev_alloc(g.ctx, (size_t)nfiles * rs.stride * rs.width + 64, &g.d_sk) != RTC_OK ||
+          rtc_dev_alloc(g.ctx, (size_t)nfiles * 4 + 64, (void**)&g.d_cnt) != RTC_OK) {
+        fprintf(stderr, "-----cannot keep the sketches resident (%s): sketches go through host memory instead\n", rtc_last_error(g.ctx));
+        rs.ok = false;
+        break;
+      }
+      // every count is written by the sketch kernels of its batch; rows of dropped files are never read
     }
+  if (!rs.ok)
+    for (Gpu& g : gpus) {
+      if (g.d_sk) CHECK(g.ctx, rtc_dev_free(g.ctx, g.d_sk));
+      if (g.d_cnt) CHECK(g.ctx, rtc_dev_free(g.ctx, g.d_cnt));
+      g.d_sk = nullptr; g.d_cnt = nullptr;
+    }
+  std::atomic<bool> resident_ok{rs.ok};
   struct Placed { uint32_t row0, rows; int gpu; };  // where a batch's sketches live (share step)
   vector<Placed> placed;
   vector<size_t> row_file;  // row (= genome id) -> list position
@@ -422,7 +452,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       if (g.d_cnt) CHECK(g.ctx, rtc_dev_free(g.ctx, g.d_cnt));
       g.d_sk = nullptr; g.d_cnt = nullptr;
     }
-  } else if (G > 1) {
+  } else if (G > 1 || gpus[0].comm) {
     // ---- share: every batch's rows travel from the GPU that sketched them to all others (RCCL broadcast) ----
     const double ts0 = get_sec();
     on_all_gpus(gpus, [&](size_t g) {
@@ -1359,8 +1389,18 @@ int main(int argc, char** argv) {
   {
     string spec = o.gpus.empty() ? (getenv("RTC_GPUS") ? getenv("RTC_GPUS") : "all") : o.gpus;
     const int ndev = rtc_device_count();
+    bool gpus_by_default = false, single_gpu_flow = false;
     vector<int> devs;
-    if (spec == "all") for (int d = 0; d < ndev; d++) devs.push_back(d);
+    // Only the row-sharded MST step (and the sketching in front of it) spreads over GPUs.  Greedy clustering has a serial
+    // dependency on the representative set, --append / --db / --dense evaluate their pairs on one GPU: those flows take
+    // the first GPU of the choice and never open a communicator.
+    single_gpu_flow =
+#ifdef GREEDY_CLUST
+        true;
+#else
+        o.has_append || o.dense;
+#endif
+    if (spec == "all") { gpus_by_default = true; for (int d = 0; d < ndev; d++) devs.push_back(d); }
     else if (spec.find(',') == string::npos && atoi(spec.c_str()) > 0 && spec.find_first_not_of("0123456789") == string::npos) {
       const int want = atoi(spec.c_str());
       if (want > ndev) { fprintf(stderr, "ERROR: --gpus %d but only %d GPU(s) are visible\n", want, ndev); return 1; }
@@ -1368,6 +1408,10 @@ int main(int argc, char** argv) {
     } else {
       size_t p0 = 0;
       while (p0 <= spec.size()) { size_t p1 = spec.find(',', p0); if (p1 == string::npos) p1 = spec.size(); if (p1 > p0) devs.push_back(atoi(spec.substr(p0, p1 - p0).c_str())); p0 = p1 + 1; }
+    }
+    if (single_gpu_flow && devs.size() > 1) {
+      if (!gpus_by_default) fprintf(stderr, "-----this flow runs on one GPU: using GPU %d of the %zu named\n", devs[0], devs.size());
+      devs.resize(1);
     }
     if (devs.empty()) { fprintf(stderr, "ERROR: no MI355X context: %s (%d devices)\n", rtc_last_error(nullptr), ndev); return 1; }
     gpus.resize(devs.size());
@@ -1378,11 +1422,22 @@ int main(int argc, char** argv) {
       if (st != RTC_OK) { fprintf(stderr, "ERROR: no MI355X context on device %d: %s\n", devs[g], rtc_last_error(nullptr)); return 1; }
       ctxs.push_back(gpus[g].ctx);
     }
-    if (gpus.size() > 1) {
+    // RTC_COMM_FORCE_RCCL=1 opens an RCCL communicator also for ONE GPU and sends the run through the share step and
+    // rtc_mst_sharded: the loader and every collective of the multi-GPU path, driven from this binary on a one-GPU box
+    if (gpus.size() > 1 || (getenv("RTC_COMM_FORCE_RCCL") && !single_gpu_flow)) {
       vector<rtc_comm*> comms(gpus.size(), nullptr);
-      CHECK(ctxs[0], rtc_comm_init_all(ctxs.data(), (int)ctxs.size(), comms.data()));
-      for (size_t g = 0; g < gpus.size(); g++) gpus[g].comm = comms[g];
-      fprintf(stderr, "-----use %zu GPUs (%s exchange)\n", gpus.size(), rtc_comm_backend(comms[0]));
+      const int st = rtc_comm_init_all(ctxs.data(), (int)ctxs.size(), comms.data());
+      if (st != RTC_OK) {
+        // the default ("all") must not turn a missing or broken RCCL into a dead command line: one GPU does the whole
+        // job, as it would on a one-GPU host.  A user who named several GPUs asked for them: that is an error.
+        if (!gpus_by_default) { fprintf(stderr, "ERROR: rtc_comm_init_all failed (%d): %s\n", st, rtc_last_error(ctxs[0])); return 1; }
+        fprintf(stderr, "Warning: no communicator among the %zu visible GPU(s) (%s); running on GPU %d alone\n", gpus.size(), rtc_last_error(ctxs[0]), gpus[0].device);
+        for (size_t g = 1; g < gpus.size(); g++) rtc_ctx_destroy(gpus[g].ctx);
+        gpus.resize(1);
+      } else {
+        for (size_t g = 0; g < gpus.size(); g++) gpus[g].comm = comms[g];
+        fprintf(stderr, "-----use %zu GPUs (%s exchange)\n", gpus.size(), rtc_comm_backend(comms[0]));
+      }
     }
   }
   rtc_ctx* ctx = gpus[0].ctx;
@@ -1543,7 +1598,7 @@ int main(int argc, char** argv) {
     else upload_sketches(gpus[g].ctx, &mh.hashes, nullptr, dss[g]);
   });
   vector<int32_t> dense; uint64_t ani[101];
-  if (G == 1 || o.dense) {  // --dense: the histograms are accumulated beside the single-GPU candidate list
+  if ((G == 1 && !gpus[0].comm) || o.dense) {  // --dense: the histograms are accumulated beside the single-GPU candidate list
     const DeviceSketches& ds = dss[0];
     if (o.dense) dense.resize((size_t)DENSE_SPAN * ds.n);
     CHECK(ctx, rtc_mst_dense(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, 0, kmer_size, is_containment, o.threshold, mst.data(), &nedges,

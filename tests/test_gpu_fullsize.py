@@ -201,67 +201,154 @@ def test_config5_kssd_per_gpu_shape_25k(ctx, oracle):
     del seq
 
 
-# ---- BASELINE config 3 per-rank shape: rank 7 of 8 over 50 000 real sketches ------------------------
-def test_config3_rank7_of_8_over_50k_sketches(ctx, oracle):
-    """50 000 sketches (s=1000) of synthetic genomes, the last of 8 triangle row ranges: candidate list
-    against the independent merge kernel + oracle on sampled rows, then all 8 ranks in lockstep (one
-    reduction per round) against the single-launch rtc_mst forest; the same machinery on a
-    3 000-genome prefix against the oracle's weights."""
+# ---- BASELINE configs 3 and 5 at their real pair-space size: 8 ranks of rtc_mst_sharded on one GPU ----------
+def _sharded_in_process(world, sk, threshold, width_k_kind=None):
+    """`world` contexts on device 0, one host thread each, rtc_comm_init_all's in-process exchange: every rank runs
+    rtc_mst_sharded (its triangle row range with the product's own split, one reduction per Boruvka round in
+    fixed-size mode, three otherwise).  Returns the per-rank (edge.mst records, ShardStats)."""
+    from rabbittclust_amd import api
+    from test_gpu_multigpu import _threads
+    ctxs = [api.Context(0) for _ in range(world)]
+    comms = api.Comm.init_all(ctxs)
+    assert all(c.backend == "in-process" for c in comms)
+    torch.cuda.synchronize()
+    try:
+        return _threads([(lambda r=r: ctxs[r].mst_sharded(comms[r], sk, threshold)) for r in range(world)])
+    finally:
+        for c in comms:
+            c.close()
+        for c in ctxs:
+            c.close()
+
+
+def _check_forest(mst, n):
+    parent = np.arange(n)
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for e in mst:
+        ra, rb = find(int(e["preNode"])), find(int(e["sufNode"]))
+        assert ra != rb  # a forest: no edge closes a cycle
+        parent[ra] = rb
+    assert bool(np.all(np.diff(mst["dist"]) >= 0))
+    return find
+
+
+def test_config3_100k_sketches_8_ranks_full_pair_space(ctx, oracle):
+    """BASELINE config 3's pair space at its real size: 100 000 MinHash sketches (k=21, s=1000; the genomes are 1 Mbp
+    instead of 5 Mbp -- the sketch kernel's genome length is covered by the 10 000 x 5 Mbp tests above, the pair space
+    only sees the sketches), sketched in 10 000-genome chunks.  All 8 triangle row ranges go through rtc_mst_sharded
+    itself (8 in-process ranks, fixed-size mode: ONE reduction per Boruvka round) and every rank must return the
+    forest of the single rtc_mst launch over the 5*10^9 pairs, bit for bit; rank 7's candidate list is checked against
+    the independent merge kernel and the oracle on sampled rows; a 3 000-sketch prefix against the oracle's MST."""
     from rabbittclust_amd import api, pipeline
-    from test_gpu_mst import _LockstepRanks
     free, _ = torch.cuda.mem_get_info()
-    if free < 40e9:
-        pytest.skip("needs ~15 GB of HBM")
-    n, L, chunk, s = 50000, 1_000_000, 10000, 1000
+    if free < 60e9:
+        pytest.skip("needs ~30 GB of HBM")
+    n, L, chunk, s, world = 100000, 1_000_000, 10000, 1000, 8
     out = torch.empty((n, s), dtype=torch.int64, device=ctx.device)
     cnt = torch.zeros(n, dtype=torch.int32, device=ctx.device)
     off = np.arange(chunk + 1, dtype=np.uint64) * np.uint64(L)
-    for c0 in range(0, n, chunk):  # sketched in 10 000-genome chunks through one 10 GB staging buffer
+    for c0 in range(0, n, chunk):  # one 10 GB staging buffer
         desc = api.synth_family_descs(chunk // 10, 10, global_seed=500 + c0)
         seq = ctx.synth_genomes(desc, off)
         ctx.sketch_minhash_into(seq, off, out[c0:c0 + chunk], cnt[c0:c0 + chunk], k=21, size=s)
         ctx.sync()
         del seq
     sk = api.SketchSet(out.view(-1), torch.arange(n, dtype=torch.int64, device=ctx.device) * s, cnt, 8, 21, "minhash")
-    assert int(cnt.min()) == s
-    world = 8
-    b = pipeline.triangle_row_ranges(n, world, fixed_cols=8.8 * s)
-    assert b[0] == 0 and b[-1] == n and all(b[i] < b[i + 1] for i in range(world))
-    pipes = [pipeline.MstPipeline(ctx, k=21, sketch_size=s, threshold=0.05, rank=r, world=world) for r in range(world)]
-    e7, m7 = pipes[7].candidate_edges(sk, b[7], b[8])
+    assert int(cnt.min()) == s == int(cnt.max())
+    single = ctx.mst(sk, 0.05)
+    find = _check_forest(single, n)
+    for f in (0, 4321, 9999):  # families (substitution rate <= 8 %) hang together in the forest
+        assert len({find(f * 10 + m_) for m_ in range(10)}) == 1
+    res = _sharded_in_process(world, sk, 0.05)
+    bounds = pipeline.triangle_row_ranges(n, world, fixed_cols=1.84 * s)  # the product's split (rtc_mst_sharded)
+    tot_edges = 0
+    for r, (mst, st) in enumerate(res):
+        assert (int(st.row0), int(st.row1)) == (bounds[r], bounds[r + 1]) and int(st.s_fixed) == s and int(st.contractions) == 0
+        assert np.array_equal(mst, single), f"rank {r} ended with a different forest"
+        tot_edges += int(st.cand_edges)
+    assert all(int(st.rounds) == int(res[0][1].rounds) for _, st in res) and int(res[0][1].rounds) >= 3
+    # rank 7's candidate list against the merge kernel and the oracle on sampled rows
+    pipe = pipeline.MstPipeline(ctx, k=21, sketch_size=s, threshold=0.05)
+    e7, m7 = pipe.candidate_edges(sk, bounds[7], bounds[8])
+    assert m7 == int(res[7][1].cand_edges)
     edges7 = e7[:m7].cpu().numpy().view(np.uint32)
-    assert m7 > 0 and np.all(edges7[:, 1] < edges7[:, 0]) and np.all(edges7[:, 0] >= b[7]) and np.all(edges7[:, 2] > 0)
+    assert np.all(edges7[:, 1] < edges7[:, 0]) and np.all(edges7[:, 0] >= bounds[7]) and np.all(edges7[:, 2] > 0)
     assert len(np.unique(edges7[:, 0].astype(np.uint64) << np.uint64(32) | edges7[:, 1])) == m7
     rng = np.random.default_rng(3)
-    for row in rng.integers(b[7], n, size=6):
+    for row in rng.integers(bounds[7], n, size=5):
         dense = ctx.pair_common(sk, row0=int(row), row1=int(row) + 1, col0=0, col1=int(row), algo=1).cpu().numpy()[0]
         mine = edges7[edges7[:, 0] == row]
         want_cols = np.nonzero(dense)[0]
         assert np.array_equal(np.sort(mine[:, 1]), want_cols) and np.array_equal(mine[np.argsort(mine[:, 1]), 2], dense[want_cols])
         for col in want_cols[:3]:
             assert oracle.common(out[row].cpu().numpy().view(np.uint64), out[int(col)].cpu().numpy().view(np.uint64)) == dense[col]
-    # all 8 ranks in lockstep == the single-launch forest
-    backends, total = [], 0
-    for r in range(world):
-        e, m = pipes[r].candidate_edges(sk, b[r], b[r + 1])
-        backends.append(pipeline.HipBoruvkaBackend(ctx, sk, e[:m].clone(), m, False))
-        total += m
-    ranks = _LockstepRanks(backends)
-    sel, rounds = pipeline.boruvka_rounds(ranks, n, None, s)
-    assert ranks.reduces == rounds
-    got = pipes[0].finish(sk, sel)
-    single = ctx.mst(sk, 0.05)
-    assert np.array_equal(got, single)
-    # prefix against the oracle
+    # total candidates of the 8 ranges == the single launch's list
+    e_all, m_all = pipe.candidate_edges(sk, 0, n)
+    assert m_all == tot_edges
+    # a 3 000-sketch prefix through the same 8-rank code against the oracle
     m = 3000
     sub = api.SketchSet(out[:m].reshape(-1), sk.start[:m], cnt[:m], 8, 21, "minhash")
-    bb = pipeline.triangle_row_ranges(m, world, fixed_cols=8.8 * s)
-    be = []
-    for r in range(world):
-        e, mm = pipes[r].candidate_edges(sub, bb[r], bb[r + 1])
-        be.append(pipeline.HipBoruvkaBackend(ctx, sub, e[:mm].clone(), mm, False))
-    sel2, _ = pipeline.boruvka_rounds(_LockstepRanks(be), m, None, s)
-    got2 = pipes[0].finish(sub, sel2)
+    res2 = _sharded_in_process(world, sub, 0.05)
     flat, start, lens = oracle.to_csr(sub.to_host())
     want = oracle.mst(flat, start, lens, 21, 0, 0.05, threads=8)
-    assert np.array_equal(np.sort(got2["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
+    for mst, _ in res2:
+        assert np.array_equal(np.sort(mst["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
+        assert np.array_equal(mst, res2[0][0])
+
+
+def test_config5_200k_kssd_sketches_8_ranks_full_pair_space(ctx, oracle):
+    """BASELINE config 5 at its real size: 200 000 x 2 Mbp genomes, --fast (KSSD k=21 -> 22, drlevel 3, u32 tuples of
+    variable count), sketched as 8 chunks of 25 000 (what each of the 8 GPUs would sketch).  The 2*10^10-pair space
+    goes through rtc_mst_sharded on 8 in-process ranks (variable sizes: the three-reduction Boruvka round) and every
+    rank must return the forest of the single rtc_mst launch; oracle on sampled sketches and on a 3 000-sketch prefix."""
+    from rabbittclust_amd import api, host
+    free, _ = torch.cuda.mem_get_info()
+    if free < 90e9:
+        pytest.skip("needs ~60 GB of HBM")
+    n, L, chunk, world = 200000, 2_000_000, 25000, 8
+    sd = host.generate_shuffle_dim(6)
+    stride = L // 4096 * 3 // 2 + 256
+    rows = torch.zeros((n, stride), dtype=torch.int32, device=ctx.device)
+    ln = torch.zeros(n, dtype=torch.int32, device=ctx.device)
+    off = np.arange(chunk + 1, dtype=np.uint64) * np.uint64(L)
+    descs = {}
+    for c0 in range(0, n, chunk):  # one 50 GB staging buffer
+        desc = api.synth_family_descs(chunk // 10, 10, global_seed=900 + c0)
+        seq = ctx.synth_genomes(desc, off)
+        part = ctx.sketch_kssd(seq, off, sd, kmer_size=21, drlevel=3, stride=stride)
+        ctx.sync()
+        pst = part.hashes.numel() // chunk
+        assert part.width == 4 and part.k == 22 and pst == stride
+        rows[c0:c0 + chunk] = part.hashes.view(chunk, pst)
+        ln[c0:c0 + chunk] = part.len
+        for g in (c0, c0 + chunk - 1):  # the sketches themselves against the oracle sketcher
+            d = desc[g - c0]
+            ref = oracle.synth_genome(int(d["fam_seed"]), int(d["mut_seed"]), int(d["mut_thr"]), L)
+            assert np.array_equal(part.hashes.view(chunk, pst)[g - c0, :int(part.len[g - c0])].cpu().numpy().view(np.uint32),
+                                  oracle.kssd_sketch(ref, 21, 3)), g
+        del seq, part
+    torch.cuda.empty_cache()
+    sk = api.SketchSet(rows.view(-1), torch.arange(n, dtype=torch.int64, device=ctx.device) * stride, ln, 4, 22, "kssd")
+    assert 380 < float(ln.float().mean()) < 600 and int(ln.min()) != int(ln.max())
+    single = ctx.mst(sk, 0.05)
+    find = _check_forest(single, n)
+    for f in (0, 7777, 19999):
+        assert len({find(f * 10 + m_) for m_ in range(10)}) == 1
+    res = _sharded_in_process(world, sk, 0.05)
+    for r, (mst, st) in enumerate(res):
+        assert int(st.s_fixed) == 0 and int(st.row1) > int(st.row0)
+        assert np.array_equal(mst, single), f"rank {r} ended with a different forest"
+    assert [int(st.row0) for _, st in res][1:] == [int(st.row1) for _, st in res][:-1] and int(res[-1][1].row1) == n
+    # prefix against the oracle (u32 index-based compute_kssd_mst restatement)
+    m = 3000
+    sub = api.SketchSet(rows[:m].reshape(-1), sk.start[:m], ln[:m], 4, 22, "kssd")
+    res2 = _sharded_in_process(world, sub, 0.05)
+    flat, start, lens = oracle.to_csr(sub.to_host(), dtype=np.uint32)
+    want = oracle.mst(flat, start, lens, 22, 0, 0.05, threads=8)
+    for mst, _ in res2:
+        assert len(mst) == len(want) and np.array_equal(np.sort(mst["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))

@@ -238,3 +238,91 @@ def test_clust_mst_no_save_keeps_sketches_on_device(oracle, tmp_path):
     _cli([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "500", "-d", "0.05", "-o", b], tmp)
     assert _partition(_parse_clusters(a)) == _partition(_parse_clusters(b))
     assert open(a).read() == open(b).read()
+
+
+def _rccl_path_for_bare_binary():
+    """where a process WITHOUT torch finds RCCL: the ROCm tree, or the wheel's copy named explicitly"""
+    for p in ("/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        if os.path.exists(p):
+            return None  # the loader's own search reaches it
+    import torch
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p if os.path.exists(p) else None
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_clust_mst_bare_binary_drives_rccl(oracle, tmp_path, fast):
+    """RTC_COMM_FORCE_RCCL=1 clust-mst --gpus 1 in a subprocess that never imports torch: the binary's own dlopen
+    of librccl, ncclCommInitAll, the share step's in-place ncclBroadcast and rtc_mst_sharded's ncclAllReduce per
+    Boruvka round -- the calls of the multi-GPU path, with one rank.  Output byte-identical to the plain run."""
+    from test_gpu_cli import _write_family_fastas
+    tmp = str(tmp_path)
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 4, 3, 1_500_000, seed=31)
+    outs = {}
+    explicit = _rccl_path_for_bare_binary()
+    for tag, env in (("plain", {}), ("rccl", dict({"RTC_COMM_FORCE_RCCL": "1"}, **({"RTC_RCCL_LIB": explicit} if explicit else {})))):
+        d = os.path.join(tmp, tag)
+        os.makedirs(d)
+        out = os.path.join(d, "res.out")
+        cmd = [os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-d", "0.05", "-t", "4", "--gpus", "1", "-o", out]
+        cmd += ["--fast"] if fast else ["-s", "500"]
+        err = _cli(cmd, d, dict(env, RTC_BATCH_BYTES=str(6 << 20), RTC_VERBOSE="1"))
+        if tag == "rccl":
+            assert "use 1 GPUs (rccl exchange)" in err and "[comm]  RCCL from " in err and "[share]" in err and "[mst gpu 0]" in err, err[-2000:]
+        folder = [os.path.join(d, x) for x in os.listdir(d) if os.path.isdir(os.path.join(d, x))][0]
+        files = sorted(f for f in os.listdir(folder) if "info" not in f)
+        outs[tag] = (open(out).read(), {f: open(os.path.join(folder, f), "rb").read() for f in files})
+    assert outs["plain"] == outs["rccl"]
+
+
+def test_clust_mst_without_rccl_falls_back_to_one_gpu(oracle, tmp_path):
+    """The default GPU choice ("all") survives a missing RCCL: a warning, then the whole job on one GPU with the same
+    output.  A user who NAMED the GPUs gets the error instead."""
+    from test_gpu_cli import _write_family_fastas
+    tmp = str(tmp_path)
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 3, 3, 1_200_000, seed=32)
+    base = [os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "400", "-d", "0.05", "-t", "4", "-e"]
+    broken = {"RTC_COMM_FORCE_RCCL": "1", "RTC_RCCL_LIB": os.path.join(tmp, "no-such-librccl.so")}
+    a, b = os.path.join(tmp, "a.out"), os.path.join(tmp, "b.out")
+    _cli(base + ["-o", a], tmp)
+    err = _cli(base + ["-o", b], tmp, broken)
+    assert "Warning: no communicator" in err and "running on GPU 0 alone" in err
+    assert open(a).read() == open(b).read()
+    r = subprocess.run(base + ["--gpus", "1", "-o", os.path.join(tmp, "c.out")], cwd=tmp, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **broken))
+    assert r.returncode == 1 and "rtc_comm_init_all failed" in r.stderr and "no-such-librccl.so" in r.stderr
+
+
+def test_clust_greedy_opens_one_context_only(oracle, tmp_path):
+    """clust-greedy clusters on one GPU by design: --gpus 0,0 must not create a second context or a communicator"""
+    from test_gpu_cli import _write_family_fastas
+    tmp = str(tmp_path)
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 3, 3, 1_200_000, seed=33)
+    a, b = os.path.join(tmp, "a.out"), os.path.join(tmp, "b.out")
+    base = [os.path.join(BIN, "clust-greedy"), "-l", "-i", lst, "-k", "21", "-s", "400", "-d", "0.05", "-t", "4", "-e"]
+    _cli(base + ["--gpus", "1", "-o", a], tmp)
+    err = _cli(base + ["--gpus", "0,0", "-o", b], tmp, {"RTC_VERBOSE": "1"})
+    assert "this flow runs on one GPU" in err and "exchange)" not in err and "1 GPU context(s)" in err
+    assert open(a).read() == open(b).read()
+
+
+@pytest.mark.parametrize("mode", ["minhash-c", "kssd"])
+def test_resident_rows_over_budget_fall_back_to_host_vectors(oracle, tmp_path, mode):
+    """the resident sketch buffer (files x largest row) is sized against the free HBM; over the budget the run
+    keeps per-batch temporaries and clusters from the host vectors -- same files, same clusters, no abort."""
+    from test_gpu_cli import _write_family_fastas
+    tmp = str(tmp_path)
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 3, 3, 1_500_000, seed=34)
+    outs = {}
+    for tag, env in (("resident", {}), ("budget", {"RTC_RESIDENT_BUDGET": "4096"})):
+        d = os.path.join(tmp, tag)
+        os.makedirs(d)
+        out = os.path.join(d, "res.out")
+        cmd = [os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-d", "0.05", "-t", "4", "--gpus", "1", "-o", out]
+        cmd += ["--fast"] if mode == "kssd" else ["-c", "1000"]
+        err = _cli(cmd, d, dict(env, RTC_BATCH_BYTES=str(6 << 20)))
+        assert ("sketches go through host memory instead" in err) == (tag == "budget")
+        folder = [os.path.join(d, x) for x in os.listdir(d) if os.path.isdir(os.path.join(d, x))][0]
+        files = sorted(f for f in os.listdir(folder) if "info" not in f)
+        outs[tag] = (open(out).read(), {f: open(os.path.join(folder, f), "rb").read() for f in files})
+    assert outs["resident"] == outs["budget"]

@@ -136,12 +136,3 @@ def test_kssd_full_queue_contigs_and_edges(ctx, oracle, k):
     for g in range(len(parts)):
         assert np.array_equal(got[g], want[g]), f"genome {g} k={k}: got {len(got[g])} want {len(want[g])}"
     assert len(got[0]) > 50
-
-
-@pytest.mark.skip(reason="covered by the CPU suite")
-def test_kssd_shuffle_table_fixture(oracle):
-    """The 4096 surviving (dim_id, rank) pairs of generate_shuffle_dim(6) pin glibc rand()."""
-    sd = oracle.kssd_shuffle_dim(6)
-    assert sorted(sd.tolist()) == list(range(1 << 24))
-    kept = np.nonzero(sd < 4096)[0]
-    assert len(kept) == 4096
