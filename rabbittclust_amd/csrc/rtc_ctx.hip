@@ -91,6 +91,7 @@ void rtc_ctx_destroy(rtc_ctx* ctx) {
   if (ctx->kssd.d_index) (void)hipFree(ctx->kssd.d_index);
   if (ctx->kssd.d_table) (void)hipFree(ctx->kssd.d_table);
   if (ctx->kssd.d_bucket) (void)hipFree(ctx->kssd.d_bucket);
+  if (ctx->kssd.d_bloom) (void)hipFree(ctx->kssd.d_bloom);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->owned_stream) (void)hipStreamDestroy(ctx->owned_stream);

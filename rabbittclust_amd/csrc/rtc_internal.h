@@ -46,6 +46,7 @@ struct rtc_ctx {
     int ck1 = 13, ck2 = 13;
     int32_t* d_table = nullptr;
     void* d_bucket = nullptr;  // bucket index (64 KiB of patterns) + ranks (64 KiB)
+    void* d_bloom = nullptr;   // blocked Bloom filter of the kept middle 12-mers and their reverse complements (64 KiB)
     int bvar = -1;             // which bucket bits the index uses, -1: none
   } kssd;
 };

@@ -557,6 +557,218 @@ __global__ __launch_bounds__(WGB, 2) void sketch_kssd_bucket_kernel(const uint8_
   drain_queue<VAR>(P, g_rank, wq, qn, lane, orow, ocnt, stride);
 }
 
+// ---- forward-strand prefilter (the default --fast configuration, K = 18..28, 24-bit dim_id) --------------
+// A k-mer is kept when the dim_id of its CANONICAL form is one of the dim_end kept dimensions (:1141-1149).
+// dim_id is the k-mer's middle 12 bases, and the middle of the reverse complement is the reverse complement of
+// the middle: whichever strand is canonical, the FORWARD k-mer's middle 12-mer lies in S2 = S u rc(S) (8192
+// 12-mers of 16 Mi).  So the steady state never forms the reverse strand, never compares strands and never checks
+// characters: per dword it decodes four bases, rolls ONE 32-bit forward window, and per k-mer probes a blocked
+// Bloom filter of S2 in LDS -- 8192 blocks of 64 bits, block = field[10..23), one bit in each half (field[0..5),
+// field[5..10)): one ds_read_b64 and seven 2-cycle-class VALU instructions, the four k-mers of a dword OR-ed into
+// one accumulator and tested with ONE compare.  Nothing is lost: a valid k-mer's bases decode exactly, and
+// whatever else decodes to a hit (characters outside ACGT, bases beyond a genome's end, ~1/400 false positives
+// of the filter) is dropped later.  Hits (~0.7 lanes per wave and dword) put the dword's POSITION into a per-wave
+// LDS queue; bloom_drain re-reads those 25 bases from memory (L2) and does the reference's arithmetic exactly:
+// characters, base counter, both strands, canonical minimum, dimension lookup (the exact bucket index, read from
+// global memory here), reduced tuple, append.
+constexpr int BLOOM_BYTES = 65536;                 // 8192 blocks x 8 B
+constexpr int BQ_CAP = 320;                        // queued positions per wave; a 16-byte group adds at most 256
+constexpr int BQ_BYTES = (WGB / 64) * BQ_CAP * 4;
+typedef uint32_t RTC_LDS* lds_u32_ptr;
+
+struct BloomSeg {  // what bloom_drain needs of the segment (passed by value: a plain-register call)
+  uint64_t g_begin, g_end, s_begin, s_end, base;   // base: queue entries are positions relative to it
+};
+
+__device__ __forceinline__ uint32_t exact_rank_global(int var, uint32_t dim_id, const uint32_t* __restrict__ g_bk,
+                                                      const uint16_t* __restrict__ g_rank) {
+  const uint32_t addr = var ? ((dim_id >> 8) & 0xfff8u) : (dim_id & 0xfff8u);
+  const uint32_t q = var ? (dim_id & 0xffffu) : ((dim_id & 0xffu) | ((dim_id >> 8) & 0xff00u));
+  const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(g_bk) + addr);
+  const uint32_t pat[4] = {e.x & 0xffffu, e.x >> 16, e.y & 0xffffu, e.y >> 16};
+  uint32_t found = 0xffffffffu;
+#pragma unroll
+  for (int sl = 0; sl < 4; sl++)
+    if (pat[sl] == q) found = g_rank[(addr >> 1) + sl] & 0xfffu;
+  return found;
+}
+
+// The queued dwords, 64 at a time, one per lane: the K + 3 bases that end the dword's four k-mers are walked base
+// by base exactly as the reference does (:1126-1161) -- any character, genome and segment edges.
+template <int K>
+__device__ __forceinline__ void bloom_drain(const uint8_t* __restrict__ seq, const BloomSeg sg, const KssdParams P,
+                                         const uint32_t* __restrict__ g_bk, const uint16_t* __restrict__ g_rank, int var,
+                                         lds_u32_ptr wq, uint32_t qn, uint32_t lane, void* orow, uint32_t* ocnt,
+                                         uint32_t stride) {
+  constexpr int NB = K + 3, NDW = (NB + 3 + 3) / 4;  // bytes walked; dwords that cover them at any alignment
+  for (uint32_t base = 0; base < qn; base += 64) {
+    const uint32_t i = base + lane;
+    const bool have = i < qn;
+    const int64_t q0 = (int64_t)sg.base + (have ? wq[i] : 0u);  // first base of the dword
+    const int64_t b0 = q0 - (K - 1);                             // first base of its first k-mer
+    const int64_t a0 = b0 & ~(int64_t)3;
+    uint32_t w[NDW + 1];
+    if (have && a0 >= (int64_t)sg.g_begin && a0 + 4 * NDW <= (int64_t)sg.g_end) {
+#pragma unroll
+      for (int j = 0; j < NDW; j++) w[j] = *reinterpret_cast<const uint32_t*>(seq + a0 + 4 * j);
+    } else {
+#pragma unroll 1
+      for (int j = 0; j < NDW; j++) {
+        uint32_t x = 0;
+#pragma unroll 1
+        for (int b = 3; b >= 0; b--) {
+          const int64_t pp = a0 + 4 * j + b;
+          const uint32_t ch = (have && pp >= (int64_t)sg.g_begin && pp < (int64_t)sg.g_end) ? seq[pp] : (uint32_t)'N';
+          x = (x << 8) | ch;
+        }
+        w[j] = x;
+      }
+    }
+    w[NDW] = 0;
+    const uint32_t sh = (uint32_t)(b0 - a0) * 8u;  // bytes to drop in front: 0, 8, 16, 24 bits
+#pragma unroll
+    for (int j = 0; j < NDW; j++) w[j] = __builtin_amdgcn_alignbit(w[j + 1], w[j], sh);  // w[] now starts at b0
+    uint64_t tuple = 0, rvs = 0;
+    int run = 0;
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+      const uint32_t ch = (w[c >> 2] >> (8 * (c & 3))) & 0xffu;
+      const uint32_t code = ((ch >> 1) ^ (ch >> 2)) & 3u;                          // BaseMap, src/SketchInfo.cpp:1007-1017
+      const bool valid = ((ch & 0xC0u) == 0x40u) && ((0x0010008Au >> (ch & 31u)) & 1u);
+      tuple = ((tuple << 2) | code) & P.tupmask;                                 // :1134
+      rvs = (rvs >> 2) + ((uint64_t)(code ^ 3u) << P.rev_add_move);              // :1135
+      run = valid ? run + 1 : 0;                                                 // base counter :1136,1161
+      if (c < K - 1) continue;
+      const int64_t pos = b0 + c;
+      const bool ok = have && run >= K && pos >= (int64_t)sg.s_begin && pos < (int64_t)sg.s_end;   // :1139 + ownership
+      const uint64_t u = tuple < rvs ? tuple : rvs;                              // :1141
+      const uint32_t dim_id = (uint32_t)(u >> P.dim_shift) & 0xffffffu;          // :1142
+      uint32_t rank = 0xffffffffu;
+      if (ok) rank = exact_rank_global(var, dim_id, g_bk, g_rank);
+      const bool keep = rank != 0xffffffffu;
+      const uint64_t bal = __ballot(keep);
+      if (bal) append_tuples(bal, keep, reduced_tuple(P, u, rank), lane, orow, ocnt, stride, P.use64);
+    }
+  }
+}
+
+template <int K, int RUN_DW, int WARM_DW>
+__global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t* __restrict__ seq,
+                                                               const KSegment* __restrict__ segs, KssdParams P,
+                                                               const uint32_t* __restrict__ g_bloom,  // 8192 x 8 B
+                                                               const uint32_t* __restrict__ g_bk,     // exact index, patterns
+                                                               const uint16_t* __restrict__ g_rank,   // exact index, ranks
+                                                               int var, void* __restrict__ out, uint32_t stride,
+                                                               uint32_t* __restrict__ cnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert((RUN_DW + WARM_DW) % 4 == 0, "a lane's window must be whole 16-byte loads");
+  static_assert(K % 2 == 0 && K >= 18 && K <= 28, "24-bit dim_id, 2K + 8 <= 64");
+  static_assert(4 * WARM_DW >= K / 2 + 5, "the warm-up must reach the first owned k-mer's middle 12-mer");
+  constexpr int OWN = RUN_DW * 4;
+  constexpr int TILE_BASES = WGB * RUN_DW * 4;
+  constexpr int NG = (RUN_DW + WARM_DW) / 4;
+  constexpr int DS = K - 12;                       // dim_shift: bit of a window where its middle 12-mer starts
+  // K = 20, 22: the four fields of a dword's k-mers lie inside the 32 bits the forward window held BEFORE the dword
+  // (bits [DS - 2 - 2b, DS + 22 - 2b) of it), so ONE 32-bit register is rolled; otherwise a 64-bit window is
+  // rolled and the 32 bits from DS up are cut out per dword (fields at [6 - 2b, 30 - 2b))
+  constexpr bool NARROW = DS >= 8 && DS <= 10;
+  const KSegment sg = segs[blockIdx.x];
+  const int t = threadIdx.x;
+  const uint32_t lane = t & 63;
+  {
+    uint4* l4 = reinterpret_cast<uint4*>(smem);
+    const uint4* g4 = reinterpret_cast<const uint4*>(g_bloom);
+    for (int i = t; i < BLOOM_BYTES / 16; i += WGB) l4[i] = g4[i];
+    __syncthreads();
+  }
+  if ((uint32_t)(uintptr_t)(RTC_LDS unsigned char*)smem != 0u) __builtin_trap();  // the filter is addressed absolutely
+  void* orow = reinterpret_cast<unsigned char*>(out) + (uint64_t)sg.genome * stride * (P.use64 ? 8 : 4);
+  uint32_t* ocnt = cnt + sg.genome;
+  const int w0 = __builtin_amdgcn_readfirstlane(t & ~63);
+  const lds_u32_ptr wq = (lds_u32_ptr)(uintptr_t)(BLOOM_BYTES + (w0 >> 6) * BQ_CAP * 4);  // this wave's queue
+  uint32_t qn = 0;                                                                        // wave-uniform
+  const BloomSeg bs{sg.g_begin, sg.g_end, sg.s_begin, sg.s_end, (sg.s_begin & ~15ULL) - 64};
+
+  // One drain site in the code (it is a long stretch of rare code): the walk leaves a tile at the group where the
+  // queue could overflow, the drain runs, and the walk comes back to that group with the window it had rolled.
+  uint32_t Fhi = 0, Flo = 0;
+  int g_resume = 0;  // first group of the current tile that still has to be probed
+  uint64_t T0 = sg.s_begin & ~15ULL;
+  for (;;) {
+    const bool more = T0 < sg.s_end;
+    bool need = !more;  // after the last tile: what is still queued
+    if (more) {
+      const int64_t own_b = (int64_t)T0 + (int64_t)OWN * w0, own_e = own_b + (int64_t)OWN * 64;
+      if (own_b >= (int64_t)sg.s_end || own_e <= (int64_t)sg.s_begin) { T0 += TILE_BASES; continue; }  // nothing of this wave's run is owned
+      // plain loads when the wave's whole window lies inside the genome, guarded ones ('N' outside) otherwise
+      const bool inside = own_b - 4 * WARM_DW >= (int64_t)sg.g_begin && own_e <= (int64_t)sg.g_end && !P.nofast;
+      const int64_t p0 = (int64_t)T0 + OWN * t - 4 * WARM_DW;
+      // four 16-byte groups of the lane's window in flight (a ring of registers: group g + 4 is requested when
+      // group g has been walked); after a drain the tile is walked again from its first group -- decode and roll
+      // only, the probes start at the group the walk had reached
+      constexpr int AHEAD = 4;
+      uint4 D[AHEAD];
+      auto fetch = [&](int g) -> uint4 {
+        return inside ? *reinterpret_cast<const uint4*>(seq + p0 + 16 * g) : load_bases16(seq, p0 + 16 * g, sg.g_begin, sg.g_end);
+      };
+#pragma unroll
+      for (int g = 0; g < AHEAD && g < NG; g++) D[g] = fetch(g);
+      Fhi = 0; Flo = 0;
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        const bool probing = g >= g_resume;                             // wave-uniform
+        if (probing && qn > (uint32_t)(BQ_CAP - 256)) { need = true; g_resume = g; break; }  // room for every lane and dword of a group
+        const uint32_t w[4] = {D[g % AHEAD].x, D[g % AHEAD].y, D[g % AHEAD].z, D[g % AHEAD].w};
+        if (g + AHEAD < NG) {
+          __builtin_amdgcn_sched_barrier(0);  // keeps the request here: hoisted, all NG groups would sit in registers
+          D[g % AHEAD] = fetch(g + AHEAD);
+        }
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+          const uint32_t codes = ((w[qd] >> 1) ^ (w[qd] >> 2)) & 0x03030303u;             // BaseMap, :1007-1017
+          const uint32_t pack = __builtin_amdgcn_udot4(codes, 0x01041040u, 0u, false);   // c0<<6|c1<<4|c2<<2|c3
+          uint32_t E;
+          if (NARROW) {
+            E = Flo;
+            Flo = (Flo << 8) | pack;                                                      // tuple :1134 four times
+          } else {
+            Fhi = __builtin_amdgcn_alignbit(Fhi, Flo, 24);
+            Flo = (Flo << 8) | pack;
+            E = __builtin_amdgcn_alignbit(Fhi, Flo, DS);
+          }
+          if (g * 4 + qd < WARM_DW || !probing) continue;
+          uint32_t acc = 0;
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            constexpr int FO0 = NARROW ? DS - 2 : 6;
+            const int fo = FO0 - 2 * b;                                                   // the field's bit offset in E
+            const uint32_t f0 = fo ? (E >> fo) : E;                                       // field[0..5): bit in the low half
+            const uint32_t a = (E >> (fo + 7)) & 0xfff8u;                                 // block = field[10..23)
+            const u32x2 blk = *(const RTC_LDS u32x2*)(uintptr_t)a;
+            const uint32_t r1 = blk.x >> (f0 & 31u);
+            const uint32_t r2 = blk.y >> ((E >> (fo + 5)) & 31u);                         // field[5..10): bit in the high half
+            acc = b ? __builtin_amdgcn_bitop3_b32(acc, r1, r2, 0xF8) : (r1 & r2);         // acc | (r1 & r2)
+          }
+          const bool hit = (acc & 1u) != 0u;
+          if (__ballot(hit)) {  // wave-uniform; about every second dword of a wave
+            const int64_t pos = p0 + 16 * g + 4 * qd;                                     // its k-mers end at pos .. pos + 3
+            const bool mine = hit && pos + 3 >= (int64_t)sg.s_begin && pos < (int64_t)sg.s_end;
+            const uint64_t bal = __ballot(mine);
+            if (mine) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint32_t)(pos - (int64_t)bs.base);
+            qn += (uint32_t)__popcll(bal);
+          }
+        }
+      }
+      if (!need) { T0 += TILE_BASES; g_resume = 0; }
+    }
+    if (need) {
+      if (qn) bloom_drain<K>(seq, bs, P, g_bk, g_rank, var, wq, qn, lane, orow, ocnt, stride);
+      qn = 0;
+    }
+    if (!more) break;
+  }
+}
+
 // one workgroup per genome: sort + dedup the appended tuples in LDS (hashArr sort :1185,:1192)
 template <typename OutT>
 __global__ __launch_bounds__(WG) void kssd_sort_unique_kernel(OutT* __restrict__ out, uint32_t stride,
@@ -849,6 +1061,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
     if (kc.d_index) { (void)hipFree(kc.d_index); kc.d_index = nullptr; }
     if (kc.d_table) { (void)hipFree(kc.d_table); kc.d_table = nullptr; }
     if (kc.d_bucket) { (void)hipFree(kc.d_bucket); kc.d_bucket = nullptr; }
+    if (kc.d_bloom) { (void)hipFree(kc.d_bloom); kc.d_bloom = nullptr; }
     kc.bvar = -1;
     if (lds_index && 4 * half_subk == 24 && !getenv("RTC_KSSD_CUCKOO")) {
       // bucket index: 8192 buckets of four 16-bit patterns (one ds_read_b64 per probe) when no bucket
@@ -888,6 +1101,22 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
         RTC_HIP(ctx, hipMemcpy((char*)kc.d_bucket + 2 * (size_t)BUCKET_BYTES, pat2.data(), BUCKET_BYTES, hipMemcpyHostToDevice));
         RTC_HIP(ctx, hipMemcpy((char*)kc.d_bucket + 3 * (size_t)BUCKET_BYTES, rnk2.data(), BUCKET_BYTES, hipMemcpyHostToDevice));
         kc.bvar = var;
+      }
+      if (kc.bvar >= 0) {
+        // the forward-strand prefilter: every kept 12-mer and its reverse complement, two bits each (block =
+        // bits 10..22, low-half bit = bits 0..4, high-half bit = bits 5..9; see sketch_kssd_bloom_kernel)
+        std::vector<uint32_t> bloom(BLOOM_BYTES / 4, 0u);
+        for (uint32_t key : keys) {
+          uint32_t rc = 0;
+          for (int i = 0; i < 12; i++) rc |= (((key >> (2 * i)) & 3u) ^ 3u) << (2 * (11 - i));
+          for (uint32_t v : {key, rc}) {
+            const uint32_t blk = (v >> 10) & 0x1fffu;
+            bloom[2 * blk] |= 1u << (v & 31u);
+            bloom[2 * blk + 1] |= 1u << ((v >> 5) & 31u);
+          }
+        }
+        RTC_HIP(ctx, hipMalloc(&kc.d_bloom, BLOOM_BYTES));
+        RTC_HIP(ctx, hipMemcpy(kc.d_bloom, bloom.data(), BLOOM_BYTES, hipMemcpyHostToDevice));
       }
     }
     // the cuckoo / HBM structures below serve the k-mer lengths the bucket kernel does not cover
@@ -958,7 +1187,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   // high words are cut (K <= 22)
   const bool use_bucket = kc.bvar >= 0 && K >= 18 && K <= 28;
   uint64_t seg_len = total / ((uint64_t)ctx->num_cu * 12);
-  const uint64_t min_seg = 4ull * (use_bucket ? WGB * 26 * 4 : TILE_BASES_MAX);
+  const uint64_t min_seg = 4ull * (use_bucket ? WGB * 27 * 4 : TILE_BASES_MAX);
   if (seg_len < min_seg) seg_len = min_seg;
   std::vector<KSegment> segs;
   segs.reserve(n + 1024);
@@ -988,7 +1217,25 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   P.m2key = (1u << (P.dimbits - P.ck2 + 1)) - 1u;
   const uint32_t* d_t2 = kc.d_index ? d_t1 + ((size_t)1 << kc.ck1) : nullptr;
   const size_t lds = lds_index ? (((size_t)1 << kc.ck1) + ((size_t)1 << kc.ck2)) * 4 : 16;
-  if (use_bucket) {
+  if (use_bucket && kc.d_bloom && !getenv("RTC_KSSD_BUCKET")) {
+    P.nofast = getenv("RTC_KSSD_NOFAST") ? atoi(getenv("RTC_KSSD_NOFAST")) : 0;
+    if (getenv("RTC_VERBOSE")) fprintf(stderr, "[kssd] forward-strand prefilter, K=%d, %zu segments\n", K, segs.size());
+    const uint32_t* d_bk = (const uint32_t*)kc.d_bucket;  // the exact index (variant kc.bvar) serves the drain from global memory
+    const uint16_t* d_rk = (const uint16_t*)((const char*)kc.d_bucket + BUCKET_BYTES);
+    const int lds_bl = BLOOM_BYTES + BQ_BYTES;
+#define LAUNCH_BLOOM(KK)                                                                                              \
+  case KK: {                                                                                                         \
+    auto kern = sketch_kssd_bloom_kernel<KK, 27, 5>;                                                                 \
+    RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bl));        \
+    hipLaunchKernelGGL(kern, dim3((uint32_t)segs.size()), dim3(WGB), lds_bl, ctx->stream, d_seq,                      \
+                       (const KSegment*)ws0, P, (const uint32_t*)kc.d_bloom, d_bk, d_rk, kc.bvar, d_out, stride, d_cnt); \
+  } break
+    switch (K) {
+      LAUNCH_BLOOM(18); LAUNCH_BLOOM(20); LAUNCH_BLOOM(22); LAUNCH_BLOOM(24); LAUNCH_BLOOM(26); LAUNCH_BLOOM(28);
+      default: return rtc_fail(ctx, RTC_ERR_ARG, "K=%d", K);
+    }
+#undef LAUNCH_BLOOM
+  } else if (use_bucket) {
     P.cf0 = P.lshift - 6;
     P.nofast = getenv("RTC_KSSD_NOFAST") ? atoi(getenv("RTC_KSSD_NOFAST")) : 0;
     P.re = (8 - (2 * K) % 8) % 8;

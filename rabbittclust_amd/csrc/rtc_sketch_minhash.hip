@@ -22,21 +22,15 @@ namespace {
 
 constexpr int WG = 512;                               // lanes per workgroup (8 waves)
 constexpr int NWAVE = WG / 64;
-#ifndef RTC_RUN_DW
 // 19 dwords = 76 owned positions per lane and tile: lane runs 76 B apart keep the set of live 128-B
 // lines (one or two lanes per line, ~1500 lanes per CU) inside the 4 MiB L2 of an XCD.  31 dwords is
 // 1 % faster but re-reads 56 % of the input from the fabric (measured: TCC_EA0_RDREQ_128B, 19 dwords: 11 %).
-#define RTC_RUN_DW 19
-#endif
-constexpr int RUN_DW = RTC_RUN_DW;                    // dwords of owned bases per lane per tile
+constexpr int RUN_DW = 19;                            // dwords of owned bases per lane per tile
 constexpr int OWN = RUN_DW * 4;                       // k-mer end positions a lane owns per tile
 // warm-up dwords in front of a lane's owned run (they only roll the windows): k-1 bases rounded up so
 // that warm-up + run are whole 16-byte loads -- 5 (20 bases, six loads per tile) for the compile-time
 // k <= 21, 9 (36 bases >= 31, seven loads) otherwise
-#ifndef RTC_WARM_SHORT
-#define RTC_WARM_SHORT 1
-#endif
-__host__ __device__ constexpr int warm_dw(int kt) { return (RTC_WARM_SHORT && kt > 0 && kt <= 21) ? 5 : 9; }
+__host__ __device__ constexpr int warm_dw(int kt) { return (kt > 0 && kt <= 21) ? 5 : 9; }
 static_assert((RUN_DW + warm_dw(21)) % 4 == 0 && (RUN_DW + warm_dw(0)) % 4 == 0, "a lane's window must be whole 16-byte loads");
 constexpr int TILE_BASES = WG * RUN_DW * 4;           // bases per tile
 constexpr int STEP_APPENDS = WG * 4;                  // worst-case appends per dword iteration
@@ -53,11 +47,7 @@ constexpr size_t LUT_LO_BYTES = 256 * 16, LUT_HI_BYTES = 256 * 4;
 // finished contribution (at most 8 KiB), one ds_read_b64 and two VALU instructions for the word.
 __host__ __device__ constexpr int lut_words(int k) { return (k + 7) / 8; }
 __host__ __device__ constexpr int lut_last_nb(int k) { return k - 8 * (lut_words(k) - 1); }   // bases of the last word, 1..8
-#ifdef RTC_NO_DIRECT_LUT
-__host__ __device__ constexpr bool lut_direct(int k) { return false; }
-#else
 __host__ __device__ constexpr bool lut_direct(int k) { return lut_last_nb(k) <= 5; }
-#endif
 __host__ __device__ constexpr int lut_los(int k) { return lut_words(k) - (lut_direct(k) ? 1 : 0); }  // words with the table pair
 __host__ __device__ constexpr int lut_his(int k) { return lut_direct(k) ? lut_los(k) : (k + 3) / 8; }  // word w has a second half iff k > 8w + 4
 // Packed layout (pk): lo(b * c) of the 4-byte tables sits in the spare fourth dword of the 16-byte entries instead --
@@ -134,7 +124,7 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t x) {
 constexpr uint64_t FMIX_C2 = 0xc4ceb9fe1a85ec53ULL;
 __device__ __forceinline__ uint64_t fmix64_open(uint64_t x) {
   x ^= x >> 33;
-#ifndef RTC_FMIX_MUL64  // cross terms as v_mul_lo + a 32-bit mad (v_mad_u64_u32, low word) and one two-input add: the plain
+  // cross terms as v_mul_lo + a 32-bit mad (v_mad_u64_u32, low word) and one two-input add: the plain
   // 64-bit product compiles to two v_mul_lo and a v_add3, 1.2 issue cycles more (same-run 82.2 -> 81.5 ms)
   constexpr uint32_t cl = 0xed558ccdu, ch = 0xff51afd7u;
   const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
@@ -142,9 +132,6 @@ __device__ __forceinline__ uint64_t fmix64_open(uint64_t x) {
   uint32_t e = xl * ch + xh * cl;
   asm("" : "+v"(e));
   x = __builtin_bit_cast(uint64_t, make_uint2((uint32_t)D, (uint32_t)(D >> 32) + e));
-#else
-  x *= 0xff51afd7ed558ccdULL;
-#endif
   x ^= x >> 33;
   return x;
 }
@@ -159,21 +146,12 @@ __device__ __forceinline__ uint64_t mm_finish(const HashParts& p) {
 // hi(hash) + 2} (mod 2^32): a hash below T has w <= hi(T) + 2, also when hi(f1) + hi(f2) wraps (w = 0 or 1 then).
 // One 64-bit add and the high word of ONE 64 x 64 product (mulhi + two cross products + add3) instead of two.
 constexpr uint32_t TEST_SLACK = 2;  // callers compare with hi(T) + TEST_SLACK and need hi(T) + TEST_SLACK < 2^32
-#ifdef RTC_TEST_TWO_HALVES   // A/B: the former form, hi(f1) + hi(f2) + 1 from the two halves separately (slack 1 suffices)
-__device__ __forceinline__ uint32_t hash_test_word(const HashParts& p) {
-  const uint32_t alo = (uint32_t)p.f1, ahi = (uint32_t)(p.f1 >> 32), blo = (uint32_t)p.f2, bhi = (uint32_t)(p.f2 >> 32);
-  const uint32_t cl = (uint32_t)FMIX_C2, ch = (uint32_t)(FMIX_C2 >> 32);
-  const uint32_t m = __umulhi(alo, cl) + __umulhi(blo, cl) + (alo + blo) * ch;
-  return m + (ahi + bhi) * cl + 1u;
-}
-#else
 __device__ __forceinline__ uint32_t hash_test_word(const HashParts& p) {
   const uint64_t S = p.f1 + p.f2;
   const uint32_t slo = (uint32_t)S, shi = (uint32_t)(S >> 32);
   const uint32_t cl = (uint32_t)FMIX_C2, ch = (uint32_t)(FMIX_C2 >> 32);
   return __umulhi(slo, cl) + slo * ch + shi * cl + 1u;
 }
-#endif
 
 constexpr uint64_t MM_C1 = 0x87c37b91114253d5ULL, MM_C2 = 0x4cf5ad432745937fULL;
 
@@ -289,20 +267,11 @@ __device__ __forceinline__ uint32_t byte_x8(uint32_t w, uint32_t three) {
 __device__ __forceinline__ uint64_t word_k1(const u32x4 e, uint32_t BL) {
   const uint32_t SH = e.z + BL, v = SH >> 1;
   const uint64_t R = (uint64_t)v * (uint32_t)MM_C2 + __builtin_bit_cast(uint64_t, make_uint2(e.x, e.y));  // v_mad_u64_u32
-  // the high word takes v * hi(c2) + (SH & 1) << 31: with hi(c2) odd that is rotr32(SH, 1) * hi(c2) -- one rotate, one
-  // product, one two-input add instead of a shift, a product and a three-input add
-  static_assert(((MM_C2 >> 32) & 1) == 1, "hi(c2) must be odd");
-#ifdef RTC_K1_ROTR   // A/B: the former form
-  uint32_t cross = __builtin_amdgcn_alignbit(SH, SH, 1) * (uint32_t)(MM_C2 >> 32);
-  asm("" : "+v"(cross));
-  const uint32_t hi = (uint32_t)(R >> 32) + cross;
-#else
-  // ... or, two issue cycles cheaper: t = hi(R) + (SH << 31) as one v_lshl_add_u32 (a fresh register, so it can be the
+  // the high word takes v * hi(c2) + (SH & 1) << 31: t = hi(R) + (SH << 31) as one v_lshl_add_u32 (a fresh register, so it can be the
   // low half of an addend pair) and v * hi(c2) + t as a 32-bit mad (v_mad_u64_u32, low word)
   uint32_t t = (SH << 31) + (uint32_t)(R >> 32);
   asm("" : "+v"(t));
   const uint32_t hi = v * (uint32_t)(MM_C2 >> 32) + t;
-#endif
   return __builtin_bit_cast(uint64_t, make_uint2((uint32_t)R, hi));
 }
 // rotl(S, 33) * c1 for a k2 word: (S.hi * c1) << 1 + P = S.hi * (2 c1 mod 2^64) + P, the table value as the
@@ -456,7 +425,6 @@ __device__ __noinline__ MergeResult merge_block(lds_u64_ptr buf, lds_ctrl_ptr ct
   // again at every merge cost 6.6 % of the kernel at s = 1000 and 25 % at s = 2000.  Falls back to
   // sorting everything when the output does not fit (2n > cap) or there is no prefix yet.
   lds_u64_ptr src = buf;
-#ifndef RTC_MERGE_FULLSORT
   if (c0 > 0 && 2 * n <= (uint32_t)cap) {
     const uint32_t m = n - c0;
     bitonic_sort_lds(buf + c0, (int)m);  // ends with a barrier
@@ -467,9 +435,9 @@ __device__ __noinline__ MergeResult merge_block(lds_u64_ptr buf, lds_ctrl_ptr ct
     }
     __syncthreads();
     src = buf + n;
-  } else
-#endif
+  } else {
     bitonic_sort_lds(buf, (int)n);
+  }
   // streaming compaction in rounds of WG elements (dest <= src index when in place; disjoint otherwise)
   const uint32_t lane = t & 63, wave = t >> 6;
   for (int r = 0; r < (int)n; r += WG) {
@@ -539,10 +507,6 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
   return ((uint64_t)uniform32((uint32_t)(v >> 32)) << 32) | uniform32((uint32_t)v);
 }
 
-#ifndef RTC_EXPRESS
-#define RTC_EXPRESS 1
-#endif
-constexpr bool EXPRESS = RTC_EXPRESS;
 template <int KT, bool PK>  // KT > 0: k known at compile time (uniform branches fold away); 0: runtime k.  PK: packed tables
 // second launch bound: 6 waves/SIMD = 3 workgroups per CU (caps the allocation at 80 VGPRs)
 __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __restrict__ seq,
@@ -661,7 +625,7 @@ restart:
       int run = 0;
       bool clean = true;  // wave-uniform: only valid bases in every lane of this wave so far in this pass
       int g0 = 0;
-      if constexpr (KT > 16 && KT <= 28 && EXPRESS) {
+      if constexpr (KT > 16 && KT <= 28) {
         // The steady state without the general walk's per-dword decisions: a wave whose windows lie inside the
         // genome, in a tile interior to the segment, outside safe mode, with a threshold whose high word
         // decides (see below), walks whole 16-byte groups -- validity of the group in one vote, the windows,
@@ -760,9 +724,6 @@ restart:
       for (int grp = g0; grp < (WARM_DW + RUN_DW) / 4; grp++) {
         const uint4 cur = nxt;
         if (grp + 1 < (WARM_DW + RUN_DW) / 4) nxt = load_bases16(tile, rq0 + 16 * (grp + 1), gb, ge);
-#ifdef RTC_CANON_NOINIT
-        __builtin_amdgcn_sched_barrier(0);  // experiment: pin the prefetch here instead of relying on the zero-initialised canon[]
-#endif
         const uint32_t wv4[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
@@ -779,11 +740,7 @@ restart:
           }
           // (zero-initialised on purpose: left uninitialised, the generated code issues the tile loads in an
           // order that re-reads 40 % more of the input from the fabric -- measured, tools/pmc_runlen.sh)
-#ifdef RTC_CANON_NOINIT
-          uint64_t canon[4];
-#else
           uint64_t canon[4] = {0, 0, 0, 0};  // top-aligned (first base in bit 63); hashing dwords only
-#endif
           bool ok[4] = {false, false, false, false};  // slow path only; the fast path derives it on demand
           bool allok = false;  // wave-uniform: all four k-mers of every lane are valid and owned
           // ---- decode four bases at once ----
@@ -830,15 +787,10 @@ restart:
                 // is smaller (of two equal ones either will do), and the hash never sees them -- table
                 // offsets are taken from whole bytes and the tables of a partially filled byte are built
                 // from the k-mer's bases only (build_kmer_lut masks by byte count).
-#ifdef RTC_CANON_MASKED
-                const uint64_t topmask = P.kmask << P.lshift;
-#else
-                const uint64_t topmask = ~0ULL;
-#endif
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
-                  const uint64_t f = (F << (P.lshift - 6 + 2 * b)) & topmask;   // lshift >= 8 in this path
-                  const uint64_t r = (R << (P.lshift - 2 - 2 * b)) & topmask;
+                  const uint64_t f = F << (P.lshift - 6 + 2 * b);   // lshift >= 8 in this path
+                  const uint64_t r = R << (P.lshift - 2 - 2 * b);
                   canon[b] = f < r ? f : r;
                 }
               }
@@ -879,13 +831,8 @@ restart:
                 }
               }
             };
-#ifdef RTC_ABLATE_HASH  // timing experiment only: everything but MurmurHash3
-            constexpr bool ablate = true;
-#else
-            constexpr bool ablate = false;
-#endif
             const uint32_t Thi = (uint32_t)(T >> 32);
-            if (!ablate && allok && P.use64 && !lo1 && Thi < 0xffffffffu - TEST_SLACK) {
+            if (allok && P.use64 && !lo1 && Thi < 0xffffffffu - TEST_SLACK) {
               // The steady state: hash = fin(f1) + fin(f2) where fin() touches the low word only, so
               // hi(hash) = hi(f1) + hi(f2) + carry.  The test word w (hash_test_word) is hi(hash) + {0, 1, 2}: with
               // w > hi(T) + TEST_SLACK the hash cannot be below T -- one 32-bit compare per k-mer and the halves'
@@ -940,7 +887,7 @@ restart:
             } else {
               uint64_t h[4], m[4];
 #pragma unroll
-              for (int b = 0; b < 4; b++) h[b] = ablate ? canon[b] * 0x9E3779B97F4A7C15ULL : kmer_hash(canon[b], P);
+              for (int b = 0; b < 4; b++) h[b] = kmer_hash(canon[b], P);
               if (allok && T != SENT) {  // one 64-bit compare per k-mer
 #pragma unroll
                 for (int b = 0; b < 4; b++) m[b] = __ballot(h[b] < T);
@@ -1099,24 +1046,22 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   int cap = 0, wgs_per_cu = 1;
   bool packed = false;  // table layout (lut_bytes): packed only where it buys a workgroup per CU
   int wgs_lo = 1, wgs_hi = 3;
-  if (const char* e = getenv("RTC_SKETCH_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 3) wgs_lo = wgs_hi = v; }  // tuning experiments
   for (int wgs = wgs_hi; wgs >= wgs_lo && cap == 0; wgs--) {
     // 52 / 78 / 156 KiB: measured on MI355X, a 53.3 KiB allocation no longer runs three workgroups per CU
     const size_t share = ((size_t)156 * 1024 / wgs) & ~(size_t)2047;
     for (int pk = 0; pk < 2 && cap == 0; pk++) {
+    // (tests: both layouts are exercised for every k by forcing one of them; either gives the same sketches)
     if (pk && (lut_his(k) == 0 || getenv("RTC_SKETCH_NO_PACKED"))) break;
-    if (!pk && getenv("RTC_SKETCH_PACKED") && lut_his(k) > 0) continue;  // A/B: the packed layout wherever it exists
+    if (!pk && getenv("RTC_SKETCH_PACKED") && lut_his(k) > 0) continue;
     const size_t fixed = lut_bytes(k, pk != 0) + ((sizeof(Ctrl) + 15) & ~(size_t)15) + QUEUE_BYTES;
     // (round 1 measured ~3000 entries of room as the break-even against lost occupancy; with the merge sorting
     // only the new candidates and the express walk a third workgroup per CU wins down to the minimum room:
     // s = 2000 at 10 000 x 5 Mbp 114.5 -> 102.1 ms, the containment sketches of config 4 190 -> 164 ms)
-    size_t want_room = MIN_ROOM;
-    if (const char* e = getenv("RTC_SKETCH_WANT_ROOM")) want_room = (size_t)std::max(atoi(e), MIN_ROOM);  // tuning experiments
+    const size_t want_room = MIN_ROOM;
     if (share > fixed && (share - fixed) / 8 >= (size_t)chunk_max + want_room) { cap = (int)((share - fixed) / 8); wgs_per_cu = wgs; packed = pk != 0; }
     }
   }
   if (cap == 0) return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "sketch chunk %u does not fit the LDS", chunk_max);
-  if (const char* e = getenv("RTC_SKETCH_CAP")) { const int v = atoi(e); if (v >= (int)(chunk_max + MIN_ROOM) && v <= cap) cap = v; }  // tuning experiments
   // partial-sketch merge: two lists fit 2*chunk_max; twice that lets the rank merge work out of place
   const int cap_merge = (int)std::max<uint32_t>(std::max<uint32_t>(2 * chunk_max, std::min<uint32_t>(4 * chunk_max, 16384)), 1024);
   const size_t lds = (size_t)cap * 8 + lut_bytes(k, packed) + ((sizeof(Ctrl) + 15) & ~(size_t)15) + QUEUE_BYTES;
@@ -1155,8 +1100,7 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     uint32_t q = n_single % slots;
     if (q > 0 && q <= slots * 3 / 5) {
       const uint32_t want = slots / q;
-      uint64_t tail_max = 8;  // more pieces fill the round better but serialise in the per-genome merge (measured: 4-8 best)
-      if (const char* e = getenv("RTC_SKETCH_TAILMAX")) tail_max = (uint64_t)std::max(1, atoi(e));  // tuning experiments
+      const uint64_t tail_max = 8;  // more pieces fill the round better but serialise in the per-genome merge (measured: 4-8 best)
       for (uint32_t g = n; g-- > 0 && q > 0;) {
         if (nsv[g] != 1) continue;
         const uint64_t len = h_off[g + 1] - h_off[g];

@@ -5,7 +5,7 @@
 #   3. rocprofv3 --pmc passes (own runs, --pmc only)                     -> gpurun_out/prof/pmc*/  and *_pmc_traffic.json
 #   4. greedy (BASELINE config 4, 50 000 containment sketches) kernel stats
 # Usage: bash tools/collect_profiles.sh [tag]     (tag names the files, e.g. r02)
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
@@ -16,12 +16,12 @@ PMCGROUPS=("FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_s
 # ---- MinHash, BASELINE config[1] ----
 python $R/bench.py --steps 5 --warmup 2 > $OUT/bench_n1.jsonl 2> $OUT/bench_n1.err
 tail -c 600 $OUT/bench_n1.jsonl; echo
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/stats.log 2>&1
 python $R/tools/kstats.py $OUT/stats | head -12
 i=0
 for grp in "${PMCGROUPS[@]}"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc$i -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc$i -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > $OUT/pmc$i.log 2>&1
 done
 python $R/tools/make_pmc_json.py $OUT $TAG > $OUT/${TAG}_pmc_traffic.json
 # ---- KSSD (--fast), BASELINE config[4] per-GPU shape ----
