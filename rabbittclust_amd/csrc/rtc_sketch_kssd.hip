@@ -562,21 +562,29 @@ __global__ __launch_bounds__(WGB, 2) void sketch_kssd_bucket_kernel(const uint8_
 // dim_id is the k-mer's middle 12 bases, and the middle of the reverse complement is the reverse complement of
 // the middle: whichever strand is canonical, the FORWARD k-mer's middle 12-mer lies in S2 = S u rc(S) (8192
 // 12-mers of 16 Mi).  So the steady state never forms the reverse strand, never compares strands and never checks
-// characters: per dword it decodes four bases, rolls ONE 32-bit forward window, and per k-mer probes a blocked
-// Bloom filter of S2 in LDS -- 8192 blocks of 64 bits, block = field[10..23), one bit in each half (field[0..5),
-// field[5..10)): one ds_read_b64 and seven 2-cycle-class VALU instructions, the four k-mers of a dword OR-ed into
-// one accumulator and tested with ONE compare.  Nothing is lost: a valid k-mer's bases decode exactly, and
-// whatever else decodes to a hit (characters outside ACGT, bases beyond a genome's end, ~1/400 false positives
-// of the filter) is dropped later.  Hits (~0.7 lanes per wave and dword) put the dword's POSITION into a per-wave
-// LDS queue; bloom_drain re-reads those 25 bases from memory (L2) and does the reference's arithmetic exactly:
-// characters, base counter, both strands, canonical minimum, dimension lookup (the exact bucket index, read from
-// global memory here), reduced tuple, append.
+// characters.  It is a conservative candidate generator:
+//   * a wave walks a contiguous stretch of its segment 1 KiB at a time, lane l holding bases 16 l .. 16 l + 15 of the
+//     chunk (ONE coalesced 16-byte load per lane: every 128-byte line is requested once; the previous layout, a run
+//     of ~100 bases per lane, asked L2 for every line about four times and was bound there);
+//   * the lane packs its 16 bases into one register (four SWAR decodes + v_dot4), takes the 16 (32) bases in
+//     front of them from its neighbour lane(s) with a DPP wave shift (lane 0: carried over from the previous
+//     chunk in SGPRs) -- no warm-up bases at all -- and cuts the 32-bit word that holds the four middle 12-mers of a
+//     dword's k-mers with one v_alignbit;
+//   * per k-mer a blocked Bloom filter of S2 in LDS is probed -- 8192 blocks of 64 bits, block = field[10..23), one
+//     bit in each half (field[0..5), field[5..10)): one ds_read_b64 and seven 2-cycle-class VALU instructions; the
+//     four k-mers of a dword are OR-ed into one accumulator and tested with ONE compare.
+// Nothing is lost: a valid k-mer's bases decode exactly, and whatever else decodes to a hit (characters outside
+// ACGT, bases beyond a genome's end, ~1/350 false positives of the filter) is dropped later.  Hits (~0.7 lanes per
+// wave and dword) put the dword's POSITION into a per-wave LDS queue; bloom_drain re-reads those K + 3 bases from
+// memory (L2) and does the reference's arithmetic exactly: characters, both strands, canonical minimum, dimension
+// lookup (the exact bucket index, read from global memory here), reduced tuple, append.
 constexpr int BLOOM_BYTES = 65536;                 // 8192 blocks x 8 B
-constexpr int BQ_CAP = 320;                        // queued positions per wave; a 16-byte group adds at most 256
+constexpr int BQ_CAP = 320;                        // queued positions per wave; one chunk adds at most 256
 constexpr int BQ_BYTES = (WGB / 64) * BQ_CAP * 4;
+constexpr int CHUNK = 1024;                        // bases a wave takes per step (64 lanes x 16)
 typedef uint32_t RTC_LDS* lds_u32_ptr;
 
-struct BloomSeg {  // what bloom_drain needs of the segment (passed by value: a plain-register call)
+struct BloomSeg {
   uint64_t g_begin, g_end, s_begin, s_end, base;   // base: queue entries are positions relative to it
 };
 
@@ -593,14 +601,31 @@ __device__ __forceinline__ uint32_t exact_rank_global(int var, uint32_t dim_id, 
   return found;
 }
 
-// The queued dwords, 64 at a time, one per lane: the K + 3 bases that end the dword's four k-mers are walked base
-// by base exactly as the reference does (:1126-1161) -- any character, genome and segment edges.
+// the k-mer `u` (canonical, exact 2K bits) of a lane with ok set: dimension lookup, reduced tuple, append
+__device__ __forceinline__ void bloom_emit(bool ok, uint64_t u, const KssdParams& P, const uint32_t* __restrict__ g_bk,
+                                           const uint16_t* __restrict__ g_rank, int var, uint32_t lane, void* orow,
+                                           uint32_t* ocnt, uint32_t stride) {
+  const uint32_t dim_id = (uint32_t)(u >> P.dim_shift) & 0xffffffu;              // :1142
+  uint32_t rank = 0xffffffffu;
+  if (ok) rank = exact_rank_global(var, dim_id, g_bk, g_rank);
+  const bool keep = rank != 0xffffffffu;
+  const uint64_t bal = __ballot(keep);
+  if (bal) append_tuples(bal, keep, reduced_tuple(P, u, rank), lane, orow, ocnt, stride, P.use64);
+}
+
+// The queued dwords, 64 at a time, one per lane.  The K + 3 bases that end the dword's four k-mers are read again:
+// when they are all ACGTacgt (one vote for the batch) both strands of the whole stretch come out of seven SWAR
+// decodes and the four k-mers are cut out of them; otherwise the batch is walked base by base exactly as the
+// reference does (:1126-1161) -- any character, genome edges.
 template <int K>
-__device__ __forceinline__ void bloom_drain(const uint8_t* __restrict__ seq, const BloomSeg sg, const KssdParams P,
-                                         const uint32_t* __restrict__ g_bk, const uint16_t* __restrict__ g_rank, int var,
-                                         lds_u32_ptr wq, uint32_t qn, uint32_t lane, void* orow, uint32_t* ocnt,
-                                         uint32_t stride) {
-  constexpr int NB = K + 3, NDW = (NB + 3 + 3) / 4;  // bytes walked; dwords that cover them at any alignment
+__device__ __forceinline__ void bloom_drain(const uint8_t* __restrict__ seq, const BloomSeg& sg, const KssdParams& P,
+                                            const uint32_t* __restrict__ g_bk, const uint16_t* __restrict__ g_rank, int var,
+                                            lds_u32_ptr wq, uint32_t qn, uint32_t lane, void* orow, uint32_t* ocnt,
+                                            uint32_t stride) {
+  constexpr int NB = K + 3;             // bases walked: the first k-mer's first .. the last k-mer's last
+  constexpr int NQ = (NB + 3) / 4;      // dwords that hold them once aligned; PAD bases follow the last k-mer
+  constexpr int PAD = 4 * NQ - NB;
+  constexpr int NDW = NQ + 1;           // dwords that cover them at any alignment
   for (uint32_t base = 0; base < qn; base += 64) {
     const uint32_t i = base + lane;
     const bool have = i < qn;
@@ -627,32 +652,79 @@ __device__ __forceinline__ void bloom_drain(const uint8_t* __restrict__ seq, con
     w[NDW] = 0;
     const uint32_t sh = (uint32_t)(b0 - a0) * 8u;  // bytes to drop in front: 0, 8, 16, 24 bits
 #pragma unroll
-    for (int j = 0; j < NDW; j++) w[j] = __builtin_amdgcn_alignbit(w[j + 1], w[j], sh);  // w[] now starts at b0
-    uint64_t tuple = 0, rvs = 0;
-    int run = 0;
+    for (int j = 0; j < NQ; j++) w[j] = __builtin_amdgcn_alignbit(w[j + 1], w[j], sh);  // w[] now starts at b0
+    // ownership of the four k-mer end positions q0 .. q0 + 3
+    bool own[4];
 #pragma unroll
-    for (int c = 0; c < NB; c++) {
-      const uint32_t ch = (w[c >> 2] >> (8 * (c & 3))) & 0xffu;
-      const uint32_t code = ((ch >> 1) ^ (ch >> 2)) & 3u;                          // BaseMap, src/SketchInfo.cpp:1007-1017
-      const bool valid = ((ch & 0xC0u) == 0x40u) && ((0x0010008Au >> (ch & 31u)) & 1u);
-      tuple = ((tuple << 2) | code) & P.tupmask;                                 // :1134
-      rvs = (rvs >> 2) + ((uint64_t)(code ^ 3u) << P.rev_add_move);              // :1135
-      run = valid ? run + 1 : 0;                                                 // base counter :1136,1161
-      if (c < K - 1) continue;
-      const int64_t pos = b0 + c;
-      const bool ok = have && run >= K && pos >= (int64_t)sg.s_begin && pos < (int64_t)sg.s_end;   // :1139 + ownership
-      const uint64_t u = tuple < rvs ? tuple : rvs;                              // :1141
-      const uint32_t dim_id = (uint32_t)(u >> P.dim_shift) & 0xffffffu;          // :1142
-      uint32_t rank = 0xffffffffu;
-      if (ok) rank = exact_rank_global(var, dim_id, g_bk, g_rank);
-      const bool keep = rank != 0xffffffffu;
-      const uint64_t bal = __ballot(keep);
-      if (bal) append_tuples(bal, keep, reduced_tuple(P, u, rank), lane, orow, ocnt, stride, P.use64);
+    for (int b = 0; b < 4; b++) own[b] = have && q0 + b >= (int64_t)sg.s_begin && q0 + b < (int64_t)sg.s_end;
+    uint32_t codes[NQ], bad = 0;
+#pragma unroll
+    for (int j = 0; j < NQ; j++) {
+      codes[j] = ((w[j] >> 1) ^ (w[j] >> 2)) & 0x03030303u;                       // BaseMap, src/SketchInfo.cpp:1007-1017
+      bad = __builtin_amdgcn_bitop3_b32(bad, __builtin_amdgcn_perm(0u, 0x54474341u, codes[j]), w[j], 0xF6);  // bad | (perm ^ w)
+    }
+    if (!__ballot(have && (bad & 0xDFDFDFDFu) != 0u)) {
+      // every base of every lane is one of ACGTacgt: F = the 4 NQ bases, first on top; R = their reverse
+      // complement (v_dot4 per dword gives the forward byte and the reverse-complement byte)
+      uint64_t F = 0, R = 0;
+#pragma unroll
+      for (int j = 0; j < NQ; j++) {
+        const uint32_t pack = __builtin_amdgcn_udot4(codes[j], 0x01041040u, 0u, false);          // c0<<6|c1<<4|c2<<2|c3
+        const uint32_t rp = __builtin_amdgcn_udot4(codes[j], 0x40100401u, 0u, false) ^ 0xffu;   // complements, reversed
+        F |= (uint64_t)pack << (8 * (NQ - 1 - j));
+        R |= (uint64_t)rp << (8 * j);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const uint64_t tuple = (F >> (2 * (PAD + 3 - b))) & P.tupmask;           // bases b .. b + K - 1 (:1134)
+        const uint64_t rvs = (R >> (2 * b)) & P.tupmask;                         // their reverse complement (:1135)
+        bloom_emit(own[b], tuple < rvs ? tuple : rvs, P, g_bk, g_rank, var, lane, orow, ocnt, stride);   // :1141
+      }
+    } else {
+      uint64_t tuple = 0, rvs = 0;
+      int run = 0;
+#pragma unroll 1
+      for (int c = 0; c < NB; c++) {
+        const uint32_t ch = w[0] & 0xffu;
+        // the stream moves down one byte (NQ dwords; rolled: this is the rare path)
+#pragma unroll
+        for (int j = 0; j < NQ; j++) w[j] = __builtin_amdgcn_alignbit(j + 1 < NQ ? w[j + 1] : 0u, w[j], 8);
+        const uint32_t code = ((ch >> 1) ^ (ch >> 2)) & 3u;
+        const bool valid = ((ch & 0xC0u) == 0x40u) && ((0x0010008Au >> (ch & 31u)) & 1u);
+        tuple = ((tuple << 2) | code) & P.tupmask;                               // :1134
+        rvs = (rvs >> 2) + ((uint64_t)(code ^ 3u) << P.rev_add_move);            // :1135
+        run = valid ? run + 1 : 0;                                               // base counter :1136,1161
+        if (c < K - 1) continue;
+        const int64_t pos = b0 + c;
+        const bool ok = have && run >= K && pos >= (int64_t)sg.s_begin && pos < (int64_t)sg.s_end;   // :1139 + ownership
+        bloom_emit(ok, tuple < rvs ? tuple : rvs, P, g_bk, g_rank, var, lane, orow, ocnt, stride);
+      }
     }
   }
 }
 
-template <int K, int RUN_DW, int WARM_DW>
+// 16 bases at q, 'N' for every position outside the genome: chunks at a genome's ends only (one instance, rolled)
+__device__ __noinline__ uint4 load_bases16_edge(const uint8_t* __restrict__ seq, int64_t q, uint64_t g_begin, uint64_t g_end) {
+  uint32_t ww[4];
+#pragma unroll 1
+  for (int d = 0; d < 4; d++) {
+    uint32_t x = 0;
+#pragma unroll 1
+    for (int b = 3; b >= 0; b--) {
+      const int64_t p = q + 4 * d + b;
+      x = (x << 8) | ((p >= (int64_t)g_begin && p < (int64_t)g_end) ? (uint32_t)seq[p] : (uint32_t)'N');
+    }
+    ww[d] = x;
+  }
+  return make_uint4(ww[0], ww[1], ww[2], ww[3]);
+}
+
+// lane l receives lane l - 1's value, lane 0 keeps `first` (DPP wave_shr:1)
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t v, uint32_t first) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
+}
+
+template <int K>
 __global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t* __restrict__ seq,
                                                                const KSegment* __restrict__ segs, KssdParams P,
                                                                const uint32_t* __restrict__ g_bloom,  // 8192 x 8 B
@@ -661,17 +733,15 @@ __global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t
                                                                int var, void* __restrict__ out, uint32_t stride,
                                                                uint32_t* __restrict__ cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  static_assert((RUN_DW + WARM_DW) % 4 == 0, "a lane's window must be whole 16-byte loads");
-  static_assert(K % 2 == 0 && K >= 18 && K <= 28, "24-bit dim_id, 2K + 8 <= 64");
-  static_assert(4 * WARM_DW >= K / 2 + 5, "the warm-up must reach the first owned k-mer's middle 12-mer");
-  constexpr int OWN = RUN_DW * 4;
-  constexpr int TILE_BASES = WGB * RUN_DW * 4;
-  constexpr int NG = (RUN_DW + WARM_DW) / 4;
+  static_assert(K % 2 == 0 && K >= 18 && K <= 28, "24-bit dim_id in the middle of at most 28 bases");
   constexpr int DS = K - 12;                       // dim_shift: bit of a window where its middle 12-mer starts
-  // K = 20, 22: the four fields of a dword's k-mers lie inside the 32 bits the forward window held BEFORE the dword
-  // (bits [DS - 2 - 2b, DS + 22 - 2b) of it), so ONE 32-bit register is rolled; otherwise a 64-bit window is
-  // rolled and the 32 bits from DS up are cut out per dword (fields at [6 - 2b, 30 - 2b))
+  // With X = (bases before the lane's 16 : the lane's 16 bases), the word E of dword qd holds the four middle
+  // 12-mers of the k-mers that end in it.  K = 20, 22: E = the 16 bases in front of the dword (fields at bits
+  // [DS - 2 - 2b, DS + 22 - 2b)); otherwise E = the 32 bits from DS up of the window that ends with the dword
+  // (fields at [6 - 2b, 30 - 2b)), which reaches into the second neighbour's bases.
   constexpr bool NARROW = DS >= 8 && DS <= 10;
+  constexpr int FO0 = NARROW ? DS - 2 : 6;
+  constexpr int AHEAD = 6;                         // chunks requested ahead of the one being walked
   const KSegment sg = segs[blockIdx.x];
   const int t = threadIdx.x;
   const uint32_t lane = t & 63;
@@ -684,63 +754,77 @@ __global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t
   if ((uint32_t)(uintptr_t)(RTC_LDS unsigned char*)smem != 0u) __builtin_trap();  // the filter is addressed absolutely
   void* orow = reinterpret_cast<unsigned char*>(out) + (uint64_t)sg.genome * stride * (P.use64 ? 8 : 4);
   uint32_t* ocnt = cnt + sg.genome;
-  const int w0 = __builtin_amdgcn_readfirstlane(t & ~63);
-  const lds_u32_ptr wq = (lds_u32_ptr)(uintptr_t)(BLOOM_BYTES + (w0 >> 6) * BQ_CAP * 4);  // this wave's queue
-  uint32_t qn = 0;                                                                        // wave-uniform
-  const BloomSeg bs{sg.g_begin, sg.g_end, sg.s_begin, sg.s_end, (sg.s_begin & ~15ULL) - 64};
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const lds_u32_ptr wq = (lds_u32_ptr)(uintptr_t)(BLOOM_BYTES + wv * BQ_CAP * 4);  // this wave's queue
+  uint32_t qn = 0;                                                                 // wave-uniform
+  const BloomSeg bs{sg.g_begin, sg.g_end, sg.s_begin, sg.s_end, (sg.s_begin & ~(uint64_t)(CHUNK - 1)) - 64};
 
-  // One drain site in the code (it is a long stretch of rare code): the walk leaves a tile at the group where the
-  // queue could overflow, the drain runs, and the walk comes back to that group with the window it had rolled.
-  uint32_t Fhi = 0, Flo = 0;
-  int g_resume = 0;  // first group of the current tile that still has to be probed
-  uint64_t T0 = sg.s_begin & ~15ULL;
+  // this wave's chunks [c, c1) of the segment's 1 KiB-aligned span
+  const int64_t A0 = (int64_t)(sg.s_begin & ~(uint64_t)(CHUNK - 1));
+  const int64_t NC = ((int64_t)sg.s_end - A0 + CHUNK - 1) / CHUNK;
+  int64_t c = NC * wv / (WGB / 64);
+  const int64_t c1 = NC * (wv + 1) / (WGB / 64);
+
+  auto fetch = [&](int64_t ci) -> uint4 {  // lane's 16 bases of chunk ci ('N' outside the genome)
+    const int64_t cb = A0 + ci * CHUNK;
+    const bool inside = cb >= (int64_t)sg.g_begin && cb + CHUNK <= (int64_t)sg.g_end && !P.nofast;  // wave-uniform
+    const int64_t q = cb + 16 * (int64_t)lane;
+    return inside ? *reinterpret_cast<const uint4*>(seq + q) : load_bases16_edge(seq, q, sg.g_begin, sg.g_end);
+  };
+  auto pack16 = [&](const uint4 d) -> uint32_t {  // 16 bases -> 32 bits, first base on top (BaseMap :1007-1017)
+    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+    uint32_t pk[4];
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {
+      const uint32_t codes = ((w[qd] >> 1) ^ (w[qd] >> 2)) & 0x03030303u;
+      pk[qd] = __builtin_amdgcn_udot4(codes, 0x01041040u, 0u, false);  // c0<<6|c1<<4|c2<<2|c3
+    }
+    return (((pk[0] << 8 | pk[1]) << 8 | pk[2]) << 8) | pk[3];
+  };
+
+  uint32_t carry1 = 0, carry2 = 0;  // the packed bases of lanes 63 / 62 of the previous chunk (SGPRs)
+  bool primed = false;
   for (;;) {
-    const bool more = T0 < sg.s_end;
-    bool need = !more;  // after the last tile: what is still queued
-    if (more) {
-      const int64_t own_b = (int64_t)T0 + (int64_t)OWN * w0, own_e = own_b + (int64_t)OWN * 64;
-      if (own_b >= (int64_t)sg.s_end || own_e <= (int64_t)sg.s_begin) { T0 += TILE_BASES; continue; }  // nothing of this wave's run is owned
-      // plain loads when the wave's whole window lies inside the genome, guarded ones ('N' outside) otherwise
-      const bool inside = own_b - 4 * WARM_DW >= (int64_t)sg.g_begin && own_e <= (int64_t)sg.g_end && !P.nofast;
-      const int64_t p0 = (int64_t)T0 + OWN * t - 4 * WARM_DW;
-      // four 16-byte groups of the lane's window in flight (a ring of registers: group g + 4 is requested when
-      // group g has been walked); after a drain the tile is walked again from its first group -- decode and roll
-      // only, the probes start at the group the walk had reached
-      constexpr int AHEAD = 4;
-      uint4 D[AHEAD];
-      auto fetch = [&](int g) -> uint4 {
-        return inside ? *reinterpret_cast<const uint4*>(seq + p0 + 16 * g) : load_bases16(seq, p0 + 16 * g, sg.g_begin, sg.g_end);
-      };
+    // (re)start of the pipeline: once per wave, and again after the queue had to be drained mid-way
+    if (qn) bloom_drain<K>(seq, bs, P, g_bk, g_rank, var, wq, qn, lane, orow, ocnt, stride);
+    qn = 0;
+    if (c >= c1) break;
+    if (!primed) {  // the bases in front of the first chunk
+      const uint32_t Wb = pack16(fetch(c - 1));
+      carry1 = __builtin_amdgcn_readlane(Wb, 63);
+      carry2 = __builtin_amdgcn_readlane(Wb, 62);
+      primed = true;
+    }
+    uint4 D[AHEAD];
 #pragma unroll
-      for (int g = 0; g < AHEAD && g < NG; g++) D[g] = fetch(g);
-      Fhi = 0; Flo = 0;
+    for (int j = 0; j < AHEAD; j++) D[j] = c + j < c1 ? fetch(c + j) : make_uint4(0u, 0u, 0u, 0u);
+    bool stop = false;
+    while (!stop) {
 #pragma unroll
-      for (int g = 0; g < NG; g++) {
-        const bool probing = g >= g_resume;                             // wave-uniform
-        if (probing && qn > (uint32_t)(BQ_CAP - 256)) { need = true; g_resume = g; break; }  // room for every lane and dword of a group
-        const uint32_t w[4] = {D[g % AHEAD].x, D[g % AHEAD].y, D[g % AHEAD].z, D[g % AHEAD].w};
-        if (g + AHEAD < NG) {
-          __builtin_amdgcn_sched_barrier(0);  // keeps the request here: hoisted, all NG groups would sit in registers
-          D[g % AHEAD] = fetch(g + AHEAD);
+      for (int j = 0; j < AHEAD; j++) {
+        if (c >= c1 || qn > (uint32_t)(BQ_CAP - 256)) { stop = true; break; }   // done, or no room for a whole chunk's hits
+        const uint32_t W = pack16(D[j]);
+        if (c + AHEAD < c1) {
+          __builtin_amdgcn_sched_barrier(0);  // the request stays here (hoisted, its registers would pile up)
+          D[j] = fetch(c + AHEAD);
         }
+        const uint32_t Wp = from_lane_below(W, carry1);
+        uint32_t Wpp = 0;
+        if (!NARROW) { Wpp = from_lane_below(Wp, carry2); carry2 = __builtin_amdgcn_readlane(W, 62); }
+        carry1 = __builtin_amdgcn_readlane(W, 63);
+        const int64_t cb = A0 + c * CHUNK;
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
-          const uint32_t codes = ((w[qd] >> 1) ^ (w[qd] >> 2)) & 0x03030303u;             // BaseMap, :1007-1017
-          const uint32_t pack = __builtin_amdgcn_udot4(codes, 0x01041040u, 0u, false);   // c0<<6|c1<<4|c2<<2|c3
           uint32_t E;
           if (NARROW) {
-            E = Flo;
-            Flo = (Flo << 8) | pack;                                                      // tuple :1134 four times
+            E = qd ? __builtin_amdgcn_alignbit(Wp, W, 32 - 8 * qd) : Wp;
           } else {
-            Fhi = __builtin_amdgcn_alignbit(Fhi, Flo, 24);
-            Flo = (Flo << 8) | pack;
-            E = __builtin_amdgcn_alignbit(Fhi, Flo, DS);
+            const int sft = 24 - 8 * qd + DS;  // bits of (Wpp : Wp : W) below E
+            E = sft == 0 ? W : sft < 32 ? __builtin_amdgcn_alignbit(Wp, W, sft) : sft == 32 ? Wp : __builtin_amdgcn_alignbit(Wpp, Wp, sft - 32);
           }
-          if (g * 4 + qd < WARM_DW || !probing) continue;
           uint32_t acc = 0;
 #pragma unroll
           for (int b = 0; b < 4; b++) {
-            constexpr int FO0 = NARROW ? DS - 2 : 6;
             const int fo = FO0 - 2 * b;                                                   // the field's bit offset in E
             const uint32_t f0 = fo ? (E >> fo) : E;                                       // field[0..5): bit in the low half
             const uint32_t a = (E >> (fo + 7)) & 0xfff8u;                                 // block = field[10..23)
@@ -751,21 +835,16 @@ __global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t
           }
           const bool hit = (acc & 1u) != 0u;
           if (__ballot(hit)) {  // wave-uniform; about every second dword of a wave
-            const int64_t pos = p0 + 16 * g + 4 * qd;                                     // its k-mers end at pos .. pos + 3
+            const int64_t pos = cb + 16 * (int64_t)lane + 4 * qd;                         // its k-mers end at pos .. pos + 3
             const bool mine = hit && pos + 3 >= (int64_t)sg.s_begin && pos < (int64_t)sg.s_end;
             const uint64_t bal = __ballot(mine);
             if (mine) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint32_t)(pos - (int64_t)bs.base);
             qn += (uint32_t)__popcll(bal);
           }
         }
+        c++;
       }
-      if (!need) { T0 += TILE_BASES; g_resume = 0; }
     }
-    if (need) {
-      if (qn) bloom_drain<K>(seq, bs, P, g_bk, g_rank, var, wq, qn, lane, orow, ocnt, stride);
-      qn = 0;
-    }
-    if (!more) break;
   }
 }
 
@@ -1225,7 +1304,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
     const int lds_bl = BLOOM_BYTES + BQ_BYTES;
 #define LAUNCH_BLOOM(KK)                                                                                              \
   case KK: {                                                                                                         \
-    auto kern = sketch_kssd_bloom_kernel<KK, 27, 5>;                                                                 \
+    auto kern = sketch_kssd_bloom_kernel<KK>;                                                                 \
     RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bl));        \
     hipLaunchKernelGGL(kern, dim3((uint32_t)segs.size()), dim3(WGB), lds_bl, ctx->stream, d_seq,                      \
                        (const KSegment*)ws0, P, (const uint32_t*)kc.d_bloom, d_bk, d_rk, kc.bvar, d_out, stride, d_cnt); \
