@@ -6,13 +6,12 @@
 // sort (:1154-1157, :1180-1193).
 //
 // The reference probes a phmap of the kept (dim_id -> rank) pairs per k-mer.  Here the kept set
-// (dim_end of 2^(4*half_subk) ids; 4096 of 16 Mi at the default drlevel 3) is compiled on the host
-// into an index that lives in LDS:
-//  * bucket index (24-bit dim_id, K = 18..28: every default configuration): 8192 buckets of four 16-bit
-//    patterns, so a probe is one ds_read_b64 and four 16-bit compares, exact (see bucket_addr).  Its
-//    kernel walks wave tiles without a branch per k-mer while the wave holds only ACGTacgt: candidates go
-//    to a per-wave LDS queue and are finished (rank, reduced tuple, append) 64 at a time.
-//  * two-table cuckoo index (other k-mer lengths, 28-bit dim_id): two ds_read_b32 per k-mer.
+// (dim_end of 2^(4*half_subk) ids; 4096 of 16 Mi at the default drlevel 3) is compiled on the host:
+//  * 24-bit dim_id, K = 18..28 (every default configuration): sketch_kssd_bloom_kernel.  The steady state looks
+//    at the FORWARD strand only -- a blocked Bloom filter in LDS of the kept middle 12-mers and their reverse
+//    complements -- and queues the positions of possible hits; those are finished exactly (both strands, canonical
+//    minimum, an exact bucket index of the kept ids: 8192 buckets of four 16-bit patterns + ranks, in global memory).
+//  * two-table cuckoo index in LDS (other k-mer lengths, 28-bit dim_id): two ds_read_b32 per k-mer.
 //  * the full table in HBM when more than 8192 ids are kept (drlevel <= 2) or nothing else can be built.
 // Survivors are appended to the genome's output row with wave-aggregated atomics;
 // kssd_sort_unique_kernel then sorts and deduplicates each row in LDS.
@@ -53,11 +52,7 @@ struct KssdParams {
   int lshift;        // 64 - 2K: top-aligned windows
   uint32_t dimmask;  // low `dimbits` bits
   uint32_t m1key, m2key;  // entry bits compared with dim_id in table 1 / table 2
-  int cf0, cr0;      // bucket kernel: forward window b = F << (cf0 + 2b), reverse = R << (cr0 - 2b)
-  int xs;            // bucket kernel: shift that brings dim_id to bits 0..23 (of the 64-bit pair / the high word)
-  int re;            // bucket kernel: the reverse extended window is kept << re (its new byte lands on a byte)
-  uint32_t rsel;     // bucket kernel: v_perm selector of the reverse window's high-word roll
-  int nofast;        // bucket kernel: RTC_KSSD_NOFAST=1 sends every tile through the general walk (tests)
+  int nofast;        // prefilter kernel: RTC_KSSD_NOFAST=1 sends every chunk through the guarded loads (tests)
   uint64_t tupmask, domask, undomask0, undomask1;
 };
 
@@ -87,49 +82,9 @@ struct KssdTables {
   const int32_t* g_table;       // full shuffle table (HBM path)
 };
 
-// ---- bucket index (the default --fast configuration) -------------------------------------------------
-// x carries dim_id in bits 0..23 (anything above).  VAR 0: bucket = dim_id[3..16), the pattern is bytes
-// 0 and 2 of x; VAR 1: bucket = dim_id[11..24), the pattern is the low half of x.  The 16-bit pattern
-// holds every key bit the bucket does not imply and five that it does, so a slot is matched by one
-// 16-bit compare and an unused slot holds a pattern no key of its bucket can produce: exact, no rank.
-// VAR 2 (K = 22, where dim_id[2..24) sits in the high word of the top-aligned window and dim_id[0..2) in the
-// low word): bucket as VAR 1, pattern = dim_id[2..18) -- the steady state tests 22 bits on the high word
-// alone and the two low bits are checked (they sit beside the rank, bits 12..13) when a candidate is drained.
-template <int VAR> __device__ __forceinline__ uint32_t bucket_addr(uint32_t x) {
-  return VAR ? ((x >> 8) & 0xfff8u) : (x & 0xfff8u);
-}
-template <int VAR> __device__ __forceinline__ uint32_t bucket_pattern(uint32_t x) {
-  return VAR == 2 ? ((x >> 2) & 0xffffu) : VAR == 1 ? (x & 0xffffu) : __builtin_amdgcn_perm(0u, x, 0x0c0c0200u);
-}
-// the bucket kernel's index starts at LDS address 0 (checked at kernel entry): a bucket's byte offset IS its
-// LDS address, read through an address_space(3) pointer (ds_read_b64, no base add)
 #define RTC_LDS __attribute__((address_space(3)))
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint2 bucket_read(uint32_t addr) {
-  const u32x2 v = *(const RTC_LDS u32x2*)(uintptr_t)addr;
-  return make_uint2(v.x, v.y);
-}
-__device__ __forceinline__ bool bucket_match(uint2 e, uint32_t q) {
-  return (e.x & 0xffffu) == q || (e.x >> 16) == q || (e.y & 0xffffu) == q || (e.y >> 16) == q;
-}
-// exact membership of a clean dim_id: rank (bits 0..11) or 0xffffffff
-template <int VAR>
-__device__ __forceinline__ uint32_t bucket_lookup(uint32_t dim_id, const uint16_t* __restrict__ g_rank) {
-  const uint32_t addr = bucket_addr<VAR>(dim_id);
-  const uint32_t q = bucket_pattern<VAR>(dim_id);
-  const uint2 e = bucket_read(addr);
-  const uint32_t pat[4] = {e.x & 0xffffu, e.x >> 16, e.y & 0xffffu, e.y >> 16};
-  uint32_t found = 0xffffffffu;
-#pragma unroll
-  for (int sl = 0; sl < 4; sl++) {
-    if (pat[sl] == q) {
-      const uint32_t r = g_rank[(addr >> 1) + sl];
-      if (VAR != 2 || (r >> 12) == (dim_id & 3u)) found = r & 0xfffu;
-    }
-  }
-  return found;
-}
 
 __device__ __forceinline__ uint64_t reduced_tuple(const KssdParams& P, uint64_t u, uint32_t rank) {   // :1150-1152
   return (((u & P.undomask0) | ((u & P.undomask1) << P.und1_shl)) >> (P.drlevel * 4)) | (uint64_t)rank;
@@ -304,258 +259,7 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
   }
 }
 
-// ---- the default --fast configuration: bucket index, branch-free steady state ---------------------
-// Candidates of the steady state (top-aligned canonical windows whose dim_id passed the bucket test) wait in
-// a per-wave LDS queue and are finished 64 at a time: exact membership, rank, reduced tuple, append.
-// 768 lanes x 2 workgroups per CU (index 64 KiB + queues each) = 6 waves per SIMD at <= 80 VGPRs: measured best of
-// 512 / 640 / 768 / 896 / 1024 (the walk is VALU-issue bound; the steady state needs 64 registers)
-constexpr int WGB = 768;                                     // lanes per workgroup of the bucket kernel
-constexpr int KQ_CAP = 128;                                  // entries per wave
-constexpr int KQ_BYTES = (WGB / 64) * KQ_CAP * 8;
-typedef uint64_t RTC_LDS* lds_u64_ptr;
-
-template <int VAR>
-__device__ __forceinline__ void drain_queue(const KssdParams& P, const uint16_t* __restrict__ g_rank, lds_u64_ptr wq,
-                                            uint32_t& qn, uint32_t lane, void* orow, uint32_t* ocnt, uint32_t stride) {
-  for (uint32_t base = 0; base < qn; base += 64) {
-    const uint32_t i = base + lane;
-    const bool have = i < qn;
-    const uint64_t uni = have ? wq[i] : 0ULL;
-    const uint64_t u = uni >> P.lshift;                                            // the exact 2K-bit tuple
-    const uint32_t dim_id = (uint32_t)(u >> P.dim_shift) & 0xffffffu;              // :1142
-    uint32_t rank = 0xffffffffu;
-    if (have) rank = bucket_lookup<VAR>(dim_id, g_rank);
-    const bool keep = rank != 0xffffffffu;
-    const uint64_t bal = __ballot(keep);
-    if (bal) append_tuples(bal, keep, reduced_tuple(P, u, rank), lane, orow, ocnt, stride, P.use64);
-  }
-  qn = 0;
-}
-
-// One 16-byte group of a lane whose wave holds only valid, owned bases.  Per dword: SWAR decode, the
-// validity of the whole group in one wave vote, forward and reverse-complement byte by one v_dot4_u32_u8
-// each, both extended windows rolled by one byte (the reverse one is kept shifted so that its new byte
-// lands on a byte boundary: v_perm + v_alignbit).  Per k-mer: the two strands top-aligned, the canonical
-// one's dim_id brought to x
-//   XMODE 0/1: context + dim_id fit the high word, so  hi(min(f, r)) = min(hi f, hi r)  -- 3 (+1) VALU
-//   XMODE 2:   64-bit compare + select + v_alignbit                                       -- 6 VALU
-//   XMODE 3:   K = 22: min(hi f, hi r) holds dim_id[2..24); the test ignores dim_id[0..2) -- 3 VALU, and four
-//              times as many candidates reach the queue, where the exact test drops three of them
-// then ONE ds_read_b64 of the bucket and four 16-bit compares (2 + 4 VALU).  Returns false, state
-// untouched, when some lane of the wave holds a character outside ACGTacgt in this group or the queue cannot
-// take the group's candidates (the caller sends the rest of the tile through the general walk).
-// wave mask of the lanes whose bucket holds the 16-bit pattern q (four v_cmp_eq_u32_sdwa + three s_or_b64)
-__device__ __forceinline__ uint64_t bucket_match_mask(uint2 e, uint32_t q) {
-  return __ballot((e.x & 0xffffu) == q) | __ballot((e.x >> 16) == q) | __ballot((e.y & 0xffffu) == q) |
-         __ballot((e.y >> 16) == q);
-}
-
-template <int XMODE, int VAR, int QCAP>
-__device__ __forceinline__ bool fast_group(const uint4 cur, const int emit_mask, const KssdParams& P,
-                                           lds_u64_ptr wq, uint32_t& qn, uint32_t lane, uint32_t& Fhi, uint32_t& Flo,
-                                           uint32_t& Rhi, uint32_t& Rlo) {
-  const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
-  uint32_t codes[4];
-  uint32_t bad = 0;
-#pragma unroll
-  for (int qd = 0; qd < 4; qd++) {
-    codes[qd] = ((w[qd] >> 1) ^ (w[qd] >> 2)) & 0x03030303u;  // BaseMap, src/SketchInfo.cpp:1007-1017
-    bad = __builtin_amdgcn_bitop3_b32(bad, __builtin_amdgcn_perm(0u, 0x54474341u, codes[qd]), w[qd], 0xF6);  // bad | (perm ^ w)
-  }
-  if (__ballot((bad & 0xDFDFDFDFu) != 0u)) return false;
-  const uint32_t Fhi0 = Fhi, Flo0 = Flo, Rhi0 = Rhi, Rlo0 = Rlo, qn0 = qn;
-  bool lost = false;  // wave-uniform
-#pragma unroll
-  for (int qd = 0; qd < 4; qd++) {
-    const uint32_t pack = __builtin_amdgcn_udot4(codes[qd], 0x01041040u, 0u, false);  // c0<<6|c1<<4|c2<<2|c3
-    // reverse-complement byte 255 - (c0 + 4 c1 + 16 c2 + 64 c3) as the LOW BYTE of an unsigned dot product with
-    // the weights 256 - {1, 4, 16, 64} on top of 255 (only that byte is used: v_perm picks it)
-    const uint32_t rp = __builtin_amdgcn_udot4(codes[qd], 0xC0F0FCFFu, 255u, false);
-    Fhi = __builtin_amdgcn_alignbit(Fhi, Flo, 24);              // tuple :1134 four times
-    Flo = (Flo << 8) | pack;
-    const uint32_t nhi = __builtin_amdgcn_perm(Rhi, rp, P.rsel);  // rvs :1135 four times, kept << P.re
-    Rlo = __builtin_amdgcn_alignbit(Rhi, Rlo, 8);
-    Rhi = nhi;
-    if (!((emit_mask >> qd) & 1)) continue;
-    const uint64_t F = ((uint64_t)Fhi << 32) | Flo, R = ((uint64_t)Rhi << 32) | Rlo;
-    uint64_t mm[4];
-    uint32_t x[4];
-    uint2 e[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-      // the four windows top-aligned; bits below a window are not cleaned -- they cannot change which of
-      // two different k-mers is smaller (:1141), and of two equal ones either will do
-      if (XMODE == 2) {
-        const uint64_t f = F << (P.cf0 + 2 * b);
-        const uint64_t r = R << (P.cr0 - 2 * b);
-        const uint64_t u = f < r ? f : r;
-        x[b] = __builtin_amdgcn_alignbit((uint32_t)(u >> 32), (uint32_t)u, P.xs);
-      } else {  // high words only (shift counts 1..31 for 18 <= K <= 22)
-        const uint32_t fh = __builtin_amdgcn_alignbit(Fhi, Flo, 32 - (P.cf0 + 2 * b));
-        const uint32_t rh = __builtin_amdgcn_alignbit(Rhi, Rlo, 32 - (P.cr0 - 2 * b));
-        const uint32_t mh = min(fh, rh);
-        x[b] = XMODE == 1 ? mh >> P.xs : mh;
-      }
-    }
-    // the four bucket reads in flight together, then the sixteen compares
-#pragma unroll
-    for (int b = 0; b < 4; b++)  // XMODE 3: x = ctx(10) | dim_id[2..24): bucket = dim_id[11..24) = x[9..22)
-      e[b] = bucket_read(XMODE == 3 ? ((x[b] >> 6) & 0xfff8u) : bucket_addr<VAR>(x[b]));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int b = 0; b < 4; b++)  // XMODE 3: pattern = dim_id[2..18) = x[0..16)
-      mm[b] = bucket_match_mask(e[b], XMODE == 3 ? (x[b] & 0xffffu) : bucket_pattern<VAR>(x[b]));
-    if (!(mm[0] | mm[1] | mm[2] | mm[3])) continue;
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const uint64_t bal = mm[b];
-      if (bal) {  // wave-uniform, ~1.5 % of the k-mer slots (XMODE 3: ~6 %)
-        const uint32_t cnt = (uint32_t)__popcll(bal);
-        const bool room = qn + cnt <= (uint32_t)QCAP;
-        lost |= !room;  // no room: the group is forgotten below and walked again by the general code
-        if (room) {
-          const uint64_t f = F << (P.cf0 + 2 * b);
-          const uint64_t r = R << (P.cr0 - 2 * b);
-          if (__builtin_amdgcn_inverse_ballot_w64(bal)) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = f < r ? f : r;
-          qn += cnt;
-        }
-      }
-    }
-  }
-  if (lost) {
-    Fhi = Fhi0; Flo = Flo0; Rhi = Rhi0; Rlo = Rlo0; qn = qn0;
-    return false;
-  }
-  return true;
-}
-
-// The groups g0.. of a lane's tile window base by base (:1126-1161): any character, any segment / genome
-// edge, guarded loads, a few live registers, one instance in the kernel.  Candidates (valid, owned k-mer ends
-// whose dim_id passes the bucket's pattern test) join the same queue as the steady state's.  Used from the
-// group that holds a character outside ACGTacgt to the end of the tile, and for wave tiles at the edges of a
-// segment.
-template <int VAR, int RUN_DW, int WARM_DW>
-__device__ __forceinline__ void slow_groups(const uint8_t* __restrict__ seq, const KSegment& sg, const KssdParams& P,
-                                            const uint16_t* __restrict__ g_rank, int64_t p0, int rel00, int rel_lo,
-                                            int rel_hi, int g0, lds_u64_ptr wq, uint32_t& qn, uint32_t lane, void* orow,
-                                            uint32_t* ocnt, uint32_t stride, uint64_t tuple, uint64_t rvs, int run) {
-#pragma unroll 1
-  for (int g = g0; g < (RUN_DW + WARM_DW) / 4; g++) {
-    const int64_t q = p0 + 16 * g;
-    uint64_t lo = 0, hi = 0;
-    if (q >= (int64_t)sg.g_begin && q + 16 <= (int64_t)sg.g_end) {
-      const uint4 cur = *reinterpret_cast<const uint4*>(seq + q);
-      lo = ((uint64_t)cur.y << 32) | cur.x;
-      hi = ((uint64_t)cur.w << 32) | cur.z;
-    } else {  // across an end of the genome: byte by byte, 'N' outside
-#pragma unroll 1
-      for (int i = 15; i >= 0; i--) {
-        const int64_t pp = q + i;
-        const uint64_t ch = (pp >= (int64_t)sg.g_begin && pp < (int64_t)sg.g_end) ? seq[pp] : (uint64_t)'N';
-        hi = (hi << 8) | (lo >> 56);
-        lo = (lo << 8) | ch;
-      }
-    }
-#pragma unroll 1
-    for (int i = 0; i < 16; i++) {
-      const uint32_t c = (uint32_t)lo & 0xffu;
-      lo = (lo >> 8) | (hi << 56);
-      hi >>= 8;
-      const uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;                        // BaseMap, src/SketchInfo.cpp:1007-1017
-      const bool valid = ((c & 0xC0u) == 0x40u) && ((0x0010008Au >> (c & 31u)) & 1u);
-      tuple = ((tuple << 2) | code) & P.tupmask;                               // :1134
-      rvs = (rvs >> 2) + ((uint64_t)(code ^ 3u) << P.rev_add_move);            // :1135
-      run = valid ? run + 1 : 0;                                               // base counter :1136,1161
-      if (16 * g + i < 4 * WARM_DW) continue;                                  // warm-up: roll only
-      const int rel = rel00 + 16 * g + i;
-      const bool ok = run >= P.K && rel >= rel_lo && rel < rel_hi;            // :1139
-      const uint64_t u = tuple < rvs ? tuple : rvs;                            // :1141
-      const uint32_t dim_id = (uint32_t)(u >> P.dim_shift) & 0xffffffu;        // :1142
-      const uint2 e = bucket_read(bucket_addr<VAR>(dim_id));
-      const uint64_t bal = __ballot(ok && bucket_match(e, bucket_pattern<VAR>(dim_id)));
-      if (bal) {
-        const uint32_t cnt = (uint32_t)__popcll(bal);
-        if (qn + cnt > (uint32_t)KQ_CAP) drain_queue<VAR>(P, g_rank, wq, qn, lane, orow, ocnt, stride);
-        if (__builtin_amdgcn_inverse_ballot_w64(bal))
-          wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = u << P.lshift;
-        qn += cnt;
-      }
-    }
-  }
-}
-
-template <int RUN_DW, int WARM_DW, int XMODE, int VAR>
-__global__ __launch_bounds__(WGB, 2) void sketch_kssd_bucket_kernel(const uint8_t* __restrict__ seq,
-                                                                const KSegment* __restrict__ segs, KssdParams P,
-                                                                const uint32_t* __restrict__ g_bk,    // 8192 x 8 B
-                                                                const uint16_t* __restrict__ g_rank,  // 32768
-                                                                void* __restrict__ out, uint32_t stride,
-                                                                uint32_t* __restrict__ cnt) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  static_assert((RUN_DW + WARM_DW) % 4 == 0, "a lane's window must be whole 16-byte loads");
-  constexpr int OWN = RUN_DW * 4;
-  constexpr int TILE_BASES = WGB * RUN_DW * 4;
-  constexpr int NG = (RUN_DW + WARM_DW) / 4;
-  const KSegment sg = segs[blockIdx.x];
-  const int t = threadIdx.x;
-  const uint32_t lane = t & 63;
-  {
-    uint4* l4 = reinterpret_cast<uint4*>(smem);
-    const uint4* g4 = reinterpret_cast<const uint4*>(g_bk);
-    for (int i = t; i < BUCKET_BYTES / 16; i += WGB) l4[i] = g4[i];
-    __syncthreads();
-  }
-  if ((uint32_t)(uintptr_t)(RTC_LDS unsigned char*)smem != 0u) __builtin_trap();  // bucket_read addresses the index absolutely
-  void* orow = reinterpret_cast<unsigned char*>(out) + (uint64_t)sg.genome * stride * (P.use64 ? 8 : 4);
-  uint32_t* ocnt = cnt + sg.genome;
-  const int w0 = __builtin_amdgcn_readfirstlane(t & ~63);
-  const lds_u64_ptr wq = (lds_u64_ptr)(uintptr_t)(BUCKET_BYTES + (w0 >> 6) * KQ_CAP * 8);  // this wave's queue
-  uint32_t qn = 0;                                                                         // wave-uniform
-
-  // the wave's bases [own_b - warm-up, own_e): all inside the genome (plain loads) and all owned positions
-  // inside the segment => every k-mer end position of the wave counts as long as the characters are valid
-  auto wave_fast = [&](uint64_t T0) {
-    const int64_t own_b = (int64_t)T0 + (int64_t)OWN * w0, own_e = own_b + (int64_t)OWN * 64;
-    return T0 < sg.s_end && own_b - 4 * WARM_DW >= (int64_t)sg.g_begin && own_e <= (int64_t)sg.g_end &&
-           own_b >= (int64_t)sg.s_begin && own_e <= (int64_t)sg.s_end && !P.nofast;
-  };
-  for (uint64_t T0 = sg.s_begin & ~15ULL; T0 < sg.s_end; T0 += TILE_BASES) {
-    const int64_t lo64 = (int64_t)sg.s_begin - (int64_t)T0;
-    const int64_t hi64 = (int64_t)sg.s_end - (int64_t)T0;
-    const int rel_lo = lo64 < 0 ? 0 : (int)lo64;
-    const int rel_hi = hi64 > TILE_BASES ? TILE_BASES : (int)hi64;
-    const int64_t own_b = (int64_t)T0 + (int64_t)OWN * w0, own_e = own_b + (int64_t)OWN * 64;
-    if (own_b >= (int64_t)sg.s_end || own_e <= (int64_t)sg.s_begin) continue;  // nothing of this wave's run is owned
-    const bool wfast = wave_fast(T0);
-    if (qn > (uint32_t)KQ_CAP / 2) drain_queue<VAR>(P, g_rank, wq, qn, lane, orow, ocnt, stride);
-    const int64_t p0 = (int64_t)T0 + OWN * t - 4 * WARM_DW;
-    int grp = 0;
-    uint32_t Fhi = 0, Flo = 0, Rhi = 0, Rlo = 0;
-    if (wfast) {
-      // the lane's whole window at once: the loads of the later groups fly while the first are walked
-      uint4 D[NG];
-      const uint4* base = reinterpret_cast<const uint4*>(seq + p0);
-#pragma unroll
-      for (int g = 0; g < NG; g++) D[g] = base[g];
-      bool good = true;
-#pragma unroll
-      for (int g = 0; g < NG; g++) {
-        if (good) {
-          int mask = 0;
-          for (int qd = 0; qd < 4; qd++) mask |= (g * 4 + qd >= WARM_DW ? 1 : 0) << qd;
-          good = fast_group<XMODE, VAR, KQ_CAP>(D[g], mask, P, wq, qn, lane, Fhi, Flo, Rhi, Rlo);
-          if (good) grp = g + 1;
-        }
-      }
-    }
-    if (grp < NG) {  // from the group with a character outside ACGTacgt (or a full queue), or the whole edge tile
-      const uint64_t F = ((uint64_t)Fhi << 32) | Flo, R = ((uint64_t)Rhi << 32) | Rlo;
-      slow_groups<VAR, RUN_DW, WARM_DW>(seq, sg, P, g_rank, p0, OWN * t - 4 * WARM_DW, rel_lo, rel_hi, grp, wq, qn, lane, orow,
-                                        ocnt, stride, F, R >> (P.re + 8), 16 * grp);
-    }
-  }
-  drain_queue<VAR>(P, g_rank, wq, qn, lane, orow, ocnt, stride);
-}
+constexpr int WGB = 768;  // lanes per workgroup of the prefilter kernel: 2 workgroups per CU (64 KiB filter + queues each) = 6 waves per SIMD
 
 // ---- forward-strand prefilter (the default --fast configuration, K = 18..28, 24-bit dim_id) --------------
 // A k-mer is kept when the dim_id of its CANONICAL form is one of the dim_end kept dimensions (:1141-1149).
@@ -613,23 +317,22 @@ __device__ __forceinline__ void bloom_emit(bool ok, uint64_t u, const KssdParams
   if (bal) append_tuples(bal, keep, reduced_tuple(P, u, rank), lane, orow, ocnt, stride, P.use64);
 }
 
-// The queued dwords, 64 at a time, one per lane.  The K + 3 bases that end the dword's four k-mers are read again:
+// n <= 64 queued dwords wq[first .. first + n), one per lane.  The K + 3 bases that end the dword's four k-mers are read again:
 // when they are all ACGTacgt (one vote for the batch) both strands of the whole stretch come out of seven SWAR
 // decodes and the four k-mers are cut out of them; otherwise the batch is walked base by base exactly as the
 // reference does (:1126-1161) -- any character, genome edges.
 template <int K>
 __device__ __forceinline__ void bloom_drain(const uint8_t* __restrict__ seq, const BloomSeg& sg, const KssdParams& P,
                                             const uint32_t* __restrict__ g_bk, const uint16_t* __restrict__ g_rank, int var,
-                                            lds_u32_ptr wq, uint32_t qn, uint32_t lane, void* orow, uint32_t* ocnt,
-                                            uint32_t stride) {
+                                            lds_u32_ptr wq, uint32_t first, uint32_t n, uint32_t lane, void* orow,
+                                            uint32_t* ocnt, uint32_t stride) {
   constexpr int NB = K + 3;             // bases walked: the first k-mer's first .. the last k-mer's last
   constexpr int NQ = (NB + 3) / 4;      // dwords that hold them once aligned; PAD bases follow the last k-mer
   constexpr int PAD = 4 * NQ - NB;
   constexpr int NDW = NQ + 1;           // dwords that cover them at any alignment
-  for (uint32_t base = 0; base < qn; base += 64) {
-    const uint32_t i = base + lane;
-    const bool have = i < qn;
-    const int64_t q0 = (int64_t)sg.base + (have ? wq[i] : 0u);  // first base of the dword
+  {
+    const bool have = lane < n;
+    const int64_t q0 = (int64_t)sg.base + (have ? wq[first + lane] : 0u);  // first base of the dword
     const int64_t b0 = q0 - (K - 1);                             // first base of its first k-mer
     const int64_t a0 = b0 & ~(int64_t)3;
     uint32_t w[NDW + 1];
@@ -786,8 +489,13 @@ __global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t
   bool primed = false;
   for (;;) {
     // (re)start of the pipeline: once per wave, and again after the queue had to be drained mid-way
-    if (qn) bloom_drain<K>(seq, bs, P, g_bk, g_rank, var, wq, qn, lane, orow, ocnt, stride);
-    qn = 0;
+    // Full batches of 64 are taken from the end of the queue (every lane busy; a drain costs the same for 3 entries
+    // as for 64); what is left (< 64) waits for the next time, or is finished after the last chunk.
+    while (qn >= 64 || (qn && c >= c1)) {
+      const uint32_t n = qn < 64 ? qn : 64;
+      bloom_drain<K>(seq, bs, P, g_bk, g_rank, var, wq, qn - n, n, lane, orow, ocnt, stride);
+      qn -= n;
+    }
     if (c >= c1) break;
     if (!primed) {  // the bases in front of the first chunk
       const uint32_t Wb = pack16(fetch(c - 1));
@@ -802,7 +510,7 @@ __global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t
     while (!stop) {
 #pragma unroll
       for (int j = 0; j < AHEAD; j++) {
-        if (c >= c1 || qn > (uint32_t)(BQ_CAP - 256)) { stop = true; break; }   // done, or no room for a whole chunk's hits
+        if (c >= c1 || qn >= (uint32_t)(BQ_CAP - 256)) { stop = true; break; }  // done, or a full batch waits (room for a whole chunk's hits is kept)
         const uint32_t W = pack16(D[j]);
         if (c + AHEAD < c1) {
           __builtin_amdgcn_sched_barrier(0);  // the request stays here (hoisted, its registers would pile up)
@@ -813,6 +521,8 @@ __global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t
         if (!NARROW) { Wpp = from_lane_below(Wp, carry2); carry2 = __builtin_amdgcn_readlane(W, 62); }
         carry1 = __builtin_amdgcn_readlane(W, 63);
         const int64_t cb = A0 + c * CHUNK;
+        const bool edge = cb < (int64_t)sg.s_begin || cb + CHUNK > (int64_t)sg.s_end;     // wave-uniform: first / last chunk of the segment
+        const uint32_t rel0 = (uint32_t)(cb - (int64_t)bs.base) + 16u * lane;            // queue entry of the lane's first dword
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
           uint32_t E;
@@ -835,10 +545,13 @@ __global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t
           }
           const bool hit = (acc & 1u) != 0u;
           if (__ballot(hit)) {  // wave-uniform; about every second dword of a wave
-            const int64_t pos = cb + 16 * (int64_t)lane + 4 * qd;                         // its k-mers end at pos .. pos + 3
-            const bool mine = hit && pos + 3 >= (int64_t)sg.s_begin && pos < (int64_t)sg.s_end;
+            bool mine = hit;
+            if (edge) {  // the dword's k-mers end at pos .. pos + 3: queued only when one of them is owned
+              const int64_t pos = cb + 16 * (int64_t)lane + 4 * qd;
+              mine = hit && pos + 3 >= (int64_t)sg.s_begin && pos < (int64_t)sg.s_end;
+            }
             const uint64_t bal = __ballot(mine);
-            if (mine) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint32_t)(pos - (int64_t)bs.base);
+            if (mine) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = rel0 + 4u * qd;
             qn += (uint32_t)__popcll(bal);
           }
         }
@@ -1143,24 +856,21 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
     if (kc.d_bloom) { (void)hipFree(kc.d_bloom); kc.d_bloom = nullptr; }
     kc.bvar = -1;
     if (lds_index && 4 * half_subk == 24 && !getenv("RTC_KSSD_CUCKOO")) {
-      // bucket index: 8192 buckets of four 16-bit patterns (one ds_read_b64 per probe) when no bucket
-      // receives more than four kept ids; two choices of bucket bits (see bucket_addr)
+      // exact index of the kept ids: 8192 buckets of four 16-bit patterns (bucket = 13 bits of dim_id, the pattern
+      // holds the other 11 and five the bucket implies -- an unused slot holds a pattern no key of its bucket can
+      // produce) when no bucket receives more than four ids; two choices of bucket bits (exact_rank_global)
       std::vector<uint32_t> keys;
       for (int t = 0; t < dim_size; t++)
         if (h_shuffled_dim[t] >= 0 && h_shuffled_dim[t] < dim_end) keys.push_back((uint32_t)t);
       if (keys.size() > (size_t)MAX_LDS_KEEP) return rtc_fail(ctx, RTC_ERR_ARG, "shuffle table is not a permutation");
-      // var 1 first: its bucket bits also serve the K = 22 variant (var 2: pattern without dim_id[0..2))
       const int order[2] = {1, 0};
       for (int oi = 0; oi < 2 && kc.bvar < 0; oi++) {
         const int var = order[oi];
         const size_t nsl = (size_t)BUCKET_BYTES / 2;
-        std::vector<uint16_t> pat(nsl), rnk(nsl, 0), pat2(nsl), rnk2(nsl, 0);
+        std::vector<uint16_t> pat(nsl), rnk(nsl, 0);
         std::vector<uint8_t> fill(8192, 0);
         for (uint32_t bk = 0; bk < 8192; bk++)  // unused slots: implied bits inverted
-          for (int sl = 0; sl < 4; sl++) {
-            pat[bk * 4 + sl] = (uint16_t)((~bk & 0x1fu) << (var ? 11 : 3));
-            pat2[bk * 4 + sl] = (uint16_t)((~bk & 0x7fu) << 9);
-          }
+          for (int sl = 0; sl < 4; sl++) pat[bk * 4 + sl] = (uint16_t)((~bk & 0x1fu) << (var ? 11 : 3));
         bool fits = true;
         for (uint32_t key : keys) {
           const uint32_t bk = var ? (key >> 11) & 0x1fffu : (key >> 3) & 0x1fffu;
@@ -1168,17 +878,13 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
           if (fill[bk] == 4) { fits = false; break; }
           pat[bk * 4 + fill[bk]] = q;
           rnk[bk * 4 + fill[bk]] = (uint16_t)h_shuffled_dim[key];
-          pat2[bk * 4 + fill[bk]] = (uint16_t)((key >> 2) & 0xffffu);
-          rnk2[bk * 4 + fill[bk]] = (uint16_t)((uint32_t)h_shuffled_dim[key] | ((key & 3u) << 12));
           fill[bk]++;
         }
         if (!fits) continue;
-        // [patterns | ranks] of the exact variant, then (var 1 only) [patterns | ranks] of variant 2
-        RTC_HIP(ctx, hipMalloc(&kc.d_bucket, (size_t)BUCKET_BYTES * 4));
+        // [patterns | ranks]
+        RTC_HIP(ctx, hipMalloc(&kc.d_bucket, (size_t)BUCKET_BYTES * 2));
         RTC_HIP(ctx, hipMemcpy(kc.d_bucket, pat.data(), BUCKET_BYTES, hipMemcpyHostToDevice));
         RTC_HIP(ctx, hipMemcpy((char*)kc.d_bucket + BUCKET_BYTES, rnk.data(), BUCKET_BYTES, hipMemcpyHostToDevice));
-        RTC_HIP(ctx, hipMemcpy((char*)kc.d_bucket + 2 * (size_t)BUCKET_BYTES, pat2.data(), BUCKET_BYTES, hipMemcpyHostToDevice));
-        RTC_HIP(ctx, hipMemcpy((char*)kc.d_bucket + 3 * (size_t)BUCKET_BYTES, rnk2.data(), BUCKET_BYTES, hipMemcpyHostToDevice));
         kc.bvar = var;
       }
       if (kc.bvar >= 0) {
@@ -1198,7 +904,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
         RTC_HIP(ctx, hipMemcpy(kc.d_bloom, bloom.data(), BLOOM_BYTES, hipMemcpyHostToDevice));
       }
     }
-    // the cuckoo / HBM structures below serve the k-mer lengths the bucket kernel does not cover
+    // the cuckoo / HBM structures below serve the k-mer lengths the prefilter kernel does not cover
     if (lds_index) {
       // two-table cuckoo placement of the kept (dim_id -> rank) pairs; smallest tables that work
       const int dimbits = 4 * half_subk;
@@ -1262,11 +968,10 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
     if (h_off[g + 1] < h_off[g]) return rtc_fail(ctx, RTC_ERR_ARG, "offsets not monotone at genome %u", g);
     total += h_off[g + 1] - h_off[g];
   }
-  // bucket kernel: dim_id of 24 bits, extended windows of 2K+8 <= 64 bits, window shifts of 1..31 bits where only
-  // high words are cut (K <= 22)
+  // prefilter kernel: dim_id of 24 bits in the middle of at most 28 bases
   const bool use_bucket = kc.bvar >= 0 && K >= 18 && K <= 28;
   uint64_t seg_len = total / ((uint64_t)ctx->num_cu * 12);
-  const uint64_t min_seg = 4ull * (use_bucket ? WGB * 27 * 4 : TILE_BASES_MAX);
+  const uint64_t min_seg = use_bucket ? (uint64_t)(WGB / 64) * CHUNK * 16 : 4ull * TILE_BASES_MAX;  // >= 16 chunks per wave
   if (seg_len < min_seg) seg_len = min_seg;
   std::vector<KSegment> segs;
   segs.reserve(n + 1024);
@@ -1296,7 +1001,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   P.m2key = (1u << (P.dimbits - P.ck2 + 1)) - 1u;
   const uint32_t* d_t2 = kc.d_index ? d_t1 + ((size_t)1 << kc.ck1) : nullptr;
   const size_t lds = lds_index ? (((size_t)1 << kc.ck1) + ((size_t)1 << kc.ck2)) * 4 : 16;
-  if (use_bucket && kc.d_bloom && !getenv("RTC_KSSD_BUCKET")) {
+  if (use_bucket && kc.d_bloom) {
     P.nofast = getenv("RTC_KSSD_NOFAST") ? atoi(getenv("RTC_KSSD_NOFAST")) : 0;
     if (getenv("RTC_VERBOSE")) fprintf(stderr, "[kssd] forward-strand prefilter, K=%d, %zu segments\n", K, segs.size());
     const uint32_t* d_bk = (const uint32_t*)kc.d_bucket;  // the exact index (variant kc.bvar) serves the drain from global memory
@@ -1314,41 +1019,6 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
       default: return rtc_fail(ctx, RTC_ERR_ARG, "K=%d", K);
     }
 #undef LAUNCH_BLOOM
-  } else if (use_bucket) {
-    P.cf0 = P.lshift - 6;
-    P.nofast = getenv("RTC_KSSD_NOFAST") ? atoi(getenv("RTC_KSSD_NOFAST")) : 0;
-    P.re = (8 - (2 * K) % 8) % 8;
-    P.cr0 = P.lshift - 2 - P.re;
-    const int nb = (2 * K + P.re) / 8;  // byte of the extended reverse window that receives the new dword
-    P.rsel = 0;
-    for (int j = 0; j < 4; j++) P.rsel |= (uint32_t)(j == nb - 4 ? 0x00 : (j < nb - 4 ? 4 + j + 1 : 0x0c)) << (8 * j);
-    const int xs_abs = P.lshift + P.dim_shift;  // bit of the top-aligned window pair where dim_id starts
-    const int xmode = xs_abs >= 32 ? (xs_abs == 32 ? 0 : 1) : 2;
-    P.xs = xs_abs >= 32 ? xs_abs - 32 : xs_abs;
-    // K = 22 (xs_abs == 30) with the var-1 buckets: the 22-bit test on the high word (XMODE 3, table variant 2)
-    const bool approx = xs_abs == 30 && kc.bvar == 1 && !getenv("RTC_KSSD_EXACT_FILTER");
-    if (getenv("RTC_VERBOSE")) fprintf(stderr, "[kssd] bucket index (bits %d, %s), K=%d, %zu segments\n", kc.bvar, approx ? "22-bit steady test" : "exact steady test", K, segs.size());
-    const size_t tb = approx ? 2 * (size_t)BUCKET_BYTES : 0;
-    const uint32_t* d_bk = (const uint32_t*)((const char*)kc.d_bucket + tb);
-    const uint16_t* d_rk = (const uint16_t*)((const char*)kc.d_bucket + tb + BUCKET_BYTES);
-    const int lds_bk = BUCKET_BYTES + KQ_BYTES;
-#define LAUNCH_BK(RUN, WARM, XM, VR)                                                                                  \
-  do {                                                                                                               \
-    auto kern = sketch_kssd_bucket_kernel<RUN, WARM, XM, VR>;                                                        \
-    RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bk));        \
-    hipLaunchKernelGGL(kern, dim3((uint32_t)segs.size()), dim3(WGB), lds_bk, ctx->stream, d_seq,                      \
-                       (const KSegment*)ws0, P, d_bk, d_rk, d_out, stride, d_cnt);                                   \
-  } while (0)
-#define LAUNCH_BKV(RUN, WARM, XM) do { if (kc.bvar) LAUNCH_BK(RUN, WARM, XM, 1); else LAUNCH_BK(RUN, WARM, XM, 0); } while (0)
-    // lane runs: 104 owned + 24 warm-up bases (K <= 25; measured best of 72 / 88 / 104 / 120: the warm-up is
-    // 6 of 32 dwords instead of 6 of 24 and the kernel is not bandwidth bound), 76 + 36 otherwise
-    if (K > 25) LAUNCH_BKV(19, 9, 2);  // K >= 22 always straddles the two words
-    else if (approx) LAUNCH_BK(26, 6, 3, 2);
-    else if (xmode == 0) LAUNCH_BKV(26, 6, 0);
-    else if (xmode == 1) LAUNCH_BKV(26, 6, 1);
-    else LAUNCH_BKV(26, 6, 2);
-#undef LAUNCH_BKV
-#undef LAUNCH_BK
   } else {
 #define LAUNCH_KSSD2(IX, RUN, WARM)                                                                                   \
   do {                                                                                                               \
