@@ -30,10 +30,7 @@
 
 namespace {
 
-#ifndef RTC_PAIR_TW
-#define RTC_PAIR_TW 1024
-#endif
-constexpr int TW = RTC_PAIR_TW;         // lanes per workgroup = columns per block (1024 or 512)
+constexpr int TW = 1024;                // lanes per workgroup = columns per block (512: two per CU, measured 60 % slower)
 constexpr int ROWS = 64;                // rows per block = mask width
 constexpr int SLOTS = 8 * TW;           // table slots
 constexpr int BUCKET = 4;               // keys per bucket
@@ -44,6 +41,7 @@ constexpr uint32_t KTARGET = SLOTS / 4;          // planned mean keys per table 
 constexpr int RPW = ROWS / (TW / 64);   // rows a wave builds at once
 constexpr int LPR = 64 / RPW;           // lanes per row in the build
 constexpr int MAXP = 512;
+constexpr int DEPTH = 2;                // trips (of four keys) of a column's slice requested ahead of the probes (3 and 4 measured slower)
 
 template <typename T> struct KeyTraits;
 template <> struct KeyTraits<uint64_t> {
@@ -193,11 +191,11 @@ __global__ __launch_bounds__(TW, TW == 1024 ? 1 : 2) void pair_tiled_kernel(cons
   for (int p = 0; p < P; p++) {
     const uint32_t chi = chi_n;
     const T* tp = tcols + tbase[p] + (c - tc0);
-    T nq[4], nq2[4];  // rows past the slice's end hold other data (the copy is padded by eight rows): masked by `rem`
+    T nq[DEPTH][4];  // rows past the slice's end hold other data (the copy is padded by 4 * DEPTH rows): masked by `rem`
 #pragma unroll
-    for (int j = 0; j < 4; j++) nq[j] = col_active ? tp[(size_t)j * tnc] : (T)0;
+    for (int d = 0; d < DEPTH; d++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) nq2[j] = col_active ? tp[(size_t)(4 + j) * tnc] : (T)0;
+      for (int j = 0; j < 4; j++) nq[d][j] = col_active ? tp[(size_t)(4 * d + j) * tnc] : (T)0;
     if (p + 1 < P) chi_n = col_active ? so[(size_t)(p + 2) * n + c] : 0;
     __syncthreads();  // previous partition's probes are done (table and rlo/rhi reusable)
     if (tid < ROWS) { sh->rlo[tid] = rlo_n; sh->rhi[tid] = rhi_n; }
@@ -259,16 +257,20 @@ __global__ __launch_bounds__(TW, TW == 1024 ? 1 : 2) void pair_tiled_kernel(cons
         const uint32_t mylen = chi - clo;
         if (sb > 0) {
 #pragma unroll
-          for (int j = 0; j < 4; j++) nq[j] = col_active ? tp[(size_t)j * tnc] : (T)0;
+          for (int d = 0; d < DEPTH; d++)
 #pragma unroll
-          for (int j = 0; j < 4; j++) nq2[j] = col_active ? tp[(size_t)(4 + j) * tnc] : (T)0;
+            for (int j = 0; j < 4; j++) nq[d][j] = col_active ? tp[(size_t)(4 * d + j) * tnc] : (T)0;
         }
         for (uint32_t e = 0; e < mylen; e += 4) {
-          T bq[4];  // two trips of keys are in flight: the walk is short, the memory far
+          T bq[4];  // DEPTH trips of keys are in flight: the walk is short, the memory far
 #pragma unroll
-          for (int j = 0; j < 4; j++) { bq[j] = nq[j]; nq[j] = nq2[j]; }
+          for (int j = 0; j < 4; j++) {
+            bq[j] = nq[0][j];
 #pragma unroll
-          for (int j = 0; j < 4; j++) nq2[j] = (e + 8 + j < mylen) ? tp[(size_t)(e + 8 + j) * tnc] : (T)0;
+            for (int d = 0; d + 1 < DEPTH; d++) nq[d][j] = nq[d + 1][j];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) nq[DEPTH - 1][j] = (e + 4 * DEPTH + j < mylen) ? tp[(size_t)(e + 4 * DEPTH + j) * tnc] : (T)0;
           // Fingerprint words of the four home buckets, read back to back; per key four 16-bit compares and
           // the overflow bit, all as wave masks.  A lane whose fingerprint matches (its key may be in the
           // home bucket) or whose bucket overflowed (it may sit further on) takes the looping lookup on the
@@ -595,7 +597,7 @@ int build_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
     void* ws4 = nullptr;
     const size_t btb = (size_t)P * 8;
     {
-      const int st = rtc_ws(ctx, 4, (tbase[P] + 8ull * tnc) * sizeof(T) + btb + 256, &ws4);  // + eight rows: unconditional first probe loads
+      const int st = rtc_ws(ctx, 4, (tbase[P] + 4ull * DEPTH * tnc) * sizeof(T) + btb + 256, &ws4);  // + 4 * DEPTH rows: unconditional first probe loads
       if (st == RTC_ERR_NOMEM) return RTC_OK;  // the merge kernel needs no scratch
       if (st != RTC_OK) return st;
     }
