@@ -220,6 +220,17 @@ int rtc_mst_dense(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t*
                   uint32_t n, uint32_t start_index, int kmer_size, int is_containment, double threshold,
                   rtc_edge* h_edges_out, uint64_t* h_n_edges, int dense_span, int32_t* h_dense, uint64_t* h_ani);
 
+/* The dense loop modifyMST (src/MST.cpp:809-1018; reached when the index path is switched off, src/sub_command.cpp:2764,
+ * :2995, :1680): EVERY pair i < j with j >= start_index is an edge -- no filters -- weighted by MinHash::distance()
+ * (the union-truncated estimator of rtc_pair_mash_dev with `sketch_size`; is_containment != 0: containDistance(),
+ * -ln(|A n B| / min(|A|, |B|)) / k) and the minimum spanning TREE over them is returned (pairs without a common hash
+ * weigh 1), records {i, j, dist} with i < j as modifyMST builds them.  dense_span / h_dense / h_ani as rtc_mst_dense
+ * (here every pair is counted, :868-879).  The estimator restates the published Mash algorithm: parity-unpinned like
+ * the k-mer hash (RabbitSketch is absent from the reference tree). */
+int rtc_mst_mash(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start, const uint32_t* d_len,
+                 uint32_t n, uint32_t start_index, int kmer_size, int is_containment, uint32_t sketch_size,
+                 rtc_edge* h_edges_out, uint64_t* h_n_edges, int dense_span, int32_t* h_dense, uint64_t* h_ani);
+
 /* ---- multi-GPU: RCCL collectives over xGMI and the sharded clust-mst step ----------------- */
 /* The reference is one shared-memory process (OpenMP over 8-row blocks of the pair space,
  * src/MST.cpp:1382, and over files, src/SketchInfo.cpp:878).  Here one rtc_comm per rtc_ctx (= per
@@ -287,6 +298,15 @@ int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_
                const uint32_t* d_len, uint32_t n, const uint32_t* h_size_cfg, int kmer_size,
                int is_containment, int is_kssd, double threshold, int32_t* h_rep_of,
                uint32_t* h_n_clusters);
+
+/* greedyCluster (src/greedy.cpp:285-351), the legacy loop without index and filters: every genome is measured
+ * against every current representative with MinHash::distance() (Mash's union-truncated estimator over
+ * `sketch_size`) or, for containment sketches, containDistance(); it joins the nearest one within the threshold
+ * (earliest of equals) or opens a cluster.  Reached with the index path switched off and by `clust-greedy --append`
+ * on MinHash sketches without a stored state (src/sub_command.cpp:91).  Estimator: parity-unpinned (RabbitSketch). */
+int rtc_greedy_mash(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start, const uint32_t* d_len,
+                    uint32_t n, int kmer_size, int is_containment, uint32_t sketch_size, double threshold,
+                    int32_t* h_rep_of, uint32_t* h_n_clusters);
 
 #ifdef __cplusplus
 }

@@ -98,6 +98,8 @@ SIGNATURES = {
     "rtc_mst": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64)]),
     "rtc_mst_append": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64)]),
     "rtc_mst_dense": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64), _i, _vp, _vp]),
+    "rtc_greedy_mash": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _i, _i, _u32, C.c_double, _vp, C.POINTER(_u32)]),
+    "rtc_mst_mash": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _i, _i, _u32, _vp, C.POINTER(_u64), _i, _vp, _vp]),
     "rtc_greedy": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _vp, _i, _i, _i, C.c_double, _vp,
                         C.POINTER(_u32)]),
 }

@@ -288,6 +288,28 @@ class Context:
                                             C.byref(stats)))
         return out[:m.value].copy(), stats
 
+    def mst_mash(self, sk, sketch_size, is_containment=False, start_index=0, span=0):
+        """modifyMST (the dense loop): spanning tree over EVERY pair, Mash-estimator / containDistance weights.
+        Returns edge.mst records {i < j}; with span > 0 also (dense[span, n], ani[101])."""
+        n = sk.n
+        out = np.zeros(max(n, 1), dtype=EDGE_DT)
+        dense = np.zeros((max(span, 1), max(n, 1)), dtype=np.int32)
+        ani = np.zeros(101, dtype=np.uint64)
+        m = C.c_uint64()
+        self.check(self.lib.rtc_mst_mash(self.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start), _t_ptr(sk.len), n,
+                                         int(start_index), sk.k, int(is_containment), int(sketch_size), _np_ptr(out),
+                                         C.byref(m), int(span), _np_ptr(dense) if span else None, _np_ptr(ani) if span else None))
+        return (out[:m.value].copy(), dense[:, :n], ani) if span else out[:m.value].copy()
+
+    def greedy_mash(self, sk, threshold, sketch_size, is_containment=False):
+        """greedyCluster (legacy loop, every representative, Mash estimator): (n_clusters, rep_of)."""
+        n = sk.n
+        rep = np.zeros(max(n, 1), dtype=np.int32)
+        nc = C.c_uint32()
+        self.check(self.lib.rtc_greedy_mash(self.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start), _t_ptr(sk.len), n, sk.k,
+                                            int(is_containment), int(sketch_size), float(threshold), _np_ptr(rep), C.byref(nc)))
+        return int(nc.value), rep[:n].copy()
+
     def greedy(self, sk, threshold, size_cfg=None, is_containment=False):
         n = sk.n
         rep = np.zeros(max(n, 1), dtype=np.int32)

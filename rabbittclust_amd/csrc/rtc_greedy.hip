@@ -249,3 +249,64 @@ extern "C" int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const u
   *h_n_clusters = (uint32_t)reps.size();
   return RTC_OK;
 }
+
+// greedyCluster (src/greedy.cpp:285-351): the legacy greedy loop that measures every genome against EVERY current
+// representative with MinHash::distance() / containDistance() -- no index, no filters.  It is what clust-greedy
+// runs when the index path is switched off and what `clust-greedy --append` runs on MinHash sketches without a
+// stored state (src/sub_command.cpp:91).  Row blocks of the dense estimator matrix come from the GPU
+// (rtc_pair_mash_dev: Mash's union-truncated counts; containment: full intersections), the serial
+// decisions are replayed on the host: a genome joins the representative at the smallest distance <= threshold
+// (the reference keeps the candidates in a map<double, int>: the smallest distance wins, of equal ones the first
+// inserted, i.e. the earliest representative at -t 1), otherwise it becomes a representative.
+extern "C" int rtc_greedy_mash(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
+                               const uint32_t* d_len, uint32_t n, int kmer_size, int is_containment,
+                               uint32_t sketch_size, double threshold, int32_t* h_rep_of, uint32_t* h_n_clusters) {
+  if (!ctx || !h_rep_of || !h_n_clusters || (n && (!d_start || !d_len))) return RTC_ERR_ARG;
+  if (!is_containment && sketch_size == 0) return rtc_fail(ctx, RTC_ERR_ARG, "sketch_size 0");
+  *h_n_clusters = 0;
+  if (n == 0) return RTC_OK;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<uint32_t> len(n);
+  RTC_HIP(ctx, hipMemcpyAsync(len.data(), d_len, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(n, 262140), ((uint64_t)1 << 24) / n));
+  void* ws = nullptr;
+  RTC_TRY(rtc_ws(ctx, 2, (size_t)B * n * 8 + 64, &ws));
+  uint32_t* d_common = (uint32_t*)ws;
+  uint32_t* d_denom = d_common + (size_t)B * n;
+  std::vector<uint32_t> common((size_t)B * n), denom(is_containment ? 0 : (size_t)B * n);
+  h_rep_of[0] = 0;  // :293-294
+  uint32_t ncl = 1;
+  for (uint32_t r0 = 1; r0 < n; r0 += B) {
+    const uint32_t r1 = std::min(n, r0 + B);
+    if (is_containment) RTC_TRY(rtc_pair_common_dev(ctx, d_hashes, width, d_start, d_len, n, r0, r1, 0, r1 - 1, d_common, n, 1, 0));
+    else RTC_TRY(rtc_pair_mash_dev(ctx, d_hashes, width, d_start, d_len, n, sketch_size, r0, r1, 0, r1 - 1, d_common, d_denom, n));
+    RTC_HIP(ctx, hipMemcpyAsync(common.data(), d_common, (size_t)(r1 - r0) * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (!is_containment) RTC_HIP(ctx, hipMemcpyAsync(denom.data(), d_denom, (size_t)(r1 - r0) * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t q = r0; q < r1; q++) {
+      const uint32_t* crow = common.data() + (size_t)(q - r0) * n;
+      const uint32_t* drow = is_containment ? nullptr : denom.data() + (size_t)(q - r0) * n;
+      double best = std::numeric_limits<double>::max();
+      int32_t best_rep = -1;
+      for (uint32_t c = 0; c < q; c++) {
+        if (h_rep_of[c] != (int32_t)c) continue;  // representatives only
+        double dist;
+        if (is_containment) {  // MinHash::containDistance(): -ln(|A n B| / min(|A|, |B|)) / k
+          const uint32_t mn = std::min(len[q], len[c]);
+          const double cj = mn ? (double)crow[c] / mn : 0.0;
+          dist = cj == 0.0 ? 1.0 : (cj == 1.0 ? 0.0 : -(1.0 / kmer_size) * log(cj));  // the in-tree operation order (src/MST.cpp:1295,1515)
+        } else {               // MinHash::distance(): Mash
+          const double j = drow[c] ? (double)crow[c] / drow[c] : 0.0;
+          dist = j == 0.0 ? 1.0 : (j == 1.0 ? 0.0 : -log(2.0 * j / (1.0 + j)) / kmer_size);
+          if (dist > 1.0) dist = 1.0;
+        }
+        if (dist <= threshold && dist < best) { best = dist; best_rep = (int32_t)c; }  // :319-326, :334-336
+      }
+      if (best_rep >= 0) h_rep_of[q] = best_rep;
+      else { h_rep_of[q] = (int32_t)q; ncl++; }
+    }
+  }
+  *h_n_clusters = ncl;
+  return RTC_OK;
+}

@@ -30,10 +30,21 @@ namespace {
 
 constexpr uint64_t KEY_NONE = 0x7FFFFFFFFFFFFFFFULL;  // above every key (fused keys use 63 bits, edge ids need n < 2^31); also a valid int64
 
+// Weight modes (the `is_containment` argument of the entry points): 0 = set Jaccard common / |A u B| (the index
+// path, src/MST.cpp:1489-1503), 1 = containment common / min(|A|, |B|) (:1504-1515, and containDistance() of the
+// dense loop), 2 | s << 2 = Mash's union-truncated estimator of the dense loop (MinHash::jaccard(), modifyMST
+// src/MST.cpp:851-866): common among the first s union elements over  min(s, |A| + |B| - common)  -- the union
+// elements Mash's merge has seen when it stops (s, or all of them when both lists run out first).
+__host__ __device__ __forceinline__ uint64_t weight_denom(uint32_t common, uint32_t sa, uint32_t sb, int wmode) {
+  if ((wmode & 3) == 1) return sa < sb ? sa : sb;
+  const uint64_t u = (uint64_t)sa + sb - common;
+  if ((wmode & 3) == 2) { const uint64_t s = (uint32_t)wmode >> 2; return u < s ? u : s; }
+  return u;
+}
 // similarity key: smaller key == more similar == smaller distance
-__device__ __forceinline__ uint64_t weight_key(uint32_t common, uint32_t sa, uint32_t sb, int is_containment) {
-  double denom = is_containment ? (double)(sa < sb ? sa : sb) : (double)((uint64_t)sa + sb - common);
-  double J = (double)common / denom;  // in (0,1]; IEEE division, correctly rounded
+__device__ __forceinline__ uint64_t weight_key(uint32_t common, uint32_t sa, uint32_t sb, int wmode) {
+  const uint64_t d = weight_denom(common, sa, sb, wmode);
+  const double J = d ? (double)common / (double)d : 0.0;  // in [0,1]; IEEE division, correctly rounded
   return 0x4000000000000000ULL - (uint64_t)__double_as_longlong(J);
 }
 
@@ -237,10 +248,19 @@ struct HostUF {
 
 }  // namespace
 
-// src/MST.cpp:1295,1489-1515 with the reference's operation order (host libm log)
-static double host_mst_distance(int common, int size0, int size1, int kmer_size, int is_containment) {
+// src/MST.cpp:1295,1489-1515 with the reference's operation order (host libm log); mode 2: Mash's
+// MinHash::distance() (-ln(2j/(1+j))/k, 1 when j = 0, never above 1)
+static double host_mst_distance(int common, int size0, int size1, int kmer_size, int wmode) {
   const double inv_kmer_size = 1.0 / kmer_size;
-  if (!is_containment) {
+  if ((wmode & 3) == 2) {
+    const uint64_t d = weight_denom((uint32_t)common, (uint32_t)size0, (uint32_t)size1, wmode);
+    const double j = d ? (double)common / (double)d : 0.0;
+    if (j == 0.0) return 1.0;
+    if (j == 1.0) return 0.0;
+    const double dist = -log(2.0 * j / (1.0 + j)) / kmer_size;
+    return dist > 1.0 ? 1.0 : dist;
+  }
+  if (!wmode) {
     int denom = size0 + size1 - common;
     double jaccard = denom == 0 ? 0.0 : (double)common / denom;
     if (jaccard == 1.0) return 0.0;
@@ -407,6 +427,20 @@ uint32_t rtc_fixed_size_of(const uint32_t* h_len, uint32_t n) {
   for (uint32_t i = 1; i < n; i++) if (h_len[i] != h_len[0]) return 0;
   return rtc_boruvka_key_bits(n, h_len[0]) ? h_len[0] : 0;
 }
+
+namespace {
+// every pair (row, col < row) of a dense tile becomes an edge (the dense loop has no filters): edge of (row, col) at
+// base + row (row - 1) / 2 - row0 (row0 - 1) / 2 + col
+__global__ __launch_bounds__(256) void all_pairs_edges_kernel(const uint32_t* __restrict__ common, uint64_t ld, uint32_t row0,
+                                                              uint32_t row1, rtc_cedge* __restrict__ edges) {
+  const uint64_t first = (uint64_t)row0 * (row0 - (row0 ? 1 : 0)) / 2;
+  for (uint32_t row = row0 + blockIdx.y; row < row1; row += gridDim.y) {
+    const uint64_t o = (uint64_t)row * (row - (row ? 1 : 0)) / 2 - first;
+    for (uint32_t col = blockIdx.x * blockDim.x + threadIdx.x; col < row; col += gridDim.x * blockDim.x)
+      edges[o + col] = rtc_cedge{row, col, common[(uint64_t)(row - row0) * ld + col]};
+  }
+}
+}  // namespace
 
 extern "C" {
 
@@ -679,6 +713,98 @@ int rtc_mst_dense(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t*
   if (verbose)
     fprintf(stderr, "[mst]   %u sketches: %llu candidate edges in %.4fs, forest (%d rounds, %llu edges) in %.4fs, finish %.4fs\n", n,
             (unsigned long long)m_edges, tv1 - tv0, rounds, (unsigned long long)nsel, tv2 - tv1, now() - tv2);
+  return RTC_OK;
+}
+
+// modifyMST (src/MST.cpp:809-1018): the dense loop.  EVERY pair i < j with j >= start_index is an edge -- no
+// "shares a hash" / size-ratio filters -- weighted by MinHash::distance() (Mash's union-truncated estimator) or, for
+// containment sketches, containDistance(); the result is a spanning TREE (pairs without a common hash weigh 1).
+// Rows are evaluated in chunks into a dense count matrix (rtc_pair_mash_dev / rtc_pair_common_dev), every pair of the
+// chunk is appended to the edge list, and the list is contracted to its own forest whenever the next chunk would
+// not fit (the reference does the same per 8-row block: sort + kruskalAlgorithm, :905-908).
+int rtc_mst_mash(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start, const uint32_t* d_len, uint32_t n,
+                 uint32_t start_index, int kmer_size, int is_containment, uint32_t sketch_size, rtc_edge* h_edges_out,
+                 uint64_t* h_n_edges, int dense_span, int32_t* h_dense, uint64_t* h_ani) {
+  if (!ctx || !h_n_edges || (n && (!d_start || !d_len || !h_edges_out))) return RTC_ERR_ARG;
+  if (dense_span < 0 || (dense_span > 0 && (!h_dense || !h_ani))) return RTC_ERR_ARG;
+  if (!is_containment && (sketch_size == 0 || sketch_size >= (1u << 29))) return rtc_fail(ctx, RTC_ERR_ARG, "sketch_size %u", sketch_size);
+  *h_n_edges = 0;
+  if (dense_span) { memset(h_dense, 0, (size_t)dense_span * n * sizeof(int32_t)); memset(h_ani, 0, 101 * sizeof(uint64_t)); }
+  if (n < 2 || start_index >= n) return RTC_OK;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  const int wmode = is_containment ? 1 : (2 | (int)(sketch_size << 2));
+  std::vector<uint32_t> h_len(n);
+  RTC_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t s_fixed = rtc_fixed_size_of(h_len.data(), n);  // equal sizes: the weight is monotone in `common` in every mode
+
+  uint64_t budget = (uint64_t)256 << 20;
+  if (const char* e = getenv("RTC_EDGE_BUDGET")) budget = std::max<uint64_t>(strtoull(e, nullptr, 10), 1024);
+  const uint32_t rbeg = std::max<uint32_t>(start_index, 1);
+  uint32_t rows_per = (uint32_t)std::min<uint64_t>(262140, std::max<uint64_t>(4, (((uint64_t)1 << 26) / n)));
+  rows_per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(rows_per, std::max<uint64_t>(budget / 2 / n, 1)));
+  auto pairs_below = [](uint64_t r) { return r * (r - (r ? 1 : 0)) / 2; };
+  const uint64_t total = pairs_below(n) - pairs_below(rbeg);
+  const uint64_t cap = std::min<uint64_t>(total, std::max<uint64_t>(budget, (uint64_t)n + (uint64_t)rows_per * n));
+  uint32_t *d_common = nullptr, *d_denom = nullptr;
+  void* ws2 = nullptr;
+  RTC_TRY(rtc_ws(ctx, 2, (size_t)rows_per * n * 4 * (is_containment ? 1 : 2) + 64, &ws2));
+  d_common = (uint32_t*)ws2;
+  d_denom = d_common + (size_t)rows_per * n;
+  rtc_cedge *d_edges = nullptr, *d_sel = nullptr;
+  if (hipMalloc((void**)&d_edges, cap * sizeof(rtc_cedge)) != hipSuccess) return rtc_fail(ctx, RTC_ERR_NOMEM, "edge list of %llu pairs", (unsigned long long)cap);
+  if (hipMalloc((void**)&d_sel, (size_t)n * sizeof(rtc_cedge)) != hipSuccess) { (void)hipFree(d_edges); return rtc_fail(ctx, RTC_ERR_NOMEM, "hipMalloc forest list"); }
+
+  DenseAcc acc{ctx, h_len.data(), n, kmer_size, wmode, dense_span, 0, h_dense, h_ani, {}, {}, {}, {}};
+  if (dense_span) {
+    const double step = 1.0 / dense_span;                              // :819-823
+    for (int i = 0; i < dense_span; i++) acc.radius.push_back(step * (double)i);
+  }
+  int st = RTC_OK;
+  uint64_t m = 0, nsel = 0;
+  for (uint32_t r0 = rbeg; r0 < n && st == RTC_OK; r0 += rows_per) {
+    const uint32_t r1 = std::min<uint32_t>(n, r0 + rows_per);
+    const uint64_t chunk = pairs_below(r1) - pairs_below(r0);
+    if (is_containment) st = rtc_pair_common_dev(ctx, d_hashes, width, d_start, d_len, n, r0, r1, 0, r1 - 1, d_common, n, 1, 0);
+    else st = rtc_pair_mash_dev(ctx, d_hashes, width, d_start, d_len, n, sketch_size, r0, r1, 0, r1 - 1, d_common, d_denom, n);
+    if (st != RTC_OK) break;
+    if (m + chunk > cap) {  // contract what is there to its forest (at most n - 1 edges)
+      st = rtc_msf_device(ctx, d_edges, m, d_len, n, wmode, s_fixed, nullptr, d_sel, &nsel, nullptr);
+      if (st != RTC_OK) break;
+      if (hipMemcpyAsync(d_edges, d_sel, nsel * sizeof(rtc_cedge), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { st = rtc_fail(ctx, RTC_ERR_HIP, "forest copy"); break; }
+      m = nsel;
+    }
+    hipLaunchKernelGGL(all_pairs_edges_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>((r1 + 255) / 256, 64)), std::min<uint32_t>(r1 - r0, 4096)),
+                       dim3(256), 0, ctx->stream, d_common, (uint64_t)n, r0, r1, d_edges + m);
+    if (hipGetLastError() != hipSuccess) { st = rtc_fail(ctx, RTC_ERR_HIP, "all_pairs_edges_kernel launch"); break; }
+    if (dense_span) { st = DenseAcc::on_new(&acc, d_edges + m, chunk); if (st != RTC_OK) break; }
+    m += chunk;
+  }
+  if (st == RTC_OK && dense_span) {  // start-bucket counts -> cumulative density counts (:985-994)
+    for (uint32_t g = 0; g < n; g++) {
+      int32_t a = 0;
+      for (int t = 0; t < dense_span; t++) { a += h_dense[(size_t)t * n + g]; h_dense[(size_t)t * n + g] = a; }
+    }
+  }
+  std::vector<rtc_cedge> sel;
+  if (st == RTC_OK) st = rtc_msf_device(ctx, d_edges, m, d_len, n, wmode, s_fixed, nullptr, d_sel, &nsel, nullptr);
+  if (st == RTC_OK && nsel) {
+    sel.resize(nsel);
+    hipError_t e = hipMemcpyAsync(sel.data(), d_sel, nsel * sizeof(rtc_cedge), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) st = rtc_fail(ctx, RTC_ERR_HIP, "forest read-back -> %s", hipGetErrorString(e));
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_edges); (void)hipFree(d_sel);
+  if (st != RTC_OK) return st;
+  RTC_TRY(rtc_edges_to_mst_host(sel.data(), nsel, h_len.data(), kmer_size, wmode, h_edges_out));
+  for (uint64_t e = 0; e < nsel; e++) std::swap(h_edges_out[e].preNode, h_edges_out[e].sufNode);  // EdgeInfo{i, j}, i < j (:891)
+  std::sort(h_edges_out, h_edges_out + nsel, [](const rtc_edge& a, const rtc_edge& b) {
+    if (a.dist != b.dist) return a.dist < b.dist;
+    if (a.preNode != b.preNode) return a.preNode < b.preNode;
+    return a.sufNode < b.sufNode;
+  });
+  *h_n_edges = nsel;
   return RTC_OK;
 }
 

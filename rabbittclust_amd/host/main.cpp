@@ -12,9 +12,10 @@
 // to write hash.sketch), are shared among the GPUs with RCCL broadcasts, and the MST runs
 // row-sharded with one all-reduce per Boruvka round (rtc_mst_sharded).  Also here: --append (clust-mst, and
 // clust-greedy --fast with or without a stored state), --dense, the tree / linkage writers, clust-greedy's
-// --save-rep cluster state (--fast) and representative database (--db ..., KSSD and MinHash).  clust-mst's
-// --db / --save-rep, the MinHash cluster state, --auto-threshold and its companions and single-FASTA input to
-// --append / --db are outside this path and exit with a message.
+// --save-rep cluster state (KSSD and MinHash) and representative database (--db ..., KSSD and MinHash), clust-greedy
+// --append on MinHash sketches, and the dense estimator loops (--inverted-index=false: modifyMST / greedyCluster).
+// clust-mst's --db / --save-rep, --auto-threshold and its companions and single-FASTA input to --append / --db are
+// outside this path and exit with a message.
 #include <math.h>
 #include <iomanip>
 #include <limits>
@@ -637,6 +638,7 @@ struct Options {
   double threshold = 0.05;
   int kmerSize = 19, sketchSize = 1000, containCompress = 1000, drlevel = 3;
   uint64_t minLen = 10000;
+  bool useIndex = true;  // --inverted-index=false: the dense estimator loops (modifyMST / greedyCluster) instead of the index path
   string gpus;  // --gpus / RTC_GPUS: "all" (default), a count, or a comma list of device ordinals
 };
 
@@ -681,7 +683,11 @@ static Options parse(int argc, char** argv) {
     else if (a == "--nexus-tree") o.nexus = true;
     else if (a == "--linkage-matrix") o.linkage = true;
 #endif
-    else if (a == "--inverted-index") { /* always on, as in the reference (src/main.cpp:104,129) */ }
+    else if (a == "--inverted-index") { /* on by default, as in the reference (src/main.cpp:104,129) */ }
+    else if (a.rfind("--inverted-index=", 0) == 0) {  // the flag's CLI11 form with a value: =false / =0 switches the index path off
+      const string v = a.substr(17);
+      o.useIndex = !(v == "false" || v == "0" || v == "off" || v == "no");
+    }
 #ifndef GREEDY_CLUST
     else if (a == "--premsted") { o.folder_path = need(i); o.has_premsted = true; }
 #endif
@@ -693,11 +699,12 @@ static Options parse(int argc, char** argv) {
 #endif
       puts("  -t,--threads N  -m,--min-length N  -c,--containment N  -k,--kmer-size N  -s,--sketch-size N\n"
            "  -l,--list  -e,--no-save  -d,--threshold X  -o,--output FILE  -i,--input FILE\n"
-           "  --presketched DIR  --fast  --drlevel N  --gpus all|N|i,j,.. (default all visible MI355X)"
+           "  --presketched DIR  --fast  --drlevel N  --gpus all|N|i,j,.. (default all visible MI355X)\n"
+           "  --inverted-index=false (MinHash: the dense loops modifyMST / greedyCluster with MinHash::distance())"
 #ifndef GREEDY_CLUST
            "  --premsted DIR  --append LIST (with --presketched/--premsted DIR)"
 #else
-           "  --append LIST (with --fast --presketched DIR)  --save-rep (with --fast: cluster_state.bin)\n"
+           "  --append LIST (with --presketched DIR)  --save-rep (cluster_state.bin beside the sketches)\n"
            "  [--fast] --db FILE --build|--query|--assign|--append LIST|--stats [--top-k N] (representative database)"
 #endif
       );
@@ -822,8 +829,12 @@ static int append_clust_mst(const Options& o, vector<Gpu>& gpus) {
   vector<rtc_edge> append_mst(genomes.size());
   uint64_t ne = 0;
   cerr << "---the start_index is: " << n_pre << endl;
-  CHECK(ctx, rtc_mst_append(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, (uint32_t)n_pre, kmer_size, is_containment, o.threshold,
-                            append_mst.data(), &ne));
+  if (!o.useIndex && !o.is_fast)  // the fallback of append_clust_mst (src/sub_command.cpp:1680): modifyMST from start_index
+    CHECK(ctx, rtc_mst_mash(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, (uint32_t)n_pre, kmer_size, is_containment, (uint32_t)mh.sketchSize,
+                            append_mst.data(), &ne, 0, nullptr, nullptr));
+  else
+    CHECK(ctx, rtc_mst_append(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, (uint32_t)n_pre, kmer_size, is_containment, o.threshold,
+                              append_mst.data(), &ne));
   append_mst.resize(ne);
   cerr << "========time of generateMST is: " << get_sec() - t2 << "========" << endl;
   vector<rtc_edge> final_graph(pre_mst);
@@ -1331,6 +1342,113 @@ static int repdb_append(const Options& o, vector<Gpu>& gpus) {
        << "  RepDB updated:    " << o.repdb_path << endl << "==========================" << endl;
   return 0;
 }
+// append_clust_greedy (src/sub_command.cpp:23-190): `clust-greedy --append LIST --presketched DIR` on MinHash sketches.
+// Without a stored state the old and the new sketches are put together, sorted by genome size (cmpGenomeSize) and
+// clustered by the legacy greedyCluster -- every representative, MinHash::distance() (rtc_greedy_mash).  With a
+// cluster_state.bin the representatives are taken from the folder's sketches by the stored ids (the reference
+// re-reads the folder, :100-139) and the new genomes go through MinHashIncrementalCluster.
+static int append_clust_greedy(const Options& o, vector<Gpu>& gpus) {
+  rtc_ctx* ctx = gpus[0].ctx;
+  const string state_file = o.folder_path + "/cluster_state.bin";
+  if (!o.sketchByFile) unsupported("single-FASTA input (run with -l and a genome list)");
+  KssdClusterState st;
+  struct stat sb;
+  bool has_state = stat(state_file.c_str(), &sb) == 0;
+  if (has_state) {
+    cerr << "===== Incremental Update Mode (MinHash) =====" << endl << "Found existing cluster state, loading..." << endl;
+    has_state = load_minhash_cluster_state(state_file, st);
+  }
+  vector<GenomeInfo> pre; MinHashSketchFile mh; bool byFile = true;
+  if (!load_minhash_sketches(o.folder_path, pre, mh, byFile)) return 1;
+  auto sketch_new = [&](int kmer, int sketch_size, bool containment, vector<GenomeInfo>& add, MinHashSketchFile& mh2) {
+    SketchJob job;
+    job.kssd = false; job.kmerSize = kmer; job.sketchSize = sketch_size; job.isContainment = containment;
+    job.containCompress = mh.containCompress; job.minLen = o.minLen; job.threads = o.threads;
+    KssdSketchFile unused; Resident rs2;
+    sketch_files(gpus, o.inputFile, job, add, &mh2, &unused, rs2, true);
+  };
+  if (!has_state) {
+    if (byFile != o.sketchByFile) {
+      cerr << "ERROR: append_clust_greedy(), the input format of append genomes and pre-sketched genome is not same (single input genome vs. genome list)" << endl;
+      return 1;
+    }
+    cerr << "-----use the same sketch parameters with pre-generated sketches" << endl << "---the kmer size is: " << mh.kmerSize << endl;
+    if (mh.isContainment) cerr << "---use the AAF distance (variable-sketch-size), the sketch size is in proportion with 1/" << mh.containCompress << endl;
+    else cerr << "---use the Mash distance (fixed-sketch-size), the sketch size is: " << mh.sketchSize << endl;
+    cerr << "---the thread number is: " << o.threads << endl << "---the threshold is: " << o.threshold << endl;
+    vector<GenomeInfo> add; MinHashSketchFile mh2;
+    sketch_new(mh.kmerSize, mh.sketchSize, mh.isContainment, add, mh2);
+    cerr << "-----the size of sketches (number of genomes or sequences) is: " << add.size() << endl;
+    // final_sketches = pre + append, sorted by genome size (length descending, id ascending; ids restart in the appended part)
+    vector<GenomeInfo> all(pre);
+    all.insert(all.end(), add.begin(), add.end());
+    vector<size_t> perm(all.size());
+    iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) {
+      if (all[a].totalSeqLength != all[b].totalSeqLength) return all[a].totalSeqLength > all[b].totalSeqLength;
+      return all[a].id < all[b].id;
+    });
+    vector<GenomeInfo> genomes; MinHashSketchFile fin = mh; fin.hashes.clear();
+    for (size_t q : perm) {
+      genomes.push_back(all[q]);
+      fin.hashes.push_back(q < pre.size() ? mh.hashes[q] : mh2.hashes[q - pre.size()]);
+    }
+    if (!o.noSave) {
+      const string folder = current_date_time();
+      string command = "mkdir -p " + folder;
+      if (system(command.c_str()) != 0) { cerr << "ERROR: cannot create " << folder << endl; return 1; }
+      save_minhash_sketches(genomes, fin, folder, byFile);
+    }
+    if (genomes.empty()) { cerr << "ERROR: no genome to cluster" << endl; return 1; }
+    DeviceSketches ds;
+    upload_sketches(ctx, &fin.hashes, nullptr, ds);
+    vector<int32_t> rep_of(genomes.size());
+    uint32_t ncl = 0;
+    // (sketches loaded from a containment folder report containCompress as their sketch size, src/Sketch_IO.cpp:334;
+    // containDistance() does not use it)
+    CHECK(ctx, rtc_greedy_mash(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, mh.kmerSize, (int)mh.isContainment,
+                               (uint32_t)mh.sketchSize, o.threshold, rep_of.data(), &ncl));
+    vector<vector<int>> cluster = clusters_from_rep_of(rep_of);
+    print_result(cluster, genomes, byFile, o.outputFile);
+    cerr << "-----write the cluster result into: " << o.outputFile << endl;
+    cerr << "-----the cluster number of " << o.outputFile << " is: " << cluster.size() << endl;
+    return 0;
+  }
+  cerr << "---the threshold is: " << o.threshold << endl << "---the thread number is: " << o.threads << endl;
+  if (byFile != o.sketchByFile) cerr << "Warning: the input format of append genomes and pre-sketched genome is not same" << endl;
+  st.genomes = pre; st.sk = KssdSketchFile(); st.sk.use64 = true; st.sk.h64 = mh.hashes;
+  st.reps = KssdSketchFile(); st.reps.use64 = true; st.rep_genomes.clear();
+  for (int rep_id : st.rep_ids) {
+    if (rep_id < 0 || (size_t)rep_id >= pre.size()) {
+      cerr << "ERROR: Representative ID " << rep_id << " out of range [0, " << pre.size() << "), cannot continue" << endl;
+      return 1;
+    }
+    st.rep_genomes.push_back(pre[rep_id]);
+    st.reps.h64.push_back(mh.hashes[rep_id]);
+  }
+  cerr << "Successfully loaded " << st.rep_ids.size() << " representatives" << endl << "Rebuilding inverted index..." << endl;
+  if (st.kmer_size <= 0 || st.sketch_size <= 0) {
+    cerr << "ERROR: Invalid kmer_size or sketch_size: kmer=" << st.kmer_size << ", sketch=" << st.sketch_size << endl;
+    return 1;
+  }
+  if (st.is_containment && mh.containCompress <= 0) { cerr << "ERROR: is_containment is true but contain_compress is " << mh.containCompress << endl; return 1; }
+  cerr << "Computing sketches for new genomes..." << endl << "  Parameters: kmer_size=" << st.kmer_size << ", sketch_size=" << st.sketch_size
+       << ", is_containment=" << st.is_containment << ", contain_compress=" << mh.containCompress << endl;
+  vector<GenomeInfo> add; MinHashSketchFile mh2;
+  sketch_new(st.kmer_size, st.sketch_size, st.is_containment, add, mh2);
+  cerr << "New genomes sketched: " << add.size() << endl;
+  if (add.empty()) { cerr << "ERROR: No new sketches generated" << endl; return 0; }
+  cerr << "Starting incremental clustering..." << endl;
+  KssdSketchFile ks2; ks2.use64 = true; ks2.h64 = std::move(mh2.hashes);
+  if (kssd_incremental_cluster(ctx, st, add, ks2, true) != 0) return 1;
+  cerr << "Incremental clustering completed" << endl;
+  if (!o.noSave && o.saveRep && !save_minhash_cluster_state(state_file, st)) return 1;
+  print_result(st.clusters, st.genomes, o.sketchByFile, o.outputFile);
+  cerr << "-----write the cluster result into: " << o.outputFile << endl;
+  cerr << "-----the cluster number of " << o.outputFile << " is: " << st.clusters.size() << endl;
+  cerr << "-----updated cluster state saved" << endl;
+  return 0;
+}
 #endif
 
 int main(int argc, char** argv) {
@@ -1339,9 +1457,6 @@ int main(int argc, char** argv) {
   if (!o.has_output && !o.db_stats) { cerr << "ERROR: option -o/--output is required (unless --buildDB or --stats is used)" << endl; return 1; }
   if (o.threads < 1) { fprintf(stderr, "-----Invalid thread number %d\n", o.threads); return 1; }
   fprintf(stderr, "-----set the thread number %d\n", o.threads);
-#ifdef GREEDY_CLUST
-  if (o.saveRep && !o.is_fast) unsupported("--save-rep on MinHash sketches (the MinHash cluster state); --fast");
-#endif
   if (!o.has_threshold) { o.threshold = 0.05; cerr << "-----use default threshold: " << o.threshold << endl; }
 
 #ifdef GREEDY_CLUST
@@ -1398,7 +1513,7 @@ int main(int argc, char** argv) {
 #ifdef GREEDY_CLUST
         true;
 #else
-        o.has_append || o.dense;
+        o.has_append || o.dense || !o.useIndex;
 #endif
     if (spec == "all") { gpus_by_default = true; for (int d = 0; d < ndev; d++) devs.push_back(d); }
     else if (spec.find(',') == string::npos && atoi(spec.c_str()) > 0 && spec.find_first_not_of("0123456789") == string::npos) {
@@ -1453,8 +1568,7 @@ int main(int argc, char** argv) {
     return rc;
   }
   if (o.has_append) {  // src/main.cpp:378-387
-    if (!o.is_fast) unsupported("clust-greedy --append on MinHash sketches (Sketch::MinHash::distance() of the absent RabbitSketch decides there); --fast");
-    const int rc = append_clust_greedy_fast(o, gpus);
+    const int rc = o.is_fast ? append_clust_greedy_fast(o, gpus) : append_clust_greedy(o, gpus);
     for (Gpu& g : gpus) { if (g.comm) rtc_comm_destroy(g.comm); }
     for (Gpu& g : gpus) rtc_ctx_destroy(g.ctx);
     return rc;
@@ -1569,9 +1683,24 @@ int main(int argc, char** argv) {
   else upload_sketches(ctx, &mh.hashes, nullptr, ds);
   vector<int32_t> rep_of(genomes.size());
   uint32_t ncl = 0;
-  CHECK(ctx, rtc_greedy(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, o.is_fast ? nullptr : size_cfg.data(), kmer_size,
-                        o.is_fast ? 0 : (int)mh.isContainment, o.is_fast ? 1 : 0, o.threshold, rep_of.data(), &ncl));
+  if (!o.is_fast && !o.useIndex)  // greedyCluster: every representative, MinHash::distance() (src/sub_command.cpp:2683,2914)
+    CHECK(ctx, rtc_greedy_mash(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, kmer_size, (int)mh.isContainment, size_cfg[0], o.threshold,
+                               rep_of.data(), &ncl));
+  else
+    CHECK(ctx, rtc_greedy(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, o.is_fast ? nullptr : size_cfg.data(), kmer_size,
+                          o.is_fast ? 0 : (int)mh.isContainment, o.is_fast ? 1 : 0, o.threshold, rep_of.data(), &ncl));
   vector<vector<int>> cluster = clusters_from_rep_of(rep_of);
+  if (!o.is_fast && o.useIndex && o.saveRep && (from_sketches || !o.noSave)) {
+    // MinHashInitialClusterWithState + save (src/sub_command.cpp:2673-2679, :2904-2909; src/greedy.cpp:1904-1960)
+    KssdClusterState st;
+    st.minhash = true; st.threshold = o.threshold; st.kmer_size = kmer_size; st.sketch_size = (int)size_cfg[0]; st.is_containment = mh.isContainment;
+    st.genomes = genomes; st.sk.use64 = true; st.sk.h64 = mh.hashes; st.clusters = cluster; st.reps.use64 = true;
+    cerr << "Building inverted index from " << cluster.size() << " representatives..." << endl;
+    for (const auto& c : cluster) if (!c.empty()) { st.rep_ids.push_back(c[0]); st.rep_genomes.push_back(genomes[c[0]]); st.reps.h64.push_back(mh.hashes[c[0]]); }
+    const string state_file = folder_path + "/cluster_state.bin";
+    if (!save_minhash_cluster_state(state_file, st)) return 1;
+    cerr << "-----saved cluster state (with inverted index) to: " << state_file << endl;
+  }
   if (o.is_fast && o.saveRep && !o.noSave && !from_sketches) {  // compute_kssd_clusters, src/sub_command.cpp:1962-1967
     KssdClusterState st;
     KssdParameters info = ks.info;
@@ -1598,7 +1727,12 @@ int main(int argc, char** argv) {
     else upload_sketches(gpus[g].ctx, &mh.hashes, nullptr, dss[g]);
   });
   vector<int32_t> dense; uint64_t ani[101];
-  if ((G == 1 && !gpus[0].comm) || o.dense) {  // --dense: the histograms are accumulated beside the single-GPU candidate list
+  if (!o.useIndex && !o.is_fast) {  // modifyMST, the dense loop (src/sub_command.cpp:2764,2995): every pair, MinHash::distance()
+    const DeviceSketches& ds = dss[0];
+    if (o.dense) dense.resize((size_t)DENSE_SPAN * ds.n);
+    CHECK(ctx, rtc_mst_mash(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, 0, kmer_size, is_containment, (uint32_t)mh.sketchSize, mst.data(),
+                            &nedges, o.dense ? DENSE_SPAN : 0, o.dense ? dense.data() : nullptr, o.dense ? ani : nullptr));
+  } else if ((G == 1 && !gpus[0].comm) || o.dense) {  // --dense: the histograms are accumulated beside the single-GPU candidate list
     const DeviceSketches& ds = dss[0];
     if (o.dense) dense.resize((size_t)DENSE_SPAN * ds.n);
     CHECK(ctx, rtc_mst_dense(ctx, ds.d_hashes, ds.width, ds.d_start, ds.d_len, ds.n, 0, kmer_size, is_containment, o.threshold, mst.data(), &nedges,

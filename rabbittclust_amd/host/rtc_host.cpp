@@ -995,6 +995,96 @@ bool save_kssd_cluster_state(const std::string& path, const KssdClusterState& st
   return true;
 }
 
+// MinHashClusterState::save (src/greedy.cpp:2134-2208): "MINHASH\0", threshold, k, sketch size, containment flag,
+// representative ids, every sketch in clustering order {id, length, hashes, file name}, the clusters (members are
+// positions in that order, the representative first), the representatives' inverted index hash -> positions in
+// representative_ids.  The reference writes the index in hash-map iteration order; here ascending by hash (readers
+// rebuild a map from it either way).
+bool save_minhash_cluster_state(const std::string& path, const KssdClusterState& st) {
+  FILE* fp = fopen(path.c_str(), "wb");
+  if (!fp) { std::cerr << "ERROR: Cannot open file for writing: " << path << std::endl; return false; }
+  const char magic[8] = {'M', 'I', 'N', 'H', 'A', 'S', 'H', '\0'};
+  fwrite(magic, 1, 8, fp);
+  wr(fp, st.threshold); wr(fp, st.kmer_size); wr(fp, st.sketch_size); wr(fp, st.is_containment);
+  const size_t rep_count = st.rep_ids.size();
+  wr(fp, rep_count);
+  fwrite(st.rep_ids.data(), sizeof(int), rep_count, fp);
+  const size_t sketch_count = st.genomes.size();
+  wr(fp, sketch_count);
+  for (size_t i = 0; i < sketch_count; i++) {
+    const GenomeInfo& g = st.genomes[i];
+    wr(fp, g.id); wr(fp, g.totalSeqLength);
+    const size_t hash_count = st.sk.h64[i].size();
+    wr(fp, hash_count);
+    if (hash_count) fwrite(st.sk.h64[i].data(), 8, hash_count, fp);
+    const size_t name_len = g.fileName.size();
+    wr(fp, name_len);
+    fwrite(g.fileName.data(), 1, name_len, fp);
+  }
+  const size_t cluster_count = st.clusters.size();
+  wr(fp, cluster_count);
+  for (const auto& c : st.clusters) {
+    const size_t m = c.size();
+    wr(fp, m);
+    fwrite(c.data(), sizeof(int), m, fp);
+  }
+  std::cerr << "Saving inverted index: ";
+  const size_t index_size = write_rep_index(fp, st);
+  std::cerr << index_size << " unique hashes..." << std::endl;
+  fclose(fp);
+  std::cerr << "Saved clustering state to: " << path << std::endl
+            << "  - " << sketch_count << " genomes" << std::endl
+            << "  - " << rep_count << " clusters (representatives)" << std::endl
+            << "  - " << index_size << " unique hashes in inverted index" << std::endl;
+  return true;
+}
+
+// MinHashClusterState::load (src/greedy.cpp:2210-2302): parameters, representative ids and clusters are kept; the
+// sketches are skipped (the caller reloads them from the folder, src/sub_command.cpp:100-139) and so is the index
+// (it is rebuilt from the representatives).
+bool load_minhash_cluster_state(const std::string& path, KssdClusterState& st) {
+  FILE* fp = fopen(path.c_str(), "rb");
+  if (!fp) { std::cerr << "ERROR: Cannot open file for reading: " << path << std::endl; return false; }
+  char magic[8] = {0};
+  if (fread(magic, 1, 8, fp) != 8 || strncmp(magic, "MINHASH", 8) != 0) {
+    std::cerr << "ERROR: Invalid file format (not a MinHash cluster state)" << std::endl;
+    fclose(fp);
+    return false;
+  }
+  st = KssdClusterState();
+  st.minhash = true; st.sk.use64 = true; st.reps.use64 = true;
+  bool ok = rd(fp, st.threshold) && rd(fp, st.kmer_size) && rd(fp, st.sketch_size) && rd(fp, st.is_containment);
+  size_t rep_count = 0, sketch_count = 0, cluster_count = 0;
+  ok = ok && rd(fp, rep_count) && rep_count < ((size_t)1 << 31);
+  if (ok) { st.rep_ids.resize(rep_count); ok = fread(st.rep_ids.data(), sizeof(int), rep_count, fp) == rep_count; }
+  ok = ok && rd(fp, sketch_count) && sketch_count < ((size_t)1 << 31);
+  for (size_t i = 0; ok && i < sketch_count; i++) {
+    int id; uint64_t len; size_t hash_count = 0, name_len = 0;
+    ok = rd(fp, id) && rd(fp, len) && rd(fp, hash_count) && hash_count < ((size_t)1 << 32) &&
+         fseek(fp, (long)(hash_count * 8), SEEK_CUR) == 0 && rd(fp, name_len) && name_len < ((size_t)1 << 20) &&
+         fseek(fp, (long)name_len, SEEK_CUR) == 0;
+  }
+  ok = ok && rd(fp, cluster_count) && cluster_count < ((size_t)1 << 31);
+  for (size_t c = 0; ok && c < cluster_count; c++) {
+    size_t m = 0;
+    ok = rd(fp, m) && m < ((size_t)1 << 31);
+    if (!ok) break;
+    std::vector<int> cl(m);
+    if (m) ok = fread(cl.data(), sizeof(int), m, fp) == m;
+    st.clusters.push_back(std::move(cl));
+  }
+  size_t index_size = 0;
+  ok = ok && rd(fp, index_size);
+  fclose(fp);
+  if (!ok) { std::cerr << "ERROR: truncated or malformed cluster state: " << path << std::endl; return false; }
+  std::cerr << "Loading inverted index: " << index_size << " unique hashes..." << std::endl;
+  std::cerr << "Loaded clustering state from: " << path << std::endl
+            << "  - " << sketch_count << " genomes" << std::endl
+            << "  - " << rep_count << " clusters (representatives)" << std::endl
+            << "  - " << index_size << " unique hashes in inverted index" << std::endl;
+  return true;
+}
+
 // src/greedy.cpp:1627-1734 (the inverted index that follows the clusters is not read: it is a function of the
 // representatives' sketches)
 bool load_kssd_cluster_state(const std::string& path, KssdClusterState& st) {

@@ -110,6 +110,12 @@ struct KssdClusterState {
 };
 bool save_kssd_cluster_state(const std::string& path, const KssdClusterState& st);
 bool load_kssd_cluster_state(const std::string& path, KssdClusterState& st);
+// cluster_state.bin of clust-greedy --save-rep on MinHash sketches (MinHashClusterState::save / ::load,
+// src/greedy.cpp:2134-2302): "MINHASH", parameters, representative ids, every sketch, clusters (representative first),
+// index.  load keeps parameters, representative ids and clusters only -- the reference skips the sketches too and
+// re-reads them from the folder.
+bool save_minhash_cluster_state(const std::string& path, const KssdClusterState& st);
+bool load_minhash_cluster_state(const std::string& path, KssdClusterState& st);
 // RepDB of clust-greedy --fast --db (KssdClusterState::save_repdb / ::load_repdb / ::print_stats,
 // src/greedy.cpp:2351-2537, :2656-2765): "REPDB002", parameters, the representatives with their sketches, the
 // clusters, every genome's file name and length, the representatives' inverted index (64-bit keys; "REPDB001"
