@@ -56,6 +56,15 @@ int rtc_memset_dev(rtc_ctx* ctx, void* d_ptr, int value, size_t bytes);
 int rtc_host_alloc(rtc_ctx* ctx, size_t bytes, void** h_ptr);
 int rtc_host_free(rtc_ctx* ctx, void* h_ptr);
 
+/* ---- 2-bit packed staging (command lines) -------------------------------------------------- */
+/* The reference feeds the sketcher ASCII records (src/SketchInfo.cpp:928-948).  The command lines send a quarter of
+ * that over PCIe: base i of a batch at bits 2 (i & 3) of d_packed[i >> 2] with A, C, G, T = 0..3, and everything that
+ * is not ACGT (N, IUPAC codes, record separators, the gaps between genomes) as d_runs[2 r] = start, d_runs[2 r + 1] =
+ * length.  This call writes the ASCII stream the sketch kernels read to d_seq[0 .. n_bases): "ACGT"[code], 'N' over the
+ * runs.  n_bases a multiple of 64, both buffers 16-byte aligned.  Context stream, asynchronous. */
+int rtc_unpack_bases_dev(rtc_ctx* ctx, const uint8_t* d_packed, uint64_t n_bases, const uint64_t* d_runs, uint64_t n_runs,
+                         uint8_t* d_seq);
+
 /* ---- timing of the last launches (HIP events on the context stream) -------------------- */
 /* Brackets subsequently enqueued work; rtc_timer_stop synchronises and returns milliseconds. */
 int rtc_timer_start(rtc_ctx* ctx);

@@ -60,6 +60,7 @@ SIGNATURES = {
     "rtc_memset_dev": (_i, [_vp, _vp, _i, C.c_size_t]),
     "rtc_host_alloc": (_i, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "rtc_host_free": (_i, [_vp, _vp]),
+    "rtc_unpack_bases_dev": (_i, [_vp, _vp, _u64, _vp, _u64, _vp]),
     "rtc_timer_start": (_i, [_vp]),
     "rtc_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "rtc_synth_genomes_dev": (_i, [_vp, _vp, _vp, _u32, _vp]),

@@ -102,4 +102,25 @@ long rtch_genome_bases(const char* path, int flat, char* out, long cap, uint64_t
   if ((long)bases.size() <= cap) memcpy(out, bases.data(), bases.size());
   return (long)bases.size();
 }
+
+void rtch_pack_force_portable(int on) { pack_force_portable(on); }
+
+// pack_bases: n characters -> ceil(n / 4) packed bytes in `out`, runs (start, length) pairs in runs_out (capacity
+// runs_cap u64 values); returns the number of u64 values the runs take (the caller retries when it exceeds runs_cap)
+long rtch_pack_bases(const char* seq, long n, unsigned char* out, unsigned long long* runs_out, long runs_cap) {
+  std::vector<uint64_t> runs;
+  pack_bases(seq, (size_t)n, out, runs);
+  for (size_t i = 0; i < runs.size() && (long)i < runs_cap; i++) runs_out[i] = runs[i];
+  return (long)runs.size();
+}
+
+// read_genome_file_packed: returns status (0 ok, 1 cannot open, 2 capacity); *used bases, *nruns u64 values written to runs_out
+int rtch_read_genome_packed(const char* path, unsigned char* out, long cap_bases, long* used, unsigned long long* runs_out, long runs_cap,
+                            long* nruns, unsigned long long* total, unsigned long long* nrec) {
+  std::vector<uint64_t> runs; SequenceInfo first; uint64_t u = 0, tot = 0, nr = 0;
+  const int st = read_genome_file_packed(path, out, (uint64_t)cap_bases, u, runs, first, tot, nr);
+  *used = (long)u; *total = tot; *nrec = nr; *nruns = (long)runs.size();
+  for (size_t i = 0; i < runs.size() && (long)i < runs_cap; i++) runs_out[i] = runs[i];
+  return st;
+}
 }

@@ -26,6 +26,7 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/time.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -151,7 +152,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   // Two lanes per GPU: lane 0 is the GPU's own context, lane 1 a second context on the same device with a
   // stream of its own, each driven by its own host thread -- the PCIe copy of one batch runs beside the
   // sketch kernel of the previous one.  Both lanes write rows of the same resident sketch buffer.
-  struct Lane { rtc_ctx* ctx; void* d_seq; std::thread worker; size_t gpu; bool owned; };
+  struct Lane { rtc_ctx* ctx; void* d_seq; std::thread worker; size_t gpu; bool owned; void* d_packed = nullptr; void* d_runs = nullptr; size_t runs_cap = 0; };
   const size_t LPG = getenv("RTC_SINGLE_LANE") ? 1 : 2;
   vector<Lane> lanes(G * LPG);
   for (size_t l = 0; l < lanes.size(); l++) {
@@ -166,6 +167,11 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   const vector<string> fileList = read_list(inputFile);
   const size_t nfiles = fileList.size();
   const bool verbose = getenv("RTC_VERBOSE") != nullptr;
+  // Staging format: the parser threads pack the bases to 2 bits and list everything that is not ACGT as runs
+  // (rtc_host: read_genome_file_packed); the GPU expands the batch again in HBM (rtc_unpack_bases_dev) in front of the
+  // sketch kernel.  A quarter of the bytes cross PCIe, which is what bounds this command line.  RTC_STAGE_ASCII=1
+  // stages the characters themselves (the former path; tests compare the two).
+  const bool packed = getenv("RTC_STAGE_ASCII") == nullptr;
   uint64_t BATCH_BYTES = (uint64_t)1 << 30;  // measured best on a 16-core quota: 0.5-1 GiB
   if (const char* e = getenv("RTC_BATCH_BYTES")) BATCH_BYTES = std::max<uint64_t>(strtoull(e, nullptr, 10), 1 << 20);
   vector<int32_t> shuffled;
@@ -197,10 +203,11 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   auto plan = [&](const vector<size_t>& files, const vector<uint64_t>& need) {
     vector<Batch> out;
     for (size_t q = 0; q < files.size(); q++) {
-      if (out.empty() || (out.back().bytes + need[q] > BATCH_BYTES && !out.back().files.empty())) out.emplace_back();
+      if (out.empty() || (out.back().bytes + need[q] + 64 > BATCH_BYTES && !out.back().files.empty())) out.emplace_back();
       Batch& b = out.back();
-      b.files.push_back(files[q]); b.slot_off.push_back(b.bytes); b.slot_len.push_back(need[q]);
-      b.bytes += need[q];
+      const uint64_t nd = packed ? (need[q] + 63) & ~(uint64_t)63 : need[q];  // packed slots start on 16-byte boundaries
+      b.files.push_back(files[q]); b.slot_off.push_back(b.bytes); b.slot_len.push_back(nd);
+      b.bytes += nd;
     }
     return out;
   };
@@ -212,6 +219,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   const size_t NSTAGE = NL + 1;
   uint64_t buf_bytes = 0;
   vector<char*> stage(NSTAGE, nullptr);
+  vector<vector<uint64_t>> stage_runs(NSTAGE);  // packed staging: the batch's runs of characters outside ACGT, batch coordinates
   // Pageable staging by default: page-locking costs ~0.15 s/GB up front while the pageable PCIe copy
   // already runs at > 30 GB/s on the MI355X hosts measured; RTC_STAGE_PINNED=1 page-locks instead.
   bool pinned = getenv("RTC_STAGE_PINNED") != nullptr;
@@ -225,19 +233,26 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   auto ensure_buffers = [&](uint64_t need) {
     if (need <= buf_bytes) return;
     free_stage();
-    for (Lane& l : lanes) if (l.d_seq) { CHECK(l.ctx, rtc_dev_free(l.ctx, l.d_seq)); l.d_seq = nullptr; }
+    for (Lane& l : lanes) {
+      if (l.d_seq) { CHECK(l.ctx, rtc_dev_free(l.ctx, l.d_seq)); l.d_seq = nullptr; }
+      if (l.d_packed) { CHECK(l.ctx, rtc_dev_free(l.ctx, l.d_packed)); l.d_packed = nullptr; }
+    }
     buf_bytes = need;
+    const uint64_t host_bytes = packed ? buf_bytes / 4 + 64 : buf_bytes + 64;
     for (int i = 0; i < (int)NSTAGE; i++) {
-      if (pinned && rtc_host_alloc(ctx, buf_bytes + 64, (void**)&stage[i]) != RTC_OK) {
+      if (pinned && rtc_host_alloc(ctx, host_bytes, (void**)&stage[i]) != RTC_OK) {
         // the host refuses to page-lock this much (ulimit -l): stage through pageable memory instead
         fprintf(stderr, "-----cannot page-lock %.2f GB (%s), staging through pageable memory\n", buf_bytes / 1e9, rtc_last_error(ctx));
         free_stage();
         pinned = false; i = -1;
         continue;
       }
-      if (!pinned && !(stage[i] = alloc_pageable(buf_bytes + 64))) { fprintf(stderr, "ERROR: cannot allocate %.2f GB of staging memory\n", buf_bytes / 1e9); exit(1); }
+      if (!pinned && !(stage[i] = alloc_pageable(host_bytes))) { fprintf(stderr, "ERROR: cannot allocate %.2f GB of staging memory\n", buf_bytes / 1e9); exit(1); }
     }
-    for (Lane& l : lanes) CHECK(l.ctx, rtc_dev_alloc(l.ctx, buf_bytes + 64, &l.d_seq));
+    for (Lane& l : lanes) {
+      CHECK(l.ctx, rtc_dev_alloc(l.ctx, buf_bytes + 128, &l.d_seq));
+      if (packed) CHECK(l.ctx, rtc_dev_alloc(l.ctx, host_bytes, &l.d_packed));
+    }
   };
   uint64_t maxb = 0;
   for (const Batch& b : batches) maxb = std::max(maxb, b.bytes);
@@ -297,7 +312,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
 
   // ---- GPU side of one batch (runs on that GPU's host thread while the next batch is parsed) ----
   // row0 < 0: not resident (retry round), results only go to the host vectors.
-  auto gpu_batch = [&](Lane& ln, const Batch& b, const char* h_seq, long row0) {
+  auto gpu_batch = [&](Lane& ln, const Batch& b, const char* h_seq, const vector<uint64_t>* h_runs, long row0) {
     Gpu& gp = gpus[ln.gpu];
     rtc_ctx* c = ln.ctx;
     const double t0 = get_sec();
@@ -312,7 +327,19 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
     const uint32_t nb = (uint32_t)kept.size();
     if (!nb) return;
     off.push_back(b.bytes);
-    CHECK(c, rtc_copy_h2d(c, ln.d_seq, h_seq, b.bytes + 64));
+    if (packed) {
+      const size_t nr = h_runs->size() / 2;
+      if (nr > ln.runs_cap) {
+        if (ln.d_runs) CHECK(c, rtc_dev_free(c, ln.d_runs));
+        ln.runs_cap = nr + nr / 2 + 1024;
+        CHECK(c, rtc_dev_alloc(c, ln.runs_cap * 16, &ln.d_runs));
+      }
+      CHECK(c, rtc_copy_h2d(c, ln.d_packed, h_seq, b.bytes / 4 + 16));
+      CHECK(c, rtc_copy_h2d(c, ln.d_runs, h_runs->data(), nr * 16));
+      CHECK(c, rtc_unpack_bases_dev(c, (const uint8_t*)ln.d_packed, b.bytes + 64, (const uint64_t*)ln.d_runs, nr, (uint8_t*)ln.d_seq));
+    } else {
+      CHECK(c, rtc_copy_h2d(c, ln.d_seq, h_seq, b.bytes + 64));
+    }
     const double t1 = get_sec();
     const bool resident = row0 >= 0 && resident_ok.load();
     const bool to_host = need_host_hashes || !resident;
@@ -379,20 +406,36 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
     for (const Batch& b : batches) {
       const double t0 = get_sec();
       char* buf = stage[bi % NSTAGE];
+      vector<uint64_t>& bruns = stage_runs[bi % NSTAGE];
       vector<uint64_t> need(b.files.size(), 0);
+      vector<vector<uint64_t>> fruns(packed ? b.files.size() : 0);
 #pragma omp parallel for num_threads(job.threads) schedule(dynamic)
       for (long q = 0; q < (long)b.files.size(); q++) {
         FileResult& r = res[b.files[q]];
         uint64_t used = 0, nrec = 0;
-        char* dst = buf + b.slot_off[q];
-        const int st = read_genome_file_flat(fileList[b.files[q]], dst, b.slot_len[q], used, r.first, r.total, nrec);
+        int st;
+        if (packed) st = read_genome_file_packed(fileList[b.files[q]], (uint8_t*)buf + b.slot_off[q] / 4, b.slot_len[q], used, fruns[q], r.first, r.total, nrec);
+        else st = read_genome_file_flat(fileList[b.files[q]], buf + b.slot_off[q], b.slot_len[q], used, r.first, r.total, nrec);
         if (st == 1) { fprintf(stderr, "cannot open the genome file: %s\n", fileList[b.files[q]].c_str()); exit(1); }
         if (st == 2) { need[q] = used + 1; used = 0; r.kept = false; }
         else r.kept = r.total >= job.minLen;                                 // :963
         if (!r.kept) used = 0;
-        memset(dst + used, 'N', b.slot_len[q] - used);  // no k-mers in the gap, nor in dropped genomes
+        // no k-mers in the gap behind the genome, nor in dropped genomes
+        if (!packed) memset(buf + b.slot_off[q] + used, 'N', b.slot_len[q] - used);
+        else {
+          vector<uint64_t>& fr = fruns[q];
+          while (!fr.empty() && fr[fr.size() - 2] >= used) { fr.pop_back(); fr.pop_back(); }
+          if (!fr.empty() && fr[fr.size() - 2] + fr[fr.size() - 1] > used) fr[fr.size() - 1] = used - fr[fr.size() - 2];
+          if (b.slot_len[q] > used) { fr.push_back(used); fr.push_back(b.slot_len[q] - used); }
+        }
       }
-      memset(buf + b.bytes, 'N', 64);
+      if (!packed) memset(buf + b.bytes, 'N', 64);
+      else {
+        bruns.clear();
+        for (size_t q = 0; q < b.files.size(); q++)
+          for (size_t e = 0; e + 1 < fruns[q].size(); e += 2) { bruns.push_back(b.slot_off[q] + fruns[q][e]); bruns.push_back(fruns[q][e + 1]); }
+        bruns.push_back(b.bytes); bruns.push_back(64);
+      }
       uint32_t nkept = 0;
       for (size_t q = 0; q < b.files.size(); q++) {
         if (need[q]) { retry_files.push_back(b.files[q]); retry_need.push_back(need[q]); }
@@ -407,7 +450,8 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       const long row0 = round == 0 ? (long)next_row : -1;
       if (round == 0) { placed.push_back(Placed{next_row, nkept, (int)ln.gpu}); next_row += nkept; }
       Lane* lnp = &ln;
-      ln.worker = std::thread([&gpu_batch, lnp, bp, buf, row0]() { gpu_batch(*lnp, *bp, buf, row0); });
+      const vector<uint64_t>* brp = &bruns;
+      ln.worker = std::thread([&gpu_batch, lnp, bp, buf, brp, row0]() { gpu_batch(*lnp, *bp, buf, brp, row0); });
       for (size_t q = 0; q < b.files.size(); q++, done_files++) if (done_files % 10000 == 0) cerr << "---finished sketching: " << done_files << " genomes" << endl;
       bi++;
     }
@@ -1775,5 +1819,8 @@ int main(int argc, char** argv) {
   for (Gpu& g : gpus) { if (g.comm) rtc_comm_destroy(g.comm); }
   for (Gpu& g : gpus) rtc_ctx_destroy(g.ctx);
   if (getenv("RTC_VERBOSE")) fprintf(stderr, "[exit]  output written at t+%.3fs, contexts released in %.3fs\n", t_end - t_main, get_sec() - t_end);
-  return 0;
+  // Everything is written and closed: leave without unmapping the GBs of staging memory page by page and without the
+  // HIP runtime's own teardown (0.15 s of a 0.9 s run on 41 Gbp); the kernel reclaims both at once.
+  fflush(nullptr);
+  _exit(0);
 }

@@ -12,6 +12,7 @@
 #include <sys/stat.h>
 #include <time.h>
 #include <zlib.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <fstream>
@@ -122,6 +123,128 @@ struct FlatSink {
   char back() const { return pos - 1 < cap ? base[pos - 1] : 0; }
   void pop_back() { pos--; }
 };
+
+// ---- 2-bit packed sink (the command lines' staging format: a quarter of the bytes over PCIe) ----
+// Base i of the slot sits at bits 2 (i & 3) of byte i >> 2 with A, C, G, T (either case) = 0, 1, 2, 3.  Every other
+// character -- N, IUPAC codes, the '\n' the reader puts between records -- is written as 0 and listed in `runs` as
+// (start, length) in slot coordinates (ascending, adjacent ones merged): rtc_unpack_bases_dev turns the packed
+// stream back into the ASCII the sketch kernels read and writes 'N' over the runs, which is all the kernels need
+// (any character outside ACGT ends a k-mer the same way).  size()/back()/pop_back() behave as FlatSink's.
+static inline uint32_t base_code(unsigned char c) { return ((c >> 1) ^ (c >> 2)) & 3u; }
+static inline bool base_valid(unsigned char c) { return ((c & 0xC0u) == 0x40u) && ((0x0010008Au >> (c & 31u)) & 1u); }
+
+struct PackedSink {
+  uint8_t* base; size_t cap;           // cap in BASES
+  std::vector<uint64_t>* runs;
+  size_t pos = 0, rec = 0;             // bases appended so far / where the current record began
+  // Lines are copied into a small character buffer first and packed a few KiB at a time: the packing loop then
+  // always works on whole 32-base groups, whatever the line length of the file (60, 70, 80 ...).
+  static constexpr size_t CH = 8192;
+  size_t done = 0, fill = 0;           // stream positions [0, done) are packed, [done, done + fill) wait in buf
+  unsigned char buf[CH + 32];  // (+ 32: headroom for the move of the unpacked remainder)
+  PackedSink(uint8_t* b, size_t c, std::vector<uint64_t>* r) : base(b), cap(c), runs(r) {}
+  void clear() { rec = pos; }
+  size_t size() const { return pos - rec; }
+  char back() const { return fill ? (char)buf[fill - 1] : 0; }
+  void put1(unsigned char c) {         // packs one character at stream position `done`
+    if (done < cap) {
+      const uint32_t sh = 2 * (done & 3);
+      const uint8_t code = base_valid(c) ? (uint8_t)(base_code(c) << sh) : 0;
+      if (sh == 0) base[done >> 2] = code; else base[done >> 2] |= code;
+      if (!base_valid(c)) {
+        if (!runs->empty() && (*runs)[runs->size() - 2] + (*runs)[runs->size() - 1] == done) (*runs)[runs->size() - 1]++;
+        else { runs->push_back(done); runs->push_back(1); }
+      }
+    }
+    done++;
+  }
+  void emit(const unsigned char* p, size_t n);   // packs n characters at stream position `done`
+  void flush(bool all) {
+    const size_t m = all ? fill : fill & ~(size_t)31;
+    emit(buf, m);
+    const size_t rest = fill - m;  // < 32 unless everything went out
+    for (size_t q = 0; q < rest; q++) buf[q] = buf[m + q];
+    fill = rest;
+  }
+  void append(const char* p, size_t n) {
+    while (n) {
+      if (fill == CH) flush(false);
+      const size_t k = n < CH - fill ? n : CH - fill;
+      memcpy(buf + fill, p, k);
+      fill += k; pos += k; p += k; n -= k;
+    }
+  }
+  void push_back(char c) { append(&c, 1); }
+  void truncate(size_t p) {  // drop everything from base p on (pop_back of a '\r', a record cut short)
+    pos = p;
+    if (p >= done) { fill = p - done; return; }
+    fill = 0; done = p;
+    if (p < cap && (p & 3)) base[p >> 2] &= (uint8_t)((1u << (2 * (p & 3))) - 1u);
+    while (!runs->empty()) {
+      uint64_t& st = (*runs)[runs->size() - 2]; uint64_t& ln = (*runs)[runs->size() - 1];
+      if (st >= p) { runs->pop_back(); runs->pop_back(); }
+      else { if (st + ln > p) ln = p - st; break; }
+    }
+  }
+  void pop_back() { truncate(pos - 1); }
+  void finish() { flush(true); }
+};
+
+// 32 bases at a time: codes by two shifts and a mask, validity by re-encoding the codes (pshufb) and comparing with
+// the upper-cased input, packing by two multiply-adds (c0 + 4 c1, then + 16 * (c2 + 4 c3)) and a byte gather
+__attribute__((target("avx2"))) static size_t pack_run_avx2(const unsigned char* p, size_t n, uint8_t* out) {
+  const __m256i m3 = _mm256_set1_epi8(3), mdf = _mm256_set1_epi8((char)0xDF);
+  const __m256i lut = _mm256_setr_epi8('A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+  const __m256i w1 = _mm256_set1_epi16(0x0401), w2 = _mm256_set1_epi32(0x00100001);
+  const __m256i gather = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    const __m256i x = _mm256_loadu_si256((const __m256i*)(p + i));
+    const __m256i c = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(x, 1), _mm256_srli_epi16(x, 2)), m3);
+    const __m256i ok = _mm256_cmpeq_epi8(_mm256_shuffle_epi8(lut, c), _mm256_and_si256(x, mdf));
+    if ((uint32_t)_mm256_movemask_epi8(ok) != 0xffffffffu) break;  // a character outside ACGTacgt: the caller goes base by base
+    const __m256i q = _mm256_shuffle_epi8(_mm256_madd_epi16(_mm256_maddubs_epi16(c, w1), w2), gather);
+    const uint32_t lo = (uint32_t)_mm256_cvtsi256_si32(q), hi = (uint32_t)_mm256_extract_epi32(q, 4);
+    memcpy(out + (i >> 2), &lo, 4);
+    memcpy(out + (i >> 2) + 4, &hi, 4);
+  }
+  return i;
+}
+
+// portable form of the same, 8 bases at a time in a 64-bit word
+static size_t pack_run_swar(const unsigned char* p, size_t n, uint8_t* out) {
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t x;
+    memcpy(&x, p + i, 8);
+    const uint64_t c = ((x >> 1) ^ (x >> 2)) & 0x0303030303030303ULL;
+    const uint64_t b0 = c & 0x0101010101010101ULL, b1 = (c >> 1) & 0x0101010101010101ULL;
+    const uint64_t e = 0x4141414141414141ULL + 2 * b0 + 6 * b1 + 0x0B * (b0 & b1);   // A, C, G, T from the codes
+    if ((x & 0xDFDFDFDFDFDFDFDFULL) != e) break;
+    uint64_t t = (c | (c >> 6)) & 0x000F000F000F000FULL;
+    t = (t | (t >> 12)) & 0x000000FF000000FFULL;
+    t = t | (t >> 24);
+    out[i >> 2] = (uint8_t)t; out[(i >> 2) + 1] = (uint8_t)(t >> 8);
+  }
+  return i;
+}
+
+static int g_pack_portable = 0;  // tests: take the 64-bit SWAR loop also where AVX2 exists
+void PackedSink::emit(const unsigned char* p, size_t n) {
+  static const bool cpu_avx2 = __builtin_cpu_supports("avx2");
+  const bool have_avx2 = cpu_avx2 && !g_pack_portable;
+  size_t i = 0;
+  while (i < n) {
+    if ((done & 3) == 0 && done + (n - i) <= cap && n - i >= 8) {  // byte-aligned, room for all: whole groups at once
+      const size_t k = have_avx2 ? pack_run_avx2(p + i, n - i, base + (done >> 2)) : pack_run_swar(p + i, n - i, base + (done >> 2));
+      done += k; i += k;
+      if (i >= n) break;
+    }
+    // up to the next group boundary (or past the character the fast loop stopped at) one by one
+    size_t k = 0;
+    do { put1(p[i++]); k++; } while (i < n && ((done & 3) != 0 || k < 8));
+  }
+}
 
 // returns sequence length, -1 at EOF, -2 on truncated quality
 template <typename Sink>
@@ -238,6 +361,44 @@ int read_genome_file_flat(const std::string& path, char* dst, uint64_t cap, uint
   if (len == -2) sink.pos = sink.rec;
   used = sink.pos;
   return sink.pos > cap ? 2 : 0;
+}
+
+int read_genome_file_packed(const std::string& path, uint8_t* dst, uint64_t cap_bases, uint64_t& used, std::vector<uint64_t>& runs,
+                            SequenceInfo& first, uint64_t& total_len, uint64_t& n_records) {
+  GzStream ks(path);
+  if (!ks.ok()) return 1;
+  int last_char = 0;
+  std::string name, comment;
+  bool has_comment = false;
+  runs.clear();
+  PackedSink sink(dst, (size_t)cap_bases, &runs);
+  total_len = 0; n_records = 0;
+  int len;
+  while ((len = next_record_t(ks, last_char, name, comment, has_comment, sink)) >= 0) {
+    total_len += (uint64_t)len;
+    if (n_records == 0) {
+      first.name = name;
+      first.comment = has_comment ? comment : std::string("noName");
+      first.strand = 0;
+      first.length = len;
+    }
+    sink.push_back('\n');
+    n_records++;
+  }
+  if (len == -2) { const size_t want = sink.pos; sink.truncate(sink.rec); if (want > cap_bases) { used = want; return 2; } }
+  sink.finish();
+  used = sink.pos;
+  return sink.pos > cap_bases ? 2 : 0;
+}
+
+void pack_force_portable(int on) { g_pack_portable = on; }
+
+size_t pack_bases(const char* seq, size_t n, uint8_t* dst, std::vector<uint64_t>& runs) {
+  runs.clear();
+  PackedSink sink(dst, n, &runs);
+  sink.append(seq, n);
+  sink.finish();
+  return sink.pos;
 }
 
 // =================================================================================================

@@ -43,6 +43,15 @@ bool read_genome_file(const std::string& path, std::string& bases, SequenceInfo&
 // Returns 0 ok, 1 cannot open, 2 capacity too small (`used` then holds a capacity that suffices).
 int read_genome_file_flat(const std::string& path, char* dst, uint64_t cap, uint64_t& used, SequenceInfo& first,
                           uint64_t& total_len, uint64_t& n_records);
+// The same into the 2-bit packed staging format (a quarter of the bytes over PCIe): base i of the stream at bits
+// 2 (i & 3) of dst[i >> 2], A/C/G/T (either case) = 0..3; every other character (N, IUPAC codes, the record
+// separators) is stored as 0 and listed in `runs` as (start, length) pairs, ascending.  cap_bases: capacity of dst in
+// bases (dst holds cap_bases / 4 bytes, cap_bases a multiple of 4).  rtc_unpack_bases_dev restores the ASCII stream
+// ('N' over the runs) on the GPU.  Same return values as read_genome_file_flat.
+int read_genome_file_packed(const std::string& path, uint8_t* dst, uint64_t cap_bases, uint64_t& used, std::vector<uint64_t>& runs,
+                            SequenceInfo& first, uint64_t& total_len, uint64_t& n_records);
+size_t pack_bases(const char* seq, size_t n, uint8_t* dst, std::vector<uint64_t>& runs);  // one buffer, for tests
+void pack_force_portable(int on);  // tests: the portable 8-bases-per-word loop instead of the AVX2 one
 // Upper bound of the bytes read_genome_file_flat writes for `path` (exact bound for plain files, the
 // ISIZE-based guess for gzip); 0 if the file cannot be opened.
 uint64_t genome_slot_bytes(const std::string& path);

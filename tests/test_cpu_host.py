@@ -255,6 +255,95 @@ def test_flat_genome_reader_matches_string_reader(host, tmp_path):
     assert run("/nonexistent/x.fa", 1, 16)[0] == -1
 
 
+def _unpack_py(packed, n, runs):
+    """rtc_unpack_bases_dev restated: "ACGT"[code] per base, 'N' over the runs."""
+    p = np.frombuffer(packed, dtype=np.uint8)
+    codes = np.stack([(p >> (2 * b)) & 3 for b in range(4)], axis=1).reshape(-1)[:n]
+    out = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].copy()
+    for st, ln in zip(runs[0::2], runs[1::2]):
+        out[st:st + ln] = ord("N")
+    return out.tobytes()
+
+
+def _normalised(stream):
+    """what the sketch kernels make of a byte stream: ACGT upper-cased, everything else ends k-mers like 'N'"""
+    a = np.frombuffer(stream, dtype=np.uint8).copy()
+    up = a & 0xDF
+    ok = np.isin(up, np.frombuffer(b"ACGT", dtype=np.uint8))
+    return np.where(ok, up, ord("N")).astype(np.uint8).tobytes()
+
+
+def test_packed_staging_equals_the_flat_stream(host, tmp_path):
+    """The 2-bit packer the command lines parse into (read_genome_file_packed / PackedSink, AVX2 and portable
+    paths): unpacked again with the runs it lists, the stream equals the flat reader's with every character outside
+    ACGT normalised to 'N' -- for every golden file, long lines, CRLF, gzip, N runs of every alignment, lower case,
+    a slot that is too small; runs are ascending, merged and inside the stream."""
+    import glob
+    import gzip
+    host.rtch_genome_bases.restype = C.c_long
+    host.rtch_genome_bases.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_long, C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+    host.rtch_pack_bases.restype = C.c_long
+    host.rtch_pack_bases.argtypes = [C.c_char_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long]
+    host.rtch_read_genome_packed.restype = C.c_int
+    host.rtch_read_genome_packed.argtypes = [C.c_char_p, C.c_void_p, C.c_long, C.POINTER(C.c_long), C.c_void_p, C.c_long,
+                                             C.POINTER(C.c_long), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+
+    def flat(path):
+        buf = np.zeros(1 << 21, dtype=np.uint8)
+        tot, nrec, fl, slot = C.c_uint64(), C.c_uint64(), C.c_int(), C.c_uint64()
+        n = host.rtch_genome_bases(str(path).encode(), 1, buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(tot), C.byref(nrec), C.byref(fl), C.byref(slot))
+        return bytes(buf[:n]), tot.value, nrec.value
+
+    def packed(path, cap):
+        out = np.zeros(cap // 4 + 8, dtype=np.uint8)
+        runs = np.zeros(1 << 18, dtype=np.uint64)
+        used, nruns, tot, nrec = C.c_long(), C.c_long(), C.c_uint64(), C.c_uint64()
+        st = host.rtch_read_genome_packed(str(path).encode(), out.ctypes.data_as(C.c_void_p), cap, C.byref(used), runs.ctypes.data_as(C.c_void_p),
+                                          len(runs), C.byref(nruns), C.byref(tot), C.byref(nrec))
+        return st, used.value, out.tobytes(), runs[:nruns.value].astype(np.int64).tolist(), tot.value, nrec.value
+
+    rng = np.random.default_rng(5)
+    seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=700_000)
+    for st in rng.integers(0, len(seq) - 200, size=300):     # N runs of every length and alignment
+        seq[st:st + int(rng.integers(1, 70))] = ord("N")
+    seq[rng.random(len(seq)) < 0.2] |= 0x20                    # lower case
+    seq[rng.integers(0, len(seq), size=50)] = rng.choice(np.frombuffer(b"RYKMswbdhv-*", dtype=np.uint8), size=50)
+    seq = seq.tobytes()
+    big = tmp_path / "big.fa"
+    with open(big, "wb") as f:
+        f.write(b">r1 first\r\n" + seq[:300_001] + b"\r\n\n>r2\n" + seq[300_001:300_070] + b"\n" + seq[300_070:])
+    biggz = tmp_path / "big.fa.gz"
+    with gzip.GzipFile(biggz, "wb", mtime=0) as f:
+        f.write(open(big, "rb").read())
+    lines = tmp_path / "lines.fa"   # 61-column lines: every line starts at a different offset within a packed byte
+    with open(lines, "wb") as f:
+        f.write(b">x\n" + b"\n".join(seq[i:i + 61] for i in range(0, 200_000, 61)) + b"\n")
+    files = sorted(glob.glob(os.path.join(GOLD, "fasta", "*"))) + [big, biggz, lines]
+    for path in files + [None] + files:   # second time: the portable 8-bases-per-word loop
+        if path is None:
+            host.rtch_pack_force_portable(1)
+            continue
+        want, tot0, nrec0 = flat(path)
+        st, used, pk, runs, tot, nrec = packed(path, 1 << 21)
+        assert st == 0 and used == len(want) and (tot, nrec) == (tot0, nrec0), path
+        assert _unpack_py(pk, used, runs) == _normalised(want), path
+        starts, lens = runs[0::2], runs[1::2]
+        assert all(l > 0 for l in lens) and all(a + l < b for a, l, b in zip(starts, lens, starts[1:])) and (not runs or starts[-1] + lens[-1] <= used), path
+        if used > 64:  # too-small slot: status 2 and the need, nothing written past the capacity
+            cap = (used - 9) // 4 * 4
+            st2, used2, pk2, runs2, *_ = packed(path, cap)
+            assert st2 == 2 and used2 >= used and pk2[cap // 4:] == bytes(len(pk2) - cap // 4), path
+    # the bare packer on a buffer (the byte loop and the group loop meet at every offset)
+    for n in (0, 1, 3, 4, 5, 31, 32, 33, 63, 64, 65, 1000, 4099):
+        src = seq[7:7 + n]
+        out = np.zeros(n // 4 + 8, dtype=np.uint8)
+        runs = np.zeros(4096, dtype=np.uint64)
+        nr = host.rtch_pack_bases(src, n, out.ctypes.data_as(C.c_void_p), runs.ctypes.data_as(C.c_void_p), len(runs))
+        assert _unpack_py(out.tobytes(), n, runs[:nr].astype(np.int64).tolist()) == _normalised(src), n
+    host.rtch_pack_force_portable(0)
+
+
 def _py_dendrogram(n, edges, names):
     """get_newick_tree / get_linkage_from_mst restated (src/MST.cpp:1090-1150, :1246-1287): Kruskal-order
     merges with the reference's union-by-rank DSU; distinct weights, so the sort order is unambiguous."""

@@ -391,11 +391,11 @@ def test_clust_greedy_fast_append(oracle, tmp_path):
     assert all(seqnames[i][1] == "N/A" for i in listed if i < len(pre) + half)          # src/MST_IO.cpp:99-104
     assert all(seqnames[i][1] != "N/A" for i in listed if i >= len(pre) + half)
     assert [seqnames[i][0] for i in listed] == [paths[order[i]] for i in listed]
-    # usage errors (src/main.cpp:378-381) and the MinHash flow, which is not offered
+    # usage errors (src/main.cpp:378-381); without --fast the MinHash flow looks for hash.sketch in the KSSD folder
     r = subprocess.run([os.path.join(BIN, "clust-greedy"), "--fast", "-l", "--append", lb, "-o", out], capture_output=True, text=True)
     assert r.returncode != 0 and "--presketched needed" in r.stderr
     r = subprocess.run([os.path.join(BIN, "clust-greedy"), "-l", "--presketched", folder, "--append", lb, "-o", out], capture_output=True, text=True)
-    assert r.returncode != 0 and "MinHash" in r.stderr
+    assert r.returncode != 0 and "hash.sketch" in r.stderr
 
 
 def _read_repdb(path):
@@ -1076,3 +1076,80 @@ def _parse_seq_clusters(path):
         elif ln.startswith("\t"):
             cur.append(int(ln.split("\t")[2]))
     return clusters
+
+
+def test_packed_staging_unpack_kernel_and_cli_identity(ctx, oracle, tmp_path):
+    """(1) rtc_unpack_bases_dev against its restatement on a packed batch with runs at every alignment.
+    (2) The command lines stage 2-bit packed bases by default: hash.sketch / kssd.hash.sketch / edge.mst / the cluster
+    text must be byte-identical to the RTC_STAGE_ASCII=1 run on genomes with N runs, IUPAC codes, lower case,
+    several records, CRLF line ends and a gzip member, over several small batches."""
+    import ctypes as C
+    import gzip
+    import torch
+    from rabbittclust_amd import _lib
+    rng = np.random.default_rng(11)
+    n = 64 * 2000
+    packed = rng.integers(0, 256, size=n // 4, dtype=np.uint8)
+    starts = np.sort(rng.choice(n - 200, size=400, replace=False))
+    runs = []
+    for st_ in starts:
+        ln = int(rng.integers(1, 130))
+        if runs and runs[-2] + runs[-1] >= st_:
+            continue
+        runs += [int(st_), ln]
+    runs += [n - 64, 64]
+    d_p = torch.from_numpy(packed).to(ctx.device)
+    d_r = torch.from_numpy(np.array(runs, dtype=np.uint64).view(np.int64)).to(ctx.device)
+    d_o = torch.zeros(n, dtype=torch.uint8, device=ctx.device)
+    ctx.check(ctx.lib.rtc_unpack_bases_dev(ctx.h, C.c_void_p(d_p.data_ptr()), n, C.c_void_p(d_r.data_ptr()), len(runs) // 2, C.c_void_p(d_o.data_ptr())))
+    ctx.sync()
+    codes = np.stack([(packed >> (2 * b)) & 3 for b in range(4)], axis=1).reshape(-1)
+    want = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].copy()
+    for st_, ln in zip(runs[0::2], runs[1::2]):
+        want[st_:st_ + ln] = ord("N")
+    assert np.array_equal(d_o.cpu().numpy(), want)
+    assert ctx.lib.rtc_unpack_bases_dev(ctx.h, C.c_void_p(d_p.data_ptr()), 100, None, 0, C.c_void_p(d_o.data_ptr())) == _lib.RTC_ERR_ARG
+    # ---- command lines ----
+    tmp = str(tmp_path)
+    L = 1_900_000
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 3, 4, L, seed=91, two_records=True)
+    for g, p in enumerate(paths):   # damage the files: N runs, IUPAC codes, lower case, CRLF, one gzip
+        raw = bytearray(open(p, "rb").read())
+        body = [i for i, c in enumerate(raw) if c in b"ACGT"]
+        sel = rng.choice(len(body), size=40, replace=False)
+        for j in sel[:25]:
+            a = body[j]
+            for q in range(a, min(a + int(rng.integers(1, 90)), len(raw))):
+                if raw[q] in b"ACGT":
+                    raw[q] = ord("N")
+        for j in sel[25:]:
+            raw[body[j]] = int(rng.choice(np.frombuffer(b"RYKMSWn", dtype=np.uint8)))
+        low = rng.random(len(raw)) < (0.3 if g % 2 else 0.0)
+        for q in np.nonzero(low)[0]:
+            if raw[q] in b"ACGT":
+                raw[q] |= 0x20
+        data = bytes(raw).replace(b"\n", b"\r\n") if g == 1 else bytes(raw)
+        if g == 2:
+            p2 = p + ".gz"
+            with gzip.GzipFile(p2, "wb", mtime=0) as f:
+                f.write(data)
+            paths[g] = p2
+        else:
+            open(p, "wb").write(data)
+    open(lst, "w").write("\n".join(paths) + "\n")
+    for tool, extra in (("clust-mst", ["-s", "500"]), ("clust-mst", ["--fast"]), ("clust-greedy", ["-c", "1000"])):
+        outs = {}
+        for tag, env in (("packed", {}), ("ascii", {"RTC_STAGE_ASCII": "1"})):
+            d = os.path.join(tmp, tool + extra[0].strip("-") + tag)
+            os.makedirs(d)
+            out = os.path.join(d, "res.out")
+            r = subprocess.run([os.path.join(BIN, tool), "-l", "-i", lst, "-k", "21", "-d", "0.05", "-t", "4", "-o", out] + extra, cwd=d,
+                               capture_output=True, text=True, timeout=600, env=dict(os.environ, RTC_BATCH_BYTES=str(5 << 20), **env))
+            assert r.returncode == 0, r.stderr[-2000:]
+            folder = [os.path.join(d, x) for x in os.listdir(d) if os.path.isdir(os.path.join(d, x))][0]
+            files = sorted(f for f in os.listdir(folder))
+            outs[tag] = (open(out).read(), {f: open(os.path.join(folder, f), "rb").read() for f in files})
+        assert outs["packed"][0] == outs["ascii"][0], (tool, extra)
+        assert outs["packed"][1].keys() == outs["ascii"][1].keys()
+        for f in outs["packed"][1]:
+            assert outs["packed"][1][f] == outs["ascii"][1][f], (tool, extra, f)

@@ -30,7 +30,7 @@ for binname, extra in (("clust-mst", ["-s", "1000"]), ("clust-mst", ["--fast"]),
     r = subprocess.run(["env", "RTC_VERBOSE=1", os.path.join(root, "rabbittclust_amd", "bin", binname), "-l", "-i", os.path.join(tmp, "list.txt"), "-k", "21",
                         "-d", "0.05", "-e", "-o", os.path.join(tmp, "out.cluster")] + extra, capture_output=True, text=True, cwd=tmp)
     dt = time.time() - t0
-    lines = [ln for ln in r.stderr.splitlines() if "time of" in ln or "cluster number" in ln or ln.startswith(("[gpu", "[plan]", "[init]", "[free]", "[tune]", "[share]", "[mst", "[ctx]", "[exit]"))]
+    lines = [ln for ln in r.stderr.splitlines() if "time of" in ln or "cluster number" in ln or ln.startswith(("[gpu", "[parse]", "[plan]", "[init]", "[free]", "[tune]", "[share]", "[mst", "[ctx]", "[exit]"))]
     print(binname, " ".join(extra), f"rc={r.returncode} wall={dt:.2f}s  {n * L / dt / 1e9:.2f} Gbp/s end-to-end from files", flush=True)
     for ln in lines:
         print("   ", ln)
