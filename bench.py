@@ -207,16 +207,16 @@ def extra_workloads(args, ctx, api, pipeline):
         algo = float(n) * L + float(sk.len.sum().item()) * sk.width
         ach = algo / (ph["sketch_ms"] * 1e-3) / 1e9
         wl = {"genomes": n, "length": L, "k": args.k, "s": args.s, "mode": "kssd"}
-        traffic, src = measured_traffic("sketch_kssd_bucket_kernel", wl)
+        traffic, src = measured_traffic("sketch_kssd_bloom_kernel", wl)
         pairs = n * (n - 1) // 2
         out["kssd"] = {
             "workload": f"{n} x {L} bp synthetic genomes, KSSD --fast k={args.k} drlevel={args.drlevel}, sketch + all-pairs + MST",
             "steps": steps, "ms_per_step": dt * 1e3, "genome_pairs_per_sec": pairs / dt, "dtype": "u64" if sk.width == 8 else "u32",
             "sketch_gbp_per_sec": float(n) * L / (ph["sketch_ms"] * 1e-3) / 1e9, "mean_sketch_size": float(sk.len.float().mean().item()),
             "phase_ms": ph, "mst_edges": int(ph["mst_edges"]),
-            "roofline": {"bound": "hbm", "kernel": "sketch_kssd_bucket_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "sketch_kssd_bloom_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "1 B/base + %d B/hash out over the whole sketch phase (bucket kernel + sort/dedup + capacity read-back); "
+                         "note": "1 B/base + %d B/hash out over the whole sketch phase (prefilter kernel + sort/dedup + capacity read-back); "
                                  "traffic from profiles/%s" % (sk.width, src)},
         }
         del seq, pipe, sk
@@ -399,7 +399,7 @@ def main():
         dist_pairs_local = ph["pairs_local"]
         dist_algo = dist_pairs_local * 2 * avg_len * width / (ph["pair_ms"] * 1e-3) / 1e9
         wl = {"genomes": n_local, "length": length, "k": args.k, "s": args.s, "mode": mode}
-        sk_kernel = "sketch_minhash_kernel" if mode == "minhash" else "sketch_kssd_bucket_kernel"
+        sk_kernel = "sketch_minhash_kernel" if mode == "minhash" else "sketch_kssd_bloom_kernel"
         sk_traffic, sk_src = measured_traffic(sk_kernel, wl)
         pr_traffic, pr_src = measured_traffic("pair_tiled_kernel", wl)
         pr_ach = pr_traffic / (ph["pair_ms"] * 1e-3) / 1e9 if pr_traffic else None
