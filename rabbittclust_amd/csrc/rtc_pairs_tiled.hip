@@ -383,46 +383,36 @@ __global__ __launch_bounds__(TW, TW == 1024 ? 1 : 2) void pair_tiled_kernel(cons
   }
 }
 
+// so[p][g] = lower_bound(sketch g, bound[p]) for p = 0..P (so[0] = 0, so[P] = len).  One lane per (p, g), p < P,
+// computes both ends of slice p, writes so[p][g] (and so[P][g] from the last partition) and folds the slice length
+// into pmax[p] (maximum over the columns [c0, c1): sizes the transposed copy) and amax[0] (maximum over every sketch
+// and partition: a single slice must fit one table build).
 template <typename T>
-__global__ void slice_offsets_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
-                                     const uint32_t* __restrict__ len, const T* __restrict__ bounds, int P,
-                                     uint32_t n, uint32_t* __restrict__ so) {
-  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (uint64_t)n * (P + 1)) return;
-  const uint32_t p = (uint32_t)(idx / n), g = (uint32_t)(idx % n);
-  const uint32_t L = len[g];
-  uint32_t r;
-  if (p == 0) r = 0;
-  else if (p == (uint32_t)P) r = L;
-  else {
-    const T* a = hashes + start[g];
-    const T b = bounds[p];
-    uint32_t lo = 0, hi = L;
-    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (a[mid] < b) lo = mid + 1; else hi = mid; }
-    r = lo;
-  }
-  so[(size_t)p * n + g] = r;
-}
-
-// per-partition maximum slice length: pmax[p] over the columns [c0, c1) (sizes the transposed copy),
-// amax[0] over every sketch and partition (a single slice must fit one table build); grid.y = partition
-__global__ __launch_bounds__(256) void partition_max_kernel(const uint32_t* __restrict__ so, int P, uint32_t n,
-                                                            uint32_t c0, uint32_t c1, uint32_t* __restrict__ amax,
-                                                            uint32_t* __restrict__ pmax) {
+__global__ __launch_bounds__(256) void slice_offsets_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
+                                                            const uint32_t* __restrict__ len, const T* __restrict__ bounds, int P,
+                                                            uint32_t n, uint32_t c0, uint32_t c1, uint32_t* __restrict__ so,
+                                                            uint32_t* __restrict__ amax, uint32_t* __restrict__ pmax) {
   const uint32_t p = blockIdx.y;
-  uint32_t v = 0, a = 0;
-  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
-    const uint32_t d = so[(size_t)(p + 1) * n + g] - so[(size_t)p * n + g];
-    a = max(a, d);
-    if (g >= c0 && g < c1) v = max(v, d);
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t d = 0, dc = 0;
+  if (g < n) {
+    const uint32_t L = len[g];
+    const T* a = hashes + start[g];
+    auto lb = [&](T b) { uint32_t lo = 0, hi = L; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < b) lo = mid + 1; else hi = mid; } return lo; };
+    const uint32_t lo = p == 0 ? 0u : lb(bounds[p]);
+    const uint32_t hi = p + 1 == (uint32_t)P ? L : lb(bounds[p + 1]);
+    so[(size_t)p * n + g] = lo;
+    if (p + 1 == (uint32_t)P) so[(size_t)P * n + g] = L;
+    d = hi - lo;
+    dc = (g >= c0 && g < c1) ? d : 0;
   }
   for (int o = 32; o > 0; o >>= 1) {
-    v = max(v, (uint32_t)__shfl_xor((int)v, o));
-    a = max(a, (uint32_t)__shfl_xor((int)a, o));
+    d = max(d, (uint32_t)__shfl_xor((int)d, o));
+    dc = max(dc, (uint32_t)__shfl_xor((int)dc, o));
   }
   if ((threadIdx.x & 63) == 0) {
-    if (v) atomicMax(&pmax[p], v);
-    if (a) atomicMax(amax, a);
+    if (dc) atomicMax(&pmax[p], dc);
+    if (d) atomicMax(amax, d);
   }
 }
 
@@ -441,10 +431,11 @@ __global__ void transpose_slices_kernel(const T* __restrict__ hashes, const uint
   for (uint32_t e = 0; e < hi - lo; e++) dst[(size_t)e * tnc] = src[e];
 }
 
-// planning inputs in one launch: sum / max of the sketch lengths and SAMPLE_PER evenly spaced
-// hashes from each of up to SAMPLE_SK evenly spaced sketches (quantiles -> partition bounds)
+// planning inputs in one launch: sum / max of the sketch lengths and SAMPLE_PER evenly spaced hashes from each of
+// up to SAMPLE_SK evenly spaced sketches (quantiles -> partition bounds).  Block i < ns samples sketch i; the sample
+// buffer is strided (SAMPLE_PER per sketch, nsamples[i] of them valid) and compacted on the host.
 constexpr int SAMPLE_SK = 64;
-constexpr int SAMPLE_PER = 256;
+constexpr int SAMPLE_PER = 64;
 struct PlanStats { unsigned long long total; uint32_t lmax; uint32_t pad; };
 
 template <typename T>
@@ -459,18 +450,14 @@ __global__ __launch_bounds__(256) void plan_stats_kernel(const T* __restrict__ h
     mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
   }
   if ((threadIdx.x & 63) == 0) { if (sum) atomicAdd(&stats->total, sum); if (mx) atomicMax(&stats->lmax, mx); }
-  if (blockIdx.x == 0) {  // every thread derives the same running offset from len[], no atomics needed
-    const uint32_t ns = min(n, (uint32_t)SAMPLE_SK);
-    uint32_t base = 0;
-    for (uint32_t i = 0; i < ns; i++) {
-      const uint32_t g = (uint32_t)((uint64_t)i * n / ns);
-      const uint32_t L = len[g];
-      const uint32_t take = min(L, (uint32_t)SAMPLE_PER);
-      for (uint32_t t = threadIdx.x; t < take; t += blockDim.x)
-        samples[base + t] = hashes[start[g] + (uint64_t)t * L / take];
-      base += take;
-    }
-    if (threadIdx.x == 0) *nsamples = base;
+  const uint32_t ns = min(n, (uint32_t)SAMPLE_SK);
+  if (blockIdx.x < ns) {
+    const uint32_t g = (uint32_t)((uint64_t)blockIdx.x * n / ns);
+    const uint32_t L = len[g];
+    const uint32_t take = min(L, (uint32_t)SAMPLE_PER);
+    for (uint32_t t = threadIdx.x; t < take; t += blockDim.x)
+      samples[blockIdx.x * SAMPLE_PER + t] = hashes[start[g] + (uint64_t)t * L / take];
+    if (threadIdx.x == 0) nsamples[blockIdx.x] = take;
   }
 }
 
@@ -522,20 +509,27 @@ int build_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
   // ---- planning inputs: one kernel, one small read-back ----
   void* wsp = nullptr;
   const size_t bsamp = (size_t)SAMPLE_SK * SAMPLE_PER * sizeof(T);
-  RTC_TRY(rtc_ws(ctx, 0, sizeof(PlanStats) + 8 + bsamp + 64, &wsp));
+  const size_t bhead = sizeof(PlanStats) + (size_t)SAMPLE_SK * 4;  // stats + per-sketch sample counts (a multiple of 8)
+  RTC_TRY(rtc_ws(ctx, 0, bhead + bsamp + 64, &wsp));
   PlanStats* d_stats = (PlanStats*)wsp;
   uint32_t* d_ns = (uint32_t*)((char*)wsp + sizeof(PlanStats));
-  T* d_samples = (T*)((char*)wsp + sizeof(PlanStats) + 8);
-  RTC_HIP(ctx, hipMemsetAsync(wsp, 0, sizeof(PlanStats) + 8, ctx->stream));
-  hipLaunchKernelGGL(plan_stats_kernel<T>, dim3(std::min<uint32_t>((n + 255) / 256, 256)), dim3(256), 0, ctx->stream,
-                     d_hashes, d_start, d_len, n, d_stats, d_samples, d_ns);
+  T* d_samples = (T*)((char*)wsp + bhead);
+  RTC_HIP(ctx, hipMemsetAsync(wsp, 0, bhead, ctx->stream));
+  hipLaunchKernelGGL(plan_stats_kernel<T>, dim3(std::max<uint32_t>(std::min<uint32_t>((n + 255) / 256, 256), std::min<uint32_t>(n, SAMPLE_SK))), dim3(256), 0,
+                     ctx->stream, d_hashes, d_start, d_len, n, d_stats, d_samples, d_ns);
   RTC_CHECK_LAUNCH(ctx);
   void* hpin = nullptr;
-  RTC_TRY(rtc_pinned(ctx, sizeof(PlanStats) + 8 + bsamp + 64 + (size_t)(MAXP + 1) * 8, &hpin));
-  RTC_HIP(ctx, hipMemcpyAsync(hpin, wsp, sizeof(PlanStats) + 8 + bsamp, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_TRY(rtc_pinned(ctx, bhead + bsamp + 64 + (size_t)(MAXP + 1) * 8, &hpin));
+  RTC_HIP(ctx, hipMemcpyAsync(hpin, wsp, bhead + bsamp, hipMemcpyDeviceToHost, ctx->stream));
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const PlanStats hst = *(const PlanStats*)hpin;
-  const uint32_t nsamp = *(const uint32_t*)((const char*)hpin + sizeof(PlanStats));
+  std::vector<T> sample;
+  {
+    const uint32_t* h_ns = (const uint32_t*)((const char*)hpin + sizeof(PlanStats));
+    const T* h_s = (const T*)((const char*)hpin + bhead);
+    for (int i = 0; i < SAMPLE_SK; i++) sample.insert(sample.end(), h_s + (size_t)i * SAMPLE_PER, h_s + (size_t)i * SAMPLE_PER + std::min<uint32_t>(h_ns[i], SAMPLE_PER));
+  }
+  const uint32_t nsamp = (uint32_t)sample.size();
   const uint64_t tot = hst.total;
   const uint32_t lmax = hst.lmax;
   if (tot == 0 || lmax >= (1u << 20) || nsamp == 0) return RTC_OK;  // nothing to gain / counters too wide: merge path
@@ -544,10 +538,8 @@ int build_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
   if (const char* e = getenv("RTC_PAIR_KTARGET")) { const int v = atoi(e); if (v >= 256 && v <= (int)KCAP_HARD) ktarget = (uint32_t)v; }  // tuning experiments
   int P = 1;
   while (P < MAXP && (double)ROWS * avg / P > ktarget) P <<= 1;
-  std::vector<T> sample((const T*)((const char*)hpin + sizeof(PlanStats) + 8),
-                        (const T*)((const char*)hpin + sizeof(PlanStats) + 8) + nsamp);
   std::sort(sample.begin(), sample.end());
-  T* h_bounds_pin = (T*)((char*)hpin + sizeof(PlanStats) + 8 + bsamp + 64 - ((sizeof(PlanStats) + 8 + bsamp + 64) % 8));
+  T* h_bounds_pin = (T*)((char*)hpin + bhead + bsamp + 64 - ((bhead + bsamp + 64) % 8));
   const uint32_t tnc = tc1 - tc0;
 
   // Memory budget of the transposed copy: sum_p(pmax[p]) * tnc elements.  With even lengths it is
@@ -574,12 +566,8 @@ int build_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
     memcpy(h_bounds_pin, bounds.data(), bb);
     RTC_HIP(ctx, hipMemcpyAsync(d_bounds, h_bounds_pin, bb, hipMemcpyHostToDevice, ctx->stream));
     RTC_HIP(ctx, hipMemsetAsync(d_max, 0, (size_t)(P + 1) * 4, ctx->stream));
-    const uint64_t work = (uint64_t)n * (P + 1);
-    hipLaunchKernelGGL(slice_offsets_kernel<T>, dim3((uint32_t)((work + 255) / 256)), dim3(256), 0, ctx->stream,
-                       d_hashes, d_start, d_len, d_bounds, P, n, d_so);
-    RTC_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(partition_max_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 64), (uint32_t)P), dim3(256), 0,
-                       ctx->stream, d_so, P, n, tc0, tc1, d_max, d_pmax);
+    hipLaunchKernelGGL(slice_offsets_kernel<T>, dim3((n + 255) / 256, (uint32_t)P), dim3(256), 0, ctx->stream, d_hashes, d_start, d_len, d_bounds,
+                       P, n, tc0, tc1, d_so, d_max, d_pmax);
     RTC_CHECK_LAUNCH(ctx);
     std::vector<uint32_t> h_maxes(P + 1);
     RTC_HIP(ctx, hipMemcpyAsync(h_maxes.data(), d_max, (size_t)(P + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
