@@ -163,6 +163,9 @@ def cpu_baseline(args, mode, seq, off, sketches_host, shuffled):
     return {
         "value": pairs / t_mst, "unit": "genome-pairs/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
         "sketch_gbp_per_sec": ns * L / t_sk / 1e9,
+        "note": "value = pairs of the sample / time of the reference's INDEX-based MST on it: that algorithm only touches pairs "
+                "that share a hash, so its rate depends on the data and on the sample size and is not comparable pair for pair "
+                "with the GPU's dense N^2 rate; sketch_gbp_per_sec is the like-for-like figure of the phase that dominates the step",
         "sample": (f"sketch: {ns} x {L} bp genomes in {t_sk:.2f}s on {cores} threads (OpenMP over genomes, {impl}; "
                    f"ours -- RabbitSketch's AVX2 kernel is absent from the reference tree); "
                    f"distance: index-based compute_{'minhash' if mode == 'minhash' else 'kssd'}_mst restatement on "
