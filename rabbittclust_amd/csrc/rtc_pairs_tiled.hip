@@ -383,27 +383,37 @@ __global__ __launch_bounds__(TW, TW == 1024 ? 1 : 2) void pair_tiled_kernel(cons
   }
 }
 
-// so[p][g] = lower_bound(sketch g, bound[p]) for p = 0..P (so[0] = 0, so[P] = len).  One lane per (p, g), p < P,
-// computes both ends of slice p, writes so[p][g] (and so[P][g] from the last partition) and folds the slice length
-// into pmax[p] (maximum over the columns [c0, c1): sizes the transposed copy) and amax[0] (maximum over every sketch
-// and partition: a single slice must fit one table build).
+// so[p][g] = lower_bound(sketch g, bound[p]) for p = 0..P (so[0] = 0, so[P] = len): one lane per (p, g)
 template <typename T>
 __global__ __launch_bounds__(256) void slice_offsets_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
                                                             const uint32_t* __restrict__ len, const T* __restrict__ bounds, int P,
-                                                            uint32_t n, uint32_t c0, uint32_t c1, uint32_t* __restrict__ so,
-                                                            uint32_t* __restrict__ amax, uint32_t* __restrict__ pmax) {
+                                                            uint32_t n, uint32_t* __restrict__ so) {
+  const uint32_t p = blockIdx.y;  // 0 .. P
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const uint32_t L = len[g];
+  uint32_t r;
+  if (p == 0) r = 0;
+  else if (p == (uint32_t)P) r = L;
+  else {
+    const T* a = hashes + start[g];
+    const T b = bounds[p];
+    uint32_t lo = 0, hi = L;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < b) lo = mid + 1; else hi = mid; }
+    r = lo;
+  }
+  so[(size_t)p * n + g] = r;
+}
+
+// slice lengths: pmax[p] = maximum over the columns [c0, c1) (sizes the transposed copy), amax[0] = maximum over every
+// sketch and partition (a single slice must fit one table build); one lane per (p, g), coalesced over g
+__global__ __launch_bounds__(256) void slice_max_kernel(const uint32_t* __restrict__ so, uint32_t n, uint32_t c0, uint32_t c1,
+                                                        uint32_t* __restrict__ amax, uint32_t* __restrict__ pmax) {
   const uint32_t p = blockIdx.y;
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t d = 0, dc = 0;
   if (g < n) {
-    const uint32_t L = len[g];
-    const T* a = hashes + start[g];
-    auto lb = [&](T b) { uint32_t lo = 0, hi = L; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < b) lo = mid + 1; else hi = mid; } return lo; };
-    const uint32_t lo = p == 0 ? 0u : lb(bounds[p]);
-    const uint32_t hi = p + 1 == (uint32_t)P ? L : lb(bounds[p + 1]);
-    so[(size_t)p * n + g] = lo;
-    if (p + 1 == (uint32_t)P) so[(size_t)P * n + g] = L;
-    d = hi - lo;
+    d = so[(size_t)(p + 1) * n + g] - so[(size_t)p * n + g];
     dc = (g >= c0 && g < c1) ? d : 0;
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -566,8 +576,10 @@ int build_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
     memcpy(h_bounds_pin, bounds.data(), bb);
     RTC_HIP(ctx, hipMemcpyAsync(d_bounds, h_bounds_pin, bb, hipMemcpyHostToDevice, ctx->stream));
     RTC_HIP(ctx, hipMemsetAsync(d_max, 0, (size_t)(P + 1) * 4, ctx->stream));
-    hipLaunchKernelGGL(slice_offsets_kernel<T>, dim3((n + 255) / 256, (uint32_t)P), dim3(256), 0, ctx->stream, d_hashes, d_start, d_len, d_bounds,
-                       P, n, tc0, tc1, d_so, d_max, d_pmax);
+    hipLaunchKernelGGL(slice_offsets_kernel<T>, dim3((n + 255) / 256, (uint32_t)P + 1), dim3(256), 0, ctx->stream, d_hashes, d_start, d_len,
+                       d_bounds, P, n, d_so);
+    RTC_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(slice_max_kernel, dim3((n + 255) / 256, (uint32_t)P), dim3(256), 0, ctx->stream, d_so, n, tc0, tc1, d_max, d_pmax);
     RTC_CHECK_LAUNCH(ctx);
     std::vector<uint32_t> h_maxes(P + 1);
     RTC_HIP(ctx, hipMemcpyAsync(h_maxes.data(), d_max, (size_t)(P + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
