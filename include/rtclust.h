@@ -190,6 +190,11 @@ int rtc_boruvka_union_dev(rtc_ctx* ctx, uint32_t n, uint32_t s_fixed, const uint
                           const uint32_t* d_ecommon, uint32_t* d_comp, uint32_t* d_succ, rtc_cedge* d_sel,
                           uint64_t* d_nsel, uint32_t* h_added);
 
+/* All rounds on ONE GPU behind one call: the minimum spanning forest (kruskalAlgorithm's result, src/MST.cpp:59-75) of
+ * a device-resident candidate list.  d_sel: n entries; *h_n_sel edges are written; h_rounds may be NULL.  Synchronous. */
+int rtc_msf_dev(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_len, uint32_t n, int is_containment,
+                rtc_cedge* d_sel, uint64_t* h_n_sel, int* h_rounds);
+
 /* Host helper closing one Boruvka round: unions the components joined by the winning edges
  * (h_ekey[c] = i<<32|j or 0x7FFF...F for none), appends them to h_sel (capacity n) and relabels
  * h_comp[v] with the new root vertex ids.  *h_added == 0 means the forest is complete. */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "rtc_boruvka_minweight_dev": (_i, [_vp, _vp, _u64, _vp, _i, _vp, _u32, _vp]),
     "rtc_boruvka_minedge_dev": (_i, [_vp, _vp, _u64, _vp, _i, _vp, _u32, _vp, _vp]),
     "rtc_boruvka_fetch_dev": (_i, [_vp, _vp, _u64, _vp, _u32, _vp, _vp]),
+    "rtc_msf_dev": (_i, [_vp, _vp, _u64, _vp, _u32, _i, _vp, C.POINTER(_u64), C.POINTER(_i)]),
     "rtc_boruvka_merge_host": (_i, [_u32, _vp, _vp, _vp, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rtc_edges_to_mst_host": (_i, [_vp, _u64, _vp, _i, _i, _vp]),
     "rtc_comm_unique_id": (_i, [_vp]),

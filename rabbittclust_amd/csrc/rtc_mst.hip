@@ -429,6 +429,15 @@ uint32_t rtc_fixed_size_of(const uint32_t* h_len, uint32_t n) {
 }
 
 namespace {
+__global__ __launch_bounds__(256) void minmax_u32_kernel(const uint32_t* __restrict__ a, uint32_t n, uint32_t* __restrict__ mm) {
+  uint32_t lo = 0xffffffffu, hi = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { lo = min(lo, a[i]); hi = max(hi, a[i]); }
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
+  if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
+}
+}  // namespace
+
+namespace {
 // every pair (row, col < row) of a dense tile becomes an edge (the dense loop has no filters): edge of (row, col) at
 // base + row (row - 1) / 2 - row0 (row0 - 1) / 2 + col
 __global__ __launch_bounds__(256) void all_pairs_edges_kernel(const uint32_t* __restrict__ common, uint64_t ld, uint32_t row0,
@@ -806,6 +815,30 @@ int rtc_mst_mash(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* 
   });
   *h_n_edges = nsel;
   return RTC_OK;
+}
+
+// The forest of a device-resident candidate list on ONE GPU: all Boruvka rounds behind one call (the per-round
+// primitives above remain for hosts that bring their own collectives).  d_sel: n entries; *h_n_sel edges are written.
+int rtc_msf_dev(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_len, uint32_t n, int is_containment,
+                rtc_cedge* d_sel, uint64_t* h_n_sel, int* h_rounds) {
+  if (!ctx || !d_len || !d_sel || !h_n_sel || (m && !d_edges)) return RTC_ERR_ARG;
+  *h_n_sel = 0;
+  if (h_rounds) *h_rounds = 0;
+  if (n < 2) return RTC_OK;
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  // equal sketch sizes (and a key that fits): one fused key per component and round
+  void* ws = nullptr;
+  RTC_TRY(rtc_ws(ctx, 5, 256, &ws));
+  uint32_t* d_mm = (uint32_t*)ws;
+  RTC_HIP(ctx, hipMemsetAsync(d_mm, 0xff, 4, ctx->stream));
+  RTC_HIP(ctx, hipMemsetAsync(d_mm + 1, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(minmax_u32_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 256)), dim3(256), 0, ctx->stream, d_len, n, d_mm);
+  RTC_CHECK_LAUNCH(ctx);
+  uint32_t mm[2] = {0, 0};
+  RTC_HIP(ctx, hipMemcpyAsync(mm, d_mm, 8, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t s_fixed = (mm[0] == mm[1] && mm[0] > 0 && rtc_boruvka_key_bits(n, mm[0])) ? mm[0] : 0;
+  return rtc_msf_device(ctx, d_edges, m, d_len, n, is_containment, s_fixed, nullptr, d_sel, h_n_sel, h_rounds);
 }
 
 }  // extern "C"

@@ -173,6 +173,7 @@ class MstPipeline:
         self.last_mst = None
         self._edge_cap = 1 << 20
         self._edges = None
+        self._sel = None
 
     # ---- pieces ---------------------------------------------------------------------------------
     def _check_equal_counts(self, n_local):
@@ -322,6 +323,15 @@ class MstPipeline:
         return int(mm[0]) if self.ctx.lib.rtc_boruvka_key_bits(sk.n, int(mm[0])) else 0
 
     def boruvka(self, sk, edges, m):
+        if not self.comm.active:  # one GPU: all rounds behind one C call (rtc_msf_dev)
+            ctx = self.ctx
+            if self._sel is None or self._sel.shape[0] < max(sk.n, 1):
+                self._sel = torch.empty((max(sk.n, 1), 3), dtype=torch.int32, device=ctx.device)
+            nsel, rounds = C.c_uint64(), C.c_int()
+            ctx.check(ctx.lib.rtc_msf_dev(ctx.h, _t_ptr(edges), m, _t_ptr(sk.len), sk.n, int(self.is_containment), _t_ptr(self._sel),
+                                          C.byref(nsel), C.byref(rounds)))
+            sel = np.ascontiguousarray(self._sel[:nsel.value].cpu().numpy().view(np.uint32)).view(CEDGE_DT).reshape(-1)
+            return sel, int(rounds.value)
         backend = HipBoruvkaBackend(self.ctx, sk, edges, m, self.is_containment)
         return boruvka_rounds(backend, sk.n, self.comm, self.fixed_size(sk))
 
