@@ -1,0 +1,402 @@
+// rtc_pairs_join.hip -- candidate edges of a lower-triangle tile by an inverted join on the device.
+//
+// The reference finds |A_i ∩ A_j| through an inverted index hash -> genomes (src/MST.cpp:1408-1435,
+// :428-487): only pairs that share a hash are ever touched.  This is the same computation laid out for a
+// GPU: the index is a sort.
+//   1. flatten   every hash of the genomes [g0, g1) with its genome id            (one streaming pass)
+//   2. sort      (hash, genome) by hash -- stable, so genomes ascend inside a posting list   (radix sort)
+//   3. count     element a of a posting list pairs with the later elements of the list whose genome is a
+//                row of the tile; the list end is found by galloping on the sorted hashes
+//   4. emit      one 64-bit code (row << bits | col) per co-occurrence
+//   5. sort      the codes on their 2*bits significant bits                        (radix sort)
+//   6. encode    run lengths of equal codes = |A_row ∩ A_col|                      (run-length encode)
+//   7. filter    the reference's candidate filters (src/MST.cpp:1468-1487) -> (i, j, common) triples
+// Results are the integers the tiled kernel (rtc_pairs_tiled.hip) produces for the same tile, pair for pair;
+// the cost is O(hashes + co-occurrences) instead of O(rows * cols * s / 64).  The tiled kernel stays the
+// general path: it is taken when the co-occurrence count (known exactly after step 3) would make the join the
+// slower of the two (many near-identical genomes: posting lists of thousands), when the scratch would not fit,
+// and by callers that hold a tiled plan across launches.  Sorting, scanning and run-length encoding are
+// rocPRIM device primitives; the kernels around them are below.
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+
+#include "rtc_internal.h"
+
+namespace {
+
+struct U32ToU64 {
+  __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; }
+};
+
+// largest hash of the genomes [g0, g0 + ng): sketches ascend, so it is the largest last element
+template <typename T>
+__global__ __launch_bounds__(256) void join_maxkey_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
+                                                          const uint32_t* __restrict__ len, uint32_t g0, uint32_t ng,
+                                                          unsigned long long* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long m = 0;
+  if (i < ng) { const uint32_t L = len[g0 + i]; if (L) m = (unsigned long long)hashes[start[g0 + i] + L - 1]; }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// keys[off[g - g0] + e] = element e of sketch g, vals[...] = g; one workgroup per genome
+template <typename T>
+__global__ __launch_bounds__(256) void join_flatten_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
+                                                           const uint32_t* __restrict__ len, const uint64_t* __restrict__ off,
+                                                           uint32_t g0, T* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t g = g0 + blockIdx.x;
+  const uint32_t L = len[g];
+  const T* src = hashes + start[g];
+  const uint64_t o = off[blockIdx.x];
+  for (uint32_t e = threadIdx.x; e < L; e += blockDim.x) { keys[o + e] = src[e]; vals[o + e] = g; }
+}
+
+// 64-bit hashes are sorted on their 32 most significant bits that vary only (half the radix passes; bottom-s MinHash
+// values are small, the bits above the largest hash are skipped as well).  Distinct hashes that agree in those bits
+// end up in one run in input order; such a run is out of order somewhere, which is what this kernel
+// looks for (a few per million hashes).  fix[0] = inversions found, fix[1] = "could not repair", fix[2..] = positions.
+constexpr uint32_t FIX_CAP = 1u << 16;
+constexpr uint32_t FIX_RUN_MAX = 2048;
+__global__ __launch_bounds__(256) void join_inversions_kernel(const uint64_t* __restrict__ ks, uint32_t K, int sh, uint32_t* __restrict__ fix) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a + 1 >= K) return;
+  if ((ks[a] >> sh) > (ks[a + 1] >> sh)) fix[1] = 1;  // not sorted on the bits asked for: never seen, never trusted
+  if (ks[a] > ks[a + 1]) {
+    const uint32_t i = atomicAdd(&fix[0], 1u);
+    if (i < FIX_CAP) fix[2 + i] = a;
+  }
+}
+
+// One lane per inversion.  First (read-only) pass: is this the first inversion of its run?  The others are struck
+// out (bit 31).  Second pass: the remaining lanes each sort their run by the full hash with a stable insertion
+// sort (two or three posting lists interleaved, rarely more than a few dozen elements); the runs are disjoint.
+__global__ __launch_bounds__(64) void join_repair_owner_kernel(const uint64_t* __restrict__ ks, int sh, uint32_t* __restrict__ fix) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nf = fix[0];
+  if (nf > FIX_CAP) { if (i == 0) fix[1] = 1; return; }
+  if (i >= nf) return;
+  const uint32_t a = fix[2 + i];
+  const uint64_t pre = ks[a] >> sh;
+  uint32_t s = a;
+  while (s > 0 && (ks[s - 1] >> sh) == pre) {
+    s--;
+    if (a - s > FIX_RUN_MAX) { fix[1] = 1; return; }
+    if (ks[s] > ks[s + 1]) { fix[2 + i] = a | 0x80000000u; return; }  // an earlier inversion of the same run
+  }
+}
+__global__ __launch_bounds__(64) void join_repair_kernel(uint64_t* __restrict__ ks, uint32_t* __restrict__ vs, uint32_t K, int sh,
+                                                         uint32_t* __restrict__ fix) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nf = fix[0];
+  if (nf > FIX_CAP || fix[1] || i >= nf) return;
+  const uint32_t a = fix[2 + i];
+  if (a & 0x80000000u) return;
+  const uint64_t pre = ks[a] >> sh;
+  uint32_t s = a;
+  while (s > 0 && (ks[s - 1] >> sh) == pre) s--;
+  uint32_t e = a + 1;
+  while (e < K && (ks[e] >> sh) == pre) {
+    e++;
+    if (e - s > FIX_RUN_MAX) { fix[1] = 1; return; }
+  }
+  for (uint32_t x = s + 1; x < e; x++) {
+    const uint64_t kx = ks[x];
+    const uint32_t vx = vs[x];
+    uint32_t y = x;
+    while (y > s && ks[y - 1] > kx) { ks[y] = ks[y - 1]; vs[y] = vs[y - 1]; y--; }
+    ks[y] = kx; vs[y] = vx;
+  }
+}
+
+// Element a of the sorted list: [a + 1, ge) are the later members of its posting list (genomes ascending).
+// lo[a] = first of them whose genome is >= row0, cnt[a] = how many of them are rows of the tile; nothing when
+// the element's own genome is not a column of the tile.
+template <typename T>
+__global__ __launch_bounds__(256) void join_count_kernel(const T* __restrict__ ks, const uint32_t* __restrict__ vs, uint32_t K,
+                                                         uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1,
+                                                         uint32_t* __restrict__ lo_out, uint32_t* __restrict__ cnt_out) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= K) return;
+  uint32_t cnt = 0, lo = a + 1;
+  const T key = ks[a];
+  if (a + 1 < K && ks[a + 1] == key) {
+    const uint32_t g = vs[a];
+    if (g >= col0 && g < col1) {
+      // gallop to the end of the posting list: largest ge with ks[ge - 1] == key
+      uint32_t step = 1, known = a + 1;  // ks[known] == key
+      while (known + step < K && ks[known + step] == key) { known += step; step <<= 1; }
+      uint32_t hi_ex = min(K, known + step);  // ks[hi_ex] != key (or K)
+      uint32_t l = known + 1, h = hi_ex;
+      while (l < h) { const uint32_t m = (l + h) >> 1; if (ks[m] == key) l = m + 1; else h = m; }
+      const uint32_t ge = l;
+      // genomes ascend in [a + 1, ge): the rows of the tile are a contiguous part of it
+      uint32_t p = a + 1, q = ge;
+      while (p < q) { const uint32_t m = (p + q) >> 1; if (vs[m] < row0) p = m + 1; else q = m; }
+      lo = p;
+      q = ge;
+      while (p < q) { const uint32_t m = (p + q) >> 1; if (vs[m] < row1) p = m + 1; else q = m; }
+      cnt = p - lo;
+    }
+  }
+  lo_out[a] = lo;
+  cnt_out[a] = cnt;
+}
+
+// codes[eoff[a] + t] = (row << bits) | col for the t-th partner of element a.  One lane per element; an
+// element with many partners (a long posting list) is written by its whole wave.
+__global__ __launch_bounds__(256) void join_emit_kernel(const uint32_t* __restrict__ vs, const uint32_t* __restrict__ lo,
+                                                        const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ eoff,
+                                                        uint32_t K, int bits, uint64_t* __restrict__ codes) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t c = 0, l = 0, col = 0;
+  uint64_t o = 0;
+  if (a < K) { c = cnt[a]; if (c) { l = lo[a]; col = vs[a]; o = eoff[a]; } }
+  const uint32_t SMALL = 24;
+  if (c && c <= SMALL)
+    for (uint32_t t = 0; t < c; t++) codes[o + t] = ((uint64_t)vs[l + t] << bits) | col;
+  uint64_t big = __ballot(c > SMALL);
+  while (big) {  // wave-uniform
+    const int src = __builtin_ctzll(big);
+    big &= big - 1ULL;
+    const uint32_t cc = (uint32_t)__shfl((int)c, src), ll = (uint32_t)__shfl((int)l, src), colc = (uint32_t)__shfl((int)col, src);
+    const uint64_t oo = ((uint64_t)(uint32_t)__shfl((int)(o >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)o, src);
+    for (uint32_t t = lane; t < cc; t += 64) codes[oo + t] = ((uint64_t)vs[ll + t] << bits) | colc;
+  }
+}
+
+// run r of the sorted codes = pair (row, col) with common = run length: the reference's filters, then append
+__global__ __launch_bounds__(256) void join_filter_kernel(const uint64_t* __restrict__ uq, const uint32_t* __restrict__ rc,
+                                                          const uint32_t* __restrict__ nruns, int bits,
+                                                          const uint32_t* __restrict__ len, int radio,
+                                                          rtc_cedge* __restrict__ edges, unsigned long long cap,
+                                                          unsigned long long* __restrict__ count) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  bool keep = false;
+  uint32_t row = 0, col = 0, common = 0;
+  if (r < *nruns) {
+    const uint64_t code = uq[r];
+    row = (uint32_t)(code >> bits);
+    col = (uint32_t)(code & ((1ULL << bits) - 1ULL));
+    common = rc[r];
+    keep = true;
+    if (radio >= 0) {  // src/MST.cpp:1484
+      const uint32_t s0 = len[row], s1 = len[col];
+      const uint32_t mn = s0 < s1 ? s0 : s1, mx = s0 > s1 ? s0 : s1;
+      if ((uint64_t)mx > (uint64_t)(uint32_t)radio * (uint64_t)mn) keep = false;
+    }
+  }
+  const uint64_t m = __ballot(keep);
+  if (!m) return;
+  unsigned long long base = 0;
+  if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(count, (unsigned long long)__popcll(m));
+  base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), __builtin_ctzll(m)) << 32) |
+         (uint32_t)__shfl((int)(uint32_t)base, __builtin_ctzll(m));
+  if (keep) {
+    const unsigned long long idx = base + __popcll(m & ((1ULL << lane) - 1ULL));
+    if (idx < cap) edges[idx] = rtc_cedge{row, col, common};
+  }
+}
+
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// 0: off, 1: on where the cost rule says so (default), 2: forced wherever the join can run at all (tests)
+int join_mode() {
+  const char* e = getenv("RTC_PAIR_JOIN");
+  if (!e) return 1;
+  return atoi(e);
+}
+
+template <typename T>
+int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const uint32_t* d_len, uint32_t n, uint32_t row0,
+              uint32_t row1, uint32_t col0, uint32_t col1, int radio, rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count,
+              int* handled) {
+  *handled = 0;
+  const int mode = join_mode();
+  if (mode <= 0 || ctx->pair_plan_hold) return RTC_OK;
+  // only pairs (row, col) with col < row exist: genomes outside [g0, g1) take no part
+  const uint32_t g0 = std::min(col0, row0), g1 = row1;
+  if (g1 <= g0 + 1) return RTC_OK;
+  const uint32_t ng = g1 - g0;
+  hipStream_t s = ctx->stream;
+
+  // ---- 1. offsets of the flat copy ----
+  void* ws0 = nullptr;
+  size_t tb_scan = 0;
+  {
+    auto it = rocprim::make_transform_iterator(d_len + g0, U32ToU64());
+    RTC_HIP(ctx, rocprim::inclusive_scan(nullptr, tb_scan, it, (uint64_t*)nullptr, (size_t)ng, rocprim::plus<uint64_t>(), s));
+  }
+  const size_t b_off = up256((size_t)(ng + 2) * 8), b_fix = up256((size_t)(FIX_CAP + 2) * 4);
+  RTC_TRY(rtc_ws(ctx, 0, b_off + b_fix + up256(tb_scan) + 256, &ws0));
+  uint64_t* d_off = (uint64_t*)ws0;
+  uint32_t* d_fix = (uint32_t*)((char*)ws0 + b_off);
+  {
+    auto it = rocprim::make_transform_iterator(d_len + g0, U32ToU64());
+    RTC_HIP(ctx, hipMemsetAsync(d_off, 0, 8, s));
+    RTC_HIP(ctx, hipMemsetAsync(d_off + ng + 1, 0, 8, s));  // [ng + 1]: the largest hash
+    void* tmp = (char*)ws0 + b_off + b_fix;
+    RTC_HIP(ctx, rocprim::inclusive_scan(tmp, tb_scan, it, d_off + 1, (size_t)ng, rocprim::plus<uint64_t>(), s));
+    hipLaunchKernelGGL(join_maxkey_kernel<T>, dim3((ng + 255) / 256), dim3(256), 0, s, d_hashes, d_start, d_len, g0, ng,
+                       (unsigned long long*)(d_off + ng + 1));
+    RTC_CHECK_LAUNCH(ctx);
+  }
+  void* hpin = nullptr;
+  RTC_TRY(rtc_pinned(ctx, 64, &hpin));
+  RTC_HIP(ctx, hipMemcpyAsync(hpin, d_off + ng, 16, hipMemcpyDeviceToHost, s));
+  RTC_HIP(ctx, hipStreamSynchronize(s));
+  const uint64_t K64 = *(const uint64_t*)hpin;
+  const uint64_t maxkey = ((const uint64_t*)hpin)[1];
+  if (K64 < 2 || K64 >= (1ull << 31)) return RTC_OK;
+  const uint32_t K = (uint32_t)K64;
+
+  // ---- cost rule, first half: the sort alone against the tiled kernel's probes ----
+  // tiled: every column of a 1024-column block probes the table of every 64-row block below the diagonal with all
+  // of its hashes, ~3.2e11 probes/s; join: ~1.1e10 (u64) / 2.8e10 (u32) sorted keys/s, ~1.5e10 co-occurrences/s
+  // (radix sort on 2*bits bits + encode + emit), measured on MI355X (tools/ubench/sort_rates.hip).
+  const double avg = (double)K / ng;
+  const double rows = (double)(row1 - row0);
+  const double cols_mean = std::max(1.0, 0.5 * ((double)std::min(col1, row0) + (double)std::min(col1, row1 - 1)) - (double)col0);
+  const double t_tiled = (rows / 64.0 + 1.0) * cols_mean * avg / 3.2e11;
+  const double t_sort = (double)K / (sizeof(T) == 8 ? 1.1e10 : 2.8e10);
+  if (mode == 1 && t_sort > 0.7 * t_tiled) return RTC_OK;
+
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+  const uint64_t avail = (uint64_t)free_b + ctx->ws_bytes[1] + ctx->ws_bytes[4];
+
+  // ---- 2. flat copy + stable sort by hash ----
+  size_t tb_sort = 0;
+  RTC_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb_sort, (const T*)nullptr, (T*)nullptr, (const uint32_t*)nullptr,
+                                         (uint32_t*)nullptr, (size_t)K, 0u, (unsigned)(8 * sizeof(T)), s));
+  size_t tb_scan2 = 0;
+  {
+    auto it = rocprim::make_transform_iterator((const uint32_t*)nullptr, U32ToU64());
+    RTC_HIP(ctx, rocprim::exclusive_scan(nullptr, tb_scan2, it, (uint64_t*)nullptr, (uint64_t)0, (size_t)K + 1,
+                                         rocprim::plus<uint64_t>(), s));
+  }
+  const size_t b_keys = up256((size_t)K * sizeof(T)), b_vals = up256((size_t)(K + 1) * 4), b_eoff = up256((size_t)(K + 1) * 8);
+  const size_t b_tmp1 = up256(std::max(tb_sort, tb_scan2));
+  // keys0 | keys1 | vals0 | vals1 | eoff | temp | lo, cnt
+  const size_t need1 = 2 * b_keys + 2 * b_vals + b_eoff + b_tmp1 + up256((size_t)(2 * (size_t)K + 1) * 4) + 256;
+  if (need1 > avail / 2) return RTC_OK;
+  ctx->pair_plan_valid = 0;  // scratch slots 1 and 4 are the tiled plan's
+  void* ws1 = nullptr;
+  {
+    const int st = rtc_ws(ctx, 1, need1, &ws1);
+    if (st == RTC_ERR_NOMEM) return RTC_OK;
+    if (st != RTC_OK) return st;
+  }
+  T* keys0 = (T*)ws1;
+  T* keys1 = (T*)((char*)ws1 + b_keys);
+  uint32_t* vals0 = (uint32_t*)((char*)ws1 + 2 * b_keys);
+  uint32_t* vals1 = (uint32_t*)((char*)ws1 + 2 * b_keys + b_vals);
+  uint64_t* d_eoff = (uint64_t*)((char*)ws1 + 2 * b_keys + 2 * b_vals);
+  void* tmp1 = (char*)ws1 + 2 * b_keys + 2 * b_vals + b_eoff;
+  hipLaunchKernelGGL(join_flatten_kernel<T>, dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, d_off, g0, keys0, vals0);
+  RTC_CHECK_LAUNCH(ctx);
+  // ---- 3. partners per element, their offsets, the co-occurrence count ----
+  uint32_t* d_lo = (uint32_t*)((char*)ws1 + 2 * b_keys + 2 * b_vals + b_eoff + b_tmp1);
+  uint32_t* d_cnt = d_lo + K;          // K + 1 entries: the scan below reads one past the end for the total
+  uint64_t E = 0;
+  // radix passes only over the bits that vary: [0, end_bit) holds every hash.  u64: first on the 32 bits below
+  // end_bit + repair of the rare mixed runs; when the repair gives up (a collision inside a very long posting
+  // list), once more on all of them.  rocPRIM 4.2 mis-sorts ranges [b > 0, 64) below ~1M keys (its merge-sort
+  // path, tools/ubench/sort_check.hip): those inputs take the full range.
+  unsigned end_bit = 1;
+  while (end_bit < 8 * sizeof(T) && (maxkey >> end_bit)) end_bit++;
+  const unsigned half_bit = end_bit > 32 ? end_bit - 32 : 0;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const bool halfsort = sizeof(T) == 8 && attempt == 0 && half_bit > 0 && (end_bit < 64 || K >= (1u << 22)) &&
+                          !getenv("RTC_JOIN_FULLSORT");
+    RTC_HIP(ctx, rocprim::radix_sort_pairs(tmp1, tb_sort, (const T*)keys0, keys1, (const uint32_t*)vals0, vals1, (size_t)K,
+                                           halfsort ? half_bit : 0u, end_bit, s));
+    if constexpr (sizeof(T) == 8) {
+      if (halfsort) {
+        RTC_HIP(ctx, hipMemsetAsync(d_fix, 0, 8, s));
+        hipLaunchKernelGGL(join_inversions_kernel, dim3((K + 255) / 256), dim3(256), 0, s, (const uint64_t*)keys1, K, (int)half_bit, d_fix);
+        RTC_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(join_repair_owner_kernel, dim3(FIX_CAP / 64), dim3(64), 0, s, (const uint64_t*)keys1, (int)half_bit, d_fix);
+        RTC_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(join_repair_kernel, dim3(FIX_CAP / 64), dim3(64), 0, s, (uint64_t*)keys1, vals1, K, (int)half_bit, d_fix);
+        RTC_CHECK_LAUNCH(ctx);
+      }
+    }
+    hipLaunchKernelGGL(join_count_kernel<T>, dim3((K + 255) / 256), dim3(256), 0, s, (const T*)keys1, (const uint32_t*)vals1, K,
+                       row0, row1, col0, col1, d_lo, d_cnt);
+    RTC_CHECK_LAUNCH(ctx);
+    RTC_HIP(ctx, hipMemsetAsync(d_cnt + K, 0, 4, s));
+    {
+      auto it = rocprim::make_transform_iterator((const uint32_t*)d_cnt, U32ToU64());
+      RTC_HIP(ctx, rocprim::exclusive_scan(tmp1, tb_scan2, it, d_eoff, (uint64_t)0, (size_t)K + 1, rocprim::plus<uint64_t>(), s));
+    }
+    RTC_HIP(ctx, hipMemcpyAsync(hpin, d_eoff + K, 8, hipMemcpyDeviceToHost, s));
+    if (halfsort) RTC_HIP(ctx, hipMemcpyAsync((char*)hpin + 8, d_fix, 8, hipMemcpyDeviceToHost, s));
+    RTC_HIP(ctx, hipStreamSynchronize(s));
+    E = *(const uint64_t*)hpin;
+    if (getenv("RTC_JOIN_DEBUG")) fprintf(stderr, "[join] K=%u attempt=%d halfsort=%d E=%llu inversions=%u giveup=%u\n", K, attempt, (int)halfsort,
+                                          (unsigned long long)E, halfsort ? ((const uint32_t*)hpin)[2] : 0u, halfsort ? ((const uint32_t*)hpin)[3] : 0u);
+    if (halfsort && ((const uint32_t*)hpin)[3]) continue;  // not repaired: sort on all bits
+    break;
+  }
+  if (E == 0) { *handled = 1; return RTC_OK; }  // no two genomes of the tile share a hash: no candidates
+  if (E >= (1ull << 31)) return RTC_OK;
+  // ---- cost rule, second half ----
+  if (mode == 1 && t_sort + (double)E / 1.5e10 > t_tiled) return RTC_OK;
+
+  int bits = 1;
+  while ((1ull << bits) < (uint64_t)n) bits++;
+  size_t tb_s2 = 0, tb_rle = 0;
+  RTC_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb_s2, (const uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)E, 0u, (unsigned)(2 * bits), s));
+  RTC_HIP(ctx, rocprim::run_length_encode(nullptr, tb_rle, (const uint64_t*)nullptr, (unsigned)E, (uint64_t*)nullptr,
+                                          (uint32_t*)nullptr, (uint32_t*)nullptr, s));
+  const size_t b_codes = up256((size_t)E * 8), b_rc = up256((size_t)E * 4), b_tmp2 = up256(std::max(tb_s2, tb_rle));
+  const size_t need4 = 2 * b_codes + b_rc + b_tmp2 + 512;
+  if (need4 > (avail - std::min<uint64_t>(avail, need1)) / 2 + ctx->ws_bytes[4]) return RTC_OK;
+  void* ws4 = nullptr;
+  {
+    const int st = rtc_ws(ctx, 4, need4, &ws4);
+    if (st == RTC_ERR_NOMEM) return RTC_OK;
+    if (st != RTC_OK) return st;
+  }
+  uint64_t* codes0 = (uint64_t*)ws4;
+  uint64_t* codes1 = (uint64_t*)((char*)ws4 + b_codes);
+  uint32_t* d_rc = (uint32_t*)((char*)ws4 + 2 * b_codes);
+  uint32_t* d_nruns = (uint32_t*)((char*)ws4 + 2 * b_codes + b_rc);
+  void* tmp2 = (char*)ws4 + 2 * b_codes + b_rc + 256;
+
+  // ---- 4-7 ----
+  hipLaunchKernelGGL(join_emit_kernel, dim3((K + 255) / 256), dim3(256), 0, s, (const uint32_t*)vals1, (const uint32_t*)d_lo,
+                     (const uint32_t*)d_cnt, (const uint64_t*)d_eoff, K, bits, codes0);
+  RTC_CHECK_LAUNCH(ctx);
+  RTC_HIP(ctx, rocprim::radix_sort_keys(tmp2, tb_s2, (const uint64_t*)codes0, codes1, (size_t)E, 0u, (unsigned)(2 * bits), s));
+  uint64_t* d_uq = codes0;
+  RTC_HIP(ctx, rocprim::run_length_encode(tmp2, tb_rle, (const uint64_t*)codes1, (unsigned)E, d_uq, d_rc, d_nruns, s));
+  hipLaunchKernelGGL(join_filter_kernel, dim3((uint32_t)((E + 255) / 256)), dim3(256), 0, s, (const uint64_t*)d_uq, (const uint32_t*)d_rc,
+                     (const uint32_t*)d_nruns, bits, d_len, radio, d_edges, (unsigned long long)cap, (unsigned long long*)d_count);
+  RTC_CHECK_LAUNCH(ctx);
+  *handled = 1;
+  return RTC_OK;
+}
+
+}  // namespace
+
+// Candidate edges (i, j, common) of rows [row0, row1) x cols [col0, col1), j < i, appended at *d_count like the
+// tiled kernel does.  *handled = 0: the caller runs the tiled kernel (nothing was appended).
+int rtc_pair_edges_join(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start, const uint32_t* d_len,
+                        uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, int radio,
+                        rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count, int* handled) {
+  *handled = 0;
+  if (n < 2) return RTC_OK;
+  if (width == 8)
+    return join_impl<uint64_t>(ctx, (const uint64_t*)d_hashes, d_start, d_len, n, row0, row1, col0, col1, radio, d_edges, cap,
+                               d_count, handled);
+  return join_impl<uint32_t>(ctx, (const uint32_t*)d_hashes, d_start, d_len, n, row0, row1, col0, col1, radio, d_edges, cap,
+                             d_count, handled);
+}

@@ -1,0 +1,182 @@
+"""GPU parity of the inverted-join candidate-edge path (rtc_pairs_join.hip): forced on, its (i, j, common)
+triples must equal the oracle's pairwise counts filtered by the reference's rules (src/MST.cpp:1468-1487)
+and the tiled kernel's output for the same tile, pair for pair."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_sketches(rng, n, smin, smax, pool_bits=20, dtype=np.uint64):
+    out = []
+    for _ in range(n):
+        s = int(rng.integers(smin, smax + 1))
+        v = np.unique(rng.integers(0, 1 << pool_bits, size=s * 2 + 2, dtype=np.uint64))[:s]
+        v = (v * np.uint64(0x9E3779B97F4A7C15)) if dtype == np.uint64 else v
+        out.append(np.sort(v.astype(dtype)))
+    return out
+
+
+def _edges(ctx, dev, row0, row1, col0, col1, radio, mode, cap=1 << 22):
+    old = os.environ.get("RTC_PAIR_JOIN")
+    os.environ["RTC_PAIR_JOIN"] = str(mode)
+    try:
+        e, m = ctx.pair_edges(dev, row0, row1, col0, col1, radio, cap)
+    finally:
+        if old is None:
+            os.environ.pop("RTC_PAIR_JOIN", None)
+        else:
+            os.environ["RTC_PAIR_JOIN"] = old
+    assert m <= cap
+    a = e[:m].cpu().numpy().view(np.uint32).astype(np.int64)
+    order = np.lexsort((a[:, 1], a[:, 0]))
+    return a[order]
+
+
+def _expected(oracle, sk, row0, row1, col0, col1, radio):
+    out = []
+    for i in range(row0, row1):
+        for j in range(col0, min(col1, i)):
+            c = oracle.common(sk[i], sk[j])
+            if c == 0:
+                continue
+            if radio >= 0:
+                mn, mx = min(len(sk[i]), len(sk[j])), max(len(sk[i]), len(sk[j]))
+                if mx > radio * mn:
+                    continue
+            out.append((i, j, c))
+    return np.array(out, dtype=np.int64).reshape(-1, 3)
+
+
+@pytest.mark.parametrize("width", [8, 4])
+def test_join_equals_oracle_and_tiled(ctx, oracle, width):
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(100 + width)
+    dt = np.uint64 if width == 8 else np.uint32
+    sk = _make_sketches(rng, 150, 0, 260, pool_bits=12, dtype=dt)
+    sk[3] = np.zeros(0, dtype=dt)
+    sk[5] = sk[4].copy()
+    sk[149] = sk[4].copy()
+    sk[70] = np.zeros(0, dtype=dt)
+    top = np.array([np.iinfo(dt).max], dtype=dt)  # the tiled table's EMPTY marker as a hash value
+    sk[10] = np.concatenate([sk[10], top]) if len(sk[10]) == 0 or sk[10][-1] != top[0] else sk[10]
+    sk[90] = np.concatenate([sk[90], top]) if len(sk[90]) == 0 or sk[90][-1] != top[0] else sk[90]
+    dev = api.SketchSet.from_host(sk, ctx.device, width=width)
+    for (r0, r1, c0, c1, radio) in [(1, 150, 0, 149, -1), (1, 150, 0, 149, 2), (37, 131, 5, 120, -1), (100, 150, 0, 149, 3),
+                                    (1, 40, 20, 39, -1), (149, 150, 0, 149, -1)]:
+        want = _expected(oracle, sk, r0, r1, c0, c1, radio)
+        got = _edges(ctx, dev, r0, r1, c0, c1, radio, mode=2)
+        assert np.array_equal(got, want), (r0, r1, c0, c1, radio)
+        tiled = _edges(ctx, dev, r0, r1, c0, c1, radio, mode=0)
+        assert np.array_equal(tiled, want)
+
+
+def test_join_appends_after_existing_edges_and_counts_past_the_capacity(ctx, oracle):
+    """Contract shared with the tiled kernel: edges go in at *count, every survivor is counted even when the
+    list is full (the caller grows it to the exact need and repeats)."""
+    import torch
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(7)
+    sk = _make_sketches(rng, 80, 50, 90, pool_bits=10)
+    dev = api.SketchSet.from_host(sk, ctx.device)
+    want = _expected(oracle, sk, 1, 80, 0, 79, -1)
+    assert len(want) > 100
+    os.environ["RTC_PAIR_JOIN"] = "2"
+    try:
+        cap = 40 + len(want) // 2
+        edges = torch.full((cap, 3), -1, dtype=torch.int32, device=ctx.device)
+        count = torch.tensor([40], dtype=torch.int64, device=ctx.device)
+        ctx.check(ctx.lib.rtc_pair_edges_dev(ctx.h, api._t_ptr(dev.hashes), dev.width, api._t_ptr(dev.start), api._t_ptr(dev.len),
+                                             dev.n, 1, 80, 0, 79, -1, api._t_ptr(edges), cap, api._t_ptr(count)))
+    finally:
+        os.environ.pop("RTC_PAIR_JOIN", None)
+    assert int(count.item()) == 40 + len(want)
+    e = edges.cpu().numpy()
+    assert (e[:40] == -1).all() and (e[40:] != -1).all()
+    got = {tuple(int(v) for v in r) for r in e[40:]}
+    assert got <= {tuple(int(v) for v in r) for r in want}
+    assert len(got) == cap - 40
+
+
+def test_join_long_posting_lists(ctx, oracle):
+    """Forty copies of one genome among unrelated ones: posting lists of length 40 (the wave-wide emit)."""
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(9)
+    sk = _make_sketches(rng, 120, 80, 100, pool_bits=30)
+    for g in range(10, 120, 3):
+        sk[g] = sk[7].copy()
+    sk[50] = sk[7][::2].copy()
+    dev = api.SketchSet.from_host(sk, ctx.device)
+    want = _expected(oracle, sk, 1, 120, 0, 119, 4)
+    got = _edges(ctx, dev, 1, 120, 0, 119, 4, mode=2)
+    assert np.array_equal(got, want)
+    assert np.array_equal(_edges(ctx, dev, 1, 120, 0, 119, 4, mode=0), want)
+
+
+@pytest.mark.parametrize("kind", ["minhash", "kssd"])
+def test_join_on_real_sketches_row_shards_equal_the_tiled_kernel(ctx, kind):
+    """2 000 synthetic genomes in families: the default dispatch (cost rule), the forced join and the tiled
+    kernel agree on every row range of an 8-way split; the MST built on top is the same either way."""
+    from rabbittclust_amd import api, host, pipeline
+    desc = api.synth_family_descs(200, 10, global_seed=5)
+    L = 200_000
+    off = np.arange(len(desc) + 1, dtype=np.uint64) * np.uint64(L)
+    seq = ctx.synth_genomes(desc, off)
+    if kind == "minhash":
+        sk = ctx.sketch_minhash(seq, off, k=21, size=1000)
+    else:
+        sk = ctx.sketch_kssd(seq, off, host.generate_shuffle_dim(6), kmer_size=21, drlevel=3)
+    n = sk.n
+    radio = 4
+    total = 0
+    bnd = pipeline.triangle_row_ranges(n, 8, fixed_cols=1.84 * 1000)
+    for a, b in zip(bnd[:-1], bnd[1:]):
+        a = max(a, 1)
+        if a >= b:
+            continue
+        t = _edges(ctx, sk, a, b, 0, b - 1, radio, mode=0)
+        j = _edges(ctx, sk, a, b, 0, b - 1, radio, mode=2)
+        d = _edges(ctx, sk, a, b, 0, b - 1, radio, mode=1)
+        assert np.array_equal(t, j) and np.array_equal(t, d)
+        total += len(t)
+    assert total > n
+    os.environ["RTC_PAIR_JOIN"] = "0"
+    try:
+        m0 = ctx.mst(sk, 0.05)
+    finally:
+        os.environ["RTC_PAIR_JOIN"] = "2"
+    try:
+        m1 = ctx.mst(sk, 0.05)
+    finally:
+        os.environ.pop("RTC_PAIR_JOIN", None)
+    assert np.array_equal(m0, m1)
+
+
+@pytest.mark.parametrize("prefixes", [400, 1])
+def test_join_u64_hashes_that_share_their_upper_half(ctx, oracle, prefixes):
+    """The join sorts 64-bit hashes on their 32 most significant varying bits and repairs the runs in which distinct
+    hashes share them.  Hashes below 2^60 here: bits [28, 60) are the sorted ones.  400 prefixes: hundreds of mixed
+    runs of a few dozen elements (repaired in place); one prefix: a single run of everything (the repair gives up,
+    the sort is repeated on all bits)."""
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(21 + prefixes)
+    pre = rng.integers(0, 1 << 32, size=prefixes, dtype=np.uint64)
+    low = rng.integers(0, 1 << 28, size=64 if prefixes > 1 else 3000, dtype=np.uint64)
+    sk = []
+    for _ in range(130):
+        s = int(rng.integers(60, 140))
+        v = (pre[rng.integers(0, prefixes, size=s)] << np.uint64(28)) | low[rng.integers(0, len(low), size=s)]
+        sk.append(np.unique(v))
+    sk[11] = sk[10].copy()
+    dev = api.SketchSet.from_host(sk, ctx.device)
+    want = _expected(oracle, sk, 1, 130, 0, 129, -1)
+    assert len(want) > 200
+    got = _edges(ctx, dev, 1, 130, 0, 129, -1, mode=2)
+    assert np.array_equal(got, want)
+    os.environ["RTC_JOIN_FULLSORT"] = "1"
+    try:
+        assert np.array_equal(_edges(ctx, dev, 1, 130, 0, 129, -1, mode=2), want)
+    finally:
+        os.environ.pop("RTC_JOIN_FULLSORT", None)
