@@ -404,8 +404,22 @@ def main():
         wl = {"genomes": n_local, "length": length, "k": args.k, "s": args.s, "mode": mode}
         sk_kernel = "sketch_minhash_kernel" if mode == "minhash" else "sketch_kssd_bloom_kernel"
         sk_traffic, sk_src = measured_traffic(sk_kernel, wl)
-        pr_traffic, pr_src = measured_traffic("pair_tiled_kernel", wl)
+        # the pair phase's device path: 3 = inverted join (rocPRIM radix sorts + the join kernels), 2 = tiled kernel
+        pair_path = int(round(ph.get("pair_path", 2.0)))
+        pr_kernel = "pair_join_phase" if pair_path == 3 else "pair_tiled_kernel"
+        pr_traffic, pr_src = measured_traffic(pr_kernel, wl)
         pr_ach = pr_traffic / (ph["pair_ms"] * 1e-3) / 1e9 if pr_traffic else None
+        if pair_path == 3:
+            dist_algo = hashes_local * world * (width + 4) / (ph["pair_ms"] * 1e-3) / 1e9  # every (hash, genome) once
+            dist_note = ("pair phase = inverted join (rtc_pairs_join.hip): achieved/frac = PMC-measured HBM bytes of all kernels "
+                         "of the phase (profiles/%s: 'pair_join_phase' = the rocPRIM sort / scan / encode kernels + join_*) / "
+                         "pair-phase time; algorithmic_* = (hash, genome) records read once = %d B per hash / time -- the "
+                         "radix passes move each record eight times" % (pr_src, width + 4))
+        else:
+            dist_note = ("achieved/frac = PMC-measured HBM bytes per launch (profiles/%s) / pair-phase time: "
+                         "the physical figure; algorithmic_* = (|A|+|B|)*%d B per pair / time, which "
+                         "exceeds 1 because a tile's sketches are reused from LDS/L2 (one LDS probe serves "
+                         "64 pairs)" % (pr_src, width))
         what = "MinHash k=%d s=%d" % (args.k, args.s) if mode == "minhash" else "KSSD --fast k=%d drlevel=%d" % (args.k, args.drlevel)
         line = {
             "metric": ("genome_pairs_per_sec_end_to_end (sketch + all-pairs Mash distance + MST), k=21 s=1000"
@@ -438,14 +452,10 @@ def main():
                          "note": "algorithmic bytes = 1 B/base + %d B/hash out per launch; traffic = rocprofv3 PMC "
                                  "bytes per launch (profiles/%s); the kernel is integer-VALU-issue bound, "
                                  "see DESIGN.md 3.1" % (width, sk_src)},
-            "roofline_dist": {"bound": "hbm", "kernel": "pair_tiled_kernel", "achieved": pr_ach, "peak": HBM_PEAK_GBS,
+            "roofline_dist": {"bound": "hbm", "kernel": pr_kernel, "achieved": pr_ach, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": (pr_ach / HBM_PEAK_GBS) if pr_ach else None,
                               "traffic": pr_traffic, "algorithmic_achieved": dist_algo,
-                              "algorithmic_frac": dist_algo / HBM_PEAK_GBS,
-                              "note": "achieved/frac = PMC-measured HBM bytes per launch (profiles/%s) / pair-phase time: "
-                                      "the physical figure; algorithmic_* = (|A|+|B|)*%d B per pair / time, which "
-                                      "exceeds 1 because a tile's sketches are reused from LDS/L2 (one LDS probe serves "
-                                      "64 pairs)" % (pr_src, width)},
+                              "algorithmic_frac": dist_algo / HBM_PEAK_GBS, "note": dist_note},
         }
         if not args.no_cpu_baseline and world == 1:
             try:

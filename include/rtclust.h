@@ -144,13 +144,21 @@ int rtc_extract_edges_dev(rtc_ctx* ctx, const uint32_t* d_common, uint64_t ld, u
                           uint32_t row1, uint32_t col0, uint32_t col1, const uint32_t* d_len,
                           int radio, rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count);
 
-/* Fused form of the two calls above for the tile rows [row0,row1) x cols [col0,col1): the pair
- * kernel applies the same filters (src/MST.cpp:1468-1487) to its counters and appends the
- * surviving (i, j, common), j < i, directly -- no dense matrix is written.  radio < 0 disables the
- * size-ratio test (greedy clustering filters on the host).  d_count as above. */
+/* Fused form of the two calls above for the tile rows [row0,row1) x cols [col0,col1): the
+ * surviving (i, j, common), j < i, of the same filters (src/MST.cpp:1468-1487) are appended
+ * directly -- no dense matrix is written.  radio < 0 disables the size-ratio test (greedy
+ * clustering filters on the host).  d_count as above.  Two device paths with identical results:
+ * the inverted join (the reference's index, src/MST.cpp:1408-1435, as a device sort of
+ * (hash, genome) + posting-list pair emission + run-length encoding; cost ~ hashes +
+ * co-occurrences) where the tile is sparse enough for it to win, otherwise the tiled kernel
+ * (cost ~ rows x cols x s / 64, independent of the data).  RTC_PAIR_JOIN=0 in the environment
+ * disables the join, =2 takes it wherever its scratch fits. */
 int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
                        const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0,
                        uint32_t col1, int radio, rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count);
+/* Which path the last rtc_pair_edges_dev of this context took: 0 none yet, 1 per-pair merge kernel,
+ * 2 tiled kernel, 3 inverted join (measurement: bench.py names the kernels of the pair phase by it). */
+int rtc_pair_last_path(const rtc_ctx* ctx);
 
 /* ---- minimum spanning forest over candidate edges (Boruvka, order-exact integer weights) -- */
 /* One Boruvka round primitive for row-sharded multi-GPU use: for every current component c

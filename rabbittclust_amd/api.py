@@ -106,6 +106,10 @@ class Context:
     def sync(self):
         self.check(self.lib.rtc_ctx_sync(self.h))
 
+    def pair_last_path(self):
+        """Path of the last pair_edges call: 0 none, 1 merge kernel, 2 tiled kernel, 3 inverted join."""
+        return int(self.lib.rtc_pair_last_path(self.h))
+
     def timer_start(self):
         self.check(self.lib.rtc_timer_start(self.h))
 

@@ -137,7 +137,110 @@ extern "C" int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const u
   G_HIP(hipMalloc(&d_edges, ecap * sizeof(rtc_cedge)));
   G_HIP(hipMalloc(&d_count, 8));
 
-  for (uint32_t q0 = 1; q0 < n; q0 += B) {
+  // ---- serial replay of the reference's decisions for one query: candidates [c0, c1), `resolve` maps a candidate's
+  // column to its genome id and says whether that genome is a representative ----
+  auto decide = [&](uint32_t q, const Cand* c0, const Cand* c1, auto&& resolve) {
+    const int sizeRef = (int)h_len[q];                                      // :1139 / :684
+    int best_common = -1; double best_dist = std::numeric_limits<double>::max(); double best_jac = -1.0;
+    uint32_t best_rep = 0xFFFFFFFFu;
+    std::vector<uint32_t> ties;
+    for (const Cand* pc = c0; pc != c1; pc++) {
+      const Cand& cd = *pc;
+      uint32_t rep;
+      if (!resolve(cd.vcol, rep)) continue;  // not a representative
+      const int common = (int)cd.common;
+      if (is_kssd) {
+        const int sizeQry = (int)h_len[rep];                                // :768
+        const int common_min = (int)ceil(jaccard_min * (sizeRef + sizeQry) / (1.0 + jaccard_min));  // :774
+        if (common < common_min) continue;
+        const int denom = sizeRef + sizeQry - common;
+        const double jac = denom == 0 ? 1.0 : (double)common / denom;      // :785-786
+        if (jac > best_jac) { best_jac = jac; best_rep = rep; ties.clear(); ties.push_back(rep); }
+        else if (jac == best_jac) ties.push_back(rep);
+      } else {
+        const int sizeQry = (int)h_size_cfg[rep];                           // :1201 getSketchSize()
+        int common_min;
+        if (fast) common_min = fixed_common_min;                            // :1206-1208
+        else if (is_containment) common_min = (int)ceil(jaccard_min * std::min(sizeRef, sizeQry));  // :1216
+        else common_min = (int)ceil(jaccard_min * (sizeRef + sizeQry) / (1.0 + jaccard_min));       // :1218
+        if (common < common_min) continue;                                  // :1222
+        if (fast) {
+          if (common > best_common) { best_common = common; best_rep = rep; ties.clear(); ties.push_back(rep); }  // :1236
+          else if (common == best_common) ties.push_back(rep);
+        } else {
+          const double dist = greedy_distance(common, sizeRef, sizeQry, kmer_size, is_containment != 0);
+          if (dist <= threshold) {                                          // :1277
+            if (dist < best_dist) { best_dist = dist; best_rep = rep; ties.clear(); ties.push_back(rep); }
+            else if (dist == best_dist) ties.push_back(rep);
+          }
+        }
+      }
+    }
+    if (ties.size() > 1) {
+      // -t 1 reference order: candidates are visited in first-touch order = (position of the first
+      // query hash they share, representative creation order); strict comparisons keep the first.
+      uint32_t bp = 0xFFFFFFFFu, bo = 0xFFFFFFFFu;
+      for (uint32_t r : ties) {
+        const uint32_t pos = first_pos(q, r), ord = rep_order[r];
+        if (pos < bp || (pos == bp && ord < bo)) { bp = pos; bo = ord; best_rep = r; }
+      }
+    }
+    if (best_rep != 0xFFFFFFFFu) {
+      h_rep_of[q] = (int32_t)best_rep;                                      // :1321-1325
+    } else {
+      h_rep_of[q] = (int32_t)q;                                             // :1327-1336
+      rep_order[q] = (uint32_t)reps.size();
+      reps.push_back(q);
+    }
+  };
+
+  // ---- one inverted join over the whole set when it is sparse enough (rtc_pairs_join.hip): every pair (q, j < q)
+  // sharing a hash, once; the replay keeps the candidates that are representatives when their query comes up --
+  // what the reference's representative-only index returns (src/greedy.cpp:1150-1196) ----
+  bool global_done = false;
+  if (n > B) {
+    int handled = 0;
+    uint64_t m = 0;
+    while (true) {
+      G_HIP(hipMemsetAsync(d_count, 0, 8, ctx->stream));
+      G_TRY(rtc_pair_edges_join(ctx, d_hashes, width, d_start, d_len, n, 1, n, 0, n - 1, -1, d_edges, ecap, (uint64_t*)d_count, 0.5,
+                                &handled));
+      if (!handled) break;
+      unsigned long long cnt = 0;
+      G_HIP(hipMemcpyAsync(&cnt, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+      G_HIP(hipStreamSynchronize(ctx->stream));
+      if (cnt <= ecap) { m = cnt; break; }
+      (void)hipFree(d_edges); d_edges = nullptr;
+      ecap = cnt + cnt / 4;
+      G_HIP(hipMalloc(&d_edges, ecap * sizeof(rtc_cedge)));
+    }
+    if (handled) {
+      h_edges.resize(m);
+      if (m) {
+        G_HIP(hipMemcpyAsync(h_edges.data(), d_edges, m * sizeof(rtc_cedge), hipMemcpyDeviceToHost, ctx->stream));
+        G_HIP(hipStreamSynchronize(ctx->stream));
+      }
+      std::vector<uint64_t> qoff((size_t)n + 1, 0);
+      for (uint64_t e = 0; e < m; e++) qoff[(size_t)h_edges[e].i + 1]++;
+      for (uint32_t i = 0; i < n; i++) qoff[i + 1] += qoff[i];
+      std::vector<Cand> cands(m);
+      {
+        std::vector<uint64_t> cur(qoff.begin(), qoff.begin() + n);
+        for (uint64_t e = 0; e < m; e++) cands[cur[h_edges[e].i]++] = Cand{h_edges[e].j, h_edges[e].common};
+      }
+      std::vector<rtc_cedge>().swap(h_edges);
+      for (uint32_t q = 1; q < n; q++) {
+        decide(q, cands.data() + qoff[q], cands.data() + qoff[q + 1], [&](uint32_t vcol, uint32_t& rep) {
+          rep = vcol;
+          return rep_order[rep] != 0xFFFFFFFFu;
+        });
+        if (fetch_status != RTC_OK) { cleanup(); return fetch_status; }
+      }
+      global_done = true;
+    }
+  }
+
+  for (uint32_t q0 = 1; q0 < n && !global_done; q0 += B) {
     const uint32_t q1 = std::min(n, q0 + B), nb = q1 - q0;
     const uint32_t nr = (uint32_t)reps.size();
     const uint32_t nv = nr + nb;
@@ -184,62 +287,12 @@ extern "C" int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const u
       std::vector<uint32_t> cur(qoff.begin(), qoff.begin() + nb);
       for (uint64_t e = 0; e < m; e++) cands[cur[h_edges[e].i - nr]++] = Cand{h_edges[e].j, h_edges[e].common};
     }
-    // ---- serial replay of the reference's decisions ----
     for (uint32_t bi = 0; bi < nb; bi++) {
-      const uint32_t q = q0 + bi;
-      const int sizeRef = (int)h_len[q];                                      // :1139 / :684
-      int best_common = -1; double best_dist = std::numeric_limits<double>::max(); double best_jac = -1.0;
-      uint32_t best_rep = 0xFFFFFFFFu;
-      std::vector<uint32_t> ties;
-      for (uint32_t ci = qoff[bi]; ci < qoff[bi + 1]; ci++) {
-        const Cand& cd = cands[ci];
-        uint32_t rep;
-        if (cd.vcol < nr) rep = reps[cd.vcol];
-        else { rep = q0 + (cd.vcol - nr); if (rep_order[rep] == 0xFFFFFFFFu) continue; }  // not a representative
-        const int common = (int)cd.common;
-        if (is_kssd) {
-          const int sizeQry = (int)h_len[rep];                                // :768
-          const int common_min = (int)ceil(jaccard_min * (sizeRef + sizeQry) / (1.0 + jaccard_min));  // :774
-          if (common < common_min) continue;
-          const int denom = sizeRef + sizeQry - common;
-          const double jac = denom == 0 ? 1.0 : (double)common / denom;      // :785-786
-          if (jac > best_jac) { best_jac = jac; best_rep = rep; ties.clear(); ties.push_back(rep); }
-          else if (jac == best_jac) ties.push_back(rep);
-        } else {
-          const int sizeQry = (int)h_size_cfg[rep];                           // :1201 getSketchSize()
-          int common_min;
-          if (fast) common_min = fixed_common_min;                            // :1206-1208
-          else if (is_containment) common_min = (int)ceil(jaccard_min * std::min(sizeRef, sizeQry));  // :1216
-          else common_min = (int)ceil(jaccard_min * (sizeRef + sizeQry) / (1.0 + jaccard_min));       // :1218
-          if (common < common_min) continue;                                  // :1222
-          if (fast) {
-            if (common > best_common) { best_common = common; best_rep = rep; ties.clear(); ties.push_back(rep); }  // :1236
-            else if (common == best_common) ties.push_back(rep);
-          } else {
-            const double dist = greedy_distance(common, sizeRef, sizeQry, kmer_size, is_containment != 0);
-            if (dist <= threshold) {                                          // :1277
-              if (dist < best_dist) { best_dist = dist; best_rep = rep; ties.clear(); ties.push_back(rep); }
-              else if (dist == best_dist) ties.push_back(rep);
-            }
-          }
-        }
-      }
-      if (ties.size() > 1) {
-        // -t 1 reference order: candidates are visited in first-touch order = (position of the first
-        // query hash they share, representative creation order); strict comparisons keep the first.
-        uint32_t bp = 0xFFFFFFFFu, bo = 0xFFFFFFFFu;
-        for (uint32_t r : ties) {
-          const uint32_t pos = first_pos(q, r), ord = rep_order[r];
-          if (pos < bp || (pos == bp && ord < bo)) { bp = pos; bo = ord; best_rep = r; }
-        }
-      }
-      if (best_rep != 0xFFFFFFFFu) {
-        h_rep_of[q] = (int32_t)best_rep;                                      // :1321-1325
-      } else {
-        h_rep_of[q] = (int32_t)q;                                             // :1327-1336
-        rep_order[q] = (uint32_t)reps.size();
-        reps.push_back(q);
-      }
+      decide(q0 + bi, cands.data() + qoff[bi], cands.data() + qoff[bi + 1], [&](uint32_t vcol, uint32_t& rep) {
+        if (vcol < nr) { rep = reps[vcol]; return true; }
+        rep = q0 + (vcol - nr);
+        return rep_order[rep] != 0xFFFFFFFFu;
+      });
     }
     if (fetch_status != RTC_OK) { cleanup(); return fetch_status; }
   }

@@ -28,6 +28,7 @@ struct rtc_ctx {
   // tiled pair kernel: the last plan (slice offsets + transposed column copy in scratch slots 1 / 4).
   // Reused only while pair_plan_hold is set by a caller that guarantees unchanged sketches between
   // launches (the row-chunk loop of the dense candidate-edge path).
+  int pair_last_path = 0;  // rtc_pair_last_path
   int pair_plan_hold = 0, pair_plan_valid = 0;
   uint32_t pair_plan_tc1_hint = 0;
   struct {
@@ -80,6 +81,10 @@ int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, co
                                int is_containment, double threshold, uint32_t s_fixed, rtc_edge_list* el,
                                const rtc_edge_observer* obs = nullptr);
 void rtc_edge_list_free(rtc_edge_list* el);
+// rtc_pairs_join.hip: candidate edges of a lower-triangle tile by the inverted join; *handled = 0 when it declines
+int rtc_pair_edges_join(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start, const uint32_t* d_len,
+                        uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, int radio,
+                        rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count, double tiled_scale, int* handled);
 int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_len, uint32_t n,
                    int is_containment, uint32_t s_fixed, const rtc_reduce_hook* hook, rtc_cedge* d_sel,
                    uint64_t* n_sel_out, int* rounds_out);

@@ -21,10 +21,6 @@ int rtc_pair_edges_tiled(rtc_ctx* ctx, const void* d_hashes, int width, const ui
                          uint32_t col1, int lower_only, int radio, rtc_cedge* d_edges, uint64_t cap,
                          uint64_t* d_count, int* handled);
 
-int rtc_pair_edges_join(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start, const uint32_t* d_len,
-                        uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, int radio,
-                        rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count, int* handled);
-
 namespace {
 
 template <typename T>
@@ -146,6 +142,8 @@ extern "C" int rtc_pair_common_dev(rtc_ctx* ctx, const void* d_hashes, int width
 // (rtc_pairs_join.hip).  Otherwise the tiled path: survivors are emitted by the pair kernel itself.  Inputs
 // the tiled scheme cannot take go through the per-pair merge kernel into a dense scratch matrix
 // (row chunks of <= 1 GiB) that rtc_extract_edges_dev filters.
+extern "C" int rtc_pair_last_path(const rtc_ctx* ctx) { return ctx ? ctx->pair_last_path : 0; }
+
 extern "C" int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
                                   const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0,
                                   uint32_t col1, int radio, rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count) {
@@ -158,12 +156,13 @@ extern "C" int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width,
   int handled = 0;
   if (!getenv("RTC_PAIR_FORCE_MERGE")) {
     RTC_TRY(rtc_pair_edges_join(ctx, d_hashes, width, d_start, d_len, n, row0, row1, col0, col1, radio, d_edges, cap, d_count,
-                                &handled));
-    if (handled) return RTC_OK;
+                                1.0, &handled));
+    if (handled) { ctx->pair_last_path = 3; return RTC_OK; }
     RTC_TRY(rtc_pair_edges_tiled(ctx, d_hashes, width, d_start, d_len, n, row0, row1, col0, col1, 1, radio, d_edges, cap,
                                  d_count, &handled));
   }
-  if (handled) return RTC_OK;
+  if (handled) { ctx->pair_last_path = 2; return RTC_OK; }
+  ctx->pair_last_path = 1;
   const uint64_t ld = col1 - col0;
   uint32_t rows_per = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(row1 - row0, ((uint64_t)1 << 30) / (ld * 4)));
   rows_per = std::min<uint32_t>(rows_per, 262140);

@@ -216,7 +216,7 @@ int join_mode() {
 template <typename T>
 int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const uint32_t* d_len, uint32_t n, uint32_t row0,
               uint32_t row1, uint32_t col0, uint32_t col1, int radio, rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count,
-              int* handled) {
+              double tiled_scale, int* handled) {
   *handled = 0;
   const int mode = join_mode();
   if (mode <= 0 || ctx->pair_plan_hold) return RTC_OK;
@@ -263,7 +263,7 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   const double avg = (double)K / ng;
   const double rows = (double)(row1 - row0);
   const double cols_mean = std::max(1.0, 0.5 * ((double)std::min(col1, row0) + (double)std::min(col1, row1 - 1)) - (double)col0);
-  const double t_tiled = (rows / 64.0 + 1.0) * cols_mean * avg / 3.2e11;
+  const double t_tiled = tiled_scale * (rows / 64.0 + 1.0) * cols_mean * avg / 3.2e11;
   const double t_sort = (double)K / (sizeof(T) == 8 ? 1.1e10 : 2.8e10);
   if (mode == 1 && t_sort > 0.7 * t_tiled) return RTC_OK;
 
@@ -388,15 +388,17 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
 }  // namespace
 
 // Candidate edges (i, j, common) of rows [row0, row1) x cols [col0, col1), j < i, appended at *d_count like the
-// tiled kernel does.  *handled = 0: the caller runs the tiled kernel (nothing was appended).
+// tiled kernel does.  *handled = 0: the caller runs the tiled kernel (nothing was appended).  tiled_scale: what
+// fraction of the tile the caller's alternative would really walk (1 for the MST flows; the greedy loop only
+// measures queries against representatives).
 int rtc_pair_edges_join(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start, const uint32_t* d_len,
                         uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, int radio,
-                        rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count, int* handled) {
+                        rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count, double tiled_scale, int* handled) {
   *handled = 0;
   if (n < 2) return RTC_OK;
   if (width == 8)
     return join_impl<uint64_t>(ctx, (const uint64_t*)d_hashes, d_start, d_len, n, row0, row1, col0, col1, radio, d_edges, cap,
-                               d_count, handled);
+                               d_count, tiled_scale, handled);
   return join_impl<uint32_t>(ctx, (const uint32_t*)d_hashes, d_start, d_len, n, row0, row1, col0, col1, radio, d_edges, cap,
-                             d_count, handled);
+                             d_count, tiled_scale, handled);
 }

@@ -387,6 +387,7 @@ class MstPipeline:
             "dist_ms": ev[2].elapsed_time(ev[3]),
             "pairs_local": float(pairs_local),
             "cand_edges": float(st.cand_edges),
+            "pair_path": float(ctx.pair_last_path()),
             "boruvka_rounds": float(st.rounds),
             "mst_edges": float(len(mst)),
         }
@@ -428,6 +429,7 @@ class MstPipeline:
             "dist_ms": ev[2].elapsed_time(ev[4]),
             "pairs_local": float(pairs_local),
             "cand_edges": float(m),
+            "pair_path": float(ctx.pair_last_path()),
             "boruvka_rounds": float(rounds),
             "mst_edges": float(len(mst)),
         }

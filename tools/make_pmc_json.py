@@ -7,16 +7,20 @@ MODE = sys.argv[3] if len(sys.argv) > 3 else "minhash"
 G = int(sys.argv[4]) if len(sys.argv) > 4 else 10000
 L = int(sys.argv[5]) if len(sys.argv) > 5 else 5_000_000
 K, S = 21, 1000
-want = ("synth_kernel", "sketch_minhash_kernel", "sketch_kssd", "transpose_slices_kernel", "pair_tiled_kernel")
+want = ("synth_kernel", "sketch_minhash_kernel", "sketch_kssd", "transpose_slices_kernel", "pair_tiled_kernel", "pair_join_phase")
+JOIN_PARTS = ("rocprim", "join_")  # pair_join_phase = every kernel of the inverted join: rocPRIM sort / scan / encode + join_*
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
 for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = next((w for w in want if w in r["Kernel_Name"]), None)
+        if name is None and any(p in r["Kernel_Name"] for p in JOIN_PARTS):
+            name = "pair_join_phase"
         if name is None:
             continue
         tot[name][r["Counter_Name"]] += float(r["Counter_Value"])
-        disp[name][r["Counter_Name"]].add(r["Dispatch_Id"])
+        # the join is many kernels per pair phase: its "launch" is the phase (one per bench step, --steps 1 in the PMC runs)
+        disp[name][r["Counter_Name"]].add("phase" if name == "pair_join_phase" else r["Dispatch_Id"])
 out = {
     "command": "rocprofv3 --pmc <group> --output-format csv -- python bench.py [--mode kssd] --steps 1 --warmup 0 "
                "--no-cpu-baseline (one run per counter group, tools/collect_profiles.sh)",
