@@ -75,3 +75,34 @@ def test_greedy_spans_several_batches(ctx, oracle):
     assert got_n == want_n
     assert np.array_equal(got, want)
     assert 1 < got_n < len(sk)
+
+
+@pytest.mark.parametrize("mode", ["minhash", "containment", "kssd"])
+def test_greedy_global_join_equals_the_batch_loop_and_the_oracle(ctx, oracle, mode, monkeypatch):
+    """n > one batch: with the inverted join forced (RTC_PAIR_JOIN=2) rtc_greedy takes every co-occurring pair of the
+    whole set from one join and replays; with it off (=0) it walks 1024-query batches against the representatives
+    through the tiled kernel.  Same decisions either way, equal to the oracle's."""
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(35)
+    if mode == "kssd":
+        sk = _family_sets(rng, 420, 6, 150, 0.6, pool_bits=30, dtype=np.uint32, ragged=True)
+        sk.sort(key=lambda a: -len(a))
+        dev = api.SketchSet.from_host(sk, ctx.device, k=22, kind="kssd", width=4)
+        flat, start, lens = oracle.to_csr(sk, dtype=np.uint32)
+        want_n, want = oracle.greedy_kssd(flat, start, lens, 22, 0.05)
+        run = lambda: ctx.greedy(dev, 0.05)
+    else:
+        cont = mode == "containment"
+        sk = _family_sets(rng, 420, 6, 150, 0.6, ragged=cont)
+        cfg = np.array([max(len(s), 100) for s in sk], dtype=np.uint32) if cont else 150
+        dev = api.SketchSet.from_host(sk, ctx.device, k=21)
+        flat, start, lens = oracle.to_csr(sk)
+        want_n, want = oracle.greedy_minhash(flat, start, lens, cfg, 21, cont, 0.05)
+        run = lambda: ctx.greedy(dev, 0.05, size_cfg=cfg, is_containment=cont)
+    assert len(sk) > 2 * 1024
+    for join in ("2", "0"):
+        monkeypatch.setenv("RTC_PAIR_JOIN", join)
+        got_n, got = run()
+        assert got_n == want_n, join
+        assert np.array_equal(got, want), join
+    assert 1 < want_n < len(sk)
