@@ -23,6 +23,8 @@
 
 #include <algorithm>
 #include <numeric>
+#include <thread>
+#include <vector>
 
 #include "rtc_internal.h"
 
@@ -225,6 +227,31 @@ __global__ __launch_bounds__(256) void boruvka_relabel_kernel(uint32_t* __restri
   }
 }
 
+// one-GPU rounds (rtc_msf_device without an all-reduce hook): the per-vertex passes are folded together.
+// begin: comp = identity, keys empty.  relabel_reset: the relabel pass of round r, the key reset of round r + 1 and the
+// zeroing of round r + 1's "edges added" counter (two counters alternate, the host still reads round r's).
+__global__ __launch_bounds__(256) void boruvka_begin_kernel(uint32_t* __restrict__ comp, unsigned long long* __restrict__ wkey,
+                                                            unsigned long long* __restrict__ ekey, uint32_t n) {
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+    comp[v] = v;
+    wkey[v] = KEY_NONE;
+    if (ekey) ekey[v] = KEY_NONE;
+  }
+}
+__global__ __launch_bounds__(256) void boruvka_relabel_reset_kernel(uint32_t* __restrict__ comp, const uint32_t* __restrict__ succ,
+                                                                    uint32_t n, unsigned long long* __restrict__ wkey,
+                                                                    unsigned long long* __restrict__ ekey,
+                                                                    uint32_t* __restrict__ added_next) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *added_next = 0;
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+    uint32_t r = comp[v];
+    while (true) { const uint32_t nx = succ[r]; if (nx == r) break; r = nx; }
+    comp[v] = r;
+    wkey[v] = KEY_NONE;
+    if (ekey) ekey[v] = KEY_NONE;
+  }
+}
+
 __global__ void iota_u32_kernel(uint32_t* p, uint32_t n) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
 }
@@ -279,7 +306,7 @@ static double host_mst_distance(int common, int size0, int size1, int kmer_size,
 // multi-GPU step; `hook` all-reduces the per-round key arrays across ranks, NULL on one GPU) ----
 int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_len, uint32_t n,
                    int is_containment, uint32_t s_fixed, const rtc_reduce_hook* hook, rtc_cedge* d_sel,
-                   uint64_t* n_sel_out, int* rounds_out) {
+                   uint64_t* n_sel_out, int* rounds_out, bool sorted) {
   *n_sel_out = 0;
   if (rounds_out) *rounds_out = 0;
   if (n < 2) return RTC_OK;
@@ -294,6 +321,48 @@ int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uin
   uint32_t* d_comp = d_ecommon + n;
   uint32_t* d_succ = d_comp + n;
   uint64_t* d_nsel = (uint64_t*)(((uintptr_t)(d_succ + n) + 63) & ~(uintptr_t)63);
+  if (!hook) {  // one GPU: four (fixed sizes) or six (variable) operations per round instead of six / ten
+    unsigned long long* wkey = (unsigned long long*)d_wkey;
+    unsigned long long* ekey = s_fixed ? nullptr : (unsigned long long*)d_ekey;
+    uint32_t* d_added = (uint32_t*)(d_nsel + 1);  // two alternating counters
+    const dim3 gn(grid_for(n, ctx->num_cu)), gm(grid_for(std::max<uint64_t>(m, 1), ctx->num_cu)), blk(256);
+    RTC_HIP(ctx, hipMemsetAsync(d_nsel, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(boruvka_begin_kernel, gn, blk, 0, ctx->stream, d_comp, wkey, ekey, n);
+    RTC_CHECK_LAUNCH(ctx);
+    void* hp = nullptr;
+    RTC_TRY(rtc_pinned(ctx, 64, &hp));
+    const RoundKeys K{s_fixed ? wkey : ekey, d_ecommon, s_fixed, idx_bits};
+    int rounds = 0;
+    for (int round = 0; round < 64; round++) {
+      const int a = round & 1;
+      if (m) {
+        if (s_fixed) {
+          hipLaunchKernelGGL(boruvka_minkey_kernel, gm, blk, 0, ctx->stream, d_edges, m, (const uint32_t*)d_comp, s_fixed, idx_bits, wkey);
+        } else {
+          hipLaunchKernelGGL(boruvka_minweight_kernel, gm, blk, 0, ctx->stream, d_edges, m, d_len, is_containment, (const uint32_t*)d_comp, wkey);
+          hipLaunchKernelGGL(boruvka_minedge_kernel, gm, blk, 0, ctx->stream, d_edges, m, d_len, is_containment, (const uint32_t*)d_comp,
+                             (const unsigned long long*)wkey, ekey);
+          hipLaunchKernelGGL(boruvka_fetch_kernel, gm, blk, 0, ctx->stream, d_edges, m, (const uint32_t*)d_comp,
+                             (const unsigned long long*)ekey, d_ecommon);
+        }
+        RTC_CHECK_LAUNCH(ctx);
+      }
+      hipLaunchKernelGGL(boruvka_hook_kernel, gn, blk, 0, ctx->stream, K, (const uint32_t*)d_comp, n, d_succ, d_sel,
+                         (unsigned long long*)d_nsel, d_added + a);
+      RTC_CHECK_LAUNCH(ctx);
+      hipLaunchKernelGGL(boruvka_relabel_reset_kernel, gn, blk, 0, ctx->stream, d_comp, (const uint32_t*)d_succ, n, wkey, ekey,
+                         d_added + (a ^ 1));
+      RTC_CHECK_LAUNCH(ctx);
+      RTC_HIP(ctx, hipMemcpyAsync(hp, d_nsel, 16, hipMemcpyDeviceToHost, ctx->stream));
+      RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      rounds++;
+      *n_sel_out = ((const unsigned long long*)hp)[0];
+      if (!((const uint32_t*)hp)[2 + a]) break;
+    }
+    if (rounds_out) *rounds_out = rounds;
+    if (sorted) RTC_TRY(rtc_sort_forest_device(ctx, d_sel, *n_sel_out, d_len, is_containment));
+    return RTC_OK;
+  }
   RTC_TRY(rtc_boruvka_init_dev(ctx, n, d_comp, d_nsel));
   int rounds = 0;
   for (int round = 0; round < 64; round++) {
@@ -318,6 +387,7 @@ int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uin
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *n_sel_out = ns;
   if (rounds_out) *rounds_out = rounds;
+  if (sorted) RTC_TRY(rtc_sort_forest_device(ctx, d_sel, ns, d_len, is_containment));
   return RTC_OK;
 }
 
@@ -387,7 +457,7 @@ int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, co
   uint32_t rows_per = (uint32_t)std::max<uint64_t>(64, (budget / 4) / std::max<uint32_t>(row1, 1) / 64 * 64);
   auto contract = [&]() -> int {
     uint64_t ns = 0;
-    RTC_TRY(rtc_msf_device(ctx, el->d_edges, el->m, d_len, n, is_containment, s_fixed, nullptr, d_sel, &ns, nullptr));
+    RTC_TRY(rtc_msf_device(ctx, el->d_edges, el->m, d_len, n, is_containment, s_fixed, nullptr, d_sel, &ns, nullptr, false));
     RTC_HIP(ctx, hipMemcpyAsync(el->d_edges, d_sel, ns * sizeof(rtc_cedge), hipMemcpyDeviceToDevice, ctx->stream));
     el->m = ns;
     el->contractions++;
@@ -573,17 +643,31 @@ int rtc_boruvka_fetch_dev(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, co
 int rtc_edges_to_mst_host(const rtc_cedge* h_sel, uint64_t m, const uint32_t* h_len, int kmer_size,
                           int is_containment, rtc_edge* h_out) {
   if ((m && (!h_sel || !h_out)) || !h_len) return RTC_ERR_ARG;
-  for (uint64_t e = 0; e < m; e++) {
-    h_out[e].preNode = (int32_t)h_sel[e].i;
-    h_out[e].sufNode = (int32_t)h_sel[e].j;
-    h_out[e].dist = host_mst_distance((int)h_sel[e].common, (int)h_len[h_sel[e].i], (int)h_len[h_sel[e].j],
-                                      kmer_size, is_containment);
+  auto fill = [&](uint64_t e0, uint64_t e1) {
+    for (uint64_t e = e0; e < e1; e++) {
+      h_out[e].preNode = (int32_t)h_sel[e].i;
+      h_out[e].sufNode = (int32_t)h_sel[e].j;
+      h_out[e].dist = host_mst_distance((int)h_sel[e].common, (int)h_len[h_sel[e].i], (int)h_len[h_sel[e].j],
+                                        kmer_size, is_containment);
+    }
+  };
+  // the distances are the host libm's (the reference's); beyond a few thousand edges the loop is split over threads
+  const uint64_t per = 4096;
+  const unsigned nt = (unsigned)std::min<uint64_t>(std::min<uint64_t>(8, std::max(1u, std::thread::hardware_concurrency())), (m + per - 1) / per);
+  if (nt <= 1) fill(0, m);
+  else {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(fill, m * t / nt, m * (t + 1) / nt);
+    fill(0, m / nt);
+    for (auto& x : th) x.join();
   }
-  std::sort(h_out, h_out + m, [](const rtc_edge& a, const rtc_edge& b) {
+  auto less = [](const rtc_edge& a, const rtc_edge& b) {
     if (a.dist != b.dist) return a.dist < b.dist;
     if (a.preNode != b.preNode) return a.preNode < b.preNode;
     return a.sufNode < b.sufNode;
-  });
+  };
+  // forests that come from the device are already in this order (rtc_sort.hip): one pass instead of a sort
+  if (!std::is_sorted(h_out, h_out + m, less)) std::sort(h_out, h_out + m, less);
   return RTC_OK;
 }
 
@@ -778,7 +862,7 @@ int rtc_mst_mash(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* 
     else st = rtc_pair_mash_dev(ctx, d_hashes, width, d_start, d_len, n, sketch_size, r0, r1, 0, r1 - 1, d_common, d_denom, n);
     if (st != RTC_OK) break;
     if (m + chunk > cap) {  // contract what is there to its forest (at most n - 1 edges)
-      st = rtc_msf_device(ctx, d_edges, m, d_len, n, wmode, s_fixed, nullptr, d_sel, &nsel, nullptr);
+      st = rtc_msf_device(ctx, d_edges, m, d_len, n, wmode, s_fixed, nullptr, d_sel, &nsel, nullptr, false);
       if (st != RTC_OK) break;
       if (hipMemcpyAsync(d_edges, d_sel, nsel * sizeof(rtc_cedge), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { st = rtc_fail(ctx, RTC_ERR_HIP, "forest copy"); break; }
       m = nsel;
