@@ -23,6 +23,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cmath>
 
 #include "rtc_internal.h"
 
@@ -56,11 +57,79 @@ __global__ __launch_bounds__(256) void join_flatten_kernel(const T* __restrict__
   for (uint32_t e = threadIdx.x; e < L; e += blockDim.x) { keys[o + e] = src[e]; vals[o + e] = g; }
 }
 
+// ---- semi-join in front of the sort (row shards of a multi-GPU run: few rows, many columns) -------------------
+// Only hashes that occur in a ROW genome can make a (row, col) pair.  A blocked Bloom filter of the rows' hashes (two
+// bits in one 64-bit word per hash, ~8 bits of filter per hash: ~6 % false positives, harmless) lets the flat copy
+// keep just the column hashes that may: the rank holding the last eighth of the rows of 100 000 sketches sorts
+// 1.3e7 instead of 1e8 records.  Order inside a genome is kept (the stable sort needs genomes ascending in a list).
+template <typename T>
+__device__ __forceinline__ void bloom_slot(T key, int wshift, uint32_t& word, unsigned long long& mask) {
+  const uint64_t h = (uint64_t)key * 0x9E3779B97F4A7C15ULL;
+  word = (uint32_t)(h >> wshift);
+  mask = (1ULL << (h & 63)) | (1ULL << ((h >> 6) & 63));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void join_bloom_build_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
+                                                               const uint32_t* __restrict__ len, uint32_t row0, int wshift,
+                                                               unsigned long long* __restrict__ bloom) {
+  const uint32_t g = row0 + blockIdx.x;
+  const uint32_t L = len[g];
+  const T* src = hashes + start[g];
+  for (uint32_t e = threadIdx.x; e < L; e += blockDim.x) {
+    uint32_t w; unsigned long long m;
+    bloom_slot<T>(src[e], wshift, w, m);
+    atomicOr(&bloom[w], m);
+  }
+}
+// FILL = false: kept[g - g0] = hashes of genome g that pass; FILL = true: write them (and g) at off[g - g0], in order
+template <typename T, bool FILL>
+__global__ __launch_bounds__(256) void join_semi_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
+                                                        const uint32_t* __restrict__ len, uint32_t g0, uint32_t row0, int wshift,
+                                                        const unsigned long long* __restrict__ bloom, uint32_t* __restrict__ kept,
+                                                        const uint64_t* __restrict__ off, T* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals) {
+  __shared__ uint32_t wtot[4];
+  const uint32_t g = g0 + blockIdx.x;
+  const uint32_t L = len[g];
+  const T* src = hashes + start[g];
+  const bool is_row = g >= row0;  // rows are later rows' columns too, and their own hashes all pass by construction
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t base = FILL ? off[blockIdx.x] : 0;
+  uint32_t total = 0;
+  for (uint32_t e0 = 0; e0 < L; e0 += 256) {
+    const uint32_t e = e0 + threadIdx.x;
+    bool keep = false;
+    T key = 0;
+    if (e < L) {
+      key = src[e];
+      keep = is_row;
+      if (!is_row) {
+        uint32_t w; unsigned long long m;
+        bloom_slot<T>(key, wshift, w, m);
+        keep = (bloom[w] & m) == m;
+      }
+    }
+    const uint64_t bal = __ballot(keep);
+    if (lane == 0) wtot[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const uint32_t t = wtot[w]; if ((uint32_t)w < wave) before += t; all += t; }
+    if (FILL && keep) {
+      const uint64_t o = base + total + before + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
+      keys[o] = key; vals[o] = g;
+    }
+    total += all;
+    __syncthreads();
+  }
+  if (!FILL && threadIdx.x == 0) kept[blockIdx.x] = total;
+}
+
 // 64-bit hashes are sorted on their 32 most significant bits that vary only (half the radix passes; bottom-s MinHash
 // values are small, the bits above the largest hash are skipped as well).  Distinct hashes that agree in those bits
 // end up in one run in input order; such a run is out of order somewhere, which is what this kernel
 // looks for (a few per million hashes).  fix[0] = inversions found, fix[1] = "could not repair", fix[2..] = positions.
-constexpr uint32_t FIX_CAP = 1u << 16;
+constexpr uint32_t FIX_CAP = 1u << 20;
 constexpr uint32_t FIX_RUN_MAX = 2048;
 __global__ __launch_bounds__(256) void join_inversions_kernel(const uint64_t* __restrict__ ks, uint32_t K, int sh, uint32_t* __restrict__ fix) {
   const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,17 +319,64 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   void* hpin = nullptr;
   RTC_TRY(rtc_pinned(ctx, 64, &hpin));
   RTC_HIP(ctx, hipMemcpyAsync(hpin, d_off + ng, 16, hipMemcpyDeviceToHost, s));
+  RTC_HIP(ctx, hipMemcpyAsync((char*)hpin + 16, d_off + (std::max(row0, g0) - g0), 8, hipMemcpyDeviceToHost, s));
   RTC_HIP(ctx, hipStreamSynchronize(s));
-  const uint64_t K64 = *(const uint64_t*)hpin;
+  uint64_t K64 = *(const uint64_t*)hpin;
+  const uint64_t K_all = K64;  // before the semi-join: what the tiled kernel would walk
   const uint64_t maxkey = ((const uint64_t*)hpin)[1];
-  if (K64 < 2 || K64 >= (1ull << 31)) return RTC_OK;
+  const uint64_t K_rows = K64 - ((const uint64_t*)hpin)[2];  // hashes of the row genomes [row0, row1)
+  if (K64 < 2) return RTC_OK;
+
+  // ---- semi-join: columns keep only the hashes some row has (0: never, 1: when the rows hold less than a quarter of
+  // the hashes, 2: whenever there is a column that is not a row) ----
+  const int semi_mode = getenv("RTC_JOIN_SEMI") ? atoi(getenv("RTC_JOIN_SEMI")) : 1;
+  const bool semi = row0 > g0 && K_rows > 0 && (semi_mode >= 2 || (semi_mode == 1 && K_rows * 4 < K64 && K64 >= (1u << 22)));
+  uint32_t* d_kept = nullptr;
+  unsigned long long* d_bloom = nullptr;
+  int wshift = 0;
+  if (semi) {
+    uint64_t words = 1024;
+    while (words * 8 < K_rows) words <<= 1;  // ~8 filter bits per hash
+    wshift = 64;
+    for (uint64_t w = words; w > 1; w >>= 1) wshift--;
+    void* ws2 = nullptr;
+    const size_t b_bloom = up256(words * 8), b_kept = up256((size_t)ng * 4);
+    size_t tb_sk = 0;
+    {
+      auto it = rocprim::make_transform_iterator((const uint32_t*)nullptr, U32ToU64());
+      RTC_HIP(ctx, rocprim::inclusive_scan(nullptr, tb_sk, it, (uint64_t*)nullptr, (size_t)ng, rocprim::plus<uint64_t>(), s));
+    }
+    {
+      const int st = rtc_ws(ctx, 2, b_bloom + b_kept + up256(tb_sk) + 256, &ws2);
+      if (st == RTC_ERR_NOMEM) return RTC_OK;
+      if (st != RTC_OK) return st;
+    }
+    d_bloom = (unsigned long long*)ws2;
+    d_kept = (uint32_t*)((char*)ws2 + b_bloom);
+    void* tmpk = (char*)ws2 + b_bloom + b_kept;
+    RTC_HIP(ctx, hipMemsetAsync(d_bloom, 0, words * 8, s));
+    hipLaunchKernelGGL(join_bloom_build_kernel<T>, dim3(row1 - row0), dim3(256), 0, s, d_hashes, d_start, d_len, row0, wshift, d_bloom);
+    RTC_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL((join_semi_kernel<T, false>), dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, g0, row0, wshift,
+                       (const unsigned long long*)d_bloom, d_kept, (const uint64_t*)nullptr, (T*)nullptr, (uint32_t*)nullptr);
+    RTC_CHECK_LAUNCH(ctx);
+    auto it = rocprim::make_transform_iterator((const uint32_t*)d_kept, U32ToU64());
+    RTC_HIP(ctx, rocprim::inclusive_scan(tmpk, tb_sk, it, d_off + 1, (size_t)ng, rocprim::plus<uint64_t>(), s));  // d_off[0] stays 0
+    RTC_HIP(ctx, hipMemcpyAsync(hpin, d_off + ng, 8, hipMemcpyDeviceToHost, s));
+    RTC_HIP(ctx, hipStreamSynchronize(s));
+    K64 = *(const uint64_t*)hpin;
+    if (getenv("RTC_JOIN_DEBUG")) fprintf(stderr, "[join] semi-join: %llu row hashes, %llu of the column + row hashes kept\n",
+                                          (unsigned long long)K_rows, (unsigned long long)K64);
+    if (K64 < 2) { *handled = 1; return RTC_OK; }
+  }
+  if (K64 >= (1ull << 31)) return RTC_OK;
   const uint32_t K = (uint32_t)K64;
 
   // ---- cost rule, first half: the sort alone against the tiled kernel's probes ----
   // tiled: every column of a 1024-column block probes the table of every 64-row block below the diagonal with all
   // of its hashes, ~3.2e11 probes/s; join: ~1.1e10 (u64) / 2.8e10 (u32) sorted keys/s, ~1.5e10 co-occurrences/s
   // (radix sort on 2*bits bits + encode + emit), measured on MI355X (tools/ubench/sort_rates.hip).
-  const double avg = (double)K / ng;
+  const double avg = (double)K_all / ng;
   const double rows = (double)(row1 - row0);
   const double cols_mean = std::max(1.0, 0.5 * ((double)std::min(col1, row0) + (double)std::min(col1, row1 - 1)) - (double)col0);
   const double t_tiled = tiled_scale * (rows / 64.0 + 1.0) * cols_mean * avg / 3.2e11;
@@ -299,7 +415,11 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   uint32_t* vals1 = (uint32_t*)((char*)ws1 + 2 * b_keys + b_vals);
   uint64_t* d_eoff = (uint64_t*)((char*)ws1 + 2 * b_keys + 2 * b_vals);
   void* tmp1 = (char*)ws1 + 2 * b_keys + 2 * b_vals + b_eoff;
-  hipLaunchKernelGGL(join_flatten_kernel<T>, dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, d_off, g0, keys0, vals0);
+  if (semi)
+    hipLaunchKernelGGL((join_semi_kernel<T, true>), dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, g0, row0, wshift,
+                       (const unsigned long long*)d_bloom, (uint32_t*)nullptr, (const uint64_t*)d_off, keys0, vals0);
+  else
+    hipLaunchKernelGGL(join_flatten_kernel<T>, dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, d_off, g0, keys0, vals0);
   RTC_CHECK_LAUNCH(ctx);
   // ---- 3. partners per element, their offsets, the co-occurrence count ----
   uint32_t* d_lo = (uint32_t*)((char*)ws1 + 2 * b_keys + 2 * b_vals + b_eoff + b_tmp1);
@@ -311,7 +431,11 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   // path, tools/ubench/sort_check.hip): those inputs take the full range.
   unsigned end_bit = 1;
   while (end_bit < 8 * sizeof(T) && (maxkey >> end_bit)) end_bit++;
-  const unsigned half_bit = end_bit > 32 ? end_bit - 32 : 0;
+  // distinct hashes that agree in the b sorted bits: about K^2 / 2^(b + 3) inversions (measured 3 535 at K = 10^7, b = 32);
+  // b grows by a radix pass (8 bits) while that would not fit half the repair list
+  unsigned sort_bits = 32;
+  while (sort_bits < 64 && (double)K * (double)K / std::ldexp(1.0, (int)sort_bits + 3) > (double)(FIX_CAP / 2)) sort_bits += 8;
+  const unsigned half_bit = end_bit > sort_bits ? end_bit - sort_bits : 0;
   for (int attempt = 0; attempt < 2; attempt++) {
     const bool halfsort = sizeof(T) == 8 && attempt == 0 && half_bit > 0 && (end_bit < 64 || K >= (1u << 22)) &&
                           !getenv("RTC_JOIN_FULLSORT");

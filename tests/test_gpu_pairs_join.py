@@ -69,6 +69,11 @@ def test_join_equals_oracle_and_tiled(ctx, oracle, width):
         want = _expected(oracle, sk, r0, r1, c0, c1, radio)
         got = _edges(ctx, dev, r0, r1, c0, c1, radio, mode=2)
         assert np.array_equal(got, want), (r0, r1, c0, c1, radio)
+        os.environ["RTC_JOIN_SEMI"] = "2"  # semi-join forced: columns keep only the hashes a row has
+        try:
+            assert np.array_equal(_edges(ctx, dev, r0, r1, c0, c1, radio, mode=2), want), (r0, r1, c0, c1, radio, "semi")
+        finally:
+            os.environ.pop("RTC_JOIN_SEMI", None)
         tiled = _edges(ctx, dev, r0, r1, c0, c1, radio, mode=0)
         assert np.array_equal(tiled, want)
 
@@ -140,6 +145,13 @@ def test_join_on_real_sketches_row_shards_equal_the_tiled_kernel(ctx, kind):
         j = _edges(ctx, sk, a, b, 0, b - 1, radio, mode=2)
         d = _edges(ctx, sk, a, b, 0, b - 1, radio, mode=1)
         assert np.array_equal(t, j) and np.array_equal(t, d)
+        # the semi-join in front of the sort (columns keep only hashes some row has): forced on, and off
+        for semi in ("2", "0"):
+            os.environ["RTC_JOIN_SEMI"] = semi
+            try:
+                assert np.array_equal(_edges(ctx, sk, a, b, 0, b - 1, radio, mode=2), t), (a, b, semi)
+            finally:
+                os.environ.pop("RTC_JOIN_SEMI", None)
         total += len(t)
     assert total > n
     os.environ["RTC_PAIR_JOIN"] = "0"
