@@ -466,7 +466,11 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     E = *(const uint64_t*)hpin;
     if (getenv("RTC_JOIN_DEBUG")) fprintf(stderr, "[join] K=%u attempt=%d halfsort=%d E=%llu inversions=%u giveup=%u\n", K, attempt, (int)halfsort,
                                           (unsigned long long)E, halfsort ? ((const uint32_t*)hpin)[2] : 0u, halfsort ? ((const uint32_t*)hpin)[3] : 0u);
-    if (halfsort && ((const uint32_t*)hpin)[3]) continue;  // not repaired: sort on all bits
+    if (halfsort && ((const uint32_t*)hpin)[3]) {  // not repaired: sort on all bits -- unless the (approximate) count
+      // of the unrepaired lists already says the input is dense: then the tiled kernel runs, without a second sort
+      if (E >= (1ull << 31) || (mode == 1 && t_sort + (double)E / 1.5e10 > t_tiled)) return RTC_OK;
+      continue;
+    }
     break;
   }
   if (E == 0) { *handled = 1; return RTC_OK; }  // no two genomes of the tile share a hash: no candidates
