@@ -326,6 +326,13 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   const uint64_t maxkey = ((const uint64_t*)hpin)[1];
   const uint64_t K_rows = K64 - ((const uint64_t*)hpin)[2];  // hashes of the row genomes [row0, row1)
   if (K64 < 2) return RTC_OK;
+  // the same input (same counts, same largest hash, same tile) was found too dense for the join a moment ago
+  // (repeated steps over one sketch set): straight to the tiled kernel, no second look
+  auto& jd = ctx->join_dense;
+  const bool seen_dense = jd.K == K_all && jd.maxkey == maxkey && jd.n == n && jd.row0 == row0 && jd.row1 == row1 &&
+                          jd.col0 == col0 && jd.col1 == col1;
+  if (seen_dense && mode == 1) return RTC_OK;
+  auto note_dense = [&]() { jd.n = n; jd.row0 = row0; jd.row1 = row1; jd.col0 = col0; jd.col1 = col1; jd.K = K_all; jd.maxkey = maxkey; };
 
   // ---- semi-join: columns keep only the hashes some row has (0: never, 1: when the rows hold less than a quarter of
   // the hashes, 2: whenever there is a column that is not a row) ----
@@ -468,15 +475,15 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
                                           (unsigned long long)E, halfsort ? ((const uint32_t*)hpin)[2] : 0u, halfsort ? ((const uint32_t*)hpin)[3] : 0u);
     if (halfsort && ((const uint32_t*)hpin)[3]) {  // not repaired: sort on all bits -- unless the (approximate) count
       // of the unrepaired lists already says the input is dense: then the tiled kernel runs, without a second sort
-      if (E >= (1ull << 31) || (mode == 1 && t_sort + (double)E / 1.5e10 > t_tiled)) return RTC_OK;
+      if (E >= (1ull << 31) || (mode == 1 && t_sort + (double)E / 1.5e10 > t_tiled)) { note_dense(); return RTC_OK; }
       continue;
     }
     break;
   }
   if (E == 0) { *handled = 1; return RTC_OK; }  // no two genomes of the tile share a hash: no candidates
-  if (E >= (1ull << 31)) return RTC_OK;
+  if (E >= (1ull << 31)) { note_dense(); return RTC_OK; }
   // ---- cost rule, second half ----
-  if (mode == 1 && t_sort + (double)E / 1.5e10 > t_tiled) return RTC_OK;
+  if (mode == 1 && t_sort + (double)E / 1.5e10 > t_tiled) { note_dense(); return RTC_OK; }
 
   int bits = 1;
   while ((1ull << bits) < (uint64_t)n) bits++;

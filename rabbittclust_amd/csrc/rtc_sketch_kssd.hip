@@ -259,7 +259,9 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
   }
 }
 
-constexpr int WGB = 768;  // lanes per workgroup of the prefilter kernel: 2 workgroups per CU (64 KiB filter + queues each) = 6 waves per SIMD
+constexpr int WGB = 1024;  // lanes per workgroup of the prefilter kernel: 2 workgroups per CU (64 KiB filter + 10 KiB of queues each) = 8 waves per SIMD
+constexpr int WGB_WAVES_EU = 8;
+typedef uint16_t bq_t;     // queue entry: dword index relative to the queue's base (4-byte entries: 768 lanes, 6 waves per SIMD, 3-4 % slower)
 
 // ---- forward-strand prefilter (the default --fast configuration, K = 18..28, 24-bit dim_id) --------------
 // A k-mer is kept when the dim_id of its CANONICAL form is one of the dim_end kept dimensions (:1141-1149).
@@ -284,9 +286,10 @@ constexpr int WGB = 768;  // lanes per workgroup of the prefilter kernel: 2 work
 // lookup (the exact bucket index, read from global memory here), reduced tuple, append.
 constexpr int BLOOM_BYTES = 65536;                 // 8192 blocks x 8 B
 constexpr int BQ_CAP = 320;                        // queued positions per wave; one chunk adds at most 256
-constexpr int BQ_BYTES = (WGB / 64) * BQ_CAP * 4;
+constexpr int BQ_BYTES = (WGB / 64) * BQ_CAP * (int)sizeof(bq_t);
+constexpr int BQ_SPAN = 255;                       // chunks a wave may walk on one queue base: 255 * 256 + 255 dwords < 2^16
 constexpr int CHUNK = 1024;                        // bases a wave takes per step (64 lanes x 16)
-typedef uint32_t RTC_LDS* lds_u32_ptr;
+typedef bq_t RTC_LDS* lds_u32_ptr;
 
 struct BloomSeg {
   uint64_t g_begin, g_end, s_begin, s_end, base;   // base: queue entries are positions relative to it
@@ -332,7 +335,7 @@ __device__ __forceinline__ void bloom_drain(const uint8_t* __restrict__ seq, con
   constexpr int NDW = NQ + 1;           // dwords that cover them at any alignment
   {
     const bool have = lane < n;
-    const int64_t q0 = (int64_t)sg.base + (have ? wq[first + lane] : 0u);  // first base of the dword
+    const int64_t q0 = (int64_t)sg.base + (have ? 4 * (int64_t)wq[first + lane] : 0);  // first base of the dword
     const int64_t b0 = q0 - (K - 1);                             // first base of its first k-mer
     const int64_t a0 = b0 & ~(int64_t)3;
     uint32_t w[NDW + 1];
@@ -428,7 +431,7 @@ __device__ __forceinline__ uint32_t from_lane_below(uint32_t v, uint32_t first) 
 }
 
 template <int K>
-__global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t* __restrict__ seq,
+__global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(const uint8_t* __restrict__ seq,
                                                                const KSegment* __restrict__ segs, KssdParams P,
                                                                const uint32_t* __restrict__ g_bloom,  // 8192 x 8 B
                                                                const uint32_t* __restrict__ g_bk,     // exact index, patterns
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t
   // (fields at [6 - 2b, 30 - 2b)), which reaches into the second neighbour's bases.
   constexpr bool NARROW = DS >= 8 && DS <= 10;
   constexpr int FO0 = NARROW ? DS - 2 : 6;
-  constexpr int AHEAD = 6;                         // chunks requested ahead of the one being walked
+  constexpr int AHEAD = 4;                         // chunks requested ahead of the one being walked (4 .. 8: no difference; 4 keeps the kernel in 64 VGPRs)
   const KSegment sg = segs[blockIdx.x];
   const int t = threadIdx.x;
   const uint32_t lane = t & 63;
@@ -458,9 +461,10 @@ __global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t
   void* orow = reinterpret_cast<unsigned char*>(out) + (uint64_t)sg.genome * stride * (P.use64 ? 8 : 4);
   uint32_t* ocnt = cnt + sg.genome;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const lds_u32_ptr wq = (lds_u32_ptr)(uintptr_t)(BLOOM_BYTES + wv * BQ_CAP * 4);  // this wave's queue
+  const lds_u32_ptr wq = (lds_u32_ptr)(uintptr_t)(BLOOM_BYTES + wv * BQ_CAP * (int)sizeof(bq_t));  // this wave's queue
   uint32_t qn = 0;                                                                 // wave-uniform
-  const BloomSeg bs{sg.g_begin, sg.g_end, sg.s_begin, sg.s_end, (sg.s_begin & ~(uint64_t)(CHUNK - 1)) - 64};
+  BloomSeg bs{sg.g_begin, sg.g_end, sg.s_begin, sg.s_end, 0};  // base: set whenever the queue is empty
+  int64_t cq = 0;                                             // the chunk the queue's base points at
 
   // this wave's chunks [c, c1) of the segment's 1 KiB-aligned span
   const int64_t A0 = (int64_t)(sg.s_begin & ~(uint64_t)(CHUNK - 1));
@@ -491,12 +495,13 @@ __global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t
     // (re)start of the pipeline: once per wave, and again after the queue had to be drained mid-way
     // Full batches of 64 are taken from the end of the queue (every lane busy; a drain costs the same for 3 entries
     // as for 64); what is left (< 64) waits for the next time, or is finished after the last chunk.
-    while (qn >= 64 || (qn && c >= c1)) {
+    while (qn >= 64 || (qn && (c >= c1 || c - cq >= BQ_SPAN))) {
       const uint32_t n = qn < 64 ? qn : 64;
       bloom_drain<K>(seq, bs, P, g_bk, g_rank, var, wq, qn - n, n, lane, orow, ocnt, stride);
       qn -= n;
     }
     if (c >= c1) break;
+    if (qn == 0) { cq = c; bs.base = (uint64_t)(A0 + c * CHUNK); }  // empty queue: its base moves up to here
     if (!primed) {  // the bases in front of the first chunk
       const uint32_t Wb = pack16(fetch(c - 1));
       carry1 = __builtin_amdgcn_readlane(Wb, 63);
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t
     while (!stop) {
 #pragma unroll
       for (int j = 0; j < AHEAD; j++) {
-        if (c >= c1 || qn >= (uint32_t)(BQ_CAP - 256)) { stop = true; break; }  // done, or a full batch waits (room for a whole chunk's hits is kept)
+        if (c >= c1 || qn >= (uint32_t)(BQ_CAP - 256) || c - cq >= BQ_SPAN) { stop = true; break; }  // done, or a full batch waits (room for a whole chunk's hits is kept)
         const uint32_t W = pack16(D[j]);
         if (c + AHEAD < c1) {
           __builtin_amdgcn_sched_barrier(0);  // the request stays here (hoisted, its registers would pile up)
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t
         carry1 = __builtin_amdgcn_readlane(W, 63);
         const int64_t cb = A0 + c * CHUNK;
         const bool edge = cb < (int64_t)sg.s_begin || cb + CHUNK > (int64_t)sg.s_end;     // wave-uniform: first / last chunk of the segment
-        const uint32_t rel0 = (uint32_t)(cb - (int64_t)bs.base) + 16u * lane;            // queue entry of the lane's first dword
+        const uint32_t rel0 = (uint32_t)(cb - (int64_t)bs.base) / 4u + 4u * lane;        // queue entry of the lane's first dword
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
           uint32_t E;
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(WGB, 6) void sketch_kssd_bloom_kernel(const uint8_t
               mine = hit && pos + 3 >= (int64_t)sg.s_begin && pos < (int64_t)sg.s_end;
             }
             const uint64_t bal = __ballot(mine);
-            if (mine) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = rel0 + 4u * qd;
+            if (mine) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (bq_t)(rel0 + qd);
             qn += (uint32_t)__popcll(bal);
           }
         }
