@@ -435,6 +435,11 @@ def main():
                        "genomes_per_gpu": n_local, "genome_length": length, "k": args.k,
                        "sketch_size": args.s if mode == "minhash" else round(avg_len, 1), "sharding": f"rows/{world}",
                        "collectives": comm_kind,
+                       "pair_phase": ("inverted join on the device (rtc_pairs_join.hip): exact |A n B| of every pair that shares a hash, "
+                                      "the reference's own algorithm (src/MST.cpp:1408-1435); pairs that share none carry no edge there "
+                                      "either (:1468), nothing of the step is skipped or cached between steps"
+                                      if pair_path == 3 else
+                                      "tiled N x N kernel (rtc_pairs_tiled.hip): every pair probed"),
                        "scaling_note": "weak in genomes: per-GPU genomes (and sketch work) fixed as N grows; the pair "
                                        "space is (N x genomes_per_gpu)^2/2, so pairs per GPU grow with N"},
             "sketch_gbp_per_sec": bases_total / (sk_ms * 1e-3) / 1e9,
