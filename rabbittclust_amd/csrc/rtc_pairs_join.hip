@@ -133,10 +133,20 @@ constexpr uint32_t FIX_CAP = 1u << 20;
 constexpr uint32_t FIX_RUN_MAX = 2048;
 __global__ __launch_bounds__(256) void join_inversions_kernel(const uint64_t* __restrict__ ks, uint32_t K, int sh, uint32_t* __restrict__ fix) {
   const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a + 1 >= K) return;
-  if ((ks[a] >> sh) > (ks[a + 1] >> sh)) fix[1] = 1;  // not sorted on the bits asked for: never seen, never trusted
-  if (ks[a] > ks[a + 1]) {
-    const uint32_t i = atomicAdd(&fix[0], 1u);
+  bool inv = false;
+  if (a + 1 < K) {
+    const uint64_t x = ks[a], y = ks[a + 1];
+    if ((x >> sh) > (y >> sh)) fix[1] = 1;  // not sorted on the bits asked for: never seen, never trusted
+    inv = x > y;
+  }
+  const uint64_t bal = __ballot(inv);  // one atomic per wave
+  if (!bal) return;
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == (uint32_t)__builtin_ctzll(bal)) base = atomicAdd(&fix[0], (uint32_t)__popcll(bal));
+  base = (uint32_t)__shfl((int)base, __builtin_ctzll(bal));
+  if (inv) {
+    const uint32_t i = base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
     if (i < FIX_CAP) fix[2 + i] = a;
   }
 }
