@@ -33,6 +33,12 @@ typedef struct rtc_ctx rtc_ctx;
 int rtc_device_count(void); /* visible GPUs (0 when there is none or the runtime fails) */
 int rtc_ctx_create(int device, rtc_ctx** out);
 void rtc_ctx_destroy(rtc_ctx* ctx);
+/* Loads the device code of the pair / MST / greedy phases ahead of their first use: the HIP runtime maps a
+ * translation unit's code object at its first kernel launch (~27 ms for these phases together on MI355X), which a
+ * one-shot command line would otherwise pay between sketching and clustering.  Runs a complete toy clustering on a
+ * context of its own; meant for a helper thread beside the sketch phase (the command lines do that).  Thread-safe
+ * against work on other contexts. */
+int rtc_warmup(int device);
 int rtc_ctx_set_stream(rtc_ctx* ctx, void* hip_stream); /* NULL = default stream */
 /* Gives the context a non-blocking stream of its own: two contexts on one device, each driven by its
  * own host thread, then overlap (the command lines copy batch i+1 while batch i is sketched). */

@@ -46,6 +46,7 @@ SIGNATURES = {
     "rtc_device_count": (_i, []),
     "rtc_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "rtc_ctx_destroy": (None, [_vp]),
+    "rtc_warmup": (_i, [_i]),
     "rtc_ctx_set_stream": (_i, [_vp, _vp]),
     "rtc_ctx_own_stream": (_i, [_vp]),
     "rtc_ctx_sync": (_i, [_vp]),

@@ -28,6 +28,7 @@ struct rtc_ctx {
   // tiled pair kernel: the last plan (slice offsets + transposed column copy in scratch slots 1 / 4).
   // Reused only while pair_plan_hold is set by a caller that guarantees unchanged sketches between
   // launches (the row-chunk loop of the dense candidate-edge path).
+  int quiet = 0;           // rtc_warmup's context: no RTC_VERBOSE lines
   int pair_last_path = 0;  // rtc_pair_last_path
   // the inverted join's last refusal for density: (genomes, hashes, largest hash, tile) of the input it counted
   struct { uint32_t n = 0, row0 = 0, row1 = 0, col0 = 0, col1 = 0; uint64_t K = 0, maxkey = 0; } join_dense;

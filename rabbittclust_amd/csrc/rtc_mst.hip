@@ -760,7 +760,7 @@ int rtc_mst_dense(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t*
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const uint32_t s_fixed = rtc_fixed_size_of(h_len.data(), n);
 
-  const bool verbose = getenv("RTC_VERBOSE") != nullptr;
+  const bool verbose = getenv("RTC_VERBOSE") != nullptr && !ctx->quiet;
   auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
   const double tv0 = now();
   rtc_edge_list el{};

@@ -8,6 +8,7 @@
 //           Handles any sketch size / width; used as fallback and as on-device cross-check.
 //   algo 2  (rtc_pairs_tiled.hip) LDS mask-table tiles.
 #include <algorithm>
+#include <vector>
 
 #include "rtc_internal.h"
 
@@ -175,4 +176,45 @@ extern "C" int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width,
                                   d_count));
   }
   return RTC_OK;
+}
+
+// ---- rtc_warmup: a toy clustering that touches every translation unit of the pair / MST / greedy phases ----
+extern "C" int rtc_warmup(int device) {
+  rtc_ctx* ctx = nullptr;
+  RTC_TRY(rtc_ctx_create(device, &ctx));
+  ctx->quiet = 1;
+  int st = RTC_OK;
+  void *d_h = nullptr, *d_s = nullptr, *d_l = nullptr, *d_e = nullptr, *d_c = nullptr;
+  do {
+    const uint32_t n = 12, s = 24;  // twelve sketches of 24 hashes, neighbours share half of them
+    std::vector<uint64_t> h((size_t)n * s), start(n);
+    std::vector<uint32_t> len(n, s), cfg(n, s);
+    for (uint32_t g = 0; g < n; g++) {
+      start[g] = (uint64_t)g * s;
+      for (uint32_t e = 0; e < s; e++) h[(size_t)g * s + e] = ((uint64_t)(g / 2) * s + e + (g & 1) * (s / 2) + 1) * 0x9E3779B97F4A7C15ULL >> 12;
+      std::sort(h.begin() + (size_t)g * s, h.begin() + (size_t)(g + 1) * s);
+    }
+#define W_HIP(call) if ((call) != hipSuccess) { st = rtc_fail(ctx, RTC_ERR_HIP, "rtc_warmup: %s", #call); break; }
+    W_HIP(hipMalloc(&d_h, h.size() * 8)); W_HIP(hipMalloc(&d_s, n * 8)); W_HIP(hipMalloc(&d_l, n * 4));
+    W_HIP(hipMalloc(&d_e, 4096 * sizeof(rtc_cedge))); W_HIP(hipMalloc(&d_c, 8));
+    W_HIP(hipMemcpy(d_h, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    W_HIP(hipMemcpy(d_s, start.data(), n * 8, hipMemcpyHostToDevice));
+    W_HIP(hipMemcpy(d_l, len.data(), n * 4, hipMemcpyHostToDevice));
+    W_HIP(hipMemset(d_c, 0, 8));
+#undef W_HIP
+    int handled = 0;
+    st = rtc_pair_edges_join(ctx, d_h, 8, (const uint64_t*)d_s, (const uint32_t*)d_l, n, 1, n, 0, n - 1, -1, (rtc_cedge*)d_e, 4096,
+                             (uint64_t*)d_c, -1.0, &handled);                                 // join + rocPRIM
+    if (st != RTC_OK) break;
+    std::vector<rtc_edge> mst(n);
+    uint64_t m = 0;
+    st = rtc_mst(ctx, d_h, 8, (const uint64_t*)d_s, (const uint32_t*)d_l, n, 21, 0, 0.05, mst.data(), &m);  // tiled kernel, Boruvka, forest sort
+    if (st != RTC_OK) break;
+    std::vector<int32_t> rep(n);
+    uint32_t ncl = 0;
+    st = rtc_greedy(ctx, d_h, 8, (const uint64_t*)d_s, (const uint32_t*)d_l, n, cfg.data(), 21, 0, 0, 0.05, rep.data(), &ncl);
+  } while (false);
+  (void)hipFree(d_h); (void)hipFree(d_s); (void)hipFree(d_l); (void)hipFree(d_e); (void)hipFree(d_c);
+  rtc_ctx_destroy(ctx);
+  return st;
 }

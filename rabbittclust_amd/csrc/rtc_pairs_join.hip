@@ -297,7 +297,7 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
               uint32_t row1, uint32_t col0, uint32_t col1, int radio, rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count,
               double tiled_scale, int* handled) {
   *handled = 0;
-  const int mode = join_mode();
+  const int mode = tiled_scale < 0 ? 2 : join_mode();  // tiled_scale < 0: rtc_warmup wants this path whatever the input
   if (mode <= 0 || ctx->pair_plan_hold) return RTC_OK;
   // only pairs (row, col) with col < row exist: genomes outside [g0, g1) take no part
   const uint32_t g0 = std::min(col0, row0), g1 = row1;

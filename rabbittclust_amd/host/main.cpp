@@ -1601,6 +1601,14 @@ int main(int argc, char** argv) {
   }
   rtc_ctx* ctx = gpus[0].ctx;
   if (getenv("RTC_VERBOSE")) fprintf(stderr, "[ctx]   HIP runtime + %zu GPU context(s) in %.3fs\n", gpus.size(), get_sec() - t_main);
+  // The device code of the pair / MST / greedy phases is mapped at its first launch (~27 ms): a helper thread does
+  // that with a toy clustering while this one reads and sketches (rtc_warmup; RTC_NO_WARMUP=1 leaves it out).
+  struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } warm;
+  if (!getenv("RTC_NO_WARMUP")) {
+    std::vector<int> wdev;
+    for (const Gpu& g : gpus) wdev.push_back(g.device);
+    warm.t = std::thread([wdev]() { for (int d : wdev) (void)rtc_warmup(d); });
+  }
   Resident rs;
 #ifndef GREEDY_CLUST
   if (o.has_append) return append_clust_mst(o, gpus);
