@@ -34,8 +34,8 @@ PROFILE_JSON = ("r03_pmc_traffic.json", "r03_kssd_pmc_traffic.json", "r02_pmc_tr
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mode", choices=("minhash", "kssd"), default="minhash")
     ap.add_argument("--genomes", type=int, default=0, help="genomes per GPU (0 = the BASELINE shape for --gpus/--mode)")
     ap.add_argument("--length", type=int, default=0, help="bases per genome (0 = 5 000 000 minhash / 2 000 000 kssd)")
