@@ -150,10 +150,18 @@ __device__ __forceinline__ uint32_t hash_test_word(const HashParts& p) {
   const uint64_t S = p.f1 + p.f2;
   const uint32_t slo = (uint32_t)S, shi = (uint32_t)(S >> 32);
   const uint32_t cl = (uint32_t)FMIX_C2, ch = (uint32_t)(FMIX_C2 >> 32);
-  return __umulhi(slo, cl) + slo * ch + shi * cl + 1u;
+  // as a chain of two 32-bit multiply-adds (v_mad_u64_u32, low word) on top of the v_mul_hi: one three-input add fewer
+  uint32_t m = __umulhi(slo, cl);
+  asm("" : "+v"(m));
+  uint32_t r = slo * ch + m;
+  asm("" : "+v"(r));
+  uint32_t r2 = shi * cl + r;
+  asm("" : "+v"(r2));
+  return r2 + 1u;
 }
 
 constexpr uint64_t MM_C1 = 0x87c37b91114253d5ULL, MM_C2 = 0x4cf5ad432745937fULL;
+constexpr uint32_t MASH_SEED = 42;  // the seed of every reference call site (Sketch::MinHash)
 
 __device__ __forceinline__ uint32_t codes_to_ascii(uint32_t e) {
   // e holds 4 base codes, first base in bits 7..6; returns the 4 ASCII bytes, first base lowest
@@ -531,7 +539,10 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
   uint32_t qn = 0;  // entries waiting in it (wave-uniform)
 
   const Segment sg = segs[blockIdx.x];
-  const KParams P = make_kparams(k, seed, PK);
+  // compile-time-k instantiations serve the reference's seed only (MASH_SEED, the launch sends any other seed to the
+  // runtime-k kernel): as an inline constant the two seed xors per k-mer stay fast-class VALU (an SGPR source makes
+  // v_xor_b32 a 4.4-cycle instruction, profiles/r03_valu_issue_cost2.txt)
+  const KParams P = make_kparams(k, KT > 0 ? MASH_SEED : seed, PK);
   const int t = threadIdx.x;
   const uint32_t lane = t & 63;
   const uint32_t s = sg.sketch_size;
@@ -639,13 +650,14 @@ restart:
           const uint8_t* base = (tile - LOAD_BIAS) + (uint32_t)(rq0 + LOAD_BIAS);
           const uint32_t Thi1 = Thi_e + TEST_SLACK;
           uint4 cur = *reinterpret_cast<const uint4*>(base), nxt1 = *reinterpret_cast<const uint4*>(base + 16);
-          // the reverse-complement extended window is kept shifted left by RE bits so that the byte of a new
-          // dword lands on a byte boundary: one v_perm (high word) + one v_alignbit (low word) roll it
-          constexpr int RE = (8 - (2 * KT) % 8) % 8, NBY = (2 * KT + RE) / 8;
-          constexpr uint32_t RSEL = (uint32_t)(0 == NBY - 4 ? 0x00 : (0 < NBY - 4 ? 5 : 0x0c)) |
-                                    (uint32_t)(1 == NBY - 4 ? 0x00 : (1 < NBY - 4 ? 6 : 0x0c)) << 8 |
-                                    (uint32_t)(2 == NBY - 4 ? 0x00 : (2 < NBY - 4 ? 7 : 0x0c)) << 16 |
-                                    (uint32_t)(3 == NBY - 4 ? 0x00 : 0x0c) << 24;
+          // Both extended windows are kept top-aligned for ONE k-mer of a dword, which is then cut without a shift:
+          // the forward one as FT = F << FS (first k-mer of the dword on top; the new byte enters at bit FS), the
+          // reverse-complement one as R << RE with the newest byte in the top byte (last k-mer of the dword on top):
+          // one v_perm (high word) + one v_alignbit (low word) roll it.
+          constexpr int FS = 58 - 2 * KT, RE = 56 - 2 * KT;
+          static_assert(FS >= 0 && FS + 8 <= 32 && RE >= 0, "express walk: 17 <= k <= 28");
+          constexpr uint32_t RSEL = 0x00070605u;  // {rp byte 0, Rhi bytes 3, 2, 1}
+          uint64_t FT = 0;
           uint32_t Rhi = 0, Rlo = 0;
           g0 = NG;
 #pragma unroll
@@ -660,7 +672,7 @@ restart:
               bad = __builtin_amdgcn_bitop3_b32(bad, __builtin_amdgcn_perm(0u, 0x54474341u, codes[qd]), w[qd], 0xF6);  // bad | (perm ^ w)
             }
             if (__ballot((bad & 0xDFDFDFDFu) != 0u)) { g0 = g; break; }
-            const uint64_t fwd0 = fwd;
+            const uint64_t FT0 = FT;
             const uint32_t Rhi0 = Rhi, Rlo0 = Rlo, qn0 = qn;
             bool lost = false;  // wave-uniform: the queue could not take this group's candidates
 #pragma unroll
@@ -669,7 +681,7 @@ restart:
               // reverse-complement byte 255 - (c0 + 4 c1 + 16 c2 + 64 c3) as the LOW BYTE of a dot product with the
               // weights 256 - {1, 4, 16, 64} on top of 255 (only that byte is used: v_perm picks it)
               const uint32_t rp = __builtin_amdgcn_udot4(codes[qd], 0xC0F0FCFFu, 255u, false);
-              const uint64_t F = (fwd << 8) | pack;
+              FT = (FT << 8) | (uint64_t)(pack << FS);  // v_lshlrev_b64 + v_lshl_or_b32
               const uint32_t nhi = __builtin_amdgcn_perm(Rhi, rp, RSEL);
               Rlo = __builtin_amdgcn_alignbit(Rhi, Rlo, 8);
               Rhi = nhi;
@@ -678,8 +690,8 @@ restart:
                 HashParts hp[4];
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
-                  const uint64_t f = F << (P.lshift - 6 + 2 * b);
-                  const uint64_t r = R << (P.lshift - 2 - 2 * b - RE);
+                  const uint64_t f = FT << (2 * b);
+                  const uint64_t r = R << (6 - 2 * b);
                   hp[b] = kmer_hash_parts(f < r ? f : r, P);
                 }
                 uint64_t cm = 0, mq[4];
@@ -710,12 +722,12 @@ restart:
                   }
                 }
               }
-              fwd = F;
             }
-            if (lost) { fwd = fwd0; Rhi = Rhi0; Rlo = Rlo0; qn = qn0; g0 = g; break; }
+            if (lost) { FT = FT0; Rhi = Rhi0; Rlo = Rlo0; qn = qn0; g0 = g; break; }
             cur = nxt1;
             nxt1 = nxt2;
           }
+          fwd = FT >> FS;
           rc = (((uint64_t)Rhi << 32) | Rlo) >> (RE + 8);  // the general walk's form
           run = 16 * g0;
         }
@@ -1193,7 +1205,7 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   // genomes (recommended k = ceil(log4(maxSize * 9999)) = 17..23, accepted up to +3), its default 21
   // and the customary 31/32; anything else takes the runtime-k kernel
   auto kern = packed ? sketch_minhash_kernel<0, true> : sketch_minhash_kernel<0, false>;
-  switch (k) {
+  switch (seed == MASH_SEED ? k : 0) {
 #define RTC_K(K) case K: kern = packed ? sketch_minhash_kernel<K, true> : sketch_minhash_kernel<K, false>; break;
     RTC_K(16) RTC_K(17) RTC_K(18) RTC_K(19) RTC_K(20) RTC_K(21) RTC_K(22) RTC_K(23) RTC_K(24)
     RTC_K(25) RTC_K(26) RTC_K(27) RTC_K(28) RTC_K(29) RTC_K(30) RTC_K(31) RTC_K(32)
