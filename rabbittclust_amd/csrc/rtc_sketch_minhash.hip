@@ -293,8 +293,16 @@ __device__ __forceinline__ uint64_t word_k2(const u32x4 e, uint32_t BL) {
   return __builtin_bit_cast(uint64_t, make_uint2((uint32_t)R, (uint32_t)(R >> 32) + cross));
 }
 
+// The table words of one k-mer: what its LDS reads return (fields a k does not use are never read or touched).
+// Two phases so that a caller can have the reads of one k-mer in flight under the arithmetic of another:
+// kmer_loads issues them (offsets + ds_read), kmer_hash_finish consumes them.
+struct KmerLoads {
+  u32x4 e[4];       // 16-byte entries {P.lo, P.hi, AH, (BL)} of the words with a table pair
+  uint32_t bl[4];   // lo(b * c) of their second halves
+  uint64_t dt;      // the last word's own table entry (lut_direct)
+};
 // x: canonical k-mer, 2 bits per base, first base in the top bits (canon << (64 - 2k))
-__device__ __forceinline__ HashParts kmer_hash_parts(uint64_t x, const KParams& P) {
+__device__ __forceinline__ KmerLoads kmer_loads(uint64_t x, const KParams& P) {
   const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
   const int k = P.k;
   // the tables start at LDS address 0 (checked at kernel entry), so an LDS address is a table offset:
@@ -315,19 +323,42 @@ __device__ __forceinline__ HashParts kmer_hash_parts(uint64_t x, const KParams& 
                                                                      : (((H) >> (32 - 2 * dnb)) << 3))))
 #define RTC_LO(w, off) (*(lds_u4_cptr)(uintptr_t)((off) + (uint32_t)((w) * LUT_LO_BYTES)))
 #define RTC_HI(w, off) (*(lds_u32_cptr)(uintptr_t)((off) + (pk ? (uint32_t)((w) * LUT_LO_BYTES) + 12u : hi_base + (uint32_t)((w) * LUT_HI_BYTES))))
-  uint64_t K0 = 0, K1 = 0, K2 = 0, K3 = 0;  // the words' contributions, already rotl(w * c, r) * c'
+  KmerLoads L = {};
   const int dw = lut_direct(k) ? lut_words(k) - 1 : -1;  // the word that has a table of its own
-  if (dw == 0) K0 = RTC_DT(hi, false);
-  else K0 = word_k1(RTC_LO(0, byte_x8<3>(hi, four)), k > 4 ? RTC_HI(0, byte_x8<2>(hi, hsh)) : 0u);
-  if (dw == 1) K1 = RTC_DT(hi, true);
-  else if (k > 8) K1 = word_k2(RTC_LO(1, byte_x8<1>(hi, four)), k > 12 ? RTC_HI(1, byte_x8<0>(hi, hsh)) : 0u);
-  if (dw == 2) K2 = RTC_DT(lo, false);
-  else if (k > 16) K2 = word_k1(RTC_LO(2, byte_x8<3>(lo, four)), k > 20 ? RTC_HI(2, byte_x8<2>(lo, hsh)) : 0u);
-  if (dw == 3) K3 = RTC_DT(lo, true);
-  else if (k > 24) K3 = word_k2(RTC_LO(3, byte_x8<1>(lo, four)), k > 28 ? RTC_HI(3, byte_x8<0>(lo, hsh)) : 0u);
+  if (dw == 0) L.dt = RTC_DT(hi, false);
+  else { L.e[0] = RTC_LO(0, byte_x8<3>(hi, four)); if (k > 4) L.bl[0] = RTC_HI(0, byte_x8<2>(hi, hsh)); }
+  if (dw == 1) L.dt = RTC_DT(hi, true);
+  else if (k > 8) { L.e[1] = RTC_LO(1, byte_x8<1>(hi, four)); if (k > 12) L.bl[1] = RTC_HI(1, byte_x8<0>(hi, hsh)); }
+  if (dw == 2) L.dt = RTC_DT(lo, false);
+  else if (k > 16) { L.e[2] = RTC_LO(2, byte_x8<3>(lo, four)); if (k > 20) L.bl[2] = RTC_HI(2, byte_x8<2>(lo, hsh)); }
+  if (dw == 3) L.dt = RTC_DT(lo, true);
+  else if (k > 24) { L.e[3] = RTC_LO(3, byte_x8<1>(lo, four)); if (k > 28) L.bl[3] = RTC_HI(3, byte_x8<0>(lo, hsh)); }
 #undef RTC_LO
 #undef RTC_HI
 #undef RTC_DT
+  return L;
+}
+__device__ __forceinline__ HashParts kmer_hash_finish(const KmerLoads& L, const KParams& P) {
+  const int k = P.k;
+  uint64_t K0 = 0, K1 = 0, K2 = 0, K3 = 0;  // the words' contributions, already rotl(w * c, r) * c'
+  const int dw = lut_direct(k) ? lut_words(k) - 1 : -1;
+  // The unused fourth dword of a 16-byte entry counts as live until here (an empty asm, no instruction): otherwise the
+  // register allocator hands that register to the next read's address while the ds_read_b128 is still in flight and
+  // has to wait for it (s_waitcnt lgkmcnt(0) between two reads of one k-mer -- the round trip this split exists to hide).
+  if (!P.packed) {
+    if (dw != 0) asm volatile("" :: "v"(L.e[0].w));
+    if (dw != 1 && k > 8) asm volatile("" :: "v"(L.e[1].w));
+    if (dw != 2 && k > 16) asm volatile("" :: "v"(L.e[2].w));
+    if (dw != 3 && k > 24) asm volatile("" :: "v"(L.e[3].w));
+  }
+  if (dw == 0) K0 = L.dt;
+  else K0 = word_k1(L.e[0], k > 4 ? L.bl[0] : 0u);
+  if (dw == 1) K1 = L.dt;
+  else if (k > 8) K1 = word_k2(L.e[1], k > 12 ? L.bl[1] : 0u);
+  if (dw == 2) K2 = L.dt;
+  else if (k > 16) K2 = word_k1(L.e[2], k > 20 ? L.bl[2] : 0u);
+  if (dw == 3) K3 = L.dt;
+  else if (k > 24) K3 = word_k2(L.e[3], k > 28 ? L.bl[3] : 0u);
   uint64_t h1 = P.seed, h2 = P.seed;
   uint64_t t0 = K0, t1 = K1;  // tail contributions
   if (k >= 16) {
@@ -356,6 +387,9 @@ __device__ __forceinline__ HashParts kmer_hash_parts(uint64_t x, const KParams& 
   h2 ^= (uint64_t)k;
   h1 += h2; h2 += h1;
   return HashParts{fmix64_open(h1), fmix64_open(h2)};
+}
+__device__ __forceinline__ HashParts kmer_hash_parts(uint64_t x, const KParams& P) {
+  return kmer_hash_finish(kmer_loads(x, P), P);
 }
 __device__ __forceinline__ uint64_t kmer_hash(uint64_t x, const KParams& P) {
   const uint64_t h = mm_finish(kmer_hash_parts(x, P));
@@ -675,6 +709,30 @@ restart:
             const uint64_t FT0 = FT;
             const uint32_t Rhi0 = Rhi, Rlo0 = Rlo, qn0 = qn;
             bool lost = false;  // wave-uniform: the queue could not take this group's candidates
+            // The k-mers of a group run as a two-stage pipeline: the table reads of k-mer n + 1 are issued before the
+            // arithmetic of k-mer n, so a wave does not park on every LDS round trip (the compiler's own order issues a
+            // word's reads right in front of their use: three waits per k-mer); the pipeline drains at the group's end.
+            KmerLoads pend = {};
+            bool have = false;  // (folds away: everything here is unrolled)
+            // finishes the pending k-mer: hash halves, high-word test, a possible candidate to the queue (per k-mer, so
+            // that no halves stay live across the dword: the registers go to the reads in flight)
+            auto finish_pending = [&]() __attribute__((always_inline)) {
+              const HashParts hp = kmer_hash_finish(pend, P);
+              const uint64_t mq = __ballot(hash_test_word(hp) <= Thi1);
+              if (mq) {  // wave-uniform, rare
+                const uint32_t add = (uint32_t)__popcll(mq);
+                if (qn + add <= (uint32_t)QCAP) {
+                  if (__builtin_amdgcn_inverse_ballot_w64(mq)) {
+                    const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+                    wq[2 * slot] = hp.f1;
+                    wq[2 * slot + 1] = hp.f2;
+                  }
+                  qn += add;
+                } else {
+                  lost = true;
+                }
+              }
+            };
 #pragma unroll
             for (int qd = 0; qd < 4; qd++) {
               const uint32_t pack = __builtin_amdgcn_udot4(codes[qd], 0x01041040u, 0u, false);
@@ -687,42 +745,20 @@ restart:
               Rhi = nhi;
               const uint64_t R = ((uint64_t)Rhi << 32) | Rlo;  // = (general walk's R) << RE
               if (g * 4 + qd >= WARM_DW) {
-                HashParts hp[4];
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                   const uint64_t f = FT << (2 * b);
                   const uint64_t r = R << (6 - 2 * b);
-                  hp[b] = kmer_hash_parts(f < r ? f : r, P);
-                }
-                uint64_t cm = 0, mq[4];
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                  const uint32_t u = hash_test_word(hp[b]);
-                  mq[b] = __ballot(u <= Thi1);
-                  cm |= mq[b];
-                }
-                if (cm) {  // wave-uniform, rare
-                  const uint32_t add = (uint32_t)(__popcll(mq[0]) + __popcll(mq[1]) + __popcll(mq[2]) + __popcll(mq[3]));
-                  if (qn + add <= (uint32_t)QCAP) {
-                    uint32_t qb = qn;
-#pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                      if (mq[b]) {  // wave-uniform
-                        if (__builtin_amdgcn_inverse_ballot_w64(mq[b])) {
-                          const uint32_t slot = qb + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq[b] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq[b], 0u));
-                          wq[2 * slot] = hp[b].f1;
-                          wq[2 * slot + 1] = hp[b].f2;
-                        }
-                        qb += (uint32_t)__popcll(mq[b]);
-                      }
-                    }
-                    qn = qb;
-                  } else {
-                    lost = true;
-                  }
+                  const KmerLoads nl = kmer_loads(f < r ? f : r, P);
+                  __builtin_amdgcn_sched_barrier(0);
+                  if (have) finish_pending();
+                  __builtin_amdgcn_sched_barrier(0);
+                  pend = nl;
+                  have = true;
                 }
               }
             }
+            if (have) finish_pending();
             if (lost) { FT = FT0; Rhi = Rhi0; Rlo = Rlo0; qn = qn0; g0 = g; break; }
             cur = nxt1;
             nxt1 = nxt2;
