@@ -719,7 +719,7 @@ restart:
             auto finish_pending = [&]() __attribute__((always_inline)) {
               const HashParts hp = kmer_hash_finish(pend, P);
               const uint64_t mq = __ballot(hash_test_word(hp) <= Thi1);
-              if (mq) {  // wave-uniform, rare
+              if (__builtin_expect(mq != 0, 0)) {  // wave-uniform, rare: kept out of line, the common path falls through
                 const uint32_t add = (uint32_t)__popcll(mq);
                 if (qn + add <= (uint32_t)QCAP) {
                   if (__builtin_amdgcn_inverse_ballot_w64(mq)) {
