@@ -13,7 +13,10 @@
 //     with one LDS atomic per wave; when the buffer fills, an in-LDS bitonic sort over the live
 //     count + dedup keeps the s smallest distinct values and lowers T.
 // Large genomes / small batches are split into several segments whose partial sketches are
-// merged by merge_partials_kernel (bottom-s is a mergeable summary).
+// merged by merge_partials_kernel (bottom-s is a mergeable summary).  The segments of a genome all start
+// from the genome's threshold (3x the expected s-th smallest hash), as a whole-genome workgroup does; a
+// genome whose merged partial sketches hold fewer than s hashes is flagged and walked once more without it
+// (a second, gated launch over the partial segments -- every other workgroup of it leaves at once).
 #include <algorithm>
 
 #include "rtc_internal.h"
@@ -556,7 +559,8 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
                                                             int k_arg, uint32_t seed, int cap,
                                                             uint64_t* out,
                                                             uint32_t* cnt, int pass_no,
-                                                            uint64_t* parts, uint32_t* pcnt) {
+                                                            uint64_t* parts, uint32_t* pcnt,
+                                                            const uint32_t* __restrict__ redo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int k = KT > 0 ? KT : k_arg;
   constexpr int WARM_DW = warm_dw(KT);
@@ -573,6 +577,9 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
   uint32_t qn = 0;  // entries waiting in it (wave-uniform)
 
   const Segment sg = segs[blockIdx.x];
+  // second launch over the partial segments: only the genomes whose merged partial sketches came out short of s
+  // under the starting threshold (flagged by merge_partials_kernel) are walked again, from "everything passes"
+  if (redo && redo[sg.final_slot] == 0) return;  // workgroup-uniform
   // compile-time-k instantiations serve the reference's seed only (MASH_SEED, the launch sends any other seed to the
   // runtime-k kernel): as an inline constant the two seed xors per k-mer stay fast-class VALU (an SGPR source makes
   // v_xor_b32 a 4.4-cycle instruction, profiles/r03_valu_issue_cost2.txt)
@@ -601,7 +608,9 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
   // grew with s -- 6 % of the kernel at s = 1000, 20 % with 1 Mbp genomes) and changes nothing in the
   // result as long as s distinct hashes below T0 exist (3 s expected); if fewer than s were found -- a
   // genome with few distinct k-mers -- the workgroup simply runs again from T0 = "none".
-  uint64_t Tstart = (pass_no == 0 && !sg.partial) ? sg.t0 : SENT;
+  // (A partial segment starts from the genome's T0 as well: the union of the segments' hashes below T0 holds the s
+  // smallest of the genome whenever s of them exist; if not, the merge flags the genome for the second launch.)
+  uint64_t Tstart = (pass_no == 0 && !redo) ? sg.t0 : SENT;
 restart:
   if (t == 0) { ctrl->T = Tstart; ctrl->T0 = Tstart; ctrl->sorted = 0; ctrl->count = 0; ctrl->overflow = 0; ctrl->saw_max = 0; ctrl->scan_base = 0; }
   build_kmer_lut(lut, k, PK);
@@ -995,7 +1004,7 @@ restart:
   }
   drain_queue();
   uint32_t n = merge_block(buf, ctrl, cap, s).count;
-  if (n < s && Tstart != SENT) {  // workgroup-uniform: the starting threshold was too optimistic for this genome
+  if (n < s && Tstart != SENT && !sg.partial) {  // workgroup-uniform: the starting threshold was too optimistic for this genome
     Tstart = SENT;
     __syncthreads();
     goto restart;
@@ -1021,14 +1030,14 @@ struct MergeJob {
   uint32_t stride;
   uint32_t expect;     // hashes the genome holds from earlier passes (0 in the first pass)
   uint32_t pass;
-  uint32_t pad;
+  uint32_t t0_used;    // the segments started from a threshold: fewer than s merged hashes flag the genome for a second walk
 };
 
 __global__ __launch_bounds__(WG) void merge_partials_kernel(const MergeJob* __restrict__ jobs,
                                                             const uint64_t* __restrict__ parts,
                                                             const uint32_t* __restrict__ pcnt, int cap,
                                                             uint64_t* out,
-                                                            uint32_t* cnt) {
+                                                            uint32_t* cnt, uint32_t* redo, int redo_run) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const lds_u64_ptr buf = (lds_u64_ptr)(lds_byte_ptr)smem;
   const lds_ctrl_ptr ctrl = (lds_ctrl_ptr)((lds_byte_ptr)smem + (size_t)cap * 8);
@@ -1036,6 +1045,7 @@ __global__ __launch_bounds__(WG) void merge_partials_kernel(const MergeJob* __re
   const int t = threadIdx.x;
   const uint32_t s = jb.sketch_size;
   if (jb.pass > 0 && cnt[jb.cnt_slot] != jb.expect) return;  // genome exhausted by earlier passes
+  if (redo_run && redo[jb.cnt_slot] == 0) return;            // second launch: flagged genomes only
   if (t == 0) { ctrl->T = SENT; ctrl->T0 = SENT; ctrl->sorted = 0; ctrl->count = 0; ctrl->overflow = 0; ctrl->saw_max = 0; ctrl->scan_base = 0; }
   __syncthreads();
   uint32_t nmerged = 0;
@@ -1059,6 +1069,7 @@ __global__ __launch_bounds__(WG) void merge_partials_kernel(const MergeJob* __re
   if (t == 0) {
     if (ctrl->saw_max && n < s) { o[n] = SENT; n++; }
     cnt[jb.cnt_slot] = jb.expect + n;
+    if (!redo_run && jb.t0_used && n < s) redo[jb.cnt_slot] = 1;  // the genome may hold hashes above its starting threshold
   }
 }
 
@@ -1127,6 +1138,7 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   uint64_t seg_len = total / target_segs;
   const uint64_t min_seg = 4ull * TILE_BASES;
   if (seg_len < min_seg) seg_len = min_seg;
+  const uint64_t seg_pref = 24ull * TILE_BASES;  // preferred segment of the few-genomes plan below
 
   // segments per genome: ~equal-length pieces of seg_len; 1 = the whole genome in one workgroup
   std::vector<uint32_t> nsv(n);
@@ -1159,6 +1171,37 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     }
   }
 
+  // Few genomes (fewer whole-genome workgroups than the chip holds at a time): the segments are dealt out so that
+  // their number is a whole multiple of the slots -- every genome gets its share of R x slots segments by largest
+  // remainder, so the workgroups are of nearly equal length and the last round is as full as the first (rounding
+  // each genome on its own left e.g. 2 000 x 5 Mbp with 4 000 workgroups for 768 slots: 5.2 rounds).
+  if (n_single <= slots && total >= (uint64_t)slots * min_seg) {
+    uint64_t rounds = total / ((uint64_t)slots * seg_pref);
+    if (const char* e = getenv("RTC_SKETCH_ROUNDS")) rounds = (uint64_t)std::max(1, atoi(e));  // tuning
+    rounds = std::max<uint64_t>(1, std::min<uint64_t>(rounds, total / ((uint64_t)slots * min_seg)));
+    const uint64_t want = rounds * slots;
+    std::vector<std::pair<double, uint32_t>> frac;
+    frac.reserve(n);
+    uint64_t given = 0;
+    for (uint32_t g = 0; g < n; g++) {
+      const uint64_t len = h_off[g + 1] - h_off[g];
+      const double quota = (double)len * (double)want / (double)total;
+      uint64_t ns = (uint64_t)quota;
+      const uint64_t most = std::min<uint64_t>(std::max<uint64_t>(len / min_seg, 1), 4096);
+      if (ns < 1) ns = 1;
+      if (ns > most) ns = most;
+      nsv[g] = (uint32_t)ns;
+      given += ns;
+      if (ns < most) frac.emplace_back(quota - (double)ns, g);
+    }
+    if (given < want) {
+      std::sort(frac.begin(), frac.end(), [](const std::pair<double, uint32_t>& a, const std::pair<double, uint32_t>& b) {
+        return a.first != b.first ? a.first > b.first : a.second < b.second;
+      });
+      for (size_t i = 0; i < frac.size() && given < want; i++) { nsv[frac[i].second]++; given++; }
+    }
+  }
+
   // starting threshold = t0_factor x the expected s-th smallest hash (0: start from "everything passes").  3 keeps
   // the restart away down to genomes whose distinct k-mers are a third of their length, and every early tile lets
   // 3 s / N of its k-mers through instead of 8 s / N: 50 000 x 1 Mbp 115 -> 107 ms, config 4's sketches 163 -> 150 ms
@@ -1170,6 +1213,7 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   std::vector<MergeJob> jobs;
   uint64_t part_elems_max = 0;
   uint32_t part_slots_max = 0;
+  bool any_partial_t0 = false;
   for (uint32_t ps = 0; ps < npass; ps++) {
     PassPlan& pl = plans[ps];
     pl.direct0 = direct.size(); pl.partial0 = partial.size(); pl.job0 = jobs.size();
@@ -1190,10 +1234,14 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
           t0 = (uint64_t)((((unsigned __int128)1 << 64) * ((uint64_t)t0_factor * s)) / len);
         direct.push_back(Segment{b, e, b, e, out_off, lo_off, g, s, g, expect, 0, 0, t0});
       } else {
-        jobs.push_back(MergeJob{part_elems, part_slots, (uint32_t)ns, out_off, g, s, chunk_max, expect, ps, 0});
+        uint64_t t0 = SENT;  // the genome's starting threshold, shared by its segments
+        if (ps == 0 && t0_factor > 0 && s > 0 && len > (uint64_t)t0_factor * s)
+          t0 = (uint64_t)((((unsigned __int128)1 << 64) * ((uint64_t)t0_factor * s)) / len);
+        if (t0 != SENT) any_partial_t0 = true;
+        jobs.push_back(MergeJob{part_elems, part_slots, (uint32_t)ns, out_off, g, s, chunk_max, expect, ps, t0 != SENT ? 1u : 0u});
         for (uint64_t i = 0; i < ns; i++) {
           const uint64_t sb = b + len * i / ns, se = b + len * (i + 1) / ns;
-          partial.push_back(Segment{b, e, sb, se, part_elems, lo_off, part_slots, s, g, expect, 1, 0, SENT});
+          partial.push_back(Segment{b, e, sb, se, part_elems, lo_off, part_slots, s, g, expect, 1, 0, t0});
           part_elems += chunk_max;
           part_slots++;
         }
@@ -1218,15 +1266,18 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   const size_t bseg = segs.size() * sizeof(Segment);
   const size_t bjobs = jobs.size() * sizeof(MergeJob);
   void* ws0 = nullptr;
-  RTC_TRY(rtc_ws(ctx, 0, bseg + bjobs + 64, &ws0));
+  const size_t bredo = any_partial_t0 ? (size_t)n * 4 : 0;
+  RTC_TRY(rtc_ws(ctx, 0, bseg + bjobs + bredo + 64, &ws0));
   Segment* d_segs = (Segment*)ws0;
   MergeJob* d_jobs = (MergeJob*)((char*)ws0 + bseg);
+  uint32_t* d_redo = (uint32_t*)((char*)ws0 + bseg + bjobs);  // per genome: walk its segments again without the threshold
   void* hp = nullptr;
   RTC_TRY(rtc_pinned(ctx, bseg + bjobs + 64, &hp));
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pinned staging may still be in flight
   memcpy(hp, segs.data(), bseg);
   memcpy((char*)hp + bseg, jobs.data(), bjobs);
   RTC_HIP(ctx, hipMemcpyAsync(ws0, hp, bseg + bjobs, hipMemcpyHostToDevice, ctx->stream));
+  if (bredo) RTC_HIP(ctx, hipMemsetAsync(d_redo, 0, bredo, ctx->stream));
 
   uint64_t* d_parts = nullptr;
   uint32_t* d_pcnt = nullptr;
@@ -1255,13 +1306,24 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     const PassPlan& pl = plans[ps];
     if (pl.ndirect + pl.npartial) {
       hipLaunchKernelGGL(kern, dim3((uint32_t)(pl.ndirect + pl.npartial)), dim3(WG), lds, ctx->stream, d_seq,
-                         d_segs + seg0[ps], k, seed, cap, d_out, d_cnt, (int)ps, d_parts, d_pcnt);
+                         d_segs + seg0[ps], k, seed, cap, d_out, d_cnt, (int)ps, d_parts, d_pcnt, (const uint32_t*)nullptr);
       RTC_CHECK_LAUNCH(ctx);
     }
     if (pl.npartial) {
       hipLaunchKernelGGL(merge_partials_kernel, dim3((uint32_t)pl.njobs), dim3(WG), lds_m, ctx->stream,
-                         d_jobs + pl.job0, d_parts, d_pcnt, cap_merge, d_out, d_cnt);
+                         d_jobs + pl.job0, d_parts, d_pcnt, cap_merge, d_out, d_cnt, d_redo, 0);
       RTC_CHECK_LAUNCH(ctx);
+      if (ps == 0 && any_partial_t0) {
+        // genomes the merge flagged (fewer than s hashes below the starting threshold): their segments once more
+        // from "everything passes", merged again; every other workgroup of the two launches leaves at once
+        hipLaunchKernelGGL(kern, dim3((uint32_t)pl.npartial), dim3(WG), lds, ctx->stream, d_seq,
+                           d_segs + seg0[ps] + pl.ndirect, k, seed, cap, d_out, d_cnt, (int)ps, d_parts, d_pcnt,
+                           (const uint32_t*)d_redo);
+        RTC_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(merge_partials_kernel, dim3((uint32_t)pl.njobs), dim3(WG), lds_m, ctx->stream,
+                           d_jobs + pl.job0, d_parts, d_pcnt, cap_merge, d_out, d_cnt, d_redo, 1);
+        RTC_CHECK_LAUNCH(ctx);
+      }
     }
   }
   return RTC_OK;

@@ -199,6 +199,42 @@ def test_starting_threshold_restart_on_low_complexity(ctx, oracle):
     assert len(got[0]) == 1000 and len(got[1]) < 100 and len(got[2]) == 1
 
 
+def test_partial_segments_start_from_the_genome_threshold(ctx, oracle):
+    """Few large genomes are cut into segments that all start from the genome's threshold; a genome with fewer than
+    s distinct k-mers below it is flagged by the merge and walked again without one (second launch over the partial
+    segments): a 3 Mbp periodic genome (period 3 000: fewer distinct k-mers than 3 s below T0), one of period 40 (fewer
+    than s in all), a poly-A genome and normal ones beside them; also with the factor that flags about every second
+    genome, with none, and with other segment counts -- identical sketches every way."""
+    import os
+    rng = np.random.default_rng(67)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    parts = [np.tile(rng.choice(acgt, size=3000), 1000),
+             rng.choice(acgt, size=2_500_000),
+             np.tile(rng.choice(acgt, size=40), 50_000),
+             oracle.synth_genome(77, 5, 200, 3_200_000),
+             np.full(1_700_000, ord("A"), dtype=np.uint8),
+             rng.choice(acgt, size=1_900_000)]
+    parts[3][1_000_000:1_000_050] = ord("N")
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(q) for q in parts])
+    seq = np.concatenate(parts)
+    want = oracle.sketch_minhash_batch(seq, off, 21, 1000)
+    d = ctx.upload_sequences(seq)
+    for env in ({}, {"RTC_SKETCH_T0_FACTOR": "1"}, {"RTC_SKETCH_T0_FACTOR": "0"}, {"RTC_SKETCH_ROUNDS": "1"},
+                {"RTC_SKETCH_ROUNDS": "4", "RTC_SKETCH_T0_FACTOR": "2"}):
+        os.environ.update(env)
+        try:
+            sk = ctx.sketch_minhash(d, off, k=21, size=1000)
+            ctx.sync()
+        finally:
+            for key in env:
+                del os.environ[key]
+        got = sk.to_host()
+        for g, (a, b) in enumerate(zip(got, want)):
+            assert np.array_equal(a, b), (env, g, len(a), len(b))
+    assert len(want[0]) == 1000 and len(want[2]) < 100 and len(want[4]) == 1
+
+
 def test_starting_threshold_factor_does_not_change_results(ctx, oracle):
     """RTC_SKETCH_T0_FACTOR = 1 makes about half of the workgroups restart, 0 disables the starting
     threshold, 40 / 2000 let so many k-mers through that the express walk's per-wave queue fills up (the
