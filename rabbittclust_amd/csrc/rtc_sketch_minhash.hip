@@ -603,7 +603,7 @@ __global__ __launch_bounds__(WG, 6) void sketch_minhash_kernel(const uint8_t* __
   }
 
   // Starting threshold.  A whole-genome workgroup knows how many k-mers are coming: the s-th smallest of N
-  // uniform hashes will be near 2^64 * s / N, so it starts at T0 = 3x that (t0_factor, host side) instead of "everything passes".
+  // uniform hashes will be near 2^64 * s / N, so it starts at T0 = 3x that (2x for dense sketches; start_threshold, host side) instead of "everything passes".
   // This skips the first tiles' flood of candidates (a dozen merges under per-dword barriers: the cost that
   // grew with s -- 6 % of the kernel at s = 1000, 20 % with 1 Mbp genomes) and changes nothing in the
   // result as long as s distinct hashes below T0 exist (3 s expected); if fewer than s were found -- a
@@ -1202,11 +1202,20 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     }
   }
 
-  // starting threshold = t0_factor x the expected s-th smallest hash (0: start from "everything passes").  3 keeps
+  // starting threshold = factor x the expected s-th smallest hash (0: start from "everything passes").  3 keeps
   // the restart away down to genomes whose distinct k-mers are a third of their length, and every early tile lets
   // 3 s / N of its k-mers through instead of 8 s / N: 50 000 x 1 Mbp 115 -> 107 ms, config 4's sketches 163 -> 150 ms
-  uint32_t t0_factor = 3;
-  if (const char* e = getenv("RTC_SKETCH_T0_FACTOR")) t0_factor = (uint32_t)std::max(0, atoi(e));  // tests of the restart path / tuning
+  // Dense sketches (a genome of fewer than 2 500 k-mers per sketch hash: the containment sketches of clust-greedy, s = length / 1000)
+  // start from 2x: there the candidates and their merges are 9 % of the kernel and a third fewer of them is worth more
+  // than the margin (50 000 x 1 Mbp at s = 2000: 98.4 -> 92.3 ms, at s = 1000 83.0 -> 81.1 ms; 5 000 k-mers per hash: no difference).
+  int t0_fixed = -1;
+  if (const char* e = getenv("RTC_SKETCH_T0_FACTOR")) t0_fixed = std::max(0, atoi(e));  // tests of the restart path / tuning
+  auto start_threshold = [&](uint64_t len, uint32_t s) -> uint64_t {
+    if (s == 0) return SENT;
+    const uint64_t f = t0_fixed >= 0 ? (uint64_t)t0_fixed : (len / s <= 2500 ? 2u : 3u);
+    if (f == 0 || len <= f * s) return SENT;
+    return (uint64_t)((((unsigned __int128)1 << 64) * (f * s)) / len);
+  };
   struct PassPlan { size_t direct0, ndirect, partial0, npartial, job0, njobs; };
   std::vector<PassPlan> plans(npass);
   std::vector<Segment> direct, partial;
@@ -1229,14 +1238,10 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
       const uint64_t lo_off = ps ? out_off - 1 : 0;
       const uint64_t ns = nsv[g];
       if (ns == 1) {
-        uint64_t t0 = SENT;
-        if (ps == 0 && t0_factor > 0 && s > 0 && len > (uint64_t)t0_factor * s)
-          t0 = (uint64_t)((((unsigned __int128)1 << 64) * ((uint64_t)t0_factor * s)) / len);
+        const uint64_t t0 = ps == 0 ? start_threshold(len, s) : SENT;
         direct.push_back(Segment{b, e, b, e, out_off, lo_off, g, s, g, expect, 0, 0, t0});
       } else {
-        uint64_t t0 = SENT;  // the genome's starting threshold, shared by its segments
-        if (ps == 0 && t0_factor > 0 && s > 0 && len > (uint64_t)t0_factor * s)
-          t0 = (uint64_t)((((unsigned __int128)1 << 64) * ((uint64_t)t0_factor * s)) / len);
+        const uint64_t t0 = ps == 0 ? start_threshold(len, s) : SENT;  // the genome's starting threshold, shared by its segments
         if (t0 != SENT) any_partial_t0 = true;
         jobs.push_back(MergeJob{part_elems, part_slots, (uint32_t)ns, out_off, g, s, chunk_max, expect, ps, t0 != SENT ? 1u : 0u});
         for (uint64_t i = 0; i < ns; i++) {
