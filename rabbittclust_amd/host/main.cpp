@@ -42,6 +42,33 @@ using namespace rtc;
 
 static double get_sec() { struct timeval tv; gettimeofday(&tv, NULL); return (double)tv.tv_sec + (double)tv.tv_usec / 1000000; }
 
+// RTC_METRICS_JSON=<file>: the phase times the reference prints under -DTimer (same labels) and the sizes of the run,
+// as one JSON object written when everything else has been written ("metrics / logging").
+struct Metrics {
+  vector<pair<string, string>> kv;  // in order of arrival; a key set twice keeps the last value
+  void put(const string& k, const string& raw) {
+    for (auto& e : kv) if (e.first == k) { e.second = raw; return; }
+    kv.emplace_back(k, raw);
+  }
+  void num(const string& k, double v) { char b[64]; snprintf(b, sizeof b, "%.9g", v); put(k, b); }
+  void str(const string& k, const string& v) {
+    string q = "\"";
+    for (char c : v) { if (c == '"' || c == '\\') q += '\\'; if ((unsigned char)c >= 0x20) q += c; }
+    put(k, q + "\"");
+  }
+  void write() const {
+    const char* path = getenv("RTC_METRICS_JSON");
+    if (!path || !*path) return;
+    FILE* f = fopen(path, "w");
+    if (!f) { fprintf(stderr, "Warning: cannot write %s\n", path); return; }
+    fputs("{", f);
+    for (size_t i = 0; i < kv.size(); i++) fprintf(f, "%s\n  \"%s\": %s", i ? "," : "", kv[i].first.c_str(), kv[i].second.c_str());
+    fputs("\n}\n", f);
+    fclose(f);
+  }
+};
+static Metrics g_metrics;
+
 #define CHECK(ctx, call)                                                                         \
   do {                                                                                           \
     int st__ = (call);                                                                           \
@@ -776,6 +803,7 @@ static Options parse(int argc, char** argv) {
   print_result(cl, genomes, sketchByFile, outputFile, threshold);
   cerr << "-----write the cluster result into: " << outputFile << endl;
   cerr << "-----the cluster number of: " << outputFile << " is: " << cl.size() << endl;
+  g_metrics.num("clusters", (double)cl.size());
 }
 
 struct Options;
@@ -1669,6 +1697,13 @@ int main(int argc, char** argv) {
     cerr << "-----the size of sketches (number of genomes or sequences) is: " << genomes.size() << endl;
     double t1 = get_sec();
     cerr << "========time of computing sketch is: " << t1 - t0 << "========" << endl;
+    {
+      uint64_t bases = 0;
+      for (const GenomeInfo& gi : genomes) bases += o.sketchByFile ? gi.totalSeqLength : (uint64_t)gi.seq0.length;
+      g_metrics.num("computing_sketch_s", t1 - t0);
+      g_metrics.num("bases", (double)bases);
+      g_metrics.num("sketch_gbp_per_s", (double)bases / (t1 - t0) / 1e9);
+    }
     folder_path = current_date_time();
     if (!o.noSave) {
       string command = "mkdir -p " + folder_path;
@@ -1676,6 +1711,7 @@ int main(int argc, char** argv) {
       if (o.is_fast) { save_kssd_sketches(genomes, ks, folder_path, sketchByFile); if (!greedy) save_kssd_index(ks, folder_path); }
       else { save_minhash_sketches(genomes, mh, folder_path, sketchByFile); save_minhash_index(mh, folder_path); }
       cerr << "========time of saveSketches is: " << get_sec() - t1 << "========" << endl;
+      g_metrics.num("saveSketches_s", get_sec() - t1);
     }
   }
   if (genomes.empty()) { cerr << "ERROR: no genome to cluster" << endl; return 1; }
@@ -1766,6 +1802,8 @@ int main(int argc, char** argv) {
   cerr << "-----write the cluster result into: " << o.outputFile << endl;
   cerr << "-----the cluster number of " << o.outputFile << " is: " << cluster.size() << endl;
   cerr << "========time of greedyCluster is: " << get_sec() - t2 << "========" << endl;
+  g_metrics.num("greedyCluster_s", get_sec() - t2);
+  g_metrics.num("clusters", (double)cluster.size());
 #else
   // ---- clust-mst: compute_clusters MST branch (src/sub_command.cpp:2924-3053, :1988-2152) ----
   const int is_containment = o.is_fast ? (int)o.isContainment : (int)mh.isContainment;
@@ -1811,10 +1849,13 @@ int main(int argc, char** argv) {
   mst.resize(nedges);
   double t3 = get_sec();
   cerr << "========time of generateMST is: " << t3 - t2 << "========" << endl;
+  g_metrics.num("generateMST_s", t3 - t2);
+  g_metrics.num("mst_edges", (double)nedges);
   if (!o.noSave && !from_sketches) {
     save_genome_info(genomes, folder_path, "mst", sketchByFile, o.is_fast);
     save_mst(mst, folder_path);
     cerr << "========time of saveMST is: " << get_sec() - t3 << "========" << endl;
+    g_metrics.num("saveMST_s", get_sec() - t3);
   }
   write_trees(o, genomes, mst, sketchByFile);
   cluster_from_mst(mst, genomes, sketchByFile, o.outputFile, o.threshold);
@@ -1824,6 +1865,20 @@ int main(int argc, char** argv) {
   }
 #endif
   const double t_end = get_sec();
+#ifdef GREEDY_CLUST
+  g_metrics.str("command", "clust-greedy");
+#else
+  g_metrics.str("command", "clust-mst");
+#endif
+  g_metrics.str("sketch", o.is_fast ? "kssd" : "minhash");
+  g_metrics.num("gpus", (double)gpus.size());
+  g_metrics.num("genomes", (double)genomes.size());
+  g_metrics.num("kmer_size", (double)kmer_size);
+  g_metrics.num("threshold", o.threshold);
+  g_metrics.num("threads", (double)o.threads);
+  g_metrics.num("from_sketches", from_sketches ? 1 : 0);
+  g_metrics.num("total_s", t_end - t_main);
+  g_metrics.write();
   for (Gpu& g : gpus) { if (g.comm) rtc_comm_destroy(g.comm); }
   for (Gpu& g : gpus) rtc_ctx_destroy(g.ctx);
   if (getenv("RTC_VERBOSE")) fprintf(stderr, "[exit]  output written at t+%.3fs, contexts released in %.3fs\n", t_end - t_main, get_sec() - t_end);

@@ -54,8 +54,8 @@ def _partition(cl):
     return sorted(tuple(sorted(c)) for c in cl)
 
 
-def _run(args, cwd):
-    r = subprocess.run(args, cwd=cwd, capture_output=True, text=True, timeout=600)
+def _run(args, cwd, env=None):
+    r = subprocess.run(args, cwd=cwd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0, r.stderr[-3000:]
     return r.stderr
 
@@ -81,10 +81,18 @@ def test_clust_mst_end_to_end_and_resume(oracle, tmp_path):
     L = 2_000_000  # large enough that tune_parameters keeps -k 21
     lst, paths, seqs = _write_family_fastas(oracle, tmp, 3, 3, L, seed=4, two_records=True)
     out = os.path.join(tmp, "mst.out")
-    _run([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "1000", "-d", "0.05", "-t", "4", "-o", out], tmp)
+    mjson = os.path.join(tmp, "metrics.json")
+    _run([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "1000", "-d", "0.05", "-t", "4", "-o", out], tmp,
+         env={"RTC_METRICS_JSON": mjson})
     folders = [d for d in os.listdir(tmp) if os.path.isdir(os.path.join(tmp, d)) and d[:2] == "20"]
     assert len(folders) == 1
     folder = os.path.join(tmp, folders[0])
+    # the metrics file: the reference's phase labels and the sizes of the run (RTC_METRICS_JSON)
+    import json
+    m = json.load(open(mjson))
+    assert m["command"] == "clust-mst" and m["sketch"] == "minhash" and m["genomes"] == 9 and m["kmer_size"] == 21
+    assert m["bases"] == 9 * L and m["gpus"] >= 1
+    assert all(m[key] > 0 for key in ("computing_sketch_s", "generateMST_s", "saveSketches_s", "saveMST_s", "total_s", "sketch_gbp_per_s"))
     # oracle on the same bytes (records of a file are separated, k-mers do not span them)
     parts, off = [], [0]
     for g, s in enumerate(seqs):
@@ -102,6 +110,7 @@ def test_clust_mst_end_to_end_and_resume(oracle, tmp_path):
     want_cl = oracle.forest_clusters(want_mst, 0.05, len(seqs))
     got_cl = _parse_clusters(out)
     assert _partition(got_cl) == _partition(want_cl)
+    assert m["clusters"] == len(got_cl) and m["mst_edges"] == len(got_mst)
     assert [c[0] for c in got_cl] == sorted(c[0] for c in got_cl)  # numbered by smallest member
     text = open(out).read()
     assert text.startswith("# Clustering threshold: 0.050000\n# Total clusters: %d\n#\n" % len(got_cl))
