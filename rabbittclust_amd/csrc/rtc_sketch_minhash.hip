@@ -1253,6 +1253,10 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
       }
     }
     pl.ndirect = direct.size() - pl.direct0; pl.npartial = partial.size() - pl.partial0; pl.njobs = jobs.size() - pl.job0;
+    // workgroups are dispatched in table order: longest genomes first, so that the last round ends with the short ones
+    // (results go to the genome's own row, the order is free)
+    std::stable_sort(direct.begin() + pl.direct0, direct.end(),
+                     [](const Segment& a, const Segment& b) { return a.g_end - a.g_begin > b.g_end - b.g_begin; });
     part_elems_max = std::max(part_elems_max, part_elems);
     part_slots_max = std::max(part_slots_max, part_slots);
   }
@@ -1321,7 +1325,11 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
       if (ps == 0 && any_partial_t0) {
         // genomes the merge flagged (fewer than s hashes below the starting threshold): their segments once more
         // from "everything passes", merged again; every other workgroup of the two launches leaves at once
-        hipLaunchKernelGGL(kern, dim3((uint32_t)pl.npartial), dim3(WG), lds, ctx->stream, d_seq,
+        // (the runtime-k instantiation: the flagged genomes are few, and the gated launch stays out of the compile-time-k
+        // kernel's per-launch statistics)
+        auto kern_redo = packed ? sketch_minhash_kernel<0, true> : sketch_minhash_kernel<0, false>;
+        RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern_redo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern_redo, dim3((uint32_t)pl.npartial), dim3(WG), lds, ctx->stream, d_seq,
                            d_segs + seg0[ps] + pl.ndirect, k, seed, cap, d_out, d_cnt, (int)ps, d_parts, d_pcnt,
                            (const uint32_t*)d_redo);
         RTC_CHECK_LAUNCH(ctx);

@@ -19,6 +19,10 @@ for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), 
         if name is None:
             continue
         tot[name][r["Counter_Name"]] += float(r["Counter_Value"])
+        # the gated second launch over the partial segments (runtime-k instantiation, every workgroup leaves at once unless the
+        # merge flagged its genome) belongs to the sketch call of the compile-time-k launch in front of it: no launch of its own
+        if name == "sketch_minhash_kernel" and "sketch_minhash_kernel<0," in r["Kernel_Name"]:
+            continue
         # the join is many kernels per pair phase: its "launch" is the phase (one per bench step, --steps 1 in the PMC runs)
         disp[name][r["Counter_Name"]].add("phase" if name == "pair_join_phase" else r["Dispatch_Id"])
 out = {
