@@ -352,3 +352,22 @@ def test_config5_200k_kssd_sketches_8_ranks_full_pair_space(ctx, oracle):
     want = oracle.mst(flat, start, lens, 22, 0, 0.05, threads=8)
     for mst, _ in res2:
         assert len(mst) == len(want) and np.array_equal(np.sort(mst["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
+
+
+def test_chromosome_sized_genomes_segments_and_passes(ctx, oracle):
+    """Maximum sizes: two genomes of 100 and 200 Mbp in one batch (768 partial segments that start from the genomes'
+    thresholds, merged on the device) at s = 1 000, and 40 + 80 Mbp at s = 20 000 (four passes over ascending hash
+    ranges, the later ones without a threshold); an N run inside.  Bit-identical to the oracle."""
+    for L, s in ((300_000_000, 1000), (120_000_000, 20000)):
+        g = oracle.synth_genome(99, 7, 100, L)
+        g[10_000_000:10_000_500] = ord("N")
+        off = np.array([0, L // 3, L], dtype=np.uint64)
+        d = ctx.upload_sequences(g)
+        sk = ctx.sketch_minhash(d, off, k=21, size=s)
+        ctx.sync()
+        got = sk.to_host()
+        want = oracle.sketch_minhash_batch(g, off, 21, s)
+        assert [len(x) for x in got] == [s, s]
+        assert all(np.array_equal(a, b) for a, b in zip(got, want)), (L, s)
+        del d, sk
+    torch.cuda.empty_cache()
