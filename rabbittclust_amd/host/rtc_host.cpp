@@ -15,6 +15,7 @@
 #include <immintrin.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
@@ -49,7 +50,7 @@ class GzStream {
       if (!f_) { close(fd_); fd_ = -1; return; }
       gzbuffer(f_, 1 << 20);
     }
-    buf_ = (char*)malloc(BUF);
+    buf_ = (char*)malloc(BUF + SLACK);
   }
   ~GzStream() {
     if (f_) gzclose(f_);  // closes fd_ too
@@ -84,6 +85,15 @@ class GzStream {
     return dret;
   }
   bool eof() const { return eof_ && begin_ >= end_; }
+  // Sequence-body fast path (sinks with take_line, the packed staging of the command lines): consumes the lines that
+  // lie whole inside the buffer, do not begin a record ('>', '@', '+') and do not end in '\r', handing each to the sink
+  // without its '\n'; empty lines are skipped.  Stops in front of the first line that needs the general code -- which
+  // then sees exactly the stream kseq's loop would see at this point (src/SketchInfo.cpp:880-948 drives that loop).
+  template <typename Sink>
+  void body_lines(Sink& s) {
+    if (begin_ < end_) begin_ += (int)s.take_lines(buf_ + begin_, (size_t)(end_ - begin_));
+  }
+  static constexpr int SLACK = 128;  // bytes a sink may read beyond the data it is handed (inside the allocation)
 
  private:
   static constexpr int BUF = 1 << 18;
@@ -175,6 +185,44 @@ struct PackedSink {
     }
   }
   void push_back(char c) { append(&c, 1); }
+  // GzStream::body_lines: p is at a line start with `avail` valid bytes (and GzStream::SLACK readable ones behind them).
+  // Takes the whole lines in front -- not a record start ('>', '@', '+'), at most 95 characters, no '\r' before the '\n' --
+  // and returns the bytes consumed; empty lines are skipped.  One pass per line: its three 32-byte blocks are loaded once,
+  // searched for the '\n' and stored behind the characters that wait for packing (the buffer has headroom for 96).
+  __attribute__((target("avx2"))) size_t take_lines_avx2(const char* p, size_t avail) {
+    const char* const p0 = p;
+    const char* const e = p + avail;
+    const __m256i nl = _mm256_set1_epi8('\n');
+    while (p < e) {
+      const char c = *p;
+      if (c == '\n') { p++; continue; }
+      if (c == '>' || c == '+' || c == '@') break;
+      if (fill + 96 > CH) flush(false);  // leaves fill < 32
+      const __m256i v0 = _mm256_loadu_si256((const __m256i*)p), v1 = _mm256_loadu_si256((const __m256i*)(p + 32)),
+                    v2 = _mm256_loadu_si256((const __m256i*)(p + 64));
+      const uint64_t m = (uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v0, nl)) |
+                         ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v1, nl)) << 32);
+      size_t n;
+      if (m) n = (size_t)__builtin_ctzll(m);
+      else {
+        const uint32_t m2 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v2, nl));
+        if (!m2) break;  // a longer line: the general code
+        n = 64 + (size_t)__builtin_ctz(m2);
+      }
+      if (n >= (size_t)(e - p) || p[n - 1] == '\r') break;  // the '\n' found lies behind the data, or a CR LF line
+      unsigned char* d = buf + fill;
+      _mm256_storeu_si256((__m256i*)d, v0);
+      _mm256_storeu_si256((__m256i*)(d + 32), v1);
+      _mm256_storeu_si256((__m256i*)(d + 64), v2);
+      fill += n; pos += n;
+      p += n + 1;
+    }
+    return (size_t)(p - p0);
+  }
+  size_t take_lines(const char* p, size_t avail) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    return avx2 ? take_lines_avx2(p, avail) : 0;
+  }
   void truncate(size_t p) {  // drop everything from base p on (pop_back of a '\r', a record cut short)
     pos = p;
     if (p >= done) { fill = p - done; return; }
@@ -260,7 +308,9 @@ int next_record_t(GzStream& ks, int& last_char, std::string& name, std::string& 
   int d = ks.get_until(0, name, false, &got);
   if (!got && ks.eof()) return -1;
   if (d != '\n' && d != -1) { ks.get_until(2, comment, false, &got); has_comment = true; }
-  while ((c = ks.getc()) != -1 && c != '>' && c != '+' && c != '@') {
+  for (;;) {
+    if constexpr (std::is_same<Sink, PackedSink>::value) ks.body_lines(seq);  // whole plain lines inside the buffer
+    if ((c = ks.getc()) == -1 || c == '>' || c == '+' || c == '@') break;
     if (c == '\n') continue;
     seq.push_back((char)c);
     ks.get_until(2, seq, true, &got);

@@ -319,7 +319,25 @@ def test_packed_staging_equals_the_flat_stream(host, tmp_path):
     lines = tmp_path / "lines.fa"   # 61-column lines: every line starts at a different offset within a packed byte
     with open(lines, "wb") as f:
         f.write(b">x\n" + b"\n".join(seq[i:i + 61] for i in range(0, 200_000, 61)) + b"\n")
-    files = sorted(glob.glob(os.path.join(GOLD, "fasta", "*"))) + [big, biggz, lines]
+    # the reader's whole-line fast path (GzStream::body_lines / PackedSink::take_lines): line lengths 1 .. 130 in turn
+    # over 1.5 MB (every offset of a '\n' against the 256 KiB read buffer and the 32-byte blocks; 96 and more characters
+    # take the general code), blank lines, a last line without '\n', CR LF in the middle of a file, and lines that
+    # begin a record in the middle of the sequence ('@', '>')
+    wide = tmp_path / "wide.fa"
+    with open(wide, "wb") as f:
+        f.write(b">w wide\n")
+        at, n = 0, 0
+        while at < 1_500_000:
+            ln = 1 + n % 130
+            f.write(seq[at % 600_000:at % 600_000 + ln] + (b"\n\n" if n % 97 == 0 else b"\n"))
+            at += ln; n += 1
+        f.write(seq[:50])
+    mixed = tmp_path / "mixed.fa"
+    with open(mixed, "wb") as f:
+        body = b"\n".join(seq[i:i + 80] for i in range(0, 400_000, 80))
+        f.write(b">m1\n" + body[:100_000] + b"\r\n" + seq[:70] + b"\r\n" + body[100_000:200_000] + b"\n@m2 second\n" + body[200_000:300_000]
+                + b"\n>m3\n" + body[300_000:] + b"\n")
+    files = sorted(glob.glob(os.path.join(GOLD, "fasta", "*"))) + [big, biggz, lines, wide, mixed]
     for path in files + [None] + files:   # second time: the portable 8-bases-per-word loop
         if path is None:
             host.rtch_pack_force_portable(1)
