@@ -85,13 +85,15 @@ class GzStream {
     return dret;
   }
   bool eof() const { return eof_ && begin_ >= end_; }
-  // Sequence-body fast path (sinks with take_line, the packed staging of the command lines): consumes the lines that
-  // lie whole inside the buffer, do not begin a record ('>', '@', '+') and do not end in '\r', handing each to the sink
-  // without its '\n'; empty lines are skipped.  Stops in front of the first line that needs the general code -- which
-  // then sees exactly the stream kseq's loop would see at this point (src/SketchInfo.cpp:880-948 drives that loop).
+  // Sequence-body fast path (the packed staging of the command lines, PackedSink::take_lines): hands the sink the buffer
+  // from a line start on; the sink consumes the blocks that are plain sequence text and says whether it stopped inside a
+  // line.  The general code continues from there -- finishing that line first -- and sees exactly the stream kseq's loop
+  // would see at this point (src/SketchInfo.cpp:880-948 drives that loop).
   template <typename Sink>
-  void body_lines(Sink& s) {
-    if (begin_ < end_) begin_ += (int)s.take_lines(buf_ + begin_, (size_t)(end_ - begin_));
+  bool body_lines(Sink& s) {
+    bool mid = false;
+    if (begin_ < end_) begin_ += (int)s.take_lines(buf_ + begin_, (size_t)(end_ - begin_), &mid);
+    return mid;
   }
   static constexpr int SLACK = 128;  // bytes a sink may read beyond the data it is handed (inside the allocation)
 
@@ -185,43 +187,51 @@ struct PackedSink {
     }
   }
   void push_back(char c) { append(&c, 1); }
-  // GzStream::body_lines: p is at a line start with `avail` valid bytes (and GzStream::SLACK readable ones behind them).
-  // Takes the whole lines in front -- not a record start ('>', '@', '+'), at most 95 characters, no '\r' before the '\n' --
-  // and returns the bytes consumed; empty lines are skipped.  One pass per line: its three 32-byte blocks are loaded once,
-  // searched for the '\n' and stored behind the characters that wait for packing (the buffer has headroom for 96).
-  __attribute__((target("avx2"))) size_t take_lines_avx2(const char* p, size_t avail) {
+  // GzStream::body_lines: p is at a line start of a sequence body with `avail` valid bytes (and GzStream::SLACK readable
+  // ones behind them).  Takes 32-byte blocks for as long as they hold nothing but sequence characters and '\n' -- no
+  // '>', '@', '+' (a record start when first on a line) and no '\r' -- dropping the '\n's on the way: a block without one is
+  // stored as it is, otherwise the pieces between the '\n's are stored one behind the other (each as a 32-byte store that the
+  // next one overwrites from its own start; the buffer has the headroom).  No load depends on where the previous line
+  // ended.  Returns the bytes consumed; *midline says whether they end inside a line, which the caller then finishes
+  // with the general code (as it does everything from the first block that is not plain).
+  __attribute__((target("avx2"))) size_t take_lines_avx2(const char* p, size_t avail, bool* midline) {
     const char* const p0 = p;
     const char* const e = p + avail;
-    const __m256i nl = _mm256_set1_epi8('\n');
-    while (p < e) {
-      const char c = *p;
-      if (c == '\n') { p++; continue; }
-      if (c == '>' || c == '+' || c == '@') break;
-      if (fill + 96 > CH) flush(false);  // leaves fill < 32
-      const __m256i v0 = _mm256_loadu_si256((const __m256i*)p), v1 = _mm256_loadu_si256((const __m256i*)(p + 32)),
-                    v2 = _mm256_loadu_si256((const __m256i*)(p + 64));
-      const uint64_t m = (uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v0, nl)) |
-                         ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v1, nl)) << 32);
-      size_t n;
-      if (m) n = (size_t)__builtin_ctzll(m);
-      else {
-        const uint32_t m2 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v2, nl));
-        if (!m2) break;  // a longer line: the general code
-        n = 64 + (size_t)__builtin_ctz(m2);
-      }
-      if (n >= (size_t)(e - p) || p[n - 1] == '\r') break;  // the '\n' found lies behind the data, or a CR LF line
+    const __m256i nl = _mm256_set1_epi8('\n'), c1 = _mm256_set1_epi8('>'), c2 = _mm256_set1_epi8('@'), c3 = _mm256_set1_epi8('+'),
+                  c4 = _mm256_set1_epi8('\r');
+    bool mid = false;
+    while (e - p >= 32) {
+      const __m256i v = _mm256_loadu_si256((const __m256i*)p);
+      const __m256i sp = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, c1), _mm256_cmpeq_epi8(v, c2)),
+                                         _mm256_or_si256(_mm256_cmpeq_epi8(v, c3), _mm256_cmpeq_epi8(v, c4)));
+      if (_mm256_movemask_epi8(sp)) break;
+      uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, nl));
+      if (fill + 64 > CH) flush(false);  // leaves fill < 32
       unsigned char* d = buf + fill;
-      _mm256_storeu_si256((__m256i*)d, v0);
-      _mm256_storeu_si256((__m256i*)(d + 32), v1);
-      _mm256_storeu_si256((__m256i*)(d + 64), v2);
-      fill += n; pos += n;
-      p += n + 1;
+      if (!m) {
+        _mm256_storeu_si256((__m256i*)d, v);
+        fill += 32; pos += 32; mid = true;
+      } else {
+        uint32_t off = 0;
+        do {
+          const uint32_t k = (uint32_t)__builtin_ctz(m);
+          _mm256_storeu_si256((__m256i*)d, _mm256_loadu_si256((const __m256i*)(p + off)));
+          d += k - off; off = k + 1; m &= m - 1;
+        } while (m);
+        _mm256_storeu_si256((__m256i*)d, _mm256_loadu_si256((const __m256i*)(p + off)));
+        d += 32 - off;
+        const size_t got = (size_t)(d - (buf + fill));
+        fill += got; pos += got; mid = off < 32;
+      }
+      p += 32;
     }
+    *midline = mid;
     return (size_t)(p - p0);
   }
-  size_t take_lines(const char* p, size_t avail) {
+  size_t take_lines(const char* p, size_t avail, bool* midline) {
     static const bool avx2 = __builtin_cpu_supports("avx2");
-    return avx2 ? take_lines_avx2(p, avail) : 0;
+    *midline = false;
+    return avx2 ? take_lines_avx2(p, avail, midline) : 0;
   }
   void truncate(size_t p) {  // drop everything from base p on (pop_back of a '\r', a record cut short)
     pos = p;
@@ -309,7 +319,9 @@ int next_record_t(GzStream& ks, int& last_char, std::string& name, std::string& 
   if (!got && ks.eof()) return -1;
   if (d != '\n' && d != -1) { ks.get_until(2, comment, false, &got); has_comment = true; }
   for (;;) {
-    if constexpr (std::is_same<Sink, PackedSink>::value) ks.body_lines(seq);  // whole plain lines inside the buffer
+    if constexpr (std::is_same<Sink, PackedSink>::value) {  // plain sequence text inside the buffer, 32 bytes at a time
+      if (ks.body_lines(seq)) { ks.get_until(2, seq, true, &got); continue; }  // it stopped inside a line: the rest of that line
+    }
     if ((c = ks.getc()) == -1 || c == '>' || c == '+' || c == '@') break;
     if (c == '\n') continue;
     seq.push_back((char)c);

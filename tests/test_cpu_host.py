@@ -337,7 +337,28 @@ def test_packed_staging_equals_the_flat_stream(host, tmp_path):
         body = b"\n".join(seq[i:i + 80] for i in range(0, 400_000, 80))
         f.write(b">m1\n" + body[:100_000] + b"\r\n" + seq[:70] + b"\r\n" + body[100_000:200_000] + b"\n@m2 second\n" + body[200_000:300_000]
                 + b"\n>m3\n" + body[300_000:] + b"\n")
-    files = sorted(glob.glob(os.path.join(GOLD, "fasta", "*"))) + [big, biggz, lines, wide, mixed]
+    # '>', '@', '+' INSIDE lines are sequence characters (kseq looks at the first character of a line only): at every offset
+    # against the 32-byte blocks, so that some open a block in the middle of a line; FASTQ with reads longer than a block and
+    # quality lines that begin with '@', '+' and '>'
+    inner = tmp_path / "inner.fa"
+    with open(inner, "wb") as f:
+        f.write(b">i inner\n")
+        for n in range(600):
+            a = 3 + (n * 7) % 90
+            f.write(seq[n * 100:n * 100 + a] + b">@+"[n % 3:n % 3 + 1] + seq[n * 100 + a:n * 100 + a + 20 + n % 40] + b"\n")
+        for n in range(900):  # plain lines in front, so that the blocks run on across the line start before the special character
+            for j in range(3):
+                f.write(seq[n * 90 + 30 * j:n * 90 + 30 * j + 17 + (n + 5 * j) % 23] + b"\n")
+            a = 1 + n % 31
+            f.write(seq[n * 90:n * 90 + a] + b">@+"[n % 3:n % 3 + 1] + seq[n * 90 + a:n * 90 + a + 25] + b"\n")
+    reads = tmp_path / "reads.fq"
+    with open(reads, "wb") as f:
+        for n in range(300):
+            ln = 40 + (n * 13) % 200
+            r = seq[n * 300:n * 300 + ln].replace(b"-", b"N").replace(b"*", b"N")
+            q = (b"@+>"[n % 3:n % 3 + 1] + b"I" * (ln - 1)) if n % 2 else b"F" * ln
+            f.write(b"@read%d x\n" % n + r + b"\n+\n" + q + b"\n")
+    files = sorted(glob.glob(os.path.join(GOLD, "fasta", "*"))) + [big, biggz, lines, wide, mixed, inner, reads]
     for path in files + [None] + files:   # second time: the portable 8-bases-per-word loop
         if path is None:
             host.rtch_pack_force_portable(1)
