@@ -228,11 +228,28 @@ struct PackedSink {
     *midline = mid;
     return (size_t)(p - p0);
   }
-  size_t take_lines(const char* p, size_t avail, bool* midline) {
-    static const bool avx2 = __builtin_cpu_supports("avx2");
-    *midline = false;
-    return avx2 ? take_lines_avx2(p, avail, midline) : 0;
+  // the same with 64-byte blocks: the four comparisons write mask registers, and ONE vpcompressb drops the '\n's
+  __attribute__((target("avx512f,avx512bw,avx512vbmi2"))) size_t take_lines_avx512(const char* p, size_t avail, bool* midline) {
+    const char* const p0 = p;
+    const char* const e = p + avail;
+    const __m512i nl = _mm512_set1_epi8('\n'), c1 = _mm512_set1_epi8('>'), c2 = _mm512_set1_epi8('@'), c3 = _mm512_set1_epi8('+'),
+                  c4 = _mm512_set1_epi8('\r');
+    bool mid = false;
+    while (e - p >= 64) {
+      const __m512i v = _mm512_loadu_si512((const void*)p);
+      if (_mm512_cmpeq_epi8_mask(v, c1) | _mm512_cmpeq_epi8_mask(v, c2) | _mm512_cmpeq_epi8_mask(v, c3) | _mm512_cmpeq_epi8_mask(v, c4)) break;
+      const __mmask64 m = _mm512_cmpeq_epi8_mask(v, nl);
+      if (fill + 64 > CH) flush(false);  // leaves fill < 32; the buffer has room for one whole block behind CH - 32
+      _mm512_storeu_si512((void*)(buf + fill), _mm512_maskz_compress_epi8(~m, v));
+      const size_t got = 64 - (size_t)__builtin_popcountll(m);
+      fill += got; pos += got;
+      mid = !(m >> 63);
+      p += 64;
+    }
+    *midline = mid;
+    return (size_t)(p - p0);
   }
+  size_t take_lines(const char* p, size_t avail, bool* midline);
   void truncate(size_t p) {  // drop everything from base p on (pop_back of a '\r', a record cut short)
     pos = p;
     if (p >= done) { fill = p - done; return; }
@@ -269,6 +286,22 @@ __attribute__((target("avx2"))) static size_t pack_run_avx2(const unsigned char*
   return i;
 }
 
+// the same 64 bases at a time: validity as one 64-bit mask, the 16 packed bytes out of the 16 dwords by one down-convert
+__attribute__((target("avx512f,avx512bw"))) static size_t pack_run_avx512(const unsigned char* p, size_t n, uint8_t* out) {
+  const __m512i m3 = _mm512_set1_epi8(3), mdf = _mm512_set1_epi8((char)0xDF);
+  const __m512i lut = _mm512_broadcast_i32x4(_mm_setr_epi8('A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0));
+  const __m512i w1 = _mm512_set1_epi16(0x0401), w2 = _mm512_set1_epi32(0x00100001);
+  size_t i = 0;
+  for (; i + 64 <= n; i += 64) {
+    const __m512i x = _mm512_loadu_si512((const void*)(p + i));
+    const __m512i c = _mm512_and_si512(_mm512_xor_si512(_mm512_srli_epi16(x, 1), _mm512_srli_epi16(x, 2)), m3);
+    if (_mm512_cmpeq_epi8_mask(_mm512_shuffle_epi8(lut, c), _mm512_and_si512(x, mdf)) != ~(__mmask64)0) break;
+    const __m512i q = _mm512_madd_epi16(_mm512_maddubs_epi16(c, w1), w2);
+    _mm_storeu_si128((__m128i*)(out + (i >> 2)), _mm512_cvtepi32_epi8(q));
+  }
+  return i;
+}
+
 // portable form of the same, 8 bases at a time in a 64-bit word
 static size_t pack_run_swar(const unsigned char* p, size_t n, uint8_t* out) {
   size_t i = 0;
@@ -287,14 +320,41 @@ static size_t pack_run_swar(const unsigned char* p, size_t n, uint8_t* out) {
   return i;
 }
 
-static int g_pack_portable = 0;  // tests: take the 64-bit SWAR loop also where AVX2 exists
+// SIMD tier of the packer and of the line intake: 0 = the best the CPU has (AVX-512 BW + VBMI2, else AVX2, else portable),
+// 1 = portable only, 2 = at most AVX2 (tests run every tier)
+static int g_pack_portable = 0;
+static int simd_tier() {  // 3: AVX-512, 2: AVX2, 1: portable
+  static const bool a512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi2");
+  static const bool a2 = __builtin_cpu_supports("avx2");
+  if (g_pack_portable == 1) return 1;
+  if (a512 && g_pack_portable != 2) return 3;
+  return a2 ? 2 : 1;
+}
+size_t PackedSink::take_lines(const char* p, size_t avail, bool* midline) {
+  *midline = false;
+  const int tier = simd_tier();
+  size_t k = 0;
+  if (tier == 3) k = take_lines_avx512(p, avail, midline);
+  if (tier >= 2 && avail - k >= 32) {
+    // (what the 64-byte blocks left: a block with a special character in it, or fewer than 64 bytes) -- the 32-byte blocks get
+    // as far as they can; they start where the wider ones stopped, inside a line or not
+    bool mid2 = false;
+    const size_t k2 = take_lines_avx2(p + k, avail - k, &mid2);
+    if (k2) *midline = mid2;
+    k += k2;
+  }
+  return k;
+}
+
 void PackedSink::emit(const unsigned char* p, size_t n) {
-  static const bool cpu_avx2 = __builtin_cpu_supports("avx2");
-  const bool have_avx2 = cpu_avx2 && !g_pack_portable;
+  const int tier = simd_tier();
   size_t i = 0;
   while (i < n) {
     if ((done & 3) == 0 && done + (n - i) <= cap && n - i >= 8) {  // byte-aligned, room for all: whole groups at once
-      const size_t k = have_avx2 ? pack_run_avx2(p + i, n - i, base + (done >> 2)) : pack_run_swar(p + i, n - i, base + (done >> 2));
+      size_t k = 0;
+      if (tier == 3) k = pack_run_avx512(p + i, n - i, base + (done >> 2));   // 64 at a time, then the rest of the run below
+      if (tier >= 2) k += pack_run_avx2(p + i + k, n - i - k, base + ((done + k) >> 2));
+      else k = pack_run_swar(p + i, n - i, base + (done >> 2));
       done += k; i += k;
       if (i >= n) break;
     }

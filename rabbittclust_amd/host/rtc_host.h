@@ -51,7 +51,7 @@ int read_genome_file_flat(const std::string& path, char* dst, uint64_t cap, uint
 int read_genome_file_packed(const std::string& path, uint8_t* dst, uint64_t cap_bases, uint64_t& used, std::vector<uint64_t>& runs,
                             SequenceInfo& first, uint64_t& total_len, uint64_t& n_records);
 size_t pack_bases(const char* seq, size_t n, uint8_t* dst, std::vector<uint64_t>& runs);  // one buffer, for tests
-void pack_force_portable(int on);  // tests: the portable 8-bases-per-word loop instead of the AVX2 one
+void pack_force_portable(int on);  // tests: 1 = the portable loops only, 2 = at most AVX2, 0 = the best tier the CPU has (AVX-512 BW + VBMI2, AVX2, portable)
 // Upper bound of the bytes read_genome_file_flat writes for `path` (exact bound for plain files, the
 // ISIZE-based guess for gzip); 0 if the file cannot be opened.
 uint64_t genome_slot_bytes(const std::string& path);

@@ -359,9 +359,10 @@ def test_packed_staging_equals_the_flat_stream(host, tmp_path):
             q = (b"@+>"[n % 3:n % 3 + 1] + b"I" * (ln - 1)) if n % 2 else b"F" * ln
             f.write(b"@read%d x\n" % n + r + b"\n+\n" + q + b"\n")
     files = sorted(glob.glob(os.path.join(GOLD, "fasta", "*"))) + [big, biggz, lines, wide, mixed, inner, reads]
-    for path in files + [None] + files:   # second time: the portable 8-bases-per-word loop
+    tiers = iter((2, 1))
+    for path in files + [None] + files + [None] + files:   # every SIMD tier: the CPU's best, at most AVX2, the portable loops
         if path is None:
-            host.rtch_pack_force_portable(1)
+            host.rtch_pack_force_portable(next(tiers))
             continue
         want, tot0, nrec0 = flat(path)
         st, used, pk, runs, tot, nrec = packed(path, 1 << 21)
