@@ -41,7 +41,7 @@ namespace {
 // which yields the same bytes zlib's transparent mode would.
 // gzip files of ordinary size are inflated in ONE call per member by libdeflate when the host has it (resolved with dlopen,
 // no build dependency; about twice zlib's rate on sequence text), from a copy of the whole file in memory; the bytes are
-// what gzread yields.  Anything it does not take -- no library, a file of more than 256 MiB, damaged or trailing data --
+// what gzread yields.  Anything it does not take -- no library, a file of more than 64 MiB, damaged or trailing data --
 // goes through zlib's streaming gzread as before (which also defines what a damaged file yields).  RTC_NO_LIBDEFLATE=1: zlib only.
 struct Deflate {
   void* (*alloc)() = nullptr;
@@ -133,7 +133,7 @@ class GzStream {
     const Deflate& lib = Deflate::get();
     if (!lib.alloc) return false;
     struct stat st;
-    if (fstat(fd_, &st) != 0 || st.st_size < 18 || st.st_size > ((off_t)256 << 20)) return false;
+    if (fstat(fd_, &st) != 0 || st.st_size < 18 || st.st_size > ((off_t)64 << 20)) return false;  // (each parser thread holds one file inflated)
     const size_t csize = (size_t)st.st_size;
     unsigned char* comp = (unsigned char*)malloc(csize);
     if (!comp) return false;
