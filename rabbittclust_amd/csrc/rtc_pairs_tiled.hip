@@ -30,37 +30,54 @@
 
 namespace {
 
-constexpr int TW = 1024;                // lanes per workgroup = columns per block (512: two per CU, measured 60 % slower)
+constexpr int TW = 1024;                // lanes per workgroup = columns per block
 constexpr int ROWS = 64;                // rows per block = mask width
-constexpr int SLOTS = 8 * TW;           // table slots
-constexpr int BUCKET = 4;               // keys per bucket
-constexpr int NB = SLOTS / BUCKET;      // buckets
-constexpr int LOG2NB = TW == 1024 ? 11 : 10;
-constexpr uint32_t KCAP_HARD = SLOTS / 16 * 11;  // max keys per table build (~69 % load)
-constexpr uint32_t KTARGET = SLOTS / 4;          // planned mean keys per table (25 % load)
+constexpr int LOG2NB = 12;
+constexpr int NB = 1 << LOG2NB;         // buckets of four 4-byte slots (64 KiB)
+constexpr int BUCKET = 4;
+constexpr uint32_t ECAP = 5120;         // entries {key, row mask} of 16 bytes (80 KiB): one per (row, element) of a table build
+constexpr uint32_t KCAP_HARD = ECAP;    // max keys per table build
+constexpr uint32_t KTARGET = 2048;      // planned mean keys per table: half a key per bucket
 constexpr int RPW = ROWS / (TW / 64);   // rows a wave builds at once
 constexpr int LPR = 64 / RPW;           // lanes per row in the build
 constexpr int MAXP = 512;
-constexpr int DEPTH = 2;                // trips (of four keys) of a column's slice requested ahead of the probes (3 and 4 measured slower)
+constexpr int DEPTH = 3;                // trips (four digests = one 16-byte load per lane) of a column's slice requested ahead of the probes
+
+// A slot names an entry: fingerprint [0,14) | entry index [14,27) | "this bucket overflowed" (slot 0 only) bit 27 |
+// generation [28,32).  A slot whose generation is not the current table's is free: a new table costs no clearing
+// (the 64 KiB are wiped once per 15 builds, when the 4-bit generation wraps).
+constexpr uint32_t FP_MASK = 0x3fffu, IDX_SHIFT = 14, IDX_MASK = 0x1fffu, FLAG_BIT = 1u << 27, GEN_SHIFT = 28;
+constexpr uint32_t MATCH_MASK = (0xfu << GEN_SHIFT) | FP_MASK;  // (slot ^ (gen | fp)) & MATCH_MASK == 0: live, same fingerprint
+constexpr uint32_t FLAG_TEST = (0xfu << GEN_SHIFT) | FLAG_BIT;  // (slot0 ^ (gen | FLAG_BIT)) & FLAG_TEST == 0: live and overflowed
 
 template <typename T> struct KeyTraits;
 template <> struct KeyTraits<uint64_t> {
-  static constexpr uint64_t EMPTY = ~0ULL;
-  __device__ static __forceinline__ uint32_t bucket(uint64_t k) {
-    return (((uint32_t)k ^ (uint32_t)(k >> 32)) * 0x9E3779B1u) >> (32 - LOG2NB);
-  }
+  __device__ static __forceinline__ uint32_t mix(uint64_t k) { return ((uint32_t)k ^ (uint32_t)(k >> 32)) * 0x9E3779B1u; }
 };
 template <> struct KeyTraits<uint32_t> {
-  static constexpr uint32_t EMPTY = ~0u;
-  __device__ static __forceinline__ uint32_t bucket(uint32_t k) { return (k * 0x9E3779B1u) >> (32 - LOG2NB); }
+  __device__ static __forceinline__ uint32_t mix(uint32_t k) { return k * 0x9E3779B1u; }
 };
+__device__ __forceinline__ uint32_t mix_bucket(uint32_t h) { return h >> (32 - LOG2NB); }
+__device__ __forceinline__ uint32_t mix_fp(uint32_t h) { return (h >> 4) & FP_MASK; }
 
-struct TileShared {
+// What a probe carries is the 32-bit digest mix(key) (the transposed column copy holds digests, 4 bytes per hash
+// whatever the key width: the probe loop is bound by the bytes it streams).  For 32-bit keys the digest is a
+// bijection of the key and stands for it everywhere; for 64-bit keys an entry keeps the key and a lane that finds
+// its digest's fingerprint fetches its own key from the sketch to compare.
+template <typename T> struct alignas(16) Entry { T key; unsigned long long mask; };
+template <typename T> __device__ __forceinline__ T entry_key(T key, uint32_t h) {
+  if constexpr (sizeof(T) == 4) return (T)h; else return key;
+}
+
+struct RowMeta {                 // one partition's view of the row block (double-buffered: written one partition ahead)
   uint32_t rlo[ROWS], rhi[ROWS];
-  uint64_t rstart[ROWS];
-  unsigned long long special;  // rows containing the EMPTY sentinel value itself
+  uint32_t ebase[ROWS];          // first entry of the row's slice inside its sub-block's table
   uint32_t nsub;
   uint32_t sub_end[ROWS + 1];
+};
+struct TileShared {
+  uint64_t rstart[ROWS];
+  RowMeta meta[2];
   // edge emission
   uint32_t rlen[ROWS];
   uint32_t wave_tot[TW / 64];
@@ -76,93 +93,114 @@ struct EdgeSink {                 // EMIT_EDGES only
   int radio;                      // < 0: no size-ratio test
 };
 
-__device__ __forceinline__ unsigned long long lds_cas(unsigned long long* p, unsigned long long cmp, unsigned long long v) {
-  return atomicCAS(p, cmp, v);
-}
-__device__ __forceinline__ uint32_t lds_cas(uint32_t* p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
-
-// Beside the keys, a bucket keeps four 15-bit fingerprints (low key bits) in 8 bytes and, in bit 31 of the
-// second word, an "overflowed" flag set by an insert that had to move past the full bucket: the probe's
-// straight line reads only those 8 bytes (one ds_read_b64) and goes to the keys when a fingerprint matches
-// or the bucket overflowed.
-template <typename T> __device__ __forceinline__ uint32_t fingerprint(T key) { return (uint32_t)key & 0x7fffu; }
-
+// Row r's element with entry index `idx` goes into the table.  The entry is written first, then a slot is claimed
+// with one compare-and-swap; a key another row has brought already only gets this row's bit.
 template <typename T>
-__device__ __forceinline__ void table_insert(T* keys, unsigned long long* masks, uint32_t* fps, TileShared* sh, T key, int r) {
+__device__ __forceinline__ void table_insert(uint32_t* slots, Entry<T>* ent, uint32_t gen28, T key, int r, uint32_t idx) {
   const unsigned long long bit = 1ULL << r;
-  if (key == KeyTraits<T>::EMPTY) { atomicOr(&sh->special, bit); return; }
-  uint32_t b = KeyTraits<T>::bucket(key);
+  const uint32_t h = KeyTraits<T>::mix(key);
+  uint32_t b = mix_bucket(h);
+  const uint32_t live = gen28 | mix_fp(h);
+  const uint32_t want = live | (idx << IDX_SHIFT);
+  const T ekey = entry_key<T>(key, h);
+  ent[idx].key = ekey;
+  ent[idx].mask = bit;
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the entry before the slot that names it (a wave's LDS operations execute in order)
   while (true) {
+    const uint4 sv = *reinterpret_cast<const uint4*>(&slots[b * BUCKET]);
+    const uint32_t s4[4] = {sv.x, sv.y, sv.z, sv.w};
 #pragma unroll
     for (int j = 0; j < BUCKET; j++) {
-      const uint32_t slot = b * BUCKET + j;
-      T old;
-      if constexpr (sizeof(T) == 8) old = (T)lds_cas((unsigned long long*)&keys[slot], (unsigned long long)KeyTraits<T>::EMPTY, (unsigned long long)key);
-      else old = (T)lds_cas((uint32_t*)&keys[slot], (uint32_t)KeyTraits<T>::EMPTY, (uint32_t)key);
-      if (old == KeyTraits<T>::EMPTY || old == key) {
-        atomicOr(&masks[slot], bit);
-        if (old == KeyTraits<T>::EMPTY) atomicOr(&fps[b * 2 + (j >> 1)], fingerprint(key) << (16 * (j & 1)));
-        return;
+      uint32_t s = s4[j];
+      if ((s >> GEN_SHIFT) != (gen28 >> GEN_SHIFT)) {  // free as far as this lane has seen
+        const uint32_t old = atomicCAS(&slots[b * BUCKET + j], s, want);
+        if (old == s) return;
+        s = old;                                       // taken in the meantime (by a live entry): look at it
+      }
+      if (((s ^ live) & MATCH_MASK) == 0) {
+        const uint32_t e2 = (s >> IDX_SHIFT) & IDX_MASK;
+        if (ent[e2].key == ekey) { atomicOr(&ent[e2].mask, bit); return; }
       }
     }
-    atomicOr(&fps[b * 2 + 1], 0x80000000u);  // overflowed
+    atomicOr(&slots[b * BUCKET], FLAG_BIT);  // full without this key: probes and inserts go on to the next bucket
     b = (b + 1) & (NB - 1);
   }
 }
 
-__device__ __forceinline__ unsigned long long table_lookup(const uint64_t* keys, const unsigned long long* masks,
-                                                           const TileShared* sh, uint64_t key) {
-  if (key == ~0ULL) return sh->special;
-  uint32_t b = KeyTraits<uint64_t>::bucket(key);
+// Row mask of the key with digest h (`key`: what an entry holds for it, entry_key()), 0 if no row of the table has it.
+// The general walk: every slot of the home bucket, then the buckets an overflow has led to.
+template <typename T>
+__device__ __forceinline__ unsigned long long table_lookup(const uint32_t* slots, const Entry<T>* ent, uint32_t gen28, T key,
+                                                           uint32_t h, uint4 sv) {
+  uint32_t b = mix_bucket(h);
+  const uint32_t live = gen28 | mix_fp(h);
   while (true) {
-    const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&keys[b * BUCKET]);
-    const ulonglong2 k23 = *reinterpret_cast<const ulonglong2*>(&keys[b * BUCKET + 2]);
-    int hit = -1;
-    if (k01.x == key) hit = 0;
-    if (k01.y == key) hit = 1;
-    if (k23.x == key) hit = 2;
-    if (k23.y == key) hit = 3;
-    if (hit >= 0) return masks[b * BUCKET + hit];
-    if (k01.x == ~0ULL || k01.y == ~0ULL || k23.x == ~0ULL || k23.y == ~0ULL) return 0ULL;
+    const uint32_t s4[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+    for (int j = 0; j < BUCKET; j++) {
+      if (((s4[j] ^ live) & MATCH_MASK) == 0) {
+        const Entry<T> e = ent[(s4[j] >> IDX_SHIFT) & IDX_MASK];
+        if (e.key == key) return e.mask;
+      }
+    }
+    if (((sv.x ^ (gen28 | FLAG_BIT)) & FLAG_TEST) != 0) return 0ULL;
     b = (b + 1) & (NB - 1);
+    sv = *reinterpret_cast<const uint4*>(&slots[b * BUCKET]);
   }
 }
 
-__device__ __forceinline__ unsigned long long table_lookup(const uint32_t* keys, const unsigned long long* masks,
-                                                           const TileShared* sh, uint32_t key) {
-  if (key == ~0u) return sh->special;
-  uint32_t b = KeyTraits<uint32_t>::bucket(key);
-  while (true) {
-    const uint4 k = *reinterpret_cast<const uint4*>(&keys[b * BUCKET]);
-    int hit = -1;
-    if (k.x == key) hit = 0;
-    if (k.y == key) hit = 1;
-    if (k.z == key) hit = 2;
-    if (k.w == key) hit = 3;
-    if (hit >= 0) return masks[b * BUCKET + hit];
-    if (k.x == ~0u || k.y == ~0u || k.z == ~0u || k.w == ~0u) return 0ULL;
-    b = (b + 1) & (NB - 1);
+// Row block meta data of one partition from the rows' slice bounds (lanes 0..63 of one wave hold one row each):
+// entry bases by a wave prefix sum; the block is split into sub-blocks only when its keys do not fit one table.
+__device__ __forceinline__ void write_meta(RowMeta* m, uint32_t lane, uint32_t nrows, uint32_t rlo, uint32_t rhi) {
+  const uint32_t sz = lane < nrows ? rhi - rlo : 0;
+  uint32_t incl = sz;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= (uint32_t)o) incl += v;
+  }
+  const uint32_t tot = (uint32_t)__shfl((int)incl, 63);
+  m->rlo[lane] = rlo;
+  m->rhi[lane] = rhi;
+  if (tot <= KCAP_HARD) {
+    m->ebase[lane] = incl - sz;
+    if (lane == 0) { m->sub_end[0] = nrows; m->nsub = 1; }
+  } else {
+    // rare: serial split by lane 0 (the sizes come back through the LDS)
+    m->ebase[lane] = sz;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      uint32_t ns = 0, acc = 0;
+      for (uint32_t r = 0; r < nrows; r++) {
+        const uint32_t szr = m->ebase[r];
+        if (acc + szr > KCAP_HARD && acc > 0) { m->sub_end[ns++] = r; acc = 0; }
+        m->ebase[r] = acc;
+        acc += szr;
+      }
+      m->sub_end[ns++] = nrows;
+      m->nsub = ns;
+    }
   }
 }
 
 // so: [(P+1)][n] slice offsets (so[p][g] = lower_bound(sketch g, bound[p])), so[0]=0, so[P]=len.
-// tcols covers the column range [tc0, tc0 + tnc): element e of column c's slice in partition p sits at
-// tcols[tbase[p] + e*tnc + (c - tc0)].
+// tcols covers the column range [tc0, tc0 + tnc): the digests of elements 4t .. 4t+3 of column c's slice in
+// partition p are the 16 bytes tcols[tbase[p] + t*tnc + (c - tc0)] (zeros past the slice's end).
 template <typename T, int NPL, int EMIT>
-__global__ __launch_bounds__(TW, TW == 1024 ? 1 : 2) void pair_tiled_kernel(const T* __restrict__ hashes,
+__global__ __launch_bounds__(TW, 1) void pair_tiled_kernel(const T* __restrict__ hashes,
                                                         const uint64_t* __restrict__ start,
-                                                        const T* __restrict__ tcols,          // transposed column slices
-                                                        const uint64_t* __restrict__ tbase,   // [P] element offsets
+                                                        const uint4* __restrict__ tcols,      // transposed column slices (digests)
+                                                        const uint64_t* __restrict__ tbase,   // [P] offsets in 16-byte groups
                                                         const uint32_t* __restrict__ so, int P, uint32_t n,
                                                         uint32_t tc0, uint32_t tnc,
                                                         uint32_t row0, uint32_t row1, uint32_t col0,
                                                         uint32_t col1, uint32_t* __restrict__ out, uint64_t ld,
                                                         int lower_only, EdgeSink sink) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* keys = reinterpret_cast<T*>(smem);
-  unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem + (size_t)SLOTS * sizeof(T));
-  uint32_t* fps = reinterpret_cast<uint32_t*>(smem + (size_t)SLOTS * (sizeof(T) + 8));  // [NB][2]
-  TileShared* sh = reinterpret_cast<TileShared*>(smem + (size_t)SLOTS * (sizeof(T) + 8 + 2));
+  uint32_t* slots = reinterpret_cast<uint32_t*>(smem);
+  Entry<T>* ent = reinterpret_cast<Entry<T>*>(smem + (size_t)NB * BUCKET * 4);
+  TileShared* sh = reinterpret_cast<TileShared*>(smem + (size_t)NB * BUCKET * 4 + (size_t)ECAP * sizeof(Entry<T>));
 
   const int tid = threadIdx.x;
   // Row blocks vary fastest in the grid: the workgroups running at the same time (round-robin over
@@ -183,123 +221,140 @@ __global__ __launch_bounds__(TW, TW == 1024 ? 1 : 2) void pair_tiled_kernel(cons
   uint32_t clo = col_active ? so[c] : 0;  // so[0][c]
   if (tid < ROWS) sh->rstart[tid] = tid < (int)nrows ? start[rb0 + tid] : 0;
   // Every global load a partition needs is requested one partition (or one phase) ahead: the column's next
-  // slice end, the rows' slice bounds (lanes 0..63), the first four probe keys (before the table is built).
+  // slice end, the rows' slice bounds (wave 0), the first probe keys (before the table is built).
   const bool rowlane = tid < (int)nrows;
   uint32_t chi_n = col_active ? so[(size_t)n + c] : 0;
-  uint32_t rlo_n = rowlane ? so[rb0 + tid] : 0, rhi_n = rowlane ? so[(size_t)n + rb0 + tid] : 0;
+  uint32_t rlo_n = 0, rhi_n = 0;
+  if (wave == 0) {
+    rlo_n = rowlane ? so[rb0 + tid] : 0;
+    rhi_n = rowlane ? so[(size_t)n + rb0 + tid] : 0;
+    write_meta(&sh->meta[0], lane, nrows, rlo_n, rhi_n);
+    rlo_n = rhi_n;
+    if (P > 1) rhi_n = rowlane ? so[(size_t)2 * n + rb0 + tid] : 0;
+  }
+  uint32_t gen = 15;  // the first build wipes the slots
 
   for (int p = 0; p < P; p++) {
     const uint32_t chi = chi_n;
-    const T* tp = tcols + tbase[p] + (c - tc0);
-    T nq[DEPTH][4];  // rows past the slice's end hold other data (the copy is padded by 4 * DEPTH rows): masked by `rem`
+    const uint4* tp = tcols + tbase[p] + (c - tc0);
+    uint4 nq[DEPTH];  // groups past the slice's end hold other data (the copy is padded by DEPTH groups): masked by `rem`
 #pragma unroll
-    for (int d = 0; d < DEPTH; d++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) nq[d][j] = col_active ? tp[(size_t)(4 * d + j) * tnc] : (T)0;
+    for (int d = 0; d < DEPTH; d++) nq[d] = col_active ? tp[(size_t)d * tnc] : make_uint4(0u, 0u, 0u, 0u);
     if (p + 1 < P) chi_n = col_active ? so[(size_t)(p + 2) * n + c] : 0;
-    __syncthreads();  // previous partition's probes are done (table and rlo/rhi reusable)
-    if (tid < ROWS) { sh->rlo[tid] = rlo_n; sh->rhi[tid] = rhi_n; }
-    if (p + 1 < P) { rlo_n = rhi_n; rhi_n = rowlane ? so[(size_t)(p + 2) * n + rb0 + tid] : 0; }
-    __syncthreads();
-    if (wave == 0) {  // split the row block only if its keys would overflow one table (rare)
-      uint32_t sz = (lane < nrows) ? sh->rhi[lane] - sh->rlo[lane] : 0;
-      uint32_t tot = sz;
-      for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-      if (tot <= KCAP_HARD) {
-        if (lane == 0) { sh->sub_end[0] = nrows; sh->nsub = 1; }
-      } else if (lane == 0) {
-        uint32_t ns = 0, acc = 0;
-        for (uint32_t r = 0; r < nrows; r++) {
-          const uint32_t szr = sh->rhi[r] - sh->rlo[r];
-          if (acc + szr > KCAP_HARD && acc > 0) { sh->sub_end[ns++] = r; acc = 0; }
-          acc += szr;
-        }
-        sh->sub_end[ns++] = nrows;
-        sh->nsub = ns;
-      }
-    }
-    __syncthreads();
-    const uint32_t nsub = sh->nsub;
+    __syncthreads();  // previous partition's probes are done (table reusable); this partition's meta data is visible
+    const RowMeta* mt = &sh->meta[p & 1];
+    const uint32_t nsub = mt->nsub;
     uint32_t ra = 0;
     for (uint32_t sb = 0; sb < nsub; sb++) {
-      const uint32_t rbnd = sh->sub_end[sb];
-      // ---- clear ----
-      {
-        uint4* kq = reinterpret_cast<uint4*>(keys);
-        for (int i = tid; i < (int)(SLOTS * sizeof(T) / 16); i += TW) kq[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-        uint4* mq = reinterpret_cast<uint4*>(masks);  // masks and fingerprints are adjacent
-        for (int i = tid; i < SLOTS * (8 + 2) / 16; i += TW) mq[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (tid == 0) sh->special = 0ULL;
+      const uint32_t rbnd = mt->sub_end[sb];
+      if (++gen == 16) {  // generation wrap (and the very first build): wipe the slots
+        uint4* sq = reinterpret_cast<uint4*>(slots);
+        for (int i = tid; i < NB * BUCKET / 4; i += TW) sq[i] = make_uint4(0u, 0u, 0u, 0u);
+        gen = 1;
+        __syncthreads();
       }
-      __syncthreads();
+      const uint32_t gen28 = gen << GEN_SHIFT;
       // ---- build: LPR lanes per row, all (<= 64) rows at once, four loads in flight per lane ----
       {
         const uint32_t r = ra + wave * RPW + lane / LPR;
         if (r < rbnd) {
           const T* rp = hashes + sh->rstart[r];
-          const uint32_t hi = sh->rhi[r];
-          for (uint32_t e = sh->rlo[r] + (lane % LPR); e < hi; e += 4 * LPR) {
+          const uint32_t lo = mt->rlo[r], hi = mt->rhi[r], eb = mt->ebase[r];
+          for (uint32_t e = lo + (lane % LPR); e < hi; e += 4 * LPR) {
             T kq[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) kq[j] = (e + LPR * j < hi) ? rp[e + LPR * j] : (T)0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) if (e + LPR * j < hi) table_insert<T>(keys, masks, fps, sh, kq[j], (int)r);
+            for (int j = 0; j < 4; j++)
+              if (e + LPR * j < hi) table_insert<T>(slots, ent, gen28, kq[j], (int)r, eb + (e + LPR * j - lo));
           }
         }
       }
       __syncthreads();
+      // next partition's row meta data, one partition ahead (wave 0, before its own probes)
+      if (sb == 0 && wave == 0 && p + 1 < P) {
+        write_meta(&sh->meta[(p + 1) & 1], lane, nrows, rlo_n, rhi_n);
+        rlo_n = rhi_n;
+        if (p + 2 < P) rhi_n = rowlane ? so[(size_t)(p + 3) * n + rb0 + tid] : 0;
+      }
       // ---- probe: this lane's column slice, read coalesced from the transposed copy ----
-      // Four keys per trip.  The next trip's global loads are issued before this trip's table work;
-      // the four home buckets are read back to back (no data-dependent loop in the common case),
-      // the row masks are fetched only by waves in which some lane hit, and the rare key whose home
-      // bucket is full without a match (or that equals the EMPTY marker) takes the looping lookup.
+      // Four digests (one 16-byte load) per trip, the next trips' loads in flight.  Straight line per key: the home
+      // bucket's four slots in one ds_read_b128, "live and my fingerprint" for each slot and "live and overflowed"
+      // for the bucket as values that are zero when true, their minimum; ONE wave vote per trip on the minimum of the
+      // four keys.  Only a trip in which some lane may have a hit goes on to the entries -- all four keys side by
+      // side: the entry of each key's matching slot (and, for 64-bit keys, the lane's own key from its sketch) in
+      // one round trip; what that leaves open (a second slot with the fingerprint, an overflowed bucket) takes the
+      // general walk.
       {
         const uint32_t mylen = chi - clo;
+        const T* kp = hashes + (col_active ? start[c] : 0) + clo;  // the lane's own slice (64-bit keys: to compare)
         if (sb > 0) {
 #pragma unroll
-          for (int d = 0; d < DEPTH; d++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) nq[d][j] = col_active ? tp[(size_t)(4 * d + j) * tnc] : (T)0;
+          for (int d = 0; d < DEPTH; d++) nq[d] = col_active ? tp[(size_t)d * tnc] : make_uint4(0u, 0u, 0u, 0u);
         }
+        const uint32_t flagq = gen28 | FLAG_BIT;
         for (uint32_t e = 0; e < mylen; e += 4) {
-          T bq[4];  // DEPTH trips of keys are in flight: the walk is short, the memory far
+          const uint4 bq = nq[0];
+#pragma unroll
+          for (int d = 0; d + 1 < DEPTH; d++) nq[d] = nq[d + 1];
+          nq[DEPTH - 1] = (e + 4 * DEPTH < mylen) ? tp[(size_t)(e / 4 + DEPTH) * tnc] : make_uint4(0u, 0u, 0u, 0u);
+          const uint32_t hq[4] = {bq.x, bq.y, bq.z, bq.w};
+          uint32_t mn[4], cs[4];
+          uint4 sv[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) sv[j] = *reinterpret_cast<const uint4*>(&slots[mix_bucket(hq[j]) * BUCKET]);
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            bq[j] = nq[0][j];
-#pragma unroll
-            for (int d = 0; d + 1 < DEPTH; d++) nq[d][j] = nq[d + 1][j];
+            const uint32_t live = gen28 | mix_fp(hq[j]);
+            const uint32_t d0 = (sv[j].x ^ live) & MATCH_MASK, d1 = (sv[j].y ^ live) & MATCH_MASK;
+            const uint32_t d2 = (sv[j].z ^ live) & MATCH_MASK, d3 = (sv[j].w ^ live) & MATCH_MASK;
+            const uint32_t fl = (sv[j].x ^ flagq) & FLAG_TEST;
+            cs[j] = min(min(d0, d1), min(d2, d3));
+            mn[j] = min(cs[j], fl);
           }
-#pragma unroll
-          for (int j = 0; j < 4; j++) nq[DEPTH - 1][j] = (e + 4 * DEPTH + j < mylen) ? tp[(size_t)(e + 4 * DEPTH + j) * tnc] : (T)0;
-          // Fingerprint words of the four home buckets, read back to back; per key four 16-bit compares and
-          // the overflow bit, all as wave masks.  A lane whose fingerprint matches (its key may be in the
-          // home bucket) or whose bucket overflowed (it may sit further on) takes the looping lookup on the
-          // keys below -- a few waves of the column block whose family lies in this row block, and the ~0.4 %
-          // of the buckets that overflow; the others never leave this straight line.
+          if (!__ballot(min(min(mn[0], mn[1]), min(mn[2], mn[3])) == 0u)) continue;
           const uint32_t rem = mylen - e;
-          uint64_t todo[4];
-          uint2 fw[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) fw[j] = *reinterpret_cast<const uint2*>(&fps[KeyTraits<T>::bucket(bq[j]) * 2]);
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const uint32_t q = fingerprint(bq[j]);
-            const uint64_t m = __ballot((fw[j].x & 0xffffu) == q) | __ballot((fw[j].x >> 16) == q) |
-                               __ballot((fw[j].y & 0xffffu) == q) | __ballot(((fw[j].y >> 16) & 0x7fffu) == q);
-            todo[j] = (m | __ballot((int32_t)fw[j].y < 0)) & __ballot(rem > (uint32_t)j);
-          }
-          if (p == P - 1) {  // the EMPTY marker as a key (only the largest value of the last partition): sh->special
-#pragma unroll
-            for (int j = 0; j < 4; j++) todo[j] |= __ballot(bq[j] == KeyTraits<T>::EMPTY && rem > (uint32_t)j);
-          }
-          if (!(todo[0] | todo[1] | todo[2] | todo[3])) continue;
+          unsigned long long hm[4];
+          T myk[4];
+          Entry<T> en[4];
+          bool open[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            if (!todo[j]) continue;  // wave-uniform
-            unsigned long long carry = 0ULL;
-            if (__builtin_amdgcn_inverse_ballot_w64(todo[j])) carry = table_lookup(keys, masks, sh, bq[j]);
+            const uint32_t live = gen28 | mix_fp(hq[j]);
+            const bool cand = cs[j] == 0u && rem > (uint32_t)j;
+            uint32_t sl = sv[j].x;  // the first slot with the fingerprint
+            if (((sv[j].x ^ live) & MATCH_MASK) != 0) sl = sv[j].y;
+            if (((sv[j].x ^ live) & MATCH_MASK) != 0 && ((sv[j].y ^ live) & MATCH_MASK) != 0) sl = sv[j].z;
+            if (((sv[j].x ^ live) & MATCH_MASK) != 0 && ((sv[j].y ^ live) & MATCH_MASK) != 0 && ((sv[j].z ^ live) & MATCH_MASK) != 0) sl = sv[j].w;
+            en[j] = ent[cand ? ((sl >> IDX_SHIFT) & IDX_MASK) : 0u];
+            if constexpr (sizeof(T) == 8) myk[j] = (mn[j] == 0u && rem > (uint32_t)j) ? kp[e + j] : (T)0;
+            else myk[j] = (T)hq[j];
+            open[j] = mn[j] == 0u && rem > (uint32_t)j;
+          }
+          bool any_open = false;
 #pragma unroll
-            for (int k = 0; k < NPL; k++) {
+          for (int j = 0; j < 4; j++) {
+            const bool hit = open[j] && cs[j] == 0u && en[j].key == myk[j];
+            hm[j] = hit ? en[j].mask : 0ULL;
+            open[j] = open[j] && !hit;
+            any_open = any_open || open[j];
+          }
+          if (__ballot(any_open)) {  // rare: fingerprint without the key, or an overflowed home bucket
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (open[j]) hm[j] = table_lookup<T>(slots, ent, gen28, myk[j], hq[j], sv[j]);
+          }
+          // the (up to) four row masks into the bit-sliced counters: a 4:2 compressor on planes 0 and 1, then a
+          // ripple from plane 2 that stops when no lane of the wave carries any more
+          {
+            const unsigned long long s1 = planes[0] ^ hm[0] ^ hm[1];
+            const unsigned long long c1 = (planes[0] & hm[0]) | (hm[1] & (planes[0] ^ hm[0]));
+            planes[0] = s1 ^ hm[2] ^ hm[3];
+            const unsigned long long c2 = (s1 & hm[2]) | (hm[3] & (s1 ^ hm[2]));
+            unsigned long long carry = (planes[1] & c1) | (c2 & (planes[1] ^ c1));
+            planes[1] = planes[1] ^ c1 ^ c2;
+#pragma unroll
+            for (int k = 2; k < NPL; k++) {
               if (!__ballot(carry != 0ULL)) break;  // wave-uniform
               const unsigned long long t = planes[k] & carry;
               planes[k] ^= carry;
@@ -426,19 +481,27 @@ __global__ __launch_bounds__(256) void slice_max_kernel(const uint32_t* __restri
   }
 }
 
-// tcols[tbase[p] + e*tnc + (c - tc0)] = element e of column c's slice in partition p
+// tcols[tbase[p] + t*tnc + (c - tc0)] = digests of elements 4t .. 4t+3 of column c's slice in partition p (zeros past its end)
 template <typename T>
 __global__ void transpose_slices_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
                                         const uint32_t* __restrict__ so, const uint64_t* __restrict__ tbase, int P,
-                                        uint32_t n, uint32_t tc0, uint32_t tnc, T* __restrict__ tcols) {
+                                        uint32_t n, uint32_t tc0, uint32_t tnc, uint4* __restrict__ tcols) {
   const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t p = blockIdx.y;
   if (ci >= tnc) return;
   const uint32_t c = tc0 + ci;
   const uint32_t lo = so[(size_t)p * n + c], hi = so[(size_t)(p + 1) * n + c];
   const T* src = hashes + start[c] + lo;
-  T* dst = tcols + tbase[p] + ci;
-  for (uint32_t e = 0; e < hi - lo; e++) dst[(size_t)e * tnc] = src[e];
+  uint4* dst = tcols + tbase[p] + ci;
+  const uint32_t len = hi - lo;
+  for (uint32_t e = 0; e < len; e += 4) {
+    uint4 v;
+    v.x = KeyTraits<T>::mix(src[e]);
+    v.y = e + 1 < len ? KeyTraits<T>::mix(src[e + 1]) : 0u;
+    v.z = e + 2 < len ? KeyTraits<T>::mix(src[e + 2]) : 0u;
+    v.w = e + 3 < len ? KeyTraits<T>::mix(src[e + 3]) : 0u;
+    dst[(size_t)(e / 4) * tnc] = v;
+  }
 }
 
 // planning inputs in one launch: sum / max of the sketch lengths and SAMPLE_PER evenly spaced hashes from each of
@@ -486,11 +549,11 @@ template <typename T, int NPL, int EMIT>
 int launch_tiled(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const PairPlan& pl, uint32_t row0,
                  uint32_t row1, uint32_t col0, uint32_t col1, uint32_t* d_common, uint64_t ld, int lower_only,
                  const EdgeSink& sink) {
-  const size_t lds = (size_t)SLOTS * (sizeof(T) + 8 + 2) + sizeof(TileShared);
+  const size_t lds = (size_t)NB * BUCKET * 4 + (size_t)ECAP * sizeof(Entry<T>) + sizeof(TileShared);
   auto kern = pair_tiled_kernel<T, NPL, EMIT>;
   RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((row1 - row0 + ROWS - 1) / ROWS, (col1 - col0 + TW - 1) / TW);
-  hipLaunchKernelGGL(kern, grid, dim3(TW), lds, ctx->stream, d_hashes, d_start, (const T*)pl.d_tcols, pl.d_tbase, pl.d_so,
+  hipLaunchKernelGGL(kern, grid, dim3(TW), lds, ctx->stream, d_hashes, d_start, (const uint4*)pl.d_tcols, pl.d_tbase, pl.d_so,
                      pl.P, pl.n, pl.tc0, pl.tnc, row0, row1, col0, col1, d_common, ld, lower_only, sink);
   RTC_CHECK_LAUNCH(ctx);
   return RTC_OK;
@@ -592,17 +655,17 @@ int build_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
     }
     // ---- partition-major transposed copy of the column slices ----
     std::vector<uint64_t> tbase(P + 1, 0);
-    for (int p = 0; p < P; p++) tbase[p + 1] = tbase[p] + (uint64_t)h_pmax[p] * tnc;
-    if (tbase[P] * sizeof(T) > budget) return RTC_OK;  // merge path (skewed lengths)
+    for (int p = 0; p < P; p++) tbase[p + 1] = tbase[p] + (uint64_t)((h_pmax[p] + 3) / 4) * tnc;  // 16-byte groups of four digests
+    if (tbase[P] * 16 > budget) return RTC_OK;  // merge path (skewed lengths)
     void* ws4 = nullptr;
     const size_t btb = (size_t)P * 8;
     {
-      const int st = rtc_ws(ctx, 4, (tbase[P] + 4ull * DEPTH * tnc) * sizeof(T) + btb + 256, &ws4);  // + 4 * DEPTH rows: unconditional first probe loads
+      const int st = rtc_ws(ctx, 4, (tbase[P] + (uint64_t)DEPTH * tnc) * 16 + btb + 256, &ws4);  // + DEPTH groups: unconditional first probe loads
       if (st == RTC_ERR_NOMEM) return RTC_OK;  // the merge kernel needs no scratch
       if (st != RTC_OK) return st;
     }
     uint64_t* d_tbase = (uint64_t*)ws4;
-    T* d_tcols = (T*)((char*)ws4 + ((btb + 255) / 256) * 256);
+    uint4* d_tcols = (uint4*)((char*)ws4 + ((btb + 255) / 256) * 256);
     memcpy(h_bounds_pin, tbase.data(), btb);  // the bounds upload completed before the read-back above
     RTC_HIP(ctx, hipMemcpyAsync(d_tbase, h_bounds_pin, btb, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(transpose_slices_kernel<T>, dim3((tnc + 255) / 256, (uint32_t)P), dim3(256), 0, ctx->stream, d_hashes,
@@ -676,3 +739,4 @@ int rtc_pair_edges_tiled(rtc_ctx* ctx, const void* d_hashes, int width, const ui
   return tiled_impl<uint32_t>(ctx, (const uint32_t*)d_hashes, d_start, d_len, n, row0, row1, col0, col1, nullptr, 0,
                               lower_only, &sink, handled);
 }
+
