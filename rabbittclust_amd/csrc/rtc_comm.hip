@@ -332,6 +332,7 @@ int rtc_comm_gather_rows(rtc_comm* c, void* d_global, size_t row_bytes, uint32_t
   if (!c || !d_global || a > b || b > n_local) return RTC_ERR_ARG;
   rtc_ctx* ctx = c->ctx;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->sketch_gen++;  // other ranks' rows arrive in the buffer
   if (!async) return comm_gather_rows_on(c, d_global, row_bytes, n_local, a, b, ctx->stream);
   // side stream: starts when the work enqueued so far on the context stream (the sketch kernel of
   // these rows) is done; rtc_comm_wait joins it back

@@ -30,8 +30,10 @@ struct rtc_ctx {
   // launches (the row-chunk loop of the dense candidate-edge path).
   int quiet = 0;           // rtc_warmup's context: no RTC_VERBOSE lines
   int pair_last_path = 0;  // rtc_pair_last_path
-  // the inverted join's last refusal for density: (genomes, hashes, largest hash, tile) of the input it counted
-  struct { uint32_t n = 0, row0 = 0, row1 = 0, col0 = 0, col1 = 0; uint64_t K = 0, maxkey = 0; } join_dense;
+  // the inverted join's last refusal for density: the input it counted
+  // keyed on the sketch buffer, its generation (every sketch / gather call on this context bumps sketch_gen) and the tile
+  struct { const void* hashes = nullptr; uint64_t gen = 0; uint32_t n = 0, row0 = 0, row1 = 0, col0 = 0, col1 = 0; uint64_t K = 0, maxkey = 0; } join_dense;
+  uint64_t sketch_gen = 1;
   int pair_plan_hold = 0, pair_plan_valid = 0;
   uint32_t pair_plan_tc1_hint = 0;
   struct {
@@ -41,6 +43,7 @@ struct rtc_ctx {
     const uint32_t* d_so;
     const uint64_t* d_tbase;
     const void* d_tcols;
+    const void* d_tcols_lo;
   } pair_plan = {};
   // KSSD filter tables of this context (cuckoo index or full table), keyed by (half_subk, drlevel, checksum)
   struct {

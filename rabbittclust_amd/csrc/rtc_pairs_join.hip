@@ -336,13 +336,13 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   const uint64_t maxkey = ((const uint64_t*)hpin)[1];
   const uint64_t K_rows = K64 - ((const uint64_t*)hpin)[2];  // hashes of the row genomes [row0, row1)
   if (K64 < 2) return RTC_OK;
-  // the same input (same counts, same largest hash, same tile) was found too dense for the join a moment ago
-  // (repeated steps over one sketch set): straight to the tiled kernel, no second look
+  // the same input (same buffer and sketch generation, same counts, same largest hash, same tile) was found too dense
+  // for the join a moment ago (repeated launches over one sketch set): straight to the tiled kernel, no second look
   auto& jd = ctx->join_dense;
-  const bool seen_dense = jd.K == K_all && jd.maxkey == maxkey && jd.n == n && jd.row0 == row0 && jd.row1 == row1 &&
-                          jd.col0 == col0 && jd.col1 == col1;
+  const bool seen_dense = jd.hashes == (const void*)d_hashes && jd.gen == ctx->sketch_gen && jd.K == K_all && jd.maxkey == maxkey &&
+                          jd.n == n && jd.row0 == row0 && jd.row1 == row1 && jd.col0 == col0 && jd.col1 == col1;
   if (seen_dense && mode == 1) return RTC_OK;
-  auto note_dense = [&]() { jd.n = n; jd.row0 = row0; jd.row1 = row1; jd.col0 = col0; jd.col1 = col1; jd.K = K_all; jd.maxkey = maxkey; };
+  auto note_dense = [&]() { jd.hashes = d_hashes; jd.gen = ctx->sketch_gen; jd.n = n; jd.row0 = row0; jd.row1 = row1; jd.col0 = col0; jd.col1 = col1; jd.K = K_all; jd.maxkey = maxkey; };
 
   // ---- semi-join: columns keep only the hashes some row has (0: never, 1: when the rows hold less than a quarter of
   // the hashes, 2: whenever there is a column that is not a row) ----

@@ -50,24 +50,25 @@ constexpr uint32_t FP_MASK = 0x3fffu, IDX_SHIFT = 14, IDX_MASK = 0x1fffu, FLAG_B
 constexpr uint32_t MATCH_MASK = (0xfu << GEN_SHIFT) | FP_MASK;  // (slot ^ (gen | fp)) & MATCH_MASK == 0: live, same fingerprint
 constexpr uint32_t FLAG_TEST = (0xfu << GEN_SHIFT) | FLAG_BIT;  // (slot0 ^ (gen | FLAG_BIT)) & FLAG_TEST == 0: live and overflowed
 
+// A key travels as its image under a bijection (multiplication by an odd constant): equal images, equal keys.  The
+// 32-bit digest that picks bucket and fingerprint is the image of a 32-bit key, the HIGH half of the image of a
+// 64-bit key; the low half of the latter is only looked at to confirm a hit.
 template <typename T> struct KeyTraits;
 template <> struct KeyTraits<uint64_t> {
-  __device__ static __forceinline__ uint32_t mix(uint64_t k) { return ((uint32_t)k ^ (uint32_t)(k >> 32)) * 0x9E3779B1u; }
+  __device__ static __forceinline__ uint64_t image(uint64_t k) { return k * 0x9E3779B97F4A7C15ULL; }
+  __device__ static __forceinline__ uint32_t digest(uint64_t m) { return (uint32_t)(m >> 32); }
 };
 template <> struct KeyTraits<uint32_t> {
-  __device__ static __forceinline__ uint32_t mix(uint32_t k) { return k * 0x9E3779B1u; }
+  __device__ static __forceinline__ uint32_t image(uint32_t k) { return k * 0x9E3779B1u; }
+  __device__ static __forceinline__ uint32_t digest(uint32_t m) { return m; }
 };
 __device__ __forceinline__ uint32_t mix_bucket(uint32_t h) { return h >> (32 - LOG2NB); }
 __device__ __forceinline__ uint32_t mix_fp(uint32_t h) { return (h >> 4) & FP_MASK; }
 
-// What a probe carries is the 32-bit digest mix(key) (the transposed column copy holds digests, 4 bytes per hash
-// whatever the key width: the probe loop is bound by the bytes it streams).  For 32-bit keys the digest is a
-// bijection of the key and stands for it everywhere; for 64-bit keys an entry keeps the key and a lane that finds
-// its digest's fingerprint fetches its own key from the sketch to compare.
+// What a probe carries is the 32-bit digest (the transposed column copy holds digests, 4 bytes per hash whatever the
+// key width: the probe loop is bound by the bytes it streams).  An entry holds the key's whole image; a lane whose
+// 64-bit key finds its fingerprint reads the low half of its image from a second transposed copy to compare.
 template <typename T> struct alignas(16) Entry { T key; unsigned long long mask; };
-template <typename T> __device__ __forceinline__ T entry_key(T key, uint32_t h) {
-  if constexpr (sizeof(T) == 4) return (T)h; else return key;
-}
 
 struct RowMeta {                 // one partition's view of the row block (double-buffered: written one partition ahead)
   uint32_t rlo[ROWS], rhi[ROWS];
@@ -98,11 +99,11 @@ struct EdgeSink {                 // EMIT_EDGES only
 template <typename T>
 __device__ __forceinline__ void table_insert(uint32_t* slots, Entry<T>* ent, uint32_t gen28, T key, int r, uint32_t idx) {
   const unsigned long long bit = 1ULL << r;
-  const uint32_t h = KeyTraits<T>::mix(key);
+  const T ekey = KeyTraits<T>::image(key);
+  const uint32_t h = KeyTraits<T>::digest(ekey);
   uint32_t b = mix_bucket(h);
   const uint32_t live = gen28 | mix_fp(h);
   const uint32_t want = live | (idx << IDX_SHIFT);
-  const T ekey = entry_key<T>(key, h);
   ent[idx].key = ekey;
   ent[idx].mask = bit;
   __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the entry before the slot that names it (a wave's LDS operations execute in order)
@@ -127,7 +128,7 @@ __device__ __forceinline__ void table_insert(uint32_t* slots, Entry<T>* ent, uin
   }
 }
 
-// Row mask of the key with digest h (`key`: what an entry holds for it, entry_key()), 0 if no row of the table has it.
+// Row mask of the key with image `key` and digest h, 0 if no row of the table has it.
 // The general walk: every slot of the home bucket, then the buckets an overflow has led to.
 template <typename T>
 __device__ __forceinline__ unsigned long long table_lookup(const uint32_t* slots, const Entry<T>* ent, uint32_t gen28, T key,
@@ -191,6 +192,7 @@ template <typename T, int NPL, int EMIT>
 __global__ __launch_bounds__(TW, 1) void pair_tiled_kernel(const T* __restrict__ hashes,
                                                         const uint64_t* __restrict__ start,
                                                         const uint4* __restrict__ tcols,      // transposed column slices (digests)
+                                                        const uint4* __restrict__ tcols_lo,   // 64-bit keys: low halves of the images, same layout
                                                         const uint64_t* __restrict__ tbase,   // [P] offsets in 16-byte groups
                                                         const uint32_t* __restrict__ so, int P, uint32_t n,
                                                         uint32_t tc0, uint32_t tnc,
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(TW, 1) void pair_tiled_kernel(const T* __restrict__
       // general walk.
       {
         const uint32_t mylen = chi - clo;
-        const T* kp = hashes + (col_active ? start[c] : 0) + clo;  // the lane's own slice (64-bit keys: to compare)
+        const uint4* tp_lo = tcols_lo + tbase[p] + (c - tc0);
         if (sb > 0) {
 #pragma unroll
           for (int d = 0; d < DEPTH; d++) nq[d] = col_active ? tp[(size_t)d * tnc] : make_uint4(0u, 0u, 0u, 0u);
@@ -318,6 +320,9 @@ __global__ __launch_bounds__(TW, 1) void pair_tiled_kernel(const T* __restrict__
           T myk[4];
           Entry<T> en[4];
           bool open[4];
+          uint4 lo4 = make_uint4(0u, 0u, 0u, 0u);
+          if constexpr (sizeof(T) == 8) lo4 = tp_lo[(size_t)(e / 4) * tnc];
+          const uint32_t lq[4] = {lo4.x, lo4.y, lo4.z, lo4.w};
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const uint32_t live = gen28 | mix_fp(hq[j]);
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(TW, 1) void pair_tiled_kernel(const T* __restrict__
             if (((sv[j].x ^ live) & MATCH_MASK) != 0 && ((sv[j].y ^ live) & MATCH_MASK) != 0) sl = sv[j].z;
             if (((sv[j].x ^ live) & MATCH_MASK) != 0 && ((sv[j].y ^ live) & MATCH_MASK) != 0 && ((sv[j].z ^ live) & MATCH_MASK) != 0) sl = sv[j].w;
             en[j] = ent[cand ? ((sl >> IDX_SHIFT) & IDX_MASK) : 0u];
-            if constexpr (sizeof(T) == 8) myk[j] = (mn[j] == 0u && rem > (uint32_t)j) ? kp[e + j] : (T)0;
+            if constexpr (sizeof(T) == 8) myk[j] = ((T)hq[j] << 32) | lq[j];
             else myk[j] = (T)hq[j];
             open[j] = mn[j] == 0u && rem > (uint32_t)j;
           }
@@ -461,46 +466,52 @@ __global__ __launch_bounds__(256) void slice_offsets_kernel(const T* __restrict_
 }
 
 // slice lengths: pmax[p] = maximum over the columns [c0, c1) (sizes the transposed copy), amax[0] = maximum over every
-// sketch and partition (a single slice must fit one table build); one lane per (p, g), coalesced over g
-__global__ __launch_bounds__(256) void slice_max_kernel(const uint32_t* __restrict__ so, uint32_t n, uint32_t c0, uint32_t c1,
-                                                        uint32_t* __restrict__ amax, uint32_t* __restrict__ pmax) {
-  const uint32_t p = blockIdx.y;
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+// sketch and partition (a single slice must fit one table build); one workgroup per partition, coalesced over g, two
+// atomics per workgroup (one per wave on a single address used to be most of this kernel's time)
+__global__ __launch_bounds__(1024) void slice_max_kernel(const uint32_t* __restrict__ so, uint32_t n, uint32_t c0, uint32_t c1,
+                                                         uint32_t* __restrict__ amax, uint32_t* __restrict__ pmax) {
+  __shared__ uint32_t sd[16], sdc[16];
+  const uint32_t p = blockIdx.x;
   uint32_t d = 0, dc = 0;
-  if (g < n) {
-    d = so[(size_t)(p + 1) * n + g] - so[(size_t)p * n + g];
-    dc = (g >= c0 && g < c1) ? d : 0;
+  for (uint32_t g = threadIdx.x; g < n; g += blockDim.x) {
+    const uint32_t v = so[(size_t)(p + 1) * n + g] - so[(size_t)p * n + g];
+    d = max(d, v);
+    if (g >= c0 && g < c1) dc = max(dc, v);
   }
   for (int o = 32; o > 0; o >>= 1) {
     d = max(d, (uint32_t)__shfl_xor((int)d, o));
     dc = max(dc, (uint32_t)__shfl_xor((int)dc, o));
   }
-  if ((threadIdx.x & 63) == 0) {
-    if (dc) atomicMax(&pmax[p], dc);
+  if ((threadIdx.x & 63) == 0) { sd[threadIdx.x >> 6] = d; sdc[threadIdx.x >> 6] = dc; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (uint32_t w = 1; w < blockDim.x / 64; w++) { d = max(d, sd[w]); dc = max(dc, sdc[w]); }
+    pmax[p] = dc;
     if (d) atomicMax(amax, d);
   }
 }
 
-// tcols[tbase[p] + t*tnc + (c - tc0)] = digests of elements 4t .. 4t+3 of column c's slice in partition p (zeros past its end)
+// tcols[tbase[p] + t*tnc + (c - tc0)] = digests of elements 4t .. 4t+3 of column c's slice in partition p (zeros past its
+// end); 64-bit keys: tcols_lo, same layout, the low halves of their images
 template <typename T>
 __global__ void transpose_slices_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
                                         const uint32_t* __restrict__ so, const uint64_t* __restrict__ tbase, int P,
-                                        uint32_t n, uint32_t tc0, uint32_t tnc, uint4* __restrict__ tcols) {
+                                        uint32_t n, uint32_t tc0, uint32_t tnc, uint4* __restrict__ tcols,
+                                        uint4* __restrict__ tcols_lo) {
   const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t p = blockIdx.y;
   if (ci >= tnc) return;
   const uint32_t c = tc0 + ci;
   const uint32_t lo = so[(size_t)p * n + c], hi = so[(size_t)(p + 1) * n + c];
   const T* src = hashes + start[c] + lo;
-  uint4* dst = tcols + tbase[p] + ci;
   const uint32_t len = hi - lo;
   for (uint32_t e = 0; e < len; e += 4) {
-    uint4 v;
-    v.x = KeyTraits<T>::mix(src[e]);
-    v.y = e + 1 < len ? KeyTraits<T>::mix(src[e + 1]) : 0u;
-    v.z = e + 2 < len ? KeyTraits<T>::mix(src[e + 2]) : 0u;
-    v.w = e + 3 < len ? KeyTraits<T>::mix(src[e + 3]) : 0u;
-    dst[(size_t)(e / 4) * tnc] = v;
+    T m[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) m[j] = e + j < len ? KeyTraits<T>::image(src[e + j]) : (T)0;
+    const size_t o = tbase[p] + (size_t)(e / 4) * tnc + ci;
+    tcols[o] = make_uint4(KeyTraits<T>::digest(m[0]), KeyTraits<T>::digest(m[1]), KeyTraits<T>::digest(m[2]), KeyTraits<T>::digest(m[3]));
+    if constexpr (sizeof(T) == 8) tcols_lo[o] = make_uint4((uint32_t)m[0], (uint32_t)m[1], (uint32_t)m[2], (uint32_t)m[3]);
   }
 }
 
@@ -543,6 +554,7 @@ struct PairPlan {
   const uint32_t* d_so = nullptr;
   const uint64_t* d_tbase = nullptr;
   const void* d_tcols = nullptr;
+  const void* d_tcols_lo = nullptr;  // 64-bit keys only
 };
 
 template <typename T, int NPL, int EMIT>
@@ -553,7 +565,7 @@ int launch_tiled(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const
   auto kern = pair_tiled_kernel<T, NPL, EMIT>;
   RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((row1 - row0 + ROWS - 1) / ROWS, (col1 - col0 + TW - 1) / TW);
-  hipLaunchKernelGGL(kern, grid, dim3(TW), lds, ctx->stream, d_hashes, d_start, (const uint4*)pl.d_tcols, pl.d_tbase, pl.d_so,
+  hipLaunchKernelGGL(kern, grid, dim3(TW), lds, ctx->stream, d_hashes, d_start, (const uint4*)pl.d_tcols, (const uint4*)pl.d_tcols_lo, pl.d_tbase, pl.d_so,
                      pl.P, pl.n, pl.tc0, pl.tnc, row0, row1, col0, col1, d_common, ld, lower_only, sink);
   RTC_CHECK_LAUNCH(ctx);
   return RTC_OK;
@@ -642,7 +654,7 @@ int build_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
     hipLaunchKernelGGL(slice_offsets_kernel<T>, dim3((n + 255) / 256, (uint32_t)P + 1), dim3(256), 0, ctx->stream, d_hashes, d_start, d_len,
                        d_bounds, P, n, d_so);
     RTC_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(slice_max_kernel, dim3((n + 255) / 256, (uint32_t)P), dim3(256), 0, ctx->stream, d_so, n, tc0, tc1, d_max, d_pmax);
+    hipLaunchKernelGGL(slice_max_kernel, dim3((uint32_t)P), dim3(1024), 0, ctx->stream, d_so, n, tc0, tc1, d_max, d_pmax);
     RTC_CHECK_LAUNCH(ctx);
     std::vector<uint32_t> h_maxes(P + 1);
     RTC_HIP(ctx, hipMemcpyAsync(h_maxes.data(), d_max, (size_t)(P + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -656,25 +668,27 @@ int build_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
     // ---- partition-major transposed copy of the column slices ----
     std::vector<uint64_t> tbase(P + 1, 0);
     for (int p = 0; p < P; p++) tbase[p + 1] = tbase[p] + (uint64_t)((h_pmax[p] + 3) / 4) * tnc;  // 16-byte groups of four digests
-    if (tbase[P] * 16 > budget) return RTC_OK;  // merge path (skewed lengths)
+    const uint64_t copies = sizeof(T) == 8 ? 2 : 1;  // 64-bit keys: digests + low halves
+    if (tbase[P] * 16 * copies > budget) return RTC_OK;  // merge path (skewed lengths)
     void* ws4 = nullptr;
     const size_t btb = (size_t)P * 8;
     {
-      const int st = rtc_ws(ctx, 4, (tbase[P] + (uint64_t)DEPTH * tnc) * 16 + btb + 256, &ws4);  // + DEPTH groups: unconditional first probe loads
+      const int st = rtc_ws(ctx, 4, (tbase[P] + (uint64_t)DEPTH * tnc) * 16 * copies + btb + 512, &ws4);  // + DEPTH groups: unconditional first probe loads
       if (st == RTC_ERR_NOMEM) return RTC_OK;  // the merge kernel needs no scratch
       if (st != RTC_OK) return st;
     }
     uint64_t* d_tbase = (uint64_t*)ws4;
     uint4* d_tcols = (uint4*)((char*)ws4 + ((btb + 255) / 256) * 256);
+    uint4* d_tcols_lo = d_tcols + (tbase[P] + (uint64_t)DEPTH * tnc);
     memcpy(h_bounds_pin, tbase.data(), btb);  // the bounds upload completed before the read-back above
     RTC_HIP(ctx, hipMemcpyAsync(d_tbase, h_bounds_pin, btb, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(transpose_slices_kernel<T>, dim3((tnc + 255) / 256, (uint32_t)P), dim3(256), 0, ctx->stream, d_hashes,
-                       d_start, d_so, d_tbase, P, n, tc0, tnc, d_tcols);
+                       d_start, d_so, d_tbase, P, n, tc0, tnc, d_tcols, d_tcols_lo);
     RTC_CHECK_LAUNCH(ctx);
     int npl = 1;
     while ((1u << npl) <= lmax) npl++;
     pl->P = P; pl->npl = npl; pl->n = n; pl->tc0 = tc0; pl->tnc = tnc;
-    pl->d_so = d_so; pl->d_tbase = d_tbase; pl->d_tcols = d_tcols;
+    pl->d_so = d_so; pl->d_tbase = d_tbase; pl->d_tcols = d_tcols; pl->d_tcols_lo = d_tcols_lo;
     *ok = 1;
     return RTC_OK;
   }
@@ -692,7 +706,7 @@ int tiled_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
   if (ctx->pair_plan_hold && ctx->pair_plan_valid && pc.hashes == (const void*)d_hashes && pc.start == (const void*)d_start &&
       pc.len == (const void*)d_len && pc.n == n && pc.width == (int)sizeof(T) && pc.tc0 <= col0 && col1 <= pc.tc1) {
     pl.P = pc.P; pl.npl = pc.npl; pl.n = n; pl.tc0 = pc.tc0; pl.tnc = pc.tc1 - pc.tc0;
-    pl.d_so = pc.d_so; pl.d_tbase = pc.d_tbase; pl.d_tcols = pc.d_tcols;
+    pl.d_so = pc.d_so; pl.d_tbase = pc.d_tbase; pl.d_tcols = pc.d_tcols; pl.d_tcols_lo = pc.d_tcols_lo;
     ok = 1;
   } else {
     const uint32_t tc1 = ctx->pair_plan_hold ? std::min(n, std::max(col1, ctx->pair_plan_tc1_hint)) : col1;
@@ -700,7 +714,7 @@ int tiled_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
     ctx->pair_plan_valid = 0;
     if (ok && ctx->pair_plan_hold) {
       pc.hashes = d_hashes; pc.start = d_start; pc.len = d_len; pc.n = n; pc.tc0 = col0; pc.tc1 = tc1;
-      pc.width = (int)sizeof(T); pc.P = pl.P; pc.npl = pl.npl; pc.d_so = pl.d_so; pc.d_tbase = pl.d_tbase; pc.d_tcols = pl.d_tcols;
+      pc.width = (int)sizeof(T); pc.P = pl.P; pc.npl = pl.npl; pc.d_so = pl.d_so; pc.d_tbase = pl.d_tbase; pc.d_tcols = pl.d_tcols; pc.d_tcols_lo = pl.d_tcols_lo;
       ctx->pair_plan_valid = 1;
     }
   }

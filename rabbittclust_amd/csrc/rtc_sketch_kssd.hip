@@ -821,6 +821,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   if (kmer_size < 2 || kmer_size > 32) return rtc_fail(ctx, RTC_ERR_ARG, "kmer_size=%d outside 2..32", kmer_size);
   if (drlevel < 0 || drlevel > 8) return rtc_fail(ctx, RTC_ERR_ARG, "drlevel=%d outside 0..8", drlevel);
   RTC_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->sketch_gen++;  // sketches on this context change: memos keyed on a sketch buffer are stale
   // src/SketchInfo.cpp:1019-1048
   const int half_k = (kmer_size + 1) / 2;
   const int K = half_k * 2;

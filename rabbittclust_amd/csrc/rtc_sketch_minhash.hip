@@ -1086,6 +1086,7 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   if (n == 0) return RTC_OK;
   if (((uintptr_t)d_seq & 15) != 0) return rtc_fail(ctx, RTC_ERR_ARG, "d_seq must be 16-byte aligned");
   RTC_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->sketch_gen++;  // sketches on this context change: memos keyed on a sketch buffer are stale
 
   uint32_t smax = 0;
   for (uint32_t g = 0; g < n; g++) {
