@@ -27,8 +27,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_JSON = ("r03_pmc_traffic.json", "r03_kssd_pmc_traffic.json", "r02_pmc_traffic.json", "r02_kssd_pmc_traffic.json",
+PROFILE_JSON = ("r04_pmc_traffic.json", "r04_kssd_pmc_traffic.json", "r04_dense_pmc_traffic.json", "r04_greedy_pmc_traffic.json",
+                "r03_pmc_traffic.json", "r03_kssd_pmc_traffic.json", "r02_pmc_traffic.json", "r02_kssd_pmc_traffic.json",
                 "r01_pmc_traffic.json")
+SURVEY_8D_PAIR_NOTE = ("SURVEY 8(d): algorithmic bytes of one genome pair = (|A| + |B|) * width (16 000 B at s = 1000, u64)")
 
 
 def parse():
@@ -52,6 +54,9 @@ def parse():
                     help="N=1 only: skip the extra workloads timed after the headline region (KSSD 25 000 x 2 Mbp, "
                          "greedy config 4, the 12 500-genome first point of the weak-scaling curve)")
     ap.add_argument("--extra-steps", type=int, default=3)
+    ap.add_argument("--only", choices=("dense_pairs", "cli", "greedy"), default=None,
+                    help="run ONE of the extra workloads alone and print {\"extra\": {...}} (the profile collection's driver)")
+    ap.add_argument("--cli-genomes", type=int, default=2048, help="extra.cli: FASTA files written to /dev/shm")
     ap.add_argument("--cpu-sample-genomes", type=int, default=0, help="0 = 1024 (SURVEY 8d: >= 1k genomes)")
     ap.add_argument("--cpu-sample-sketches", type=int, default=8000)
     return ap.parse_args()
@@ -67,6 +72,8 @@ def respawn_under_torchrun(args):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    # the hosts' driver only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's buffer exchange between the
+    # rank processes fails with "hipIpcGetMemHandle: invalid argument"
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -163,9 +170,10 @@ def cpu_baseline(args, mode, seq, off, sketches_host, shuffled):
     return {
         "value": pairs / t_mst, "unit": "genome-pairs/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
         "sketch_gbp_per_sec": ns * L / t_sk / 1e9,
-        "note": "value = pairs of the sample / time of the reference's INDEX-based MST on it: that algorithm only touches pairs "
-                "that share a hash, so its rate depends on the data and on the sample size and is not comparable pair for pair "
-                "with the GPU's dense N^2 rate; sketch_gbp_per_sec is the like-for-like figure of the phase that dominates the step",
+        "note": "value = pairs of the sample / time of the reference's INDEX-based MST on it (src/MST.cpp:1408-1435): only pairs "
+                "that share a hash are touched, so the rate depends on the data and on the sample size -- the GPU's pair phase on "
+                "this workload is the same algorithm (inverted join), compare dist_pairs_per_sec with it only at equal N; "
+                "sketch_gbp_per_sec is the like-for-like figure of the phase that is 97 % of the step",
         "sample": (f"sketch: {ns} x {L} bp genomes in {t_sk:.2f}s on {cores} threads (OpenMP over genomes, {impl}; "
                    f"ours -- RabbitSketch's AVX2 kernel is absent from the reference tree); "
                    f"distance: index-based compute_{'minhash' if mode == 'minhash' else 'kssd'}_mst restatement on "
@@ -178,124 +186,256 @@ def _mean_phases(phases):
     return {k: float(np.mean([p[k] for p in phases])) for k in phases[0]}
 
 
-def extra_workloads(args, ctx, api, pipeline):
-    """N=1 only, AFTER the timed headline region: the other single-GPU shapes of BASELINE.json on the same clock.
-      kssd    configs[4] per-GPU shape: 25 000 x 2 Mbp, --fast k=21 drlevel=3, sketch + all-pairs + MST
-      greedy  configs[3]: 50 000 prefix genomes of 0.4 .. 2 Mbp, -c 1000 containment sketches + rtc_greedy
-      weak_first_point  12 500 x 5 Mbp MinHash: the per-GPU load of the N>1 runs, so the 1 -> 8 curve has a first point
-                        with the same per-GPU work
-    Each gets `--extra-steps` timed steps after one warm-up."""
+def extra_kssd(args, ctx, api, pipeline, steps):
+    """configs[4] per-GPU shape: 25 000 x 2 Mbp, --fast k=21 drlevel=3, sketch + all-pairs + MST."""
     import numpy as np
+    import torch
+    from rabbittclust_amd import host
+    n, L = 25000, 2_000_000
+    shuffled = host.generate_shuffle_dim(6 if 6 - args.drlevel >= 2 else args.drlevel + 2)
+    desc = api.synth_family_descs(n // 10, 10, global_seed=42)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    seq = ctx.synth_genomes(desc, off)
+    ctx.sync()
+    pipe = pipeline.MstPipeline(ctx, k=args.k, threshold=args.threshold, mode="kssd", drlevel=args.drlevel, shuffled_dim=shuffled)
+    pipe.step(seq, off)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ph = _mean_phases([pipe.step(seq, off) for _ in range(steps)])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    sk = pipe.last_sketches
+    algo = float(n) * L + float(sk.len.sum().item()) * sk.width
+    ach = algo / (ph["sketch_ms"] * 1e-3) / 1e9
+    wl = {"genomes": n, "length": L, "k": args.k, "s": args.s, "mode": "kssd"}
+    traffic, src = measured_traffic("sketch_kssd_bloom_kernel", wl)
+    pairs = n * (n - 1) // 2
+    return {
+        "workload": f"{n} x {L} bp synthetic genomes, KSSD --fast k={args.k} drlevel={args.drlevel}, sketch + all-pairs + MST",
+        "steps": steps, "ms_per_step": dt * 1e3, "genome_pairs_per_sec": pairs / dt, "dtype": "u64" if sk.width == 8 else "u32",
+        "sketch_gbp_per_sec": float(n) * L / (ph["sketch_ms"] * 1e-3) / 1e9, "mean_sketch_size": float(sk.len.float().mean().item()),
+        "phase_ms": ph, "mst_edges": int(ph["mst_edges"]),
+        "roofline": {"bound": "hbm", "kernel": "sketch_kssd_bloom_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                     "note": "1 B/base + %d B/hash out over the whole sketch phase (prefilter kernel + sort/dedup + capacity read-back); "
+                             "traffic from profiles/%s" % (sk.width, src)},
+    }
+
+
+def extra_greedy(args, ctx, api, pipeline, steps):
+    """configs[3]: 50 000 prefix genomes of 0.4 .. 2 Mbp, -c 1000 containment sketches + rtc_greedy."""
+    import numpy as np
+    n, L, fam = 50000, 2_000_000, 10
+    rng = np.random.default_rng(1)
+    desc = api.synth_family_descs(n // fam, fam, global_seed=43, max_rate=0.04)
+    for f in range(n // fam):  # true prefixes of one genome
+        desc[f * fam:(f + 1) * fam] = desc[f * fam]
+    frac = rng.uniform(0.2, 1.0, size=n)
+    frac[::fam] = 1.0
+    lens = (frac * L).astype(np.uint64) // 16 * 16
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    seq = ctx.synth_genomes(desc, off)
+    sizes = np.maximum((lens.astype(np.float64) * 1.0125 / 1000).astype(np.uint32), 100)  # max(fileBytes / 1000, 100)
+    ctx.sync()
+    sk_ms, gr_s, ncl = [], [], 0
+    for it in range(steps + 1):
+        ctx.timer_start()
+        sk = ctx.sketch_minhash(seq, off, k=args.k, sizes=sizes)
+        ms = ctx.timer_stop()
+        t0 = time.perf_counter()
+        ncl, rep = ctx.greedy(sk, args.threshold, size_cfg=sizes, is_containment=True)
+        g = time.perf_counter() - t0
+        if it:
+            sk_ms.append(ms)
+            gr_s.append(g)
+    bases = float(off[-1])
+    algo = bases + float(sizes.sum()) * 8
+    ach = algo / (float(np.mean(sk_ms)) * 1e-3) / 1e9
+    traffic, src = measured_traffic("sketch_minhash_kernel", {"genomes": n, "mode": "greedy"})
+    return {
+        "workload": f"{n} prefix genomes of {int(lens.min())} .. {int(lens.max())} bp ({bases / 1e9:.1f} Gbp), clust-greedy -c 1000 "
+                    f"(containment sketches of {int(sizes.min())} .. {int(sizes.max())} hashes), d={args.threshold}",
+        "steps": steps, "sketch_ms": float(np.mean(sk_ms)), "sketch_gbp_per_sec": bases / (float(np.mean(sk_ms)) * 1e-3) / 1e9,
+        "greedy_s": float(np.mean(gr_s)), "genomes_per_sec": n / (float(np.mean(sk_ms)) * 1e-3 + float(np.mean(gr_s))),
+        "clusters": int(ncl), "dtype": "u64",
+        "roofline": {"bound": "hbm", "kernel": "sketch_minhash_kernel<21, true>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                     "note": "1 B/base + 8 B/hash out; traffic = rocprofv3 PMC bytes per launch (profiles/%s)" % src},
+    }
+
+
+def extra_weak_first_point(args, ctx, api, pipeline, steps):
+    """12 500 x 5 Mbp MinHash: the per-GPU load of the N>1 runs on one GPU (= `bench.py --gpus 1 --genomes 12500`), so that the
+    1 -> 8 curve has a first point with the same per-GPU work."""
+    import numpy as np
+    import torch
+    n, L = 12500, 5_000_000
+    free, _ = torch.cuda.mem_get_info()
+    if free < n * L * 1.2:
+        raise MemoryError(f"{free / 1e9:.0f} GB free")
+    desc = api.synth_family_descs(n // args.family, args.family, global_seed=42)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    seq = ctx.synth_genomes(desc, off)
+    ctx.sync()
+    pipe = pipeline.MstPipeline(ctx, k=args.k, sketch_size=args.s, threshold=args.threshold)
+    pipe.step(seq, off)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ph = _mean_phases([pipe.step(seq, off) for _ in range(steps)])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {
+        "workload": f"{n} x {L} bp, MinHash k={args.k} s={args.s}: the per-GPU load of the N>1 runs on one GPU "
+                    f"(also `python bench.py --gpus 1 --genomes {n}`)",
+        "steps": steps, "ms_per_step": dt * 1e3, "genome_pairs_per_sec": n * (n - 1) // 2 / dt,
+        "sketch_gbp_per_sec": float(n) * L / (ph["sketch_ms"] * 1e-3) / 1e9, "phase_ms": ph,
+    }
+
+
+DENSE_N, DENSE_FAM, DENSE_RATE, DENSE_L = 10000, 10, 0.01, 500_000
+
+
+def extra_dense_pairs(args, ctx, api, pipeline, steps):
+    """The dense regime of the distance half: 10 000 u64 sketches (s = 1000) in 10 families of 1 000 near-identical genomes
+    (substitution rate <= 1 %): posting lists as long as a family, 3.5e9 co-occurrences -- the input on which the reference's
+    posting-list walk (src/MST.cpp:1412-1435) goes quadratic and for which the tiled N x N kernel exists.  The cost rule of
+    rtc_pair_edges_dev picks the path itself (no environment override): `pair_path` must read 2.  One step = candidate edges
+    of the whole lower triangle (plan + pair_tiled_kernel) + Boruvka + host distances."""
+    import numpy as np
+    import torch
+    n, fam = DENSE_N, DENSE_FAM
+    desc = api.synth_family_descs(fam, n // fam, global_seed=42, max_rate=DENSE_RATE)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(DENSE_L)
+    seq = ctx.synth_genomes(desc, off)
+    sk = ctx.sketch_minhash(seq, off, k=args.k, size=args.s)
+    ctx.sync()
+    del seq
+    pipe = pipeline.MstPipeline(ctx, k=args.k, sketch_size=args.s, threshold=args.threshold)
+    pairs = n * (n - 1) // 2
+    rec = []
+    for it in range(steps + 1):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        edges, m = pipe.candidate_edges(sk, 0, n)
+        ev[1].record()
+        path = ctx.pair_last_path()
+        kms = ctx.pair_last_kernel_ms() if path == 2 else float("nan")
+        sel, rounds = pipe.boruvka(sk, edges, m)
+        mst = pipe.finish(sk, sel)
+        ev[2].record()
+        torch.cuda.synchronize()
+        rec.append({"pair_ms": ev[0].elapsed_time(ev[1]), "mst_ms": ev[1].elapsed_time(ev[2]), "kernel_ms": kms,
+                    "cand_edges": float(m), "pair_path": float(path), "boruvka_rounds": float(rounds), "mst_edges": float(len(mst))})
+    first, ph = rec[0], _mean_phases(rec[1:])
+    width = sk.width
+    avg_len = float(sk.len.float().mean().item())
+    bytes_pair = 2 * avg_len * width
+    wl = {"genomes": n, "mode": "dense_pairs"}
+    traffic, src = measured_traffic("pair_tiled_kernel", wl)
+    kern_s = ph["kernel_ms"] * 1e-3
+    algo = pairs * bytes_pair / kern_s / 1e9
+    return {
+        "workload": f"{n} u64 sketches of {int(avg_len)} hashes: {fam} families of {n // fam} genomes ({DENSE_L} bp, substitution rate "
+                    f"<= {DENSE_RATE}), all-pairs candidate edges + MST at d={args.threshold}; default dispatch",
+        "steps": steps, "pair_path": int(round(ph["pair_path"])), "pair_ms": ph["pair_ms"], "pair_kernel_ms": ph["kernel_ms"],
+        "mst_ms": ph["mst_ms"], "dist_pairs_per_sec": pairs / ((ph["pair_ms"] + ph["mst_ms"]) * 1e-3),
+        "pair_phase_pairs_per_sec": pairs / (ph["pair_ms"] * 1e-3), "cand_edges": int(ph["cand_edges"]),
+        "mst_edges": int(ph["mst_edges"]), "boruvka_rounds": ph["boruvka_rounds"], "dtype": "u64",
+        "first_call_pair_ms": first["pair_ms"],
+        "first_call_note": "the first launch on a sketch set also pays the inverted join's look at it (sort + co-occurrence count, "
+                           "refused as too dense) and the code objects' first mapping; later launches go straight to the tiled kernel",
+        "roofline_dist": {"bound": "hbm", "kernel": "pair_tiled_kernel", "bytes_per_pair": bytes_pair,
+                          "algorithmic_achieved": algo, "algorithmic_frac": algo / HBM_PEAK_GBS,
+                          "achieved": (traffic / kern_s / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": (traffic / kern_s / 1e9 / HBM_PEAK_GBS) if traffic else None, "traffic": traffic,
+                          "note": SURVEY_8D_PAIR_NOTE + " x pairs of the launch / the kernel's duration (HIP events on its launch stream, "
+                                  "rtc_pair_last_kernel_ms) = algorithmic_*: above 1 by construction, a probe of the LDS table serves the "
+                                  "64 rows of a block and a block's sketches are read once; achieved/frac = PMC-measured HBM bytes per "
+                                  "launch (profiles/%s) / the same duration" % src},
+    }
+
+
+def extra_cli(args, ctx, api, pipeline, steps):
+    """The drop-in command line from FASTA files, on the driver's clock: `--cli-genomes` x 5 Mbp genomes written as 80-column
+    FASTA to /dev/shm (outside the timed region), then bin/clust-mst -l ... -e with RTC_METRICS_JSON, MinHash and --fast.
+    The page cache is warm (tmpfs); PCIe, parsing, HIP start-up and process exit are all inside `wall_s`."""
+    import shutil
+    import tempfile
+    import numpy as np
+    n, L = int(args.cli_genomes), 5_000_000
+    binp = os.path.join(ROOT, "rabbittclust_amd", "bin", "clust-mst")
+    if not os.path.exists(binp):
+        raise FileNotFoundError(binp)
+    tmp = tempfile.mkdtemp(prefix="rtc_bench_cli_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        t0 = time.time()
+        desc = api.synth_family_descs(max(1, n // 8), 8, global_seed=77)[:n]
+        nl = np.full((L // 80, 1), 10, dtype=np.uint8)
+        paths = []
+        chunk = 256
+        for c0 in range(0, n, chunk):
+            c1 = min(n, c0 + chunk)
+            off = np.arange(c1 - c0 + 1, dtype=np.uint64) * np.uint64(L)
+            seq = ctx.synth_genomes(desc[c0:c1], off).cpu().numpy()
+            for g in range(c0, c1):
+                p = os.path.join(tmp, f"g{g:05d}.fna")
+                body = np.concatenate([seq[(g - c0) * L:(g - c0 + 1) * L].reshape(-1, 80), nl], axis=1).tobytes()
+                with open(p, "wb") as f:
+                    f.write(f">g{g} synthetic\n".encode() + body)
+                paths.append(p)
+            del seq
+        with open(os.path.join(tmp, "list.txt"), "w") as f:
+            f.write("\n".join(paths) + "\n")
+        t_write = time.time() - t0
+        out = {"workload": f"{n} x {L} bp genomes as 80-column FASTA files in tmpfs (written in {t_write:.1f}s, outside the timed "
+                           f"region), bin/clust-mst -l -i list -k {args.k} -d {args.threshold} -e, page cache warm",
+               "host_cores": usable_cores()}
+        for name, extra in (("minhash", ["-s", str(args.s)]), ("fast", ["--fast"])):
+            best = None
+            for rep in range(2):  # the second run has the code objects and the files' pages warm
+                mj = os.path.join(tmp, f"metrics_{name}.json")
+                env = dict(os.environ, RTC_METRICS_JSON=mj)
+                t0 = time.perf_counter()
+                r = subprocess.run([binp, "-l", "-i", os.path.join(tmp, "list.txt"), "-k", str(args.k), "-d", str(args.threshold), "-e",
+                                    "-o", os.path.join(tmp, f"out_{name}.cluster")] + extra, capture_output=True, text=True, cwd=tmp, env=env)
+                wall = time.perf_counter() - t0
+                if r.returncode != 0:
+                    raise RuntimeError(f"clust-mst {' '.join(extra)} rc={r.returncode}: {r.stderr[-400:]}")
+                m = json.load(open(mj))
+                cur = {"wall_s": wall, "end_to_end_gbp_per_sec": n * L / wall / 1e9,
+                       "computing_sketch_s": m.get("computing_sketch_s"), "sketch_phase_gbp_per_sec": m.get("sketch_gbp_per_s"),
+                       "generateMST_s": m.get("generateMST_s"), "total_s": m.get("total_s"), "threads": m.get("threads"),
+                       "genomes": m.get("genomes"), "clusters": m.get("clusters"), "mst_edges": m.get("mst_edges"),
+                       "parse_s": m.get("parse_s"), "parse_gbp_per_sec": m.get("parse_gbp_per_s"),
+                       "parse_gbp_per_sec_per_thread": m.get("parse_gbp_per_s_per_thread"), "hip_init_s": m.get("hip_init_s")}
+                if best is None or cur["wall_s"] < best["wall_s"]:
+                    best = cur
+            out[name] = best
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+EXTRAS = (("kssd", extra_kssd), ("greedy", extra_greedy), ("weak_first_point", extra_weak_first_point),
+          ("dense_pairs", extra_dense_pairs), ("cli", extra_cli))
+
+
+def extra_workloads(args, ctx, api, pipeline, only=None):
+    """N=1 only, AFTER the timed headline region: the other single-GPU shapes of BASELINE.json and the two regimes the headline
+    workload does not reach, on the same clock.  Each gets `--extra-steps` timed steps after one warm-up.  A failing extra
+    never costs the headline line: its entry becomes {"error": ...} (tests/test_gpu_bench.py asserts there is none)."""
     import torch
     out = {}
     steps = max(1, args.extra_steps)
-
-    # ---- KSSD (--fast) ----
-    try:
-        from rabbittclust_amd import host
-        n, L = 25000, 2_000_000
-        shuffled = host.generate_shuffle_dim(6 if 6 - args.drlevel >= 2 else args.drlevel + 2)
-        desc = api.synth_family_descs(n // 10, 10, global_seed=42)
-        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
-        seq = ctx.synth_genomes(desc, off)
-        ctx.sync()
-        pipe = pipeline.MstPipeline(ctx, k=args.k, threshold=args.threshold, mode="kssd", drlevel=args.drlevel, shuffled_dim=shuffled)
-        pipe.step(seq, off)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ph = _mean_phases([pipe.step(seq, off) for _ in range(steps)])
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        sk = pipe.last_sketches
-        algo = float(n) * L + float(sk.len.sum().item()) * sk.width
-        ach = algo / (ph["sketch_ms"] * 1e-3) / 1e9
-        wl = {"genomes": n, "length": L, "k": args.k, "s": args.s, "mode": "kssd"}
-        traffic, src = measured_traffic("sketch_kssd_bloom_kernel", wl)
-        pairs = n * (n - 1) // 2
-        out["kssd"] = {
-            "workload": f"{n} x {L} bp synthetic genomes, KSSD --fast k={args.k} drlevel={args.drlevel}, sketch + all-pairs + MST",
-            "steps": steps, "ms_per_step": dt * 1e3, "genome_pairs_per_sec": pairs / dt, "dtype": "u64" if sk.width == 8 else "u32",
-            "sketch_gbp_per_sec": float(n) * L / (ph["sketch_ms"] * 1e-3) / 1e9, "mean_sketch_size": float(sk.len.float().mean().item()),
-            "phase_ms": ph, "mst_edges": int(ph["mst_edges"]),
-            "roofline": {"bound": "hbm", "kernel": "sketch_kssd_bloom_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "1 B/base + %d B/hash out over the whole sketch phase (prefilter kernel + sort/dedup + capacity read-back); "
-                                 "traffic from profiles/%s" % (sk.width, src)},
-        }
-        del seq, pipe, sk
+    for name, fn in EXTRAS:
+        if only and name != only:
+            continue
+        try:
+            out[name] = fn(args, ctx, api, pipeline, steps)
+        except Exception as e:
+            out[name] = {"error": repr(e)}
         torch.cuda.empty_cache()
-    except Exception as e:  # an extra never costs the headline line
-        out["kssd"] = {"error": repr(e)}
-
-    # ---- greedy, containment (config 4) ----
-    try:
-        n, L, fam = 50000, 2_000_000, 10
-        rng = np.random.default_rng(1)
-        desc = api.synth_family_descs(n // fam, fam, global_seed=43, max_rate=0.04)
-        for f in range(n // fam):  # true prefixes of one genome
-            desc[f * fam:(f + 1) * fam] = desc[f * fam]
-        frac = rng.uniform(0.2, 1.0, size=n)
-        frac[::fam] = 1.0
-        lens = (frac * L).astype(np.uint64) // 16 * 16
-        off = np.zeros(n + 1, dtype=np.uint64)
-        off[1:] = np.cumsum(lens)
-        seq = ctx.synth_genomes(desc, off)
-        sizes = np.maximum((lens.astype(np.float64) * 1.0125 / 1000).astype(np.uint32), 100)  # max(fileBytes / 1000, 100)
-        ctx.sync()
-        sk_ms, gr_s, ncl = [], [], 0
-        for it in range(steps + 1):
-            ctx.timer_start()
-            sk = ctx.sketch_minhash(seq, off, k=args.k, sizes=sizes)
-            ms = ctx.timer_stop()
-            t0 = time.perf_counter()
-            ncl, rep = ctx.greedy(sk, args.threshold, size_cfg=sizes, is_containment=True)
-            g = time.perf_counter() - t0
-            if it:
-                sk_ms.append(ms)
-                gr_s.append(g)
-        bases = float(off[-1])
-        algo = bases + float(sizes.sum()) * 8
-        ach = algo / (float(np.mean(sk_ms)) * 1e-3) / 1e9
-        out["greedy"] = {
-            "workload": f"{n} prefix genomes of {int(lens.min())} .. {int(lens.max())} bp ({bases / 1e9:.1f} Gbp), clust-greedy -c 1000 "
-                        f"(containment sketches of {int(sizes.min())} .. {int(sizes.max())} hashes), d={args.threshold}",
-            "steps": steps, "sketch_ms": float(np.mean(sk_ms)), "sketch_gbp_per_sec": bases / (float(np.mean(sk_ms)) * 1e-3) / 1e9,
-            "greedy_s": float(np.mean(gr_s)), "genomes_per_sec": n / (float(np.mean(sk_ms)) * 1e-3 + float(np.mean(gr_s))),
-            "clusters": int(ncl), "dtype": "u64",
-            "roofline": {"bound": "hbm", "kernel": "sketch_minhash_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None},
-        }
-        del seq, sk
-        torch.cuda.empty_cache()
-    except Exception as e:
-        out["greedy"] = {"error": repr(e)}
-
-    # ---- the N>1 per-GPU load on one GPU ----
-    try:
-        n, L = 12500, 5_000_000
-        free, _ = torch.cuda.mem_get_info()
-        if free < n * L * 1.2:
-            raise MemoryError(f"{free / 1e9:.0f} GB free")
-        desc = api.synth_family_descs(n // args.family, args.family, global_seed=42)
-        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
-        seq = ctx.synth_genomes(desc, off)
-        ctx.sync()
-        pipe = pipeline.MstPipeline(ctx, k=args.k, sketch_size=args.s, threshold=args.threshold)
-        pipe.step(seq, off)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ph = _mean_phases([pipe.step(seq, off) for _ in range(steps)])
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        out["weak_first_point"] = {
-            "workload": f"{n} x {L} bp, MinHash k={args.k} s={args.s}: the per-GPU load of the N>1 runs on one GPU",
-            "steps": steps, "ms_per_step": dt * 1e3, "genome_pairs_per_sec": n * (n - 1) // 2 / dt,
-            "sketch_gbp_per_sec": float(n) * L / (ph["sketch_ms"] * 1e-3) / 1e9, "phase_ms": ph,
-        }
-        del seq, pipe
-        torch.cuda.empty_cache()
-    except Exception as e:
-        out["weak_first_point"] = {"error": repr(e)}
     return out
 
 
@@ -323,6 +463,9 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s); reporting n_gpus={world}",
               file=sys.stderr)
     ctx = api.Context(local)
+    if args.only:
+        print(json.dumps({"extra": extra_workloads(args, ctx, api, pipeline, only=args.only)}))
+        return
 
     mode = args.mode
     if mode == "minhash":
@@ -390,6 +533,10 @@ def main():
     bases_total = float(n_local) * length * world
     ms_step = dt / args.steps * 1e3
     ph = {k: float(np.mean([p[k] for p in phases])) for k in phases[0]}
+    ranks_ph = None
+    if dist is not None:  # every rank's phase means, so that the N>1 line shows the spread and not only rank 0
+        ranks_ph = [None] * world
+        dist.all_gather_object(ranks_ph, ph)
 
     if rank == 0:
         sk_ms = ph["sketch_ms"]
@@ -400,7 +547,8 @@ def main():
         achieved = algo_bytes / (sk_ms * 1e-3) / 1e9
         avg_len = float(sk_all.len.float().mean().item())
         dist_pairs_local = ph["pairs_local"]
-        dist_algo = dist_pairs_local * 2 * avg_len * width / (ph["pair_ms"] * 1e-3) / 1e9
+        survey_bytes_pair = 2 * avg_len * width  # (|A| + |B|) * w per genome pair
+        dist_algo = survey_8d = dist_pairs_local * survey_bytes_pair / (ph["pair_ms"] * 1e-3) / 1e9
         wl = {"genomes": n_local, "length": length, "k": args.k, "s": args.s, "mode": mode}
         sk_kernel = "sketch_minhash_kernel" if mode == "minhash" else "sketch_kssd_bloom_kernel"
         sk_traffic, sk_src = measured_traffic(sk_kernel, wl)
@@ -414,7 +562,10 @@ def main():
             dist_note = ("pair phase = inverted join (rtc_pairs_join.hip): achieved/frac = PMC-measured HBM bytes of all kernels "
                          "of the phase (profiles/%s: 'pair_join_phase' = the rocPRIM sort / scan / encode kernels + join_*) / "
                          "pair-phase time; algorithmic_* = (hash, genome) records read once = %d B per hash / time -- the "
-                         "radix passes move each record eight times" % (pr_src, width + 4))
+                         "radix passes move each record several times; survey_8d_* = %s x the pairs of the tile / pair-phase time: "
+                         "far above the peak because the join never touches a pair that shares no hash -- a data-dependent figure, "
+                         "not a kernel rate (extra.dense_pairs times the tiled N x N kernel, whose cost the data cannot change)"
+                         % (pr_src, width + 4, SURVEY_8D_PAIR_NOTE))
         else:
             dist_note = ("achieved/frac = PMC-measured HBM bytes per launch (profiles/%s) / pair-phase time: "
                          "the physical figure; algorithmic_* = (|A|+|B|)*%d B per pair / time, which "
@@ -441,7 +592,11 @@ def main():
                                       if pair_path == 3 else
                                       "tiled N x N kernel (rtc_pairs_tiled.hip): every pair probed"),
                        "scaling_note": "weak in genomes: per-GPU genomes (and sketch work) fixed as N grows; the pair "
-                                       "space is (N x genomes_per_gpu)^2/2, so pairs per GPU grow with N"},
+                                       "space is (N x genomes_per_gpu)^2/2, so pairs per GPU grow with N",
+                       "value_note": "value = N(N-1)/2 pairs / step time, and the step is ~97 % O(N) sketching: the figure grows "
+                                     "with the genome count by construction (6.2e8 at 10 000 genomes, 7.8e8 at 12 500); "
+                                     "sketch_gbp_per_sec is the size-independent headline, dist_pairs_per_sec and "
+                                     "extra.dense_pairs the distance half"},
             "sketch_gbp_per_sec": bases_total / (sk_ms * 1e-3) / 1e9,
             "dist_pairs_per_sec": pairs / (ph["dist_ms"] * 1e-3),
             "per_gpu": {"sketch_gbp_per_sec": float(n_local) * length / (sk_ms * 1e-3) / 1e9,
@@ -460,11 +615,29 @@ def main():
             "roofline_dist": {"bound": "hbm", "kernel": pr_kernel, "achieved": pr_ach, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": (pr_ach / HBM_PEAK_GBS) if pr_ach else None,
                               "traffic": pr_traffic, "algorithmic_achieved": dist_algo,
-                              "algorithmic_frac": dist_algo / HBM_PEAK_GBS, "note": dist_note},
+                              "algorithmic_frac": dist_algo / HBM_PEAK_GBS,
+                              "survey_8d_bytes_per_pair": survey_bytes_pair, "survey_8d_achieved": survey_8d,
+                              "survey_8d_frac": survey_8d / HBM_PEAK_GBS, "note": dist_note},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if ranks_ph:
+            keys = ("sketch_ms", "gather_ms", "pair_ms", "mst_ms", "dist_ms", "cand_edges", "pairs_local")
+            s_fixed = pipe.fixed_size(sk_all)
+            rounds = ph["boruvka_rounds"]
+            line["per_rank"] = {
+                "phase_ms_min": {k: min(r[k] for r in ranks_ph) for k in keys},
+                "phase_ms_max": {k: max(r[k] for r in ranks_ph) for k in keys},
+                "gather_ms_exposed_max": max(r["gather_ms"] for r in ranks_ph),
+                "boruvka_rounds": rounds,
+                "all_reduce_bytes_per_step": rounds * n_total * (8 if s_fixed else 20),
+                "note": "gather_ms = what is left of the sketch all-gather after the local sketching (the first 80 % travel beside "
+                        "the second sketch launch); every Boruvka round all-reduces (MIN) one u64[n] key array when all sketches "
+                        "have one size, else u64 + u64 + u32 arrays; cand_edges / pairs_local are per-rank counts (row ranges of "
+                        "equal cost, not equal pairs)"}
+        if not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(args, mode, seq, off, pipe.last_sketches.to_host(), shuffled)
+                line["cpu_baseline"] = cpu_baseline(args, mode, seq, off, pipe.last_sketches.to_host()[:n_local], shuffled)
+                if world > 1:
+                    line["cpu_baseline"]["sample"] += " -- rank 0's genomes and host cores only, timed after the multi-GPU region"
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_extra and mode == "minhash" and not args.genomes and not args.length:

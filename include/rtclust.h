@@ -165,6 +165,9 @@ int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width, const uint
 /* Which path the last rtc_pair_edges_dev of this context took: 0 none yet, 1 per-pair merge kernel,
  * 2 tiled kernel, 3 inverted join (measurement: bench.py names the kernels of the pair phase by it). */
 int rtc_pair_last_path(const rtc_ctx* ctx);
+/* Duration of this context's last tiled pair kernel launch (rtc_pair_last_path == 2), from HIP events recorded on the
+ * stream it was launched on; waits for the launch to finish (measurement: bench.py's roofline_dist). */
+int rtc_pair_last_kernel_ms(rtc_ctx* ctx, float* ms_out);
 
 /* ---- minimum spanning forest over candidate edges (Boruvka, order-exact integer weights) -- */
 /* One Boruvka round primitive for row-sharded multi-GPU use: for every current component c

@@ -73,6 +73,7 @@ SIGNATURES = {
     "rtc_pair_mash_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u64]),
     "rtc_extract_edges_dev": (_i, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _vp, _i, _vp, _u64, _vp]),
     "rtc_pair_last_path": (_i, [_vp]),
+    "rtc_pair_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_float)]),
     "rtc_pair_edges_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _i, _vp, _u64, _vp]),
     "rtc_boruvka_key_bits": (_i, [_u32, _u32]),
     "rtc_boruvka_minkey_dev": (_i, [_vp, _vp, _u64, _vp, _u32, _u32, _vp]),

@@ -110,6 +110,12 @@ class Context:
         """Path of the last pair_edges call: 0 none, 1 merge kernel, 2 tiled kernel, 3 inverted join."""
         return int(self.lib.rtc_pair_last_path(self.h))
 
+    def pair_last_kernel_ms(self):
+        """Duration of the last tiled pair kernel launch (HIP events on its launch stream)."""
+        ms = C.c_float()
+        self.check(self.lib.rtc_pair_last_kernel_ms(self.h, C.byref(ms)))
+        return float(ms.value)
+
     def timer_start(self):
         self.check(self.lib.rtc_timer_start(self.h))
 

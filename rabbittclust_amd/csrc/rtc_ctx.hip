@@ -93,6 +93,8 @@ void rtc_ctx_destroy(rtc_ctx* ctx) {
   if (ctx->kssd.d_bucket) (void)hipFree(ctx->kssd.d_bucket);
   if (ctx->kssd.d_bloom) (void)hipFree(ctx->kssd.d_bloom);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->pk0) (void)hipEventDestroy(ctx->pk0);
+  if (ctx->pk1) (void)hipEventDestroy(ctx->pk1);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->owned_stream) (void)hipStreamDestroy(ctx->owned_stream);
   delete ctx;

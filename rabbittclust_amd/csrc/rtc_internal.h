@@ -25,6 +25,9 @@ struct rtc_ctx {
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // HIP events around the last pair_tiled_kernel launch, on the stream it was launched on (rtc_pair_last_kernel_ms)
+  hipEvent_t pk0 = nullptr, pk1 = nullptr;
+  int pk_valid = 0;
   // tiled pair kernel: the last plan (slice offsets + transposed column copy in scratch slots 1 / 4).
   // Reused only while pair_plan_hold is set by a caller that guarantees unchanged sketches between
   // launches (the row-chunk loop of the dense candidate-edge path).

@@ -565,9 +565,13 @@ int launch_tiled(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const
   auto kern = pair_tiled_kernel<T, NPL, EMIT>;
   RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((row1 - row0 + ROWS - 1) / ROWS, (col1 - col0 + TW - 1) / TW);
+  if (!ctx->pk0) { RTC_HIP(ctx, hipEventCreate(&ctx->pk0)); RTC_HIP(ctx, hipEventCreate(&ctx->pk1)); }
+  RTC_HIP(ctx, hipEventRecord(ctx->pk0, ctx->stream));
   hipLaunchKernelGGL(kern, grid, dim3(TW), lds, ctx->stream, d_hashes, d_start, (const uint4*)pl.d_tcols, (const uint4*)pl.d_tcols_lo, pl.d_tbase, pl.d_so,
                      pl.P, pl.n, pl.tc0, pl.tnc, row0, row1, col0, col1, d_common, ld, lower_only, sink);
   RTC_CHECK_LAUNCH(ctx);
+  RTC_HIP(ctx, hipEventRecord(ctx->pk1, ctx->stream));
+  ctx->pk_valid = 1;
   return RTC_OK;
 }
 
@@ -754,3 +758,13 @@ int rtc_pair_edges_tiled(rtc_ctx* ctx, const void* d_hashes, int width, const ui
                               lower_only, &sink, handled);
 }
 
+// Duration of the last pair_tiled_kernel launch of this context (HIP events on its launch stream); waits for it.
+extern "C" int rtc_pair_last_kernel_ms(rtc_ctx* ctx, float* ms_out) {
+  if (!ctx || !ms_out) return RTC_ERR_ARG;
+  *ms_out = 0.f;
+  if (!ctx->pk_valid) return rtc_fail(ctx, RTC_ERR_ARG, "no tiled pair kernel has run on this context");
+  RTC_HIP(ctx, hipSetDevice(ctx->device));
+  RTC_HIP(ctx, hipEventSynchronize(ctx->pk1));
+  RTC_HIP(ctx, hipEventElapsedTime(ms_out, ctx->pk0, ctx->pk1));
+  return RTC_OK;
+}

@@ -429,6 +429,8 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   vector<size_t> retry_files; vector<uint64_t> retry_need;
   size_t done_files = 0, bi = 0;
   uint32_t next_row = 0;
+  double parse_s = 0;       // wall time the parser threads took, summed over the batches (the GPU lanes work beside it)
+  uint64_t parse_bytes = 0;
   for (int round = 0; round < 2; round++) {  // round 1: files whose slot guess was too small (gzip ISIZE)
     for (const Batch& b : batches) {
       const double t0 = get_sec();
@@ -469,6 +471,8 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
         if (res[b.files[q]].kept) { nkept++; if (round == 0) row_file.push_back(b.files[q]); }
       }
       if (!retry_files.empty()) resident_ok.store(false);  // retried files arrive out of list order: ids are no longer row numbers
+      parse_s += get_sec() - t0;
+      parse_bytes += b.bytes;
       if (verbose) fprintf(stderr, "[parse] batch %zu: %zu files, %.2f GB in %.3fs\n", bi, b.files.size(), b.bytes / 1e9, get_sec() - t0);
       Lane& ln = lanes[bi % NL];
       if (ln.worker.joinable()) ln.worker.join();
@@ -492,6 +496,11 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
     retry_files.clear(); retry_need.clear();
   }
   if (shuffle_thread.joinable()) shuffle_thread.join();
+  if (parse_s > 0) {  // the host feed: what ONE host can parse bounds what it can hand to 8 GPUs
+    g_metrics.num("parse_s", parse_s);
+    g_metrics.num("parse_gbp_per_s", (double)parse_bytes / parse_s / 1e9);
+    g_metrics.num("parse_gbp_per_s_per_thread", (double)parse_bytes / parse_s / 1e9 / std::max(1, job.threads));
+  }
   const double tf0 = get_sec();
   // (the second lanes' contexts and every device staging buffer live until the process ends, see below)
   if (pinned) free_stage();
@@ -1628,6 +1637,7 @@ int main(int argc, char** argv) {
     }
   }
   rtc_ctx* ctx = gpus[0].ctx;
+  g_metrics.num("hip_init_s", get_sec() - t_main);
   if (getenv("RTC_VERBOSE")) fprintf(stderr, "[ctx]   HIP runtime + %zu GPU context(s) in %.3fs\n", gpus.size(), get_sec() - t_main);
   // The device code of the pair / MST / greedy phases is mapped at its first launch (~27 ms): a helper thread does
   // that with a toy clustering while this one reads and sketches (rtc_warmup; RTC_NO_WARMUP=1 leaves it out).

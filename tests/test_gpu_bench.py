@@ -1,0 +1,37 @@
+"""bench.py end to end on the GPU box: the default line must carry every extra workload WITHOUT an error entry (an extra that
+breaks is reported as {"error": ...} so that it never costs the headline -- which also means nobody notices unless a test
+looks), the dense extra must have gone through the tiled kernel by the cost rule's own choice, and the roofline objects
+must be complete."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_default_line_has_every_extra_without_error(ctx):
+    env = {k: v for k, v in os.environ.items() if not k.startswith("RTC_PAIR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--extra-steps", "1",
+                        "--cli-genomes", "64", "--cpu-sample-genomes", "32", "--cpu-sample-sketches", "2000"],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 1 and line["value"] > 0
+    for key in ("roofline", "roofline_dist", "cpu_baseline", "extra"):
+        assert key in line, key
+    assert line["roofline"]["frac"] > 0 and line["cpu_baseline"].get("value"), line["cpu_baseline"]
+    assert line["roofline_dist"]["survey_8d_bytes_per_pair"] == 16000.0
+    ex = line["extra"]
+    assert set(ex) == {"kssd", "greedy", "weak_first_point", "dense_pairs", "cli"}
+    for name, v in ex.items():
+        assert "error" not in v, (name, v)
+    d = ex["dense_pairs"]
+    assert d["pair_path"] == 2 and d["pair_kernel_ms"] > 0 and d["cand_edges"] >= 10 * 1000 * 999 // 2
+    assert d["roofline_dist"]["bytes_per_pair"] == 16000.0 and d["roofline_dist"]["algorithmic_frac"] > 0
+    for mode in ("minhash", "fast"):
+        c = ex["cli"][mode]
+        assert c["genomes"] == 64 and c["wall_s"] > 0 and c["computing_sketch_s"] > 0 and c["parse_gbp_per_sec_per_thread"] > 0
