@@ -3,9 +3,10 @@
 #   1. bench.py JSON lines (minhash N=1 default; --mode kssd)          -> gpurun_out/prof/bench_*.jsonl
 #   2. rocprofv3 --kernel-trace --stats of the same commands            -> gpurun_out/prof/stats*/  (kernel_stats.csv)
 #   3. rocprofv3 --pmc passes (own runs, --pmc only)                     -> gpurun_out/prof/pmc*/  and *_pmc_traffic.json
-#   4. greedy (BASELINE config 4, 50 000 containment sketches) kernel stats
+#   4. greedy (BASELINE config 4, 50 000 containment sketches) kernel stats + PMC passes of its sketch kernel
+#   5. the dense regime of the pair phase (bench.py --only dense_pairs: 10 families of 1 000, tiled N x N kernel): stats + PMC
 # Usage: bash tools/collect_profiles.sh [tag]     (tag names the files, e.g. r02)
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
@@ -40,9 +41,28 @@ python $R/tools/make_pmc_json.py $K ${TAG}_kssd kssd 25000 2000000 > $OUT/${TAG}
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/greedy_stats -- python $R/tools/run_configs.py greedy 50000 2000000 > $OUT/greedy.log 2>&1
 tail -3 $OUT/greedy.log
 python $R/tools/kstats.py $OUT/greedy_stats | head -8
+i=0
+for grp in "${PMCGROUPS[@]}"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $grp --output-format csv -d $OUT/greedy_pmc/pmc$i -- python $R/bench.py --only greedy --extra-steps 1 > $OUT/greedy_pmc$i.log 2>&1
+done
+# 50 000 prefix genomes of 0.4 .. 2 Mbp: 64 Gbp, mean length 1.28 Mbp (the "derived" per-step figures use genomes x this length)
+python $R/tools/make_pmc_json.py $OUT/greedy_pmc ${TAG}_greedy greedy 50000 1280000 > $OUT/${TAG}_greedy_pmc_traffic.json
+# ---- dense regime of the pair phase (tiled N x N kernel) ----
+D=$OUT/dense; mkdir -p $D
+python $R/bench.py --only dense_pairs > $D/bench_dense.jsonl 2> $D/bench_dense.err
+tail -c 600 $D/bench_dense.jsonl; echo
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python $R/bench.py --only dense_pairs > $D/stats.log 2>&1
+python $R/tools/kstats.py $D/stats | head -8
+i=0
+for grp in "${PMCGROUPS[@]}"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $grp --output-format csv -d $D/pmc$i -- python $R/bench.py --only dense_pairs --extra-steps 1 > $D/pmc$i.log 2>&1
+done
+python $R/tools/make_pmc_json.py $D ${TAG}_dense dense_pairs 10000 500000 > $OUT/${TAG}_dense_pmc_traffic.json
 python - <<PY
 import json
-for f in ("$OUT/${TAG}_pmc_traffic.json", "$OUT/${TAG}_kssd_pmc_traffic.json"):
+for f in ("$OUT/${TAG}_pmc_traffic.json", "$OUT/${TAG}_kssd_pmc_traffic.json", "$OUT/${TAG}_greedy_pmc_traffic.json", "$OUT/${TAG}_dense_pmc_traffic.json"):
     d = json.load(open(f))
     for k, v in d["kernels"].items():
         print(k, {a: b for a, b in v.items() if a in ("hbm_bytes_per_launch", "derived")})
