@@ -259,37 +259,49 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
   }
 }
 
-constexpr int WGB = 1024;  // lanes per workgroup of the prefilter kernel: 2 workgroups per CU (64 KiB filter + 10 KiB of queues each) = 8 waves per SIMD
-constexpr int WGB_WAVES_EU = 8;
-typedef uint16_t bq_t;     // queue entry: dword index relative to the queue's base (4-byte entries: 768 lanes, 6 waves per SIMD, 3-4 % slower)
+constexpr int WGB = 1024;  // lanes per workgroup of the prefilter kernel; one workgroup per CU (64 KiB of filters + 50 KiB of queues)
+constexpr int WGB_WAVES_EU = 4;
+typedef uint16_t bq_t;     // exact-drain queue entry: dword index relative to the queue's base
 
 // ---- forward-strand prefilter (the default --fast configuration, K = 18..28, 24-bit dim_id) --------------
 // A k-mer is kept when the dim_id of its CANONICAL form is one of the dim_end kept dimensions (:1141-1149).
 // dim_id is the k-mer's middle 12 bases, and the middle of the reverse complement is the reverse complement of
 // the middle: whichever strand is canonical, the FORWARD k-mer's middle 12-mer lies in S2 = S u rc(S) (8192
 // 12-mers of 16 Mi).  So the steady state never forms the reverse strand, never compares strands and never checks
-// characters.  It is a conservative candidate generator:
+// characters.  It is a conservative candidate generator in two stages:
 //   * a wave walks a contiguous stretch of its segment 1 KiB at a time, lane l holding bases 16 l .. 16 l + 15 of the
-//     chunk (ONE coalesced 16-byte load per lane: every 128-byte line is requested once; the previous layout, a run
-//     of ~100 bases per lane, asked L2 for every line about four times and was bound there);
+//     chunk (ONE coalesced 16-byte load per lane: every 128-byte line is requested once);
 //   * the lane packs its 16 bases into one register (four SWAR decodes + v_dot4), takes the 16 (32) bases in
 //     front of them from its neighbour lane(s) with a DPP wave shift (lane 0: carried over from the previous
-//     chunk in SGPRs) -- no warm-up bases at all -- and cuts the 32-bit word that holds the four middle 12-mers of a
+//     chunk in SGPRs) -- no warm-up bases at all -- and cuts the 32-bit word E that holds the four middle 12-mers of a
 //     dword's k-mers with one v_alignbit;
-//   * per k-mer a blocked Bloom filter of S2 in LDS is probed -- 8192 blocks of 64 bits, block = field[10..23), one
-//     bit in each half (field[0..5), field[5..10)): one ds_read_b64 and seven 2-cycle-class VALU instructions; the
-//     four k-mers of a dword are OR-ed into one accumulator and tested with ONE compare.
+//   * stage 1, once per DWORD: the four middle 12-mers of a dword's k-mers share nine bases (18 bits of E).  A
+//     2^18-bit map in LDS (32 KiB) says whether those 18 bits occur in ANY member of S2 at one of the four
+//     alignments (11.7 % of the map is set): one ds_read_b32 and six VALU instructions for four k-mers.  Until round
+//     4 every k-mer probed a blocked Bloom filter -- one random ds_read_b64 each, and the kernel sat on the LDS
+//     (SQ_LDS_IDX_ACTIVE 81 % of the cycles, 69 % of them bank conflicts: 32 random bank pairs per 32-lane group);
+//   * the dwords that pass (one lane in eight) go, as (E, position), to a per-wave LDS queue; stage 2 takes 64 of
+//     them at a time -- every lane busy -- and probes a blocked Bloom filter of S2 (4096 blocks of 64 bits, block
+//     and bits from a multiplicative hash of the whole 12-mer, so that a 12-mer that shares 18 bits with a member
+//     is no likelier to pass than any other) for the four k-mers of each.
 // Nothing is lost: a valid k-mer's bases decode exactly, and whatever else decodes to a hit (characters outside
-// ACGT, bases beyond a genome's end, ~1/350 false positives of the filter) is dropped later.  Hits (~0.7 lanes per
-// wave and dword) put the dword's POSITION into a per-wave LDS queue; bloom_drain re-reads those K + 3 bases from
-// memory (L2) and does the reference's arithmetic exactly: characters, both strands, canonical minimum, dimension
-// lookup (the exact bucket index, read from global memory here), reduced tuple, append.
-constexpr int BLOOM_BYTES = 65536;                 // 8192 blocks x 8 B
+// ACGT, bases beyond a genome's end, false positives: together 0.5 % of the dwords, 0.2 % are true members) is
+// dropped later.  Survivors put the dword's POSITION into a second per-wave queue; bloom_drain re-reads those K + 3
+// bases from memory (L2 / Infinity Cache) and does the reference's arithmetic exactly: characters, both strands,
+// canonical minimum, dimension lookup (the exact bucket index, read from global memory here), reduced tuple, append.
+constexpr int CORE_BYTES = 32768;                  // stage 1: 2^18 bits
+constexpr int BLOOM2_LOG2 = 12;                    // stage 2: 4096 blocks x 8 B
+constexpr int BLOOM2_BYTES = (1 << BLOOM2_LOG2) * 8;
+constexpr int BLOOM_BYTES = CORE_BYTES + BLOOM2_BYTES;   // what the host uploads: [map | filter]
+constexpr uint32_t BLOOM2_MUL = 0x9E3779B1u;
+constexpr int Q1_CAP = 320;                        // (E, position) pairs per wave: < 64 left over + at most 256 per chunk
+constexpr int Q1_BYTES = (WGB / 64) * Q1_CAP * 8;
 constexpr int BQ_CAP = 320;                        // queued positions per wave; one chunk adds at most 256
 constexpr int BQ_BYTES = (WGB / 64) * BQ_CAP * (int)sizeof(bq_t);
 constexpr int BQ_SPAN = 255;                       // chunks a wave may walk on one queue base: 255 * 256 + 255 dwords < 2^16
 constexpr int CHUNK = 1024;                        // bases a wave takes per step (64 lanes x 16)
 typedef bq_t RTC_LDS* lds_u32_ptr;
+typedef u32x2 RTC_LDS* lds_q1_ptr;
 
 struct BloomSeg {
   uint64_t g_begin, g_end, s_begin, s_end, base;   // base: queue entries are positions relative to it
@@ -430,10 +442,39 @@ __device__ __forceinline__ uint32_t from_lane_below(uint32_t v, uint32_t first) 
   return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
 }
 
+// stage 2: n <= 64 queued dwords q[0 .. n), one per lane: the four k-mers of each against the Bloom filter of S2;
+// the owned survivors' positions go to the exact-drain queue.  Returns the new length of that queue.
+template <int K>
+__device__ __forceinline__ uint32_t bloom_stage2(lds_q1_ptr q, uint32_t n, uint32_t lane, lds_u32_ptr wq, uint32_t qn,
+                                                 const BloomSeg& bs) {
+  constexpr int DS = K - 12;
+  constexpr bool NARROW = DS >= 8 && DS <= 10;
+  constexpr int FO0 = NARROW ? DS - 2 : 6;
+  const bool have = lane < n;
+  u32x2 ent = {0u, 0u};
+  if (have) ent = q[lane];
+  const uint32_t E = ent.x;
+  uint32_t acc = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const uint32_t field = (E >> (FO0 - 2 * b)) & 0xffffffu;
+    const uint32_t h = field * BLOOM2_MUL;
+    const uint32_t a = (uint32_t)CORE_BYTES + ((h >> (32 - BLOOM2_LOG2 - 3)) & (uint32_t)(((1 << BLOOM2_LOG2) - 1) << 3));
+    const u32x2 blk = *(const RTC_LDS u32x2*)(uintptr_t)a;
+    acc |= (blk.x >> ((h >> 8) & 31u)) & (blk.y >> ((h >> 13) & 31u));
+  }
+  // the dword's k-mers end at pos .. pos + 3: queued only when one of them is owned by this segment
+  const int64_t pos = (int64_t)bs.base + 4 * (int64_t)ent.y;
+  const bool mine = have && (acc & 1u) != 0u && pos + 3 >= (int64_t)bs.s_begin && pos < (int64_t)bs.s_end;
+  const uint64_t bal = __ballot(mine);
+  if (mine) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (bq_t)ent.y;
+  return qn + (uint32_t)__popcll(bal);
+}
+
 template <int K>
 __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(const uint8_t* __restrict__ seq,
                                                                const KSegment* __restrict__ segs, KssdParams P,
-                                                               const uint32_t* __restrict__ g_bloom,  // 8192 x 8 B
+                                                               const uint32_t* __restrict__ g_bloom,  // [2^18-bit map | 4096 x 8 B]
                                                                const uint32_t* __restrict__ g_bk,     // exact index, patterns
                                                                const uint16_t* __restrict__ g_rank,   // exact index, ranks
                                                                int var, void* __restrict__ out, uint32_t stride,
@@ -444,10 +485,11 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
   // With X = (bases before the lane's 16 : the lane's 16 bases), the word E of dword qd holds the four middle
   // 12-mers of the k-mers that end in it.  K = 20, 22: E = the 16 bases in front of the dword (fields at bits
   // [DS - 2 - 2b, DS + 22 - 2b)); otherwise E = the 32 bits from DS up of the window that ends with the dword
-  // (fields at [6 - 2b, 30 - 2b)), which reaches into the second neighbour's bases.
+  // (fields at [6 - 2b, 30 - 2b)), which reaches into the second neighbour's bases.  The 18 bits [FO0, FO0 + 18)
+  // of E belong to all four fields.
   constexpr bool NARROW = DS >= 8 && DS <= 10;
   constexpr int FO0 = NARROW ? DS - 2 : 6;
-  constexpr int AHEAD = 4;                         // chunks requested ahead of the one being walked (4 .. 8: no difference; 4 keeps the kernel in 64 VGPRs)
+  constexpr int AHEAD = 4;                         // chunks requested ahead of the one being walked
   const KSegment sg = segs[blockIdx.x];
   const int t = threadIdx.x;
   const uint32_t lane = t & 63;
@@ -457,14 +499,15 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
     for (int i = t; i < BLOOM_BYTES / 16; i += WGB) l4[i] = g4[i];
     __syncthreads();
   }
-  if ((uint32_t)(uintptr_t)(RTC_LDS unsigned char*)smem != 0u) __builtin_trap();  // the filter is addressed absolutely
+  if ((uint32_t)(uintptr_t)(RTC_LDS unsigned char*)smem != 0u) __builtin_trap();  // the filters are addressed absolutely
   void* orow = reinterpret_cast<unsigned char*>(out) + (uint64_t)sg.genome * stride * (P.use64 ? 8 : 4);
   uint32_t* ocnt = cnt + sg.genome;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const lds_u32_ptr wq = (lds_u32_ptr)(uintptr_t)(BLOOM_BYTES + wv * BQ_CAP * (int)sizeof(bq_t));  // this wave's queue
-  uint32_t qn = 0;                                                                 // wave-uniform
-  BloomSeg bs{sg.g_begin, sg.g_end, sg.s_begin, sg.s_end, 0};  // base: set whenever the queue is empty
-  int64_t cq = 0;                                             // the chunk the queue's base points at
+  const lds_q1_ptr q1 = (lds_q1_ptr)(uintptr_t)(BLOOM_BYTES + wv * Q1_CAP * 8);                      // stage-1 survivors
+  const lds_u32_ptr wq = (lds_u32_ptr)(uintptr_t)(BLOOM_BYTES + Q1_BYTES + wv * BQ_CAP * (int)sizeof(bq_t));  // stage-2 survivors
+  uint32_t q1n = 0, qn = 0;                                                        // wave-uniform
+  BloomSeg bs{sg.g_begin, sg.g_end, sg.s_begin, sg.s_end, 0};  // base: set whenever both queues are empty
+  int64_t cq = 0;                                             // the chunk the queues' base points at
 
   // this wave's chunks [c, c1) of the segment's 1 KiB-aligned span
   const int64_t A0 = (int64_t)(sg.s_begin & ~(uint64_t)(CHUNK - 1));
@@ -492,16 +535,19 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
   uint32_t carry1 = 0, carry2 = 0;  // the packed bases of lanes 63 / 62 of the previous chunk (SGPRs)
   bool primed = false;
   for (;;) {
-    // (re)start of the pipeline: once per wave, and again after the queue had to be drained mid-way
-    // Full batches of 64 are taken from the end of the queue (every lane busy; a drain costs the same for 3 entries
-    // as for 64); what is left (< 64) waits for the next time, or is finished after the last chunk.
-    while (qn >= 64 || (qn && (c >= c1 || c - cq >= BQ_SPAN))) {
+    // (re)start of the pipeline: once per wave, and again after the exact-drain queue had to be emptied mid-way.
+    // At the end of the wave's stretch, and when the queues' base is too far behind, what stage 1 left (< 64) goes
+    // through stage 2 first.  Full batches of 64 are taken from the end of the exact-drain queue (every lane busy; a
+    // drain costs the same for 3 entries as for 64); what is left (< 64) waits for the next time, or for the end.
+    const bool flush = c >= c1 || c - cq >= BQ_SPAN;
+    if (flush && q1n) { qn = bloom_stage2<K>(q1, q1n, lane, wq, qn, bs); q1n = 0; }
+    while (qn >= 64 || (qn && flush)) {
       const uint32_t n = qn < 64 ? qn : 64;
       bloom_drain<K>(seq, bs, P, g_bk, g_rank, var, wq, qn - n, n, lane, orow, ocnt, stride);
       qn -= n;
     }
     if (c >= c1) break;
-    if (qn == 0) { cq = c; bs.base = (uint64_t)(A0 + c * CHUNK); }  // empty queue: its base moves up to here
+    if (qn == 0 && q1n == 0) { cq = c; bs.base = (uint64_t)(A0 + c * CHUNK); }  // empty queues: their base moves up to here
     if (!primed) {  // the bases in front of the first chunk
       const uint32_t Wb = pack16(fetch(c - 1));
       carry1 = __builtin_amdgcn_readlane(Wb, 63);
@@ -526,39 +572,38 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
         if (!NARROW) { Wpp = from_lane_below(Wp, carry2); carry2 = __builtin_amdgcn_readlane(W, 62); }
         carry1 = __builtin_amdgcn_readlane(W, 63);
         const int64_t cb = A0 + c * CHUNK;
-        const bool edge = cb < (int64_t)sg.s_begin || cb + CHUNK > (int64_t)sg.s_end;     // wave-uniform: first / last chunk of the segment
         const uint32_t rel0 = (uint32_t)(cb - (int64_t)bs.base) / 4u + 4u * lane;        // queue entry of the lane's first dword
+        // stage 1 for the lane's four dwords side by side: the four words E, their four map reads in flight together,
+        // four votes; then the survivors of all four go to the queue with ONE update of its length
+        uint32_t E[4], mw[4];
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
-          uint32_t E;
           if (NARROW) {
-            E = qd ? __builtin_amdgcn_alignbit(Wp, W, 32 - 8 * qd) : Wp;
+            E[qd] = qd ? __builtin_amdgcn_alignbit(Wp, W, 32 - 8 * qd) : Wp;
           } else {
             const int sft = 24 - 8 * qd + DS;  // bits of (Wpp : Wp : W) below E
-            E = sft == 0 ? W : sft < 32 ? __builtin_amdgcn_alignbit(Wp, W, sft) : sft == 32 ? Wp : __builtin_amdgcn_alignbit(Wpp, Wp, sft - 32);
+            E[qd] = sft == 0 ? W : sft < 32 ? __builtin_amdgcn_alignbit(Wp, W, sft) : sft == 32 ? Wp : __builtin_amdgcn_alignbit(Wpp, Wp, sft - 32);
           }
-          uint32_t acc = 0;
+          // the 18 bits all four fields share, E[FO0 .. FO0 + 18), against the map
+          mw[qd] = *(const RTC_LDS uint32_t*)(uintptr_t)((E[qd] >> (FO0 + 3)) & 0x7ffcu);
+        }
+        uint32_t at = q1n;  // wave-uniform
 #pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const int fo = FO0 - 2 * b;                                                   // the field's bit offset in E
-            const uint32_t f0 = fo ? (E >> fo) : E;                                       // field[0..5): bit in the low half
-            const uint32_t a = (E >> (fo + 7)) & 0xfff8u;                                 // block = field[10..23)
-            const u32x2 blk = *(const RTC_LDS u32x2*)(uintptr_t)a;
-            const uint32_t r1 = blk.x >> (f0 & 31u);
-            const uint32_t r2 = blk.y >> ((E >> (fo + 5)) & 31u);                         // field[5..10): bit in the high half
-            acc = b ? __builtin_amdgcn_bitop3_b32(acc, r1, r2, 0xF8) : (r1 & r2);         // acc | (r1 & r2)
+        for (int qd = 0; qd < 4; qd++) {
+          const bool pass = ((mw[qd] >> ((E[qd] >> FO0) & 31u)) & 1u) != 0u;
+          const uint64_t bal = __ballot(pass);
+          if (pass) {
+            u32x2 ent;
+            ent.x = E[qd];
+            ent.y = rel0 + qd;
+            q1[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = ent;
           }
-          const bool hit = (acc & 1u) != 0u;
-          if (__ballot(hit)) {  // wave-uniform; about every second dword of a wave
-            bool mine = hit;
-            if (edge) {  // the dword's k-mers end at pos .. pos + 3: queued only when one of them is owned
-              const int64_t pos = cb + 16 * (int64_t)lane + 4 * qd;
-              mine = hit && pos + 3 >= (int64_t)sg.s_begin && pos < (int64_t)sg.s_end;
-            }
-            const uint64_t bal = __ballot(mine);
-            if (mine) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (bq_t)(rel0 + qd);
-            qn += (uint32_t)__popcll(bal);
-          }
+          at += (uint32_t)__popcll(bal);
+        }
+        q1n = at;
+        while (q1n >= 64) {  // wave-uniform: full batches for stage 2, taken from the end of the queue
+          q1n -= 64;
+          qn = bloom_stage2<K>(q1 + q1n, 64, lane, wq, qn, bs);
         }
         c++;
       }
@@ -894,16 +939,24 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
         kc.bvar = var;
       }
       if (kc.bvar >= 0) {
-        // the forward-strand prefilter: every kept 12-mer and its reverse complement, two bits each (block =
-        // bits 10..22, low-half bit = bits 0..4, high-half bit = bits 5..9; see sketch_kssd_bloom_kernel)
+        // the forward-strand prefilter over S2 = every kept 12-mer and its reverse complement (sketch_kssd_bloom_kernel):
+        // [0, 32 KiB) stage 1: bit c of the map is set when c = 18 bits of a member at one of the four alignments a
+        // dword's k-mers have (member >> 0, 2, 4, 6); [32 KiB, 64 KiB) stage 2: blocked Bloom filter, block and the two
+        // bits (one per 32-bit half) from a multiplicative hash of the member
         std::vector<uint32_t> bloom(BLOOM_BYTES / 4, 0u);
+        uint32_t* bl2 = bloom.data() + CORE_BYTES / 4;
         for (uint32_t key : keys) {
           uint32_t rc = 0;
           for (int i = 0; i < 12; i++) rc |= (((key >> (2 * i)) & 3u) ^ 3u) << (2 * (11 - i));
           for (uint32_t v : {key, rc}) {
-            const uint32_t blk = (v >> 10) & 0x1fffu;
-            bloom[2 * blk] |= 1u << (v & 31u);
-            bloom[2 * blk + 1] |= 1u << ((v >> 5) & 31u);
+            for (int al = 0; al < 4; al++) {
+              const uint32_t core = (v >> (2 * al)) & 0x3ffffu;
+              bloom[core >> 5] |= 1u << (core & 31u);
+            }
+            const uint32_t h = v * BLOOM2_MUL;
+            const uint32_t blk = h >> (32 - BLOOM2_LOG2);
+            bl2[2 * blk] |= 1u << ((h >> 8) & 31u);
+            bl2[2 * blk + 1] |= 1u << ((h >> 13) & 31u);
           }
         }
         RTC_HIP(ctx, hipMalloc(&kc.d_bloom, BLOOM_BYTES));
@@ -1012,7 +1065,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
     if (getenv("RTC_VERBOSE")) fprintf(stderr, "[kssd] forward-strand prefilter, K=%d, %zu segments\n", K, segs.size());
     const uint32_t* d_bk = (const uint32_t*)kc.d_bucket;  // the exact index (variant kc.bvar) serves the drain from global memory
     const uint16_t* d_rk = (const uint16_t*)((const char*)kc.d_bucket + BUCKET_BYTES);
-    const int lds_bl = BLOOM_BYTES + BQ_BYTES;
+    const int lds_bl = BLOOM_BYTES + Q1_BYTES + BQ_BYTES;
 #define LAUNCH_BLOOM(KK)                                                                                              \
   case KK: {                                                                                                         \
     auto kern = sketch_kssd_bloom_kernel<KK>;                                                                 \
