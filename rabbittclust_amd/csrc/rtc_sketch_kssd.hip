@@ -259,8 +259,8 @@ __global__ __launch_bounds__(WG) void sketch_kssd_kernel(const uint8_t* __restri
   }
 }
 
-constexpr int WGB = 1024;  // lanes per workgroup of the prefilter kernel; one workgroup per CU (64 KiB of filters + 50 KiB of queues)
-constexpr int WGB_WAVES_EU = 4;
+constexpr int WGB = 1024;  // lanes per workgroup of the prefilter kernel: 2 workgroups per CU (64 KiB of filters + 16 KiB of queues each) = 8 waves per SIMD
+constexpr int WGB_WAVES_EU = 8;
 typedef uint16_t bq_t;     // exact-drain queue entry: dword index relative to the queue's base
 
 // ---- forward-strand prefilter (the default --fast configuration, K = 18..28, 24-bit dim_id) --------------
@@ -294,14 +294,17 @@ constexpr int BLOOM2_LOG2 = 12;                    // stage 2: 4096 blocks x 8 B
 constexpr int BLOOM2_BYTES = (1 << BLOOM2_LOG2) * 8;
 constexpr int BLOOM_BYTES = CORE_BYTES + BLOOM2_BYTES;   // what the host uploads: [map | filter]
 constexpr uint32_t BLOOM2_MUL = 0x9E3779B1u;
-constexpr int Q1_CAP = 320;                        // (E, position) pairs per wave: < 64 left over + at most 256 per chunk
-constexpr int Q1_BYTES = (WGB / 64) * Q1_CAP * 8;
-constexpr int BQ_CAP = 320;                        // queued positions per wave; one chunk adds at most 256
+constexpr int Q1_CAP = 128;                        // stage-1 survivors per wave, (E: 4 B, position: 2 B) in two arrays: < 64 left over + what a
+                                                   // chunk adds; a chunk that would not fit (more than a quarter of its dwords pass the map:
+                                                   // 11.7 % do on random sequence) is walked dword by dword with the queues served in between
+constexpr int Q1_BYTES = (WGB / 64) * Q1_CAP * 6;
+constexpr int BQ_CAP = 128;                        // stage-2 survivors per wave: < 64 left over + at most 64 per stage-2 batch
 constexpr int BQ_BYTES = (WGB / 64) * BQ_CAP * (int)sizeof(bq_t);
+static_assert(BLOOM_BYTES + Q1_BYTES + BQ_BYTES <= 81920, "two workgroups per CU");
 constexpr int BQ_SPAN = 255;                       // chunks a wave may walk on one queue base: 255 * 256 + 255 dwords < 2^16
 constexpr int CHUNK = 1024;                        // bases a wave takes per step (64 lanes x 16)
 typedef bq_t RTC_LDS* lds_u32_ptr;
-typedef u32x2 RTC_LDS* lds_q1_ptr;
+typedef uint32_t RTC_LDS* lds_q1_ptr;
 
 struct BloomSeg {
   uint64_t g_begin, g_end, s_begin, s_end, base;   // base: queue entries are positions relative to it
@@ -442,18 +445,17 @@ __device__ __forceinline__ uint32_t from_lane_below(uint32_t v, uint32_t first) 
   return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
 }
 
-// stage 2: n <= 64 queued dwords q[0 .. n), one per lane: the four k-mers of each against the Bloom filter of S2;
-// the owned survivors' positions go to the exact-drain queue.  Returns the new length of that queue.
+// stage 2: n <= 64 queued dwords (qe[i], qr[i]), i < n, one per lane: the four k-mers of each against the Bloom filter of
+// S2; the owned survivors' positions go to the exact-drain queue.  Returns the new length of that queue (at most + 64).
 template <int K>
-__device__ __forceinline__ uint32_t bloom_stage2(lds_q1_ptr q, uint32_t n, uint32_t lane, lds_u32_ptr wq, uint32_t qn,
-                                                 const BloomSeg& bs) {
+__device__ __forceinline__ uint32_t bloom_stage2(lds_q1_ptr qe, lds_u32_ptr qr, uint32_t n, uint32_t lane, lds_u32_ptr wq,
+                                                 uint32_t qn, const BloomSeg& bs) {
   constexpr int DS = K - 12;
   constexpr bool NARROW = DS >= 8 && DS <= 10;
   constexpr int FO0 = NARROW ? DS - 2 : 6;
   const bool have = lane < n;
-  u32x2 ent = {0u, 0u};
-  if (have) ent = q[lane];
-  const uint32_t E = ent.x;
+  uint32_t E = 0, rel = 0;
+  if (have) { E = qe[lane]; rel = qr[lane]; }
   uint32_t acc = 0;
 #pragma unroll
   for (int b = 0; b < 4; b++) {
@@ -464,10 +466,10 @@ __device__ __forceinline__ uint32_t bloom_stage2(lds_q1_ptr q, uint32_t n, uint3
     acc |= (blk.x >> ((h >> 8) & 31u)) & (blk.y >> ((h >> 13) & 31u));
   }
   // the dword's k-mers end at pos .. pos + 3: queued only when one of them is owned by this segment
-  const int64_t pos = (int64_t)bs.base + 4 * (int64_t)ent.y;
+  const int64_t pos = (int64_t)bs.base + 4 * (int64_t)rel;
   const bool mine = have && (acc & 1u) != 0u && pos + 3 >= (int64_t)bs.s_begin && pos < (int64_t)bs.s_end;
   const uint64_t bal = __ballot(mine);
-  if (mine) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (bq_t)ent.y;
+  if (mine) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (bq_t)rel;
   return qn + (uint32_t)__popcll(bal);
 }
 
@@ -503,23 +505,28 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
   void* orow = reinterpret_cast<unsigned char*>(out) + (uint64_t)sg.genome * stride * (P.use64 ? 8 : 4);
   uint32_t* ocnt = cnt + sg.genome;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const lds_q1_ptr q1 = (lds_q1_ptr)(uintptr_t)(BLOOM_BYTES + wv * Q1_CAP * 8);                      // stage-1 survivors
-  const lds_u32_ptr wq = (lds_u32_ptr)(uintptr_t)(BLOOM_BYTES + Q1_BYTES + wv * BQ_CAP * (int)sizeof(bq_t));  // stage-2 survivors
+  // this wave's queues: stage-1 survivors as E[Q1_CAP] (4 B) and positions[Q1_CAP] (2 B), stage-2 survivors as positions
+  const lds_q1_ptr q1e = (lds_q1_ptr)(uintptr_t)(BLOOM_BYTES + wv * Q1_CAP * 6);
+  const lds_u32_ptr q1r = (lds_u32_ptr)(uintptr_t)(BLOOM_BYTES + wv * Q1_CAP * 6 + Q1_CAP * 4);
+  const lds_u32_ptr wq = (lds_u32_ptr)(uintptr_t)(BLOOM_BYTES + Q1_BYTES + wv * BQ_CAP * (int)sizeof(bq_t));
   uint32_t q1n = 0, qn = 0;                                                        // wave-uniform
   BloomSeg bs{sg.g_begin, sg.g_end, sg.s_begin, sg.s_end, 0};  // base: set whenever both queues are empty
-  int64_t cq = 0;                                             // the chunk the queues' base points at
+  int cq = 0;                                                 // the chunk the queues' base points at
 
-  // this wave's chunks [c, c1) of the segment's 1 KiB-aligned span
+  // this wave's chunks [c, c1) of the segment's 1 KiB-aligned span (a segment is a genome or a piece of one: < 2^31 chunks)
   const int64_t A0 = (int64_t)(sg.s_begin & ~(uint64_t)(CHUNK - 1));
   const int64_t NC = ((int64_t)sg.s_end - A0 + CHUNK - 1) / CHUNK;
-  int64_t c = NC * wv / (WGB / 64);
-  const int64_t c1 = NC * (wv + 1) / (WGB / 64);
+  int c = (int)(NC * wv / (WGB / 64));
+  const int c1 = (int)(NC * (wv + 1) / (WGB / 64));
+  // chunks [in_lo, in_hi) lie inside the genome: one 16-byte load per lane; the others (a genome's first and last) byte by byte
+  const int64_t lo64 = ((int64_t)sg.g_begin - A0 + CHUNK - 1) >> 10, hi64 = ((int64_t)sg.g_end - A0) >> 10;  // CHUNK = 2^10
+  const int in_lo = P.nofast ? 0x7fffffff : (int)(lo64 < -1 ? -1 : lo64), in_hi = (int)(hi64 > 0x7fffffff ? 0x7fffffff : hi64);
+  const uint8_t* lane_seq = seq + A0 + 16 * (int64_t)lane;
 
-  auto fetch = [&](int64_t ci) -> uint4 {  // lane's 16 bases of chunk ci ('N' outside the genome)
-    const int64_t cb = A0 + ci * CHUNK;
-    const bool inside = cb >= (int64_t)sg.g_begin && cb + CHUNK <= (int64_t)sg.g_end && !P.nofast;  // wave-uniform
-    const int64_t q = cb + 16 * (int64_t)lane;
-    return inside ? *reinterpret_cast<const uint4*>(seq + q) : load_bases16_edge(seq, q, sg.g_begin, sg.g_end);
+  auto fetch = [&](int ci) -> uint4 {  // lane's 16 bases of chunk ci ('N' outside the genome)
+    const bool inside = ci >= in_lo && ci < in_hi;  // wave-uniform
+    return inside ? *reinterpret_cast<const uint4*>(lane_seq + (int64_t)ci * CHUNK)
+                  : load_bases16_edge(seq, A0 + (int64_t)ci * CHUNK + 16 * (int64_t)lane, sg.g_begin, sg.g_end);
   };
   auto pack16 = [&](const uint4 d) -> uint32_t {  // 16 bases -> 32 bits, first base on top (BaseMap :1007-1017)
     const uint32_t w[4] = {d.x, d.y, d.z, d.w};
@@ -531,23 +538,65 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
     }
     return (((pk[0] << 8 | pk[1]) << 8 | pk[2]) << 8) | pk[3];
   };
+  auto word_of = [&](int qd, uint32_t W, uint32_t Wp, uint32_t Wpp) -> uint32_t {  // E of the lane's dword qd (0..3, a constant)
+    if (NARROW) return qd ? __builtin_amdgcn_alignbit(Wp, W, 32 - 8 * qd) : Wp;
+    const int sft = 24 - 8 * qd + DS;  // bits of (Wpp : Wp : W) below E
+    return sft == 0 ? W : sft < 32 ? __builtin_amdgcn_alignbit(Wp, W, sft) : sft == 32 ? Wp : __builtin_amdgcn_alignbit(Wpp, Wp, sft - 32);
+  };
+  auto map_word = [&](uint32_t E) -> uint32_t {  // stage 1: the 18 bits all four fields share, E[FO0 .. FO0 + 18), against the map
+    return *(const RTC_LDS uint32_t*)(uintptr_t)((E >> (FO0 + 3)) & 0x7ffcu);
+  };
 
   uint32_t carry1 = 0, carry2 = 0;  // the packed bases of lanes 63 / 62 of the previous chunk (SGPRs)
   bool primed = false;
+  int careful = -1;                 // >= 0: chunk c did not fit the stage-1 queue; its dword `careful` is next, one per round
   for (;;) {
-    // (re)start of the pipeline: once per wave, and again after the exact-drain queue had to be emptied mid-way.
-    // At the end of the wave's stretch, and when the queues' base is too far behind, what stage 1 left (< 64) goes
-    // through stage 2 first.  Full batches of 64 are taken from the end of the exact-drain queue (every lane busy; a
-    // drain costs the same for 3 entries as for 64); what is left (< 64) waits for the next time, or for the end.
+    // The one place where the queues are served (and where the pipeline (re)starts): a full batch of the exact-drain
+    // queue first (64 entries from its end: every lane busy, a drain costs the same for 3 entries as for 64), then a full
+    // batch of stage-1 survivors through stage 2; at the end of the wave's stretch, and when the queues' base is too far
+    // behind, also what is left of either.
     const bool flush = c >= c1 || c - cq >= BQ_SPAN;
-    if (flush && q1n) { qn = bloom_stage2<K>(q1, q1n, lane, wq, qn, bs); q1n = 0; }
-    while (qn >= 64 || (qn && flush)) {
-      const uint32_t n = qn < 64 ? qn : 64;
-      bloom_drain<K>(seq, bs, P, g_bk, g_rank, var, wq, qn - n, n, lane, orow, ocnt, stride);
-      qn -= n;
+    for (;;) {
+      if (qn >= 64 || (flush && qn && q1n == 0)) {
+        const uint32_t n = qn < 64 ? qn : 64;
+        bloom_drain<K>(seq, bs, P, g_bk, g_rank, var, wq, qn - n, n, lane, orow, ocnt, stride);
+        qn -= n;
+      } else if (q1n >= 64 || (flush && q1n)) {
+        const uint32_t n = q1n < 64 ? q1n : 64;
+        q1n -= n;
+        qn = bloom_stage2<K>(q1e + q1n, q1r + q1n, n, lane, wq, qn, bs);
+      } else {
+        break;
+      }
     }
     if (c >= c1) break;
-    if (qn == 0 && q1n == 0) { cq = c; bs.base = (uint64_t)(A0 + c * CHUNK); }  // empty queues: their base moves up to here
+    if (qn == 0 && q1n == 0) { cq = c; bs.base = (uint64_t)(A0 + (int64_t)c * CHUNK); }  // empty queues: their base moves up to here
+    if (careful >= 0) {
+      // One dword of chunk c per round (q1n, qn < 64 here; a dword adds at most 64): the chunk and the one in front
+      // of it are read again.  Rare by construction -- long stretches whose 9-mers all occur in kept 12-mers.
+      const uint32_t Wb = pack16(fetch(c - 1));
+      const uint32_t W = pack16(fetch(c));
+      const uint32_t Wp = from_lane_below(W, __builtin_amdgcn_readlane(Wb, 63));
+      const uint32_t Wpp = from_lane_below(Wp, __builtin_amdgcn_readlane(Wb, 62));
+      const uint32_t e4[4] = {word_of(0, W, Wp, Wpp), word_of(1, W, Wp, Wpp), word_of(2, W, Wp, Wpp), word_of(3, W, Wp, Wpp)};
+      const uint32_t E = careful == 0 ? e4[0] : careful == 1 ? e4[1] : careful == 2 ? e4[2] : e4[3];
+      const bool pass = ((map_word(E) >> ((E >> FO0) & 31u)) & 1u) != 0u;
+      const uint64_t bal = __ballot(pass);
+      if (pass) {
+        const uint32_t at = q1n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        q1e[at] = E;
+        q1r[at] = (bq_t)(((uint32_t)(c - cq) << 8) + 4u * lane + (uint32_t)careful);
+      }
+      q1n += (uint32_t)__popcll(bal);
+      if (++careful == 4) {
+        careful = -1;
+        carry1 = __builtin_amdgcn_readlane(W, 63);
+        carry2 = __builtin_amdgcn_readlane(W, 62);
+        primed = true;
+        c++;
+      }
+      continue;
+    }
     if (!primed) {  // the bases in front of the first chunk
       const uint32_t Wb = pack16(fetch(c - 1));
       carry1 = __builtin_amdgcn_readlane(Wb, 63);
@@ -561,7 +610,7 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
     while (!stop) {
 #pragma unroll
       for (int j = 0; j < AHEAD; j++) {
-        if (c >= c1 || qn >= (uint32_t)(BQ_CAP - 256) || c - cq >= BQ_SPAN) { stop = true; break; }  // done, or a full batch waits (room for a whole chunk's hits is kept)
+        if (c >= c1 || qn >= 64u || c - cq >= BQ_SPAN) { stop = true; break; }  // done, or a full exact-drain batch waits
         const uint32_t W = pack16(D[j]);
         if (c + AHEAD < c1) {
           __builtin_amdgcn_sched_barrier(0);  // the request stays here (hoisted, its registers would pile up)
@@ -569,41 +618,37 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
         }
         const uint32_t Wp = from_lane_below(W, carry1);
         uint32_t Wpp = 0;
-        if (!NARROW) { Wpp = from_lane_below(Wp, carry2); carry2 = __builtin_amdgcn_readlane(W, 62); }
-        carry1 = __builtin_amdgcn_readlane(W, 63);
-        const int64_t cb = A0 + c * CHUNK;
-        const uint32_t rel0 = (uint32_t)(cb - (int64_t)bs.base) / 4u + 4u * lane;        // queue entry of the lane's first dword
+        if (!NARROW) Wpp = from_lane_below(Wp, carry2);
+        const uint32_t rel0 = ((uint32_t)(c - cq) << 8) + 4u * lane;  // queue entry of the lane's first dword: dwords from the base
         // stage 1 for the lane's four dwords side by side: the four words E, their four map reads in flight together,
-        // four votes; then the survivors of all four go to the queue with ONE update of its length
+        // four votes; the survivors of all four go to the queue with ONE update of its length
         uint32_t E[4], mw[4];
+        uint64_t bal[4];
+        uint32_t pv[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) { E[qd] = word_of(qd, W, Wp, Wpp); mw[qd] = map_word(E[qd]); }
+        uint32_t total = 0;
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
-          if (NARROW) {
-            E[qd] = qd ? __builtin_amdgcn_alignbit(Wp, W, 32 - 8 * qd) : Wp;
-          } else {
-            const int sft = 24 - 8 * qd + DS;  // bits of (Wpp : Wp : W) below E
-            E[qd] = sft == 0 ? W : sft < 32 ? __builtin_amdgcn_alignbit(Wp, W, sft) : sft == 32 ? Wp : __builtin_amdgcn_alignbit(Wpp, Wp, sft - 32);
-          }
-          // the 18 bits all four fields share, E[FO0 .. FO0 + 18), against the map
-          mw[qd] = *(const RTC_LDS uint32_t*)(uintptr_t)((E[qd] >> (FO0 + 3)) & 0x7ffcu);
+          pv[qd] = __builtin_amdgcn_ubfe(mw[qd], E[qd] >> FO0, 1u);  // the map's bit, 0 or 1 (the offset's low five bits count)
+          bal[qd] = __ballot(pv[qd] != 0u);
+          total += (uint32_t)__popcll(bal[qd]);
         }
-        uint32_t at = q1n;  // wave-uniform
+        if (q1n + total >= (uint32_t)Q1_CAP) { careful = 0; stop = true; break; }  // (the carries still describe chunk c - 1)
+        carry1 = __builtin_amdgcn_readlane(W, 63);
+        if (!NARROW) carry2 = __builtin_amdgcn_readlane(W, 62);
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
-          const bool pass = ((mw[qd] >> ((E[qd] >> FO0) & 31u)) & 1u) != 0u;
-          const uint64_t bal = __ballot(pass);
-          if (pass) {
-            u32x2 ent;
-            ent.x = E[qd];
-            ent.y = rel0 + qd;
-            q1[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = ent;
+          if (pv[qd] != 0u) {
+            const uint32_t at = q1n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[qd] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[qd], 0u));
+            q1e[at] = E[qd];
+            q1r[at] = (bq_t)(rel0 + qd);
           }
-          at += (uint32_t)__popcll(bal);
+          q1n += (uint32_t)__popcll(bal[qd]);
         }
-        q1n = at;
-        while (q1n >= 64) {  // wave-uniform: full batches for stage 2, taken from the end of the queue
+        if (q1n >= 64) {  // wave-uniform: one full batch for stage 2 from the end of the queue (q1n < 128, qn < 64 here)
           q1n -= 64;
-          qn = bloom_stage2<K>(q1 + q1n, 64, lane, wq, qn, bs);
+          qn = bloom_stage2<K>(q1e + q1n, q1r + q1n, 64, lane, wq, qn, bs);
         }
         c++;
       }
