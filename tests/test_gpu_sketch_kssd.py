@@ -136,3 +136,34 @@ def test_kssd_full_queue_contigs_and_edges(ctx, oracle, k):
     for g in range(len(parts)):
         assert np.array_equal(got[g], want[g]), f"genome {g} k={k}: got {len(got[g])} want {len(want[g])}"
     assert len(got[0]) > 50
+
+
+@pytest.mark.parametrize("k", [21, 25])
+def test_kssd_stretches_that_flood_the_first_stage(ctx, oracle, k):
+    """A genome stitched from KEPT 12-mers (members of the shuffled dimension set and their reverse complements): about a
+    third of its dwords pass the prefilter's first stage, more than the stage-1 queue takes per chunk, so the kernel
+    walks those chunks dword by dword with the queues served in between; random stretches, an N run and a second
+    ordinary genome sit around them.  Tuple lists must still equal the oracle's."""
+    rng = np.random.default_rng(77 + k)
+    p = oracle.kssd_params(k, 3)
+    sd = np.asarray(oracle.kssd_shuffle_dim(p.half_subk))
+    kept = np.nonzero((sd >= 0) & (sd < 4096))[0]
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def twelve(v):  # 24-bit dim_id -> its 12 bases, first base in the top bits
+        return alphabet[[(int(v) >> (2 * (11 - i))) & 3 for i in range(12)]]
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    pieces = []
+    for v in rng.choice(kept, size=9000):
+        m = twelve(v)
+        if rng.random() < 0.5:
+            m = np.array([comp[int(b)] for b in m[::-1]], dtype=np.uint8)
+        pieces.append(m)
+    flood = np.concatenate(pieces)                                  # 108 000 bases of back-to-back members
+    rnd = lambda n: rng.choice(alphabet, size=n)
+    g0 = np.concatenate([rnd(70_001), flood[:60_000], np.full(37, ord("N"), dtype=np.uint8), flood[60_000:], rnd(50_003)])
+    g1 = rnd(150_000)
+    seq = np.concatenate([g0, g1])
+    off = np.array([0, len(g0), len(g0) + len(g1)], dtype=np.uint64)
+    got = _check(ctx, oracle, seq, off, k, 3)
+    assert len(got[0]) > 100
