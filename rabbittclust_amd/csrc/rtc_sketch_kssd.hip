@@ -463,7 +463,7 @@ __device__ __forceinline__ uint32_t bloom_stage2(lds_q1_ptr qe, lds_u32_ptr qr, 
     const uint32_t h = field * BLOOM2_MUL;
     const uint32_t a = (uint32_t)CORE_BYTES + ((h >> (32 - BLOOM2_LOG2 - 3)) & (uint32_t)(((1 << BLOOM2_LOG2) - 1) << 3));
     const u32x2 blk = *(const RTC_LDS u32x2*)(uintptr_t)a;
-    acc |= (blk.x >> ((h >> 8) & 31u)) & (blk.y >> ((h >> 13) & 31u));
+    acc |= (blk.x >> ((h >> 8) & 31u)) & (blk.x >> ((h >> 3) & 31u)) & (blk.y >> ((h >> 13) & 31u)) & (blk.y >> (h & 31u));  // four bits per member
   }
   // the dword's k-mers end at pos .. pos + 3: queued only when one of them is owned by this segment
   const int64_t pos = (int64_t)bs.base + 4 * (int64_t)rel;
@@ -986,8 +986,8 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
       if (kc.bvar >= 0) {
         // the forward-strand prefilter over S2 = every kept 12-mer and its reverse complement (sketch_kssd_bloom_kernel):
         // [0, 32 KiB) stage 1: bit c of the map is set when c = 18 bits of a member at one of the four alignments a
-        // dword's k-mers have (member >> 0, 2, 4, 6); [32 KiB, 64 KiB) stage 2: blocked Bloom filter, block and the two
-        // bits (one per 32-bit half) from a multiplicative hash of the member
+        // dword's k-mers have (member >> 0, 2, 4, 6); [32 KiB, 64 KiB) stage 2: blocked Bloom filter, block and the four
+        // bits (two per 32-bit half) from a multiplicative hash of the member
         std::vector<uint32_t> bloom(BLOOM_BYTES / 4, 0u);
         uint32_t* bl2 = bloom.data() + CORE_BYTES / 4;
         for (uint32_t key : keys) {
@@ -1000,8 +1000,8 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
             }
             const uint32_t h = v * BLOOM2_MUL;
             const uint32_t blk = h >> (32 - BLOOM2_LOG2);
-            bl2[2 * blk] |= 1u << ((h >> 8) & 31u);
-            bl2[2 * blk + 1] |= 1u << ((h >> 13) & 31u);
+            bl2[2 * blk] |= (1u << ((h >> 8) & 31u)) | (1u << ((h >> 3) & 31u));
+            bl2[2 * blk + 1] |= (1u << ((h >> 13) & 31u)) | (1u << (h & 31u));
           }
         }
         RTC_HIP(ctx, hipMalloc(&kc.d_bloom, BLOOM_BYTES));
