@@ -281,7 +281,7 @@ typedef uint16_t bq_t;     // exact-drain queue entry: dword index relative to t
 //     4 every k-mer probed a blocked Bloom filter -- one random ds_read_b64 each, and the kernel sat on the LDS
 //     (SQ_LDS_IDX_ACTIVE 81 % of the cycles, 69 % of them bank conflicts: 32 random bank pairs per 32-lane group);
 //   * the dwords that pass (one lane in eight) go, as (E, position), to a per-wave LDS queue; stage 2 takes 64 of
-//     them at a time -- every lane busy -- and probes a blocked Bloom filter of S2 (4096 blocks of 64 bits, block
+//     them at a time -- every lane busy -- and probes a blocked Bloom filter of S2 (3584 blocks of 64 bits, block
 //     and bits from a multiplicative hash of the whole 12-mer, so that a 12-mer that shares 18 bits with a member
 //     is no likelier to pass than any other) for the four k-mers of each.
 // Nothing is lost: a valid k-mer's bases decode exactly, and whatever else decodes to a hit (characters outside
@@ -290,21 +290,21 @@ typedef uint16_t bq_t;     // exact-drain queue entry: dword index relative to t
 // bases from memory (L2 / Infinity Cache) and does the reference's arithmetic exactly: characters, both strands,
 // canonical minimum, dimension lookup (the exact bucket index, read from global memory here), reduced tuple, append.
 constexpr int CORE_BYTES = 32768;                  // stage 1: 2^18 bits
-constexpr int BLOOM2_LOG2 = 12;                    // stage 2: 4096 blocks x 8 B
-constexpr int BLOOM2_BYTES = (1 << BLOOM2_LOG2) * 8;
+constexpr uint32_t BLOOM2_BLOCKS = 3584;           // stage 2: 3584 blocks x 8 B (28 KiB: what two workgroups per CU leave)
+constexpr int BLOOM2_BYTES = BLOOM2_BLOCKS * 8;
 constexpr int BLOOM_BYTES = CORE_BYTES + BLOOM2_BYTES;   // what the host uploads: [map | filter]
 constexpr uint32_t BLOOM2_MUL = 0x9E3779B1u;
-constexpr int Q1_CAP = 128;                        // stage-1 survivors per wave, (E: 4 B, position: 2 B) in two arrays: < 64 left over + what a
+constexpr int Q1_CAP = 128;                        // stage-1 survivors per wave, (E, position) pairs of 8 bytes: < 64 left over + what a
                                                    // chunk adds; a chunk that would not fit (more than a quarter of its dwords pass the map:
                                                    // 11.7 % do on random sequence) is walked dword by dword with the queues served in between
-constexpr int Q1_BYTES = (WGB / 64) * Q1_CAP * 6;
+constexpr int Q1_BYTES = (WGB / 64) * Q1_CAP * 8;
 constexpr int BQ_CAP = 128;                        // stage-2 survivors per wave: < 64 left over + at most 64 per stage-2 batch
 constexpr int BQ_BYTES = (WGB / 64) * BQ_CAP * (int)sizeof(bq_t);
 static_assert(BLOOM_BYTES + Q1_BYTES + BQ_BYTES <= 81920, "two workgroups per CU");
 constexpr int BQ_SPAN = 255;                       // chunks a wave may walk on one queue base: 255 * 256 + 255 dwords < 2^16
 constexpr int CHUNK = 1024;                        // bases a wave takes per step (64 lanes x 16)
 typedef bq_t RTC_LDS* lds_u32_ptr;
-typedef uint32_t RTC_LDS* lds_q1_ptr;
+typedef u32x2 RTC_LDS* lds_q1_ptr;
 
 struct BloomSeg {
   uint64_t g_begin, g_end, s_begin, s_end, base;   // base: queue entries are positions relative to it
@@ -445,38 +445,42 @@ __device__ __forceinline__ uint32_t from_lane_below(uint32_t v, uint32_t first) 
   return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
 }
 
-// stage 2: n <= 64 queued dwords (qe[i], qr[i]), i < n, one per lane: the four k-mers of each against the Bloom filter of
-// S2; the owned survivors' positions go to the exact-drain queue.  Returns the new length of that queue (at most + 64).
+// stage 2: n <= 64 queued dwords q[0 .. n), one per lane: the four k-mers of each against the Bloom filter of S2 (the
+// four blocks requested together); the owned survivors' positions go to the exact-drain queue.  Returns the new length
+// of that queue (at most + 64).
 template <int K>
-__device__ __forceinline__ uint32_t bloom_stage2(lds_q1_ptr qe, lds_u32_ptr qr, uint32_t n, uint32_t lane, lds_u32_ptr wq,
-                                                 uint32_t qn, const BloomSeg& bs) {
+__device__ __forceinline__ uint32_t bloom_stage2(lds_q1_ptr q, uint32_t n, uint32_t lane, lds_u32_ptr wq, uint32_t qn,
+                                                 const BloomSeg& bs) {
   constexpr int DS = K - 12;
   constexpr bool NARROW = DS >= 8 && DS <= 10;
   constexpr int FO0 = NARROW ? DS - 2 : 6;
   const bool have = lane < n;
-  uint32_t E = 0, rel = 0;
-  if (have) { E = qe[lane]; rel = qr[lane]; }
-  uint32_t acc = 0;
+  u32x2 ent = {0u, 0u};
+  if (have) ent = q[lane];
+  const uint32_t E = ent.x;
+  uint32_t h[4];
+  u32x2 blk[4];
 #pragma unroll
   for (int b = 0; b < 4; b++) {
-    const uint32_t field = (E >> (FO0 - 2 * b)) & 0xffffffu;
-    const uint32_t h = field * BLOOM2_MUL;
-    const uint32_t a = (uint32_t)CORE_BYTES + ((h >> (32 - BLOOM2_LOG2 - 3)) & (uint32_t)(((1 << BLOOM2_LOG2) - 1) << 3));
-    const u32x2 blk = *(const RTC_LDS u32x2*)(uintptr_t)a;
-    acc |= (blk.x >> ((h >> 8) & 31u)) & (blk.x >> ((h >> 3) & 31u)) & (blk.y >> ((h >> 13) & 31u)) & (blk.y >> (h & 31u));  // four bits per member
+    h[b] = ((E >> (FO0 - 2 * b)) & 0xffffffu) * BLOOM2_MUL;
+    blk[b] = *(const RTC_LDS u32x2*)(uintptr_t)((uint32_t)CORE_BYTES + (__umulhi(h[b], BLOOM2_BLOCKS) << 3));
   }
+  uint32_t acc = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++)  // four bits per member
+    acc |= (blk[b].x >> ((h[b] >> 8) & 31u)) & (blk[b].x >> ((h[b] >> 3) & 31u)) & (blk[b].y >> ((h[b] >> 13) & 31u)) & (blk[b].y >> (h[b] & 31u));
   // the dword's k-mers end at pos .. pos + 3: queued only when one of them is owned by this segment
-  const int64_t pos = (int64_t)bs.base + 4 * (int64_t)rel;
+  const int64_t pos = (int64_t)bs.base + 4 * (int64_t)ent.y;
   const bool mine = have && (acc & 1u) != 0u && pos + 3 >= (int64_t)bs.s_begin && pos < (int64_t)bs.s_end;
   const uint64_t bal = __ballot(mine);
-  if (mine) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (bq_t)rel;
+  if (mine) wq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (bq_t)ent.y;
   return qn + (uint32_t)__popcll(bal);
 }
 
 template <int K>
 __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(const uint8_t* __restrict__ seq,
                                                                const KSegment* __restrict__ segs, KssdParams P,
-                                                               const uint32_t* __restrict__ g_bloom,  // [2^18-bit map | 4096 x 8 B]
+                                                               const uint32_t* __restrict__ g_bloom,  // [2^18-bit map | 3584 x 8 B]
                                                                const uint32_t* __restrict__ g_bk,     // exact index, patterns
                                                                const uint16_t* __restrict__ g_rank,   // exact index, ranks
                                                                int var, void* __restrict__ out, uint32_t stride,
@@ -505,9 +509,8 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
   void* orow = reinterpret_cast<unsigned char*>(out) + (uint64_t)sg.genome * stride * (P.use64 ? 8 : 4);
   uint32_t* ocnt = cnt + sg.genome;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  // this wave's queues: stage-1 survivors as E[Q1_CAP] (4 B) and positions[Q1_CAP] (2 B), stage-2 survivors as positions
-  const lds_q1_ptr q1e = (lds_q1_ptr)(uintptr_t)(BLOOM_BYTES + wv * Q1_CAP * 6);
-  const lds_u32_ptr q1r = (lds_u32_ptr)(uintptr_t)(BLOOM_BYTES + wv * Q1_CAP * 6 + Q1_CAP * 4);
+  // this wave's queues: stage-1 survivors as (E, position) pairs, stage-2 survivors as positions
+  const lds_q1_ptr q1 = (lds_q1_ptr)(uintptr_t)(BLOOM_BYTES + wv * Q1_CAP * 8);
   const lds_u32_ptr wq = (lds_u32_ptr)(uintptr_t)(BLOOM_BYTES + Q1_BYTES + wv * BQ_CAP * (int)sizeof(bq_t));
   uint32_t q1n = 0, qn = 0;                                                        // wave-uniform
   BloomSeg bs{sg.g_begin, sg.g_end, sg.s_begin, sg.s_end, 0};  // base: set whenever both queues are empty
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
       } else if (q1n >= 64 || (flush && q1n)) {
         const uint32_t n = q1n < 64 ? q1n : 64;
         q1n -= n;
-        qn = bloom_stage2<K>(q1e + q1n, q1r + q1n, n, lane, wq, qn, bs);
+        qn = bloom_stage2<K>(q1 + q1n, n, lane, wq, qn, bs);
       } else {
         break;
       }
@@ -584,8 +587,10 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
       const uint64_t bal = __ballot(pass);
       if (pass) {
         const uint32_t at = q1n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        q1e[at] = E;
-        q1r[at] = (bq_t)(((uint32_t)(c - cq) << 8) + 4u * lane + (uint32_t)careful);
+        u32x2 ent;
+        ent.x = E;
+        ent.y = ((uint32_t)(c - cq) << 8) + 4u * lane + (uint32_t)careful;
+        q1[at] = ent;
       }
       q1n += (uint32_t)__popcll(bal);
       if (++careful == 4) {
@@ -641,14 +646,16 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
         for (int qd = 0; qd < 4; qd++) {
           if (pv[qd] != 0u) {
             const uint32_t at = q1n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[qd] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[qd], 0u));
-            q1e[at] = E[qd];
-            q1r[at] = (bq_t)(rel0 + qd);
+            u32x2 ent;
+            ent.x = E[qd];
+            ent.y = rel0 + qd;
+            q1[at] = ent;
           }
           q1n += (uint32_t)__popcll(bal[qd]);
         }
         if (q1n >= 64) {  // wave-uniform: one full batch for stage 2 from the end of the queue (q1n < 128, qn < 64 here)
           q1n -= 64;
-          qn = bloom_stage2<K>(q1e + q1n, q1r + q1n, 64, lane, wq, qn, bs);
+          qn = bloom_stage2<K>(q1 + q1n, 64, lane, wq, qn, bs);
         }
         c++;
       }
@@ -986,7 +993,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
       if (kc.bvar >= 0) {
         // the forward-strand prefilter over S2 = every kept 12-mer and its reverse complement (sketch_kssd_bloom_kernel):
         // [0, 32 KiB) stage 1: bit c of the map is set when c = 18 bits of a member at one of the four alignments a
-        // dword's k-mers have (member >> 0, 2, 4, 6); [32 KiB, 64 KiB) stage 2: blocked Bloom filter, block and the four
+        // dword's k-mers have (member >> 0, 2, 4, 6); [32 KiB, 60 KiB) stage 2: blocked Bloom filter, block and the four
         // bits (two per 32-bit half) from a multiplicative hash of the member
         std::vector<uint32_t> bloom(BLOOM_BYTES / 4, 0u);
         uint32_t* bl2 = bloom.data() + CORE_BYTES / 4;
@@ -999,7 +1006,7 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
               bloom[core >> 5] |= 1u << (core & 31u);
             }
             const uint32_t h = v * BLOOM2_MUL;
-            const uint32_t blk = h >> (32 - BLOOM2_LOG2);
+            const uint32_t blk = (uint32_t)(((uint64_t)h * BLOOM2_BLOCKS) >> 32);
             bl2[2 * blk] |= (1u << ((h >> 8) & 31u)) | (1u << ((h >> 3) & 31u));
             bl2[2 * blk + 1] |= (1u << ((h >> 13) & 31u)) | (1u << (h & 31u));
           }
