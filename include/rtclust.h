@@ -24,7 +24,9 @@ typedef enum {
   RTC_ERR_HIP = 2,         /* HIP runtime failure; see rtc_last_error() */
   RTC_ERR_UNSUPPORTED = 3, /* valid request outside what the GPU path implements */
   RTC_ERR_OVERFLOW = 4,    /* caller-provided output capacity too small; required size reported */
-  RTC_ERR_NOMEM = 5
+  RTC_ERR_NOMEM = 5,
+  RTC_ERR_COMM = 6         /* a collective did not complete within RTC_COMM_TIMEOUT_S (default 120 s) or the communicator was
+                              aborted after one: every later call on that communicator returns this at once */
 } rtc_status;
 
 typedef struct rtc_ctx rtc_ctx;

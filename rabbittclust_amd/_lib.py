@@ -10,9 +10,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTC_HIP_LIB") or os.path.join(_HERE, "librtclust_hip.so")  # override: alternative builds
 
-RTC_OK, RTC_ERR_ARG, RTC_ERR_HIP, RTC_ERR_UNSUPPORTED, RTC_ERR_OVERFLOW, RTC_ERR_NOMEM = range(6)
+RTC_OK, RTC_ERR_ARG, RTC_ERR_HIP, RTC_ERR_UNSUPPORTED, RTC_ERR_OVERFLOW, RTC_ERR_NOMEM, RTC_ERR_COMM = range(7)
 STATUS_NAMES = {0: "RTC_OK", 1: "RTC_ERR_ARG", 2: "RTC_ERR_HIP", 3: "RTC_ERR_UNSUPPORTED",
-                4: "RTC_ERR_OVERFLOW", 5: "RTC_ERR_NOMEM"}
+                4: "RTC_ERR_OVERFLOW", 5: "RTC_ERR_NOMEM", 6: "RTC_ERR_COMM"}
 
 
 class RtcError(RuntimeError):

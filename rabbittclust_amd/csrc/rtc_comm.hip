@@ -23,7 +23,9 @@
 #include <mutex>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
+#include <thread>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -114,17 +116,32 @@ const Rccl* rccl() {  // nullptr when the library or one of its symbols is missi
   const Rccl* nc__ = rccl();                                                                           \
   if (!nc__) return rtc_fail((ctx), RTC_ERR_UNSUPPORTED, "RCCL is not available: %s", g_rccl.err)
 
+// Watchdog: no collective may wait longer than this for its peers (RTC_COMM_TIMEOUT_S, default 120 s; <= 0: forever).
+// A rank that never arrives -- it failed before the call, took another branch, died -- otherwise leaves the others inside
+// the collective until somebody kills the job.
+double comm_timeout_s() {
+  const char* e = getenv("RTC_COMM_TIMEOUT_S");
+  const double v = e ? atof(e) : 120.0;
+  return v > 0 ? v : 1e30;
+}
+
 struct LocalGroup {  // in-process exchange for contexts sharing a device
   std::mutex m;
   std::condition_variable cv;
   int n = 0, arrived = 0;
   uint64_t gen = 0;
+  bool broken = false;  // a barrier timed out: every rank of the group fails from now on
   std::vector<const void*> ptr;
-  void barrier() {
+  bool barrier() {      // false: a peer did not arrive in time (or the group broke earlier)
     std::unique_lock<std::mutex> lk(m);
+    if (broken) return false;
     const uint64_t g = gen;
-    if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); }
-    else cv.wait(lk, [&] { return gen != g; });
+    if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); return true; }
+    const double t = comm_timeout_s();
+    const bool ok = t >= 1e29 ? (cv.wait(lk, [&] { return gen != g || broken; }), true)
+                              : cv.wait_for(lk, std::chrono::duration<double>(t), [&] { return gen != g || broken; });
+    if (!ok || broken) { broken = true; cv.notify_all(); return false; }
+    return true;
   }
 };
 
@@ -136,8 +153,9 @@ struct rtc_comm {
   ncclComm_t nccl = nullptr;
   std::shared_ptr<LocalGroup> local;
   hipStream_t side = nullptr;      // gathers overlap compute on the context stream
-  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr, ev_watch = nullptr;
   bool side_busy = false;
+  bool broken = false;             // a collective timed out and the communicator was aborted
 };
 
 #define RTC_NCCL(ctx, call)                                                                     \
@@ -161,23 +179,55 @@ __global__ void local_reduce_kernel(const void* const* __restrict__ srcs, int ns
   }
 }
 
+int comm_broken(rtc_comm* c, const char* what) {
+  c->broken = true;
+  return rtc_fail(c->ctx, RTC_ERR_COMM, "%s: rank %d of %d waited %.0f s for its peers (RTC_COMM_TIMEOUT_S); the communicator is "
+                  "aborted", what, c->rank, c->size, comm_timeout_s());
+}
+#define RTC_LOCAL_BARRIER(c, what) do { if (!(c)->local->barrier()) return comm_broken((c), (what)); } while (0)
+
+// RCCL collectives are enqueued, not awaited: the host polls an event behind the collective on its stream, and when the
+// deadline passes aborts the communicator (ncclCommAbort: the only way out of a collective whose peers never come).
+int comm_watch(rtc_comm* c, hipStream_t stream, const char* what) {
+  rtc_ctx* ctx = c->ctx;
+  if (!c->nccl) return RTC_OK;
+  RTC_HIP(ctx, hipEventRecord(c->ev_watch, stream));
+  const double limit = comm_timeout_s();
+  const auto t0 = std::chrono::steady_clock::now();
+  int spins = 0;
+  for (;;) {
+    const hipError_t e = hipEventQuery(c->ev_watch);
+    if (e == hipSuccess) return RTC_OK;
+    if (e != hipErrorNotReady) return rtc_fail(ctx, RTC_ERR_HIP, "%s: hipEventQuery -> %s", what, hipGetErrorString(e));
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+      if (const Rccl* nc = rccl()) (void)nc->CommAbort(c->nccl);
+      c->nccl = nullptr;
+      return comm_broken(c, what);
+    }
+    if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));  // the first ~ms busy: collectives are short
+  }
+}
+#define RTC_COMM_ALIVE(c) do { if ((c)->broken) return rtc_fail((c)->ctx, RTC_ERR_COMM, "the communicator was aborted after a collective timed out"); } while (0)
+
 int comm_finish_init(rtc_comm* c) {
   rtc_ctx* ctx = c->ctx;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
   RTC_HIP(ctx, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   RTC_HIP(ctx, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
   RTC_HIP(ctx, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  RTC_HIP(ctx, hipEventCreateWithFlags(&c->ev_watch, hipEventDisableTiming));
   return RTC_OK;
 }
 
 // dtype 0 = int64, 1 = uint32, 2 = uint64; op 0 = MIN, 1 = MAX; on `stream`
 int comm_all_reduce_on(rtc_comm* c, void* d_buf, size_t count, int dtype, int op, hipStream_t stream) {
   rtc_ctx* ctx = c->ctx;
+  RTC_COMM_ALIVE(c);
   if ((c->size == 1 && !c->nccl) || count == 0) return RTC_OK;
   if (c->nccl) {
     RTC_NEED_RCCL(ctx);
     RTC_NCCL(ctx, nc__->AllReduce(d_buf, d_buf, count, dtype == 0 ? ncclInt64 : dtype == 1 ? ncclUint32 : ncclUint64, op == 0 ? ncclMin : ncclMax, c->nccl, stream));
-    return RTC_OK;
+    return comm_watch(c, stream, "all-reduce");
   }
   LocalGroup& g = *c->local;
   const size_t esz = dtype == 1 ? 4 : 8;
@@ -187,7 +237,7 @@ int comm_all_reduce_on(rtc_comm* c, void* d_buf, size_t count, int dtype, int op
   const void** d_ptrs = (const void**)((char*)ws + ((count * esz + 63) & ~(size_t)63));
   RTC_HIP(ctx, hipStreamSynchronize(stream));
   g.ptr[c->rank] = d_buf;
-  g.barrier();
+  RTC_LOCAL_BARRIER(c, "all-reduce");
   std::vector<const void*> ptrs(g.ptr.begin(), g.ptr.begin() + c->size);
   RTC_HIP(ctx, hipMemcpyAsync((void*)d_ptrs, ptrs.data(), (size_t)c->size * 8, hipMemcpyHostToDevice, stream));
   const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min<size_t>((count + 255) / 256, 2048));
@@ -196,16 +246,17 @@ int comm_all_reduce_on(rtc_comm* c, void* d_buf, size_t count, int dtype, int op
   else hipLaunchKernelGGL(local_reduce_kernel<uint32_t>, dim3(grid), dim3(256), 0, stream, (const void* const*)d_ptrs, c->size, count, op, (uint32_t*)tmp);
   RTC_HIP(ctx, hipGetLastError());
   RTC_HIP(ctx, hipStreamSynchronize(stream));
-  g.barrier();  // everybody has read everybody's input
+  RTC_LOCAL_BARRIER(c, "all-reduce");  // everybody has read everybody's input
   RTC_HIP(ctx, hipMemcpyAsync(d_buf, tmp, count * esz, hipMemcpyDeviceToDevice, stream));
   RTC_HIP(ctx, hipStreamSynchronize(stream));
-  g.barrier();
+  RTC_LOCAL_BARRIER(c, "all-reduce");
   return RTC_OK;
 }
 
 // rows [a, b) of every rank's block of the canonical global buffer travel to all ranks, in place
 int comm_gather_rows_on(rtc_comm* c, void* d_global, size_t row_bytes, uint32_t n_local, uint32_t a, uint32_t b, hipStream_t stream) {
   rtc_ctx* ctx = c->ctx;
+  RTC_COMM_ALIVE(c);
   if ((c->size == 1 && !c->nccl) || b <= a || row_bytes == 0) return RTC_OK;
   const size_t bytes = (size_t)(b - a) * row_bytes;
   if (c->nccl) {
@@ -217,19 +268,19 @@ int comm_gather_rows_on(rtc_comm* c, void* d_global, size_t row_bytes, uint32_t 
       if (st != ncclSuccess) { (void)nc__->GroupEnd(); return rtc_fail(ctx, RTC_ERR_HIP, "ncclBroadcast -> %s", nc__->GetErrorString(st)); }
     }
     RTC_NCCL(ctx, nc__->GroupEnd());
-    return RTC_OK;
+    return stream == c->side ? RTC_OK : comm_watch(c, stream, "gather");  // side stream: rtc_comm_wait watches it
   }
   LocalGroup& g = *c->local;
   RTC_HIP(ctx, hipStreamSynchronize(stream));
   g.ptr[c->rank] = d_global;
-  g.barrier();
+  RTC_LOCAL_BARRIER(c, "gather");
   for (int r = 0; r < c->size; r++) {
     if (r == c->rank) continue;
     const size_t off = ((size_t)r * n_local + a) * row_bytes;
     RTC_HIP(ctx, hipMemcpyAsync((char*)d_global + off, (const char*)g.ptr[r] + off, bytes, hipMemcpyDefault, stream));
   }
   RTC_HIP(ctx, hipStreamSynchronize(stream));
-  g.barrier();
+  RTC_LOCAL_BARRIER(c, "gather");
   return RTC_OK;
 }
 
@@ -300,6 +351,7 @@ void rtc_comm_destroy(rtc_comm* c) {
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->ev_watch) (void)hipEventDestroy(c->ev_watch);
   if (c->nccl && rccl()) (void)rccl()->CommDestroy(c->nccl);
   delete c;
 }
@@ -316,6 +368,7 @@ int rtc_comm_all_reduce(rtc_comm* c, void* d_buf, size_t count, int dtype, int o
 
 int rtc_comm_all_reduce_host(rtc_comm* c, int64_t* h_vals, size_t count, int op) {
   if (!c || !h_vals || count == 0 || count > 64 || op < 0 || op > 1) return RTC_ERR_ARG;
+  RTC_COMM_ALIVE(c);
   if (c->size == 1 && !c->nccl) return RTC_OK;
   rtc_ctx* ctx = c->ctx;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
@@ -347,32 +400,34 @@ int rtc_comm_gather_rows(rtc_comm* c, void* d_global, size_t row_bytes, uint32_t
 int rtc_comm_broadcast(rtc_comm* c, void* d_buf, size_t bytes, int root) {
   if (!c || (bytes && !d_buf) || root < 0 || root >= c->size) return RTC_ERR_ARG;
   rtc_ctx* ctx = c->ctx;
+  RTC_COMM_ALIVE(c);
   if ((c->size == 1 && !c->nccl) || bytes == 0) return RTC_OK;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
   if (c->nccl) {
     RTC_NEED_RCCL(ctx);
     RTC_NCCL(ctx, nc__->Broadcast(d_buf, d_buf, bytes, ncclInt8, root, c->nccl, ctx->stream));
-    return RTC_OK;
+    return comm_watch(c, ctx->stream, "broadcast");
   }
   LocalGroup& g = *c->local;
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   g.ptr[c->rank] = d_buf;
-  g.barrier();
+  RTC_LOCAL_BARRIER(c, "broadcast");
   if (c->rank != root) RTC_HIP(ctx, hipMemcpyAsync(d_buf, g.ptr[root], bytes, hipMemcpyDefault, ctx->stream));
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  g.barrier();
+  RTC_LOCAL_BARRIER(c, "broadcast");
   return RTC_OK;
 }
 
 int rtc_comm_wait(rtc_comm* c) {
   if (!c) return RTC_ERR_ARG;
+  RTC_COMM_ALIVE(c);
   if (!c->side_busy) return RTC_OK;
   rtc_ctx* ctx = c->ctx;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
   RTC_HIP(ctx, hipEventRecord(c->ev_done, c->side));
   RTC_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done, 0));
   c->side_busy = false;
-  return RTC_OK;
+  return comm_watch(c, c->side, "gather (side stream)");  // the host waits here for the gathers, with the deadline
 }
 
 // Contiguous row ranges of the strict lower triangle with equal cost; row i costs (i + fixed_cols)

@@ -326,3 +326,44 @@ def test_resident_rows_over_budget_fall_back_to_host_vectors(oracle, tmp_path, m
         files = sorted(f for f in os.listdir(folder) if "info" not in f)
         outs[tag] = (open(out).read(), {f: open(os.path.join(folder, f), "rb").read() for f in files})
     assert outs["resident"] == outs["budget"]
+
+
+def test_collective_watchdog_fails_fast_when_a_rank_skips_a_round(oracle):
+    """A rank that never arrives (it took another branch, failed before the call) must not leave the others inside the
+    collective: with RTC_COMM_TIMEOUT_S=1 the waiting rank returns RTC_ERR_COMM after about a second, and the
+    communicator group stays broken -- the late rank's own next collective fails at once instead of hanging."""
+    import time
+    import torch
+    from rabbittclust_amd import _lib, api
+    ctxs = [api.Context(0) for _ in range(2)]
+    comms = api.Comm.init_all(ctxs)
+    os.environ["RTC_COMM_TIMEOUT_S"] = "1"
+    try:
+        def rank0():
+            t = torch.arange(8, dtype=torch.int64, device=ctxs[0].device)
+            comms[0].all_reduce(t, "min")          # round 1: both ranks
+            t0 = time.time()
+            try:
+                comms[0].all_reduce(t, "min")      # round 2: rank 1 never comes
+            except _lib.RtcError as e:
+                return e.status, time.time() - t0
+            return 0, time.time() - t0
+
+        def rank1():
+            t = torch.arange(8, dtype=torch.int64, device=ctxs[1].device) + 5
+            comms[1].all_reduce(t, "min")          # round 1
+            time.sleep(2.5)                        # "skips" round 2, comes back later for another collective
+            t0 = time.time()
+            try:
+                comms[1].all_reduce_host([1, 2], "max")
+            except _lib.RtcError as e:
+                return e.status, time.time() - t0
+            return 0, time.time() - t0
+        (s0, dt0), (s1, dt1) = _threads([rank0, rank1])
+        assert s0 == _lib.RTC_ERR_COMM and 0.8 < dt0 < 2.4, (s0, dt0)
+        assert s1 == _lib.RTC_ERR_COMM and dt1 < 0.5, (s1, dt1)
+        assert "RTC_COMM_TIMEOUT_S" in ctxs[0].lib.rtc_last_error(ctxs[0].h).decode()
+    finally:
+        os.environ.pop("RTC_COMM_TIMEOUT_S", None)
+        for c in comms:
+            c.close()
