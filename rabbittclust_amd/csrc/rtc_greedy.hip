@@ -198,6 +198,8 @@ extern "C" int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const u
   // sharing a hash, once; the replay keeps the candidates that are representatives when their query comes up --
   // what the reference's representative-only index returns (src/greedy.cpp:1150-1196) ----
   bool global_done = false;
+  uint64_t global_pair_budget = (uint64_t)1 << 27;
+  if (const char* e = getenv("RTC_GREEDY_GLOBAL_PAIRS")) global_pair_budget = strtoull(e, nullptr, 10);  // tests of the fall-through
   if (n > B) {
     int handled = 0;
     uint64_t m = 0;
@@ -210,9 +212,22 @@ extern "C" int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const u
       G_HIP(hipMemcpyAsync(&cnt, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
       G_HIP(hipStreamSynchronize(ctx->stream));
       if (cnt <= ecap) { m = cnt; break; }
+      // The whole set's candidate pairs at once: 12 B each here, ~20 B each on the host while they are bucketed.  The
+      // join's cost rule weighs time, not this memory: beyond the budget (2^27 pairs = 1.6 GB + 2.7 GB by default), or
+      // when the larger list cannot be allocated, the block loop below takes over -- it never holds more than one block
+      // of queries' candidates.
+      const uint64_t old_cap = ecap;
+      if (cnt > global_pair_budget) { handled = 0; break; }
       (void)hipFree(d_edges); d_edges = nullptr;
       ecap = cnt + cnt / 4;
-      G_HIP(hipMalloc(&d_edges, ecap * sizeof(rtc_cedge)));
+      if (hipMalloc(&d_edges, ecap * sizeof(rtc_cedge)) != hipSuccess) {
+        (void)hipGetLastError();
+        d_edges = nullptr;
+        ecap = old_cap;
+        G_HIP(hipMalloc(&d_edges, ecap * sizeof(rtc_cedge)));
+        handled = 0;
+        break;
+      }
     }
     if (handled) {
       h_edges.resize(m);

@@ -31,11 +31,44 @@ __global__ __launch_bounds__(256) void unpack_bases_kernel(const uint4* __restri
   }
 }
 
-// one workgroup per run: 'N' over [start, start + len)
-__global__ __launch_bounds__(256) void patch_runs_kernel(const uint64_t* __restrict__ runs, uint8_t* __restrict__ out, uint64_t limit) {
-  const uint64_t st = runs[2 * (uint64_t)blockIdx.x], ln = runs[2 * (uint64_t)blockIdx.x + 1];
-  const uint64_t en = st + ln < limit ? st + ln : limit;
-  for (uint64_t p = st + threadIdx.x; p < en; p += blockDim.x) out[p] = (uint8_t)'N';
+// 'N' over every run [start, start + len).  Runs come in two kinds: millions of short ones (every record separator of
+// a contig-rich assembly or a FASTQ file is a run of one byte) and a few very long ones (a dropped genome's whole slot,
+// the gap behind a genome whose slot was sized from a wrong gzip ISIZE).  One LANE per run writes the short ones and
+// lists the long ones; the workgroups of a second launch then share the listed runs in 64 KiB pieces, 16-byte stores
+// for the aligned interior.  (One workgroup per run, whatever its length, used to serialise both kinds.)
+constexpr uint64_t SHORT_RUN = 64;
+constexpr uint32_t LONG_CAP = 65536;  // listed long runs; beyond that a lane writes its run itself
+
+__global__ __launch_bounds__(256) void patch_short_runs_kernel(const uint64_t* __restrict__ runs, uint64_t n_runs, uint8_t* __restrict__ out,
+                                                               uint64_t limit, uint32_t* __restrict__ n_long, uint64_t* __restrict__ long_runs) {
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_runs; r += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t st = runs[2 * r], ln = runs[2 * r + 1];
+    const uint64_t en = st + ln < limit ? st + ln : limit;
+    if (ln > SHORT_RUN) {
+      const uint32_t at = atomicAdd(n_long, 1u);
+      if (at < LONG_CAP) { long_runs[2 * (uint64_t)at] = st; long_runs[2 * (uint64_t)at + 1] = en; continue; }
+    }
+    for (uint64_t p = st; p < en; p++) out[p] = (uint8_t)'N';
+  }
+}
+
+__global__ __launch_bounds__(256) void patch_long_runs_kernel(const uint32_t* __restrict__ n_long, const uint64_t* __restrict__ long_runs,
+                                                              uint8_t* __restrict__ out) {
+  const uint4 n16 = make_uint4(0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu);
+  const uint32_t nl = min(*n_long, LONG_CAP);
+  uint64_t piece = 0;  // every workgroup walks the (short) list and takes its 64 KiB pieces in turn
+  for (uint32_t r = 0; r < nl; r++) {
+    const uint64_t st = long_runs[2 * (uint64_t)r], en = long_runs[2 * (uint64_t)r + 1];
+    for (uint64_t a = st; a < en; a += 65536, piece++) {
+      if (piece % gridDim.x != blockIdx.x) continue;
+      const uint64_t b = a + 65536 < en ? a + 65536 : en;
+      const uint64_t a16 = (a + 15) & ~(uint64_t)15, b16 = b & ~(uint64_t)15;
+      if (a16 >= b16) { for (uint64_t p = a + threadIdx.x; p < b; p += blockDim.x) out[p] = (uint8_t)'N'; continue; }
+      if (a + threadIdx.x < a16) out[a + threadIdx.x] = (uint8_t)'N';
+      for (uint64_t p = a16 + 16 * (uint64_t)threadIdx.x; p < b16; p += 16 * (uint64_t)blockDim.x) *reinterpret_cast<uint4*>(out + p) = n16;
+      if (b16 + threadIdx.x < b) out[b16 + threadIdx.x] = (uint8_t)'N';
+    }
+  }
 }
 
 }  // namespace
@@ -45,7 +78,6 @@ extern "C" int rtc_unpack_bases_dev(rtc_ctx* ctx, const uint8_t* d_packed, uint6
   if (!ctx || (n_bases && (!d_packed || !d_seq)) || (n_runs && !d_runs)) return RTC_ERR_ARG;
   if (((uintptr_t)d_packed & 15) || ((uintptr_t)d_seq & 15)) return rtc_fail(ctx, RTC_ERR_ARG, "buffers must be 16-byte aligned");
   if (n_bases & 63) return rtc_fail(ctx, RTC_ERR_ARG, "n_bases must be a multiple of 64 (pad the batch)");
-  if (n_runs > 0x7fffffffull) return rtc_fail(ctx, RTC_ERR_ARG, "too many runs");
   if (!n_bases) return RTC_OK;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
   const uint64_t n16 = n_bases / 64;
@@ -53,7 +85,16 @@ extern "C" int rtc_unpack_bases_dev(rtc_ctx* ctx, const uint8_t* d_packed, uint6
   hipLaunchKernelGGL(unpack_bases_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)d_packed, n16, (uint4*)d_seq);
   RTC_CHECK_LAUNCH(ctx);
   if (n_runs) {
-    hipLaunchKernelGGL(patch_runs_kernel, dim3((uint32_t)n_runs), dim3(256), 0, ctx->stream, d_runs, d_seq, n_bases);
+    void* ws = nullptr;
+    RTC_TRY(rtc_ws(ctx, 3, 64 + (size_t)LONG_CAP * 16, &ws));
+    uint32_t* d_nlong = (uint32_t*)ws;
+    uint64_t* d_long = (uint64_t*)((char*)ws + 64);
+    RTC_HIP(ctx, hipMemsetAsync(d_nlong, 0, 4, ctx->stream));
+    const uint32_t gs = (uint32_t)std::min<uint64_t>((n_runs + 255) / 256, (uint64_t)ctx->num_cu * 8);
+    hipLaunchKernelGGL(patch_short_runs_kernel, dim3(gs), dim3(256), 0, ctx->stream, d_runs, n_runs, d_seq, n_bases, d_nlong, d_long);
+    RTC_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(patch_long_runs_kernel, dim3((uint32_t)ctx->num_cu), dim3(256), 0, ctx->stream, (const uint32_t*)d_nlong,
+                       (const uint64_t*)d_long, d_seq);
     RTC_CHECK_LAUNCH(ctx);
   }
   return RTC_OK;

@@ -33,6 +33,7 @@
 #include <fstream>
 #include <iostream>
 #include <numeric>
+#include <mutex>
 #include <thread>
 
 #include "rtc_host.h"
@@ -69,11 +70,20 @@ struct Metrics {
 };
 static Metrics g_metrics;
 
+// The warm-up helper thread (rtc_warmup beside the sketch phase) is joined before the process leaves through exit():
+// static destructors and the HIP runtime's teardown must not run while it is still inside a HIP call.
+static std::thread g_warmup_thread;
+static std::mutex g_warmup_mutex;
+static void join_warmup() {
+  std::lock_guard<std::mutex> lk(g_warmup_mutex);
+  if (g_warmup_thread.joinable() && g_warmup_thread.get_id() != std::this_thread::get_id()) g_warmup_thread.join();
+}
 #define CHECK(ctx, call)                                                                         \
   do {                                                                                           \
     int st__ = (call);                                                                           \
     if (st__ != RTC_OK) {                                                                        \
       fprintf(stderr, "ERROR: %s failed (%d): %s\n", #call, st__, rtc_last_error(ctx));          \
+      join_warmup();                                                                             \
       exit(1);                                                                                   \
     }                                                                                            \
   } while (0)
@@ -1587,14 +1597,16 @@ int main(int argc, char** argv) {
     const int ndev = rtc_device_count();
     bool gpus_by_default = false, single_gpu_flow = false;
     vector<int> devs;
-    // Only the row-sharded MST step (and the sketching in front of it) spreads over GPUs.  Greedy clustering has a serial
-    // dependency on the representative set, --append / --db / --dense evaluate their pairs on one GPU: those flows take
-    // the first GPU of the choice and never open a communicator.
+    // Sketching from genome files spreads over every GPU of the choice in every flow (lanes on all of them, the rows
+    // shared afterwards); of the clustering steps only the row-sharded MST does.  Greedy clustering has a serial
+    // dependency on the representative set, --dense / --inverted-index=false evaluate their pairs on one GPU: those
+    // cluster on the first GPU.  Flows that sketch little or nothing here (--presketched, --append, --db) take the first
+    // GPU of the choice alone and never open a communicator.
     single_gpu_flow =
 #ifdef GREEDY_CLUST
-        true;
+        o.has_append || !o.repdb_path.empty() || o.has_presketched;
 #else
-        o.has_append || o.dense || !o.useIndex;
+        o.has_append || ((o.dense || !o.useIndex) && o.has_presketched);
 #endif
     if (spec == "all") { gpus_by_default = true; for (int d = 0; d < ndev; d++) devs.push_back(d); }
     else if (spec.find(',') == string::npos && atoi(spec.c_str()) > 0 && spec.find_first_not_of("0123456789") == string::npos) {
@@ -1641,11 +1653,11 @@ int main(int argc, char** argv) {
   if (getenv("RTC_VERBOSE")) fprintf(stderr, "[ctx]   HIP runtime + %zu GPU context(s) in %.3fs\n", gpus.size(), get_sec() - t_main);
   // The device code of the pair / MST / greedy phases is mapped at its first launch (~27 ms): a helper thread does
   // that with a toy clustering while this one reads and sketches (rtc_warmup; RTC_NO_WARMUP=1 leaves it out).
-  struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } warm;
+  struct Joiner { ~Joiner() { join_warmup(); } } warm;
   if (!getenv("RTC_NO_WARMUP")) {
     std::vector<int> wdev;
     for (const Gpu& g : gpus) wdev.push_back(g.device);
-    warm.t = std::thread([wdev]() { for (int d : wdev) (void)rtc_warmup(d); });
+    g_warmup_thread = std::thread([wdev]() { for (int d : wdev) (void)rtc_warmup(d); });
   }
   Resident rs;
 #ifndef GREEDY_CLUST
@@ -1889,6 +1901,7 @@ int main(int argc, char** argv) {
   g_metrics.num("from_sketches", from_sketches ? 1 : 0);
   g_metrics.num("total_s", t_end - t_main);
   g_metrics.write();
+  join_warmup();
   for (Gpu& g : gpus) { if (g.comm) rtc_comm_destroy(g.comm); }
   for (Gpu& g : gpus) rtc_ctx_destroy(g.ctx);
   if (getenv("RTC_VERBOSE")) fprintf(stderr, "[exit]  output written at t+%.3fs, contexts released in %.3fs\n", t_end - t_main, get_sec() - t_end);

@@ -13,7 +13,12 @@
 #include <sys/stat.h>
 #include <time.h>
 #include <zlib.h>
-#include <immintrin.h>
+#if defined(__x86_64__)
+#include <immintrin.h>  // the AVX2 / AVX-512 tiers of the FASTA intake; other hosts build the portable tier only
+#define RTC_HOST_X86 1
+#else
+#define RTC_HOST_X86 0
+#endif
 
 #include <algorithm>
 #include <type_traits>
@@ -147,9 +152,13 @@ class GzStream {
     bool ok = have == csize;
     void* d = ok ? lib.alloc() : nullptr;
     ok = ok && d;
-    uint32_t isize;  // the last member's length mod 2^32: the first guess of the output size
+    // One inflated file per parser thread: bounded at 1 GiB and at 64 x the compressed size (sequence text deflates
+    // 3-4 x; a file that wants more -- crafted, or mostly one letter -- goes through zlib's streaming gzread, which
+    // needs 1 MiB).  The trailing ISIZE (the last member's length mod 2^32) is only a first guess inside that bound.
+    const size_t cap_max = std::min<size_t>((size_t)1 << 30, csize * 64 + 65536);
+    uint32_t isize;
     memcpy(&isize, comp + csize - 4, 4);
-    size_t cap = std::max<size_t>((size_t)isize + 64, csize * 3), out = 0, in = 0;
+    size_t cap = std::min(cap_max, std::max<size_t>((size_t)isize + 64, csize * 3)), out = 0, in = 0;
     char* mem = ok ? (char*)malloc(cap) : nullptr;
     ok = ok && mem;
     while (ok && in < csize) {
@@ -157,10 +166,11 @@ class GzStream {
       size_t used = 0, made = 0;
       const int rc = lib.gunzip_ex(d, comp + in, csize - in, mem + out, cap - out, &used, &made);
       if (rc == 3) {  // LIBDEFLATE_INSUFFICIENT_SPACE
-        if (cap > ((size_t)8 << 30)) { ok = false; break; }
-        char* bigger = (char*)realloc(mem, cap * 2);
+        if (cap >= cap_max) { ok = false; break; }
+        const size_t grown = std::min(cap_max, cap * 2);
+        char* bigger = (char*)realloc(mem, grown);
         if (!bigger) { ok = false; break; }
-        mem = bigger; cap *= 2;
+        mem = bigger; cap = grown;
         continue;
       }
       if (rc != 0 || used == 0) { ok = false; break; }
@@ -267,6 +277,7 @@ struct PackedSink {
     }
   }
   void push_back(char c) { append(&c, 1); }
+#if RTC_HOST_X86
   // GzStream::body_lines: p is at a line start of a sequence body with `avail` valid bytes (and GzStream::SLACK readable
   // ones behind them).  Takes 32-byte blocks for as long as they hold nothing but sequence characters and '\n' -- no
   // '>', '@', '+' (a record start when first on a line) and no '\r' -- dropping the '\n's on the way: a block without one is
@@ -329,6 +340,7 @@ struct PackedSink {
     *midline = mid;
     return (size_t)(p - p0);
   }
+#endif
   size_t take_lines(const char* p, size_t avail, bool* midline);
   void truncate(size_t p) {  // drop everything from base p on (pop_back of a '\r', a record cut short)
     pos = p;
@@ -345,6 +357,7 @@ struct PackedSink {
   void finish() { flush(true); }
 };
 
+#if RTC_HOST_X86
 // 32 bases at a time: codes by two shifts and a mask, validity by re-encoding the codes (pshufb) and comparing with
 // the upper-cased input, packing by two multiply-adds (c0 + 4 c1, then + 16 * (c2 + 4 c3)) and a byte gather
 __attribute__((target("avx2"))) static size_t pack_run_avx2(const unsigned char* p, size_t n, uint8_t* out) {
@@ -382,6 +395,8 @@ __attribute__((target("avx512f,avx512bw"))) static size_t pack_run_avx512(const 
   return i;
 }
 
+#endif
+
 // portable form of the same, 8 bases at a time in a 64-bit word
 static size_t pack_run_swar(const unsigned char* p, size_t n, uint8_t* out) {
   size_t i = 0;
@@ -404,16 +419,21 @@ static size_t pack_run_swar(const unsigned char* p, size_t n, uint8_t* out) {
 // 1 = portable only, 2 = at most AVX2 (tests run every tier)
 static int g_pack_portable = 0;
 static int simd_tier() {  // 3: AVX-512, 2: AVX2, 1: portable
+#if !RTC_HOST_X86
+  return 1;
+#else
   static const bool a512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi2");
   static const bool a2 = __builtin_cpu_supports("avx2");
   if (g_pack_portable == 1) return 1;
   if (a512 && g_pack_portable != 2) return 3;
   return a2 ? 2 : 1;
+#endif
 }
 size_t PackedSink::take_lines(const char* p, size_t avail, bool* midline) {
   *midline = false;
   const int tier = simd_tier();
   size_t k = 0;
+#if RTC_HOST_X86
   if (tier == 3) k = take_lines_avx512(p, avail, midline);
   if (tier >= 2 && avail - k >= 32) {
     // (what the 64-byte blocks left: a block with a special character in it, or fewer than 64 bytes) -- the 32-byte blocks get
@@ -423,6 +443,9 @@ size_t PackedSink::take_lines(const char* p, size_t avail, bool* midline) {
     if (k2) *midline = mid2;
     k += k2;
   }
+#else
+  (void)tier; (void)p; (void)avail;
+#endif
   return k;
 }
 
@@ -432,9 +455,12 @@ void PackedSink::emit(const unsigned char* p, size_t n) {
   while (i < n) {
     if ((done & 3) == 0 && done + (n - i) <= cap && n - i >= 8) {  // byte-aligned, room for all: whole groups at once
       size_t k = 0;
+#if RTC_HOST_X86
       if (tier == 3) k = pack_run_avx512(p + i, n - i, base + (done >> 2));   // 64 at a time, then the rest of the run below
       if (tier >= 2) k += pack_run_avx2(p + i + k, n - i - k, base + ((done + k) >> 2));
-      else k = pack_run_swar(p + i, n - i, base + (done >> 2));
+      else
+#endif
+        k = pack_run_swar(p + i, n - i, base + (done >> 2));
       done += k; i += k;
       if (i >= n) break;
     }
@@ -1118,53 +1144,58 @@ std::vector<rtc_edge> by_distance(const std::vector<rtc_edge>& mst) {
 }
 }  // namespace
 
-std::string get_newick_tree(const std::vector<GenomeInfo>& g, const std::vector<rtc_edge>& mst, bool sketchByFile) {  // src/MST.cpp:1090-1150
-  const int N = (int)g.size();
-  auto name = [&](int v) { return sketchByFile ? g[v].fileName : g[v].seq0.name; };
-  if (N == 0) return ";";
-  if (N == 1) return name(0) + ";";
-  const std::vector<rtc_edge> edges = by_distance(mst);
-  const int maxNodes = 2 * N - 1;
-  std::vector<std::vector<std::pair<int, double>>> children(maxNodes);
-  std::vector<double> height(maxNodes, 0.0);
-  std::vector<int> repNode(maxNodes, -1);
-  for (int i = 0; i < N; i++) repNode[i] = i;
-  DSU dsu(N);
-  int nextNode = N;
-  for (const rtc_edge& e : edges) {
-    const int ru = dsu.find(e.preNode), rv = dsu.find(e.sufNode);
-    if (ru == rv) continue;
-    const int nodeU = repNode[ru], nodeV = repNode[rv];
-    const double h = e.dist;
-    const int newNode = nextNode++;
-    children[newNode].push_back({nodeU, std::max(0.0, h - height[nodeU])});
-    children[newNode].push_back({nodeV, std::max(0.0, h - height[nodeV])});
-    height[newNode] = h;
-    repNode[dsu.unite(ru, rv)] = newNode;
+// Newick text of the single-linkage dendrogram the MST defines (what src/MST.cpp:1044-1150 prints): edges in ascending
+// weight (std::sort with the reference's comparator, so ties fall as they do there) merge the sets of their two ends; a
+// merge is an inner node at height = the edge's weight whose first branch leads to the top node of preNode's set and
+// whose second to sufNode's, branch length = height difference (never negative); the text starts at the top node of
+// genome 0's set.  Merges live in one flat array (node id = leaves + merge number), the sets in a plain parent array
+// with the set's current top node kept at its representative, and the text is written by an explicit stack (a
+// caterpillar of 100 000 leaves would overflow a recursive writer).
+std::string get_newick_tree(const std::vector<GenomeInfo>& g, const std::vector<rtc_edge>& mst, bool sketchByFile) {
+  const int leaves = (int)g.size();
+  auto label = [&](int v) -> const std::string& { return sketchByFile ? g[v].fileName : g[v].seq0.name; };
+  if (leaves == 0) return ";";
+  if (leaves == 1) return label(0) + ";";
+  struct Merge { int kid[2]; double len[2]; double at; };
+  std::vector<Merge> merges;
+  merges.reserve(leaves - 1);
+  std::vector<int> set_of(leaves), top(leaves);
+  for (int v = 0; v < leaves; v++) set_of[v] = top[v] = v;
+  auto rep = [&](int v) { while (set_of[v] != v) { set_of[v] = set_of[set_of[v]]; v = set_of[v]; } return v; };
+  auto level = [&](int node) { return node < leaves ? 0.0 : merges[node - leaves].at; };
+  for (const rtc_edge& e : by_distance(mst)) {
+    const int a = rep(e.preNode), b = rep(e.sufNode);
+    if (a == b) continue;
+    Merge m;
+    m.kid[0] = top[a]; m.kid[1] = top[b];
+    m.at = e.dist;
+    for (int side = 0; side < 2; side++) m.len[side] = std::max(0.0, m.at - level(m.kid[side]));
+    merges.push_back(m);
+    set_of[b] = a;
+    top[a] = leaves + (int)merges.size() - 1;
   }
-  const int root = repNode[dsu.find(0)];
-  // build_newick_tree_recursive (:1044-1066) without the recursion (a 100 000-leaf caterpillar would overflow the stack)
-  std::string s;
-  struct Frame { int node; size_t next; };
-  std::vector<Frame> st{{root, 0}};
-  while (!st.empty()) {
-    Frame& f = st.back();
-    const auto& ch = children[f.node];
-    if (ch.empty()) { s += name(f.node); st.pop_back(); }
-    else if (f.next == ch.size()) { s += ")"; st.pop_back(); }
-    else {
-      if (f.next == 0) s += "("; else s += ",";
-      const int child = ch[f.next].first;
-      f.next++;
-      st.push_back({child, 0});
+  std::string text;
+  struct Visit { int node; int done; };  // done: how many of an inner node's two branches are written
+  std::vector<Visit> path{{top[rep(0)], 0}};
+  while (!path.empty()) {
+    Visit& v = path.back();
+    if (v.node < leaves) {
+      text += label(v.node);
+    } else if (v.done < 2) {
+      text += v.done == 0 ? "(" : ",";
+      const int kid = merges[v.node - leaves].kid[v.done++];
+      path.push_back({kid, 0});
       continue;
+    } else {
+      text += ")";
     }
-    if (!st.empty()) {  // the finished subtree was child number next-1 of the new top: its branch length follows
-      const Frame& up = st.back();
-      s += ":" + std::to_string(children[up.node][up.next - 1].second);
+    path.pop_back();
+    if (!path.empty()) {  // the subtree just closed hangs on branch done-1 of the node now on top
+      const Visit& up = path.back();
+      text += ":" + std::to_string(merges[up.node - leaves].len[up.done - 1]);
     }
   }
-  return s + ";";
+  return text + ";";
 }
 
 static FILE* open_out(const std::string& output, const char* who) {

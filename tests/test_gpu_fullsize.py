@@ -238,21 +238,20 @@ def _check_forest(mst, n):
 
 
 def test_config3_100k_sketches_8_ranks_full_pair_space(ctx, oracle):
-    """BASELINE config 3's pair space at its real size: 100 000 MinHash sketches (k=21, s=1000; the genomes are 1 Mbp
-    instead of 5 Mbp -- the sketch kernel's genome length is covered by the 10 000 x 5 Mbp tests above, the pair space
-    only sees the sketches), sketched in 10 000-genome chunks.  All 8 triangle row ranges go through rtc_mst_sharded
+    """BASELINE config 3 at its real size: 100 000 x 5 Mbp genomes (500 Gbp, synthesised and sketched in ten 50 GB chunks
+    of 10 000 genomes; k=21, s=1000) and the 5*10^9-pair space over their sketches.  All 8 triangle row ranges go through rtc_mst_sharded
     itself (8 in-process ranks, fixed-size mode: ONE reduction per Boruvka round) and every rank must return the
     forest of the single rtc_mst launch over the 5*10^9 pairs, bit for bit; rank 7's candidate list is checked against
     the independent merge kernel and the oracle on sampled rows; a 3 000-sketch prefix against the oracle's MST."""
     from rabbittclust_amd import api, pipeline
     free, _ = torch.cuda.mem_get_info()
-    if free < 60e9:
-        pytest.skip("needs ~30 GB of HBM")
-    n, L, chunk, s, world = 100000, 1_000_000, 10000, 1000, 8
+    if free < 80e9:
+        pytest.skip("needs ~60 GB of HBM")
+    n, L, chunk, s, world = 100000, 5_000_000, 10000, 1000, 8
     out = torch.empty((n, s), dtype=torch.int64, device=ctx.device)
     cnt = torch.zeros(n, dtype=torch.int32, device=ctx.device)
     off = np.arange(chunk + 1, dtype=np.uint64) * np.uint64(L)
-    for c0 in range(0, n, chunk):  # one 10 GB staging buffer
+    for c0 in range(0, n, chunk):  # one 50 GB staging buffer
         desc = api.synth_family_descs(chunk // 10, 10, global_seed=500 + c0)
         seq = ctx.synth_genomes(desc, off)
         ctx.sketch_minhash_into(seq, off, out[c0:c0 + chunk], cnt[c0:c0 + chunk], k=21, size=s)

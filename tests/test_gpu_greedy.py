@@ -105,4 +105,9 @@ def test_greedy_global_join_equals_the_batch_loop_and_the_oracle(ctx, oracle, mo
         got_n, got = run()
         assert got_n == want_n, join
         assert np.array_equal(got, want), join
+    # the global join's pair list over its memory budget: the run falls through to the block loop, same decisions
+    monkeypatch.setenv("RTC_PAIR_JOIN", "2")
+    monkeypatch.setenv("RTC_GREEDY_GLOBAL_PAIRS", "1000")
+    got_n, got = run()
+    assert got_n == want_n and np.array_equal(got, want)
     assert 1 < want_n < len(sk)

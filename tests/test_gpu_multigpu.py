@@ -293,17 +293,26 @@ def test_clust_mst_without_rccl_falls_back_to_one_gpu(oracle, tmp_path):
     assert r.returncode == 1 and "rtc_comm_init_all failed" in r.stderr and "no-such-librccl.so" in r.stderr
 
 
-def test_clust_greedy_opens_one_context_only(oracle, tmp_path):
-    """clust-greedy clusters on one GPU by design: --gpus 0,0 must not create a second context or a communicator"""
+def test_clust_greedy_sketches_on_every_gpu_and_clusters_on_one(oracle, tmp_path):
+    """clust-greedy from genome files: the sketch phase uses every GPU of the choice (--gpus 0,0: two lanes' contexts and
+    the share step), the clustering runs on the first; from a sketch folder there is nothing to spread: one context, no
+    communicator.  Same clusters every way."""
     from test_gpu_cli import _write_family_fastas
     tmp = str(tmp_path)
     lst, paths, seqs = _write_family_fastas(oracle, tmp, 3, 3, 1_200_000, seed=33)
-    a, b = os.path.join(tmp, "a.out"), os.path.join(tmp, "b.out")
-    base = [os.path.join(BIN, "clust-greedy"), "-l", "-i", lst, "-k", "21", "-s", "400", "-d", "0.05", "-t", "4", "-e"]
-    _cli(base + ["--gpus", "1", "-o", a], tmp)
+    a, b, c = os.path.join(tmp, "a.out"), os.path.join(tmp, "b.out"), os.path.join(tmp, "c.out")
+    base = [os.path.join(BIN, "clust-greedy"), "-l", "-i", lst, "-k", "21", "-s", "400", "-d", "0.05", "-t", "4"]
+    _cli(base + ["-e", "--gpus", "1", "-o", a], tmp)
     err = _cli(base + ["--gpus", "0,0", "-o", b], tmp, {"RTC_VERBOSE": "1"})
-    assert "this flow runs on one GPU" in err and "exchange)" not in err and "1 GPU context(s)" in err
+    assert "use 2 GPUs" in err and "2 GPU context(s)" in err and "[share]" in err
     assert open(a).read() == open(b).read()
+    folder = [d for d in os.listdir(tmp) if os.path.isdir(os.path.join(tmp, d)) and os.path.exists(os.path.join(tmp, d, "hash.sketch"))]
+    assert len(folder) == 1
+    err = _cli([os.path.join(BIN, "clust-greedy"), "--presketched", os.path.join(tmp, folder[0]), "-d", "0.05", "-t", "4", "--gpus", "0,0", "-o", c],
+               tmp, {"RTC_VERBOSE": "1"})
+    assert "this flow runs on one GPU" in err and "exchange)" not in err and "1 GPU context(s)" in err
+    part = lambda f: sorted(tuple(sorted(ln.split("\t")[-1] for ln in blk.strip().split("\n")[1:])) for blk in open(f).read().split("the cluster")[1:])
+    assert part(a) == part(c)
 
 
 @pytest.mark.parametrize("mode", ["minhash-c", "kssd"])
