@@ -391,12 +391,12 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
 
   // ---- cost rule, first half: the sort alone against the tiled kernel's probes ----
   // tiled: every column of a 1024-column block probes the table of every 64-row block below the diagonal with all
-  // of its hashes, ~3.2e11 probes/s; join: ~1.1e10 (u64) / 2.8e10 (u32) sorted keys/s, ~1.5e10 co-occurrences/s
+  // of its hashes, ~4.0e11 probes/s (round 4's kernel, planning included); join: ~1.1e10 (u64) / 2.8e10 (u32) sorted keys/s, ~1.5e10 co-occurrences/s
   // (radix sort on 2*bits bits + encode + emit), measured on MI355X (tools/ubench/sort_rates.hip).
   const double avg = (double)K_all / ng;
   const double rows = (double)(row1 - row0);
   const double cols_mean = std::max(1.0, 0.5 * ((double)std::min(col1, row0) + (double)std::min(col1, row1 - 1)) - (double)col0);
-  const double t_tiled = tiled_scale * (rows / 64.0 + 1.0) * cols_mean * avg / 3.2e11;
+  const double t_tiled = tiled_scale * (rows / 64.0 + 1.0) * cols_mean * avg / 4.0e11;
   const double t_sort = (double)K / (sizeof(T) == 8 ? 1.1e10 : 2.8e10);
   if (mode == 1 && t_sort > 0.7 * t_tiled) return RTC_OK;
 
