@@ -33,6 +33,7 @@
 #include <fstream>
 #include <iostream>
 #include <numeric>
+#include <functional>
 #include <mutex>
 #include <thread>
 
@@ -72,6 +73,7 @@ static Metrics g_metrics;
 
 // The warm-up helper thread (rtc_warmup beside the sketch phase) is joined before the process leaves through exit():
 // static destructors and the HIP runtime's teardown must not run while it is still inside a HIP call.
+static std::thread* g_gpu_thread = nullptr;  // main's GPU bring-up thread while it runs
 static std::thread g_warmup_thread;
 static std::mutex g_warmup_mutex;
 static void join_warmup() {
@@ -182,24 +184,15 @@ struct FileResult {           // indexed by list position, so late (retried) fil
   bool on_host = false;  // h64 / h32 hold the sketch (otherwise it lives in HBM only)
 };
 
+// gpus_ready (optional): the HIP runtime and the contexts are still coming up on another thread (main); wait() returns
+// when `gpus` is filled, *done says whether it already is.  Everything the host can do alone happens before wait() is
+// called -- the list, the slot sizes, the plan, and the PARSING: batch after batch into staging buffers of their own for
+// as long as the GPUs are not there (0.05-0.24 s of runtime start-up = 6-28 GB of FASTA at the parser's rate), which
+// the lanes then take back to back.
+struct GpusReady { std::function<void()> wait; const std::atomic<bool>* done; };
 static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const SketchJob& job, vector<GenomeInfo>& genomes,
-                         MinHashSketchFile* mh, KssdSketchFile* ks, Resident& rs, bool need_host_hashes) {
-  rtc_ctx* ctx = gpus[0].ctx;
-  const size_t G = gpus.size();
-  // Two lanes per GPU: lane 0 is the GPU's own context, lane 1 a second context on the same device with a
-  // stream of its own, each driven by its own host thread -- the PCIe copy of one batch runs beside the
-  // sketch kernel of the previous one.  Both lanes write rows of the same resident sketch buffer.
-  struct Lane { rtc_ctx* ctx; void* d_seq; std::thread worker; size_t gpu; bool owned; void* d_packed = nullptr; void* d_runs = nullptr; size_t runs_cap = 0; };
-  const size_t LPG = getenv("RTC_SINGLE_LANE") ? 1 : 2;
-  vector<Lane> lanes(G * LPG);
-  for (size_t l = 0; l < lanes.size(); l++) {
-    lanes[l].gpu = l % G; lanes[l].d_seq = nullptr; lanes[l].owned = l >= G; lanes[l].ctx = gpus[l % G].ctx;
-    if (lanes[l].owned) {
-      CHECK(ctx, rtc_ctx_create(gpus[l % G].device, &lanes[l].ctx));
-      CHECK(lanes[l].ctx, rtc_ctx_own_stream(lanes[l].ctx));
-    }
-  }
-  const size_t NL = lanes.size();
+                         MinHashSketchFile* mh, KssdSketchFile* ks, Resident& rs, bool need_host_hashes,
+                         const GpusReady* gpus_ready = nullptr) {
   const double tp00 = get_sec();
   const vector<string> fileList = read_list(inputFile);
   const size_t nfiles = fileList.size();
@@ -230,7 +223,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   const double tp0 = get_sec();
   vector<uint64_t> slot(nfiles);
   vector<FileResult> res(nfiles);
-#pragma omp parallel for num_threads(job.threads) schedule(dynamic, 16)
+#pragma omp parallel for num_threads(job.threads) schedule(static)
   for (long i = 0; i < (long)nfiles; i++) {
     slot[i] = genome_slot_bytes(fileList[i]);
     res[i].flen = job.isContainment ? file_length_for_containment(fileList[i]) : 0;
@@ -251,15 +244,100 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   vector<size_t> all(nfiles);
   iota(all.begin(), all.end(), 0);
   vector<Batch> batches = plan(all, slot);
+  uint64_t maxb = 0;
+  for (const Batch& b : batches) maxb = std::max(maxb, b.bytes);
+
+  // ---- the parser side of one batch: every file of it into its slot of `buf`, the runs of the packed format collected ----
+  vector<size_t> retry_files; vector<uint64_t> retry_need;
+  vector<size_t> row_file;  // row (= genome id) -> list position
+  double parse_s = 0;       // wall time the parser threads took, summed over the batches (the GPU lanes work beside it)
+  uint64_t parse_bytes = 0;
+  auto parse_batch = [&](const Batch& b, size_t bi, char* buf, vector<uint64_t>& bruns, int round) -> uint32_t {
+    const double t0 = get_sec();
+    vector<uint64_t> need(b.files.size(), 0);
+    vector<vector<uint64_t>> fruns(packed ? b.files.size() : 0);
+#pragma omp parallel for num_threads(job.threads) schedule(dynamic)
+    for (long q = 0; q < (long)b.files.size(); q++) {
+      FileResult& r = res[b.files[q]];
+      uint64_t used = 0, nrec = 0;
+      int st;
+      if (packed) st = read_genome_file_packed(fileList[b.files[q]], (uint8_t*)buf + b.slot_off[q] / 4, b.slot_len[q], used, fruns[q], r.first, r.total, nrec);
+      else st = read_genome_file_flat(fileList[b.files[q]], buf + b.slot_off[q], b.slot_len[q], used, r.first, r.total, nrec);
+      if (st == 1) { fprintf(stderr, "cannot open the genome file: %s\n", fileList[b.files[q]].c_str()); exit(1); }
+      if (st == 2) { need[q] = used + 1; used = 0; r.kept = false; }
+      else r.kept = r.total >= job.minLen;                                 // :963
+      if (!r.kept) used = 0;
+      // no k-mers in the gap behind the genome, nor in dropped genomes
+      if (!packed) memset(buf + b.slot_off[q] + used, 'N', b.slot_len[q] - used);
+      else {
+        vector<uint64_t>& fr = fruns[q];
+        while (!fr.empty() && fr[fr.size() - 2] >= used) { fr.pop_back(); fr.pop_back(); }
+        if (!fr.empty() && fr[fr.size() - 2] + fr[fr.size() - 1] > used) fr[fr.size() - 1] = used - fr[fr.size() - 2];
+        if (b.slot_len[q] > used) { fr.push_back(used); fr.push_back(b.slot_len[q] - used); }
+      }
+    }
+    if (!packed) memset(buf + b.bytes, 'N', 64);
+    else {
+      bruns.clear();
+      for (size_t q = 0; q < b.files.size(); q++)
+        for (size_t e = 0; e + 1 < fruns[q].size(); e += 2) { bruns.push_back(b.slot_off[q] + fruns[q][e]); bruns.push_back(fruns[q][e + 1]); }
+      bruns.push_back(b.bytes); bruns.push_back(64);
+    }
+    uint32_t nkept = 0;
+    for (size_t q = 0; q < b.files.size(); q++) {
+      if (need[q]) { retry_files.push_back(b.files[q]); retry_need.push_back(need[q]); }
+      if (res[b.files[q]].kept) { nkept++; if (round == 0) row_file.push_back(b.files[q]); }
+    }
+    parse_s += get_sec() - t0;
+    parse_bytes += b.bytes;
+    if (verbose) fprintf(stderr, "[parse] batch %zu: %zu files, %.2f GB in %.3fs\n", bi, b.files.size(), b.bytes / 1e9, get_sec() - t0);
+    return nkept;
+  };
+  // Pageable staging by default: page-locking costs ~0.15 s/GB up front while the pageable PCIe copy
+  // already runs at > 30 GB/s on the MI355X hosts measured; RTC_STAGE_PINNED=1 page-locks instead.
+  bool pinned = getenv("RTC_STAGE_PINNED") != nullptr;
+  // batches parsed while the GPUs come up (pageable staging only: page-locking needs a context), each into a buffer of
+  // its own, up to RTC_PREPARSE_BYTES of host memory (default 8 GiB)
+  struct PreBatch { char* buf; vector<uint64_t> runs; uint32_t kept; };
+  vector<PreBatch> pre;
+  if (gpus_ready && !pinned) {
+    uint64_t budget = (uint64_t)8 << 30, used = 0;
+    if (const char* e = getenv("RTC_PREPARSE_BYTES")) budget = strtoull(e, nullptr, 10);
+    while (pre.size() < batches.size() && !gpus_ready->done->load(std::memory_order_acquire)) {
+      const Batch& b = batches[pre.size()];
+      const uint64_t host_bytes = packed ? b.bytes / 4 + 64 : b.bytes + 64;
+      if (used + host_bytes > budget) break;
+      char* buf = alloc_pageable(host_bytes);
+      if (!buf) break;
+      used += host_bytes;
+      pre.push_back(PreBatch{buf, {}, 0});
+      pre.back().kept = parse_batch(b, pre.size() - 1, buf, pre.back().runs, 0);
+    }
+    if (verbose) fprintf(stderr, "[init]  %zu of %zu batches parsed before the GPUs were up\n", pre.size(), batches.size());
+  }
+  if (gpus_ready) gpus_ready->wait();
+  rtc_ctx* ctx = gpus[0].ctx;
+  const size_t G = gpus.size();
+  // Two lanes per GPU: lane 0 is the GPU's own context, lane 1 a second context on the same device with a
+  // stream of its own, each driven by its own host thread -- the PCIe copy of one batch runs beside the
+  // sketch kernel of the previous one.  Both lanes write rows of the same resident sketch buffer.
+  struct Lane { rtc_ctx* ctx; void* d_seq; std::thread worker; size_t gpu; bool owned; void* d_packed = nullptr; void* d_runs = nullptr; size_t runs_cap = 0; };
+  const size_t LPG = getenv("RTC_SINGLE_LANE") ? 1 : 2;
+  vector<Lane> lanes(G * LPG);
+  for (size_t l = 0; l < lanes.size(); l++) {
+    lanes[l].gpu = l % G; lanes[l].d_seq = nullptr; lanes[l].owned = l >= G; lanes[l].ctx = gpus[l % G].ctx;
+    if (lanes[l].owned) {
+      CHECK(ctx, rtc_ctx_create(gpus[l % G].device, &lanes[l].ctx));
+      CHECK(lanes[l].ctx, rtc_ctx_own_stream(lanes[l].ctx));
+    }
+  }
+  const size_t NL = lanes.size();
 
   // ---- staging: G+1 host buffers (one being parsed, one per GPU in flight) and one device buffer per GPU ----
   const size_t NSTAGE = NL + 1;
   uint64_t buf_bytes = 0;
   vector<char*> stage(NSTAGE, nullptr);
   vector<vector<uint64_t>> stage_runs(NSTAGE);  // packed staging: the batch's runs of characters outside ACGT, batch coordinates
-  // Pageable staging by default: page-locking costs ~0.15 s/GB up front while the pageable PCIe copy
-  // already runs at > 30 GB/s on the MI355X hosts measured; RTC_STAGE_PINNED=1 page-locks instead.
-  bool pinned = getenv("RTC_STAGE_PINNED") != nullptr;
   auto free_stage = [&]() {
     for (size_t i = 0; i < NSTAGE; i++) {
       if (stage[i] && pinned) CHECK(ctx, rtc_host_free(ctx, stage[i]));
@@ -291,8 +369,6 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       if (packed) CHECK(l.ctx, rtc_dev_alloc(l.ctx, host_bytes, &l.d_packed));
     }
   };
-  uint64_t maxb = 0;
-  for (const Batch& b : batches) maxb = std::max(maxb, b.bytes);
   ensure_buffers(maxb);
   if (verbose) fprintf(stderr, "[plan] %zu files, %zu batches, %zu GPU(s), staging %zu x %.2f GB, %.3fs\n", nfiles, batches.size(), G, NSTAGE, buf_bytes / 1e9, get_sec() - tp0);
 
@@ -345,7 +421,6 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   std::atomic<bool> resident_ok{rs.ok};
   struct Placed { uint32_t row0, rows; int gpu; };  // where a batch's sketches live (share step)
   vector<Placed> placed;
-  vector<size_t> row_file;  // row (= genome id) -> list position
 
   // ---- GPU side of one batch (runs on that GPU's host thread while the next batch is parsed) ----
   // row0 < 0: not resident (retry round), results only go to the host vectors.
@@ -436,54 +511,15 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   };
 
   // ---- pipeline: parse batch i into stage[i % (G+1)] while the GPU threads work on batches i-1 .. i-G ----
-  vector<size_t> retry_files; vector<uint64_t> retry_need;
   size_t done_files = 0, bi = 0;
   uint32_t next_row = 0;
-  double parse_s = 0;       // wall time the parser threads took, summed over the batches (the GPU lanes work beside it)
-  uint64_t parse_bytes = 0;
   for (int round = 0; round < 2; round++) {  // round 1: files whose slot guess was too small (gzip ISIZE)
     for (const Batch& b : batches) {
-      const double t0 = get_sec();
-      char* buf = stage[bi % NSTAGE];
-      vector<uint64_t>& bruns = stage_runs[bi % NSTAGE];
-      vector<uint64_t> need(b.files.size(), 0);
-      vector<vector<uint64_t>> fruns(packed ? b.files.size() : 0);
-#pragma omp parallel for num_threads(job.threads) schedule(dynamic)
-      for (long q = 0; q < (long)b.files.size(); q++) {
-        FileResult& r = res[b.files[q]];
-        uint64_t used = 0, nrec = 0;
-        int st;
-        if (packed) st = read_genome_file_packed(fileList[b.files[q]], (uint8_t*)buf + b.slot_off[q] / 4, b.slot_len[q], used, fruns[q], r.first, r.total, nrec);
-        else st = read_genome_file_flat(fileList[b.files[q]], buf + b.slot_off[q], b.slot_len[q], used, r.first, r.total, nrec);
-        if (st == 1) { fprintf(stderr, "cannot open the genome file: %s\n", fileList[b.files[q]].c_str()); exit(1); }
-        if (st == 2) { need[q] = used + 1; used = 0; r.kept = false; }
-        else r.kept = r.total >= job.minLen;                                 // :963
-        if (!r.kept) used = 0;
-        // no k-mers in the gap behind the genome, nor in dropped genomes
-        if (!packed) memset(buf + b.slot_off[q] + used, 'N', b.slot_len[q] - used);
-        else {
-          vector<uint64_t>& fr = fruns[q];
-          while (!fr.empty() && fr[fr.size() - 2] >= used) { fr.pop_back(); fr.pop_back(); }
-          if (!fr.empty() && fr[fr.size() - 2] + fr[fr.size() - 1] > used) fr[fr.size() - 1] = used - fr[fr.size() - 2];
-          if (b.slot_len[q] > used) { fr.push_back(used); fr.push_back(b.slot_len[q] - used); }
-        }
-      }
-      if (!packed) memset(buf + b.bytes, 'N', 64);
-      else {
-        bruns.clear();
-        for (size_t q = 0; q < b.files.size(); q++)
-          for (size_t e = 0; e + 1 < fruns[q].size(); e += 2) { bruns.push_back(b.slot_off[q] + fruns[q][e]); bruns.push_back(fruns[q][e + 1]); }
-        bruns.push_back(b.bytes); bruns.push_back(64);
-      }
-      uint32_t nkept = 0;
-      for (size_t q = 0; q < b.files.size(); q++) {
-        if (need[q]) { retry_files.push_back(b.files[q]); retry_need.push_back(need[q]); }
-        if (res[b.files[q]].kept) { nkept++; if (round == 0) row_file.push_back(b.files[q]); }
-      }
+      const bool preparsed = round == 0 && bi < pre.size();  // parsed while the GPUs came up, in a buffer of its own
+      char* buf = preparsed ? pre[bi].buf : stage[bi % NSTAGE];
+      vector<uint64_t>& bruns = preparsed ? pre[bi].runs : stage_runs[bi % NSTAGE];
+      const uint32_t nkept = preparsed ? pre[bi].kept : parse_batch(b, bi, buf, bruns, round);
       if (!retry_files.empty()) resident_ok.store(false);  // retried files arrive out of list order: ids are no longer row numbers
-      parse_s += get_sec() - t0;
-      parse_bytes += b.bytes;
-      if (verbose) fprintf(stderr, "[parse] batch %zu: %zu files, %.2f GB in %.3fs\n", bi, b.files.size(), b.bytes / 1e9, get_sec() - t0);
       Lane& ln = lanes[bi % NL];
       if (ln.worker.joinable()) ln.worker.join();
       if (shuffle_thread.joinable()) shuffle_thread.join();
@@ -1591,8 +1627,10 @@ int main(int argc, char** argv) {
 #endif
 
   // ---- GPUs: one context (and one host thread when it works) per device; RCCL communicators among them ----
+  // The HIP runtime, the contexts and the communicators come up on a thread of their own (0.05-0.24 s): a run from a genome
+  // list reads the list, sizes its slots and PARSES ITS FIRST BATCH meanwhile (sketch_files); every other flow waits here.
   vector<Gpu> gpus;
-  {
+  auto init_gpus = [&]() -> int {
     string spec = o.gpus.empty() ? (getenv("RTC_GPUS") ? getenv("RTC_GPUS") : "all") : o.gpus;
     const int ndev = rtc_device_count();
     bool gpus_by_default = false, single_gpu_flow = false;
@@ -1647,18 +1685,45 @@ int main(int argc, char** argv) {
         fprintf(stderr, "-----use %zu GPUs (%s exchange)\n", gpus.size(), rtc_comm_backend(comms[0]));
       }
     }
-  }
-  rtc_ctx* ctx = gpus[0].ctx;
-  g_metrics.num("hip_init_s", get_sec() - t_main);
-  if (getenv("RTC_VERBOSE")) fprintf(stderr, "[ctx]   HIP runtime + %zu GPU context(s) in %.3fs\n", gpus.size(), get_sec() - t_main);
-  // The device code of the pair / MST / greedy phases is mapped at its first launch (~27 ms): a helper thread does
-  // that with a toy clustering while this one reads and sketches (rtc_warmup; RTC_NO_WARMUP=1 leaves it out).
+    return 0;
+  };
+  int gpu_rc = 0;
+  double t_gpus = 0;
+  std::atomic<bool> gpus_done{false};
+  std::thread gpu_thread([&]() { gpu_rc = init_gpus(); t_gpus = get_sec(); gpus_done.store(true, std::memory_order_release); });
+  // whichever way this function is left before the GPUs were asked for (return, exit()): not with that thread inside HIP
+  g_gpu_thread = &gpu_thread;
+  atexit([]() { if (g_gpu_thread && g_gpu_thread->joinable()) g_gpu_thread->join(); });
+  struct GpuJoin { std::thread& t; ~GpuJoin() { if (t.joinable()) t.join(); g_gpu_thread = nullptr; } } gpu_join{gpu_thread};
+  rtc_ctx* ctx = nullptr;
   struct Joiner { ~Joiner() { join_warmup(); } } warm;
-  if (!getenv("RTC_NO_WARMUP")) {
-    std::vector<int> wdev;
-    for (const Gpu& g : gpus) wdev.push_back(g.device);
-    g_warmup_thread = std::thread([wdev]() { for (int d : wdev) (void)rtc_warmup(d); });
-  }
+  bool gpus_up = false;
+  const std::function<void()> wait_gpus = [&]() {
+    if (gpus_up) return;
+    const double t_asked = get_sec();
+    gpu_thread.join();
+    gpus_up = true;
+    if (gpu_rc != 0) { fflush(nullptr); _exit(gpu_rc); }
+    ctx = gpus[0].ctx;
+    g_metrics.num("hip_init_s", t_gpus - t_main);
+    g_metrics.num("hip_init_exposed_s", std::max(0.0, t_gpus - t_asked));  // what the main thread still had to wait for
+    if (getenv("RTC_VERBOSE")) fprintf(stderr, "[ctx]   HIP runtime + %zu GPU context(s) in %.3fs (asked for at t+%.3fs, waited %.3fs)\n", gpus.size(),
+                                       t_gpus - t_main, t_asked - t_main, std::max(0.0, t_gpus - t_asked));
+    // The device code of the pair / MST / greedy phases is mapped at its first launch (~27 ms): a helper thread does
+    // that with a toy clustering while this one reads and sketches (rtc_warmup; RTC_NO_WARMUP=1 leaves it out).
+    if (!getenv("RTC_NO_WARMUP")) {
+      std::vector<int> wdev;
+      for (const Gpu& g : gpus) wdev.push_back(g.device);
+      g_warmup_thread = std::thread([wdev]() { for (int d : wdev) (void)rtc_warmup(d); });
+    }
+  };
+  const bool list_run = !o.has_presketched && !o.has_append && o.has_input && o.sketchByFile
+#ifdef GREEDY_CLUST
+                        && o.repdb_path.empty()
+#endif
+      ;
+  const GpusReady gpus_ready{wait_gpus, &gpus_done};
+  if (!list_run) wait_gpus();
   Resident rs;
 #ifndef GREEDY_CLUST
   if (o.has_append) return append_clust_mst(o, gpus);
@@ -1713,8 +1778,9 @@ int main(int argc, char** argv) {
     job.kssd = o.is_fast; job.kmerSize = o.kmerSize; job.sketchSize = o.sketchSize; job.isContainment = o.isContainment;
     job.containCompress = o.containCompress; job.drlevel = o.drlevel; job.minLen = o.minLen; job.threads = o.threads;
     if (getenv("RTC_VERBOSE")) fprintf(stderr, "[tune]  cal_size + tune_parameters in %.3fs\n", get_sec() - t0);
-    if (o.sketchByFile) sketch_files(gpus, o.inputFile, job, genomes, &mh, &ks, rs, !o.noSave);
-    else sketch_sequences(gpus, seq_recs, job, genomes, &mh, &ks);
+    if (o.sketchByFile) sketch_files(gpus, o.inputFile, job, genomes, &mh, &ks, rs, !o.noSave, &gpus_ready);
+    else { wait_gpus(); sketch_sequences(gpus, seq_recs, job, genomes, &mh, &ks); }
+    wait_gpus();
     mh.kmerSize = o.kmerSize; mh.isContainment = o.isContainment; mh.containCompress = o.containCompress; mh.sketchSize = o.sketchSize;
     cerr << "-----the size of sketches (number of genomes or sequences) is: " << genomes.size() << endl;
     double t1 = get_sec();
