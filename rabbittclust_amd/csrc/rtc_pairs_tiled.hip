@@ -213,7 +213,9 @@ __global__ __launch_bounds__(TW, 1) void pair_tiled_kernel(const T* __restrict__
   const uint32_t cb0 = col0 + blockIdx.y * TW;
   if (lower_only && cb0 + 1 > rb0 + nrows - 1) return;  // no (row, col) with col < row in this block
   const uint32_t c = cb0 + tid;
-  const bool col_active = c < col1;
+  // (lower_only: a column at or beyond the block's last row pairs with none of its rows -- in a block on the diagonal
+  // that is half of the lanes, whole waves of them: they take no part in the probes)
+  const bool col_active = c < col1 && (!lower_only || c + 1 < rb0 + nrows);
   const uint32_t wave = tid >> 6, lane = tid & 63;
 
   unsigned long long planes[NPL];
