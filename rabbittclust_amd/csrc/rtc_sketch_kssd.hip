@@ -531,15 +531,17 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
     return inside ? *reinterpret_cast<const uint4*>(lane_seq + (int64_t)ci * CHUNK)
                   : load_bases16_edge(seq, A0 + (int64_t)ci * CHUNK + 16 * (int64_t)lane, sg.g_begin, sg.g_end);
   };
-  auto pack16 = [&](const uint4 d) -> uint32_t {  // 16 bases -> 32 bits, first base on top (BaseMap :1007-1017)
+  // 16 bases -> 32 bits, first base on top, in the FILTERS' alphabet: bits 1 and 2 of the character as they are (A 0, C 1,
+  // T 2, G 3 -- a Gray code of BaseMap's A 0, C 1, G 2, T 3, :1007-1017), which saves the xor that turns them into
+  // BaseMap's codes: one v_and and one v_dot4 per dword (the dot product of 2 x code with the weights 64, 16, 4, 1 is twice
+  // the packed byte).  The host builds the map and the Bloom filter over the same alphabet (gray24); the exact drain reads
+  // the characters again and works in the reference's encoding.
+  auto pack16 = [&](const uint4 d) -> uint32_t {
     const uint32_t w[4] = {d.x, d.y, d.z, d.w};
     uint32_t pk[4];
 #pragma unroll
-    for (int qd = 0; qd < 4; qd++) {
-      const uint32_t codes = ((w[qd] >> 1) ^ (w[qd] >> 2)) & 0x03030303u;
-      pk[qd] = __builtin_amdgcn_udot4(codes, 0x01041040u, 0u, false);  // c0<<6|c1<<4|c2<<2|c3
-    }
-    return (((pk[0] << 8 | pk[1]) << 8 | pk[2]) << 8) | pk[3];
+    for (int qd = 0; qd < 4; qd++) pk[qd] = __builtin_amdgcn_udot4(w[qd] & 0x06060606u, 0x01041040u, 0u, false);
+    return (pk[0] << 23) | (pk[1] << 15) | (pk[2] << 7) | (pk[3] >> 1);
   };
   auto word_of = [&](int qd, uint32_t W, uint32_t Wp, uint32_t Wpp) -> uint32_t {  // E of the lane's dword qd (0..3, a constant)
     if (NARROW) return qd ? __builtin_amdgcn_alignbit(Wp, W, 32 - 8 * qd) : Wp;
@@ -1000,7 +1002,8 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
         for (uint32_t key : keys) {
           uint32_t rc = 0;
           for (int i = 0; i < 12; i++) rc |= (((key >> (2 * i)) & 3u) ^ 3u) << (2 * (11 - i));
-          for (uint32_t v : {key, rc}) {
+          for (uint32_t v0 : {key, rc}) {
+            const uint32_t v = v0 ^ ((v0 >> 1) & 0x555555u);  // gray24: every base b as b ^ (b >> 1), the prefilter's alphabet
             for (int al = 0; al < 4; al++) {
               const uint32_t core = (v >> (2 * al)) & 0x3ffffu;
               bloom[core >> 5] |= 1u << (core & 31u);
