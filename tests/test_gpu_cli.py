@@ -1162,3 +1162,45 @@ def test_packed_staging_unpack_kernel_and_cli_identity(ctx, oracle, tmp_path):
         assert outs["packed"][1].keys() == outs["ascii"][1].keys()
         for f in outs["packed"][1]:
             assert outs["packed"][1][f] == outs["ascii"][1][f], (tool, extra, f)
+
+
+def test_batches_parsed_while_the_gpus_come_up_change_nothing(oracle, tmp_path):
+    """The command line parses batch after batch into buffers of their own while the HIP runtime and the contexts come up on
+    another thread, and hands them to the lanes afterwards.  With small batches (many of them before the GPUs are there),
+    with the pre-parse switched off (RTC_PREPARSE_BYTES=0) and with a budget that stops it after a few batches, the
+    cluster file, hash.sketch and edge.mst must be byte-identical -- including a gzip file whose slot guess is too small
+    (retry round) and a genome below the length filter."""
+    import gzip
+    import re
+    tmp = str(tmp_path)
+    lst, paths, seqs = _write_family_fastas(oracle, tmp, 5, 4, 300_000, seed=91)
+    short = os.path.join(tmp, "short.fna")
+    open(short, "wb").write(b">short x\n" + b"ACGT" * 1000 + b"\n")
+    gz = os.path.join(tmp, "g_extra.fna.gz")
+    with gzip.open(gz, "wb") as f:   # two members: the trailing ISIZE covers only the last one
+        f.write(open(paths[3], "rb").read())
+    with open(gz, "ab") as f:
+        f.write(gzip.compress(b">tail y\n" + b"ACGTTGCA" * 20000 + b"\n"))
+    open(lst, "a").write(short + "\n" + gz + "\n")
+    outs = []
+    for name, env in (("pre", {"RTC_BATCH_BYTES": "2000000"}), ("off", {"RTC_BATCH_BYTES": "2000000", "RTC_PREPARSE_BYTES": "0"}),
+                      ("few", {"RTC_BATCH_BYTES": "2000000", "RTC_PREPARSE_BYTES": "1500000"})):
+        d = os.path.join(tmp, name)
+        os.makedirs(d)
+        err = _run([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "500", "-d", "0.05", "-t", "4", "-o", os.path.join(d, "out.cluster")],
+                   d, dict(env, RTC_VERBOSE="1"))
+        m = re.search(r"\[init\]\s+(\d+) of (\d+) batches parsed before the GPUs were up", err)
+        assert m, err[-2000:]
+        npre, nb = int(m.group(1)), int(m.group(2))
+        assert nb >= 3
+        if name == "off":
+            assert npre == 0
+        if name == "few":
+            assert npre <= 3
+        folder = [x for x in os.listdir(d) if os.path.isdir(os.path.join(d, x))]
+        assert len(folder) == 1
+        fd = os.path.join(d, folder[0])
+        outs.append((open(os.path.join(d, "out.cluster"), "rb").read(), open(os.path.join(fd, "hash.sketch"), "rb").read(),
+                     open(os.path.join(fd, "edge.mst"), "rb").read(), npre))
+    assert outs[0][:3] == outs[1][:3] == outs[2][:3]
+    assert outs[0][3] >= 1  # the default budget parsed at least the first batch ahead of the GPUs
