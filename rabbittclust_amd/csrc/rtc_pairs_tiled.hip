@@ -291,7 +291,7 @@ __global__ __launch_bounds__(TW, 1) void pair_tiled_kernel(const T* __restrict__
       // general walk.
       {
         const uint32_t mylen = chi - clo;
-        const uint4* tp_lo = tcols_lo + tbase[p] + (c - tc0);
+        const uint4* tp_lo = sizeof(T) == 8 ? tcols_lo + tbase[p] + (c - tc0) : nullptr;  // 64-bit keys only
         if (sb > 0) {
 #pragma unroll
           for (int d = 0; d < DEPTH; d++) nq[d] = col_active ? tp[(size_t)d * tnc] : make_uint4(0u, 0u, 0u, 0u);
