@@ -228,9 +228,12 @@ __global__ __launch_bounds__(256) void join_count_kernel(const T* __restrict__ k
 
 // codes[eoff[a] + t] = (row << bits) | col for the t-th partner of element a.  One lane per element; an
 // element with many partners (a long posting list) is written by its whole wave.
+// Code: uint32_t when two genome indices fit 32 bits (up to 65 536 genomes: the second sort then moves half the bytes at
+// more than twice the key rate), uint64_t otherwise.
+template <typename Code>
 __global__ __launch_bounds__(256) void join_emit_kernel(const uint32_t* __restrict__ vs, const uint32_t* __restrict__ lo,
                                                         const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ eoff,
-                                                        uint32_t K, int bits, uint64_t* __restrict__ codes) {
+                                                        uint32_t K, int bits, Code* __restrict__ codes) {
   const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63;
   uint32_t c = 0, l = 0, col = 0;
@@ -238,19 +241,20 @@ __global__ __launch_bounds__(256) void join_emit_kernel(const uint32_t* __restri
   if (a < K) { c = cnt[a]; if (c) { l = lo[a]; col = vs[a]; o = eoff[a]; } }
   const uint32_t SMALL = 24;
   if (c && c <= SMALL)
-    for (uint32_t t = 0; t < c; t++) codes[o + t] = ((uint64_t)vs[l + t] << bits) | col;
+    for (uint32_t t = 0; t < c; t++) codes[o + t] = (Code)(((Code)vs[l + t] << bits) | col);
   uint64_t big = __ballot(c > SMALL);
   while (big) {  // wave-uniform
     const int src = __builtin_ctzll(big);
     big &= big - 1ULL;
     const uint32_t cc = (uint32_t)__shfl((int)c, src), ll = (uint32_t)__shfl((int)l, src), colc = (uint32_t)__shfl((int)col, src);
     const uint64_t oo = ((uint64_t)(uint32_t)__shfl((int)(o >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)o, src);
-    for (uint32_t t = lane; t < cc; t += 64) codes[oo + t] = ((uint64_t)vs[ll + t] << bits) | colc;
+    for (uint32_t t = lane; t < cc; t += 64) codes[oo + t] = (Code)(((Code)vs[ll + t] << bits) | colc);
   }
 }
 
 // run r of the sorted codes = pair (row, col) with common = run length: the reference's filters, then append
-__global__ __launch_bounds__(256) void join_filter_kernel(const uint64_t* __restrict__ uq, const uint32_t* __restrict__ rc,
+template <typename Code>
+__global__ __launch_bounds__(256) void join_filter_kernel(const Code* __restrict__ uq, const uint32_t* __restrict__ rc,
                                                           const uint32_t* __restrict__ nruns, int bits,
                                                           const uint32_t* __restrict__ len, int radio,
                                                           rtc_cedge* __restrict__ edges, unsigned long long cap,
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256) void join_filter_kernel(const uint64_t* __rest
   bool keep = false;
   uint32_t row = 0, col = 0, common = 0;
   if (r < *nruns) {
-    const uint64_t code = uq[r];
+    const uint64_t code = (uint64_t)uq[r];
     row = (uint32_t)(code >> bits);
     col = (uint32_t)(code & ((1ULL << bits) - 1ULL));
     common = rc[r];
@@ -290,6 +294,44 @@ int join_mode() {
   const char* e = getenv("RTC_PAIR_JOIN");
   if (!e) return 1;
   return atoi(e);
+}
+
+// The second half of the join: one code (row << bits | col) per co-occurrence, sorted, run lengths = |A_row n A_col|,
+// the reference's filters, append.  *fit = 0: the scratch does not fit (the caller's alternative runs).
+template <typename Code>
+int join_pairs_tail(rtc_ctx* ctx, const uint32_t* vals1, const uint32_t* d_lo, const uint32_t* d_cnt, const uint64_t* d_eoff, uint32_t K,
+                    uint64_t E, int bits, const uint32_t* d_len, int radio, rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count,
+                    uint64_t avail, size_t need1, int* fit) {
+  *fit = 0;
+  hipStream_t s = ctx->stream;
+  size_t tb_s2 = 0, tb_rle = 0;
+  RTC_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb_s2, (const Code*)nullptr, (Code*)nullptr, (size_t)E, 0u, (unsigned)(2 * bits), s));
+  RTC_HIP(ctx, rocprim::run_length_encode(nullptr, tb_rle, (const Code*)nullptr, (unsigned)E, (Code*)nullptr,
+                                          (uint32_t*)nullptr, (uint32_t*)nullptr, s));
+  const size_t b_codes = up256((size_t)E * sizeof(Code)), b_rc = up256((size_t)E * 4), b_tmp2 = up256(std::max(tb_s2, tb_rle));
+  const size_t need4 = 2 * b_codes + b_rc + b_tmp2 + 512;
+  if (need4 > (avail - std::min<uint64_t>(avail, need1)) / 2 + ctx->ws_bytes[4]) return RTC_OK;
+  void* ws4 = nullptr;
+  {
+    const int st = rtc_ws(ctx, 4, need4, &ws4);
+    if (st == RTC_ERR_NOMEM) return RTC_OK;
+    if (st != RTC_OK) return st;
+  }
+  Code* codes0 = (Code*)ws4;
+  Code* codes1 = (Code*)((char*)ws4 + b_codes);
+  uint32_t* d_rc = (uint32_t*)((char*)ws4 + 2 * b_codes);
+  uint32_t* d_nruns = (uint32_t*)((char*)ws4 + 2 * b_codes + b_rc);
+  void* tmp2 = (char*)ws4 + 2 * b_codes + b_rc + 256;
+  hipLaunchKernelGGL(join_emit_kernel<Code>, dim3((K + 255) / 256), dim3(256), 0, s, vals1, d_lo, d_cnt, d_eoff, K, bits, codes0);
+  RTC_CHECK_LAUNCH(ctx);
+  RTC_HIP(ctx, rocprim::radix_sort_keys(tmp2, tb_s2, (const Code*)codes0, codes1, (size_t)E, 0u, (unsigned)(2 * bits), s));
+  Code* d_uq = codes0;
+  RTC_HIP(ctx, rocprim::run_length_encode(tmp2, tb_rle, (const Code*)codes1, (unsigned)E, d_uq, d_rc, d_nruns, s));
+  hipLaunchKernelGGL(join_filter_kernel<Code>, dim3((uint32_t)((E + 255) / 256)), dim3(256), 0, s, (const Code*)d_uq, (const uint32_t*)d_rc,
+                     (const uint32_t*)d_nruns, bits, d_len, radio, d_edges, (unsigned long long)cap, (unsigned long long*)d_count);
+  RTC_CHECK_LAUNCH(ctx);
+  *fit = 1;
+  return RTC_OK;
 }
 
 template <typename T>
@@ -497,35 +539,10 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
 
   int bits = 1;
   while ((1ull << bits) < (uint64_t)n) bits++;
-  size_t tb_s2 = 0, tb_rle = 0;
-  RTC_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb_s2, (const uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)E, 0u, (unsigned)(2 * bits), s));
-  RTC_HIP(ctx, rocprim::run_length_encode(nullptr, tb_rle, (const uint64_t*)nullptr, (unsigned)E, (uint64_t*)nullptr,
-                                          (uint32_t*)nullptr, (uint32_t*)nullptr, s));
-  const size_t b_codes = up256((size_t)E * 8), b_rc = up256((size_t)E * 4), b_tmp2 = up256(std::max(tb_s2, tb_rle));
-  const size_t need4 = 2 * b_codes + b_rc + b_tmp2 + 512;
-  if (need4 > (avail - std::min<uint64_t>(avail, need1)) / 2 + ctx->ws_bytes[4]) return RTC_OK;
-  void* ws4 = nullptr;
-  {
-    const int st = rtc_ws(ctx, 4, need4, &ws4);
-    if (st == RTC_ERR_NOMEM) return RTC_OK;
-    if (st != RTC_OK) return st;
-  }
-  uint64_t* codes0 = (uint64_t*)ws4;
-  uint64_t* codes1 = (uint64_t*)((char*)ws4 + b_codes);
-  uint32_t* d_rc = (uint32_t*)((char*)ws4 + 2 * b_codes);
-  uint32_t* d_nruns = (uint32_t*)((char*)ws4 + 2 * b_codes + b_rc);
-  void* tmp2 = (char*)ws4 + 2 * b_codes + b_rc + 256;
-
-  // ---- 4-7 ----
-  hipLaunchKernelGGL(join_emit_kernel, dim3((K + 255) / 256), dim3(256), 0, s, (const uint32_t*)vals1, (const uint32_t*)d_lo,
-                     (const uint32_t*)d_cnt, (const uint64_t*)d_eoff, K, bits, codes0);
-  RTC_CHECK_LAUNCH(ctx);
-  RTC_HIP(ctx, rocprim::radix_sort_keys(tmp2, tb_s2, (const uint64_t*)codes0, codes1, (size_t)E, 0u, (unsigned)(2 * bits), s));
-  uint64_t* d_uq = codes0;
-  RTC_HIP(ctx, rocprim::run_length_encode(tmp2, tb_rle, (const uint64_t*)codes1, (unsigned)E, d_uq, d_rc, d_nruns, s));
-  hipLaunchKernelGGL(join_filter_kernel, dim3((uint32_t)((E + 255) / 256)), dim3(256), 0, s, (const uint64_t*)d_uq, (const uint32_t*)d_rc,
-                     (const uint32_t*)d_nruns, bits, d_len, radio, d_edges, (unsigned long long)cap, (unsigned long long*)d_count);
-  RTC_CHECK_LAUNCH(ctx);
+  int fit = 0;
+  if (2 * bits <= 32) RTC_TRY((join_pairs_tail<uint32_t>(ctx, vals1, d_lo, d_cnt, d_eoff, K, E, bits, d_len, radio, d_edges, cap, d_count, avail, need1, &fit)));
+  else RTC_TRY((join_pairs_tail<uint64_t>(ctx, vals1, d_lo, d_cnt, d_eoff, K, E, bits, d_len, radio, d_edges, cap, d_count, avail, need1, &fit)));
+  if (!fit) return RTC_OK;
   *handled = 1;
   return RTC_OK;
 }
