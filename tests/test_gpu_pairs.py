@@ -105,19 +105,48 @@ def test_tiled_u32_sentinel(ctx, oracle):
     assert np.array_equal(got, want)
 
 
+def _colliding_pool(rng, width, want=2500):
+    """Keys whose table coordinates collide in rtc_pairs_tiled.hip: the digest (image of a 32-bit key under x 0x9E3779B1, high
+    half of the image of a 64-bit key under x 0x9E3779B97F4A7C15) picks the bucket with its top 12 bits and the fingerprint
+    with bits 4..17.  Returns groups of >= 6 keys that agree in BOTH (more than a bucket's four slots: the bucket overflows
+    and every lookup in the group is decided by the key comparison), plus keys that share only the bucket."""
+    n = 1 << 26
+    if width == 4:
+        keys = np.unique(rng.integers(0, 1 << 32, size=n, dtype=np.uint64)).astype(np.uint64)
+        dig = (keys * np.uint64(0x9E3779B1)) & np.uint64(0xffffffff)
+    else:
+        keys = np.unique(rng.integers(0, 1 << 63, size=n, dtype=np.uint64))
+        dig = (keys * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(32)
+    # one fingerprint (n / 2^14 keys), then the buckets that received the most of them
+    sel = np.nonzero(((dig >> np.uint64(4)) & np.uint64(0x3fff)) == np.uint64(0x155))[0]   # one fingerprint: n / 2^14 keys
+    sub, ssig = keys[sel], (dig[sel] >> np.uint64(20))
+    order = np.argsort(ssig, kind="stable")
+    sub, ssig = sub[order], ssig[order]
+    uniq, start, cnt = np.unique(ssig, return_index=True, return_counts=True)
+    pool = []
+    for st, c in zip(start[np.argsort(-cnt)], np.sort(cnt)[::-1]):
+        if c < 2 or len(pool) >= want:
+            break
+        pool.extend(sub[st:st + c].tolist())
+    return np.array(sorted(set(pool)), dtype=np.uint64), int(np.max(cnt))
+
+
 @pytest.mark.parametrize("width", [8, 4])
 def test_tiled_fingerprint_collisions(ctx, oracle, width):
-    """Every hash shares its low 15 bits (the table's bucket fingerprints are those bits): each probe that
-    finds an occupied home bucket is a fingerprint match, so all decisions fall to the key comparison; the
-    sketches also overlap heavily (ripple of the bit-sliced counters) and fill buckets to overflowing."""
+    """Hashes chosen so that they share fingerprint AND bucket in the tiled kernel's table (groups larger than a bucket):
+    every probe of such a key finds its fingerprint in an overflowed bucket, all decisions fall to the comparison of the
+    whole key image, and the walk has to follow the overflow into the next buckets; the sketches also overlap heavily
+    (carry-save + ripple of the bit-sliced counters)."""
     from rabbittclust_amd import api
     rng = np.random.default_rng(23 + width)
-    hi_bits = 48 if width == 8 else 16
-    pool = (np.unique(rng.integers(0, 1 << hi_bits, size=9000, dtype=np.uint64)) << np.uint64(15)) | np.uint64(0x1234)
+    pool, biggest = _colliding_pool(rng, width)
+    assert len(pool) >= 1500 and biggest >= (3 if width == 8 else 3)
+    filler = np.unique(rng.integers(0, 1 << (62 if width == 8 else 32), size=4000, dtype=np.uint64))
+    pool = np.unique(np.concatenate([pool, filler]))
     sk = []
     for g in range(150):
         size = int(rng.integers(200, 3000))
-        v = np.sort(rng.choice(pool, size=size, replace=False))
+        v = np.sort(rng.choice(pool, size=min(size, len(pool)), replace=False))
         sk.append(v.astype(np.uint64 if width == 8 else np.uint32))
     dev = api.SketchSet.from_host(sk, ctx.device, width=width)
     want = _oracle_matrix(oracle, sk)
