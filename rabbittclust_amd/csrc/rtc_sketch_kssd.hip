@@ -665,10 +665,97 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
   }
 }
 
+// One WAVE per genome for rows of at most 64 * NPER tuples (a 2 Mbp genome at drlevel 3 yields ~490, a 5 Mbp one ~1 200):
+// element e = 64 r + lane sits in register r of its lane, the bitonic network exchanges across lanes with a wave shuffle
+// while the distance is below 64 and between registers of one lane above -- no LDS, no workgroup barrier (the LDS
+// kernel below pays 45 of them for 512 tuples; it keeps the longer rows).  Dedup and compaction run register by register
+// (ascending e), one ballot each.
+template <typename OutT, int NPER>
+__device__ __forceinline__ void wave_sort_unique(OutT* __restrict__ row, uint32_t m, uint32_t lane, uint32_t* __restrict__ cnt_out) {
+  constexpr int N = 64 * NPER;
+  OutT v[NPER];
+#pragma unroll
+  for (int r = 0; r < NPER; r++) { const uint32_t e = 64u * r + lane; v[r] = e < m ? row[e] : (OutT)~(OutT)0; }
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {  // partner in another register of this lane
+#pragma unroll
+        for (int r = 0; r < NPER; r++) {
+          const int pr = r ^ (j >> 6);
+          if (pr > r) {
+            const bool up = ((64 * r) & k) == 0;  // k >= 128 here: the direction is the register's
+            const OutT a = v[r], b = v[pr];
+            const bool sw = (a > b) == up;
+            v[r] = sw ? b : a;
+            v[pr] = sw ? a : b;
+          }
+        }
+      } else {        // partner in lane ^ j, same register
+#pragma unroll
+        for (int r = 0; r < NPER; r++) {
+          OutT o;
+          if constexpr (sizeof(OutT) == 8) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v[r], j), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v[r] >> 32), j);
+            o = ((OutT)hi << 32) | lo;
+          } else {
+            o = (OutT)__shfl_xor((int)v[r], j);
+          }
+          const uint32_t e = 64u * r + lane;
+          const bool up = (e & (uint32_t)k) == 0, lower = (lane & (uint32_t)j) == 0;
+          const OutT mn = v[r] < o ? v[r] : o, mx = v[r] < o ? o : v[r];
+          v[r] = (lower == up) ? mn : mx;
+        }
+      }
+    }
+  }
+  // the first m sorted entries are exactly the real ones (padding is the maximum value): distinct values to the row's front
+  uint32_t written = 0;  // wave-uniform
+  OutT last = 0;         // the value in front of register r's lane 0: lane 63 of register r - 1
+#pragma unroll
+  for (int r = 0; r < NPER; r++) {
+    OutT prev;
+    if constexpr (sizeof(OutT) == 8) {
+      const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v[r], 1), hi = (uint32_t)__shfl_up((int)(uint32_t)(v[r] >> 32), 1);
+      prev = ((OutT)hi << 32) | lo;
+    } else {
+      prev = (OutT)__shfl_up((int)v[r], 1);
+    }
+    if (lane == 0) prev = last;
+    const uint32_t e = 64u * r + lane;
+    const bool keep = e < m && (e == 0 || v[r] != prev);
+    const uint64_t bal = __ballot(keep);
+    // every read of the row happened before the sort: writing in place is safe
+    if (keep) row[written + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL))] = v[r];
+    written += (uint32_t)__popcll(bal);
+    if constexpr (sizeof(OutT) == 8) {
+      last = ((OutT)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v[r] >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v[r], 63);
+    } else {
+      last = (OutT)__builtin_amdgcn_readlane((int)v[r], 63);
+    }
+  }
+  if (lane == 0) *cnt_out = written;
+}
+
+constexpr int WAVE_SORT_MAX = 1024;  // tuples a wave sorts in registers (16 per lane)
+template <typename OutT>
+__global__ __launch_bounds__(256) void kssd_sort_unique_wave_kernel(OutT* __restrict__ out, uint32_t stride, uint32_t* __restrict__ cnt, uint32_t n) {
+  const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= n) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t m = min(cnt[g], stride);
+  if (m == 0 || m > (uint32_t)WAVE_SORT_MAX) return;
+  OutT* row = out + (uint64_t)g * stride;
+  if (m <= 256) wave_sort_unique<OutT, 4>(row, m, lane, cnt + g);
+  else if (m <= 512) wave_sort_unique<OutT, 8>(row, m, lane, cnt + g);
+  else wave_sort_unique<OutT, 16>(row, m, lane, cnt + g);
+}
+
 // one workgroup per genome: sort + dedup the appended tuples in LDS (hashArr sort :1185,:1192)
 template <typename OutT>
 __global__ __launch_bounds__(WG) void kssd_sort_unique_kernel(OutT* __restrict__ out, uint32_t stride,
-                                                              uint32_t* __restrict__ cnt, int cap) {
+                                                              uint32_t* __restrict__ cnt, int cap, int wave_max) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   OutT* buf = reinterpret_cast<OutT*>(smem);
   uint32_t* wave_tot = reinterpret_cast<uint32_t*>(smem + (size_t)cap * sizeof(OutT));  // [WG/64]
@@ -676,7 +763,7 @@ __global__ __launch_bounds__(WG) void kssd_sort_unique_kernel(OutT* __restrict__
   const uint32_t g = blockIdx.x;
   const int t = threadIdx.x;
   const uint32_t m = min(cnt[g], stride);
-  if (m == 0 || m > (uint32_t)cap) return;  // rows beyond one LDS buffer go through kssd_big_* below
+  if (m <= (uint32_t)wave_max || m > (uint32_t)cap) return;  // short rows: kssd_sort_unique_wave_kernel; rows beyond one LDS buffer: kssd_big_* below
   OutT* row = out + (uint64_t)g * stride;
   int n2 = 64;  // bitonic network over the next power of two (a 2 Mbp genome at drlevel 3: ~490 tuples -> 512)
   while (n2 < (int)m) n2 <<= 1;
@@ -1165,14 +1252,20 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   int cap = 1024;
   while (cap < (int)h_max && cap < cap_max) cap <<= 1;
   const size_t lds_s = (size_t)cap * (use64 ? 8 : 4) + (WG / 64 + 1) * 4;
-  if (use64) {
+  // rows of up to WAVE_SORT_MAX tuples: one wave each, in registers; the LDS kernel only when some row is longer
+  if (use64) hipLaunchKernelGGL(kssd_sort_unique_wave_kernel<uint64_t>, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, (uint64_t*)d_out, stride, d_cnt, n);
+  else hipLaunchKernelGGL(kssd_sort_unique_wave_kernel<uint32_t>, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, (uint32_t*)d_out, stride, d_cnt, n);
+  RTC_CHECK_LAUNCH(ctx);
+  if (h_max <= (uint32_t)WAVE_SORT_MAX) {
+    // every row is done
+  } else if (use64) {
     auto kern = kssd_sort_unique_kernel<uint64_t>;
     RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-    hipLaunchKernelGGL(kern, dim3(n), dim3(WG), lds_s, ctx->stream, (uint64_t*)d_out, stride, d_cnt, cap);
+    hipLaunchKernelGGL(kern, dim3(n), dim3(WG), lds_s, ctx->stream, (uint64_t*)d_out, stride, d_cnt, cap, WAVE_SORT_MAX);
   } else {
     auto kern = kssd_sort_unique_kernel<uint32_t>;
     RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-    hipLaunchKernelGGL(kern, dim3(n), dim3(WG), lds_s, ctx->stream, (uint32_t*)d_out, stride, d_cnt, cap);
+    hipLaunchKernelGGL(kern, dim3(n), dim3(WG), lds_s, ctx->stream, (uint32_t*)d_out, stride, d_cnt, cap, WAVE_SORT_MAX);
   }
   RTC_CHECK_LAUNCH(ctx);
   if (h_max > (uint32_t)cap) RTC_TRY(kssd_sort_big_rows(ctx, d_out, stride, d_cnt, n, use64, cap));
