@@ -27,12 +27,15 @@ open(os.path.join(tmp, "list.txt"), "w").write("\n".join(paths) + "\n")
 del ctx
 for r in range(runs):
     t0 = time.time()
-    res = subprocess.run(["env", "RTC_VERBOSE=1", os.path.join(root, "rabbittclust_amd", "bin", "clust-mst"), "-l", "-i", os.path.join(tmp, "list.txt"), "-k", "21",
+    res = subprocess.run(["env", "RTC_VERBOSE=1"] + [f"{k}={v}" for k, v in os.environ.items() if k.startswith("RTC_")] + [ os.path.join(root, "rabbittclust_amd", "bin", "clust-mst"), "-l", "-i", os.path.join(tmp, "list.txt"), "-k", "21",
                           "-d", "0.05", "-e", "-o", os.path.join(tmp, "out.cluster")] + extra, capture_output=True, text=True, cwd=tmp)
     dt = time.time() - t0
     print(f"run {r}: rc={res.returncode} wall={dt:.3f}s {n * L / dt / 1e9:.1f} Gbp/s", flush=True)
     keep = [ln for ln in res.stderr.splitlines() if ln.startswith(("[init]", "[ctx]", "[plan]", "[tune]", "[exit]", "[free]", "[share]")) or "time of" in ln]
     gp = [ln for ln in res.stderr.splitlines() if ln.startswith("[gpu")]
-    for ln in keep + gp[:3] + (["   ..."] if len(gp) > 3 else []):
-        print("   ", ln)
+    if os.environ.get("TL_BRIEF"):
+        print("   ", " | ".join(ln.strip() for ln in keep if ln.startswith(("[init]  ", "[ctx]", "[exit]")) and "list" not in ln))
+    else:
+        for ln in keep + gp[:3] + (["   ..."] if len(gp) > 3 else []):
+            print("   ", ln)
 shutil.rmtree(tmp)
