@@ -210,7 +210,10 @@ __global__ __launch_bounds__(TW, 1) void pair_tiled_kernel(const T* __restrict__
   // once per row block.
   const uint32_t rb0 = row0 + blockIdx.x * ROWS;
   const uint32_t nrows = min((uint32_t)ROWS, row1 - rb0);
-  const uint32_t cb0 = col0 + blockIdx.y * TW;
+  // the column blocks run from the last to the first: the blocks near the diagonal -- whose columns are related to their rows
+  // (families sit side by side) and resolve hits on most trips -- start first, and the launch's last, partly idle round of
+  // workgroups is made of the cheap ones far below the diagonal
+  const uint32_t cb0 = col0 + (gridDim.y - 1 - blockIdx.y) * TW;
   if (lower_only && cb0 + 1 > rb0 + nrows - 1) return;  // no (row, col) with col < row in this block
   const uint32_t c = cb0 + tid;
   // (lower_only: a column at or beyond the block's last row pairs with none of its rows -- in a block on the diagonal
