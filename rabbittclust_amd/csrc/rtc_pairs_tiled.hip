@@ -1,21 +1,25 @@
-// rtc_pairs_tiled.hip -- all-pairs |A_i ∩ A_j| with an LDS-resident row-block inverted table.
+// rtc_pairs_tiled.hip -- all-pairs |A_i n A_j| with an LDS-resident row-block inverted table.
 //
 // Dense (every pair is evaluated, no data-dependent skipping of pairs) but work-efficient form of
 // the reference's inverted-index intersection (src/MST.cpp:1408-1435): instead of one merge per
 // pair, a workgroup owns a block of 64 rows x 1024 columns and, for each hash-range partition p,
-//   1. builds in LDS an open-addressing table  hash -> 64-bit mask of the rows containing it
-//      (bucketised, 4 keys per 32-byte bucket; ds_cmpst_b64 / ds_or_b64), from the rows' sorted
-//      slices that fall in partition p;
-//   2. every lane (= one column sketch) streams its own slice of partition p and probes the table
-//      with two ds_read_b128; a hit returns the mask of ALL 64 rows containing that hash;
-//   3. masks are accumulated in per-lane bit-sliced counters (plane k holds bit k of the 64 row
-//      counters), i.e. one probe serves 64 pairs and the add is a wave-uniform ripple of
-//      AND/XOR on 64-bit registers.
-// The column slices are first copied into a partition-major, element-major, column-minor layout
-// (tcols[base[p] + e*n + c]) so that the probe loop's loads are coalesced across lanes (= columns).
+//   1. builds in LDS a table  hash -> 64-bit mask of the rows containing it  from the rows' sorted slices that fall
+//      in partition p: 4-byte slots (fingerprint | entry index | overflow flag | generation) in buckets of four,
+//      entries {key image, row mask} in an array of their own (ds_cmpst_b32 claims a slot, ds_or_b64 adds a row);
+//      a slot of another generation is free, so a new table costs no clearing;
+//   2. every lane (= one column sketch) streams its own slice of partition p as 32-bit DIGESTS, four per 16-byte load,
+//      and reads each key's home bucket with one ds_read_b128; one wave vote per trip of four keys decides whether any
+//      lane may have a hit, and only then are entries read and key images compared (a hit returns the mask of ALL 64
+//      rows containing that hash);
+//   3. masks are accumulated in per-lane bit-sliced counters (plane k holds bit k of the 64 row counters), i.e. one
+//      probe serves 64 pairs; the (up to) four masks of a trip go through a 4:2 carry-save compressor, then a
+//      wave-uniform ripple of AND/XOR on 64-bit registers.
+// The column slices are first copied into a partition-major, group-major, column-minor layout of digests
+// (tcols[base[p] + t*n + c] = elements 4t..4t+3 of column c's slice; 64-bit keys: a second copy with the low halves of
+// the key images, read only to confirm a hit) so that the probe loop's loads are coalesced across lanes (= columns).
 // After the last partition each lane unpacks its 64 counters and writes them (coalesced across
 // lanes) to common[row][col].  Partition boundaries are data quantiles computed from a sample, so
-// the table load stays ~25 %; blocks whose slices would overflow the table are split into row
+// the table holds about half a key per bucket; blocks whose slices would overflow the table are split into row
 // sub-blocks inside the kernel, and inputs the scheme cannot take fall back to the merge kernel.
 //
 // Two output forms of the same kernel: EMIT_DENSE stores the counts into common[row][col];
