@@ -8,13 +8,16 @@
 // The reference probes a phmap of the kept (dim_id -> rank) pairs per k-mer.  Here the kept set
 // (dim_end of 2^(4*half_subk) ids; 4096 of 16 Mi at the default drlevel 3) is compiled on the host:
 //  * 24-bit dim_id, K = 18..28 (every default configuration): sketch_kssd_bloom_kernel.  The steady state looks
-//    at the FORWARD strand only -- a blocked Bloom filter in LDS of the kept middle 12-mers and their reverse
-//    complements -- and queues the positions of possible hits; those are finished exactly (both strands, canonical
-//    minimum, an exact bucket index of the kept ids: 8192 buckets of four 16-bit patterns + ranks, in global memory).
+//    at the FORWARD strand only, in two stages over the kept middle 12-mers and their reverse complements: a 2^18-bit
+//    map in LDS of the 18 bits the four k-mers of a dword share (one read per dword), then, 64 surviving dwords at a
+//    time, a blocked Bloom filter; it queues the positions of possible hits, and those are finished exactly (both
+//    strands, canonical minimum, an exact bucket index of the kept ids: 8192 buckets of four 16-bit patterns + ranks,
+//    in global memory).
 //  * two-table cuckoo index in LDS (other k-mer lengths, 28-bit dim_id): two ds_read_b32 per k-mer.
 //  * the full table in HBM when more than 8192 ids are kept (drlevel <= 2) or nothing else can be built.
-// Survivors are appended to the genome's output row with wave-aggregated atomics;
-// kssd_sort_unique_kernel then sorts and deduplicates each row in LDS.
+// Survivors are appended to the genome's output row with wave-aggregated atomics; each row is then sorted and
+// deduplicated -- by one wave in registers up to 1 024 tuples (kssd_sort_unique_wave_kernel), in LDS
+// (kssd_sort_unique_kernel) or by a global merge sort (kssd_big_*) beyond.
 #include <algorithm>
 #include <vector>
 
