@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <time.h>
+
 #include "rtc_internal.h"
 
 static thread_local std::string g_err;  // failures that happen without a context
@@ -25,12 +27,26 @@ int rtc_ws(rtc_ctx* ctx, int slot, size_t bytes, void** out) {
     ctx->ws[slot] = nullptr;
     ctx->ws_bytes[slot] = 0;
     size_t want = bytes + bytes / 4 + 4096;
+    ctx->free_hbm_at = -1.0;
     hipError_t e = hipMalloc(&ctx->ws[slot], want);
     if (e != hipSuccess) return rtc_fail(ctx, RTC_ERR_NOMEM, "hipMalloc(%zu) scratch: %s", want, hipGetErrorString(e));
     ctx->ws_bytes[slot] = want;
   }
   *out = ctx->ws[slot];
   return RTC_OK;
+}
+
+uint64_t rtc_free_hbm(rtc_ctx* ctx) {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  const double now = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+  if (ctx->free_hbm_at < 0 || now - ctx->free_hbm_at > 0.1) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
+    ctx->free_hbm_cached = free_b;
+    ctx->free_hbm_at = now;
+  }
+  return ctx->free_hbm_cached;
 }
 
 int rtc_pinned(rtc_ctx* ctx, size_t bytes, void** out) {
@@ -133,6 +149,7 @@ int rtc_device_info(rtc_ctx* ctx, int out[3]) {
 }
 
 int rtc_dev_alloc(rtc_ctx* ctx, size_t bytes, void** d_ptr) {
+  if (ctx) ctx->free_hbm_at = -1.0;
   if (!ctx || !d_ptr) return RTC_ERR_ARG;
   *d_ptr = nullptr;
   if (bytes == 0) bytes = 16;
@@ -143,6 +160,7 @@ int rtc_dev_alloc(rtc_ctx* ctx, size_t bytes, void** d_ptr) {
 }
 
 int rtc_dev_free(rtc_ctx* ctx, void* d_ptr) {
+  if (ctx) ctx->free_hbm_at = -1.0;
   if (!ctx) return RTC_ERR_ARG;
   if (d_ptr) RTC_HIP(ctx, hipFree(d_ptr));
   return RTC_OK;

@@ -24,6 +24,8 @@ struct rtc_ctx {
   // pinned host staging for small synchronous read-backs
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
+  uint64_t free_hbm_cached = 0;   // rtc_free_hbm
+  double free_hbm_at = -1.0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // HIP events around the last pair_tiled_kernel launch, on the stream it was launched on (rtc_pair_last_kernel_ms)
   hipEvent_t pk0 = nullptr, pk1 = nullptr;
@@ -65,6 +67,9 @@ int rtc_fail(rtc_ctx* ctx, int code, const char* fmt, ...);
 // returns device scratch slot `slot` grown to at least `bytes`
 int rtc_ws(rtc_ctx* ctx, int slot, size_t bytes, void** out);
 int rtc_pinned(rtc_ctx* ctx, size_t bytes, void** out);
+// free HBM of the context's device, for the scratch budgets of the pair phase: hipMemGetInfo walks the driver's tables, so the
+// answer is kept for 100 ms or until this context allocates or frees (the budgets are halves of the free memory, not margins)
+uint64_t rtc_free_hbm(rtc_ctx* ctx);
 
 // ---- internal C++ interfaces shared by the translation units ----------------------------------
 // all-reduce of a per-round key array across the ranks of a multi-GPU run (rtc_comm.hip);

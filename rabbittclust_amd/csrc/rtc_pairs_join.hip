@@ -442,9 +442,7 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   const double t_sort = (double)K / (sizeof(T) == 8 ? 1.1e10 : 2.8e10);
   if (mode == 1 && t_sort > 0.7 * t_tiled) return RTC_OK;
 
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
-  const uint64_t avail = (uint64_t)free_b + ctx->ws_bytes[1] + ctx->ws_bytes[4];
+  const uint64_t avail = rtc_free_hbm(ctx) + ctx->ws_bytes[1] + ctx->ws_bytes[4];
 
   // ---- 2. flat copy + stable sort by hash ----
   size_t tb_sort = 0;

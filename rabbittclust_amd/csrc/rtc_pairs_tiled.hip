@@ -642,8 +642,7 @@ int build_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
 
   // Memory budget of the transposed copy: sum_p(pmax[p]) * tnc elements.  With even lengths it is
   // ~1.8x the hashes themselves; it is allowed 16x (or 1 GiB) and never more than half of the free HBM.
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+  const uint64_t free_b = rtc_free_hbm(ctx);
   uint64_t budget = std::max<uint64_t>((uint64_t)1 << 30, 16ull * tot * sizeof(T));
   budget = std::min<uint64_t>(budget, (uint64_t)(free_b + ctx->ws_bytes[4]) / 2);
   if (const char* e = getenv("RTC_PAIR_TCOLS_BUDGET")) budget = strtoull(e, nullptr, 10);  // tests of the fallback
