@@ -35,7 +35,7 @@ def _check(ctx, oracle, seq, off, k, drlevel):
     return got
 
 
-@pytest.mark.parametrize("k,drlevel", [(21, 3), (22, 3), (19, 3), (21, 4), (31, 3), (25, 3)])
+@pytest.mark.parametrize("k,drlevel", [(21, 3), (22, 3), (19, 3), (21, 4), (31, 3), (25, 3), (17, 3), (23, 3), (27, 3)])
 def test_kssd_matches_oracle(ctx, oracle, k, drlevel):
     rng = np.random.default_rng(k * 10 + drlevel)
     seq, off = _genomes(rng, [600_000, 250_001, 30_720, 10, 0, 123_456], n_rate=0.001)
