@@ -117,6 +117,18 @@ int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uint64_t* h
 int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uint64_t* h_off, uint32_t n,
                         int kmer_size, int drlevel, const int32_t* h_shuffled_dim, void* d_out,
                         uint32_t stride, uint32_t* d_cnt, int* width_out, uint32_t* h_need);
+/* The same sketches straight from a batch in the 2-bit staging format (see rtc_unpack_bases_dev for the layout): the
+ * records sketchFileWithKssd walks (src/SketchInfo.cpp:1120-1166) as they crossed PCIe, 0.25 B per base read once, no
+ * ASCII copy in HBM.  d_packed (16-byte aligned) holds n_bases / 4 bytes, n_bases a multiple of 64; d_runs[2 r],
+ * d_runs[2 r + 1] = start and length of run r of characters outside ACGT, ascending by start and disjoint -- a k-mer
+ * counts exactly when none of its characters lies in a run (:1136-1139, :1160-1164) nor outside its genome's
+ * [h_off[g], h_off[g + 1]).  Everything else as rtc_sketch_kssd_dev, whose results it reproduces bit for bit.
+ * Returns RTC_ERR_UNSUPPORTED outside the prefilter kernel's configurations (17 <= kmer_size <= 28 with half_subk = 6,
+ * i.e. drlevel <= 4): callers then expand the batch with rtc_unpack_bases_dev and call rtc_sketch_kssd_dev. */
+int rtc_sketch_kssd_packed_dev(rtc_ctx* ctx, const uint8_t* d_packed, uint64_t n_bases, const uint64_t* d_runs,
+                               uint64_t n_runs, const uint64_t* h_off, uint32_t n, int kmer_size, int drlevel,
+                               const int32_t* h_shuffled_dim, void* d_out, uint32_t stride, uint32_t* d_cnt,
+                               int* width_out, uint32_t* h_need);
 
 /* ---- all-pairs sorted-sketch intersection ----------------------------------------------- */
 /* common[i][j] = |A_i ∩ A_j| for i in [row0,row1), j in [col0,col1): the integers that

@@ -68,6 +68,8 @@ SIGNATURES = {
     "rtc_sketch_minhash_dev": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _vp, _u32, _vp, _u32, _vp]),
     "rtc_sketch_kssd_dev": (_i, [_vp, _vp, _vp, _u32, _i, _i, _vp, _vp, _u32, _vp,
                                  C.POINTER(_i), C.POINTER(_u32)]),
+    "rtc_sketch_kssd_packed_dev": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u32, _i, _i, _vp, _vp, _u32, _vp,
+                                        C.POINTER(_i), C.POINTER(_u32)]),
     "rtc_pair_common_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _u64,
                                  _i, _i]),
     "rtc_pair_mash_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u64]),

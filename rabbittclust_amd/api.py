@@ -200,6 +200,34 @@ class Context:
         start = torch.arange(n, dtype=torch.int64, device=self.device) * stride
         return SketchSet(out.view(-1), start, cnt[:n], int(width.value), half_k * 2, "kssd")
 
+    def sketch_kssd_packed(self, packed, n_bases, runs, off, shuffled_dim, kmer_size=21, drlevel=3, stride=None):
+        """sketch_kssd over a batch in the 2-bit staging format: `packed` uint8 device tensor of n_bases / 4 bytes,
+        `runs` int64 device tensor of (start, length) pairs (ascending, disjoint) for everything outside ACGT."""
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        sd = np.ascontiguousarray(shuffled_dim, dtype=np.int32)
+        half_k = (kmer_size + 1) // 2
+        use64 = half_k - drlevel > 8
+        maxlen = int((off[1:] - off[:-1]).max()) if n else 0
+        if stride is None:
+            stride = int(maxlen / (16 ** drlevel) * 1.5) + 256
+        n_runs = int(runs.numel() // 2) if runs is not None else 0
+        while True:
+            out = torch.empty((max(n, 1), stride), dtype=torch.int64 if use64 else torch.int32, device=self.device)
+            cnt = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+            width = C.c_int()
+            need = C.c_uint32()
+            st = self.lib.rtc_sketch_kssd_packed_dev(self.h, _t_ptr(packed), int(n_bases), _t_ptr(runs) if n_runs else None,
+                                                     n_runs, _np_ptr(off), n, kmer_size, drlevel, _np_ptr(sd), _t_ptr(out),
+                                                     stride, _t_ptr(cnt), C.byref(width), C.byref(need))
+            if st == _lib.RTC_ERR_OVERFLOW:
+                stride = int(need.value) + 64
+                continue
+            self.check(st)
+            break
+        start = torch.arange(n, dtype=torch.int64, device=self.device) * stride
+        return SketchSet(out.view(-1), start, cnt[:n], int(width.value), half_k * 2, "kssd")
+
     # ---- all pairs ----------------------------------------------------------------------------
     def pair_common(self, sk, row0=0, row1=None, col0=0, col1=None, lower_only=False, algo=0, out=None):
         n = sk.n

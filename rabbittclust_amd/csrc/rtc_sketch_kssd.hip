@@ -668,6 +668,267 @@ __global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_bloom_kernel(co
   }
 }
 
+// ---- the same prefilter over the command lines' 2-bit staging format (rtc_unpack.hip: base i at bits 2 (i & 3) of byte
+// i >> 2, BaseMap codes; everything that is not ACGT -- N, IUPAC codes, record separators, the gaps between genomes --
+// listed as runs (start, length), ascending and disjoint) ------------------------------------------------------------------
+// The batch is sketched as it crossed PCIe: 0.25 B per base read once, no ASCII copy in HBM, no character decode.  A lane
+// holds 64 bases (one 16-byte load: a wave takes 4 096 bases per step); its four words are turned into the filters'
+// alphabet and order with five instructions each (v_bfrev puts the first base on top, the Gray code of a code b is
+// b ^ (b >> 1)), the bases in front of a word come from the lane's own previous word or, for its first, from the
+// neighbour lane (DPP).  Stage 1, the queues and stage 2 are those of the ASCII kernel.  The exact drain takes the
+// K + 3 codes of a queued dword from the packed stream and asks the run list whether a k-mer's window touches a run
+// (the last run that starts at or before the k-mer's end must have ended before its first base): a k-mer is valid in
+// the reference (:1136-1139, :1160-1164) exactly when none of its K characters is outside ACGT.
+struct PackedBatch {
+  const uint8_t* bytes;      // packed bases
+  uint64_t n_bases;          // bases the buffer holds (a multiple of 64)
+  const uint64_t* runs;      // (start, length) pairs
+  const uint2* seg_runs;     // per segment: the runs [x, y) that can touch a k-mer the segment owns (packed_seg_runs_kernel)
+};
+
+// per segment, the first run that ends behind s_begin - (K - 1) and the first that starts at or behind s_end: the exact
+// drain looks a window up among these only (none for most segments of a finished genome)
+__global__ __launch_bounds__(256) void packed_seg_runs_kernel(const KSegment* __restrict__ segs, uint32_t nseg, const uint64_t* __restrict__ runs,
+                                                              uint32_t n_runs, int K, uint2* __restrict__ seg_runs) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseg) return;
+  const int64_t first = (int64_t)segs[s].s_begin - (K - 1), end = (int64_t)segs[s].s_end;
+  uint32_t lo = 0, hi = n_runs;  // runs that end at or before `first` (ends ascend with the starts: the runs are disjoint)
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((int64_t)(runs[2 * (uint64_t)mid] + runs[2 * (uint64_t)mid + 1]) <= first) lo = mid + 1; else hi = mid; }
+  const uint32_t x = lo;
+  hi = n_runs;                   // runs that start before `end`
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((int64_t)runs[2 * (uint64_t)mid] < end) lo = mid + 1; else hi = mid; }
+  seg_runs[s] = make_uint2(x, lo);
+}
+
+// is [first, last] free of the runs [rlo, rhi)?  (ascending by start, disjoint; the runs in front of rlo end at or before first)
+__device__ __forceinline__ bool window_valid(const uint64_t* __restrict__ runs, uint32_t rlo, uint32_t rhi, int64_t first, int64_t last) {
+  uint32_t lo = rlo, hi = rhi;  // -> the number of runs that start at or before `last`
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((int64_t)runs[2 * (uint64_t)mid] <= last) lo = mid + 1; else hi = mid; }
+  if (lo == rlo) return true;
+  return (int64_t)(runs[2 * (uint64_t)(lo - 1)] + runs[2 * (uint64_t)(lo - 1) + 1]) <= first;
+}
+
+// n <= 64 queued dwords wq[first .. first + n), one per lane.  The K + 3 codes that end the dword's four k-mers (at most 62
+// bits) are taken from the stream again at their own alignment; the forward strand of all of them is the stream bit-reversed
+// with the two bits of every base put back in order, the reverse complement is the stream inverted as it lies (the reference
+// appends complements from the top, :1135: a k-mer's first base ends up lowest).  What the characters were is the run list's
+// business: a lane whose whole stretch is clear of runs (nearly all) asks once, the others once per k-mer.
+template <int K>
+__device__ __forceinline__ void packed_drain(const PackedBatch& B, uint2 sr, const BloomSeg& sg, const KssdParams& P,
+                                             const uint32_t* __restrict__ g_bk, const uint16_t* __restrict__ g_rank, int var,
+                                             lds_u32_ptr wq, uint32_t first, uint32_t n, uint32_t lane, void* orow,
+                                             uint32_t* ocnt, uint32_t stride) {
+  constexpr int NB = K + 3;  // bases walked: the first k-mer's first .. the last k-mer's last
+  const bool have = lane < n;
+  const int64_t q0 = (int64_t)sg.base + (have ? 4 * (int64_t)wq[first + lane] : 0);  // first base of the dword
+  const int64_t b0 = q0 - (K - 1);                                                    // first base of its first k-mer
+  const int64_t s0 = b0 < 0 ? 0 : b0;
+  uint32_t w[3] = {0u, 0u, 0u};
+  if (have) {
+    const uint64_t nbytes = B.n_bases / 4;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const uint64_t byte = ((uint64_t)(s0 >> 4) + j) * 4;
+      if (byte + 4 <= nbytes) w[j] = *reinterpret_cast<const uint32_t*>(B.bytes + byte);
+    }
+  }
+  const uint32_t sh = 2u * (uint32_t)(s0 & 15);  // bits in front of base s0 in w[0]
+  uint64_t X = ((uint64_t)__builtin_amdgcn_alignbit(w[2], w[1], sh) << 32) | __builtin_amdgcn_alignbit(w[1], w[0], sh);  // base s0 + t at bits 2 t
+  if (b0 < 0) X = b0 > -4 ? X << (2 * (uint32_t)(-b0)) : 0;  // (k-mers that begin in front of the batch are never owned)
+  const uint64_t Y = __brevll(X);
+  const uint64_t F = ((Y & 0x5555555555555555ull) << 1) | ((Y >> 1) & 0x5555555555555555ull);  // base t at bits [62 - 2 t, 64 - 2 t)
+  const uint64_t R = ~X;
+  const bool clean = have && window_valid(B.runs, sr.x, sr.y, b0, b0 + NB - 1);
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const int64_t pos = q0 + b;  // the k-mer of bases b .. b + K - 1 of the stretch ends here
+    bool ok = have && pos >= (int64_t)sg.s_begin && pos < (int64_t)sg.s_end && pos - (K - 1) >= (int64_t)sg.g_begin && pos < (int64_t)sg.g_end;
+    if (ok && !clean) ok = window_valid(B.runs, sr.x, sr.y, pos - (K - 1), pos);                  // :1136-1139, :1160-1164
+    const uint64_t tuple = (F >> (64 - 2 * (b + K))) & P.tupmask;                                 // :1134
+    const uint64_t rvs = (R >> (2 * b)) & P.tupmask;                                              // :1135
+    bloom_emit(ok, tuple < rvs ? tuple : rvs, P, g_bk, g_rank, var, lane, orow, ocnt, stride);   // :1141
+  }
+}
+
+// 16 packed bases (first base in the low bits, BaseMap codes) -> first base on top, Gray codes: the filters' word
+__device__ __forceinline__ uint32_t packed_word(uint32_t x) {
+  const uint32_t y = __brev(x);  // pairs in order, the two bits of a pair swapped: (lo, hi)
+  return ((y & 0x55555555u) << 1) | (((y >> 1) ^ y) & 0x55555555u);  // (hi, lo ^ hi)
+}
+
+constexpr int PCHUNK = 4096;   // bases a wave takes per step of the packed kernel (64 lanes x 64)
+constexpr int PQ_SPAN = 63;    // chunks on one queue base: 63 * 1024 + 1023 dwords < 2^16
+
+template <int K>
+__global__ __launch_bounds__(WGB, WGB_WAVES_EU) void sketch_kssd_packed_kernel(PackedBatch B, const KSegment* __restrict__ segs, KssdParams P,
+                                                               const uint32_t* __restrict__ g_bloom, const uint32_t* __restrict__ g_bk,
+                                                               const uint16_t* __restrict__ g_rank, int var, void* __restrict__ out,
+                                                               uint32_t stride, uint32_t* __restrict__ cnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert(K % 2 == 0 && K >= 18 && K <= 28, "24-bit dim_id in the middle of at most 28 bases");
+  constexpr int DS = K - 12;
+  constexpr bool NARROW = DS >= 8 && DS <= 10;
+  constexpr int FO0 = NARROW ? DS - 2 : 6;
+  constexpr int AHEAD = 2;
+  const KSegment sg = segs[blockIdx.x];
+  const int t = threadIdx.x;
+  const uint32_t lane = t & 63;
+  {
+    uint4* l4 = reinterpret_cast<uint4*>(smem);
+    const uint4* g4 = reinterpret_cast<const uint4*>(g_bloom);
+    for (int i = t; i < BLOOM_BYTES / 16; i += WGB) l4[i] = g4[i];
+    __syncthreads();
+  }
+  if ((uint32_t)(uintptr_t)(RTC_LDS unsigned char*)smem != 0u) __builtin_trap();  // the filters are addressed absolutely
+  void* orow = reinterpret_cast<unsigned char*>(out) + (uint64_t)sg.genome * stride * (P.use64 ? 8 : 4);
+  uint32_t* ocnt = cnt + sg.genome;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const lds_q1_ptr q1 = (lds_q1_ptr)(uintptr_t)(BLOOM_BYTES + wv * Q1_CAP * 8);
+  const lds_u32_ptr wq = (lds_u32_ptr)(uintptr_t)(BLOOM_BYTES + Q1_BYTES + wv * BQ_CAP * (int)sizeof(bq_t));
+  uint32_t q1n = 0, qn = 0;
+  BloomSeg bs{sg.g_begin, sg.g_end, sg.s_begin, sg.s_end, 0};
+  const uint2 srange = B.seg_runs[blockIdx.x];
+  int cq = 0;
+
+  const int64_t A0 = (int64_t)(sg.s_begin & ~(uint64_t)(PCHUNK - 1));
+  const int64_t NC = ((int64_t)sg.s_end - A0 + PCHUNK - 1) / PCHUNK;
+  int c = (int)(NC * wv / (WGB / 64));
+  const int c1 = (int)(NC * (wv + 1) / (WGB / 64));
+  const int64_t nbytes = (int64_t)(B.n_bases / 4);
+
+  auto fetch = [&](int ci) -> uint4 {  // the lane's 64 bases of chunk ci (zeros outside the buffer: candidates at most, dropped later)
+    const int64_t byte = (A0 + (int64_t)ci * PCHUNK) / 4 + 16 * (int64_t)lane;
+    if (byte < 0 || byte + 16 > nbytes) return make_uint4(0u, 0u, 0u, 0u);
+    return *reinterpret_cast<const uint4*>(B.bytes + byte);
+  };
+  // the word E of dword qd of the lane's word j: G = the lane's four words, P3 / P2 = the last two words of the lane below
+  auto word_of = [&](int j, int qd, const uint32_t* G, uint32_t P3, uint32_t P2) -> uint32_t {
+    const uint32_t W = G[j], Wp = j >= 1 ? G[j - 1] : P3, Wpp = j >= 2 ? G[j - 2] : (j == 1 ? P3 : P2);
+    if (NARROW) return qd ? __builtin_amdgcn_alignbit(Wp, W, 32 - 8 * qd) : Wp;
+    const int sft = 24 - 8 * qd + DS;
+    return sft == 0 ? W : sft < 32 ? __builtin_amdgcn_alignbit(Wp, W, sft) : sft == 32 ? Wp : __builtin_amdgcn_alignbit(Wpp, Wp, sft - 32);
+  };
+  auto map_word = [&](uint32_t E) -> uint32_t { return *(const RTC_LDS uint32_t*)(uintptr_t)((E >> (FO0 + 3)) & 0x7ffcu); };
+
+  uint32_t carry3 = 0, carry2 = 0;  // words 3 and 2 of lane 63 of the previous chunk
+  bool primed = false;
+  int careful = -1;                 // >= 0: dword `careful` (0 .. 15 = 4 j + qd) of chunk c is next, one per round
+  for (;;) {
+    const bool flush = c >= c1 || c - cq >= PQ_SPAN;
+    for (;;) {
+      if (qn >= 64 || (flush && qn && q1n == 0)) {
+        const uint32_t n = qn < 64 ? qn : 64;
+        packed_drain<K>(B, srange, bs, P, g_bk, g_rank, var, wq, qn - n, n, lane, orow, ocnt, stride);
+        qn -= n;
+      } else if (q1n >= 64 || (flush && q1n)) {
+        const uint32_t n = q1n < 64 ? q1n : 64;
+        q1n -= n;
+        qn = bloom_stage2<K>(q1 + q1n, n, lane, wq, qn, bs);
+      } else {
+        break;
+      }
+    }
+    if (c >= c1) break;
+    if (qn == 0 && q1n == 0) { cq = c; bs.base = (uint64_t)(A0 + (int64_t)c * PCHUNK); }
+    if (careful >= 0) {
+      const uint4 db = fetch(c - 1), dc = fetch(c);
+      const uint32_t G[4] = {packed_word(dc.x), packed_word(dc.y), packed_word(dc.z), packed_word(dc.w)};
+      const uint32_t b3 = packed_word(db.w), b2 = packed_word(db.z);
+      const uint32_t P3 = from_lane_below(G[3], __builtin_amdgcn_readlane(b3, 63)), P2 = from_lane_below(G[2], __builtin_amdgcn_readlane(b2, 63));
+      uint32_t E = 0;
+#pragma unroll
+      for (int i = 0; i < 16; i++) if (careful == i) E = word_of(i >> 2, i & 3, G, P3, P2);
+      const bool pass = ((map_word(E) >> ((E >> FO0) & 31u)) & 1u) != 0u;
+      const uint64_t bal = __ballot(pass);
+      if (pass) {
+        u32x2 ent;
+        ent.x = E;
+        ent.y = ((uint32_t)(c - cq) << 10) + 16u * lane + (uint32_t)careful;
+        q1[q1n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = ent;
+      }
+      q1n += (uint32_t)__popcll(bal);
+      if (++careful == 16) {
+        careful = -1;
+        carry3 = __builtin_amdgcn_readlane(G[3], 63);
+        carry2 = __builtin_amdgcn_readlane(G[2], 63);
+        primed = true;
+        c++;
+      }
+      continue;
+    }
+    if (!primed) {
+      const uint4 db = fetch(c - 1);
+      carry3 = __builtin_amdgcn_readlane(packed_word(db.w), 63);
+      carry2 = __builtin_amdgcn_readlane(packed_word(db.z), 63);
+      primed = true;
+    }
+    uint4 D[AHEAD];
+#pragma unroll
+    for (int j = 0; j < AHEAD; j++) D[j] = c + j < c1 ? fetch(c + j) : make_uint4(0u, 0u, 0u, 0u);
+    bool stop = false;
+    while (!stop) {
+#pragma unroll
+      for (int u = 0; u < AHEAD; u++) {
+        if (c >= c1 || qn >= 64u || c - cq >= PQ_SPAN) { stop = true; break; }
+        const uint32_t G[4] = {packed_word(D[u].x), packed_word(D[u].y), packed_word(D[u].z), packed_word(D[u].w)};
+        if (c + AHEAD < c1) {
+          __builtin_amdgcn_sched_barrier(0);
+          D[u] = fetch(c + AHEAD);
+        }
+        const uint32_t P3 = from_lane_below(G[3], carry3);
+        uint32_t P2 = 0;
+        if (!NARROW) P2 = from_lane_below(G[2], carry2);
+        const uint32_t relc = ((uint32_t)(c - cq) << 10) + 16u * lane;
+        bool spill = false;  // wave-uniform: a word's survivors would not fit the stage-1 queue
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          uint32_t E[4], mw[4], pv[4];
+          uint64_t bal[4];
+#pragma unroll
+          for (int qd = 0; qd < 4; qd++) { E[qd] = word_of(j, qd, G, P3, P2); mw[qd] = map_word(E[qd]); }
+          uint32_t total = 0;
+#pragma unroll
+          for (int qd = 0; qd < 4; qd++) {
+            pv[qd] = __builtin_amdgcn_ubfe(mw[qd], E[qd] >> FO0, 1u);
+            bal[qd] = __ballot(pv[qd] != 0u);
+            total += (uint32_t)__popcll(bal[qd]);
+          }
+          if (q1n + total >= (uint32_t)Q1_CAP) { careful = 4 * j; spill = true; break; }  // dwords 0 .. 4 j - 1 of the chunk are queued
+#pragma unroll
+          for (int qd = 0; qd < 4; qd++) {
+            if (pv[qd] != 0u) {
+              u32x2 ent;
+              ent.x = E[qd];
+              ent.y = relc + 4 * j + qd;
+              q1[q1n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[qd] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[qd], 0u))] = ent;
+            }
+            q1n += (uint32_t)__popcll(bal[qd]);
+          }
+          if (q1n >= 64) {
+            if (qn >= 64u) { careful = 4 * j + 4; spill = true; break; }  // the exact-drain queue is served first: the rest of the chunk one dword per round
+            q1n -= 64;
+            qn = bloom_stage2<K>(q1 + q1n, 64, lane, wq, qn, bs);
+          }
+        }
+        if (spill) {
+          if (careful >= 16) {  // the chunk was complete after all
+            careful = -1;
+            carry3 = __builtin_amdgcn_readlane(G[3], 63);
+            carry2 = __builtin_amdgcn_readlane(G[2], 63);
+            c++;
+          }
+          stop = true;
+          break;
+        }
+        carry3 = __builtin_amdgcn_readlane(G[3], 63);
+        if (!NARROW) carry2 = __builtin_amdgcn_readlane(G[2], 63);
+        c++;
+      }
+    }
+  }
+}
+
 // One WAVE per genome for rows of at most 64 * NPER tuples (a 2 Mbp genome at drlevel 3 yields ~490, a 5 Mbp one ~1 200):
 // element e = 64 r + lane sits in register r of its lane, the bitonic network exchanges across lanes with a wave shuffle
 // while the distance is below 64 and between registers of one lane above -- no LDS, no workgroup barrier (the LDS
@@ -1003,9 +1264,12 @@ static int kssd_sort_big_rows(rtc_ctx* ctx, void* d_out, uint32_t stride, uint32
   return RTC_OK;
 }
 
-extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uint64_t* h_off, uint32_t n,
-                                   int kmer_size, int drlevel, const int32_t* h_shuffled_dim, void* d_out,
-                                   uint32_t stride, uint32_t* d_cnt, int* width_out, uint32_t* h_need) {
+// the batch in the staging format (rtc_sketch_kssd_packed_dev); d_seq then holds the packed bases
+struct PackedArgs { uint64_t n_bases; const uint64_t* d_runs; uint64_t n_runs; };
+
+static int sketch_kssd_impl(rtc_ctx* ctx, const uint8_t* d_seq, const PackedArgs* pk, const uint64_t* h_off, uint32_t n,
+                            int kmer_size, int drlevel, const int32_t* h_shuffled_dim, void* d_out,
+                            uint32_t stride, uint32_t* d_cnt, int* width_out, uint32_t* h_need) {
   if (!ctx || !h_off || !h_shuffled_dim || !width_out || (n && (!d_seq || !d_out || !d_cnt))) return RTC_ERR_ARG;
   if (kmer_size < 2 || kmer_size > 32) return rtc_fail(ctx, RTC_ERR_ARG, "kmer_size=%d outside 2..32", kmer_size);
   if (drlevel < 0 || drlevel > 8) return rtc_fail(ctx, RTC_ERR_ARG, "drlevel=%d outside 0..8", drlevel);
@@ -1036,7 +1300,9 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   P.dimbits = 4 * half_subk;
   P.dim_end = dim_end;
   if (n == 0) return RTC_OK;
-  if (((uintptr_t)d_seq & 15) != 0) return rtc_fail(ctx, RTC_ERR_ARG, "d_seq must be 16-byte aligned");
+  if (((uintptr_t)d_seq & 15) != 0) return rtc_fail(ctx, RTC_ERR_ARG, "the sequence buffer must be 16-byte aligned");
+  if (pk && ((pk->n_bases & 63) || pk->n_runs >> 32 || (pk->n_runs && !pk->d_runs)))
+    return rtc_fail(ctx, RTC_ERR_ARG, "packed batch: n_bases must be a multiple of 64, fewer than 2^32 runs");
   RTC_HIP(ctx, hipSetDevice(ctx->device));
 
   // ---- filter structures (cached in the context: one host thread per context, freed with it) ----
@@ -1174,8 +1440,13 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   }
   // prefilter kernel: dim_id of 24 bits in the middle of at most 28 bases
   const bool use_bucket = kc.bvar >= 0 && K >= 18 && K <= 28;
+  if (pk) {
+    if (!(use_bucket && kc.d_bloom))
+      return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "packed input is sketched by the prefilter kernel only (k 17..28, drlevel <= 4): unpack the batch (rtc_unpack_bases_dev) for k=%d, drlevel=%d", kmer_size, drlevel);
+    if (h_off[n] > pk->n_bases) return rtc_fail(ctx, RTC_ERR_ARG, "offsets reach %llu, the batch holds %llu bases", (unsigned long long)h_off[n], (unsigned long long)pk->n_bases);
+  }
   uint64_t seg_len = total / ((uint64_t)ctx->num_cu * 12);
-  const uint64_t min_seg = use_bucket ? (uint64_t)(WGB / 64) * CHUNK * 16 : 4ull * TILE_BASES_MAX;  // >= 16 chunks per wave
+  const uint64_t min_seg = pk ? (uint64_t)(WGB / 64) * PCHUNK * 8 : use_bucket ? (uint64_t)(WGB / 64) * CHUNK * 16 : 4ull * TILE_BASES_MAX;  // >= 16 (8) chunks per wave
   if (seg_len < min_seg) seg_len = min_seg;
   std::vector<KSegment> segs;
   segs.reserve(n + 1024);
@@ -1205,7 +1476,30 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   P.m2key = (1u << (P.dimbits - P.ck2 + 1)) - 1u;
   const uint32_t* d_t2 = kc.d_index ? d_t1 + ((size_t)1 << kc.ck1) : nullptr;
   const size_t lds = lds_index ? (((size_t)1 << kc.ck1) + ((size_t)1 << kc.ck2)) * 4 : 16;
-  if (use_bucket && kc.d_bloom) {
+  if (pk) {
+    if (getenv("RTC_VERBOSE")) fprintf(stderr, "[kssd] forward-strand prefilter over packed bases, K=%d, %zu segments, %llu runs\n", K, segs.size(), (unsigned long long)pk->n_runs);
+    void* ws4 = nullptr;
+    RTC_TRY(rtc_ws(ctx, 4, segs.size() * sizeof(uint2) + 64, &ws4));
+    hipLaunchKernelGGL(packed_seg_runs_kernel, dim3((uint32_t)((segs.size() + 255) / 256)), dim3(256), 0, ctx->stream, (const KSegment*)ws0,
+                       (uint32_t)segs.size(), pk->d_runs, (uint32_t)pk->n_runs, K, (uint2*)ws4);
+    RTC_CHECK_LAUNCH(ctx);
+    const PackedBatch B{d_seq, pk->n_bases, pk->d_runs, (const uint2*)ws4};
+    const uint32_t* d_bk = (const uint32_t*)kc.d_bucket;
+    const uint16_t* d_rk = (const uint16_t*)((const char*)kc.d_bucket + BUCKET_BYTES);
+    const int lds_bl = BLOOM_BYTES + Q1_BYTES + BQ_BYTES;
+#define LAUNCH_PACKED(KK)                                                                                             \
+  case KK: {                                                                                                         \
+    auto kern = sketch_kssd_packed_kernel<KK>;                                                                       \
+    RTC_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bl));        \
+    hipLaunchKernelGGL(kern, dim3((uint32_t)segs.size()), dim3(WGB), lds_bl, ctx->stream, B, (const KSegment*)ws0, P,  \
+                       (const uint32_t*)kc.d_bloom, d_bk, d_rk, kc.bvar, d_out, stride, d_cnt);                       \
+  } break
+    switch (K) {
+      LAUNCH_PACKED(18); LAUNCH_PACKED(20); LAUNCH_PACKED(22); LAUNCH_PACKED(24); LAUNCH_PACKED(26); LAUNCH_PACKED(28);
+      default: return rtc_fail(ctx, RTC_ERR_ARG, "K=%d", K);
+    }
+#undef LAUNCH_PACKED
+  } else if (use_bucket && kc.d_bloom) {
     P.nofast = getenv("RTC_KSSD_NOFAST") ? atoi(getenv("RTC_KSSD_NOFAST")) : 0;
     if (getenv("RTC_VERBOSE")) fprintf(stderr, "[kssd] forward-strand prefilter, K=%d, %zu segments\n", K, segs.size());
     const uint32_t* d_bk = (const uint32_t*)kc.d_bucket;  // the exact index (variant kc.bvar) serves the drain from global memory
@@ -1273,4 +1567,18 @@ extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uin
   RTC_CHECK_LAUNCH(ctx);
   if (h_max > (uint32_t)cap) RTC_TRY(kssd_sort_big_rows(ctx, d_out, stride, d_cnt, n, use64, cap));
   return RTC_OK;
+}
+
+extern "C" int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uint64_t* h_off, uint32_t n,
+                                   int kmer_size, int drlevel, const int32_t* h_shuffled_dim, void* d_out,
+                                   uint32_t stride, uint32_t* d_cnt, int* width_out, uint32_t* h_need) {
+  return sketch_kssd_impl(ctx, d_seq, nullptr, h_off, n, kmer_size, drlevel, h_shuffled_dim, d_out, stride, d_cnt, width_out, h_need);
+}
+
+extern "C" int rtc_sketch_kssd_packed_dev(rtc_ctx* ctx, const uint8_t* d_packed, uint64_t n_bases, const uint64_t* d_runs,
+                                          uint64_t n_runs, const uint64_t* h_off, uint32_t n, int kmer_size, int drlevel,
+                                          const int32_t* h_shuffled_dim, void* d_out, uint32_t stride, uint32_t* d_cnt,
+                                          int* width_out, uint32_t* h_need) {
+  const PackedArgs pk{n_bases, d_runs, n_runs};
+  return sketch_kssd_impl(ctx, d_packed, &pk, h_off, n, kmer_size, drlevel, h_shuffled_dim, d_out, stride, d_cnt, width_out, h_need);
 }

@@ -424,6 +424,10 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   struct Placed { uint32_t row0, rows; int gpu; };  // where a batch's sketches live (share step)
   vector<Placed> placed;
 
+  // KSSD over packed staging: the prefilter kernel reads the 2-bit stream itself (rtc_sketch_kssd_packed_dev) for the
+  // k-mer lengths it covers; RTC_KSSD_UNPACK=1 expands every batch first (the former path; tests compare the two)
+  std::atomic<bool> kssd_direct{job.kssd && packed && getenv("RTC_KSSD_UNPACK") == nullptr && half_subk == 6 &&
+                                (job.kmerSize + 1) / 2 * 2 >= 18 && (job.kmerSize + 1) / 2 * 2 <= 28};
   // ---- GPU side of one batch (runs on that GPU's host thread while the next batch is parsed) ----
   // row0 < 0: not resident (retry round), results only go to the host vectors.
   auto gpu_batch = [&](Lane& ln, const Batch& b, const char* h_seq, const vector<uint64_t>* h_runs, long row0) {
@@ -450,7 +454,8 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       }
       CHECK(c, rtc_copy_h2d(c, ln.d_packed, h_seq, b.bytes / 4 + 16));
       CHECK(c, rtc_copy_h2d(c, ln.d_runs, h_runs->data(), nr * 16));
-      CHECK(c, rtc_unpack_bases_dev(c, (const uint8_t*)ln.d_packed, b.bytes + 64, (const uint64_t*)ln.d_runs, nr, (uint8_t*)ln.d_seq));
+      if (!kssd_direct.load())
+        CHECK(c, rtc_unpack_bases_dev(c, (const uint8_t*)ln.d_packed, b.bytes + 64, (const uint64_t*)ln.d_runs, nr, (uint8_t*)ln.d_seq));
     } else {
       CHECK(c, rtc_copy_h2d(c, ln.d_seq, h_seq, b.bytes + 64));
     }
@@ -479,8 +484,21 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       }
       while (true) {
         int width = 0; uint32_t need = 0;
-        int st = rtc_sketch_kssd_dev(c, (const uint8_t*)ln.d_seq, off.data(), nb, job.kmerSize, job.drlevel, shuffled.data(),
-                                     d_out, stride, d_cnt, &width, &need);
+        int st;
+        if (kssd_direct.load()) {
+          // the batch is sketched as it crossed PCIe; configurations the packed kernel does not serve (a shuffle table
+          // its exact index cannot hold) are expanded in HBM after all, from here on for every batch
+          st = rtc_sketch_kssd_packed_dev(c, (const uint8_t*)ln.d_packed, b.bytes + 64, (const uint64_t*)ln.d_runs, h_runs->size() / 2,
+                                          off.data(), nb, job.kmerSize, job.drlevel, shuffled.data(), d_out, stride, d_cnt, &width, &need);
+          if (st == RTC_ERR_UNSUPPORTED) {
+            kssd_direct.store(false);
+            CHECK(c, rtc_unpack_bases_dev(c, (const uint8_t*)ln.d_packed, b.bytes + 64, (const uint64_t*)ln.d_runs, h_runs->size() / 2, (uint8_t*)ln.d_seq));
+            continue;
+          }
+        } else {
+          st = rtc_sketch_kssd_dev(c, (const uint8_t*)ln.d_seq, off.data(), nb, job.kmerSize, job.drlevel, shuffled.data(),
+                                   d_out, stride, d_cnt, &width, &need);
+        }
         if (st == RTC_ERR_OVERFLOW) {
           // a genome with more tuples than a resident row: this batch goes to a wider temporary buffer and
           // the run falls back to the host vectors (the other batches are pulled from HBM at the end)
