@@ -202,7 +202,10 @@ class Context:
 
     def sketch_kssd_packed(self, packed, n_bases, runs, off, shuffled_dim, kmer_size=21, drlevel=3, stride=None):
         """sketch_kssd over a batch in the 2-bit staging format: `packed` uint8 device tensor of n_bases / 4 bytes,
-        `runs` int64 device tensor of (start, length) pairs (ascending, disjoint) for everything outside ACGT."""
+        `runs` int64 device tensor of (start, length) pairs (ascending, disjoint) for everything outside ACGT.
+        (`packed` may be a PackedBatch; n_bases and runs are then taken from it.)"""
+        if isinstance(packed, PackedBatch):
+            packed, n_bases, runs = packed.packed, packed.n_bases, packed.runs
         off = np.ascontiguousarray(off, dtype=np.uint64)
         n = len(off) - 1
         sd = np.ascontiguousarray(shuffled_dim, dtype=np.int32)
@@ -445,6 +448,44 @@ def mst_distance(common, size0, size1, kmer_size, is_containment):
     if c == 0.0:
         return 1.0
     return -inv_k * math.log(c)
+
+
+class PackedBatch:
+    """A batch in the command lines' 2-bit staging format, resident in HBM (include/rtclust.h, rtc_unpack_bases_dev):
+    `packed` uint8[n_bases / 4], `runs` int64[2 r] = (start, length) of every stretch outside ACGT (ascending)."""
+
+    def __init__(self, packed, n_bases, runs):
+        self.packed, self.n_bases, self.runs = packed, int(n_bases), runs
+
+
+def pack_staging(seq, total):
+    """Characters resident in HBM -> PackedBatch, what the command lines' parser produces on the host (rtc_host.cpp:
+    PackedSink).  Torch plumbing for benchmarks and tests, in pieces that keep the temporaries small; not a product path."""
+    total = int(total)
+    n_bases = (total + 63) // 64 * 64 + 64
+    dev = seq.device
+    packed = torch.empty(n_bases // 4, dtype=torch.uint8, device=dev)
+    runs = []
+    step = 1 << 28
+    for a in range(0, n_bases, step):
+        b = min(a + step, n_bases)
+        x = seq[a:min(b, total)]
+        if x.numel() < b - a:
+            x = torch.cat([x, torch.full((b - a - x.numel(),), ord("N"), dtype=torch.uint8, device=dev)])
+        c = (((x >> 1) ^ (x >> 2)) & 3).view(-1, 4)
+        packed[a // 4:b // 4] = c[:, 0] | (c[:, 1] << 2) | (c[:, 2] << 4) | (c[:, 3] << 6)
+        up = x & 0xDF
+        idx = torch.nonzero(~((up == 65) | (up == 67) | (up == 71) | (up == 84))).view(-1)
+        if idx.numel():
+            first = torch.ones_like(idx, dtype=torch.bool)
+            first[1:] = idx[1:] != idx[:-1] + 1
+            last = torch.ones_like(idx, dtype=torch.bool)
+            last[:-1] = first[1:]
+            starts, ends = idx[first], idx[last] + 1
+            runs.append(torch.stack([starts + a, ends - starts], dim=1).reshape(-1))  # a stretch across a seam: two runs that touch
+        del x, c, up, idx
+    runs = torch.cat(runs).contiguous() if runs else torch.zeros(0, dtype=torch.int64, device=dev)
+    return PackedBatch(packed, n_bases, runs)
 
 
 def synth_family_descs(n_families, per_family, global_seed=42, max_rate=0.08, n_every=0):

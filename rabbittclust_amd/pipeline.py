@@ -160,7 +160,8 @@ def boruvka_rounds(backend, n, comm=None, s_fixed=0):
 
 
 class MstPipeline:
-    """mode "minhash": rtc_sketch_minhash_dev; mode "kssd": rtc_sketch_kssd_dev (--fast, u32/u64 tuples)."""
+    """mode "minhash": rtc_sketch_minhash_dev; mode "kssd": rtc_sketch_kssd_dev (--fast, u32/u64 tuples), or
+    rtc_sketch_kssd_packed_dev when the step is handed an api.PackedBatch instead of characters."""
 
     def __init__(self, ctx, k=21, sketch_size=1000, threshold=0.05, is_containment=False,
                  dist=None, rank=0, world=1, mode="minhash", drlevel=3, shuffled_dim=None, comm=None):
@@ -270,11 +271,18 @@ class MstPipeline:
 
         return self.gather_parts(out, cnt, [(0, split), (split, n_local)], self.k, before_part=sketch_part)
 
+    def _sketch_kssd(self, seq, off):
+        """characters (rtc_sketch_kssd_dev) or a batch in the 2-bit staging format (rtc_sketch_kssd_packed_dev)"""
+        from .api import PackedBatch
+        if isinstance(seq, PackedBatch):
+            return self.ctx.sketch_kssd_packed(seq, None, None, off, self.shuffled_dim, kmer_size=self.k, drlevel=self.drlevel)
+        return self.ctx.sketch_kssd(seq, off, self.shuffled_dim, kmer_size=self.k, drlevel=self.drlevel)
+
     def sketch_kssd_and_gather(self, seq, off):
         """Multi-GPU KSSD (--fast) sketch phase (sketchFileWithKssd on every rank's genomes, then one
         all-gather): sketch sizes vary per genome, so the ranks first agree on the row stride."""
         ctx = self.ctx
-        sk = ctx.sketch_kssd(seq, off, self.shuffled_dim, kmer_size=self.k, drlevel=self.drlevel)
+        sk = self._sketch_kssd(seq, off)
         if not self.comm.active:
             return (lambda: sk), []
         n_local = sk.n
@@ -353,7 +361,7 @@ class MstPipeline:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
         if self.mode == "kssd":
-            loc = ctx.sketch_kssd(seq, off, self.shuffled_dim, kmer_size=self.k, drlevel=self.drlevel)
+            loc = self._sketch_kssd(seq, off)
             ev[1].record()
             n_local = loc.n
             stride = loc.hashes.numel() // max(n_local, 1)

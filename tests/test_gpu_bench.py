@@ -26,9 +26,12 @@ def test_bench_default_line_has_every_extra_without_error(ctx):
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"].get("value"), line["cpu_baseline"]
     assert line["roofline_dist"]["survey_8d_bytes_per_pair"] == 16000.0
     ex = line["extra"]
-    assert set(ex) == {"kssd", "greedy", "weak_first_point", "dense_pairs", "cli"}
+    assert set(ex) == {"kssd", "kssd_packed", "greedy", "weak_first_point", "dense_pairs", "cli"}
     for name, v in ex.items():
         assert "error" not in v, (name, v)
+    # the same genomes sketched from characters and from the 2-bit staging format: same sketches, same forest
+    assert ex["kssd_packed"]["mean_sketch_size"] == ex["kssd"]["mean_sketch_size"] and ex["kssd_packed"]["mst_edges"] == ex["kssd"]["mst_edges"]
+    assert ex["kssd_packed"]["roofline"]["kernel"] == "sketch_kssd_packed_kernel" and ex["kssd_packed"]["roofline"]["physical_frac"] > 0
     d = ex["dense_pairs"]
     assert d["pair_path"] == 2 and d["pair_kernel_ms"] > 0 and d["cand_edges"] >= 10 * 1000 * 999 // 2
     assert d["roofline_dist"]["bytes_per_pair"] == 16000.0 and d["roofline_dist"]["algorithmic_frac"] > 0

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the round's judged profile artifacts on the GPU box (run through gpurun):
-#   1. bench.py JSON lines (minhash N=1 default; --mode kssd)          -> gpurun_out/prof/bench_*.jsonl
+#   1. bench.py JSON lines (minhash N=1 default; --mode kssd [--staging packed])       -> gpurun_out/prof/bench_*.jsonl
 #   2. rocprofv3 --kernel-trace --stats of the same commands            -> gpurun_out/prof/stats*/  (kernel_stats.csv)
 #   3. rocprofv3 --pmc passes (own runs, --pmc only)                     -> gpurun_out/prof/pmc*/  and *_pmc_traffic.json
 #   4. greedy (BASELINE config 4, 50 000 containment sketches) kernel stats + PMC passes of its sketch kernel
@@ -37,6 +37,18 @@ for grp in "${PMCGROUPS[@]}"; do
   timeout 600 rocprofv3 --pmc $grp --output-format csv -d $K/pmc$i -- python $R/bench.py --mode kssd --steps 1 --warmup 0 --no-cpu-baseline > $K/pmc$i.log 2>&1
 done
 python $R/tools/make_pmc_json.py $K ${TAG}_kssd kssd 25000 2000000 > $OUT/${TAG}_kssd_pmc_traffic.json
+# ---- KSSD from the 2-bit staging format (rtc_sketch_kssd_packed_dev), same shape ----
+KP=$OUT/kssd_packed; mkdir -p $KP
+python $R/bench.py --mode kssd --staging packed --steps 3 --warmup 1 > $KP/bench_kssd_packed_n1.jsonl 2> $KP/bench_kssd_packed_n1.err
+tail -c 400 $KP/bench_kssd_packed_n1.jsonl; echo
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $KP/stats -- python $R/bench.py --mode kssd --staging packed --steps 3 --warmup 1 --no-cpu-baseline > $KP/stats.log 2>&1
+python $R/tools/kstats.py $KP/stats | head -8
+i=0
+for grp in "${PMCGROUPS[@]}"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $grp --output-format csv -d $KP/pmc$i -- python $R/bench.py --mode kssd --staging packed --steps 1 --warmup 0 --no-cpu-baseline > $KP/pmc$i.log 2>&1
+done
+python $R/tools/make_pmc_json.py $KP ${TAG}_kssd_packed kssd 25000 2000000 packed > $OUT/${TAG}_kssd_packed_pmc_traffic.json
 # ---- greedy, BASELINE config[3] ----
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/greedy_stats -- python $R/tools/run_configs.py greedy 50000 2000000 > $OUT/greedy.log 2>&1
 tail -3 $OUT/greedy.log
@@ -62,7 +74,7 @@ done
 python $R/tools/make_pmc_json.py $D ${TAG}_dense dense_pairs 10000 500000 > $OUT/${TAG}_dense_pmc_traffic.json
 python - <<PY
 import json
-for f in ("$OUT/${TAG}_pmc_traffic.json", "$OUT/${TAG}_kssd_pmc_traffic.json", "$OUT/${TAG}_greedy_pmc_traffic.json", "$OUT/${TAG}_dense_pmc_traffic.json"):
+for f in ("$OUT/${TAG}_pmc_traffic.json", "$OUT/${TAG}_kssd_pmc_traffic.json", "$OUT/${TAG}_kssd_packed_pmc_traffic.json", "$OUT/${TAG}_greedy_pmc_traffic.json", "$OUT/${TAG}_dense_pmc_traffic.json"):
     d = json.load(open(f))
     for k, v in d["kernels"].items():
         print(k, {a: b for a, b in v.items() if a in ("hbm_bytes_per_launch", "derived")})

@@ -11,6 +11,9 @@ cp $P/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json
 cp $P/kssd/bench_kssd_n1.jsonl $R/profiles/${TAG}_kssd_bench_n1.jsonl
 cp $(ls -t $(find $P/kssd/stats -name "*kernel_stats.csv") | head -1) $R/profiles/${TAG}_kssd_kernel_stats.csv
 cp $P/${TAG}_kssd_pmc_traffic.json $R/profiles/${TAG}_kssd_pmc_traffic.json
+cp $P/kssd_packed/bench_kssd_packed_n1.jsonl $R/profiles/${TAG}_kssd_packed_bench_n1.jsonl
+cp $(ls -t $(find $P/kssd_packed/stats -name "*kernel_stats.csv") | head -1) $R/profiles/${TAG}_kssd_packed_kernel_stats.csv
+cp $P/${TAG}_kssd_packed_pmc_traffic.json $R/profiles/${TAG}_kssd_packed_pmc_traffic.json
 cp $(ls -t $(find $P/greedy_stats -name "*kernel_stats.csv") | head -1) $R/profiles/${TAG}_greedy_kernel_stats.csv
 grep -v "^[EWI]2026\|rocprofv3\|amdgpu.ids" $P/greedy.log > $R/profiles/${TAG}_greedy_run.log
 cp $P/${TAG}_greedy_pmc_traffic.json $R/profiles/${TAG}_greedy_pmc_traffic.json

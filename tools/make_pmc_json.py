@@ -1,11 +1,12 @@
 """Fold the rocprofv3 --pmc CSVs written by tools/collect_profiles.sh into one JSON (per-kernel,
 per-launch counter sums plus the derived figures DESIGN.md quotes).
-Usage: make_pmc_json.py <dir> <tag> [mode genomes length]   (defaults: the bench.py N=1 workload)"""
+Usage: make_pmc_json.py <dir> <tag> [mode genomes length [staging]]   (defaults: the bench.py N=1 workload)"""
 import collections, csv, glob, json, os, sys
 root, tag = sys.argv[1], sys.argv[2]
 MODE = sys.argv[3] if len(sys.argv) > 3 else "minhash"
 G = int(sys.argv[4]) if len(sys.argv) > 4 else 10000
 L = int(sys.argv[5]) if len(sys.argv) > 5 else 5_000_000
+STAGING = sys.argv[6] if len(sys.argv) > 6 else None  # "packed": bench.py --mode kssd --staging packed
 K, S = 21, 1000
 want = ("synth_kernel", "sketch_minhash_kernel", "sketch_kssd", "transpose_slices_kernel", "pair_tiled_kernel", "pair_join_phase")
 JOIN_PARTS = ("rocprim", "join_")  # pair_join_phase = every kernel of the inverted join: rocPRIM sort / scan / encode + join_*
@@ -28,7 +29,7 @@ for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), 
 out = {
     "command": "rocprofv3 --pmc <group> --output-format csv -- python bench.py [--mode kssd] --steps 1 --warmup 0 "
                "--no-cpu-baseline (one run per counter group, tools/collect_profiles.sh)",
-    "workload": {"genomes": G, "length": L, "k": K, "s": S, "mode": MODE},
+    "workload": {"genomes": G, "length": L, "k": K, "s": S, "mode": MODE, **({"staging": STAGING} if STAGING else {})},
     "units": "hbm_bytes_per_launch = fabric-side bytes = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B + 64*WRREQ_64B + "
              "32*(WRREQ - WRREQ_64B), Infinity-Cache hits included (MI355X_MICROARCH.md, HBM section).  FETCH_SIZE / "
              "WRITE_SIZE (1024-byte units) are kept beside them: FETCH_SIZE = RDREQ x 64 B, i.e. half the bytes of "
