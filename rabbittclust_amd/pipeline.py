@@ -159,6 +159,12 @@ def boruvka_rounds(backend, n, comm=None, s_fixed=0):
     return backend.selected(), rounds
 
 
+def _gather_stride(sk):
+    """Row length at which a rank's KSSD sketches travel: its longest sketch, rounded up to 4 tuples (at least 4)."""
+    longest = int(sk.len.max().item()) if sk.n else 0
+    return max(4, (longest + 3) // 4 * 4)
+
+
 class MstPipeline:
     """mode "minhash": rtc_sketch_minhash_dev; mode "kssd": rtc_sketch_kssd_dev (--fast, u32/u64 tuples), or
     rtc_sketch_kssd_packed_dev when the step is handed an api.PackedBatch instead of characters."""
@@ -288,13 +294,16 @@ class MstPipeline:
         n_local = sk.n
         self._check_equal_counts(n_local)
         stride = sk.hashes.numel() // max(n_local, 1)
-        t = torch.tensor([stride], dtype=torch.int64, device=ctx.device)
+        # rows travel at the longest sketch of any rank (a multiple of 4 tuples), not at the allocated stride: the
+        # allocation is 1.5x the expected count + 256, i.e. twice what a 2 Mbp genome yields
+        t = torch.tensor([_gather_stride(sk)], dtype=torch.int64, device=ctx.device)
         self.comm.all_reduce_max(t)
         gstride = int(t.item())
         rows = sk.hashes.view(n_local, stride)
         if gstride != stride:
             wide = torch.zeros((n_local, gstride), dtype=rows.dtype, device=rows.device)
-            wide[:, :stride] = rows
+            m = min(stride, gstride)
+            wide[:, :m] = rows[:, :m]
             rows = wide
         return self.gather_parts(rows, sk.len.contiguous(), [(0, n_local)], sk.k, kind="kssd", width=sk.width)
 
@@ -354,6 +363,56 @@ class MstPipeline:
             raise _lib.RtcError(st, "rtc_edges_to_mst_host")
         return out[: len(sel)]
 
+    def _kssd_sketch_and_gather_native(self, seq, off, ev_sketched):
+        """--fast sketch phase over the C ABI's communicator.  KSSD sketches vary in length, so a part's rows travel at the
+        longest sketch any rank produced for it (agreed with one host all-reduce; the allocation is twice that).  The genomes
+        are sketched in two parts like the MinHash step: the first part's rows travel on the communicator's side stream
+        while the second part is sketched, and the gathered set keeps the two parts as two blocks of rows with a stride
+        each (`start` carries the layout; no copy into a common stride)."""
+        ctx, comm = self.ctx, self.comm.c
+        W, n_local = comm.size, len(off) - 1
+        cut = self.split_point(n_local) if W > 1 else n_local
+        parts = [(0, cut), (cut, n_local)] if 0 < cut < n_local else [(0, n_local)]
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        blocks, width, kk, dt = [], 4, 0, torch.int32
+        for i, (a, b) in enumerate(parts):
+            loc = self._sketch_kssd(seq, off[a:b + 1])
+            if i == len(parts) - 1:
+                ev_sketched.record()
+            m = b - a
+            stride = loc.hashes.numel() // max(m, 1)
+            v = comm.all_reduce_host([_gather_stride(loc), n_local, -n_local, loc.width, -loc.width], "max")
+            if int(v[1]) != n_local or int(-v[2]) != n_local:
+                raise ValueError("multi-GPU step: ranks hold different genome counts")
+            if int(v[3]) != loc.width or int(-v[4]) != loc.width:
+                raise ValueError("multi-GPU step: ranks disagree on the tuple width")
+            g = int(v[0])
+            g_h = torch.empty((W * m, g), dtype=loc.hashes.dtype, device=ctx.device)
+            g_l = torch.empty(W * m, dtype=torch.int32, device=ctx.device)
+            w = min(stride, g)
+            g_h[comm.rank * m:(comm.rank + 1) * m, :w] = loc.hashes.view(m, stride)[:, :w]
+            g_l[comm.rank * m:(comm.rank + 1) * m] = loc.len
+            last = i == len(parts) - 1
+            comm.gather_rows(g_h, m, 0, m, async_=not last)   # the side stream starts behind what the context stream holds so far
+            comm.gather_rows(g_l, m, 0, m, async_=not last)
+            blocks.append((m, g, g_h, g_l))
+            width, kk, dt = loc.width, loc.k, loc.hashes.dtype
+        if len(parts) > 1:
+            comm.wait()
+        if len(blocks) == 1:
+            m, g, g_h, g_l = blocks[0]
+            start = torch.arange(W * m, dtype=torch.int64, device=ctx.device) * g
+            return SketchSet(g_h.view(-1), start, g_l, width, kk, "kssd")
+        # canonical order: genome q of rank r at r * n_local + q; block i holds rank r's part i at rows [r * m_i, (r + 1) * m_i)
+        hashes = torch.cat([blk[2].view(-1) for blk in blocks])
+        starts, lens, base = [], [], 0
+        for m, g, g_h, g_l in blocks:
+            starts.append((torch.arange(W * m, dtype=torch.int64, device=ctx.device) * g + base).view(W, m))
+            lens.append(g_l.view(W, m))
+            base += W * m * g
+        return SketchSet(hashes, torch.cat(starts, dim=1).reshape(-1).contiguous(), torch.cat(lens, dim=1).reshape(-1).contiguous(),
+                         width, kk, "kssd")
+
     # ---- one step ---------------------------------------------------------------------------------
     def step_native(self, seq, off, sizes=None):
         """The step with both multi-GPU phases behind the C ABI (NativeComm)."""
@@ -361,22 +420,7 @@ class MstPipeline:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
         if self.mode == "kssd":
-            loc = self._sketch_kssd(seq, off)
-            ev[1].record()
-            n_local = loc.n
-            stride = loc.hashes.numel() // max(n_local, 1)
-            v = comm.all_reduce_host([stride, n_local, -n_local], "max")
-            if int(v[1]) != n_local or int(-v[2]) != n_local:
-                raise ValueError("multi-GPU step: ranks hold different genome counts")
-            gstride, n = int(v[0]), comm.size * n_local
-            g_h = torch.zeros((n, gstride), dtype=loc.hashes.dtype, device=ctx.device)
-            g_l = torch.zeros(n, dtype=torch.int32, device=ctx.device)
-            g_h[comm.rank * n_local:(comm.rank + 1) * n_local, :stride] = loc.hashes.view(n_local, stride)
-            g_l[comm.rank * n_local:(comm.rank + 1) * n_local] = loc.len
-            comm.gather_rows(g_h, n_local, 0, n_local)
-            comm.gather_rows(g_l, n_local, 0, n_local)
-            start = torch.arange(n, dtype=torch.int64, device=ctx.device) * gstride
-            sk = SketchSet(g_h.view(-1), start, g_l, loc.width, loc.k, "kssd")
+            sk = self._kssd_sketch_and_gather_native(seq, off, ev[1])
         else:
             sk = ctx.sketch_minhash_sharded(comm, seq, off, k=self.k, size=self.s, sizes=sizes)
             ev[1].record()
