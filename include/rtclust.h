@@ -124,7 +124,7 @@ int rtc_sketch_kssd_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uint64_t* h_of
  * counts exactly when none of its characters lies in a run (:1136-1139, :1160-1164) nor outside its genome's
  * [h_off[g], h_off[g + 1]).  Everything else as rtc_sketch_kssd_dev, whose results it reproduces bit for bit.
  * Returns RTC_ERR_UNSUPPORTED outside the prefilter kernel's configurations (17 <= kmer_size <= 28 with half_subk = 6,
- * i.e. drlevel <= 4): callers then expand the batch with rtc_unpack_bases_dev and call rtc_sketch_kssd_dev. */
+ * i.e. drlevel 3 (the default) or 4: at most 4 096 kept dimensions): callers then expand the batch with rtc_unpack_bases_dev and call rtc_sketch_kssd_dev. */
 int rtc_sketch_kssd_packed_dev(rtc_ctx* ctx, const uint8_t* d_packed, uint64_t n_bases, const uint64_t* d_runs,
                                uint64_t n_runs, const uint64_t* h_off, uint32_t n, int kmer_size, int drlevel,
                                const int32_t* h_shuffled_dim, void* d_out, uint32_t stride, uint32_t* d_cnt,

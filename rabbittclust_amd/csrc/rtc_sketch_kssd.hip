@@ -1442,7 +1442,7 @@ static int sketch_kssd_impl(rtc_ctx* ctx, const uint8_t* d_seq, const PackedArgs
   const bool use_bucket = kc.bvar >= 0 && K >= 18 && K <= 28;
   if (pk) {
     if (!(use_bucket && kc.d_bloom))
-      return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "packed input is sketched by the prefilter kernel only (k 17..28, drlevel <= 4): unpack the batch (rtc_unpack_bases_dev) for k=%d, drlevel=%d", kmer_size, drlevel);
+      return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "packed input is sketched by the prefilter kernel only (k 17..28, drlevel 3 or 4): unpack the batch (rtc_unpack_bases_dev) for k=%d, drlevel=%d", kmer_size, drlevel);
     if (h_off[n] > pk->n_bases) return rtc_fail(ctx, RTC_ERR_ARG, "offsets reach %llu, the batch holds %llu bases", (unsigned long long)h_off[n], (unsigned long long)pk->n_bases);
   }
   uint64_t seg_len = total / ((uint64_t)ctx->num_cu * 12);

@@ -296,18 +296,22 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   // Pageable staging by default: page-locking costs ~0.15 s/GB up front while the pageable PCIe copy
   // already runs at > 30 GB/s on the MI355X hosts measured; RTC_STAGE_PINNED=1 page-locks instead.
   bool pinned = getenv("RTC_STAGE_PINNED") != nullptr;
-  // batches parsed while the GPUs come up (pageable staging only: page-locking needs a context), each into a buffer of
-  // its own, up to RTC_PREPARSE_BYTES of host memory (default 1 GiB = four packed 1-GiB batches: once the GPUs are there
-  // the lanes are bound by the H2D copy, 12 ms per batch against 9 ms of parsing, so a few batches in hand keep them busy;
-  // 8 GiB measured no better inside the run and 0.05-0.1 s worse at process exit)
+  // batches parsed while the GPUs come up (pageable staging only: page-locking needs a context).  The first PRE_RING of
+  // them go straight into what becomes the staging ring (every configuration has at least three ring buffers: two lanes
+  // + the one being parsed), so they cost no memory of their own -- every GiB of staging a run touches is 0.06 s at
+  // process exit (the kernel frees it page by page), which is what a fourth pre-parsed 1-GiB batch in a buffer of its
+  // own used to cost a 0.5 s run while saving it 0.05 s.  RTC_PREPARSE_BYTES (default: the three ring buffers) allows
+  // more batches, each in a buffer of its own; 0 = parse only once the GPUs are there.
   struct PreBatch { char* buf; vector<uint64_t> runs; uint32_t kept; };
   vector<PreBatch> pre;
+  const size_t PRE_RING = 3;
+  const uint64_t ring_host_bytes = packed ? maxb / 4 + 64 : maxb + 64;
   if (gpus_ready && !pinned) {
-    uint64_t budget = (uint64_t)1 << 30, used = 0;
+    uint64_t budget = PRE_RING * ring_host_bytes, used = 0;
     if (const char* e = getenv("RTC_PREPARSE_BYTES")) budget = strtoull(e, nullptr, 10);
     while (pre.size() < batches.size() && !gpus_ready->done->load(std::memory_order_acquire)) {
       const Batch& b = batches[pre.size()];
-      const uint64_t host_bytes = packed ? b.bytes / 4 + 64 : b.bytes + 64;
+      const uint64_t host_bytes = pre.size() < PRE_RING ? ring_host_bytes : packed ? b.bytes / 4 + 64 : b.bytes + 64;
       if (used + host_bytes > budget) break;
       char* buf = alloc_pageable(host_bytes);
       if (!buf) break;
@@ -354,9 +358,13 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       if (l.d_seq) { CHECK(l.ctx, rtc_dev_free(l.ctx, l.d_seq)); l.d_seq = nullptr; }
       if (l.d_packed) { CHECK(l.ctx, rtc_dev_free(l.ctx, l.d_packed)); l.d_packed = nullptr; }
     }
+    const bool first = buf_bytes == 0;
     buf_bytes = need;
     const uint64_t host_bytes = packed ? buf_bytes / 4 + 64 : buf_bytes + 64;
     for (int i = 0; i < (int)NSTAGE; i++) {
+      // the buffers the first batches were parsed into while the GPUs came up ARE ring slots 0 .. PRE_RING - 1 (batch i
+      // of the pipeline below lives in slot i % NSTAGE, NSTAGE >= PRE_RING)
+      if (first && !pinned && (size_t)i < PRE_RING && (size_t)i < pre.size() && host_bytes == ring_host_bytes) { stage[i] = pre[i].buf; continue; }
       if (pinned && rtc_host_alloc(ctx, host_bytes, (void**)&stage[i]) != RTC_OK) {
         // the host refuses to page-lock this much (ulimit -l): stage through pageable memory instead
         fprintf(stderr, "-----cannot page-lock %.2f GB (%s), staging through pageable memory\n", buf_bytes / 1e9, rtc_last_error(ctx));
@@ -426,7 +434,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
 
   // KSSD over packed staging: the prefilter kernel reads the 2-bit stream itself (rtc_sketch_kssd_packed_dev) for the
   // k-mer lengths it covers; RTC_KSSD_UNPACK=1 expands every batch first (the former path; tests compare the two)
-  std::atomic<bool> kssd_direct{job.kssd && packed && getenv("RTC_KSSD_UNPACK") == nullptr && half_subk == 6 &&
+  std::atomic<bool> kssd_direct{job.kssd && packed && getenv("RTC_KSSD_UNPACK") == nullptr && half_subk == 6 && job.drlevel >= 3 &&
                                 (job.kmerSize + 1) / 2 * 2 >= 18 && (job.kmerSize + 1) / 2 * 2 <= 28};
   // ---- GPU side of one batch (runs on that GPU's host thread while the next batch is parsed) ----
   // row0 < 0: not resident (retry round), results only go to the host vectors.

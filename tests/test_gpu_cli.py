@@ -1192,7 +1192,8 @@ def test_batches_parsed_while_the_gpus_come_up_change_nothing(oracle, tmp_path):
     open(lst, "a").write(short + "\n" + gz + "\n")
     outs = []
     for name, env in (("pre", {"RTC_BATCH_BYTES": "2000000"}), ("off", {"RTC_BATCH_BYTES": "2000000", "RTC_PREPARSE_BYTES": "0"}),
-                      ("few", {"RTC_BATCH_BYTES": "2000000", "RTC_PREPARSE_BYTES": "1500000"})):
+                      ("few", {"RTC_BATCH_BYTES": "2000000", "RTC_PREPARSE_BYTES": "1500000"}),
+                      ("many", {"RTC_BATCH_BYTES": "2000000", "RTC_PREPARSE_BYTES": "100000000"})):  # beyond the three ring buffers
         d = os.path.join(tmp, name)
         os.makedirs(d)
         err = _run([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "500", "-d", "0.05", "-t", "4", "-o", os.path.join(d, "out.cluster")],
@@ -1203,12 +1204,12 @@ def test_batches_parsed_while_the_gpus_come_up_change_nothing(oracle, tmp_path):
         assert nb >= 3
         if name == "off":
             assert npre == 0
-        if name == "few":
+        if name in ("few", "pre"):   # the default budget is the three buffers that become the staging ring
             assert npre <= 3
         folder = [x for x in os.listdir(d) if os.path.isdir(os.path.join(d, x))]
         assert len(folder) == 1
         fd = os.path.join(d, folder[0])
         outs.append((open(os.path.join(d, "out.cluster"), "rb").read(), open(os.path.join(fd, "hash.sketch"), "rb").read(),
                      open(os.path.join(fd, "edge.mst"), "rb").read(), npre))
-    assert outs[0][:3] == outs[1][:3] == outs[2][:3]
+    assert outs[0][:3] == outs[1][:3] == outs[2][:3] == outs[3][:3]
     assert outs[0][3] >= 1  # the default budget parsed at least the first batch ahead of the GPUs

@@ -159,8 +159,59 @@ def test_packed_kssd_overflow_protocol_and_unsupported_configurations(ctx, oracl
     sk = _sketch_packed(ctx, g, off, sd, 21, 3, stride=16)   # RTC_ERR_OVERFLOW reports the stride, the wrapper retries
     assert np.array_equal(sk.to_host()[0], oracle.kssd_sketch(g, 21, 3))
     from rabbittclust_amd.api import RtcError
-    for k, dr in [(31, 3), (15, 3)]:                         # outside the prefilter kernel: callers unpack instead
+    for k, dr in [(31, 3), (15, 3), (21, 2)]:                # outside the prefilter kernel: callers unpack instead
         p = oracle.kssd_params(k, dr)
         with pytest.raises(RtcError) as e:
             _sketch_packed(ctx, g, off, oracle.kssd_shuffle_dim(p.half_subk), k, dr)
         assert "UNSUPPORTED" in str(e.value).upper()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_packed_kssd_random_layouts(ctx, oracle, seed):
+    """Hundreds of genomes of 0 .. 40 000 bases at arbitrary offsets (no alignment to bytes, words or lanes), runs of every
+    length from one character to whole genomes placed at random -- touching each other, ending a genome, covering one -- and
+    gaps between genomes that belong to no genome at all; k and drlevel drawn per seed."""
+    rng = np.random.default_rng(1000 + seed)
+    k = [21, 18, 26][seed - 1]
+    dr = [3, 3, 4][seed - 1]
+    parts, off_b, off_e, pos = [], [], [], 0
+    for g in range(300):
+        gap = int(rng.integers(0, 70)) if rng.random() < 0.5 else 0
+        if gap:
+            parts.append(rng.choice(ACGT, size=gap)); pos += gap   # bases between two genomes: owned by nobody
+        L = int(rng.choice([0, 5, k - 1, k, k + 1, 63, 64, 65, 1000, 4095, 4096, 4097, 20_000, 40_000]))
+        s = rng.choice(ACGT, size=L)
+        nr = int(rng.integers(0, 6)) if L else 0
+        for _ in range(nr):
+            a = int(rng.integers(0, L))
+            ln = int(rng.choice([1, 1, 2, 3, 17, 64, 200, L]))
+            s[a:a + ln] = rng.choice(np.frombuffer(b"NnRYKM-*", dtype=np.uint8), size=len(s[a:a + ln]))
+        low = rng.random(L) < 0.2
+        s[low & (s > 64)] |= 0x20
+        parts.append(s); off_b.append(pos); pos += L; off_e.append(pos)
+    seq = np.concatenate(parts)
+    # the API takes contiguous genomes (off[g + 1] is where g ends AND g + 1 begins): the gaps become genomes of their own
+    bounds = sorted(set([0] + off_b + off_e + [len(seq)]))
+    off = np.array(bounds, dtype=np.uint64)
+    p = oracle.kssd_params(k, dr)
+    sd = oracle.kssd_shuffle_dim(p.half_subk)
+    got = _sketch_packed(ctx, seq, off, sd, k, dr).to_host()
+    want = oracle.sketch_kssd_batch(seq, off, sd, kmer_size=k, drlevel=dr, threads=4)
+    assert sum(len(w) for w in want) > (20 if dr == 3 else 2)
+    for g in range(len(off) - 1):
+        assert np.array_equal(got[g], want[g]), f"genome {g} [{off[g]}, {off[g + 1]}): got {len(got[g])} want {len(want[g])}"
+
+
+def test_packed_kssd_without_any_run(ctx, oracle):
+    """n_runs = 0 with a null run pointer: every base of the batch is ACGT, the padding behind the last genome is not owned."""
+    rng = np.random.default_rng(9)
+    seq = rng.choice(ACGT, size=64 * 5000)          # a multiple of 64: no padding characters at all inside the genomes
+    off = np.array([0, 100_000, 100_000, len(seq)], dtype=np.uint64)
+    packed, n_bases, runs = pack_batch(seq)
+    assert len(runs) == 2 and runs[0] == len(seq)   # only the pad run; leave it out: nothing owns those bases
+    d_p = torch.from_numpy(packed).to(ctx.device)
+    sd = oracle.kssd_shuffle_dim(6)
+    sk = ctx.sketch_kssd_packed(d_p, n_bases, None, off, sd, kmer_size=21, drlevel=3)
+    got = sk.to_host()
+    for g in range(3):
+        assert np.array_equal(got[g], oracle.kssd_sketch(seq[int(off[g]):int(off[g + 1])], 21, 3))
