@@ -382,7 +382,8 @@ def extra_dense_pairs(args, ctx, api, pipeline, steps):
 def extra_cli(args, ctx, api, pipeline, steps):
     """The drop-in command line from FASTA files, on the driver's clock: `--cli-genomes` x 5 Mbp genomes written as 80-column
     FASTA to /dev/shm (outside the timed region), then bin/clust-mst -l ... -e with RTC_METRICS_JSON, MinHash and --fast.
-    The page cache is warm (tmpfs); PCIe, parsing, HIP start-up and process exit are all inside `wall_s`."""
+    The page cache is warm (tmpfs); PCIe, parsing, HIP start-up and process exit are all inside `wall_s`.  The runs are a second
+    apart so that none is charged the driver's asynchronous teardown of the one before it."""
     import shutil
     import tempfile
     import numpy as np
@@ -423,11 +424,16 @@ def extra_cli(args, ctx, api, pipeline, steps):
             f.write("\n".join(paths) + "\n")
         t_write = time.time() - t0
         out = {"workload": f"{n} x {L} bp genomes as 80-column FASTA files in {where} (written in {t_write:.1f}s, outside the timed "
-                           f"region), bin/clust-mst -l -i list -k {args.k} -d {args.threshold} -e, page cache warm",
+                           f"region), bin/clust-mst -l -i list -k {args.k} -d {args.threshold} -e, page cache warm, best of two runs "
+                           f"started a second after the previous process left",
                "host_cores": usable_cores()}
         for name, extra in (("minhash", ["-s", str(args.s)]), ("fast", ["--fast"])):
             best = None
             for rep in range(2):  # the second run has the code objects and the files' pages warm
+                # A process that has left is not gone: the driver tears its GPU state down asynchronously (~0.25 s of work), and a
+                # process launched inside that window pays it in its own HIP start-up (0.07 -> 0.13-0.26 s) or at its own exit
+                # (0.001 -> 0.12 s): tools/cli_timeline.py, TL_SLEEP=0 against 1.  One command line is one process.
+                time.sleep(1.0)
                 mj = os.path.join(tmp, f"metrics_{name}.json")
                 env = dict(os.environ, RTC_METRICS_JSON=mj)
                 t0 = time.perf_counter()

@@ -69,6 +69,11 @@ int rtc_ws(rtc_ctx* ctx, int slot, size_t bytes, void** out);
 int rtc_pinned(rtc_ctx* ctx, size_t bytes, void** out);
 // free HBM of the context's device, for the scratch budgets of the pair phase: hipMemGetInfo walks the driver's tables, so the
 // answer is kept for 100 ms or until this context allocates or frees (the budgets are halves of the free memory, not margins)
+// One empty launch per sketch translation unit: the HIP runtime maps a unit's device code at its first launch (~10 ms each);
+// rtc_warmup does that beside the command lines' first PCIe copies instead of in front of their first sketch.
+int rtc_touch_sketch_minhash(rtc_ctx* ctx);
+int rtc_touch_sketch_kssd(rtc_ctx* ctx);
+int rtc_touch_unpack(rtc_ctx* ctx);
 uint64_t rtc_free_hbm(rtc_ctx* ctx);
 
 // ---- internal C++ interfaces shared by the translation units ----------------------------------

@@ -1582,3 +1582,10 @@ extern "C" int rtc_sketch_kssd_packed_dev(rtc_ctx* ctx, const uint8_t* d_packed,
   const PackedArgs pk{n_bases, d_runs, n_runs};
   return sketch_kssd_impl(ctx, d_packed, &pk, h_off, n, kmer_size, drlevel, h_shuffled_dim, d_out, stride, d_cnt, width_out, h_need);
 }
+
+namespace { __global__ void touch_unit_kernel() {} }
+int rtc_touch_sketch_kssd(rtc_ctx* ctx) {
+  hipLaunchKernelGGL(touch_unit_kernel, dim3(1), dim3(64), 0, ctx->stream);
+  RTC_CHECK_LAUNCH(ctx);
+  return RTC_OK;
+}

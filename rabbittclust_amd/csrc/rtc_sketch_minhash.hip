@@ -1342,3 +1342,10 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
   }
   return RTC_OK;
 }
+
+namespace { __global__ void touch_unit_kernel() {} }
+int rtc_touch_sketch_minhash(rtc_ctx* ctx) {
+  hipLaunchKernelGGL(touch_unit_kernel, dim3(1), dim3(64), 0, ctx->stream);
+  RTC_CHECK_LAUNCH(ctx);
+  return RTC_OK;
+}

@@ -99,3 +99,10 @@ extern "C" int rtc_unpack_bases_dev(rtc_ctx* ctx, const uint8_t* d_packed, uint6
   }
   return RTC_OK;
 }
+
+namespace { __global__ void touch_unit_kernel() {} }
+int rtc_touch_unpack(rtc_ctx* ctx) {
+  hipLaunchKernelGGL(touch_unit_kernel, dim3(1), dim3(64), 0, ctx->stream);
+  RTC_CHECK_LAUNCH(ctx);
+  return RTC_OK;
+}

@@ -374,10 +374,15 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       }
       if (!pinned && !(stage[i] = alloc_pageable(host_bytes))) { fprintf(stderr, "ERROR: cannot allocate %.2f GB of staging memory\n", buf_bytes / 1e9); exit(1); }
     }
-    for (Lane& l : lanes) {
-      CHECK(l.ctx, rtc_dev_alloc(l.ctx, buf_bytes + 128, &l.d_seq));
-      if (packed) CHECK(l.ctx, rtc_dev_alloc(l.ctx, host_bytes, &l.d_packed));
-    }
+    // (the device staging buffers are allocated by the lanes themselves when their first batch arrives: lane_buffers)
+  };
+  // A lane's device staging, allocated on the lane's own host thread in front of its first copy: the two lanes of a GPU do
+  // it side by side and the main thread is already parsing (two 1-GiB hipMallocs and two of 256 MiB used to sit between
+  // "the GPUs are there" and the first batch).  The character buffer only where something reads characters.
+  auto lane_buffers = [&](Lane& l, bool need_chars) {
+    const uint64_t host_bytes = packed ? buf_bytes / 4 + 64 : buf_bytes + 64;
+    if (packed && !l.d_packed) CHECK(l.ctx, rtc_dev_alloc(l.ctx, host_bytes, &l.d_packed));
+    if (need_chars && !l.d_seq) CHECK(l.ctx, rtc_dev_alloc(l.ctx, buf_bytes + 128, &l.d_seq));
   };
   ensure_buffers(maxb);
   if (verbose) fprintf(stderr, "[plan] %zu files, %zu batches, %zu GPU(s), staging %zu x %.2f GB, %.3fs\n", nfiles, batches.size(), G, NSTAGE, buf_bytes / 1e9, get_sec() - tp0);
@@ -403,7 +408,8 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
     for (Gpu& g : gpus) {
       size_t fr = 0, tot = 0;
       CHECK(g.ctx, rtc_dev_mem_info(g.ctx, &fr, &tot));
-      const size_t lim = budget ? budget : fr / 2;
+      const size_t staging = NL / G * (size_t)(buf_bytes + buf_bytes / 4 + 256);  // the lanes allocate theirs with their first batch
+      const size_t lim = budget ? budget : (fr > staging ? fr - staging : 0) / 2;
       if (want > lim) {
         fprintf(stderr, "-----resident sketch rows would take %.2f GB (%zu genomes x %u hashes, the largest genome sets the row) of %.2f GB free: "
                         "sketches go through host memory instead\n", want / 1e9, nfiles, rs.stride, fr / 1e9);
@@ -453,6 +459,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
     const uint32_t nb = (uint32_t)kept.size();
     if (!nb) return;
     off.push_back(b.bytes);
+    lane_buffers(ln, !packed || !kssd_direct.load());
     if (packed) {
       const size_t nr = h_runs->size() / 2;
       if (nr > ln.runs_cap) {
@@ -500,6 +507,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
                                           off.data(), nb, job.kmerSize, job.drlevel, shuffled.data(), d_out, stride, d_cnt, &width, &need);
           if (st == RTC_ERR_UNSUPPORTED) {
             kssd_direct.store(false);
+            lane_buffers(ln, true);
             CHECK(c, rtc_unpack_bases_dev(c, (const uint8_t*)ln.d_packed, b.bytes + 64, (const uint64_t*)ln.d_runs, h_runs->size() / 2, (uint8_t*)ln.d_seq));
             continue;
           }
@@ -1998,7 +2006,8 @@ int main(int argc, char** argv) {
   join_warmup();
   for (Gpu& g : gpus) { if (g.comm) rtc_comm_destroy(g.comm); }
   for (Gpu& g : gpus) rtc_ctx_destroy(g.ctx);
-  if (getenv("RTC_VERBOSE")) fprintf(stderr, "[exit]  output written at t+%.3fs, contexts released in %.3fs\n", t_end - t_main, get_sec() - t_end);
+  if (getenv("RTC_VERBOSE")) fprintf(stderr, "[exit]  output written at t+%.3fs, contexts released in %.3fs (main entered at %.6f, leaving at %.6f)\n", t_end - t_main,
+                                     get_sec() - t_end, t_main, get_sec());
   // Everything is written and closed: leave without unmapping the GBs of staging memory page by page and without the
   // HIP runtime's own teardown (0.15 s of a 0.9 s run on 41 Gbp); the kernel reclaims both at once.
   std::cout.flush();

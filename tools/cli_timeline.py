@@ -26,11 +26,20 @@ for c0 in range(0, n, 256):
 open(os.path.join(tmp, "list.txt"), "w").write("\n".join(paths) + "\n")
 del ctx
 for r in range(runs):
+    time.sleep(float(os.environ.get("TL_SLEEP", "0")))  # the previous process's GPU state is torn down by the driver after it has left
     t0 = time.time()
     res = subprocess.run(["env", "RTC_VERBOSE=1"] + [f"{k}={v}" for k, v in os.environ.items() if k.startswith("RTC_")] + [ os.path.join(root, "rabbittclust_amd", "bin", "clust-mst"), "-l", "-i", os.path.join(tmp, "list.txt"), "-k", "21",
                           "-d", "0.05", "-e", "-o", os.path.join(tmp, "out.cluster")] + extra, capture_output=True, text=True, cwd=tmp)
     dt = time.time() - t0
-    print(f"run {r}: rc={res.returncode} wall={dt:.3f}s {n * L / dt / 1e9:.1f} Gbp/s", flush=True)
+    import re
+    m = re.search(r"GPU context\(s\) in ([0-9.]+)s", res.stderr)
+    init = float(m.group(1)) if m else 0.0
+    m = re.search(r"output written at t\+([0-9.]+)s", res.stderr)
+    written = float(m.group(1)) if m else 0.0
+    m = re.search(r"main entered at ([0-9.]+), leaving at ([0-9.]+)", res.stderr)
+    start, leave = (float(m.group(1)) - t0, t0 + dt - float(m.group(2))) if m else (0.0, 0.0)
+    print(f"run {r}: rc={res.returncode} wall={dt:.3f}s {n * L / dt / 1e9:.1f} Gbp/s   (process start {start:.3f}, runtime up at {init:.3f}, output "
+          f"{written - init:.3f} s later, _exit to reaped {leave:.3f} s)", flush=True)
     keep = [ln for ln in res.stderr.splitlines() if ln.startswith(("[init]", "[ctx]", "[plan]", "[tune]", "[exit]", "[free]", "[share]")) or "time of" in ln]
     gp = [ln for ln in res.stderr.splitlines() if ln.startswith("[gpu")]
     if os.environ.get("TL_BRIEF"):
