@@ -384,7 +384,24 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
     if (packed && !l.d_packed) CHECK(l.ctx, rtc_dev_alloc(l.ctx, host_bytes, &l.d_packed));
     if (need_chars && !l.d_seq) CHECK(l.ctx, rtc_dev_alloc(l.ctx, buf_bytes + 128, &l.d_seq));
   };
+  // KSSD over packed staging: the prefilter kernel reads the 2-bit stream itself (rtc_sketch_kssd_packed_dev) for the
+  // k-mer lengths it covers; RTC_KSSD_UNPACK=1 expands every batch first (the former path; tests compare the two)
+  std::atomic<bool> kssd_direct{job.kssd && packed && getenv("RTC_KSSD_UNPACK") == nullptr && half_subk == 6 && job.drlevel >= 3 &&
+                                (job.kmerSize + 1) / 2 * 2 >= 18 && (job.kmerSize + 1) / 2 * 2 <= 28};
   ensure_buffers(maxb);
+  // Each lane's first PCIe copy costs 17-29 ms instead of 6 (the runtime sets up the stream's copy path) and its buffers 5 ms:
+  // the lanes do both now, on their worker threads, while this thread sizes and allocates the resident rows; the pipeline
+  // joins a lane's worker before it hands it a batch.
+  if (!getenv("RTC_NO_WARMUP"))
+    for (size_t l = 0; l < NL; l++) {
+      Lane* lp = &lanes[l];
+      const char* src = stage[l % NSTAGE];
+      const uint64_t warm_bytes = std::min<uint64_t>((uint64_t)8 << 20, packed ? buf_bytes / 4 : buf_bytes);
+      lp->worker = std::thread([&lane_buffers, &kssd_direct, lp, src, warm_bytes, packed]() {
+        lane_buffers(*lp, !packed || !kssd_direct.load());
+        CHECK(lp->ctx, rtc_copy_h2d(lp->ctx, packed ? lp->d_packed : lp->d_seq, src, warm_bytes));
+      });
+    }
   if (verbose) fprintf(stderr, "[plan] %zu files, %zu batches, %zu GPU(s), staging %zu x %.2f GB, %.3fs\n", nfiles, batches.size(), G, NSTAGE, buf_bytes / 1e9, get_sec() - tp0);
 
   // ---- resident sketch rows: genome id g (list order among the kept files) owns row g on every GPU ----
@@ -438,10 +455,6 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   struct Placed { uint32_t row0, rows; int gpu; };  // where a batch's sketches live (share step)
   vector<Placed> placed;
 
-  // KSSD over packed staging: the prefilter kernel reads the 2-bit stream itself (rtc_sketch_kssd_packed_dev) for the
-  // k-mer lengths it covers; RTC_KSSD_UNPACK=1 expands every batch first (the former path; tests compare the two)
-  std::atomic<bool> kssd_direct{job.kssd && packed && getenv("RTC_KSSD_UNPACK") == nullptr && half_subk == 6 && job.drlevel >= 3 &&
-                                (job.kmerSize + 1) / 2 * 2 >= 18 && (job.kmerSize + 1) / 2 * 2 <= 28};
   // ---- GPU side of one batch (runs on that GPU's host thread while the next batch is parsed) ----
   // row0 < 0: not resident (retry round), results only go to the host vectors.
   auto gpu_batch = [&](Lane& ln, const Batch& b, const char* h_seq, const vector<uint64_t>* h_runs, long row0) {
@@ -460,6 +473,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
     if (!nb) return;
     off.push_back(b.bytes);
     lane_buffers(ln, !packed || !kssd_direct.load());
+    const double t0b = get_sec();
     if (packed) {
       const size_t nr = h_runs->size() / 2;
       if (nr > ln.runs_cap) {
@@ -542,7 +556,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       }
     }
     if (temp) { CHECK(c, rtc_dev_free(c, d_out)); CHECK(c, rtc_dev_free(c, d_cnt)); }
-    if (verbose) fprintf(stderr, "[gpu %d.%d] %u genomes, %.2f GB: h2d %.3fs sketch%s %.3fs\n", (int)ln.gpu, (int)ln.owned, nb, b.bytes / 1e9, t1 - t0,
+    if (verbose) fprintf(stderr, "[gpu %d.%d] %u genomes, %.2f GB: alloc %.3fs h2d %.3fs sketch%s %.3fs\n", (int)ln.gpu, (int)ln.owned, nb, b.bytes / 1e9, t0b - t0, t1 - t0b,
                          to_host || temp ? "+d2h" : "", get_sec() - t1);
   };
 
