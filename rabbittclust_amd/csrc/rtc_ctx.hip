@@ -232,3 +232,10 @@ int rtc_timer_stop(rtc_ctx* ctx, float* ms_out) {
 }
 
 }  // extern "C"
+
+// measurement hook (not part of include/rtclust.h): the HIP runtime's own teardown of a device, timed by the command lines'
+// RTC_EXIT_PROBE to tell what a process leaves to the kernel at _exit
+extern "C" int rtc_debug_device_reset(int device) {
+  if (hipSetDevice(device) != hipSuccess) return RTC_ERR_HIP;
+  return hipDeviceReset() == hipSuccess ? RTC_OK : RTC_ERR_HIP;
+}

@@ -74,6 +74,12 @@ static Metrics g_metrics;
 // The warm-up helper thread (rtc_warmup beside the sketch phase) is joined before the process leaves through exit():
 // static destructors and the HIP runtime's teardown must not run while it is still inside a HIP call.
 static std::thread* g_gpu_thread = nullptr;  // main's GPU bring-up thread while it runs
+// RTC_EXIT_PROBE=1 (measurement only): what the process leaves to the kernel at _exit -- the pageable staging ring and the
+// lanes' device staging -- is released by hand, timed, before leaving: says which of them the time between _exit and the
+// parent's wait() belongs to (tools/cli_timeline.py)
+extern "C" int rtc_debug_device_reset(int device);
+static std::vector<char*> g_exit_probe_host;
+static std::vector<std::pair<rtc_ctx*, void*>> g_exit_probe_dev;
 static std::thread g_warmup_thread;
 static std::mutex g_warmup_mutex;
 static void join_warmup() {
@@ -603,7 +609,8 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   // Pageable staging is NOT returned here: munmap of GBs of touched pages takes ~0.1 s and holds the
   // address-space lock, which stalls every hipMalloc of the clustering phase that follows (measured:
   // candidate edges 117 ms instead of 3 ms).  The pages go back when the process ends.
-  for (auto& p : stage) p = nullptr;
+  for (auto& p : stage) { if (p) g_exit_probe_host.push_back(p); p = nullptr; }
+  for (Lane& l : lanes) { if (l.d_seq) g_exit_probe_dev.push_back({l.ctx, l.d_seq}); if (l.d_packed) g_exit_probe_dev.push_back({l.ctx, l.d_packed}); }
   // The device staging buffers stay allocated until the process ends: hipFree of a multi-GB buffer
   // costs ~0.4 s here and the clustering phase needs far less than the 288 GB that are there.
   if (verbose) fprintf(stderr, "[free]  host staging %.3fs\n", get_sec() - tf0);
@@ -1629,6 +1636,7 @@ static int append_clust_greedy(const Options& o, vector<Gpu>& gpus) {
 #endif
 
 int main(int argc, char** argv) {
+  if (const char* e = getenv("RTC_START_DELAY_MS")) usleep(1000 * atoi(e));  // (measurement only)
   const double t_main = get_sec();
   Options o = parse(argc, argv);
   if (!o.has_output && !o.db_stats) { cerr << "ERROR: option -o/--output is required (unless --buildDB or --stats is used)" << endl; return 1; }
@@ -2018,6 +2026,23 @@ int main(int argc, char** argv) {
   g_metrics.num("total_s", t_end - t_main);
   g_metrics.write();
   join_warmup();
+  if (const char* e = getenv("RTC_EXIT_DELAY_MS")) usleep(1000 * atoi(e));  // (measurement only, with RTC_EXIT_PROBE)
+  if (getenv("RTC_EXIT_PROBE")) {
+    const double p0 = get_sec();
+    for (char* p : g_exit_probe_host) free(p);
+    const double p1 = get_sec();
+    for (auto& d : g_exit_probe_dev) (void)rtc_dev_free(d.first, d.second);
+    const double p2 = get_sec();
+    fprintf(stderr, "[probe] %zu host staging buffers freed in %.3fs, %zu device buffers in %.3fs\n", g_exit_probe_host.size(), p1 - p0,
+            g_exit_probe_dev.size(), p2 - p1);
+    if (strcmp(getenv("RTC_EXIT_PROBE"), "reset") == 0) {
+      for (Gpu& g : gpus) (void)rtc_debug_device_reset(g.device);
+      fprintf(stderr, "[probe] hipDeviceReset in %.3fs\n", get_sec() - p2);
+      fprintf(stderr, "[exit]  output written at t+%.3fs, contexts released in %.3fs (main entered at %.6f, leaving at %.6f)\n", t_end - t_main, 0.0, t_main, get_sec());
+      fflush(nullptr);
+      _exit(0);
+    }
+  }
   for (Gpu& g : gpus) { if (g.comm) rtc_comm_destroy(g.comm); }
   for (Gpu& g : gpus) rtc_ctx_destroy(g.ctx);
   if (getenv("RTC_VERBOSE")) fprintf(stderr, "[exit]  output written at t+%.3fs, contexts released in %.3fs (main entered at %.6f, leaving at %.6f)\n", t_end - t_main,

@@ -42,6 +42,9 @@ for r in range(runs):
           f"{written - init:.3f} s later, _exit to reaped {leave:.3f} s)", flush=True)
     keep = [ln for ln in res.stderr.splitlines() if ln.startswith(("[init]", "[ctx]", "[plan]", "[tune]", "[exit]", "[free]", "[share]")) or "time of" in ln]
     gp = [ln for ln in res.stderr.splitlines() if ln.startswith("[gpu")]
+    for ln in res.stderr.splitlines():
+        if ln.startswith("[probe]"):
+            print("   ", ln)
     if os.environ.get("TL_BRIEF"):
         print("   ", " | ".join(ln.strip() for ln in keep if ln.startswith(("[init]  ", "[ctx]", "[exit]")) and "list" not in ln))
     else:
