@@ -424,12 +424,12 @@ def extra_cli(args, ctx, api, pipeline, steps):
             f.write("\n".join(paths) + "\n")
         t_write = time.time() - t0
         out = {"workload": f"{n} x {L} bp genomes as 80-column FASTA files in {where} (written in {t_write:.1f}s, outside the timed "
-                           f"region), bin/clust-mst -l -i list -k {args.k} -d {args.threshold} -e, page cache warm, best of two runs "
+                           f"region), bin/clust-mst -l -i list -k {args.k} -d {args.threshold} -e, page cache warm, best of three runs "
                            f"started a second after the previous process left",
                "host_cores": usable_cores()}
         for name, extra in (("minhash", ["-s", str(args.s)]), ("fast", ["--fast"])):
             best = None
-            for rep in range(2):  # the second run has the code objects and the files' pages warm
+            for rep in range(3):  # from the second run on the code objects and the files' pages are warm
                 # A process that has left is not gone: the driver tears its GPU state down asynchronously (~0.25 s of work), and a
                 # process launched inside that window pays it in its own HIP start-up (0.07 -> 0.13-0.26 s) or at its own exit
                 # (0.001 -> 0.12 s): tools/cli_timeline.py, TL_SLEEP=0 against 1.  One command line is one process.
