@@ -1638,6 +1638,11 @@ static int append_clust_greedy(const Options& o, vector<Gpu>& gpus) {
 int main(int argc, char** argv) {
   if (const char* e = getenv("RTC_START_DELAY_MS")) usleep(1000 * atoi(e));  // (measurement only)
   const double t_main = get_sec();
+  // The staging batches leave pageable memory 15 % faster through the runtime's copy kernels than through the SDMA engines
+  // (2 048 x 5 Mbp: output 0.112-0.127 s after the runtime is up against 0.128-0.153 s, tools/cli_timeline.py) and the
+  // sketch kernels leave the CUs idle two thirds of the time anyway.  Has to be in the environment before the runtime
+  // starts; a value the user has set is left alone (HSA_ENABLE_SDMA=1 brings the engines back).
+  setenv("HSA_ENABLE_SDMA", "0", 0);
   Options o = parse(argc, argv);
   if (!o.has_output && !o.db_stats) { cerr << "ERROR: option -o/--output is required (unless --buildDB or --stats is used)" << endl; return 1; }
   if (o.threads < 1) { fprintf(stderr, "-----Invalid thread number %d\n", o.threads); return 1; }
