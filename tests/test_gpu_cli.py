@@ -1172,8 +1172,9 @@ def test_packed_staging_unpack_kernel_and_cli_identity(ctx, oracle, tmp_path):
             assert outs["packed"][1][f] == outs["ascii"][1][f], (tool, extra, f)
 
 
-def test_batches_parsed_while_the_gpus_come_up_change_nothing(oracle, tmp_path):
-    """The command line parses batch after batch into buffers of their own while the HIP runtime and the contexts come up on
+@pytest.mark.parametrize("mode", [["-s", "500"], ["--fast"]])
+def test_batches_parsed_while_the_gpus_come_up_change_nothing(oracle, tmp_path, mode):
+    """(--fast: the packed batches are sketched as they are, retry round included.)  The command line parses batch after batch into buffers of their own while the HIP runtime and the contexts come up on
     another thread, and hands them to the lanes afterwards.  With small batches (many of them before the GPUs are there),
     with the pre-parse switched off (RTC_PREPARSE_BYTES=0) and with a budget that stops it after a few batches, the
     cluster file, hash.sketch and edge.mst must be byte-identical -- including a gzip file whose slot guess is too small
@@ -1196,7 +1197,7 @@ def test_batches_parsed_while_the_gpus_come_up_change_nothing(oracle, tmp_path):
                       ("many", {"RTC_BATCH_BYTES": "2000000", "RTC_PREPARSE_BYTES": "100000000"})):  # beyond the three ring buffers
         d = os.path.join(tmp, name)
         os.makedirs(d)
-        err = _run([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "500", "-d", "0.05", "-t", "4", "-o", os.path.join(d, "out.cluster")],
+        err = _run([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-d", "0.05", "-t", "4", "-o", os.path.join(d, "out.cluster")] + mode,
                    d, dict(env, RTC_VERBOSE="1"))
         m = re.search(r"\[init\]\s+(\d+) of (\d+) batches parsed before the GPUs were up", err)
         assert m, err[-2000:]
@@ -1209,7 +1210,7 @@ def test_batches_parsed_while_the_gpus_come_up_change_nothing(oracle, tmp_path):
         folder = [x for x in os.listdir(d) if os.path.isdir(os.path.join(d, x))]
         assert len(folder) == 1
         fd = os.path.join(d, folder[0])
-        outs.append((open(os.path.join(d, "out.cluster"), "rb").read(), open(os.path.join(fd, "hash.sketch"), "rb").read(),
+        outs.append((open(os.path.join(d, "out.cluster"), "rb").read(), open(os.path.join(fd, "kssd.hash.sketch" if mode == ["--fast"] else "hash.sketch"), "rb").read(),
                      open(os.path.join(fd, "edge.mst"), "rb").read(), npre))
     assert outs[0][:3] == outs[1][:3] == outs[2][:3] == outs[3][:3]
     assert outs[0][3] >= 1  # the default budget parsed at least the first batch ahead of the GPUs
