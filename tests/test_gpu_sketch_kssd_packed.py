@@ -166,14 +166,18 @@ def test_packed_kssd_overflow_protocol_and_unsupported_configurations(ctx, oracl
         assert "UNSUPPORTED" in str(e.value).upper()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+import os
+SOAK_SEEDS = int(os.environ.get("RTC_SOAK_SEEDS", "3"))  # RTC_SOAK_SEEDS=60: a longer walk through random layouts
+
+
+@pytest.mark.parametrize("seed", list(range(1, SOAK_SEEDS + 1)))
 def test_packed_kssd_random_layouts(ctx, oracle, seed):
     """Hundreds of genomes of 0 .. 40 000 bases at arbitrary offsets (no alignment to bytes, words or lanes), runs of every
     length from one character to whole genomes placed at random -- touching each other, ending a genome, covering one -- and
     gaps between genomes that belong to no genome at all; k and drlevel drawn per seed."""
     rng = np.random.default_rng(1000 + seed)
-    k = [21, 18, 26][seed - 1]
-    dr = [3, 3, 4][seed - 1]
+    k = [21, 18, 26, 17, 22, 23, 24, 25, 27, 28, 19, 20][(seed - 1) % 12]
+    dr = [3, 3, 4][(seed - 1) % 3]
     parts, off_b, off_e, pos = [], [], [], 0
     for g in range(300):
         gap = int(rng.integers(0, 70)) if rng.random() < 0.5 else 0
