@@ -282,3 +282,35 @@ def test_packed_table_layout_matches_oracle(ctx, oracle, k):
             _check(ctx, oracle, seq, off, k, size=1900)
         finally:
             del os.environ["RTC_SKETCH_NO_PACKED"]
+
+
+import os
+SOAK_SEEDS = int(os.environ.get("RTC_SOAK_SEEDS", "3"))  # RTC_SOAK_SEEDS=60: a longer walk through random layouts
+
+
+@pytest.mark.parametrize("seed", list(range(1, SOAK_SEEDS + 1)))
+def test_sketch_random_layouts(ctx, oracle, seed):
+    """Hundreds of genomes of 0 .. 60 000 bases at arbitrary offsets, runs of characters outside ACGT of every length placed at
+    random (touching, ending a genome, covering one), lower case, per-genome sketch sizes; k and the size regime per seed."""
+    rng = np.random.default_rng(4000 + seed)
+    k = [21, 17, 16, 32, 25, 19, 11, 28, 23, 31, 20, 13][(seed - 1) % 12]
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    parts, off = [], [0]
+    for g in range(200):
+        L = int(rng.choice([0, 5, k - 1, k, k + 1, 63, 64, 65, 1000, 4863, 4864, 4865, 20_000, 60_000]))
+        s = rng.choice(acgt, size=L)
+        for _ in range(int(rng.integers(0, 6)) if L else 0):
+            a = int(rng.integers(0, L))
+            ln = int(rng.choice([1, 1, 2, 3, 17, 64, 200, L]))
+            s[a:a + ln] = rng.choice(np.frombuffer(b"NnRYKM-*\n", dtype=np.uint8), size=len(s[a:a + ln]))
+        low = rng.random(L) < 0.2
+        s[low & (s > 64)] |= 0x20
+        parts.append(s)
+        off.append(off[-1] + L)
+    seq = np.concatenate(parts)
+    off = np.array(off, dtype=np.uint64)
+    if seed % 2:
+        _check(ctx, oracle, seq, off, k, size=int(rng.choice([10, 100, 1000])))
+    else:
+        sizes = rng.integers(1, 1500, size=len(off) - 1).astype(np.uint32)   # containment mode: a size per genome
+        _check(ctx, oracle, seq, off, k, sizes=sizes)
