@@ -192,3 +192,39 @@ def test_join_u64_hashes_that_share_their_upper_half(ctx, oracle, prefixes):
         assert np.array_equal(_edges(ctx, dev, 1, 130, 0, 129, -1, mode=2), want)
     finally:
         os.environ.pop("RTC_JOIN_FULLSORT", None)
+
+
+SOAK_SEEDS = int(os.environ.get("RTC_SOAK_SEEDS", "3"))  # RTC_SOAK_SEEDS=40: a longer walk through random tiles
+
+
+@pytest.mark.parametrize("seed", list(range(1, SOAK_SEEDS + 1)))
+def test_pair_paths_on_random_tiles(ctx, oracle, seed):
+    """Random sketch sets (u64 / u32, ragged sizes 0 .. 600, hash pools from dense to sparse, duplicates of whole sketches,
+    the table's empty marker as a hash), random row / column ranges and size-ratio filters: the join, the join with its
+    semi-join forced and the tiled kernel all give the oracle's (i, j, common) triples."""
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(7000 + seed)
+    dt = np.uint64 if seed % 2 else np.uint32
+    n = int(rng.integers(40, 260))
+    sk = _make_sketches(rng, n, 0, int(rng.choice([8, 60, 300, 600])), pool_bits=int(rng.choice([8, 11, 14, 20])), dtype=dt)
+    for _ in range(int(rng.integers(0, 6))):
+        a, b = rng.integers(0, n, size=2)
+        sk[int(a)] = sk[int(b)].copy()
+    if rng.random() < 0.5:
+        q = int(rng.integers(0, n))
+        top = np.array([np.iinfo(dt).max], dtype=dt)
+        if len(sk[q]) == 0 or sk[q][-1] != top[0]:
+            sk[q] = np.concatenate([sk[q], top])
+    dev = api.SketchSet.from_host(sk, ctx.device, width=8 if dt == np.uint64 else 4)
+    for _ in range(3):
+        r0 = int(rng.integers(1, n)); r1 = int(rng.integers(r0 + 1, n + 1))
+        c0 = int(rng.integers(0, r1 - 1)); c1 = int(rng.integers(c0 + 1, r1))
+        radio = int(rng.choice([-1, 1, 2, 4]))
+        want = _expected(oracle, sk, r0, r1, c0, c1, radio)
+        assert np.array_equal(_edges(ctx, dev, r0, r1, c0, c1, radio, mode=2), want), (seed, r0, r1, c0, c1, radio, "join")
+        os.environ["RTC_JOIN_SEMI"] = "2"
+        try:
+            assert np.array_equal(_edges(ctx, dev, r0, r1, c0, c1, radio, mode=2), want), (seed, r0, r1, c0, c1, radio, "semi")
+        finally:
+            os.environ.pop("RTC_JOIN_SEMI", None)
+        assert np.array_equal(_edges(ctx, dev, r0, r1, c0, c1, radio, mode=0), want), (seed, r0, r1, c0, c1, radio, "tiled")
