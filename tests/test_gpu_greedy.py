@@ -111,3 +111,43 @@ def test_greedy_global_join_equals_the_batch_loop_and_the_oracle(ctx, oracle, mo
     got_n, got = run()
     assert got_n == want_n and np.array_equal(got, want)
     assert 1 < want_n < len(sk)
+
+
+import os
+SOAK_SEEDS = int(os.environ.get("RTC_SOAK_SEEDS", "3"))  # RTC_SOAK_SEEDS=40: a longer walk
+
+
+@pytest.mark.parametrize("seed", list(range(1, SOAK_SEEDS + 1)))
+def test_greedy_on_random_families(ctx, oracle, seed):
+    """Family structure, drift, sizes, raggedness and threshold drawn per seed; fixed-size MinHash, containment MinHash and
+    KSSD u32 in turn: representative of every genome equal to the oracle's -t 1 replay."""
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(11000 + seed)
+    n_fam, per = int(rng.integers(3, 60)), int(rng.integers(1, 9))
+    size = int(rng.choice([50, 200, 500]))
+    drift = float(rng.choice([0.1, 0.5, 0.9]))
+    thr = float(rng.choice([0.02, 0.05, 0.1]))
+    kind = seed % 3
+    if kind == 0:
+        sk = _family_sets(rng, n_fam, per, size, drift)
+        sk = [s[:size] for s in sk if len(s) >= size] or [np.arange(size, dtype=np.uint64)]  # fixed-size mode: every sketch full
+        dev = api.SketchSet.from_host(sk, ctx.device, k=21)
+        flat, start, lens = oracle.to_csr(sk)
+        want_n, want = oracle.greedy_minhash(flat, start, lens, size, 21, False, thr)
+        got_n, got = ctx.greedy(dev, thr, size_cfg=size, is_containment=False)
+    elif kind == 1:
+        sk = _family_sets(rng, n_fam, per, size, drift, ragged=True)
+        cfg = np.array([max(len(s), 100) for s in sk], dtype=np.uint32)
+        dev = api.SketchSet.from_host(sk, ctx.device, k=21)
+        flat, start, lens = oracle.to_csr(sk)
+        want_n, want = oracle.greedy_minhash(flat, start, lens, cfg, 21, True, thr)
+        got_n, got = ctx.greedy(dev, thr, size_cfg=cfg, is_containment=True)
+    else:
+        sk = _family_sets(rng, n_fam, per, size, drift, pool_bits=30, dtype=np.uint32, ragged=True)
+        sk.sort(key=lambda a: -len(a))
+        dev = api.SketchSet.from_host(sk, ctx.device, k=22, kind="kssd", width=4)
+        flat, start, lens = oracle.to_csr(sk, dtype=np.uint32)
+        want_n, want = oracle.greedy_kssd(flat, start, lens, 22, thr)
+        got_n, got = ctx.greedy(dev, thr)
+    assert got_n == want_n, (seed, kind)
+    assert np.array_equal(got, want), (seed, kind)

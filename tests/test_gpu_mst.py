@@ -439,3 +439,35 @@ def test_mst_dense_histograms_equal_brute_force(ctx, oracle, shape):
     finally:
         del os.environ["RTC_EDGE_BUDGET"]
     assert np.array_equal(dense2, want_dense) and np.array_equal(ani2, want_ani) and np.array_equal(mst2, mst)
+
+
+import os
+SOAK_SEEDS = int(os.environ.get("RTC_SOAK_SEEDS", "3"))  # RTC_SOAK_SEEDS=40: a longer walk
+
+
+@pytest.mark.parametrize("seed", list(range(1, SOAK_SEEDS + 1)))
+def test_mst_on_random_sketch_sets(ctx, oracle, seed):
+    """Random collections (30 .. 400 sketches of 1 .. 300 hashes out of pools that make ties, empty sketches, exact copies),
+    Jaccard and containment, k and threshold per seed: weight multiset bit for bit and the partition at several cuts."""
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(30, 400))
+    pool = np.unique(rng.integers(1, 1 << 62, size=int(rng.choice([300, 2000, 20000])), dtype=np.uint64))
+    smax = int(rng.choice([12, 100, 300]))
+    sk = [np.sort(rng.choice(pool, size=min(len(pool), int(rng.integers(1, smax + 1))), replace=False)) for _ in range(n)]
+    for _ in range(int(rng.integers(0, 5))):
+        sk[int(rng.integers(0, n))] = np.zeros(0, dtype=np.uint64)
+    for _ in range(int(rng.integers(0, 5))):
+        a, b = rng.integers(0, n, size=2)
+        sk[int(a)] = sk[int(b)].copy()
+    k = int(rng.choice([17, 21, 25]))
+    thr = float(rng.choice([0.01, 0.05, 0.1]))
+    dev = api.SketchSet.from_host(sk, ctx.device, k=k)
+    flat, start, lens = oracle.to_csr(sk)
+    for containment in (False, True):
+        got = ctx.mst(dev, thr, is_containment=containment)
+        want = oracle.mst(flat, start, lens, k, containment, thr, threads=1)
+        assert len(got) == len(want), (seed, containment)
+        assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64)), (seed, containment)
+        for cut in (thr, 0.2, 0.5):
+            assert _partition(oracle.forest_clusters(want, cut, n)) == _partition(_clusters_from_edges(got, cut, n)), (seed, containment, cut)
