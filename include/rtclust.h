@@ -105,6 +105,19 @@ int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uint64_t* h
                            int k, uint32_t seed, const uint32_t* h_sizes, uint32_t size,
                            uint64_t* d_out, uint32_t stride, uint32_t* d_cnt);
 
+/* The same sketches straight from a batch in the 2-bit staging format (layout: rtc_unpack_bases_dev above) -- the records
+ * `update()` is handed one by one (src/SketchInfo.cpp:928-948) as they crossed PCIe, 0.25 B per base read once, no ASCII
+ * copy in HBM.  d_packed (16-byte aligned) holds n_bases / 4 bytes, n_bases a multiple of 64 and >= h_off[n];
+ * d_runs[2 r], d_runs[2 r + 1] = start and length of run r of characters outside ACGT, ascending by start and disjoint
+ * (record separators and the gaps between genomes are runs too): a k-mer counts exactly when none of its k characters
+ * lies in a run nor outside its genome's [h_off[g], h_off[g + 1]) -- what update() does with a character outside ACGT.
+ * Every k in 1..32 and every sketch size; everything else as rtc_sketch_minhash_dev, whose results it reproduces bit
+ * for bit. */
+int rtc_sketch_minhash_packed_dev(rtc_ctx* ctx, const uint8_t* d_packed, uint64_t n_bases, const uint64_t* d_runs,
+                                  uint64_t n_runs, const uint64_t* h_off, uint32_t n, int k, uint32_t seed,
+                                  const uint32_t* h_sizes, uint32_t size, uint64_t* d_out, uint32_t stride,
+                                  uint32_t* d_cnt);
+
 /* ---- KSSD sketching (--fast) ------------------------------------------------------------- */
 /* Replaces the per-file body of sketchFileWithKssd (src/SketchInfo.cpp:994-1252): 2-bit rolling
  * k-mer (k rounded up to even, :1019-1020), canonical min, shuffled-dimension filter, dr_tuple,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "rtc_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "rtc_synth_genomes_dev": (_i, [_vp, _vp, _vp, _u32, _vp]),
     "rtc_sketch_minhash_dev": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _vp, _u32, _vp, _u32, _vp]),
+    "rtc_sketch_minhash_packed_dev": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u32, _i, _u32, _vp, _u32, _vp, _u32, _vp]),
     "rtc_sketch_kssd_dev": (_i, [_vp, _vp, _vp, _u32, _i, _i, _vp, _vp, _u32, _vp,
                                  C.POINTER(_i), C.POINTER(_u32)]),
     "rtc_sketch_kssd_packed_dev": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u32, _i, _i, _vp, _vp, _u32, _vp,

@@ -172,6 +172,32 @@ class Context:
             self.h, _t_ptr(seq), _np_ptr(off), n, k, seed,
             _np_ptr(sizes) if sizes is not None else None, int(size), _t_ptr(out), int(out.shape[1]), _t_ptr(cnt)))
 
+    def sketch_minhash_packed(self, packed, off, k=21, size=1000, sizes=None, seed=42, n_bases=None, runs=None, out=None, cnt=None):
+        """sketch_minhash over a batch in the 2-bit staging format (a PackedBatch, or `packed` uint8 device tensor of
+        n_bases / 4 bytes with `runs` int64 (start, length) pairs).  `out` / `cnt`: caller-provided rows as in sketch_minhash_into."""
+        if isinstance(packed, PackedBatch):
+            packed, n_bases, runs = packed.packed, packed.n_bases, packed.runs
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        if sizes is not None:
+            sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+            stride = int(sizes.max()) if n else 1
+        else:
+            stride = int(size)
+        stride = max(stride, 1)
+        if out is None:
+            out = torch.empty((max(n, 1), stride), dtype=torch.int64, device=self.device)
+            cnt = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+        else:
+            assert out.is_contiguous() and cnt.is_contiguous() and out.shape[0] >= n and cnt.shape[0] >= n
+            stride = int(out.shape[1])
+        n_runs = int(runs.numel() // 2) if runs is not None else 0
+        self.check(self.lib.rtc_sketch_minhash_packed_dev(
+            self.h, _t_ptr(packed), int(n_bases), _t_ptr(runs) if n_runs else None, n_runs, _np_ptr(off), n, k, seed,
+            _np_ptr(sizes) if sizes is not None else None, int(size), _t_ptr(out), stride, _t_ptr(cnt)))
+        start = torch.arange(n, dtype=torch.int64, device=self.device) * stride
+        return SketchSet(out.view(-1), start, cnt[:n], 8, k, "minhash")
+
     def sketch_kssd(self, seq, off, shuffled_dim, kmer_size=21, drlevel=3, stride=None):
         """sketchFileWithKssd's per-file body.  shuffled_dim: int32[2^(4*half_subk)] from the host."""
         off = np.ascontiguousarray(off, dtype=np.uint64)

@@ -73,6 +73,7 @@ int rtc_pinned(rtc_ctx* ctx, size_t bytes, void** out);
 // rtc_warmup does that beside the command lines' first PCIe copies instead of in front of their first sketch.
 int rtc_touch_sketch_minhash(rtc_ctx* ctx);
 int rtc_touch_sketch_kssd(rtc_ctx* ctx);
+int rtc_touch_sketch_minhash_packed(rtc_ctx* ctx);
 int rtc_touch_unpack(rtc_ctx* ctx);
 uint64_t rtc_free_hbm(rtc_ctx* ctx);
 

@@ -186,7 +186,7 @@ extern "C" int rtc_warmup(int device) {
   int st = RTC_OK;
   void *d_h = nullptr, *d_s = nullptr, *d_l = nullptr, *d_e = nullptr, *d_c = nullptr;
   // the sketch units first: the command lines' first batch reaches them a few milliseconds from now
-  (void)rtc_touch_unpack(ctx); (void)rtc_touch_sketch_minhash(ctx); (void)rtc_touch_sketch_kssd(ctx);
+  (void)rtc_touch_unpack(ctx); (void)rtc_touch_sketch_minhash(ctx); (void)rtc_touch_sketch_kssd(ctx); (void)rtc_touch_sketch_minhash_packed(ctx);
   do {
     const uint32_t n = 12, s = 24;  // twelve sketches of 24 hashes, neighbours share half of them
     std::vector<uint64_t> h((size_t)n * s), start(n);

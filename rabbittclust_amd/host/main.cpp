@@ -390,10 +390,12 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
     if (packed && !l.d_packed) CHECK(l.ctx, rtc_dev_alloc(l.ctx, host_bytes, &l.d_packed));
     if (need_chars && !l.d_seq) CHECK(l.ctx, rtc_dev_alloc(l.ctx, buf_bytes + 128, &l.d_seq));
   };
-  // KSSD over packed staging: the prefilter kernel reads the 2-bit stream itself (rtc_sketch_kssd_packed_dev) for the
-  // k-mer lengths it covers; RTC_KSSD_UNPACK=1 expands every batch first (the former path; tests compare the two)
-  std::atomic<bool> kssd_direct{job.kssd && packed && getenv("RTC_KSSD_UNPACK") == nullptr && half_subk == 6 && job.drlevel >= 3 &&
-                                (job.kmerSize + 1) / 2 * 2 >= 18 && (job.kmerSize + 1) / 2 * 2 <= 28};
+  // Sketching over packed staging: the kernels read the 2-bit stream themselves -- rtc_sketch_minhash_packed_dev for every k,
+  // rtc_sketch_kssd_packed_dev for the k-mer lengths the prefilter kernel covers.  RTC_SKETCH_UNPACK=1 (for --fast also the
+  // older RTC_KSSD_UNPACK=1) expands every batch to characters in HBM first (the former path; tests compare the stagings)
+  std::atomic<bool> direct{packed && getenv("RTC_SKETCH_UNPACK") == nullptr &&
+                           (!job.kssd || (getenv("RTC_KSSD_UNPACK") == nullptr && half_subk == 6 && job.drlevel >= 3 &&
+                                          (job.kmerSize + 1) / 2 * 2 >= 18 && (job.kmerSize + 1) / 2 * 2 <= 28))};
   ensure_buffers(maxb);
   // Each lane's first PCIe copy costs 17-29 ms instead of 6 (the runtime sets up the stream's copy path) and its buffers 5 ms:
   // the lanes do both now, on their worker threads, while this thread sizes and allocates the resident rows; the pipeline
@@ -403,8 +405,8 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       Lane* lp = &lanes[l];
       const char* src = stage[l % NSTAGE];
       const uint64_t warm_bytes = std::min<uint64_t>((uint64_t)8 << 20, packed ? buf_bytes / 4 : buf_bytes);
-      lp->worker = std::thread([&lane_buffers, &kssd_direct, lp, src, warm_bytes, packed]() {
-        lane_buffers(*lp, !packed || !kssd_direct.load());
+      lp->worker = std::thread([&lane_buffers, &direct, lp, src, warm_bytes, packed]() {
+        lane_buffers(*lp, !direct.load());
         CHECK(lp->ctx, rtc_copy_h2d(lp->ctx, packed ? lp->d_packed : lp->d_seq, src, warm_bytes));
       });
     }
@@ -478,7 +480,8 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
     const uint32_t nb = (uint32_t)kept.size();
     if (!nb) return;
     off.push_back(b.bytes);
-    lane_buffers(ln, !packed || !kssd_direct.load());
+    bool dir = direct.load();  // read once per batch: another lane may switch the run to the unpack path meanwhile
+    lane_buffers(ln, !dir);
     const double t0b = get_sec();
     if (packed) {
       const size_t nr = h_runs->size() / 2;
@@ -489,7 +492,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       }
       CHECK(c, rtc_copy_h2d(c, ln.d_packed, h_seq, b.bytes / 4 + 16));
       CHECK(c, rtc_copy_h2d(c, ln.d_runs, h_runs->data(), nr * 16));
-      if (!kssd_direct.load())
+      if (!dir)
         CHECK(c, rtc_unpack_bases_dev(c, (const uint8_t*)ln.d_packed, b.bytes + 64, (const uint64_t*)ln.d_runs, nr, (uint8_t*)ln.d_seq));
     } else {
       CHECK(c, rtc_copy_h2d(c, ln.d_seq, h_seq, b.bytes + 64));
@@ -508,8 +511,11 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
     bool row_overflow = false;
     if (!job.kssd) {
       if (!resident) { stride = *std::max_element(sizes.begin(), sizes.end()); CHECK(c, rtc_dev_alloc(c, (size_t)nb * stride * 8, &d_out)); }
-      CHECK(c, rtc_sketch_minhash_dev(c, (const uint8_t*)ln.d_seq, off.data(), nb, job.kmerSize, 42, sizes.data(), stride,
-                                      (uint64_t*)d_out, stride, d_cnt));
+      // the batch is sketched as it crossed PCIe (the records update() is handed, src/SketchInfo.cpp:928-948, at 2 bits a base)
+      if (dir) CHECK(c, rtc_sketch_minhash_packed_dev(c, (const uint8_t*)ln.d_packed, b.bytes + 64, (const uint64_t*)ln.d_runs, h_runs->size() / 2,
+                                                      off.data(), nb, job.kmerSize, 42, sizes.data(), stride, (uint64_t*)d_out, stride, d_cnt));
+      else CHECK(c, rtc_sketch_minhash_dev(c, (const uint8_t*)ln.d_seq, off.data(), nb, job.kmerSize, 42, sizes.data(), stride,
+                                           (uint64_t*)d_out, stride, d_cnt));
     } else {
       if (!resident) {
         uint64_t maxlen = 0;
@@ -520,13 +526,14 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       while (true) {
         int width = 0; uint32_t need = 0;
         int st;
-        if (kssd_direct.load()) {
+        if (dir) {
           // the batch is sketched as it crossed PCIe; configurations the packed kernel does not serve (a shuffle table
           // its exact index cannot hold) are expanded in HBM after all, from here on for every batch
           st = rtc_sketch_kssd_packed_dev(c, (const uint8_t*)ln.d_packed, b.bytes + 64, (const uint64_t*)ln.d_runs, h_runs->size() / 2,
                                           off.data(), nb, job.kmerSize, job.drlevel, shuffled.data(), d_out, stride, d_cnt, &width, &need);
           if (st == RTC_ERR_UNSUPPORTED) {
-            kssd_direct.store(false);
+            direct.store(false);
+            dir = false;
             lane_buffers(ln, true);
             CHECK(c, rtc_unpack_bases_dev(c, (const uint8_t*)ln.d_packed, b.bytes + 64, (const uint64_t*)ln.d_runs, h_runs->size() / 2, (uint8_t*)ln.d_seq));
             continue;
