@@ -166,8 +166,9 @@ def _gather_stride(sk):
 
 
 class MstPipeline:
-    """mode "minhash": rtc_sketch_minhash_dev; mode "kssd": rtc_sketch_kssd_dev (--fast, u32/u64 tuples), or
-    rtc_sketch_kssd_packed_dev when the step is handed an api.PackedBatch instead of characters."""
+    """mode "minhash": rtc_sketch_minhash_dev; mode "kssd": rtc_sketch_kssd_dev (--fast, u32/u64 tuples); handed an
+    api.PackedBatch instead of characters, the step sketches it as it is (rtc_sketch_minhash_packed_dev /
+    rtc_sketch_kssd_packed_dev)."""
 
     def __init__(self, ctx, k=21, sketch_size=1000, threshold=0.05, is_containment=False,
                  dist=None, rank=0, world=1, mode="minhash", drlevel=3, shuffled_dim=None, comm=None):
@@ -272,8 +273,13 @@ class MstPipeline:
         split = self.split_point(n_local, slots=3 * ctx.num_cu())
 
         def sketch_part(a, b):
-            ctx.sketch_minhash_into(seq, off[a:b + 1], out[a:b], cnt[a:b], k=self.k, size=self.s,
-                                    sizes=None if sizes is None else sizes[a:b])
+            from .api import PackedBatch
+            if isinstance(seq, PackedBatch):
+                ctx.sketch_minhash_packed(seq, off[a:b + 1], k=self.k, size=self.s, sizes=None if sizes is None else sizes[a:b],
+                                          out=out[a:b], cnt=cnt[a:b])
+            else:
+                ctx.sketch_minhash_into(seq, off[a:b + 1], out[a:b], cnt[a:b], k=self.k, size=self.s,
+                                        sizes=None if sizes is None else sizes[a:b])
 
         return self.gather_parts(out, cnt, [(0, split), (split, n_local)], self.k, before_part=sketch_part)
 
@@ -445,6 +451,7 @@ class MstPipeline:
         }
 
     def step(self, seq, off, sizes=None):
+        from .api import PackedBatch
         if isinstance(self.comm, NativeComm):
             return self.step_native(seq, off, sizes)
         ctx = self.ctx
@@ -453,7 +460,10 @@ class MstPipeline:
         if self.mode == "kssd":
             finish, works = self.sketch_kssd_and_gather(seq, off)
         elif not self.comm.active:
-            sk0 = ctx.sketch_minhash(seq, off, k=self.k, size=self.s, sizes=sizes)
+            if isinstance(seq, PackedBatch):
+                sk0 = ctx.sketch_minhash_packed(seq, off, k=self.k, size=self.s, sizes=sizes)
+            else:
+                sk0 = ctx.sketch_minhash(seq, off, k=self.k, size=self.s, sizes=sizes)
             finish, works = (lambda: sk0), []
         else:
             finish, works = self.sketch_and_gather(seq, off, sizes)

@@ -26,12 +26,21 @@ def test_bench_default_line_has_every_extra_without_error(ctx):
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"].get("value"), line["cpu_baseline"]
     assert line["roofline_dist"]["survey_8d_bytes_per_pair"] == 16000.0
     ex = line["extra"]
-    assert set(ex) == {"kssd", "kssd_packed", "greedy", "weak_first_point", "dense_pairs", "cli"}
+    assert set(ex) == {"minhash_packed", "kssd", "kssd_packed", "greedy", "weak_first_point", "dense_pairs", "config3_1gpu", "config5_1gpu", "cli"}
     for name, v in ex.items():
         assert "error" not in v, (name, v)
     # the same genomes sketched from characters and from the 2-bit staging format: same sketches, same forest
     assert ex["kssd_packed"]["mean_sketch_size"] == ex["kssd"]["mean_sketch_size"] and ex["kssd_packed"]["mst_edges"] == ex["kssd"]["mst_edges"]
     assert ex["kssd_packed"]["roofline"]["kernel"] == "sketch_kssd_packed_kernel" and ex["kssd_packed"]["roofline"]["physical_frac"] > 0
+    # the headline's genomes from the 2-bit staging format: same forest, fewer milliseconds of sketching than bytes would suggest
+    mp = ex["minhash_packed"]
+    assert mp["mst_edges"] == line["mst_edges"] and mp["roofline"]["physical_frac"] > 0 and mp["phase_ms"]["sketch_ms"] > 0
+    # the north-star configurations on one GPU: whole job, clusters, and the CPU side labelled as extrapolated
+    for name, n in (("config3_1gpu", 100000), ("config5_1gpu", 200000)):
+        c = ex[name]
+        assert c["total_s"] > 0 and c["sketch_s"] > 0 and c["pair_ms"] > 0 and c["mst_ms"] > 0 and c["pair_path"] in (2, 3)
+        assert 0 < c["clusters"] <= n // 10 * 2 and c["mst_edges"] > n // 2, (name, c["clusters"], c["mst_edges"])
+        assert c["cpu_extrapolated_s"] > 0 and "EXTRAPOLATED" in c["cpu_extrapolated"]["label"] and c["cpu_extrapolated"]["sample"]
     d = ex["dense_pairs"]
     assert d["pair_path"] == 2 and d["pair_kernel_ms"] > 0 and d["cand_edges"] >= 10 * 1000 * 999 // 2
     assert d["roofline_dist"]["bytes_per_pair"] == 16000.0 and d["roofline_dist"]["algorithmic_frac"] > 0

@@ -1089,9 +1089,9 @@ def _parse_seq_clusters(path):
 
 def test_packed_staging_unpack_kernel_and_cli_identity(ctx, oracle, tmp_path):
     """(1) rtc_unpack_bases_dev against its restatement on a packed batch with runs at every alignment.
-    (2) The command lines stage 2-bit packed bases by default (and --fast sketches them as they are,
+    (2) The command lines stage 2-bit packed bases by default and sketch them as they are (rtc_sketch_minhash_packed_dev,
     rtc_sketch_kssd_packed_dev): hash.sketch / kssd.hash.sketch / edge.mst / the cluster text must be byte-identical to
-    the RTC_STAGE_ASCII=1 run (and to the RTC_KSSD_UNPACK=1 run) on genomes with N runs, IUPAC codes, lower case,
+    the RTC_STAGE_ASCII=1 run and to the RTC_SKETCH_UNPACK=1 / RTC_KSSD_UNPACK=1 run on genomes with N runs, IUPAC codes, lower case,
     several records, CRLF line ends and a gzip member, over several small batches."""
     import ctypes as C
     import gzip
@@ -1149,9 +1149,10 @@ def test_packed_staging_unpack_kernel_and_cli_identity(ctx, oracle, tmp_path):
     open(lst, "w").write("\n".join(paths) + "\n")
     for tool, extra in (("clust-mst", ["-s", "500"]), ("clust-mst", ["--fast"]), ("clust-greedy", ["-c", "1000"])):
         outs = {}
-        variants = [("packed", {"RTC_VERBOSE": "1"}), ("ascii", {"RTC_STAGE_ASCII": "1"})]
-        if extra == ["--fast"]:  # KSSD reads the packed stream itself; RTC_KSSD_UNPACK=1 expands it first
-            variants.append(("unpack", {"RTC_KSSD_UNPACK": "1", "RTC_VERBOSE": "1"}))
+        # the sketch kernels read the packed stream themselves; RTC_SKETCH_UNPACK=1 (--fast: also the older RTC_KSSD_UNPACK=1)
+        # expands every batch to characters in HBM first
+        variants = [("packed", {"RTC_VERBOSE": "1"}), ("ascii", {"RTC_STAGE_ASCII": "1", "RTC_VERBOSE": "1"}),
+                    ("unpack", {"RTC_KSSD_UNPACK" if extra == ["--fast"] else "RTC_SKETCH_UNPACK": "1", "RTC_VERBOSE": "1"})]
         for tag, env in variants:
             d = os.path.join(tmp, tool + extra[0].strip("-") + tag)
             os.makedirs(d)
@@ -1162,10 +1163,8 @@ def test_packed_staging_unpack_kernel_and_cli_identity(ctx, oracle, tmp_path):
             folder = [os.path.join(d, x) for x in os.listdir(d) if os.path.isdir(os.path.join(d, x))][0]
             files = sorted(f for f in os.listdir(folder))
             outs[tag] = (open(out).read(), {f: open(os.path.join(folder, f), "rb").read() for f in files})
-            if extra == ["--fast"]:
-                assert ("over packed bases" in r.stderr) == (tag == "packed"), r.stderr[-2000:]
-        if "unpack" in outs:
-            assert outs["unpack"] == outs["packed"]
+            assert ("over packed bases" in r.stderr) == (tag == "packed"), r.stderr[-2000:]
+        assert outs["unpack"] == outs["packed"]
         assert outs["packed"][0] == outs["ascii"][0], (tool, extra)
         assert outs["packed"][1].keys() == outs["ascii"][1].keys()
         for f in outs["packed"][1]:
