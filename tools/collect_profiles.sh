@@ -1,12 +1,13 @@
 #!/bin/bash
-# Collects the round's judged profile artifacts on the GPU box (run through gpurun):
-#   1. bench.py JSON lines (minhash N=1 default; --mode kssd [--staging packed])       -> gpurun_out/prof/bench_*.jsonl
-#   2. rocprofv3 --kernel-trace --stats of the same commands            -> gpurun_out/prof/stats*/  (kernel_stats.csv)
-#   3. rocprofv3 --pmc passes (own runs, --pmc only)                     -> gpurun_out/prof/pmc*/  and *_pmc_traffic.json
-#   4. greedy (BASELINE config 4, 50 000 containment sketches) kernel stats + PMC passes of its sketch kernel
-#   5. the dense regime of the pair phase (bench.py --only dense_pairs: 10 families of 1 000, tiled N x N kernel): stats + PMC
-# Usage: bash tools/collect_profiles.sh [tag]     (tag names the files, e.g. r02)
-TAG=${1:-r04}
+# Collects the round's judged profile artifacts on the GPU box (run through gpurun).  Per section:
+#   bench.py JSON line                                     -> gpurun_out/prof/<section>/bench.jsonl
+#   rocprofv3 --kernel-trace --stats of the same command   -> gpurun_out/prof/<section>/stats/  (kernel_stats.csv)
+#   rocprofv3 --pmc passes (own runs, --pmc only)          -> gpurun_out/prof/<section>/pmc*/  and <tag>_<section>_pmc_traffic.json
+# Sections: minhash (BASELINE config[1], the judged line with every extra), minhash_packed (the same batch from the 2-bit
+# staging format), kssd / kssd_packed (config[4]'s per-GPU shape), greedy (config[3]), dense (tiled N x N kernel regime).
+# Usage: bash tools/collect_profiles.sh [tag] [section ...]     (tag names the files, e.g. r05; no section = all)
+TAG=${1:-r05}; shift
+SECTIONS=${@:-minhash minhash_packed kssd kssd_packed greedy dense}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
@@ -14,68 +15,52 @@ cd /tmp && export TMPDIR=/tmp
 PMCGROUPS=("FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" \
         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE")
-# ---- MinHash, BASELINE config[1] ----
-python $R/bench.py --steps 5 --warmup 2 > $OUT/bench_n1.jsonl 2> $OUT/bench_n1.err
-tail -c 600 $OUT/bench_n1.jsonl; echo
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/stats.log 2>&1
-python $R/tools/kstats.py $OUT/stats | head -12
-i=0
-for grp in "${PMCGROUPS[@]}"; do
-  i=$((i+1))
-  timeout 600 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc$i -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > $OUT/pmc$i.log 2>&1
+# section <dir> <bench flags of the JSON line> -- <flags of the stats run> -- <flags of the PMC runs>
+run_section() {
+  local D=$OUT/$1; shift
+  mkdir -p $D
+  local full=() stats=() pmc=() which=full
+  for a in "$@"; do
+    if [ "$a" = "--" ]; then if [ $which = full ]; then which=stats; else which=pmc; fi; continue; fi
+    case $which in full) full+=("$a");; stats) stats+=("$a");; pmc) pmc+=("$a");; esac
+  done
+  python $R/bench.py "${full[@]}" > $D/bench.jsonl 2> $D/bench.err
+  tail -c 400 $D/bench.jsonl; echo
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python $R/bench.py "${stats[@]}" > $D/stats.log 2>&1
+  python $R/tools/kstats.py $D/stats | head -10
+  local i=0
+  for grp in "${PMCGROUPS[@]}"; do
+    i=$((i+1))
+    timeout 900 rocprofv3 --pmc $grp --output-format csv -d $D/pmc$i -- python $R/bench.py "${pmc[@]}" > $D/pmc$i.log 2>&1
+  done
+}
+for S in $SECTIONS; do
+  case $S in
+    minhash)
+      run_section minhash --steps 5 --warmup 2 -- --steps 3 --warmup 1 --no-cpu-baseline --no-extra -- --steps 1 --warmup 0 --no-cpu-baseline --no-extra
+      python $R/tools/make_pmc_json.py $OUT/minhash $TAG > $OUT/${TAG}_pmc_traffic.json;;
+    minhash_packed)
+      run_section minhash_packed --staging packed --steps 5 --warmup 2 --no-extra -- --staging packed --steps 3 --warmup 1 --no-cpu-baseline --no-extra -- --staging packed --steps 1 --warmup 0 --no-cpu-baseline --no-extra
+      python $R/tools/make_pmc_json.py $OUT/minhash_packed ${TAG}_minhash_packed minhash 10000 5000000 packed > $OUT/${TAG}_minhash_packed_pmc_traffic.json;;
+    kssd)
+      run_section kssd --mode kssd --steps 3 --warmup 1 -- --mode kssd --steps 3 --warmup 1 --no-cpu-baseline -- --mode kssd --steps 1 --warmup 0 --no-cpu-baseline
+      python $R/tools/make_pmc_json.py $OUT/kssd ${TAG}_kssd kssd 25000 2000000 > $OUT/${TAG}_kssd_pmc_traffic.json;;
+    kssd_packed)
+      run_section kssd_packed --mode kssd --staging packed --steps 3 --warmup 1 -- --mode kssd --staging packed --steps 3 --warmup 1 --no-cpu-baseline -- --mode kssd --staging packed --steps 1 --warmup 0 --no-cpu-baseline
+      python $R/tools/make_pmc_json.py $OUT/kssd_packed ${TAG}_kssd_packed kssd 25000 2000000 packed > $OUT/${TAG}_kssd_packed_pmc_traffic.json;;
+    greedy)
+      # 50 000 prefix genomes of 0.4 .. 2 Mbp: 64 Gbp, mean length 1.28 Mbp (the "derived" per-step figures use genomes x this length)
+      run_section greedy --only greedy -- --only greedy -- --only greedy --extra-steps 1
+      python $R/tools/make_pmc_json.py $OUT/greedy ${TAG}_greedy greedy 50000 1280000 > $OUT/${TAG}_greedy_pmc_traffic.json;;
+    dense)
+      run_section dense --only dense_pairs -- --only dense_pairs -- --only dense_pairs --extra-steps 1
+      python $R/tools/make_pmc_json.py $OUT/dense ${TAG}_dense dense_pairs 10000 500000 > $OUT/${TAG}_dense_pmc_traffic.json;;
+  esac
 done
-python $R/tools/make_pmc_json.py $OUT $TAG > $OUT/${TAG}_pmc_traffic.json
-# ---- KSSD (--fast), BASELINE config[4] per-GPU shape ----
-K=$OUT/kssd; mkdir -p $K
-python $R/bench.py --mode kssd --steps 3 --warmup 1 > $K/bench_kssd_n1.jsonl 2> $K/bench_kssd_n1.err
-tail -c 400 $K/bench_kssd_n1.jsonl; echo
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $K/stats -- python $R/bench.py --mode kssd --steps 3 --warmup 1 --no-cpu-baseline > $K/stats.log 2>&1
-python $R/tools/kstats.py $K/stats | head -8
-i=0
-for grp in "${PMCGROUPS[@]}"; do
-  i=$((i+1))
-  timeout 600 rocprofv3 --pmc $grp --output-format csv -d $K/pmc$i -- python $R/bench.py --mode kssd --steps 1 --warmup 0 --no-cpu-baseline > $K/pmc$i.log 2>&1
-done
-python $R/tools/make_pmc_json.py $K ${TAG}_kssd kssd 25000 2000000 > $OUT/${TAG}_kssd_pmc_traffic.json
-# ---- KSSD from the 2-bit staging format (rtc_sketch_kssd_packed_dev), same shape ----
-KP=$OUT/kssd_packed; mkdir -p $KP
-python $R/bench.py --mode kssd --staging packed --steps 3 --warmup 1 > $KP/bench_kssd_packed_n1.jsonl 2> $KP/bench_kssd_packed_n1.err
-tail -c 400 $KP/bench_kssd_packed_n1.jsonl; echo
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $KP/stats -- python $R/bench.py --mode kssd --staging packed --steps 3 --warmup 1 --no-cpu-baseline > $KP/stats.log 2>&1
-python $R/tools/kstats.py $KP/stats | head -8
-i=0
-for grp in "${PMCGROUPS[@]}"; do
-  i=$((i+1))
-  timeout 600 rocprofv3 --pmc $grp --output-format csv -d $KP/pmc$i -- python $R/bench.py --mode kssd --staging packed --steps 1 --warmup 0 --no-cpu-baseline > $KP/pmc$i.log 2>&1
-done
-python $R/tools/make_pmc_json.py $KP ${TAG}_kssd_packed kssd 25000 2000000 packed > $OUT/${TAG}_kssd_packed_pmc_traffic.json
-# ---- greedy, BASELINE config[3] ----
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/greedy_stats -- python $R/tools/run_configs.py greedy 50000 2000000 > $OUT/greedy.log 2>&1
-tail -3 $OUT/greedy.log
-python $R/tools/kstats.py $OUT/greedy_stats | head -8
-i=0
-for grp in "${PMCGROUPS[@]}"; do
-  i=$((i+1))
-  timeout 600 rocprofv3 --pmc $grp --output-format csv -d $OUT/greedy_pmc/pmc$i -- python $R/bench.py --only greedy --extra-steps 1 > $OUT/greedy_pmc$i.log 2>&1
-done
-# 50 000 prefix genomes of 0.4 .. 2 Mbp: 64 Gbp, mean length 1.28 Mbp (the "derived" per-step figures use genomes x this length)
-python $R/tools/make_pmc_json.py $OUT/greedy_pmc ${TAG}_greedy greedy 50000 1280000 > $OUT/${TAG}_greedy_pmc_traffic.json
-# ---- dense regime of the pair phase (tiled N x N kernel) ----
-D=$OUT/dense; mkdir -p $D
-python $R/bench.py --only dense_pairs > $D/bench_dense.jsonl 2> $D/bench_dense.err
-tail -c 600 $D/bench_dense.jsonl; echo
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python $R/bench.py --only dense_pairs > $D/stats.log 2>&1
-python $R/tools/kstats.py $D/stats | head -8
-i=0
-for grp in "${PMCGROUPS[@]}"; do
-  i=$((i+1))
-  timeout 600 rocprofv3 --pmc $grp --output-format csv -d $D/pmc$i -- python $R/bench.py --only dense_pairs --extra-steps 1 > $D/pmc$i.log 2>&1
-done
-python $R/tools/make_pmc_json.py $D ${TAG}_dense dense_pairs 10000 500000 > $OUT/${TAG}_dense_pmc_traffic.json
 python - <<PY
-import json
-for f in ("$OUT/${TAG}_pmc_traffic.json", "$OUT/${TAG}_kssd_pmc_traffic.json", "$OUT/${TAG}_kssd_packed_pmc_traffic.json", "$OUT/${TAG}_greedy_pmc_traffic.json", "$OUT/${TAG}_dense_pmc_traffic.json"):
+import glob, json
+for f in sorted(glob.glob("$OUT/${TAG}_*pmc_traffic.json")):
     d = json.load(open(f))
     for k, v in d["kernels"].items():
-        print(k, {a: b for a, b in v.items() if a in ("hbm_bytes_per_launch", "derived")})
+        print(f.split("/")[-1], k, {a: b for a, b in v.items() if a in ("hbm_bytes_per_launch", "derived")})
 PY

@@ -6,9 +6,9 @@ root, tag = sys.argv[1], sys.argv[2]
 MODE = sys.argv[3] if len(sys.argv) > 3 else "minhash"
 G = int(sys.argv[4]) if len(sys.argv) > 4 else 10000
 L = int(sys.argv[5]) if len(sys.argv) > 5 else 5_000_000
-STAGING = sys.argv[6] if len(sys.argv) > 6 else None  # "packed": bench.py --mode kssd --staging packed
+STAGING = sys.argv[6] if len(sys.argv) > 6 else None  # "packed": bench.py --staging packed
 K, S = 21, 1000
-want = ("synth_kernel", "sketch_minhash_kernel", "sketch_kssd", "transpose_slices_kernel", "pair_tiled_kernel", "pair_join_phase")
+want = ("synth_kernel", "sketch_minhash_kernel", "sketch_minhash_packed_kernel", "sketch_kssd", "transpose_slices_kernel", "pair_tiled_kernel", "pair_join_phase")
 JOIN_PARTS = ("rocprim", "join_")  # pair_join_phase = every kernel of the inverted join: rocPRIM sort / scan / encode + join_*
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
@@ -22,7 +22,7 @@ for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), 
         tot[name][r["Counter_Name"]] += float(r["Counter_Value"])
         # the gated second launch over the partial segments (runtime-k instantiation, every workgroup leaves at once unless the
         # merge flagged its genome) belongs to the sketch call of the compile-time-k launch in front of it: no launch of its own
-        if name == "sketch_minhash_kernel" and "sketch_minhash_kernel<0," in r["Kernel_Name"]:
+        if name.startswith("sketch_minhash") and "_kernel<0," in r["Kernel_Name"]:
             continue
         # the join is many kernels per pair phase: its "launch" is the phase (one per bench step, --steps 1 in the PMC runs)
         disp[name][r["Counter_Name"]].add("phase" if name == "pair_join_phase" else r["Dispatch_Id"])
@@ -55,7 +55,7 @@ for name in want:
         k["hbm_bytes_per_launch"] = rd + wr
     elif "FETCH_SIZE_per_launch" in k and "WRITE_SIZE_per_launch" in k:
         k["hbm_bytes_per_launch"] = (2.0 * k["FETCH_SIZE_per_launch"] + k["WRITE_SIZE_per_launch"]) * 1024.0
-    if name in ("sketch_minhash_kernel", "sketch_kssd") and "SQ_INSTS_VALU_per_launch" in k:
+    if name in ("sketch_minhash_kernel", "sketch_minhash_packed_kernel", "sketch_kssd") and "SQ_INSTS_VALU_per_launch" in k:
         steps = G * L / 64.0
         k["derived"] = {
             "kmer_wave_steps": steps,
