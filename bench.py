@@ -27,9 +27,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_JSON = ("r04_pmc_traffic.json", "r04_kssd_pmc_traffic.json", "r04_kssd_packed_pmc_traffic.json", "r04_dense_pmc_traffic.json", "r04_greedy_pmc_traffic.json",
-                "r03_pmc_traffic.json", "r03_kssd_pmc_traffic.json", "r02_pmc_traffic.json", "r02_kssd_pmc_traffic.json",
-                "r01_pmc_traffic.json")
+def _profile_jsons():
+    """committed PMC summaries, newest round first (profiles/rNN_*pmc_traffic.json)"""
+    import glob
+    return [os.path.basename(f) for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*pmc_traffic.json")), reverse=True)]
+
+
+PROFILE_JSON = _profile_jsons()
 SURVEY_8D_PAIR_NOTE = ("SURVEY 8(d): algorithmic bytes of one genome pair = (|A| + |B|) * width (16 000 B at s = 1000, u64)")
 
 
