@@ -74,12 +74,16 @@ static Metrics g_metrics;
 // The warm-up helper thread (rtc_warmup beside the sketch phase) is joined before the process leaves through exit():
 // static destructors and the HIP runtime's teardown must not run while it is still inside a HIP call.
 static std::thread* g_gpu_thread = nullptr;  // main's GPU bring-up thread while it runs
-// RTC_EXIT_PROBE=1 (measurement only): what the process leaves to the kernel at _exit -- the pageable staging ring and the
-// lanes' device staging -- is released by hand, timed, before leaving: says which of them the time between _exit and the
-// parent's wait() belongs to (tools/cli_timeline.py)
+#ifdef RTC_MEASURE
+// Measurement build only (`make measure` -> bin/clust-mst-measure, tools/cli_timeline.py; the shipped binaries hold none of
+// this).  RTC_EXIT_PROBE=1: what the process leaves to the kernel at _exit -- the pageable staging ring and the lanes' device
+// staging -- is released by hand, timed, before leaving: says which of them the time between _exit and the parent's wait()
+// belongs to.  RTC_EXIT_DELAY_MS / RTC_START_DELAY_MS: a sleep before leaving / before anything else.  RTC_NO_THP=1: staging
+// memory without transparent huge pages.
 extern "C" int rtc_debug_device_reset(int device);
 static std::vector<char*> g_exit_probe_host;
 static std::vector<std::pair<rtc_ctx*, void*>> g_exit_probe_dev;
+#endif
 static std::thread g_warmup_thread;
 static std::mutex g_warmup_mutex;
 static void join_warmup() {
@@ -178,7 +182,10 @@ struct SketchJob {
 static char* alloc_pageable(size_t bytes) {  // 2 MiB-aligned, transparent huge pages if the host allows
   void* p = nullptr;
   if (posix_memalign(&p, (size_t)2 << 20, bytes) != 0) return nullptr;
-  if (!getenv("RTC_NO_THP")) madvise(p, bytes, MADV_HUGEPAGE);  // (the switch: measurement only -- without huge pages the parse is 15 % slower and the exit 0.04 s longer)
+#ifdef RTC_MEASURE
+  if (getenv("RTC_NO_THP")) return (char*)p;  // (without huge pages the parse is 15 % slower and the exit 0.04 s longer)
+#endif
+  madvise(p, bytes, MADV_HUGEPAGE);
   return (char*)p;
 }
 
@@ -616,8 +623,11 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   // Pageable staging is NOT returned here: munmap of GBs of touched pages takes ~0.1 s and holds the
   // address-space lock, which stalls every hipMalloc of the clustering phase that follows (measured:
   // candidate edges 117 ms instead of 3 ms).  The pages go back when the process ends.
-  for (auto& p : stage) { if (p) g_exit_probe_host.push_back(p); p = nullptr; }
+#ifdef RTC_MEASURE
+  for (auto& p : stage) if (p) g_exit_probe_host.push_back(p);
   for (Lane& l : lanes) { if (l.d_seq) g_exit_probe_dev.push_back({l.ctx, l.d_seq}); if (l.d_packed) g_exit_probe_dev.push_back({l.ctx, l.d_packed}); }
+#endif
+  for (auto& p : stage) p = nullptr;
   // The device staging buffers stay allocated until the process ends: hipFree of a multi-GB buffer
   // costs ~0.4 s here and the clustering phase needs far less than the 288 GB that are there.
   if (verbose) fprintf(stderr, "[free]  host staging %.3fs\n", get_sec() - tf0);
@@ -1642,15 +1652,37 @@ static int append_clust_greedy(const Options& o, vector<Gpu>& gpus) {
 }
 #endif
 
+// Will this run use exactly one GPU?  Answered without the HIP runtime (its environment must be final before it starts): a
+// --gpus / RTC_GPUS choice that names one device, or "all" on a host whose driver topology lists one GPU node.
+static bool single_gpu_run(const string& spec) {
+  if (spec != "all") return spec.find(',') == string::npos;
+  for (const char* v : {"HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"})
+    if (const char* e = getenv(v)) return *e != 0 && strchr(e, ',') == nullptr;
+  int gpus = 0;
+  for (int node = 0; node < 64; node++) {
+    FILE* f = fopen(("/sys/class/kfd/kfd/topology/nodes/" + std::to_string(node) + "/properties").c_str(), "r");
+    if (!f) break;
+    char key[64]; unsigned long long val;
+    while (fscanf(f, "%63s %llu", key, &val) == 2)
+      if (strcmp(key, "simd_count") == 0 && val > 0) gpus++;
+    fclose(f);
+  }
+  return gpus == 1;
+}
+
 int main(int argc, char** argv) {
-  if (const char* e = getenv("RTC_START_DELAY_MS")) usleep(1000 * atoi(e));  // (measurement only)
+#ifdef RTC_MEASURE
+  if (const char* e = getenv("RTC_START_DELAY_MS")) usleep(1000 * atoi(e));
+#endif
   const double t_main = get_sec();
+  Options o = parse(argc, argv);
   // The staging batches leave pageable memory 15 % faster through the runtime's copy kernels than through the SDMA engines
   // (2 048 x 5 Mbp: output 0.112-0.127 s after the runtime is up against 0.128-0.153 s, tools/cli_timeline.py) and the
-  // sketch kernels leave the CUs idle two thirds of the time anyway.  Has to be in the environment before the runtime
-  // starts; a value the user has set is left alone (HSA_ENABLE_SDMA=1 brings the engines back).
-  setenv("HSA_ENABLE_SDMA", "0", 0);
-  Options o = parse(argc, argv);
+  // sketch kernels leave the CUs idle two thirds of the time anyway.  Measured on ONE GPU only, so only a run on one GPU
+  // gets it: with several, RCCL's collectives and the share step's peer copies would land on the CUs beside the sketch
+  // kernels, which nobody has timed.  Has to be in the environment before the runtime starts (hence the look at the
+  // driver's topology instead of a device count); a value the user has set is left alone.
+  if (single_gpu_run(o.gpus.empty() ? (getenv("RTC_GPUS") ? getenv("RTC_GPUS") : "all") : o.gpus)) setenv("HSA_ENABLE_SDMA", "0", 0);
   if (!o.has_output && !o.db_stats) { cerr << "ERROR: option -o/--output is required (unless --buildDB or --stats is used)" << endl; return 1; }
   if (o.threads < 1) { fprintf(stderr, "-----Invalid thread number %d\n", o.threads); return 1; }
   fprintf(stderr, "-----set the thread number %d\n", o.threads);
@@ -2038,7 +2070,8 @@ int main(int argc, char** argv) {
   g_metrics.num("total_s", t_end - t_main);
   g_metrics.write();
   join_warmup();
-  if (const char* e = getenv("RTC_EXIT_DELAY_MS")) usleep(1000 * atoi(e));  // (measurement only, with RTC_EXIT_PROBE)
+#ifdef RTC_MEASURE
+  if (const char* e = getenv("RTC_EXIT_DELAY_MS")) usleep(1000 * atoi(e));
   if (getenv("RTC_EXIT_PROBE")) {
     const double p0 = get_sec();
     for (char* p : g_exit_probe_host) free(p);
@@ -2055,6 +2088,7 @@ int main(int argc, char** argv) {
       _exit(0);
     }
   }
+#endif
   for (Gpu& g : gpus) { if (g.comm) rtc_comm_destroy(g.comm); }
   for (Gpu& g : gpus) rtc_ctx_destroy(g.ctx);
   if (getenv("RTC_VERBOSE")) fprintf(stderr, "[exit]  output written at t+%.3fs, contexts released in %.3fs (main entered at %.6f, leaving at %.6f)\n", t_end - t_main,

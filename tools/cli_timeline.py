@@ -28,7 +28,7 @@ del ctx
 for r in range(runs):
     time.sleep(float(os.environ.get("TL_SLEEP", "0")))  # the previous process's GPU state is torn down by the driver after it has left
     t0 = time.time()
-    res = subprocess.run(["env", "RTC_VERBOSE=1"] + [f"{k}={v}" for k, v in os.environ.items() if k.startswith("RTC_")] + [ os.path.join(root, "rabbittclust_amd", "bin", "clust-mst"), "-l", "-i", os.path.join(tmp, "list.txt"), "-k", "21",
+    res = subprocess.run(["env", "RTC_VERBOSE=1"] + [f"{k}={v}" for k, v in os.environ.items() if k.startswith("RTC_")] + [ os.path.join(root, "rabbittclust_amd", "bin", "clust-mst-measure" if os.path.exists(os.path.join(root, "rabbittclust_amd", "bin", "clust-mst-measure")) else "clust-mst"), "-l", "-i", os.path.join(tmp, "list.txt"), "-k", "21",
                           "-d", "0.05", "-e", "-o", os.path.join(tmp, "out.cluster")] + extra, capture_output=True, text=True, cwd=tmp)
     dt = time.time() - t0
     import re
