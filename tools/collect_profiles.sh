@@ -57,6 +57,9 @@ for S in $SECTIONS; do
       python $R/tools/make_pmc_json.py $OUT/dense ${TAG}_dense dense_pairs 10000 500000 > $OUT/${TAG}_dense_pmc_traffic.json;;
   esac
 done
+# what travels back is the summaries: the raw counter and trace CSVs (tens of MB per run) stay on the box
+find $OUT -type d -name "pmc[0-9]*" -prune -exec rm -rf {} +
+find $OUT -path "*stats*" -type f ! -name "*kernel_stats.csv" ! -name "stats.log" -delete
 python - <<PY
 import glob, json
 for f in sorted(glob.glob("$OUT/${TAG}_*pmc_traffic.json")):
