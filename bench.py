@@ -566,7 +566,7 @@ def extra_cli(args, ctx, api, pipeline, steps):
     binp = os.path.join(ROOT, "rabbittclust_amd", "bin", "clust-mst")
     if not os.path.exists(binp):
         raise FileNotFoundError(binp)
-    need = int(n * L * 1.02) + (64 << 20)
+    need = int(n * L * 1.15) + (64 << 20)  # the plain files and, beside them, an eighth of them gzip'd
     where = None  # tmpfs when it has the room (the page cache is warm either way: the files were just written)
     for cand in ("/dev/shm", tempfile.gettempdir()):
         try:
@@ -602,31 +602,90 @@ def extra_cli(args, ctx, api, pipeline, steps):
                            f"region), bin/clust-mst -l -i list -k {args.k} -d {args.threshold} -e, page cache warm, best of three runs "
                            f"started a second after the previous process left",
                "host_cores": usable_cores()}
-        for name, extra in (("minhash", ["-s", str(args.s)]), ("fast", ["--fast"])):
+        def run_cli(tag, list_file, extra, n_files, bases):
             best = None
             for rep in range(3):  # from the second run on the code objects and the files' pages are warm
                 # A process that has left is not gone: the driver tears its GPU state down asynchronously (~0.25 s of work), and a
                 # process launched inside that window pays it in its own HIP start-up (0.07 -> 0.13-0.26 s) or at its own exit
                 # (0.001 -> 0.12 s): tools/cli_timeline.py, TL_SLEEP=0 against 1.  One command line is one process.
                 time.sleep(1.0)
-                mj = os.path.join(tmp, f"metrics_{name}.json")
+                mj = os.path.join(tmp, f"metrics_{tag}.json")
                 env = dict(os.environ, RTC_METRICS_JSON=mj)
                 t0 = time.perf_counter()
-                r = subprocess.run([binp, "-l", "-i", os.path.join(tmp, "list.txt"), "-k", str(args.k), "-d", str(args.threshold), "-e",
-                                    "-o", os.path.join(tmp, f"out_{name}.cluster")] + extra, capture_output=True, text=True, cwd=tmp, env=env)
+                r = subprocess.run([binp, "-l", "-i", list_file, "-k", str(args.k), "-d", str(args.threshold), "-e",
+                                    "-o", os.path.join(tmp, f"out_{tag}.cluster")] + extra, capture_output=True, text=True, cwd=tmp, env=env)
                 wall = time.perf_counter() - t0
                 if r.returncode != 0:
                     raise RuntimeError(f"clust-mst {' '.join(extra)} rc={r.returncode}: {r.stderr[-400:]}")
                 m = json.load(open(mj))
-                cur = {"wall_s": wall, "end_to_end_gbp_per_sec": n * L / wall / 1e9,
+                cur = {"wall_s": wall, "end_to_end_gbp_per_sec": bases / wall / 1e9,
                        "computing_sketch_s": m.get("computing_sketch_s"), "sketch_phase_gbp_per_sec": m.get("sketch_gbp_per_s"),
                        "generateMST_s": m.get("generateMST_s"), "total_s": m.get("total_s"), "threads": m.get("threads"),
                        "genomes": m.get("genomes"), "clusters": m.get("clusters"), "mst_edges": m.get("mst_edges"),
                        "parse_s": m.get("parse_s"), "parse_gbp_per_sec": m.get("parse_gbp_per_s"),
-                       "parse_gbp_per_sec_per_thread": m.get("parse_gbp_per_s_per_thread"), "hip_init_s": m.get("hip_init_s"), "hip_init_exposed_s": m.get("hip_init_exposed_s")}
+                       "parse_gbp_per_sec_per_thread": m.get("parse_gbp_per_s_per_thread"), "hip_init_s": m.get("hip_init_s"), "hip_init_exposed_s": m.get("hip_init_exposed_s"),
+                       "batches": m.get("batches"), "gpu_copy_ms_per_batch": m.get("gpu_copy_ms_per_batch"),
+                       "gpu_sketch_ms_per_batch": m.get("gpu_sketch_ms_per_batch"), "runs_per_genome": m.get("runs_per_genome"),
+                       "inflate_gb_per_sec_per_thread": m.get("inflate_gb_per_s_per_thread")}
                 if best is None or cur["wall_s"] < best["wall_s"]:
                     best = cur
-            out[name] = best
+            return best
+
+        plain_list = os.path.join(tmp, "list.txt")
+        out["minhash"] = run_cli("minhash", plain_list, ["-s", str(args.s)], n, n * L)
+        out["fast"] = run_cli("fast", plain_list, ["--fast"], n, n * L)
+        out["batch_note"] = ("gpu_copy_ms_per_batch / gpu_sketch_ms_per_batch: a lane's host thread per staged batch -- PCIe copy of the 2-bit "
+                             "batch + run list, then the sketch launch straight from it (no unpack pass since round 5) + the read-back of "
+                             "the counts; two lanes per GPU work beside the parser threads")
+        # ---- the shapes sketchFiles actually opens (src/SketchInfo.cpp:880-948): gzip'd files, many-contig assemblies ----
+        ngz = min(n, max(16, n // 8))
+        t0 = time.time()
+        subprocess.run("head -%d list.txt | xargs -P %d -n 4 gzip -6 -k" % (ngz, usable_cores()), shell=True, cwd=tmp, check=True)
+        t_gz = time.time() - t0
+        gz_paths = [p + ".gz" for p in paths[:ngz]]
+        with open(os.path.join(tmp, "list_gz.txt"), "w") as f:
+            f.write("\n".join(gz_paths) + "\n")
+        gz_bytes = sum(os.path.getsize(p) for p in gz_paths)
+        g = run_cli("gz", os.path.join(tmp, "list_gz.txt"), ["-s", str(args.s)], ngz, ngz * L)
+        g["workload"] = (f"the first {ngz} of the same genomes as .fna.gz (gzip -6, {gz_bytes / 1e9:.2f} GB compressed, written in {t_gz:.1f}s outside "
+                         "the timed region), MinHash")
+        g["limit"] = ("compressed input is bound by inflate on the parser threads (inflate_gb_per_sec_per_thread x threads, libdeflate where "
+                      "the host has it, zlib otherwise); DESIGN.md 6 costs the alternatives")
+        out["gz"] = g
+        for p in gz_paths:
+            os.unlink(p)
+        for p in paths:
+            os.unlink(p)
+        # 200-contig assemblies: records of 5-45 kbp (a multiple of the 80-column line), three N runs of 10-500 bases per genome
+        t0 = time.time()
+        rng = np.random.default_rng(5)
+        cpaths = []
+        for c0 in range(0, n, chunk):
+            c1 = min(n, c0 + chunk)
+            off = np.arange(c1 - c0 + 1, dtype=np.uint64) * np.uint64(L)
+            seq = ctx.synth_genomes(desc[c0:c1], off).cpu().numpy()
+            for gi in range(c0, c1):
+                a = seq[(gi - c0) * L:(gi - c0 + 1) * L].copy()
+                for _ in range(3):
+                    st = int(rng.integers(0, L - 600))
+                    a[st:st + int(rng.integers(10, 500))] = ord("N")
+                body = np.concatenate([a.reshape(-1, 80), nl], axis=1).tobytes()
+                nlines = L // 80
+                cuts = [0]
+                while cuts[-1] < nlines:
+                    cuts.append(min(nlines, cuts[-1] + int(rng.integers(63, 563))))
+                p = os.path.join(tmp, f"c{gi:05d}.fna")
+                with open(p, "wb") as f:
+                    f.write(b"".join(f">g{gi}_contig{r} synthetic\n".encode() + body[cuts[r] * 81:cuts[r + 1] * 81] for r in range(len(cuts) - 1)))
+                cpaths.append(p)
+            del seq
+        with open(os.path.join(tmp, "list_contigs.txt"), "w") as f:
+            f.write("\n".join(cpaths) + "\n")
+        t_c = time.time() - t0
+        c = run_cli("contigs", os.path.join(tmp, "list_contigs.txt"), ["-s", str(args.s)], n, n * L)
+        c["workload"] = (f"{n} x {L} bp assemblies of ~200 contigs (records of 5-45 kbp) with three N runs each, plain FASTA (written in {t_c:.1f}s "
+                         "outside the timed region), MinHash: every record separator and N stretch is a run of the staging format")
+        out["contigs"] = c
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -265,6 +265,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
   vector<size_t> row_file;  // row (= genome id) -> list position
   double parse_s = 0;       // wall time the parser threads took, summed over the batches (the GPU lanes work beside it)
   uint64_t parse_bytes = 0;
+  std::atomic<uint64_t> gpu_copy_us{0}, gpu_sketch_us{0}, gpu_batches{0}, runs_total{0};  // the lanes' side of the batches (metrics)
   auto parse_batch = [&](const Batch& b, size_t bi, char* buf, vector<uint64_t>& bruns, int round) -> uint32_t {
     const double t0 = get_sec();
     vector<uint64_t> need(b.files.size(), 0);
@@ -576,6 +577,10 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
       }
     }
     if (temp) { CHECK(c, rtc_dev_free(c, d_out)); CHECK(c, rtc_dev_free(c, d_cnt)); }
+    gpu_copy_us += (uint64_t)((t1 - t0b) * 1e6);
+    gpu_sketch_us += (uint64_t)((get_sec() - t1) * 1e6);
+    gpu_batches++;
+    if (h_runs) runs_total += h_runs->size() / 2;
     if (verbose) fprintf(stderr, "[gpu %d.%d] %u genomes, %.2f GB: alloc %.3fs h2d %.3fs sketch%s %.3fs\n", (int)ln.gpu, (int)ln.owned, nb, b.bytes / 1e9, t0b - t0, t1 - t0b,
                          to_host || temp ? "+d2h" : "", get_sec() - t1);
   };
@@ -616,6 +621,17 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
     g_metrics.num("parse_s", parse_s);
     g_metrics.num("parse_gbp_per_s", (double)parse_bytes / parse_s / 1e9);
     g_metrics.num("parse_gbp_per_s_per_thread", (double)parse_bytes / parse_s / 1e9 / std::max(1, job.threads));
+  }
+  if (gpu_batches.load()) {  // per batch, on the lane's host thread: copy (+ unpack where a path still needs characters), sketch + read-back of the counts
+    g_metrics.num("batches", (double)gpu_batches.load());
+    g_metrics.num("gpu_copy_ms_per_batch", gpu_copy_us.load() / 1e3 / gpu_batches.load());
+    g_metrics.num("gpu_sketch_ms_per_batch", gpu_sketch_us.load() / 1e3 / gpu_batches.load());
+    g_metrics.num("runs_per_genome", (double)runs_total.load() / std::max<size_t>(1, nfiles));
+  }
+  {
+    double inf_s = 0; uint64_t inf_b = 0;
+    rtc_host_inflate_stats(&inf_s, &inf_b);
+    if (inf_b) { g_metrics.num("inflate_s_all_threads", inf_s); g_metrics.num("inflate_gb_per_s_per_thread", (double)inf_b / inf_s / 1e9); }
   }
   const double tf0 = get_sec();
   // (the second lanes' contexts and every device staging buffer live until the process ends, see below)

@@ -12,6 +12,7 @@
 #include <string.h>
 #include <sys/stat.h>
 #include <time.h>
+#include <atomic>
 #include <zlib.h>
 #if defined(__x86_64__)
 #include <immintrin.h>  // the AVX2 / AVX-512 tiers of the FASTA intake; other hosts build the portable tier only
@@ -130,6 +131,10 @@ class GzStream {
     return mid;
   }
   static constexpr int SLACK = 128;  // bytes a sink may read beyond the data it is handed (inside the allocation)
+  // what decompression cost, summed over the parser threads (rtc_host_inflate_stats: the command lines' metrics)
+  static std::atomic<uint64_t>& inflate_ns() { static std::atomic<uint64_t> v{0}; return v; }
+  static std::atomic<uint64_t>& inflate_bytes() { static std::atomic<uint64_t> v{0}; return v; }
+  static uint64_t now_ns() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec; }
 
  private:
   static constexpr int BUF = 1 << 18;
@@ -164,7 +169,10 @@ class GzStream {
     while (ok && in < csize) {
       if (csize - in < 18 || comp[in] != 0x1f || comp[in + 1] != 0x8b) { ok = false; break; }  // trailing bytes that are no member
       size_t used = 0, made = 0;
+      const uint64_t t_in = now_ns();
       const int rc = lib.gunzip_ex(d, comp + in, csize - in, mem + out, cap - out, &used, &made);
+      inflate_ns() += now_ns() - t_in;
+      if (rc == 0) inflate_bytes() += made;
       if (rc == 3) {  // LIBDEFLATE_INSUFFICIENT_SPACE
         if (cap >= cap_max) { ok = false; break; }
         const size_t grown = std::min(cap_max, cap * 2);
@@ -190,7 +198,11 @@ class GzStream {
       memcpy(buf_, mem_ + mem_pos_, n);
       mem_pos_ += n;
       end_ = (int)n;
-    } else if (f_) end_ = gzread(f_, buf_, BUF);
+    } else if (f_) {
+      const uint64_t t_in = now_ns();  // (f_ is only ever a gzip stream)
+      end_ = gzread(f_, buf_, BUF);
+      if (end_ > 0) { inflate_ns() += now_ns() - t_in; inflate_bytes() += (uint64_t)end_; }
+    }
     else {
       ssize_t r;
       do { r = read(fd_, buf_, BUF); } while (r < 0 && errno == EINTR);
@@ -512,6 +524,10 @@ int next_record(GzStream& ks, int& last_char, FastaRecord& r) {
 }
 
 }  // namespace
+void rtc_host_inflate_stats(double* seconds, uint64_t* bytes_out) {
+  if (seconds) *seconds = (double)GzStream::inflate_ns().load() * 1e-9;
+  if (bytes_out) *bytes_out = GzStream::inflate_bytes().load();
+}
 
 bool read_fasta(const std::string& path, std::vector<FastaRecord>& out) {
   GzStream ks(path);

@@ -171,4 +171,8 @@ void print_linkage_matrix(int n, const std::vector<rtc_edge>& mst, const std::st
 
 std::string current_date_time();  // src/common.hpp:36-44
 
+// Time the parser threads spent inside gzip decompression (libdeflate or zlib), summed over threads, and the bytes it produced
+// since the process started: the command lines report them (RTC_METRICS_JSON: inflate_gb_per_s_per_thread).
+void rtc_host_inflate_stats(double* seconds, uint64_t* bytes_out);
+
 }  // namespace rtc

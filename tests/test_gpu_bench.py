@@ -44,6 +44,10 @@ def test_bench_default_line_has_every_extra_without_error(ctx):
     d = ex["dense_pairs"]
     assert d["pair_path"] == 2 and d["pair_kernel_ms"] > 0 and d["cand_edges"] >= 10 * 1000 * 999 // 2
     assert d["roofline_dist"]["bytes_per_pair"] == 16000.0 and d["roofline_dist"]["algorithmic_frac"] > 0
+    for mode in ("gz", "contigs"):
+        c = ex["cli"][mode]
+        assert c["wall_s"] > 0 and c["clusters"] > 0 and c["gpu_sketch_ms_per_batch"] > 0, (mode, c)
+    assert ex["cli"]["gz"]["inflate_gb_per_sec_per_thread"] > 0 and ex["cli"]["contigs"]["runs_per_genome"] > 100
     for mode in ("minhash", "fast"):
         c = ex["cli"][mode]
         assert c["genomes"] == 64 and c["wall_s"] > 0 and c["computing_sketch_s"] > 0 and c["parse_gbp_per_sec_per_thread"] > 0

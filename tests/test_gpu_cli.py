@@ -123,6 +123,61 @@ def test_clust_mst_end_to_end_and_resume(oracle, tmp_path):
     assert open(out3).read() == text  # --premsted re-cuts the saved MST: identical text
 
 
+@pytest.mark.parametrize("shape", ["contigs", "gz"])
+def test_clust_mst_real_input_shapes_match_the_oracle(oracle, tmp_path, shape):
+    """What sketchFiles actually opens (src/SketchInfo.cpp:880-948): assemblies of ~200 contigs with N runs -- every record
+    separator and N stretch is a run of the staging format, most waves of the packed sketch kernel still take the express walk --
+    and gzip'd files (two of them with several members).  hash.sketch must equal the oracle run on the same records."""
+    import gzip
+    tmp = str(tmp_path)
+    rng = np.random.default_rng(23)
+    from rabbittclust_amd import api
+    L = 2_400_000
+    desc = api.synth_family_descs(2, 4, global_seed=61)
+    paths, parts, off = [], [], [0]
+    for g, d in enumerate(desc):
+        a = oracle.synth_genome(int(d["fam_seed"]), int(d["mut_seed"]), int(d["mut_thr"]), L).copy()
+        for _ in range(3):
+            st = int(rng.integers(0, L - 600))
+            a[st:st + int(rng.integers(1, 500))] = ord("N")
+        cuts = [0]
+        while cuts[-1] < L:
+            cuts.append(min(L, cuts[-1] + (int(rng.integers(1000, 25_000)) if shape == "contigs" else L)))
+        recs = [a[cuts[r]:cuts[r + 1]].tobytes() for r in range(len(cuts) - 1)]
+        text = b"".join(f">g{g}_c{r} x\n".encode() + b"\n".join(rec[i:i + 80] for i in range(0, len(rec), 80)) + b"\n" for r, rec in enumerate(recs))
+        pth = os.path.join(tmp, f"g{g}.fna" + (".gz" if shape == "gz" else ""))
+        if shape == "gz":
+            half = len(text) // 2 if g % 4 == 1 else len(text)  # some files as two gzip members
+            with open(pth, "wb") as f:
+                f.write(gzip.compress(text[:half], 6))
+                if half < len(text):
+                    f.write(gzip.compress(text[half:], 6))
+        else:
+            open(pth, "wb").write(text)
+        paths.append(pth)
+        body = b"\n".join(recs)  # records of a genome are separated: k-mers never span them
+        parts.append(np.frombuffer(body, dtype=np.uint8))
+        off.append(off[-1] + len(body))
+    lst = os.path.join(tmp, "list.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    out = os.path.join(tmp, "res.out")
+    mj = os.path.join(tmp, "m.json")
+    err = _run([os.path.join(BIN, "clust-mst"), "-l", "-i", lst, "-k", "21", "-s", "1000", "-d", "0.05", "-t", "4", "-o", out], tmp,
+               env={"RTC_METRICS_JSON": mj, "RTC_VERBOSE": "1", "RTC_BATCH_BYTES": str(6 << 20)})
+    assert "over packed bases" in err
+    folder = [os.path.join(tmp, d) for d in os.listdir(tmp) if os.path.isdir(os.path.join(tmp, d))][0]
+    want = oracle.sketch_minhash_batch(np.concatenate(parts), np.array(off, dtype=np.uint64), 21, 1000)
+    _, got = _read_hash_sketch(folder)
+    assert len(got) == len(want) and all(np.array_equal(x, y) for x, y in zip(got, want))
+    import json
+    m = json.load(open(mj))
+    assert m["batches"] >= 2 and m["gpu_sketch_ms_per_batch"] > 0
+    if shape == "contigs":
+        assert m["runs_per_genome"] > 100
+    else:
+        assert m["inflate_gb_per_s_per_thread"] > 0
+
+
 def test_clust_mst_fast_kssd_end_to_end(oracle, tmp_path):
     tmp = str(tmp_path)
     L = 2_000_000
