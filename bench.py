@@ -505,12 +505,20 @@ def extra_dense_pairs(args, ctx, api, pipeline, steps):
     n, fam = DENSE_N, DENSE_FAM
     desc = api.synth_family_descs(fam, n // fam, global_seed=42, max_rate=DENSE_RATE)
     off = np.arange(n + 1, dtype=np.uint64) * np.uint64(DENSE_L)
-    seq = ctx.synth_genomes(desc, off)
-    sk = ctx.sketch_minhash(seq, off, k=args.k, size=args.s)
-    ctx.sync()
-    del seq
     pipe = pipeline.MstPipeline(ctx, k=args.k, sketch_size=args.s, threshold=args.threshold)
     pairs = n * (n - 1) // 2
+    # code objects warm, sketch set cold: a toy set of its own (256 sketches of two families, other buffers) takes the same
+    # device path once -- what rtc_warmup does for the command lines -- so that the first launch on the real set below pays
+    # what a real run pays for a set it meets once (the look at its density), not the runtime's first mapping of the kernels
+    toy_desc = api.synth_family_descs(2, 128, global_seed=7, max_rate=DENSE_RATE)
+    toy_off = np.arange(len(toy_desc) + 1, dtype=np.uint64) * np.uint64(60_000)
+    toy = ctx.sketch_minhash(ctx.synth_genomes(toy_desc, toy_off), toy_off, k=args.k, size=args.s)
+    toy_pipe = pipeline.MstPipeline(ctx, k=args.k, sketch_size=args.s, threshold=args.threshold)
+    te, tm = toy_pipe.candidate_edges(toy, 0, toy.n)
+    toy_path = ctx.pair_last_path()
+    toy_pipe.finish(toy, toy_pipe.boruvka(toy, te, tm)[0])
+    sk = ctx.sketch_minhash(ctx.synth_genomes(desc, off), off, k=args.k, size=args.s)  # a fresh sketch generation: no memo of this set anywhere
+    ctx.sync()
     rec = []
     for it in range(steps + 1):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -537,12 +545,16 @@ def extra_dense_pairs(args, ctx, api, pipeline, steps):
         "workload": f"{n} u64 sketches of {int(avg_len)} hashes: {fam} families of {n // fam} genomes ({DENSE_L} bp, substitution rate "
                     f"<= {DENSE_RATE}), all-pairs candidate edges + MST at d={args.threshold}; default dispatch",
         "steps": steps, "pair_path": int(round(ph["pair_path"])), "pair_ms": ph["pair_ms"], "pair_kernel_ms": ph["kernel_ms"],
-        "mst_ms": ph["mst_ms"], "dist_pairs_per_sec": pairs / ((ph["pair_ms"] + ph["mst_ms"]) * 1e-3),
+        "mst_ms": ph["mst_ms"], "dist_pairs_per_sec": pairs / ((first["pair_ms"] + first["mst_ms"]) * 1e-3),
+        "dist_pairs_per_sec_steady": pairs / ((ph["pair_ms"] + ph["mst_ms"]) * 1e-3),
         "pair_phase_pairs_per_sec": pairs / (ph["pair_ms"] * 1e-3), "cand_edges": int(ph["cand_edges"]),
         "mst_edges": int(ph["mst_edges"]), "boruvka_rounds": ph["boruvka_rounds"], "dtype": "u64",
-        "first_call_pair_ms": first["pair_ms"],
-        "first_call_note": "the first launch on a sketch set also pays the inverted join's look at it (sort + co-occurrence count, "
-                           "refused as too dense) and the code objects' first mapping; later launches go straight to the tiled kernel",
+        "first_call_pair_ms": first["pair_ms"], "first_call_mst_ms": first["mst_ms"], "first_call_pair_path": int(first["pair_path"]),
+        "warmup_toy_pair_path": int(toy_path),
+        "first_call_note": "a real run meets each sketch set once: first_call_* = the first launch on this set with the code objects warm "
+                           "(a 256-sketch toy set took the same path before) -- it pays the cost rule's look at the set (a 1/64 sample of the "
+                           "hash space counted into a table, 40 us; no flat copy, no sort) -- and dist_pairs_per_sec is computed from it; "
+                           "pair_ms / *_steady = later launches on the same set (the refusal is remembered)",
         "roofline_dist": {"bound": "hbm", "kernel": "pair_tiled_kernel", "bytes_per_pair": bytes_pair,
                           "algorithmic_achieved": algo, "algorithmic_frac": algo / HBM_PEAK_GBS,
                           "achieved": (traffic / kern_s / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

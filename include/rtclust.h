@@ -185,7 +185,11 @@ int rtc_extract_edges_dev(rtc_ctx* ctx, const uint32_t* d_common, uint64_t ld, u
  * (hash, genome) + posting-list pair emission + run-length encoding; cost ~ hashes +
  * co-occurrences) where the tile is sparse enough for it to win, otherwise the tiled kernel
  * (cost ~ rows x cols x s / 64, independent of the data).  RTC_PAIR_JOIN=0 in the environment
- * disables the join, =2 takes it wherever its scratch fits. */
+ * disables the join, =2 takes it wherever its scratch fits.
+ * Overflow protocol: a count beyond `cap` on return means the list was too short -- grow it to at least the count and call
+ * again from the old count.  When the join's density sample says that a list is too short for the set before the tiled
+ * kernel has run, the count comes back as an ESTIMATE above `cap` with nothing appended (one launch saved); the repeated
+ * call always runs to the end and returns the exact count. */
 int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
                        const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0,
                        uint32_t col1, int radio, rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count);

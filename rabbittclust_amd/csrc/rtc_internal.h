@@ -37,7 +37,7 @@ struct rtc_ctx {
   int pair_last_path = 0;  // rtc_pair_last_path
   // the inverted join's last refusal for density: the input it counted
   // keyed on the sketch buffer, its generation (every sketch / gather call on this context bumps sketch_gen) and the tile
-  struct { const void* hashes = nullptr; uint64_t gen = 0; uint32_t n = 0, row0 = 0, row1 = 0, col0 = 0, col1 = 0; uint64_t K = 0, maxkey = 0; } join_dense;
+  struct { const void* hashes = nullptr; uint64_t gen = 0; uint32_t n = 0, row0 = 0, row1 = 0, col0 = 0, col1 = 0; uint64_t K = 0, maxkey = 0; uint64_t edges_hint = 0; /* set by a refusal from the sample, for this call only: candidate edges to expect */ } join_dense;
   uint64_t sketch_gen = 1;
   int pair_plan_hold = 0, pair_plan_valid = 0;
   uint32_t pair_plan_tc1_hint = 0;

@@ -143,6 +143,8 @@ extern "C" int rtc_pair_common_dev(rtc_ctx* ctx, const void* d_hashes, int width
 // (rtc_pairs_join.hip).  Otherwise the tiled path: survivors are emitted by the pair kernel itself.  Inputs
 // the tiled scheme cannot take go through the per-pair merge kernel into a dense scratch matrix
 // (row chunks of <= 1 GiB) that rtc_extract_edges_dev filters.
+namespace { __global__ void add_count_kernel(unsigned long long* count, unsigned long long add) { *count += add; } }
+
 extern "C" int rtc_pair_last_path(const rtc_ctx* ctx) { return ctx ? ctx->pair_last_path : 0; }
 
 extern "C" int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
@@ -159,6 +161,17 @@ extern "C" int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width,
     RTC_TRY(rtc_pair_edges_join(ctx, d_hashes, width, d_start, d_len, n, row0, row1, col0, col1, radio, d_edges, cap, d_count,
                                 1.0, &handled));
     if (handled) { ctx->pair_last_path = 3; return RTC_OK; }
+    // The join has just refused the set as dense from its sample and expects more candidate edges than the caller's list
+    // holds: say so through the count (the protocol of an overflowing list: "count past the capacity, grow, call again") BEFORE
+    // the tiled kernel walks the whole tile for a list that cannot take its output.  The second call finds the refusal
+    // remembered and runs the kernel, whatever the list holds by then.
+    if (const uint64_t hint = ctx->join_dense.edges_hint; hint > cap && hint <= ((uint64_t)64 << 20)) {
+      ctx->join_dense.edges_hint = 0;
+      hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, ctx->stream, (unsigned long long*)d_count, (unsigned long long)hint);
+      RTC_CHECK_LAUNCH(ctx);
+      ctx->pair_last_path = 2;
+      return RTC_OK;
+    }
     RTC_TRY(rtc_pair_edges_tiled(ctx, d_hashes, width, d_start, d_len, n, row0, row1, col0, col1, 1, radio, d_edges, cap,
                                  d_count, &handled));
   }

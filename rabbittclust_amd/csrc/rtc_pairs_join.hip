@@ -45,6 +45,35 @@ __global__ __launch_bounds__(256) void join_maxkey_kernel(const T* __restrict__ 
   if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
+// A look at the density of the input before anything is sorted: 1/64 of the hash space (by a multiplicative hash of the value)
+// is counted into a direct-address table, Sum c (c - 1) / 2 over its cells x 64 estimates the co-occurrences of the whole set.
+// Sets with posting lists of thousands (families of near-identical genomes) show up here for 40 us instead of after a flat
+// copy, a radix sort of every hash and a count (0.6 ms + 300 MB of scratch) -- the first launch on such a set used to pay that.
+constexpr int SAMPLE_SHIFT = 6, SAMPLE_CELL_BITS = 20;
+template <typename T>
+__global__ __launch_bounds__(256) void join_sample_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
+                                                          const uint32_t* __restrict__ len, uint32_t g0, uint32_t* __restrict__ table) {
+  const uint32_t g = g0 + blockIdx.x;
+  const uint32_t L = len[g];
+  const T* src = hashes + start[g];
+  for (uint32_t e = threadIdx.x; e < L; e += blockDim.x) {
+    const uint64_t x = (uint64_t)src[e] * 0x9E3779B97F4A7C15ull;
+    if ((x >> (64 - SAMPLE_SHIFT)) == 0) atomicAdd(table + (uint32_t)((x >> (64 - SAMPLE_SHIFT - SAMPLE_CELL_BITS)) & ((1u << SAMPLE_CELL_BITS) - 1u)), 1u);
+  }
+}
+// out[0] = Sum c (c - 1) / 2, out[1] = Sum c^2, out[2] = Sum c over the cells (Sum c^2 / Sum c: the list length a sampled hash sees)
+__global__ __launch_bounds__(256) void join_sample_sum_kernel(const uint32_t* __restrict__ table, unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0, sq = 0, su = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (1u << SAMPLE_CELL_BITS); i += gridDim.x * blockDim.x) {
+    const unsigned long long c = table[i];
+    acc += c * (c - 1) / 2;
+    sq += c * c;
+    su += c;
+  }
+  for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o); sq += __shfl_xor(sq, o); su += __shfl_xor(su, o); }
+  if ((threadIdx.x & 63) == 0 && su) { atomicAdd(out, acc); atomicAdd(out + 1, sq); atomicAdd(out + 2, su); }
+}
+
 // keys[off[g - g0] + e] = element e of sketch g, vals[...] = g; one workgroup per genome
 template <typename T>
 __global__ __launch_bounds__(256) void join_flatten_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
@@ -339,6 +368,7 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
               uint32_t row1, uint32_t col0, uint32_t col1, int radio, rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count,
               double tiled_scale, int* handled) {
   *handled = 0;
+  ctx->join_dense.edges_hint = 0;
   const int mode = tiled_scale < 0 ? 2 : join_mode();  // tiled_scale < 0: rtc_warmup wants this path whatever the input
   if (mode <= 0 || ctx->pair_plan_hold) return RTC_OK;
   // only pairs (row, col) with col < row exist: genomes outside [g0, g1) take no part
@@ -354,29 +384,40 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     auto it = rocprim::make_transform_iterator(d_len + g0, U32ToU64());
     RTC_HIP(ctx, rocprim::inclusive_scan(nullptr, tb_scan, it, (uint64_t*)nullptr, (size_t)ng, rocprim::plus<uint64_t>(), s));
   }
-  const size_t b_off = up256((size_t)(ng + 2) * 8), b_fix = up256((size_t)(FIX_CAP + 2) * 4);
-  RTC_TRY(rtc_ws(ctx, 0, b_off + b_fix + up256(tb_scan) + 256, &ws0));
+  const bool sampled = mode == 1;  // the cost rule is in charge: let it see the density before anything is sorted
+  const size_t b_off = up256((size_t)(ng + 5) * 8), b_fix = up256((size_t)(FIX_CAP + 2) * 4), b_tab = sampled ? ((size_t)4 << SAMPLE_CELL_BITS) : 0;
+  RTC_TRY(rtc_ws(ctx, 0, b_off + b_fix + up256(tb_scan) + b_tab + 256, &ws0));
   uint64_t* d_off = (uint64_t*)ws0;
   uint32_t* d_fix = (uint32_t*)((char*)ws0 + b_off);
   {
     auto it = rocprim::make_transform_iterator(d_len + g0, U32ToU64());
     RTC_HIP(ctx, hipMemsetAsync(d_off, 0, 8, s));
-    RTC_HIP(ctx, hipMemsetAsync(d_off + ng + 1, 0, 8, s));  // [ng + 1]: the largest hash
+    RTC_HIP(ctx, hipMemsetAsync(d_off + ng + 1, 0, 32, s));  // [ng + 1]: the largest hash, [ng + 2 .. ng + 4]: the sample's sums
     void* tmp = (char*)ws0 + b_off + b_fix;
     RTC_HIP(ctx, rocprim::inclusive_scan(tmp, tb_scan, it, d_off + 1, (size_t)ng, rocprim::plus<uint64_t>(), s));
     hipLaunchKernelGGL(join_maxkey_kernel<T>, dim3((ng + 255) / 256), dim3(256), 0, s, d_hashes, d_start, d_len, g0, ng,
                        (unsigned long long*)(d_off + ng + 1));
     RTC_CHECK_LAUNCH(ctx);
+    if (sampled) {
+      uint32_t* d_tab = (uint32_t*)((char*)ws0 + b_off + b_fix + up256(tb_scan));
+      RTC_HIP(ctx, hipMemsetAsync(d_tab, 0, b_tab, s));
+      hipLaunchKernelGGL(join_sample_kernel<T>, dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, g0, d_tab);
+      RTC_CHECK_LAUNCH(ctx);
+      hipLaunchKernelGGL(join_sample_sum_kernel, dim3(256), dim3(256), 0, s, (const uint32_t*)d_tab, (unsigned long long*)(d_off + ng + 2));
+      RTC_CHECK_LAUNCH(ctx);
+    }
   }
   void* hpin = nullptr;
   RTC_TRY(rtc_pinned(ctx, 64, &hpin));
   RTC_HIP(ctx, hipMemcpyAsync(hpin, d_off + ng, 16, hipMemcpyDeviceToHost, s));
+  RTC_HIP(ctx, hipMemcpyAsync((char*)hpin + 24, d_off + ng + 2, 24, hipMemcpyDeviceToHost, s));
   RTC_HIP(ctx, hipMemcpyAsync((char*)hpin + 16, d_off + (std::max(row0, g0) - g0), 8, hipMemcpyDeviceToHost, s));
   RTC_HIP(ctx, hipStreamSynchronize(s));
   uint64_t K64 = *(const uint64_t*)hpin;
   const uint64_t K_all = K64;  // before the semi-join: what the tiled kernel would walk
   const uint64_t maxkey = ((const uint64_t*)hpin)[1];
   const uint64_t K_rows = K64 - ((const uint64_t*)hpin)[2];  // hashes of the row genomes [row0, row1)
+  const double E_sample = sampled ? (double)((const uint64_t*)hpin)[3] * (double)(1u << SAMPLE_SHIFT) : 0.0;  // co-occurrences among all of [g0, g1), estimated
   if (K64 < 2) return RTC_OK;
   // the same input (same buffer and sketch generation, same counts, same largest hash, same tile) was found too dense
   // for the join a moment ago (repeated launches over one sketch set): straight to the tiled kernel, no second look
@@ -441,6 +482,22 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   const double t_tiled = tiled_scale * (rows / 64.0 + 1.0) * cols_mean * avg / 4.0e11;
   const double t_sort = (double)K / (sizeof(T) == 8 ? 1.1e10 : 2.8e10);
   if (mode == 1 && t_sort > 0.7 * t_tiled) return RTC_OK;
+  if (sampled) {
+    // the sample's verdict, with a margin of 1.5 for its noise (what it lets through is still counted exactly below):
+    // the tile holds rows x cols_mean of the ng (ng - 1) / 2 pairs the sample looked at
+    const double frac = std::min(1.0, rows * cols_mean / (0.5 * (double)ng * (double)(ng - 1)));
+    if (t_sort + E_sample * frac / 1.5e10 > 1.5 * t_tiled) {
+      // How many candidate edges such a set is likely to yield, for the caller's list: genomes that share a hash come in
+      // groups about as large as the posting list a sampled hash sees (Sum c^2 / Sum c), and a group of g yields g (g - 1) / 2
+      // pairs.  1.5 x that, never more than the tile holds; a list that turns out too short is grown and the launch redone as ever.
+      const double sq = (double)((const uint64_t*)hpin)[4], su = (double)((const uint64_t*)hpin)[5];
+      const double g = su > 0 ? sq / su : 1.0;
+      const double pairs_tile = rows * cols_mean;
+      jd.edges_hint = (uint64_t)std::min(pairs_tile, 1.5 * frac * 0.5 * (double)ng * std::max(0.0, g - 1.0)) + 1024;
+      note_dense();
+      return RTC_OK;
+    }
+  }
 
   const uint64_t avail = rtc_free_hbm(ctx) + ctx->ws_bytes[1] + ctx->ws_bytes[4];
 
