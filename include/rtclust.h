@@ -41,6 +41,10 @@ void rtc_ctx_destroy(rtc_ctx* ctx);
  * context of its own; meant for a helper thread beside the sketch phase (the command lines do that).  Thread-safe
  * against work on other contexts. */
 int rtc_warmup(int device);
+/* The library's switches (RTC_PAIR_JOIN, RTC_EDGE_BUDGET, RTC_SKETCH_T0_FACTOR, RTC_COMM_TIMEOUT_S ...: README) are read from
+ * the environment once, by rtc_ctx_create; no call looks at the environment again.  This reads them anew for a context
+ * that is already there (tests and tuning runs that change a switch between calls). */
+int rtc_ctx_reload_options(rtc_ctx* ctx);
 int rtc_ctx_set_stream(rtc_ctx* ctx, void* hip_stream); /* NULL = default stream */
 /* Gives the context a non-blocking stream of its own: two contexts on one device, each driven by its
  * own host thread, then overlap (the command lines copy batch i+1 while batch i is sketched). */

@@ -47,6 +47,7 @@ SIGNATURES = {
     "rtc_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "rtc_ctx_destroy": (None, [_vp]),
     "rtc_warmup": (_i, [_i]),
+    "rtc_ctx_reload_options": (_i, [_vp]),
     "rtc_ctx_set_stream": (_i, [_vp, _vp]),
     "rtc_ctx_own_stream": (_i, [_vp]),
     "rtc_ctx_sync": (_i, [_vp]),

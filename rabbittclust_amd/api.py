@@ -5,6 +5,7 @@ torch.distributed.  All compute goes through librtclust_hip.so; nothing in this 
 CPU fallback.  Names follow the reference's vocabulary (genomes, sketches, hashes, MST edges).
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -61,6 +62,16 @@ class SketchSet:
         return SketchSet(h, torch.from_numpy(start).to(device), torch.from_numpy(lens).to(device), width, k, kind)
 
 
+_LIVE = None  # weak set of the live contexts (reload_all_options)
+
+
+def reload_all_options():
+    """every live Context reads the RTC_* switches again (the library reads them once, at rtc_ctx_create): tests that flip one"""
+    for c in list(_LIVE or ()):
+        if c.h:
+            c.reload_options()
+
+
 class Context:
     """One context per GPU (one process per GPU in multi-GPU runs)."""
 
@@ -77,6 +88,11 @@ class Context:
         if st != _lib.RTC_OK:
             raise RtcError(st, "rtc_ctx_create: " + self.lib.rtc_last_error(None).decode(errors="replace"))
         self.h = h
+        global _LIVE
+        if _LIVE is None:
+            import weakref
+            _LIVE = weakref.WeakSet()
+        _LIVE.add(self)
         self.use_torch_stream()
 
     def close(self):
@@ -93,6 +109,34 @@ class Context:
     def check(self, st):
         if st != _lib.RTC_OK:
             raise RtcError(st, self.lib.rtc_last_error(self.h).decode(errors="replace"))
+
+    def reload_options(self):
+        """the library's RTC_* switches are read when the context is created: read them again (tests that flip one)"""
+        self.check(self.lib.rtc_ctx_reload_options(self.h))
+
+    def env(self, **switches):
+        """context manager: RTC_* switches set in the environment (None: unset) and read by this context, restored on exit"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            old = {k: os.environ.get(k) for k in switches}
+            try:
+                for k, v in switches.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = str(v)
+                self.reload_options()
+                yield self
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+                self.reload_options()
+        return scope()
 
     def num_cu(self):
         info = (C.c_int * 3)()

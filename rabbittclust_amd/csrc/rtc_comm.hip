@@ -119,9 +119,8 @@ const Rccl* rccl() {  // nullptr when the library or one of its symbols is missi
 // Watchdog: no collective may wait longer than this for its peers (RTC_COMM_TIMEOUT_S, default 120 s; <= 0: forever).
 // A rank that never arrives -- it failed before the call, took another branch, died -- otherwise leaves the others inside
 // the collective until somebody kills the job.
-double comm_timeout_s() {
-  const char* e = getenv("RTC_COMM_TIMEOUT_S");
-  const double v = e ? atof(e) : 120.0;
+double comm_timeout_s(const rtc_ctx* ctx) {  // the context's option, read from the environment when the context was created
+  const double v = ctx->opt.comm_timeout_s;
   return v > 0 ? v : 1e30;
 }
 
@@ -132,12 +131,11 @@ struct LocalGroup {  // in-process exchange for contexts sharing a device
   uint64_t gen = 0;
   bool broken = false;  // a barrier timed out: every rank of the group fails from now on
   std::vector<const void*> ptr;
-  bool barrier() {      // false: a peer did not arrive in time (or the group broke earlier)
+  bool barrier(double t) {  // t: the calling rank's deadline in seconds; false: a peer did not arrive in time (or the group broke earlier)
     std::unique_lock<std::mutex> lk(m);
     if (broken) return false;
     const uint64_t g = gen;
     if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); return true; }
-    const double t = comm_timeout_s();
     const bool ok = t >= 1e29 ? (cv.wait(lk, [&] { return gen != g || broken; }), true)
                               : cv.wait_for(lk, std::chrono::duration<double>(t), [&] { return gen != g || broken; });
     if (!ok || broken) { broken = true; cv.notify_all(); return false; }
@@ -154,6 +152,8 @@ struct rtc_comm {
   std::shared_ptr<LocalGroup> local;
   hipStream_t side = nullptr;      // gathers overlap compute on the context stream
   hipEvent_t ev_ready = nullptr, ev_done = nullptr, ev_watch = nullptr;
+  hipEvent_t ev_front = nullptr, ev_front_side = nullptr;  // in front of the collective(s) being watched (context / side stream)
+  bool side_front_pending = false;
   bool side_busy = false;
   bool broken = false;             // a collective timed out and the communicator was aborted
 };
@@ -182,23 +182,46 @@ __global__ void local_reduce_kernel(const void* const* __restrict__ srcs, int ns
 int comm_broken(rtc_comm* c, const char* what) {
   c->broken = true;
   return rtc_fail(c->ctx, RTC_ERR_COMM, "%s: rank %d of %d waited %.0f s for its peers (RTC_COMM_TIMEOUT_S); the communicator is "
-                  "aborted", what, c->rank, c->size, comm_timeout_s());
+                  "aborted", what, c->rank, c->size, comm_timeout_s(c->ctx));
 }
-#define RTC_LOCAL_BARRIER(c, what) do { if (!(c)->local->barrier()) return comm_broken((c), (what)); } while (0)
+#define RTC_LOCAL_BARRIER(c, what) do { if (!(c)->local->barrier(comm_timeout_s((c)->ctx))) return comm_broken((c), (what)); } while (0)
 
 // RCCL collectives are enqueued, not awaited: the host polls an event behind the collective on its stream, and when the
 // deadline passes aborts the communicator (ncclCommAbort: the only way out of a collective whose peers never come).
+// The deadline counts the wait for the PEERS only: the clock starts when the stream has reached the collective (the event
+// comm_front recorded in front of it has completed) -- kernels queued ahead of it on the stream, e.g. a long pair phase on
+// a rank that arrives late for a good reason, are not time spent waiting for anybody.
+int comm_front(rtc_comm* c, hipStream_t stream) {
+  if (!c->nccl) return RTC_OK;
+  if (stream == c->side) {
+    if (c->side_front_pending) return RTC_OK;  // the first gather of a batch marks the front; rtc_comm_wait watches the batch
+    c->side_front_pending = true;
+    RTC_HIP(c->ctx, hipEventRecord(c->ev_front_side, stream));
+  } else {
+    RTC_HIP(c->ctx, hipEventRecord(c->ev_front, stream));
+  }
+  return RTC_OK;
+}
 int comm_watch(rtc_comm* c, hipStream_t stream, const char* what) {
   rtc_ctx* ctx = c->ctx;
   if (!c->nccl) return RTC_OK;
   RTC_HIP(ctx, hipEventRecord(c->ev_watch, stream));
-  const double limit = comm_timeout_s();
-  const auto t0 = std::chrono::steady_clock::now();
+  const hipEvent_t front = stream == c->side ? c->ev_front_side : c->ev_front;
+  if (stream == c->side) c->side_front_pending = false;
+  const double limit = comm_timeout_s(ctx);
+  auto t0 = std::chrono::steady_clock::now();
+  bool reached = false;  // the stream has arrived at the collective: the clock runs
   int spins = 0;
   for (;;) {
     const hipError_t e = hipEventQuery(c->ev_watch);
     if (e == hipSuccess) return RTC_OK;
     if (e != hipErrorNotReady) return rtc_fail(ctx, RTC_ERR_HIP, "%s: hipEventQuery -> %s", what, hipGetErrorString(e));
+    if (!reached) {
+      const hipError_t f = hipEventQuery(front);
+      if (f == hipErrorNotReady) { if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50)); continue; }
+      reached = true;  // (an event never recorded reads as complete: the clock then starts at once, as before)
+      t0 = std::chrono::steady_clock::now();
+    }
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
       if (const Rccl* nc = rccl()) (void)nc->CommAbort(c->nccl);
       c->nccl = nullptr;
@@ -216,6 +239,8 @@ int comm_finish_init(rtc_comm* c) {
   RTC_HIP(ctx, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
   RTC_HIP(ctx, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
   RTC_HIP(ctx, hipEventCreateWithFlags(&c->ev_watch, hipEventDisableTiming));
+  RTC_HIP(ctx, hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming));
+  RTC_HIP(ctx, hipEventCreateWithFlags(&c->ev_front_side, hipEventDisableTiming));
   return RTC_OK;
 }
 
@@ -226,6 +251,7 @@ int comm_all_reduce_on(rtc_comm* c, void* d_buf, size_t count, int dtype, int op
   if ((c->size == 1 && !c->nccl) || count == 0) return RTC_OK;
   if (c->nccl) {
     RTC_NEED_RCCL(ctx);
+    RTC_TRY(comm_front(c, stream));
     RTC_NCCL(ctx, nc__->AllReduce(d_buf, d_buf, count, dtype == 0 ? ncclInt64 : dtype == 1 ? ncclUint32 : ncclUint64, op == 0 ? ncclMin : ncclMax, c->nccl, stream));
     return comm_watch(c, stream, "all-reduce");
   }
@@ -261,6 +287,7 @@ int comm_gather_rows_on(rtc_comm* c, void* d_global, size_t row_bytes, uint32_t 
   const size_t bytes = (size_t)(b - a) * row_bytes;
   if (c->nccl) {
     RTC_NEED_RCCL(ctx);
+    RTC_TRY(comm_front(c, stream));
     RTC_NCCL(ctx, nc__->GroupStart());
     for (int r = 0; r < c->size; r++) {
       char* p = (char*)d_global + ((size_t)r * n_local + a) * row_bytes;
@@ -310,7 +337,7 @@ int rtc_comm_init_rank(rtc_ctx* ctx, int nranks, int rank, const void* id, rtc_c
   RTC_HIP(ctx, hipSetDevice(ctx->device));
   std::unique_ptr<rtc_comm> c(new rtc_comm());
   c->ctx = ctx; c->rank = rank; c->size = nranks;
-  if (nranks > 1 || (id && getenv("RTC_COMM_FORCE_RCCL"))) {  // the env switch drives the RCCL calls on one GPU (tests)
+  if (nranks > 1 || (id && ctx->opt.comm_force_rccl)) {  // the env switch drives the RCCL calls on one GPU (tests)
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
     RTC_NEED_RCCL(ctx);
@@ -328,7 +355,7 @@ int rtc_comm_init_all(rtc_ctx** ctxs, int n, rtc_comm** comms_out) {
   for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (ctxs[i]->device == ctxs[j]->device) distinct = false;
   std::vector<std::unique_ptr<rtc_comm>> cs;
   for (int i = 0; i < n; i++) { cs.emplace_back(new rtc_comm()); cs[i]->ctx = ctxs[i]; cs[i]->rank = i; cs[i]->size = n; }
-  if ((n > 1 && distinct) || (n == 1 && getenv("RTC_COMM_FORCE_RCCL"))) {  // the env switch: RCCL on one GPU (tests)
+  if ((n > 1 && distinct) || (n == 1 && ctxs[0]->opt.comm_force_rccl)) {  // the env switch: RCCL on one GPU (tests)
     std::vector<int> devs(n);
     std::vector<ncclComm_t> nc(n);
     for (int i = 0; i < n; i++) devs[i] = ctxs[i]->device;
@@ -352,6 +379,8 @@ void rtc_comm_destroy(rtc_comm* c) {
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   if (c->ev_watch) (void)hipEventDestroy(c->ev_watch);
+  if (c->ev_front) (void)hipEventDestroy(c->ev_front);
+  if (c->ev_front_side) (void)hipEventDestroy(c->ev_front_side);
   if (c->nccl && rccl()) (void)rccl()->CommDestroy(c->nccl);
   delete c;
 }
@@ -405,6 +434,7 @@ int rtc_comm_broadcast(rtc_comm* c, void* d_buf, size_t bytes, int root) {
   RTC_HIP(ctx, hipSetDevice(ctx->device));
   if (c->nccl) {
     RTC_NEED_RCCL(ctx);
+    RTC_TRY(comm_front(c, ctx->stream));
     RTC_NCCL(ctx, nc__->Broadcast(d_buf, d_buf, bytes, ncclInt8, root, c->nccl, ctx->stream));
     return comm_watch(c, ctx->stream, "broadcast");
   }

@@ -72,6 +72,41 @@ int rtc_device_count(void) {
   return ndev;
 }
 
+}  // extern "C"
+
+void rtc_options_from_env(rtc_options* o) {
+  *o = rtc_options();
+  auto num = [](const char* name, long long dflt) -> long long { const char* e = getenv(name); return e ? atoll(e) : dflt; };
+  auto flag = [](const char* name) -> int { return getenv(name) != nullptr; };
+  o->verbose = flag("RTC_VERBOSE");
+  o->pair_join = (int)num("RTC_PAIR_JOIN", 1);
+  o->join_semi = (int)num("RTC_JOIN_SEMI", 1);
+  o->join_fullsort = flag("RTC_JOIN_FULLSORT");
+  o->join_debug = flag("RTC_JOIN_DEBUG");
+  o->pair_force_merge = flag("RTC_PAIR_FORCE_MERGE");
+  o->pair_ktarget = (uint32_t)std::max<long long>(0, num("RTC_PAIR_KTARGET", 0));
+  if (const char* e = getenv("RTC_PAIR_TCOLS_BUDGET")) o->pair_tcols_budget = std::max<uint64_t>(strtoull(e, nullptr, 10), 1);
+  if (const char* e = getenv("RTC_EDGE_BUDGET")) o->edge_budget = std::max<uint64_t>(strtoull(e, nullptr, 10), 1024);
+  if (const char* e = getenv("RTC_GREEDY_GLOBAL_PAIRS")) { o->has_greedy_global_pairs = true; o->greedy_global_pairs = strtoull(e, nullptr, 10); }
+  o->kssd_cuckoo = flag("RTC_KSSD_CUCKOO");
+  o->kssd_nofast = (int)num("RTC_KSSD_NOFAST", 0);
+  o->sketch_packed = flag("RTC_SKETCH_PACKED");
+  o->sketch_no_packed = flag("RTC_SKETCH_NO_PACKED");
+  o->sketch_rounds = (int)std::max<long long>(0, num("RTC_SKETCH_ROUNDS", 0));
+  if (getenv("RTC_SKETCH_ROUNDS") && o->sketch_rounds < 1) o->sketch_rounds = 1;
+  o->sketch_t0_factor = getenv("RTC_SKETCH_T0_FACTOR") ? (int)std::max<long long>(0, num("RTC_SKETCH_T0_FACTOR", 0)) : -1;
+  o->comm_force_rccl = flag("RTC_COMM_FORCE_RCCL");
+  if (const char* e = getenv("RTC_COMM_TIMEOUT_S")) o->comm_timeout_s = atof(e);
+}
+
+extern "C" {
+
+int rtc_ctx_reload_options(rtc_ctx* ctx) {
+  if (!ctx) return RTC_ERR_ARG;
+  rtc_options_from_env(&ctx->opt);
+  return RTC_OK;
+}
+
 int rtc_ctx_create(int device, rtc_ctx** out) {
   if (!out) return RTC_ERR_ARG;
   *out = nullptr;
@@ -84,6 +119,7 @@ int rtc_ctx_create(int device, rtc_ctx** out) {
   if (e != hipSuccess) return rtc_fail(nullptr, RTC_ERR_HIP, "hipSetDevice(%d) -> %s", device, hipGetErrorString(e));
   rtc_ctx* ctx = new rtc_ctx();
   ctx->device = device;
+  rtc_options_from_env(&ctx->opt);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
     ctx->num_cu = prop.multiProcessorCount;

@@ -135,6 +135,7 @@ extern "C" int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const u
 #define G_TRY(call) do { st = (call); if (st != RTC_OK) { cleanup(); return st; } } while (0)
 #define G_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return rtc_fail(ctx, RTC_ERR_HIP, "%s -> %s", #call, hipGetErrorString(e__)); } } while (0)
   G_HIP(hipMalloc(&d_edges, ecap * sizeof(rtc_cedge)));
+  ctx->free_hbm_at = -1.0;  // the pair phase sizes its scratch from rtc_free_hbm: this allocation changed it
   G_HIP(hipMalloc(&d_count, 8));
 
   // ---- serial replay of the reference's decisions for one query: candidates [c0, c1), `resolve` maps a candidate's
@@ -199,7 +200,7 @@ extern "C" int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const u
   // what the reference's representative-only index returns (src/greedy.cpp:1150-1196) ----
   bool global_done = false;
   uint64_t global_pair_budget = (uint64_t)1 << 27;
-  if (const char* e = getenv("RTC_GREEDY_GLOBAL_PAIRS")) global_pair_budget = strtoull(e, nullptr, 10);  // tests of the fall-through
+  if (ctx->opt.has_greedy_global_pairs) global_pair_budget = ctx->opt.greedy_global_pairs;  // tests of the fall-through
   if (n > B) {
     int handled = 0;
     uint64_t m = 0;
@@ -225,6 +226,7 @@ extern "C" int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const u
         d_edges = nullptr;
         ecap = old_cap;
         G_HIP(hipMalloc(&d_edges, ecap * sizeof(rtc_cedge)));
+        ctx->free_hbm_at = -1.0;  // the pair phase sizes its scratch from rtc_free_hbm: this allocation changed it
         handled = 0;
         break;
       }
@@ -287,6 +289,7 @@ extern "C" int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const u
       (void)hipFree(d_edges); d_edges = nullptr;
       ecap = cnt + cnt / 4;
       G_HIP(hipMalloc(&d_edges, ecap * sizeof(rtc_cedge)));
+      ctx->free_hbm_at = -1.0;  // the pair phase sizes its scratch from rtc_free_hbm: this allocation changed it
     }
     h_edges.resize(m);
     if (m) {

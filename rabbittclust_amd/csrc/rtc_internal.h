@@ -11,8 +11,33 @@
 
 #include "../../include/rtclust.h"
 
+// The library's switches (README: environment).  Read from the environment ONCE, when the context is created -- no call path
+// asks the environment again; rtc_ctx_reload_options reads them anew for a context that is already there (tests, tuning runs).
+struct rtc_options {
+  int verbose = 0;                 // RTC_VERBOSE
+  int pair_join = 1;               // RTC_PAIR_JOIN: 0 never, 1 by the cost rule, 2 wherever its scratch fits
+  int join_semi = 1;               // RTC_JOIN_SEMI: 0 never, 1 by rule, 2 always
+  int join_fullsort = 0;           // RTC_JOIN_FULLSORT
+  int join_debug = 0;              // RTC_JOIN_DEBUG
+  int pair_force_merge = 0;        // RTC_PAIR_FORCE_MERGE
+  uint32_t pair_ktarget = 0;       // RTC_PAIR_KTARGET (0: the kernel's default)
+  uint64_t pair_tcols_budget = 0;  // RTC_PAIR_TCOLS_BUDGET (0: default)
+  uint64_t edge_budget = 0;        // RTC_EDGE_BUDGET (0: default)
+  bool has_greedy_global_pairs = false;
+  uint64_t greedy_global_pairs = 0;  // RTC_GREEDY_GLOBAL_PAIRS
+  int kssd_cuckoo = 0;             // RTC_KSSD_CUCKOO
+  int kssd_nofast = 0;             // RTC_KSSD_NOFAST
+  int sketch_packed = 0, sketch_no_packed = 0;  // RTC_SKETCH_PACKED / RTC_SKETCH_NO_PACKED (LDS table layout of the MinHash kernels)
+  int sketch_rounds = 0;           // RTC_SKETCH_ROUNDS (0: planned)
+  int sketch_t0_factor = -1;       // RTC_SKETCH_T0_FACTOR (-1: by rule)
+  int comm_force_rccl = 0;         // RTC_COMM_FORCE_RCCL
+  double comm_timeout_s = 120.0;   // RTC_COMM_TIMEOUT_S (<= 0: forever)
+};
+void rtc_options_from_env(rtc_options* o);
+
 struct rtc_ctx {
   int device = 0;
+  rtc_options opt;
   hipStream_t stream = nullptr;
   hipStream_t owned_stream = nullptr;  // rtc_ctx_own_stream
   int num_cu = 256;

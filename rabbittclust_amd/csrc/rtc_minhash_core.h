@@ -645,8 +645,8 @@ int minhash_run(rtc_ctx* ctx, const uint64_t* h_off, uint32_t n, int k, const ui
     const size_t share = ((size_t)156 * 1024 / wgs) & ~(size_t)2047;
     for (int pk = 0; pk < 2 && cap == 0; pk++) {
     // (tests: both layouts are exercised for every k by forcing one of them; either gives the same sketches)
-    if (pk && (lut_his(k) == 0 || getenv("RTC_SKETCH_NO_PACKED"))) break;
-    if (!pk && getenv("RTC_SKETCH_PACKED") && lut_his(k) > 0) continue;
+    if (pk && (lut_his(k) == 0 || ctx->opt.sketch_no_packed)) break;
+    if (!pk && ctx->opt.sketch_packed && lut_his(k) > 0) continue;
     const size_t fixed = lut_bytes(k, pk != 0) + ((sizeof(Ctrl) + 15) & ~(size_t)15) + QUEUE_BYTES;
     // (round 1 measured ~3000 entries of room as the break-even against lost occupancy; with the merge sorting
     // only the new candidates and the express walk a third workgroup per CU wins down to the minimum room:
@@ -712,7 +712,7 @@ int minhash_run(rtc_ctx* ctx, const uint64_t* h_off, uint32_t n, int k, const ui
   // each genome on its own left e.g. 2 000 x 5 Mbp with 4 000 workgroups for 768 slots: 5.2 rounds).
   if (n_single <= slots && total >= (uint64_t)slots * min_seg) {
     uint64_t rounds = total / ((uint64_t)slots * seg_pref);
-    if (const char* e = getenv("RTC_SKETCH_ROUNDS")) rounds = (uint64_t)std::max(1, atoi(e));  // tuning
+    if (ctx->opt.sketch_rounds > 0) rounds = (uint64_t)ctx->opt.sketch_rounds;  // tuning
     rounds = std::max<uint64_t>(1, std::min<uint64_t>(rounds, total / ((uint64_t)slots * min_seg)));
     const uint64_t want = rounds * slots;
     std::vector<std::pair<double, uint32_t>> frac;
@@ -743,8 +743,7 @@ int minhash_run(rtc_ctx* ctx, const uint64_t* h_off, uint32_t n, int k, const ui
   // Dense sketches (a genome of fewer than 2 500 k-mers per sketch hash: the containment sketches of clust-greedy, s = length / 1000)
   // start from 2x: there the candidates and their merges are 9 % of the kernel and a third fewer of them is worth more
   // than the margin (50 000 x 1 Mbp at s = 2000: 98.4 -> 92.3 ms, at s = 1000 83.0 -> 81.1 ms; 5 000 k-mers per hash: no difference).
-  int t0_fixed = -1;
-  if (const char* e = getenv("RTC_SKETCH_T0_FACTOR")) t0_fixed = std::max(0, atoi(e));  // tests of the restart path / tuning
+  const int t0_fixed = ctx->opt.sketch_t0_factor;  // (-1: by rule) tests of the restart path / tuning
   auto start_threshold = [&](uint64_t len, uint32_t s) -> uint64_t {
     if (s == 0) return SENT;
     const uint64_t f = t0_fixed >= 0 ? (uint64_t)t0_fixed : (len / s <= 2500 ? 2u : 3u);

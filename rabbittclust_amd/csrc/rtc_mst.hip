@@ -403,7 +403,7 @@ int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, co
                                const rtc_edge_observer* obs) {
   const int radio = (int)(2.0 * exp(threshold * (kmer_size - 1)) - 1.0);  // src/MST.cpp:26-37,1292
   uint64_t budget = (uint64_t)256 << 20;  // edges (3 GiB)
-  if (const char* e = getenv("RTC_EDGE_BUDGET")) budget = std::max<uint64_t>(strtoull(e, nullptr, 10), 1024);  // tests of the dense path
+  if (ctx->opt.edge_budget) budget = ctx->opt.edge_budget;  // tests of the dense path
   budget = std::max<uint64_t>(budget, 66ull * n + 1024);  // a 64-row block on top of a contracted list always fits
   el->m = 0;
   if (row1 <= std::max<uint32_t>(row0, 1)) return RTC_OK;
@@ -419,6 +419,7 @@ int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, co
     RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (el->d_edges) (void)hipFree(el->d_edges);
     el->d_edges = nd; el->cap = want;
+    ctx->free_hbm_at = -1.0;  // (allocated and freed behind rtc_free_hbm's back: the pair phase sizes its scratch from it)
     return RTC_OK;
   };
   RTC_TRY(ensure(std::min<uint64_t>(budget, std::max<uint64_t>((uint64_t)1 << 20, (uint64_t)n * 16))));
@@ -760,7 +761,7 @@ int rtc_mst_dense(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t*
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const uint32_t s_fixed = rtc_fixed_size_of(h_len.data(), n);
 
-  const bool verbose = getenv("RTC_VERBOSE") != nullptr && !ctx->quiet;
+  const bool verbose = ctx->opt.verbose && !ctx->quiet;
   auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
   const double tv0 = now();
   rtc_edge_list el{};
@@ -832,7 +833,7 @@ int rtc_mst_mash(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* 
   const uint32_t s_fixed = rtc_fixed_size_of(h_len.data(), n);  // equal sizes: the weight is monotone in `common` in every mode
 
   uint64_t budget = (uint64_t)256 << 20;
-  if (const char* e = getenv("RTC_EDGE_BUDGET")) budget = std::max<uint64_t>(strtoull(e, nullptr, 10), 1024);
+  if (ctx->opt.edge_budget) budget = ctx->opt.edge_budget;
   const uint32_t rbeg = std::max<uint32_t>(start_index, 1);
   uint32_t rows_per = (uint32_t)std::min<uint64_t>(262140, std::max<uint64_t>(4, (((uint64_t)1 << 26) / n)));
   rows_per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(rows_per, std::max<uint64_t>(budget / 2 / n, 1)));

@@ -157,7 +157,7 @@ extern "C" int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width,
   if (!d_hashes) return RTC_ERR_ARG;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
   int handled = 0;
-  if (!getenv("RTC_PAIR_FORCE_MERGE")) {
+  if (!ctx->opt.pair_force_merge) {
     RTC_TRY(rtc_pair_edges_join(ctx, d_hashes, width, d_start, d_len, n, row0, row1, col0, col1, radio, d_edges, cap, d_count,
                                 1.0, &handled));
     if (handled) { ctx->pair_last_path = 3; return RTC_OK; }

@@ -318,12 +318,6 @@ __global__ __launch_bounds__(256) void join_filter_kernel(const Code* __restrict
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// 0: off, 1: on where the cost rule says so (default), 2: forced wherever the join can run at all (tests)
-int join_mode() {
-  const char* e = getenv("RTC_PAIR_JOIN");
-  if (!e) return 1;
-  return atoi(e);
-}
 
 // The second half of the join: one code (row << bits | col) per co-occurrence, sorted, run lengths = |A_row n A_col|,
 // the reference's filters, append.  *fit = 0: the scratch does not fit (the caller's alternative runs).
@@ -369,7 +363,7 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
               double tiled_scale, int* handled) {
   *handled = 0;
   ctx->join_dense.edges_hint = 0;
-  const int mode = tiled_scale < 0 ? 2 : join_mode();  // tiled_scale < 0: rtc_warmup wants this path whatever the input
+  const int mode = tiled_scale < 0 ? 2 : ctx->opt.pair_join;  // 0: off, 1: where the cost rule says so, 2: wherever it can run (tests)  // tiled_scale < 0: rtc_warmup wants this path whatever the input
   if (mode <= 0 || ctx->pair_plan_hold) return RTC_OK;
   // only pairs (row, col) with col < row exist: genomes outside [g0, g1) take no part
   const uint32_t g0 = std::min(col0, row0), g1 = row1;
@@ -429,7 +423,7 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
 
   // ---- semi-join: columns keep only the hashes some row has (0: never, 1: when the rows hold less than a quarter of
   // the hashes, 2: whenever there is a column that is not a row) ----
-  const int semi_mode = getenv("RTC_JOIN_SEMI") ? atoi(getenv("RTC_JOIN_SEMI")) : 1;
+  const int semi_mode = ctx->opt.join_semi;
   const bool semi = row0 > g0 && K_rows > 0 && (semi_mode >= 2 || (semi_mode == 1 && K_rows * 4 < K64 && K64 >= (1u << 22)));
   uint32_t* d_kept = nullptr;
   unsigned long long* d_bloom = nullptr;
@@ -465,7 +459,7 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     RTC_HIP(ctx, hipMemcpyAsync(hpin, d_off + ng, 8, hipMemcpyDeviceToHost, s));
     RTC_HIP(ctx, hipStreamSynchronize(s));
     K64 = *(const uint64_t*)hpin;
-    if (getenv("RTC_JOIN_DEBUG")) fprintf(stderr, "[join] semi-join: %llu row hashes, %llu of the column + row hashes kept\n",
+    if (ctx->opt.join_debug) fprintf(stderr, "[join] semi-join: %llu row hashes, %llu of the column + row hashes kept\n",
                                           (unsigned long long)K_rows, (unsigned long long)K64);
     if (K64 < 2) { *handled = 1; return RTC_OK; }
   }
@@ -552,7 +546,7 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   const unsigned half_bit = end_bit > sort_bits ? end_bit - sort_bits : 0;
   for (int attempt = 0; attempt < 2; attempt++) {
     const bool halfsort = sizeof(T) == 8 && attempt == 0 && half_bit > 0 && (end_bit < 64 || K >= (1u << 22)) &&
-                          !getenv("RTC_JOIN_FULLSORT");
+                          !ctx->opt.join_fullsort;
     RTC_HIP(ctx, rocprim::radix_sort_pairs(tmp1, tb_sort, (const T*)keys0, keys1, (const uint32_t*)vals0, vals1, (size_t)K,
                                            halfsort ? half_bit : 0u, end_bit, s));
     if constexpr (sizeof(T) == 8) {
@@ -578,7 +572,7 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     if (halfsort) RTC_HIP(ctx, hipMemcpyAsync((char*)hpin + 8, d_fix, 8, hipMemcpyDeviceToHost, s));
     RTC_HIP(ctx, hipStreamSynchronize(s));
     E = *(const uint64_t*)hpin;
-    if (getenv("RTC_JOIN_DEBUG")) fprintf(stderr, "[join] K=%u attempt=%d halfsort=%d E=%llu inversions=%u giveup=%u\n", K, attempt, (int)halfsort,
+    if (ctx->opt.join_debug) fprintf(stderr, "[join] K=%u attempt=%d halfsort=%d E=%llu inversions=%u giveup=%u\n", K, attempt, (int)halfsort,
                                           (unsigned long long)E, halfsort ? ((const uint32_t*)hpin)[2] : 0u, halfsort ? ((const uint32_t*)hpin)[3] : 0u);
     if (halfsort && ((const uint32_t*)hpin)[3]) {  // not repaired: sort on all bits -- unless the (approximate) count
       // of the unrepaired lists already says the input is dense: then the tiled kernel runs, without a second sort

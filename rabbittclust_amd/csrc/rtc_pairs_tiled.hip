@@ -633,7 +633,7 @@ int build_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
   if (tot == 0 || lmax >= (1u << 20) || nsamp == 0) return RTC_OK;  // nothing to gain / counters too wide: merge path
   const double avg = (double)tot / n;
   uint32_t ktarget = KTARGET;
-  if (const char* e = getenv("RTC_PAIR_KTARGET")) { const int v = atoi(e); if (v >= 256 && v <= (int)KCAP_HARD) ktarget = (uint32_t)v; }  // tuning experiments
+  if (ctx->opt.pair_ktarget >= 256 && ctx->opt.pair_ktarget <= KCAP_HARD) ktarget = ctx->opt.pair_ktarget;  // tuning experiments
   int P = 1;
   while (P < MAXP && (double)ROWS * avg / P > ktarget) P <<= 1;
   std::sort(sample.begin(), sample.end());
@@ -645,7 +645,7 @@ int build_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
   const uint64_t free_b = rtc_free_hbm(ctx);
   uint64_t budget = std::max<uint64_t>((uint64_t)1 << 30, 16ull * tot * sizeof(T));
   budget = std::min<uint64_t>(budget, (uint64_t)(free_b + ctx->ws_bytes[4]) / 2);
-  if (const char* e = getenv("RTC_PAIR_TCOLS_BUDGET")) budget = strtoull(e, nullptr, 10);  // tests of the fallback
+  if (ctx->opt.pair_tcols_budget) budget = ctx->opt.pair_tcols_budget;  // tests of the fallback
 
   for (int attempt = 0; attempt < 3; attempt++) {
     std::vector<T> bounds(P + 1);

@@ -1316,7 +1316,7 @@ static int sketch_kssd_impl(rtc_ctx* ctx, const uint8_t* d_seq, const PackedArgs
     if (kc.d_bucket) { (void)hipFree(kc.d_bucket); kc.d_bucket = nullptr; }
     if (kc.d_bloom) { (void)hipFree(kc.d_bloom); kc.d_bloom = nullptr; }
     kc.bvar = -1;
-    if (lds_index && 4 * half_subk == 24 && !getenv("RTC_KSSD_CUCKOO")) {
+    if (lds_index && 4 * half_subk == 24 && !ctx->opt.kssd_cuckoo) {
       // exact index of the kept ids: 8192 buckets of four 16-bit patterns (bucket = 13 bits of dim_id, the pattern
       // holds the other 11 and five the bucket implies -- an unused slot holds a pattern no key of its bucket can
       // produce) when no bucket receives more than four ids; two choices of bucket bits (exact_rank_global)
@@ -1477,7 +1477,7 @@ static int sketch_kssd_impl(rtc_ctx* ctx, const uint8_t* d_seq, const PackedArgs
   const uint32_t* d_t2 = kc.d_index ? d_t1 + ((size_t)1 << kc.ck1) : nullptr;
   const size_t lds = lds_index ? (((size_t)1 << kc.ck1) + ((size_t)1 << kc.ck2)) * 4 : 16;
   if (pk) {
-    if (getenv("RTC_VERBOSE")) fprintf(stderr, "[kssd] forward-strand prefilter over packed bases, K=%d, %zu segments, %llu runs\n", K, segs.size(), (unsigned long long)pk->n_runs);
+    if (ctx->opt.verbose) fprintf(stderr, "[kssd] forward-strand prefilter over packed bases, K=%d, %zu segments, %llu runs\n", K, segs.size(), (unsigned long long)pk->n_runs);
     void* ws4 = nullptr;
     RTC_TRY(rtc_ws(ctx, 4, segs.size() * sizeof(uint2) + 64, &ws4));
     hipLaunchKernelGGL(packed_seg_runs_kernel, dim3((uint32_t)((segs.size() + 255) / 256)), dim3(256), 0, ctx->stream, (const KSegment*)ws0,
@@ -1500,8 +1500,8 @@ static int sketch_kssd_impl(rtc_ctx* ctx, const uint8_t* d_seq, const PackedArgs
     }
 #undef LAUNCH_PACKED
   } else if (use_bucket && kc.d_bloom) {
-    P.nofast = getenv("RTC_KSSD_NOFAST") ? atoi(getenv("RTC_KSSD_NOFAST")) : 0;
-    if (getenv("RTC_VERBOSE")) fprintf(stderr, "[kssd] forward-strand prefilter, K=%d, %zu segments\n", K, segs.size());
+    P.nofast = ctx->opt.kssd_nofast;
+    if (ctx->opt.verbose) fprintf(stderr, "[kssd] forward-strand prefilter, K=%d, %zu segments\n", K, segs.size());
     const uint32_t* d_bk = (const uint32_t*)kc.d_bucket;  // the exact index (variant kc.bvar) serves the drain from global memory
     const uint16_t* d_rk = (const uint16_t*)((const char*)kc.d_bucket + BUCKET_BYTES);
     const int lds_bl = BLOOM_BYTES + Q1_BYTES + BQ_BYTES;
@@ -1526,7 +1526,7 @@ static int sketch_kssd_impl(rtc_ctx* ctx, const uint8_t* d_seq, const PackedArgs
                        d_t1, d_t2, (const int32_t*)kc.d_table, d_out, stride, d_cnt);                               \
   } while (0)
 #define LAUNCH_KSSD(IX) do { if (K <= 25) LAUNCH_KSSD2(IX, 18, 6); else LAUNCH_KSSD2(IX, 19, 9); } while (0)
-    if (getenv("RTC_VERBOSE")) fprintf(stderr, "[kssd] %s index, K=%d, %zu segments\n", lds_index ? "cuckoo" : "HBM table", K, segs.size());
+    if (ctx->opt.verbose) fprintf(stderr, "[kssd] %s index, K=%d, %zu segments\n", lds_index ? "cuckoo" : "HBM table", K, segs.size());
     if (lds_index) LAUNCH_KSSD(IDX_CUCKOO); else LAUNCH_KSSD(IDX_HBM);
 #undef LAUNCH_KSSD2
 #undef LAUNCH_KSSD

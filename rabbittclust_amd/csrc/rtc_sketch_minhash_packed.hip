@@ -535,7 +535,7 @@ extern "C" int rtc_sketch_minhash_packed_dev(rtc_ctx* ctx, const uint8_t* d_pack
     void* ws = nullptr;
     RTC_TRY(rtc_ws(ctx, 3, pi.nsegs * sizeof(uint2) + 64, &ws));
     d_seg_runs = (uint2*)ws;
-    if (getenv("RTC_VERBOSE") && !ctx->quiet) fprintf(stderr, "[minhash] sketching over packed bases, k=%d, %zu segments, %llu runs\n", k, pi.nsegs, (unsigned long long)n_runs);
+    if (ctx->opt.verbose && !ctx->quiet) fprintf(stderr, "[minhash] sketching over packed bases, k=%d, %zu segments, %llu runs\n", k, pi.nsegs, (unsigned long long)n_runs);
     hipLaunchKernelGGL(minhash_seg_runs_kernel, dim3((uint32_t)((pi.nsegs + 255) / 256)), dim3(256), 0, ctx->stream, pi.d_segs, (uint32_t)pi.nsegs,
                        d_runs, (uint32_t)n_runs, k, d_seg_runs);
     RTC_CHECK_LAUNCH(ctx);

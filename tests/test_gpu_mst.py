@@ -8,6 +8,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _reload_options():
+    """the library reads its RTC_* switches when a context is created: every live context reads them again"""
+    from rabbittclust_amd import api
+    api.reload_all_options()
+
+
 def _partition(clusters):
     return sorted(tuple(sorted(c)) for c in clusters)
 
@@ -102,10 +108,12 @@ def test_extract_edges_equals_oracle_candidates(ctx, oracle):
     e1, m4 = ctx.pair_edges(sk, r0, r1, 0, r1 - 1, radio, cap=n * n)
     assert sorted(map(tuple, e1[:m4].cpu().numpy().view(np.uint32).tolist())) == sub
     os.environ["RTC_PAIR_FORCE_MERGE"] = "1"
+    _reload_options()
     try:
         e2, m5 = ctx.pair_edges(sk, r0, r1, 0, r1 - 1, radio, cap=n * n)
     finally:
         del os.environ["RTC_PAIR_FORCE_MERGE"]
+        _reload_options()
     assert sorted(map(tuple, e2[:m5].cpu().numpy().view(np.uint32).tolist())) == sub
 
 
@@ -161,10 +169,12 @@ def test_mst_dense_input_edge_budget_contraction(ctx, oracle):
     want = oracle.mst(flat, start, lens, 21, 0, 0.05, threads=1)
     ref = ctx.mst(dev, 0.05)
     os.environ["RTC_EDGE_BUDGET"] = "40000"
+    _reload_options()
     try:
         got = ctx.mst(dev, 0.05)
     finally:
         del os.environ["RTC_EDGE_BUDGET"]
+        _reload_options()
     assert np.array_equal(got, ref)
     assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
 
@@ -181,6 +191,7 @@ def test_pair_tiled_falls_back_when_transposed_copy_exceeds_budget(ctx, oracle):
     dev = api.SketchSet.from_host(sk, ctx.device, k=21)
     ref = ctx.pair_common(dev, algo=1).cpu().numpy()
     os.environ["RTC_PAIR_TCOLS_BUDGET"] = "100000"
+    _reload_options()
     try:
         got = ctx.pair_common(dev, algo=0).cpu().numpy()
         with pytest.raises(_lib.RtcError) as ei:
@@ -188,6 +199,7 @@ def test_pair_tiled_falls_back_when_transposed_copy_exceeds_budget(ctx, oracle):
         assert ei.value.status == _lib.RTC_ERR_UNSUPPORTED
     finally:
         del os.environ["RTC_PAIR_TCOLS_BUDGET"]
+        _reload_options()
     assert np.array_equal(got, ref)
     assert ref[7, 7] == len(sk[7]) and ref[3, 7] == oracle.common(sk[3], sk[7])
 
@@ -434,10 +446,12 @@ def test_mst_dense_histograms_equal_brute_force(ctx, oracle, shape):
     assert want_ani.sum() > 5000 and want_dense[-1].max() > 20
     assert np.array_equal(mst, ctx.mst(dev, 0.05))
     os.environ["RTC_EDGE_BUDGET"] = "21000"
+    _reload_options()
     try:
         mst2, dense2, ani2 = ctx.mst_dense(dev, 0.05)
     finally:
         del os.environ["RTC_EDGE_BUDGET"]
+        _reload_options()
     assert np.array_equal(dense2, want_dense) and np.array_equal(ani2, want_ani) and np.array_equal(mst2, mst)
 
 

@@ -14,6 +14,12 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+def _reload_options():
+    """the library reads its RTC_* switches when a context is created: every live context reads them again"""
+    from rabbittclust_amd import api
+    api.reload_all_options()
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "rabbittclust_amd", "bin")
 
@@ -95,11 +101,13 @@ def test_rccl_calls_single_rank(oracle):
     import torch
     from rabbittclust_amd import api, pipeline
     os.environ["RTC_COMM_FORCE_RCCL"] = "1"
+    _reload_options()
     try:
         ctx = api.Context(0)
         comm = api.Comm.init_rank(ctx, 1, 0, api.Comm.unique_id(ctx.lib))
     finally:
         del os.environ["RTC_COMM_FORCE_RCCL"]
+        _reload_options()
     assert comm.backend == "rccl" and comm.size == 1
     t = torch.tensor([5, -3, 1 << 40], dtype=torch.int64, device=ctx.device)
     comm.all_reduce(t, "min"); comm.all_reduce(t, "max")
@@ -347,6 +355,7 @@ def test_collective_watchdog_fails_fast_when_a_rank_skips_a_round(oracle):
     ctxs = [api.Context(0) for _ in range(2)]
     comms = api.Comm.init_all(ctxs)
     os.environ["RTC_COMM_TIMEOUT_S"] = "1"
+    _reload_options()
     try:
         def rank0():
             t = torch.arange(8, dtype=torch.int64, device=ctxs[0].device)
@@ -374,5 +383,6 @@ def test_collective_watchdog_fails_fast_when_a_rank_skips_a_round(oracle):
         assert "RTC_COMM_TIMEOUT_S" in ctxs[0].lib.rtc_last_error(ctxs[0].h).decode()
     finally:
         os.environ.pop("RTC_COMM_TIMEOUT_S", None)
+        _reload_options()
         for c in comms:
             c.close()

@@ -9,6 +9,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _reload_options():
+    """the library reads its RTC_* switches when a context is created: every live context reads them again"""
+    from rabbittclust_amd import api
+    api.reload_all_options()
+
+
 def _make_sketches(rng, n, smin, smax, pool_bits=20, dtype=np.uint64):
     out = []
     for _ in range(n):
@@ -22,13 +28,16 @@ def _make_sketches(rng, n, smin, smax, pool_bits=20, dtype=np.uint64):
 def _edges(ctx, dev, row0, row1, col0, col1, radio, mode, cap=1 << 22):
     old = os.environ.get("RTC_PAIR_JOIN")
     os.environ["RTC_PAIR_JOIN"] = str(mode)
+    _reload_options()
     try:
         e, m = ctx.pair_edges(dev, row0, row1, col0, col1, radio, cap)
     finally:
         if old is None:
             os.environ.pop("RTC_PAIR_JOIN", None)
+            _reload_options()
         else:
             os.environ["RTC_PAIR_JOIN"] = old
+            _reload_options()
     assert m <= cap
     a = e[:m].cpu().numpy().view(np.uint32).astype(np.int64)
     order = np.lexsort((a[:, 1], a[:, 0]))
@@ -70,10 +79,12 @@ def test_join_equals_oracle_and_tiled(ctx, oracle, width):
         got = _edges(ctx, dev, r0, r1, c0, c1, radio, mode=2)
         assert np.array_equal(got, want), (r0, r1, c0, c1, radio)
         os.environ["RTC_JOIN_SEMI"] = "2"  # semi-join forced: columns keep only the hashes a row has
+        _reload_options()
         try:
             assert np.array_equal(_edges(ctx, dev, r0, r1, c0, c1, radio, mode=2), want), (r0, r1, c0, c1, radio, "semi")
         finally:
             os.environ.pop("RTC_JOIN_SEMI", None)
+            _reload_options()
         tiled = _edges(ctx, dev, r0, r1, c0, c1, radio, mode=0)
         assert np.array_equal(tiled, want)
 
@@ -89,6 +100,7 @@ def test_join_appends_after_existing_edges_and_counts_past_the_capacity(ctx, ora
     want = _expected(oracle, sk, 1, 80, 0, 79, -1)
     assert len(want) > 100
     os.environ["RTC_PAIR_JOIN"] = "2"
+    _reload_options()
     try:
         cap = 40 + len(want) // 2
         edges = torch.full((cap, 3), -1, dtype=torch.int32, device=ctx.device)
@@ -97,6 +109,7 @@ def test_join_appends_after_existing_edges_and_counts_past_the_capacity(ctx, ora
                                              dev.n, 1, 80, 0, 79, -1, api._t_ptr(edges), cap, api._t_ptr(count)))
     finally:
         os.environ.pop("RTC_PAIR_JOIN", None)
+        _reload_options()
     assert int(count.item()) == 40 + len(want)
     e = edges.cpu().numpy()
     assert (e[:40] == -1).all() and (e[40:] != -1).all()
@@ -148,21 +161,26 @@ def test_join_on_real_sketches_row_shards_equal_the_tiled_kernel(ctx, kind):
         # the semi-join in front of the sort (columns keep only hashes some row has): forced on, and off
         for semi in ("2", "0"):
             os.environ["RTC_JOIN_SEMI"] = semi
+            _reload_options()
             try:
                 assert np.array_equal(_edges(ctx, sk, a, b, 0, b - 1, radio, mode=2), t), (a, b, semi)
             finally:
                 os.environ.pop("RTC_JOIN_SEMI", None)
+                _reload_options()
         total += len(t)
     assert total > n
     os.environ["RTC_PAIR_JOIN"] = "0"
+    _reload_options()
     try:
         m0 = ctx.mst(sk, 0.05)
     finally:
         os.environ["RTC_PAIR_JOIN"] = "2"
+        _reload_options()
     try:
         m1 = ctx.mst(sk, 0.05)
     finally:
         os.environ.pop("RTC_PAIR_JOIN", None)
+        _reload_options()
     assert np.array_equal(m0, m1)
 
 
@@ -188,10 +206,12 @@ def test_join_u64_hashes_that_share_their_upper_half(ctx, oracle, prefixes):
     got = _edges(ctx, dev, 1, 130, 0, 129, -1, mode=2)
     assert np.array_equal(got, want)
     os.environ["RTC_JOIN_FULLSORT"] = "1"
+    _reload_options()
     try:
         assert np.array_equal(_edges(ctx, dev, 1, 130, 0, 129, -1, mode=2), want)
     finally:
         os.environ.pop("RTC_JOIN_FULLSORT", None)
+        _reload_options()
 
 
 SOAK_SEEDS = int(os.environ.get("RTC_SOAK_SEEDS", "3"))  # RTC_SOAK_SEEDS=40: a longer walk through random tiles
@@ -223,8 +243,10 @@ def test_pair_paths_on_random_tiles(ctx, oracle, seed):
         want = _expected(oracle, sk, r0, r1, c0, c1, radio)
         assert np.array_equal(_edges(ctx, dev, r0, r1, c0, c1, radio, mode=2), want), (seed, r0, r1, c0, c1, radio, "join")
         os.environ["RTC_JOIN_SEMI"] = "2"
+        _reload_options()
         try:
             assert np.array_equal(_edges(ctx, dev, r0, r1, c0, c1, radio, mode=2), want), (seed, r0, r1, c0, c1, radio, "semi")
         finally:
             os.environ.pop("RTC_JOIN_SEMI", None)
+            _reload_options()
         assert np.array_equal(_edges(ctx, dev, r0, r1, c0, c1, radio, mode=0), want), (seed, r0, r1, c0, c1, radio, "tiled")

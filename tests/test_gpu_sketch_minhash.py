@@ -5,6 +5,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _reload_options():
+    """the library reads its RTC_* switches when a context is created: every live context reads them again"""
+    from rabbittclust_amd import api
+    api.reload_all_options()
+
+
 def _random_genomes(rng, lens, n_rate=0.0, lower_rate=0.0):
     parts, off = [], [0]
     for L in lens:
@@ -223,12 +229,14 @@ def test_partial_segments_start_from_the_genome_threshold(ctx, oracle):
     for env in ({}, {"RTC_SKETCH_T0_FACTOR": "1"}, {"RTC_SKETCH_T0_FACTOR": "0"}, {"RTC_SKETCH_ROUNDS": "1"},
                 {"RTC_SKETCH_ROUNDS": "4", "RTC_SKETCH_T0_FACTOR": "2"}):
         os.environ.update(env)
+        _reload_options()
         try:
             sk = ctx.sketch_minhash(d, off, k=21, size=1000)
             ctx.sync()
         finally:
             for key in env:
                 del os.environ[key]
+            _reload_options()
         got = sk.to_host()
         for g, (a, b) in enumerate(zip(got, want)):
             assert np.array_equal(a, b), (env, g, len(a), len(b))
@@ -250,11 +258,13 @@ def test_starting_threshold_factor_does_not_change_results(ctx, oracle):
     ctx.sync()
     for f in ("1", "0", "8", "40", "2000"):
         os.environ["RTC_SKETCH_T0_FACTOR"] = f
+        _reload_options()
         try:
             alt = ctx.sketch_minhash(seq, off, k=21, size=500)
             ctx.sync()
         finally:
             del os.environ["RTC_SKETCH_T0_FACTOR"]
+            _reload_options()
         import torch
         assert torch.equal(alt.hashes, ref.hashes) and torch.equal(alt.len, ref.len), f
     host = seq[: 3 * L].cpu().numpy()
@@ -271,17 +281,21 @@ def test_packed_table_layout_matches_oracle(ctx, oracle, k):
     rng = np.random.default_rng(300 + k)
     seq, off = _random_genomes(rng, [260_000, 123_457, 15_361, 700_001], n_rate=0.0005, lower_rate=0.01)
     os.environ["RTC_SKETCH_PACKED"] = "1"
+    _reload_options()
     try:
         _check(ctx, oracle, seq, off, k, size=1000)
     finally:
         del os.environ["RTC_SKETCH_PACKED"]
+        _reload_options()
     if k == 21:
         _check(ctx, oracle, seq, off, k, size=1900)
         os.environ["RTC_SKETCH_NO_PACKED"] = "1"
+        _reload_options()
         try:
             _check(ctx, oracle, seq, off, k, size=1900)
         finally:
             del os.environ["RTC_SKETCH_NO_PACKED"]
+            _reload_options()
 
 
 import os

@@ -13,6 +13,12 @@ from test_gpu_sketch_minhash import _random_genomes
 
 pytestmark = pytest.mark.gpu
 
+
+def _reload_options():
+    """the library reads its RTC_* switches when a context is created: every live context reads them again"""
+    from rabbittclust_amd import api
+    api.reload_all_options()
+
 ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 
@@ -214,11 +220,13 @@ def test_packed_partial_segments_start_from_the_genome_threshold(ctx, oracle):
     for env in ({}, {"RTC_SKETCH_T0_FACTOR": "1"}, {"RTC_SKETCH_T0_FACTOR": "0"}, {"RTC_SKETCH_ROUNDS": "1"},
                 {"RTC_SKETCH_ROUNDS": "4", "RTC_SKETCH_T0_FACTOR": "2"}):
         os.environ.update(env)
+        _reload_options()
         try:
             got = _sketch_packed(ctx, seq, off, 21, size=1000).to_host()
         finally:
             for key in env:
                 del os.environ[key]
+            _reload_options()
         for g, (a, b) in enumerate(zip(got, want)):
             assert np.array_equal(a, b), (env, g, len(a), len(b))
     assert len(want[0]) == 1000 and len(want[2]) < 100 and len(want[4]) == 1
@@ -238,12 +246,14 @@ def test_packed_starting_threshold_factor_does_not_change_results(ctx, oracle):
     for f in (None, "1", "0", "8", "40", "2000"):
         if f is not None:
             os.environ["RTC_SKETCH_T0_FACTOR"] = f
+            _reload_options()
         try:
             alt = ctx.sketch_minhash_packed(pb, off, k=21, size=500)
             ctx.sync()
         finally:
             if f is not None:
                 del os.environ["RTC_SKETCH_T0_FACTOR"]
+                _reload_options()
         assert torch.equal(alt.hashes, ref.hashes) and torch.equal(alt.len, ref.len), f
 
 
@@ -253,10 +263,12 @@ def test_packed_input_with_the_packed_table_layout(ctx, oracle, k):
     rng = np.random.default_rng(300 + k)
     seq, off = _random_genomes(rng, [260_000, 123_457, 15_361, 700_001], n_rate=0.0005, lower_rate=0.01)
     os.environ["RTC_SKETCH_PACKED"] = "1"
+    _reload_options()
     try:
         _check(ctx, oracle, seq, off, k, size=1000, ascii_too=False)
     finally:
         del os.environ["RTC_SKETCH_PACKED"]
+        _reload_options()
     if k == 21:
         _check(ctx, oracle, seq, off, k, size=1900)
 
