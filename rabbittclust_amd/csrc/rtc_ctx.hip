@@ -140,6 +140,7 @@ void rtc_ctx_destroy(rtc_ctx* ctx) {
   for (int i = 0; i < 6; i++)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->sticky) (void)hipHostFree(ctx->sticky);
   if (ctx->kssd.d_index) (void)hipFree(ctx->kssd.d_index);
   if (ctx->kssd.d_table) (void)hipFree(ctx->kssd.d_table);
   if (ctx->kssd.d_bucket) (void)hipFree(ctx->kssd.d_bucket);
@@ -171,7 +172,7 @@ int rtc_ctx_sync(rtc_ctx* ctx) {
   if (!ctx) return RTC_ERR_ARG;
   RTC_HIP(ctx, hipSetDevice(ctx->device));  // the current device is per host thread; a NULL stream means ITS default stream
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return RTC_OK;
+  return rtc_sticky_error(ctx);  // what an asynchronous argument check found meanwhile
 }
 
 const char* rtc_last_error(const rtc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }

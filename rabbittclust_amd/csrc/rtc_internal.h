@@ -49,6 +49,9 @@ struct rtc_ctx {
   // pinned host staging for small synchronous read-backs
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
+  // a word of page-locked host memory the device can write: asynchronous argument checks (rtc_check_runs_async) raise it, the
+  // next packed sketch call and rtc_ctx_sync report it
+  uint32_t* sticky = nullptr;
   uint64_t free_hbm_cached = 0;   // rtc_free_hbm
   double free_hbm_at = -1.0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -100,6 +103,10 @@ int rtc_touch_sketch_minhash(rtc_ctx* ctx);
 int rtc_touch_sketch_kssd(rtc_ctx* ctx);
 int rtc_touch_sketch_minhash_packed(rtc_ctx* ctx);
 int rtc_touch_unpack(rtc_ctx* ctx);
+// The run list's contract -- ascending by start, disjoint, inside the batch -- checked on the device in one pass, without a host
+// round trip: a violation raises the context's sticky flag (rtc_unpack.hip).  rtc_sticky_error: RTC_ERR_ARG once if it is up.
+int rtc_check_runs_async(rtc_ctx* ctx, const uint64_t* d_runs, uint64_t n_runs, uint64_t n_bases);
+int rtc_sticky_error(rtc_ctx* ctx);
 uint64_t rtc_free_hbm(rtc_ctx* ctx);
 
 // ---- internal C++ interfaces shared by the translation units ----------------------------------

@@ -1304,6 +1304,10 @@ static int sketch_kssd_impl(rtc_ctx* ctx, const uint8_t* d_seq, const PackedArgs
   if (pk && ((pk->n_bases & 63) || pk->n_runs >> 32 || (pk->n_runs && !pk->d_runs)))
     return rtc_fail(ctx, RTC_ERR_ARG, "packed batch: n_bases must be a multiple of 64, fewer than 2^32 runs");
   RTC_HIP(ctx, hipSetDevice(ctx->device));
+  if (pk) {  // the run list's contract, checked on the device beside the sketching; reported behind the capacity read-back below
+    RTC_TRY(rtc_sticky_error(ctx));
+    RTC_TRY(rtc_check_runs_async(ctx, pk->d_runs, pk->n_runs, pk->n_bases));
+  }
 
   // ---- filter structures (cached in the context: one host thread per context, freed with it) ----
   bool lds_index = dim_end <= 4096 && 4 * half_subk <= 28;  // ranks fit 12 bits, entries 32
@@ -1580,7 +1584,9 @@ extern "C" int rtc_sketch_kssd_packed_dev(rtc_ctx* ctx, const uint8_t* d_packed,
                                           const int32_t* h_shuffled_dim, void* d_out, uint32_t stride, uint32_t* d_cnt,
                                           int* width_out, uint32_t* h_need) {
   const PackedArgs pk{n_bases, d_runs, n_runs};
-  return sketch_kssd_impl(ctx, d_packed, &pk, h_off, n, kmer_size, drlevel, h_shuffled_dim, d_out, stride, d_cnt, width_out, h_need);
+  const int st = sketch_kssd_impl(ctx, d_packed, &pk, h_off, n, kmer_size, drlevel, h_shuffled_dim, d_out, stride, d_cnt, width_out, h_need);
+  // (the capacity read-back has synchronised the stream: what the run check found is known by now)
+  return st == RTC_OK && ctx ? rtc_sticky_error(ctx) : st;
 }
 
 namespace { __global__ void touch_unit_kernel() {} }

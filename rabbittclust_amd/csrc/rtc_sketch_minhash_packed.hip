@@ -47,16 +47,6 @@ __global__ __launch_bounds__(256) void minhash_seg_runs_kernel(const Segment* __
   seg_runs[s] = make_uint2(x, lo);
 }
 
-// the run list's contract (ascending by start, disjoint, inside the batch): one pass, a flag for the host
-__global__ __launch_bounds__(256) void minhash_check_runs_kernel(const uint64_t* __restrict__ runs, uint64_t n_runs, uint64_t n_bases, uint32_t* __restrict__ bad) {
-  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_runs; r += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t st = runs[2 * r], ln = runs[2 * r + 1], en = st + ln;
-    bool ok = en >= st && en <= n_bases;
-    if (r + 1 < n_runs) ok = ok && en <= runs[2 * (r + 1)];
-    if (!ok) *bad = 1u;
-  }
-}
-
 // 16 packed bases (first base in the low bits) -> first base on top, every base's two bits in order
 __device__ __forceinline__ uint32_t pair_rev(uint32_t x) {
   const uint32_t y = __brev(x);  // pairs in order, the two bits of a pair swapped
@@ -515,6 +505,8 @@ extern "C" int rtc_sketch_minhash_packed_dev(rtc_ctx* ctx, const uint8_t* d_pack
     return rtc_fail(ctx, RTC_ERR_ARG, "packed batch: n_bases must be a multiple of 64, fewer than 2^32 runs");
   if (h_off[n] > n_bases) return rtc_fail(ctx, RTC_ERR_ARG, "packed batch: the genomes end at base %llu, the buffer holds %llu", (unsigned long long)h_off[n], (unsigned long long)n_bases);
 
+  RTC_TRY(rtc_sticky_error(ctx));
+  RTC_TRY(rtc_check_runs_async(ctx, d_runs, n_runs, n_bases));  // asynchronous: a violation surfaces at the next packed call or rtc_ctx_sync
   typedef void (*kern_t)(PackedIn, const Segment*, const uint2*, int, uint32_t, int, uint64_t*, uint32_t*, int, uint64_t*, uint32_t*, const uint32_t*);
   auto pick = [&](bool runtime_k, bool packed) -> kern_t {
     kern_t kern = packed ? sketch_minhash_packed_kernel<0, true> : sketch_minhash_packed_kernel<0, false>;

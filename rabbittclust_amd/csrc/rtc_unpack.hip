@@ -71,7 +71,36 @@ __global__ __launch_bounds__(256) void patch_long_runs_kernel(const uint32_t* __
   }
 }
 
+// the run list's contract (ascending by start, disjoint, inside the batch): one pass, a flag in host memory
+__global__ __launch_bounds__(256) void check_runs_kernel(const uint64_t* __restrict__ runs, uint64_t n_runs, uint64_t n_bases, uint32_t* __restrict__ bad) {
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_runs; r += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t st = runs[2 * r], ln = runs[2 * r + 1], en = st + ln;
+    bool ok = en >= st && en <= n_bases;
+    if (r + 1 < n_runs) ok = ok && en <= runs[2 * (r + 1)];
+    if (!ok) *bad = 1u;
+  }
+}
+
 }  // namespace
+
+int rtc_check_runs_async(rtc_ctx* ctx, const uint64_t* d_runs, uint64_t n_runs, uint64_t n_bases) {
+  if (!n_runs) return RTC_OK;
+  if (!ctx->sticky) {
+    RTC_HIP(ctx, hipHostMalloc((void**)&ctx->sticky, 64, hipHostMallocMapped));
+    *ctx->sticky = 0;
+  }
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n_runs + 255) / 256, (uint64_t)ctx->num_cu * 4);
+  hipLaunchKernelGGL(check_runs_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_runs, n_runs, n_bases, ctx->sticky);
+  RTC_CHECK_LAUNCH(ctx);
+  return RTC_OK;
+}
+
+int rtc_sticky_error(rtc_ctx* ctx) {
+  if (!ctx->sticky || !*(volatile uint32_t*)ctx->sticky) return RTC_OK;
+  *ctx->sticky = 0;
+  return rtc_fail(ctx, RTC_ERR_ARG, "the run list of an earlier packed batch was not ascending, disjoint and inside the batch: the sketches of that "
+                                    "batch are not valid (rtc_sketch_minhash_packed_dev / rtc_sketch_kssd_packed_dev / rtc_unpack_bases_dev)");
+}
 
 extern "C" int rtc_unpack_bases_dev(rtc_ctx* ctx, const uint8_t* d_packed, uint64_t n_bases, const uint64_t* d_runs,
                                     uint64_t n_runs, uint8_t* d_seq) {
@@ -85,6 +114,7 @@ extern "C" int rtc_unpack_bases_dev(rtc_ctx* ctx, const uint8_t* d_packed, uint6
   hipLaunchKernelGGL(unpack_bases_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)d_packed, n16, (uint4*)d_seq);
   RTC_CHECK_LAUNCH(ctx);
   if (n_runs) {
+    RTC_TRY(rtc_check_runs_async(ctx, d_runs, n_runs, n_bases));
     void* ws = nullptr;
     RTC_TRY(rtc_ws(ctx, 3, 64 + (size_t)LONG_CAP * 16, &ws));
     uint32_t* d_nlong = (uint32_t*)ws;

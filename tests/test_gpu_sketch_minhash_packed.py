@@ -160,6 +160,26 @@ def test_packed_sketch_argument_errors(ctx):
     assert call(n_bases, off, 1000) == _lib.RTC_OK
 
 
+def test_packed_run_list_contract_is_checked_on_the_device(ctx):
+    """runs out of order, overlapping, or beyond the batch: the asynchronous check raises the context's flag, the next
+    rtc_ctx_sync (or packed call) returns RTC_ERR_ARG -- once; runs that merely touch are fine"""
+    from rabbittclust_amd import _lib
+    rng = np.random.default_rng(3)
+    seq, off = _random_genomes(rng, [40_000])
+    packed, n_bases, _ = pack_batch(seq)
+    d_p = torch.from_numpy(packed).to(ctx.device)
+    for runs, ok in (([100, 10, 110, 5], True), ([500, 10, 100, 10], False), ([100, 50, 120, 5], False), ([n_bases - 10, 20], False)):
+        d_r = torch.tensor(runs, dtype=torch.int64, device=ctx.device)
+        ctx.sketch_minhash_packed(d_p, off, k=21, size=100, n_bases=n_bases, runs=d_r)
+        if ok:
+            ctx.sync()
+        else:
+            with pytest.raises(_lib.RtcError) as e:
+                ctx.sync()
+            assert e.value.status == _lib.RTC_ERR_ARG and "run list" in str(e.value)
+            ctx.sync()  # reported once
+
+
 def test_packed_sketch_many_tiny_genomes_and_max_size(ctx, oracle):
     rng = np.random.default_rng(12)
     lens = [int(x) for x in rng.integers(0, 3000, size=600)]
