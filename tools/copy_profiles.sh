@@ -14,3 +14,4 @@ for S in minhash minhash_packed kssd kssd_packed greedy dense; do
   [ -s $P/${N}_pmc_traffic.json ] && cp $P/${N}_pmc_traffic.json $R/profiles/${N}_pmc_traffic.json
 done
 ls -la $R/profiles/${TAG}_*
+python $R/tools/profiles_readme.py $TAG > /dev/null
