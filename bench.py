@@ -507,12 +507,20 @@ def extra_dense_pairs(args, ctx, api, pipeline, steps):
     off = np.arange(n + 1, dtype=np.uint64) * np.uint64(DENSE_L)
     pipe = pipeline.MstPipeline(ctx, k=args.k, sketch_size=args.s, threshold=args.threshold)
     pairs = n * (n - 1) // 2
-    # code objects warm, sketch set cold: a toy set of its own (256 sketches of two families, other buffers) takes the same
+    # code objects warm, sketch set cold: a toy set of its own (256 u32 sketches of two families, other buffers) takes the same
     # device path once -- what rtc_warmup does for the command lines -- so that the first launch on the real set below pays
     # what a real run pays for a set it meets once (the look at its density), not the runtime's first mapping of the kernels
-    toy_desc = api.synth_family_descs(2, 128, global_seed=7, max_rate=DENSE_RATE)
-    toy_off = np.arange(len(toy_desc) + 1, dtype=np.uint64) * np.uint64(60_000)
-    toy = ctx.sketch_minhash(ctx.synth_genomes(toy_desc, toy_off), toy_off, k=args.k, size=args.s)
+    # (u32 sketches: the toy goes through the u32 instantiation of the tiled kernel, so that the kernel statistics of this run's
+    # pair_tiled_kernel<unsigned long, ...> are the real set's launches only; the code object is one per translation unit)
+    rng = np.random.default_rng(7)
+    toy_rows = []
+    for f in range(2):
+        fam = np.unique(rng.integers(0, 1 << 32, size=1100, dtype=np.uint64).astype(np.uint32))[:1000]
+        for m in range(128):
+            v = fam.copy()
+            v[rng.integers(0, len(v), size=8)] = rng.integers(0, 1 << 32, size=8, dtype=np.uint64).astype(np.uint32)
+            toy_rows.append(np.unique(v))
+    toy = api.SketchSet.from_host(toy_rows, ctx.device, k=args.k, kind="kssd", width=4)
     toy_pipe = pipeline.MstPipeline(ctx, k=args.k, sketch_size=args.s, threshold=args.threshold)
     te, tm = toy_pipe.candidate_edges(toy, 0, toy.n)
     toy_path = ctx.pair_last_path()
