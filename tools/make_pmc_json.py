@@ -19,6 +19,8 @@ for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), 
             name = "pair_join_phase"
         if name is None:
             continue
+        if MODE == "dense_pairs" and name == "pair_tiled_kernel" and "pair_tiled_kernel<unsigned int" in r["Kernel_Name"]:
+            continue  # the u32 toy set that warms the code path in front of the first call on the real (u64) set
         tot[name][r["Counter_Name"]] += float(r["Counter_Value"])
         # the gated second launch over the partial segments (runtime-k instantiation, every workgroup leaves at once unless the
         # merge flagged its genome) belongs to the sketch call of the compile-time-k launch in front of it: no launch of its own
