@@ -614,11 +614,12 @@ struct MinhashLaunch {     // one launch of the sketch kernel
   const uint32_t* d_redo;
 };
 
-// tile_bases: bases a workgroup takes per tile (the unit the segment lengths are planned in).  prepare(MinhashPlanInfo)
+// tile_bases: bases a workgroup takes per tile (the unit the segment lengths are planned in); min_room: candidate slots the
+// kernel's buffer must offer beyond the sketch size.  prepare(MinhashPlanInfo)
 // and launch(MinhashLaunch) return a status; everything is enqueued on the context stream.
 template <class Prepare, class Launch>
 int minhash_run(rtc_ctx* ctx, const uint64_t* h_off, uint32_t n, int k, const uint32_t* h_sizes, uint32_t size,
-                uint64_t* d_out, uint32_t stride, uint32_t* d_cnt, uint64_t tile_bases, Prepare&& prepare, Launch&& launch) {
+                uint64_t* d_out, uint32_t stride, uint32_t* d_cnt, uint64_t tile_bases, size_t min_room, Prepare&& prepare, Launch&& launch) {
   RTC_HIP(ctx, hipSetDevice(ctx->device));
   ctx->sketch_gen++;  // sketches on this context change: memos keyed on a sketch buffer are stale
 
@@ -651,7 +652,7 @@ int minhash_run(rtc_ctx* ctx, const uint64_t* h_off, uint32_t n, int k, const ui
     // (round 1 measured ~3000 entries of room as the break-even against lost occupancy; with the merge sorting
     // only the new candidates and the express walk a third workgroup per CU wins down to the minimum room:
     // s = 2000 at 10 000 x 5 Mbp 114.5 -> 102.1 ms, the containment sketches of config 4 190 -> 164 ms)
-    const size_t want_room = MIN_ROOM;
+    const size_t want_room = min_room;  // what the kernel's safe mode may append between two looks at the count
     if (share > fixed && (share - fixed) / 8 >= (size_t)chunk_max + want_room) { cap = (int)((share - fixed) / 8); wgs_per_cu = wgs; packed = pk != 0; }
     }
   }

@@ -524,7 +524,7 @@ extern "C" int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const 
     RTC_CHECK_LAUNCH(ctx);
     return RTC_OK;
   };
-  return minhash_run(ctx, h_off, n, k, h_sizes, size, d_out, stride, d_cnt, (uint64_t)TILE_BASES, prepare, launch);
+  return minhash_run(ctx, h_off, n, k, h_sizes, size, d_out, stride, d_cnt, (uint64_t)TILE_BASES, (size_t)MIN_ROOM, prepare, launch);
 }
 
 namespace { __global__ void touch_unit_kernel() {} }

@@ -26,6 +26,11 @@ namespace {
 constexpr int P_NL = 1;                        // 16-byte loads (64 bases) per lane and tile
 constexpr int P_CHUNK = 64 * 64;               // bases of one wave load
 constexpr int P_TILE_BASES = WG * 64 * P_NL;   // bases per tile
+// Safe mode appends ONE k-mer per lane between two looks at the candidate count (sketch_minhash_kernel: four): the room
+// the buffer has to guarantee is a quarter, and a third workgroup per CU fits up to s = 3 318 (3 574 with the packed
+// tables) instead of 1 782 (2 038) -- the sizes clust-greedy's containment sketches of 2 - 3.5 Mbp genomes have.
+constexpr int P_STEP_APPENDS = WG;
+constexpr int P_MIN_ROOM = P_STEP_APPENDS;
 
 struct PackedIn {
   const uint8_t* bytes;     // packed bases: base i at bits 2 (i & 3) of bytes[i >> 2]
@@ -111,7 +116,7 @@ restart:
   uint64_t T = uniform64(Tstart);
   qn = 0;
   bool safe_mode = true;
-  const uint32_t room = (uint32_t)cap - s;  // >= MIN_ROOM by construction
+  const uint32_t room = (uint32_t)cap - s;  // >= P_MIN_ROOM by construction
   uint32_t rcur = sr.x;  // wave-uniform cursor into the run list: every run in front of it ends before anything this wave still looks at
 
   auto drain_queue = [&]() {  // as in sketch_minhash_kernel
@@ -318,13 +323,6 @@ restart:
             for (int q = 0; q < 4; q++) {
               const int i0 = 16 * d + 4 * q;           // the step's first position among the lane's 64
               const int rel0 = lrel + i0;              // ... in tile coordinates
-              if (safe_mode) {
-                // bound the next step's appends so the buffer cannot overflow
-                __syncthreads();
-                const uint32_t cn = uniform32(ctrl->count);
-                if ((uint32_t)cap - cn < (uint32_t)STEP_APPENDS) T = uniform64(merge_block(buf, ctrl, cap, s).T);
-                __syncthreads();
-              }
               const uint32_t y = (wd >> (8 * q)) & 0xffu;  // four bases, the first lowest
               const uint32_t pack = ((y & 3u) << 6) | ((y & 0xcu) << 2) | ((y >> 2) & 0xcu) | (y >> 6);
               const uint32_t rp = y ^ 0xffu;
@@ -363,20 +361,18 @@ restart:
                 const int rel = rel0 + b;
                 ok[b] = win == 0 && rel >= rel_lo && rel < rel_hi;
               }
-              auto append = [&](const uint64_t (&m)[4], const uint64_t (&h)[4]) __attribute__((always_inline)) {
-                if (!(m[0] | m[1] | m[2] | m[3])) return;
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                  const uint64_t bal = m[b];
-                  if (bal) {  // wave-uniform
-                    uint32_t base = 0;
-                    if (lane == 0) base = __hip_atomic_fetch_add(&ctrl->count, (uint32_t)__popcll(bal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    base = __shfl(base, 0);
-                    const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
-                    if ((bal >> lane) & 1ULL) {
-                      if (idx < (uint32_t)cap) buf[idx] = h[b];
-                      else ctrl->overflow = 1;
-                    }
+              // what this wave appends directly (not through its queue): filled by the branches below, appended behind them --
+              // in safe mode one k-mer per lane at a time, every wave meeting the same barriers whether it appends or not
+              uint64_t am[4] = {0, 0, 0, 0}, ah[4] = {0, 0, 0, 0};
+              auto append1 = [&](uint64_t bal, uint64_t hv) __attribute__((always_inline)) {
+                if (bal) {  // wave-uniform
+                  uint32_t base = 0;
+                  if (lane == 0) base = __hip_atomic_fetch_add(&ctrl->count, (uint32_t)__popcll(bal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  base = __shfl(base, 0);
+                  const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
+                  if ((bal >> lane) & 1ULL) {
+                    if (idx < (uint32_t)cap) buf[idx] = hv;
+                    else ctrl->overflow = 1;
                   }
                 }
               };
@@ -417,8 +413,8 @@ restart:
                       asm volatile("" : "+v"(qh.f1), "+v"(qh.f2));  // keeps the finishing arithmetic inside this branch
                       h[b] = mm_finish(qh);
                       m[b] = __ballot(h[b] < T);
+                      am[b] = m[b]; ah[b] = h[b];
                     }
-                    append(m, h);
                   }
                 }
               } else {
@@ -436,7 +432,22 @@ restart:
 #pragma unroll
                   for (int b = 0; b < 4; b++) m[b] &= __ballot(h[b] >= lo1);
                 }
-                append(m, h);
+#pragma unroll
+                for (int b = 0; b < 4; b++) { am[b] = m[b]; ah[b] = h[b]; }
+              }
+              if (safe_mode) {
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                  // bound the next appends (at most one per lane) so the buffer cannot overflow
+                  __syncthreads();
+                  const uint32_t cn = uniform32(ctrl->count);
+                  if ((uint32_t)cap - cn < (uint32_t)P_STEP_APPENDS) T = uniform64(merge_block(buf, ctrl, cap, s).T);
+                  __syncthreads();
+                  append1(am[b], ah[b]);
+                }
+              } else if (am[0] | am[1] | am[2] | am[3]) {
+#pragma unroll
+                for (int b = 0; b < 4; b++) append1(am[b], ah[b]);
               }
             }
           }
@@ -539,7 +550,7 @@ extern "C" int rtc_sketch_minhash_packed_dev(rtc_ctx* ctx, const uint8_t* d_pack
     RTC_CHECK_LAUNCH(ctx);
     return RTC_OK;
   };
-  return minhash_run(ctx, h_off, n, k, h_sizes, size, d_out, stride, d_cnt, (uint64_t)P_TILE_BASES, prepare, launch);
+  return minhash_run(ctx, h_off, n, k, h_sizes, size, d_out, stride, d_cnt, (uint64_t)P_TILE_BASES, (size_t)P_MIN_ROOM, prepare, launch);
 }
 
 namespace { __global__ void touch_unit_kernel() {} }

@@ -180,6 +180,16 @@ def test_packed_run_list_contract_is_checked_on_the_device(ctx):
             ctx.sync()  # reported once
 
 
+@pytest.mark.parametrize("size", [2035, 2500, 3318, 3319, 3574, 3575, 4000])
+def test_packed_sketch_sizes_around_the_third_workgroup_per_cu(ctx, oracle, size):
+    """the packed kernel's safe mode appends one k-mer per lane between two looks at the candidate count, so a third
+    workgroup per CU fits up to s = 3 318 (3 574 with the packed tables): sizes on both sides of every boundary, on genomes
+    that start without a threshold (short ones: everything passes at first, safe mode, merges under the minimum room)"""
+    rng = np.random.default_rng(900 + size)
+    seq, off = _random_genomes(rng, [300_000, 40_000, 3000, 1_200_000, 70_001], n_rate=0.0005)
+    _check(ctx, oracle, seq, off, 21, size=size)
+
+
 def test_packed_sketch_many_tiny_genomes_and_max_size(ctx, oracle):
     rng = np.random.default_rng(12)
     lens = [int(x) for x in rng.integers(0, 3000, size=600)]
