@@ -22,7 +22,11 @@ constexpr int OWN = RUN_DW * 4;                       // k-mer end positions a l
 __host__ __device__ constexpr int warm_dw(int kt) { return (kt > 0 && kt <= 21) ? 5 : 9; }
 static_assert((RUN_DW + warm_dw(21)) % 4 == 0 && (RUN_DW + warm_dw(0)) % 4 == 0, "a lane's window must be whole 16-byte loads");
 constexpr int TILE_BASES = WG * RUN_DW * 4;           // bases per tile
-constexpr int STEP_APPENDS = WG * 4;                  // worst-case appends per dword iteration
+// Safe mode appends ONE k-mer per lane between two looks at the candidate count (four until round 5): the room the buffer
+// has to guarantee is a quarter, and a third workgroup per CU fits up to s = 3 318 at k = 21 (3 574 with the packed tables)
+// instead of 1 782 (2 038) -- clust-greedy's containment sketches of 2 - 3.5 Mbp genomes, and BASELINE config 4's sketches
+// no longer need the packed layout (its stride-16 reads cost bank conflicts): 115.6 -> 112.5 ms there, 85.8 -> 81.0 ms at s = 3000.
+constexpr int STEP_APPENDS = WG;                      // worst-case appends between two looks at the count in safe mode
 constexpr int MIN_ROOM = STEP_APPENDS;                // candidate room the buffer always offers
 constexpr uint64_t SENT = ~0ULL;
 // per-wave queue of possible candidates (unfinished hash halves) in LDS: see the steady state of the kernel
@@ -41,7 +45,7 @@ __host__ __device__ constexpr int lut_los(int k) { return lut_words(k) - (lut_di
 __host__ __device__ constexpr int lut_his(int k) { return lut_direct(k) ? lut_los(k) : (k + 3) / 8; }  // word w has a second half iff k > 8w + 4
 // Packed layout (pk): lo(b * c) of the 4-byte tables sits in the spare fourth dword of the 16-byte entries instead --
 // lut_his(k) KiB less LDS, stride-16 reads (more bank conflicts: the headline shape loses 1.9 %, k = 23 6.5 %).  The
-// launch picks it only where it buys a workgroup per CU (k = 21: 1778 < s <= 2034, BASELINE config 4's sketches).
+// launch picks it only where it buys a workgroup per CU (k = 21: 3318 < s <= 3574).
 __host__ __device__ constexpr size_t lut_direct_bytes(int k) { return lut_direct(k) ? ((size_t)8 << (2 * lut_last_nb(k))) : 0; }
 __host__ __device__ constexpr size_t lut_bytes(int k, bool pk) {
   return (size_t)lut_los(k) * LUT_LO_BYTES + (pk ? 0 : (size_t)lut_his(k) * LUT_HI_BYTES) + lut_direct_bytes(k);

@@ -257,13 +257,6 @@ restart:
           const uint32_t wv = wv4[qd];
           const bool hashing = d >= WARM_DW;  // wave-uniform
           const int rel0 = OWN * t + 4 * (d - WARM_DW);
-          if (safe_mode && hashing) {
-            // bound the next dword's appends so the buffer cannot overflow
-            __syncthreads();
-            const uint32_t cn = uniform32(ctrl->count);
-            if ((uint32_t)cap - cn < (uint32_t)STEP_APPENDS) T = uniform64(merge_block(buf, ctrl, cap, s).T);
-            __syncthreads();
-          }
           // (zero-initialised on purpose: left uninitialised, the generated code issues the tile loads in an
           // order that re-reads 40 % more of the input from the fabric -- measured, tools/pmc_runlen.sh)
           uint64_t canon[4] = {0, 0, 0, 0};  // top-aligned (first base in bit 63); hashing dwords only
@@ -340,20 +333,18 @@ restart:
           }
           if (hashing) {  // wave-uniform
             // appends the k-mers selected by the wave masks m[] (T is scalar: compares write the masks directly)
-            auto append = [&](const uint64_t (&m)[4], const uint64_t (&h)[4]) __attribute__((always_inline)) {
-              if (!(m[0] | m[1] | m[2] | m[3])) return;
-#pragma unroll
-              for (int b = 0; b < 4; b++) {
-                const uint64_t bal = m[b];
-                if (bal) {  // wave-uniform
-                  uint32_t base = 0;
-                  if (lane == 0) base = __hip_atomic_fetch_add(&ctrl->count, (uint32_t)__popcll(bal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  base = __shfl(base, 0);
-                  const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
-                  if ((bal >> lane) & 1ULL) {
-                    if (idx < (uint32_t)cap) buf[idx] = h[b];
-                    else ctrl->overflow = 1;
-                  }
+            // what this wave appends directly (not through its queue): filled by the branches below, appended behind them --
+            // in safe mode one k-mer per lane at a time, every wave meeting the same barriers whether it appends or not
+            uint64_t am[4] = {0, 0, 0, 0}, ah[4] = {0, 0, 0, 0};
+            auto append1 = [&](uint64_t bal, uint64_t hv) __attribute__((always_inline)) {
+              if (bal) {  // wave-uniform
+                uint32_t base = 0;
+                if (lane == 0) base = __hip_atomic_fetch_add(&ctrl->count, (uint32_t)__popcll(bal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                base = __shfl(base, 0);
+                const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
+                if ((bal >> lane) & 1ULL) {
+                  if (idx < (uint32_t)cap) buf[idx] = hv;
+                  else ctrl->overflow = 1;
                 }
               }
             };
@@ -406,8 +397,8 @@ restart:
                     asm volatile("" : "+v"(q.f1), "+v"(q.f2));
                     h[b] = mm_finish(q);
                     m[b] = __ballot(h[b] < T);
+                    am[b] = m[b]; ah[b] = h[b];
                   }
-                  append(m, h);
                 }
               }
             } else {
@@ -430,7 +421,22 @@ restart:
 #pragma unroll
                 for (int b = 0; b < 4; b++) m[b] &= __ballot(h[b] >= lo1);
               }
-              append(m, h);
+#pragma unroll
+              for (int b = 0; b < 4; b++) { am[b] = m[b]; ah[b] = h[b]; }
+            }
+            if (safe_mode) {
+#pragma unroll
+              for (int b = 0; b < 4; b++) {
+                // bound the next appends (at most one per lane) so the buffer cannot overflow
+                __syncthreads();
+                const uint32_t cn = uniform32(ctrl->count);
+                if ((uint32_t)cap - cn < (uint32_t)STEP_APPENDS) T = uniform64(merge_block(buf, ctrl, cap, s).T);
+                __syncthreads();
+                append1(am[b], ah[b]);
+              }
+            } else if (am[0] | am[1] | am[2] | am[3]) {
+#pragma unroll
+              for (int b = 0; b < 4; b++) append1(am[b], ah[b]);
             }
           }
         }

@@ -26,11 +26,6 @@ namespace {
 constexpr int P_NL = 1;                        // 16-byte loads (64 bases) per lane and tile
 constexpr int P_CHUNK = 64 * 64;               // bases of one wave load
 constexpr int P_TILE_BASES = WG * 64 * P_NL;   // bases per tile
-// Safe mode appends ONE k-mer per lane between two looks at the candidate count (sketch_minhash_kernel: four): the room
-// the buffer has to guarantee is a quarter, and a third workgroup per CU fits up to s = 3 318 (3 574 with the packed
-// tables) instead of 1 782 (2 038) -- the sizes clust-greedy's containment sketches of 2 - 3.5 Mbp genomes have.
-constexpr int P_STEP_APPENDS = WG;
-constexpr int P_MIN_ROOM = P_STEP_APPENDS;
 
 struct PackedIn {
   const uint8_t* bytes;     // packed bases: base i at bits 2 (i & 3) of bytes[i >> 2]
@@ -116,7 +111,7 @@ restart:
   uint64_t T = uniform64(Tstart);
   qn = 0;
   bool safe_mode = true;
-  const uint32_t room = (uint32_t)cap - s;  // >= P_MIN_ROOM by construction
+  const uint32_t room = (uint32_t)cap - s;  // >= MIN_ROOM by construction
   uint32_t rcur = sr.x;  // wave-uniform cursor into the run list: every run in front of it ends before anything this wave still looks at
 
   auto drain_queue = [&]() {  // as in sketch_minhash_kernel
@@ -441,7 +436,7 @@ restart:
                   // bound the next appends (at most one per lane) so the buffer cannot overflow
                   __syncthreads();
                   const uint32_t cn = uniform32(ctrl->count);
-                  if ((uint32_t)cap - cn < (uint32_t)P_STEP_APPENDS) T = uniform64(merge_block(buf, ctrl, cap, s).T);
+                  if ((uint32_t)cap - cn < (uint32_t)STEP_APPENDS) T = uniform64(merge_block(buf, ctrl, cap, s).T);
                   __syncthreads();
                   append1(am[b], ah[b]);
                 }
@@ -550,7 +545,7 @@ extern "C" int rtc_sketch_minhash_packed_dev(rtc_ctx* ctx, const uint8_t* d_pack
     RTC_CHECK_LAUNCH(ctx);
     return RTC_OK;
   };
-  return minhash_run(ctx, h_off, n, k, h_sizes, size, d_out, stride, d_cnt, (uint64_t)P_TILE_BASES, (size_t)P_MIN_ROOM, prepare, launch);
+  return minhash_run(ctx, h_off, n, k, h_sizes, size, d_out, stride, d_cnt, (uint64_t)P_TILE_BASES, (size_t)MIN_ROOM, prepare, launch);
 }
 
 namespace { __global__ void touch_unit_kernel() {} }

@@ -158,6 +158,16 @@ def test_sketch_stride_smaller_than_size_fails_loudly(ctx):
     assert st == _lib.RTC_ERR_ARG
 
 
+@pytest.mark.parametrize("size", [2035, 3318, 3319, 3574, 3575])
+def test_sketch_sizes_around_the_third_workgroup_per_cu(ctx, oracle, size):
+    """safe mode appends one k-mer per lane between two looks at the candidate count, so a third workgroup per CU fits up
+    to s = 3 318 (3 574 with the packed tables): sizes on both sides of every boundary, on genomes that start without a
+    threshold (short ones: everything passes at first, safe mode, merges under the minimum room)"""
+    rng = np.random.default_rng(900 + size)
+    seq, off = _random_genomes(rng, [300_000, 40_000, 3000, 1_200_000, 70_001], n_rate=0.0005)
+    _check(ctx, oracle, seq, off, 21, size=size)
+
+
 def test_sketch_many_tiny_genomes_and_max_size(ctx, oracle):
     rng = np.random.default_rng(12)
     lens = [int(x) for x in rng.integers(0, 3000, size=600)]
@@ -276,7 +286,7 @@ def test_starting_threshold_factor_does_not_change_results(ctx, oracle):
 @pytest.mark.parametrize("k", [21, 17, 19, 23, 12, 28, 31, 32, 9])
 def test_packed_table_layout_matches_oracle(ctx, oracle, k):
     """The packed LDS table layout (lo(b*c) in the entries' fourth dword): forced everywhere by RTC_SKETCH_PACKED, and
-    picked by the launch on its own for sketch sizes it buys a third workgroup per CU for (k = 21: s = 1900)."""
+    picked by the launch on its own for sketch sizes it buys a third workgroup per CU for (k = 21: s = 3400)."""
     import os
     rng = np.random.default_rng(300 + k)
     seq, off = _random_genomes(rng, [260_000, 123_457, 15_361, 700_001], n_rate=0.0005, lower_rate=0.01)
@@ -288,11 +298,11 @@ def test_packed_table_layout_matches_oracle(ctx, oracle, k):
         del os.environ["RTC_SKETCH_PACKED"]
         _reload_options()
     if k == 21:
-        _check(ctx, oracle, seq, off, k, size=1900)
+        _check(ctx, oracle, seq, off, k, size=3400)
         os.environ["RTC_SKETCH_NO_PACKED"] = "1"
         _reload_options()
         try:
-            _check(ctx, oracle, seq, off, k, size=1900)
+            _check(ctx, oracle, seq, off, k, size=3400)
         finally:
             del os.environ["RTC_SKETCH_NO_PACKED"]
             _reload_options()

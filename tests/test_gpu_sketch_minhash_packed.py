@@ -300,7 +300,7 @@ def test_packed_input_with_the_packed_table_layout(ctx, oracle, k):
         del os.environ["RTC_SKETCH_PACKED"]
         _reload_options()
     if k == 21:
-        _check(ctx, oracle, seq, off, k, size=1900)
+        _check(ctx, oracle, seq, off, k, size=3400)
 
 
 def test_packed_sketch_runs_that_touch_and_batch_edges(ctx, oracle):
