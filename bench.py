@@ -287,7 +287,7 @@ def extra_greedy(args, ctx, api, pipeline, steps):
         "steps": steps, "sketch_ms": float(np.mean(sk_ms)), "sketch_gbp_per_sec": bases / (float(np.mean(sk_ms)) * 1e-3) / 1e9,
         "greedy_s": float(np.mean(gr_s)), "genomes_per_sec": n / (float(np.mean(sk_ms)) * 1e-3 + float(np.mean(gr_s))),
         "clusters": int(ncl), "dtype": "u64",
-        "roofline": {"bound": "hbm", "kernel": "sketch_minhash_kernel<21, true>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "sketch_minhash_kernel<21, false>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                      "note": "1 B/base + 8 B/hash out; traffic = rocprofv3 PMC bytes per launch (profiles/%s)" % src},
     }
