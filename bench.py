@@ -281,11 +281,32 @@ def extra_greedy(args, ctx, api, pipeline, steps):
     algo = bases + float(sizes.sum()) * 8
     ach = algo / (float(np.mean(sk_ms)) * 1e-3) / 1e9
     traffic, src = measured_traffic("sketch_minhash_kernel", {"genomes": n, "mode": "greedy"})
+    # the same genomes from the 2-bit staging format (what clust-greedy sketches per batch): same sketches, timed the same way
+    import torch
+    ref_hashes, ref_len = sk.hashes.clone(), sk.len.clone()
+    del sk
+    pb = api.pack_staging(seq, int(off[-1]))
+    del seq
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    pk_ms = []
+    for it in range(steps + 1):
+        ctx.timer_start()
+        skp = ctx.sketch_minhash_packed(pb, off, k=args.k, sizes=sizes)
+        ms = ctx.timer_stop()
+        if it:
+            pk_ms.append(ms)
+    same = bool(torch.equal(skp.hashes, ref_hashes) and torch.equal(skp.len, ref_len))
+    ach_p = algo / (float(np.mean(pk_ms)) * 1e-3) / 1e9
     return {
         "workload": f"{n} prefix genomes of {int(lens.min())} .. {int(lens.max())} bp ({bases / 1e9:.1f} Gbp), clust-greedy -c 1000 "
                     f"(containment sketches of {int(sizes.min())} .. {int(sizes.max())} hashes), d={args.threshold}",
         "steps": steps, "sketch_ms": float(np.mean(sk_ms)), "sketch_gbp_per_sec": bases / (float(np.mean(sk_ms)) * 1e-3) / 1e9,
         "greedy_s": float(np.mean(gr_s)), "genomes_per_sec": n / (float(np.mean(sk_ms)) * 1e-3 + float(np.mean(gr_s))),
+        "sketch_ms_packed": float(np.mean(pk_ms)), "packed_sketches_identical": same,
+        "roofline_packed": {"bound": "hbm", "kernel": "sketch_minhash_packed_kernel<21, false>", "achieved": ach_p, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": ach_p / HBM_PEAK_GBS,
+                            "note": "the same genomes resident at 2 bits a base (rtc_sketch_minhash_packed_dev), SURVEY 8(d)'s 1 B/base + 8 B/hash"},
         "clusters": int(ncl), "dtype": "u64",
         "roofline": {"bound": "hbm", "kernel": "sketch_minhash_kernel<21, false>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

@@ -41,6 +41,7 @@ def test_bench_default_line_has_every_extra_without_error(ctx):
         assert c["total_s"] > 0 and c["sketch_s"] > 0 and c["pair_ms"] > 0 and c["mst_ms"] > 0 and c["pair_path"] in (2, 3)
         assert n // 10 <= c["clusters"] < n and c["mst_edges"] > n // 2, (name, c["clusters"], c["mst_edges"])
         assert c["cpu_extrapolated_s"] > 0 and "EXTRAPOLATED" in c["cpu_extrapolated"]["label"] and c["cpu_extrapolated"]["sample"]
+    assert ex["greedy"]["packed_sketches_identical"] and ex["greedy"]["sketch_ms_packed"] > 0
     d = ex["dense_pairs"]
     assert d["pair_path"] == 2 and d["pair_kernel_ms"] > 0 and d["cand_edges"] >= 10 * 1000 * 999 // 2
     assert d["roofline_dist"]["bytes_per_pair"] == 16000.0 and d["roofline_dist"]["algorithmic_frac"] > 0
