@@ -178,6 +178,76 @@ def test_clust_mst_real_input_shapes_match_the_oracle(oracle, tmp_path, shape):
         assert m["inflate_gb_per_s_per_thread"] > 0
 
 
+CLI_SOAK_SEEDS = int(os.environ.get("RTC_SOAK_SEEDS", "3"))
+
+
+@pytest.mark.parametrize("seed", list(range(1, CLI_SOAK_SEEDS + 1)))
+def test_cli_random_inputs_identical_across_stagings(oracle, tmp_path, seed):
+    """Random small collections through both command lines' sketch paths: genomes of random length cut into random
+    contigs, N runs and IUPAC codes of every length, lower case, CRLF, gzip (one or several members), tiny files below the
+    length filter -- in batches of a few files.  The packed staging (default: the sketch kernels read the 2-bit stream)
+    and the character staging (RTC_STAGE_ASCII=1) must write byte-identical hash.sketch / kssd.hash.sketch and cluster
+    files; MinHash sketches are also compared with the oracle run on the same records."""
+    import gzip
+    tmp = str(tmp_path)
+    rng = np.random.default_rng(7000 + seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    junk = np.frombuffer(b"NNNNnRYKMSWBDHV", dtype=np.uint8)
+    paths, parts, off = [], [], [0]
+    base = rng.choice(acgt, size=420_000)
+    for g in range(int(rng.integers(8, 14))):
+        L = int(rng.choice([20_000, 90_000, 150_000, 260_000, 400_000]))
+        a = base[:L].copy()
+        mut = rng.random(L) < rng.uniform(0.0, 0.06)
+        a[mut] = rng.choice(acgt, size=int(mut.sum()))
+        for _ in range(int(rng.integers(0, 6))):
+            st = int(rng.integers(0, L))
+            ln = int(rng.choice([1, 2, 7, 21, 64, 300, 5000]))
+            a[st:st + ln] = rng.choice(junk, size=len(a[st:st + ln]))
+        low = rng.random(L) < (0.3 if g % 3 == 0 else 0.0)
+        a[low & (a > 64)] |= 0x20
+        cuts = [0]
+        while cuts[-1] < L:
+            cuts.append(min(L, cuts[-1] + int(rng.choice([60, 1000, 9000, 40_000, L]))))
+        recs = [a[cuts[r]:cuts[r + 1]].tobytes() for r in range(len(cuts) - 1)]
+        width = int(rng.choice([60, 70, 80, 1 << 20]))
+        eol = b"\r\n" if g % 4 == 1 else b"\n"
+        text = b"".join(f">g{g}_c{r} d".encode() + eol + eol.join(rec[i:i + width] for i in range(0, len(rec), width)) + eol for r, rec in enumerate(recs))
+        pth = os.path.join(tmp, f"g{g}.fna")
+        if g % 4 == 2:
+            pth += ".gz"
+            half = len(text) // 3 if g % 8 == 2 else len(text)
+            with open(pth, "wb") as f:
+                f.write(gzip.compress(text[:half], 5))
+                if half < len(text):
+                    f.write(gzip.compress(text[half:], 5))
+        else:
+            open(pth, "wb").write(text)
+        paths.append(pth)
+        body = b"\n".join(recs)
+        parts.append(np.frombuffer(body, dtype=np.uint8))
+        off.append(off[-1] + len(body))
+    lst = os.path.join(tmp, "list.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    for tool, extra, sk_name in (("clust-mst", ["-s", "400"], "hash.sketch"), ("clust-mst", ["--fast"], "kssd.hash.sketch"),
+                                 ("clust-greedy", ["-c", "500"], "hash.sketch")):
+        outs = {}
+        for tag, env in (("packed", {}), ("ascii", {"RTC_STAGE_ASCII": "1"})):
+            d = os.path.join(tmp, tool + extra[0].strip("-") + tag)
+            os.makedirs(d)
+            out = os.path.join(d, "res.out")
+            _run([os.path.join(BIN, tool), "-l", "-i", lst, "-k", "21", "-d", "0.05", "-t", "4", "-m", "10000", "-o", out] + extra, d,
+                 env=dict(env, RTC_BATCH_BYTES=str(1 << 20)))
+            folder = [os.path.join(d, x) for x in os.listdir(d) if os.path.isdir(os.path.join(d, x))][0]
+            outs[tag] = (open(out).read().replace(d, ""), open(os.path.join(folder, sk_name), "rb").read(), folder)
+        assert outs["packed"][1] == outs["ascii"][1], (tool, extra, "sketch files differ between the stagings")
+        assert outs["packed"][0] == outs["ascii"][0], (tool, extra, "cluster files differ between the stagings")
+        if tool == "clust-mst" and extra == ["-s", "400"]:
+            hdr, got = _read_hash_sketch(outs["packed"][2])  # (tune_parameters may have lowered k for genomes this small: the header says)
+            want = oracle.sketch_minhash_batch(np.concatenate(parts), np.array(off, dtype=np.uint64), hdr[1], 400)
+            assert len(got) == len(want) and all(np.array_equal(x, y) for x, y in zip(got, want))
+
+
 def test_clust_mst_fast_kssd_end_to_end(oracle, tmp_path):
     tmp = str(tmp_path)
     L = 2_000_000
