@@ -643,7 +643,7 @@ def extra_cli(args, ctx, api, pipeline, steps):
                            f"region), bin/clust-mst -l -i list -k {args.k} -d {args.threshold} -e, page cache warm, best of three runs "
                            f"started a second after the previous process left",
                "host_cores": usable_cores()}
-        def run_cli(tag, list_file, extra, n_files, bases):
+        def run_cli(tag, list_file, extra, n_files, bases, tool="clust-mst"):
             best = None
             for rep in range(3):  # from the second run on the code objects and the files' pages are warm
                 # A process that has left is not gone: the driver tears its GPU state down asynchronously (~0.25 s of work), and a
@@ -653,15 +653,15 @@ def extra_cli(args, ctx, api, pipeline, steps):
                 mj = os.path.join(tmp, f"metrics_{tag}.json")
                 env = dict(os.environ, RTC_METRICS_JSON=mj)
                 t0 = time.perf_counter()
-                r = subprocess.run([binp, "-l", "-i", list_file, "-k", str(args.k), "-d", str(args.threshold), "-e",
+                r = subprocess.run([os.path.join(os.path.dirname(binp), tool), "-l", "-i", list_file, "-k", str(args.k), "-d", str(args.threshold), "-e",
                                     "-o", os.path.join(tmp, f"out_{tag}.cluster")] + extra, capture_output=True, text=True, cwd=tmp, env=env)
                 wall = time.perf_counter() - t0
                 if r.returncode != 0:
-                    raise RuntimeError(f"clust-mst {' '.join(extra)} rc={r.returncode}: {r.stderr[-400:]}")
+                    raise RuntimeError(f"{tool} {' '.join(extra)} rc={r.returncode}: {r.stderr[-400:]}")
                 m = json.load(open(mj))
                 cur = {"wall_s": wall, "end_to_end_gbp_per_sec": bases / wall / 1e9,
                        "computing_sketch_s": m.get("computing_sketch_s"), "sketch_phase_gbp_per_sec": m.get("sketch_gbp_per_s"),
-                       "generateMST_s": m.get("generateMST_s"), "total_s": m.get("total_s"), "threads": m.get("threads"),
+                       "generateMST_s": m.get("generateMST_s"), "greedyCluster_s": m.get("greedyCluster_s"), "total_s": m.get("total_s"), "threads": m.get("threads"),
                        "genomes": m.get("genomes"), "clusters": m.get("clusters"), "mst_edges": m.get("mst_edges"),
                        "parse_s": m.get("parse_s"), "parse_gbp_per_sec": m.get("parse_gbp_per_s"),
                        "parse_gbp_per_sec_per_thread": m.get("parse_gbp_per_s_per_thread"), "hip_init_s": m.get("hip_init_s"), "hip_init_exposed_s": m.get("hip_init_exposed_s"),
@@ -675,6 +675,7 @@ def extra_cli(args, ctx, api, pipeline, steps):
         plain_list = os.path.join(tmp, "list.txt")
         out["minhash"] = run_cli("minhash", plain_list, ["-s", str(args.s)], n, n * L)
         out["fast"] = run_cli("fast", plain_list, ["--fast"], n, n * L)
+        out["greedy"] = run_cli("greedy", plain_list, ["-c", "1000"], n, n * L, tool="clust-greedy")  # config 3's command line: containment sketches of 5 000 hashes
         out["batch_note"] = ("gpu_copy_ms_per_batch / gpu_sketch_ms_per_batch: a lane's host thread per staged batch -- PCIe copy of the 2-bit "
                              "batch + run list, then the sketch launch straight from it (no unpack pass since round 5) + the read-back of "
                              "the counts; two lanes per GPU work beside the parser threads")

@@ -49,6 +49,7 @@ def test_bench_default_line_has_every_extra_without_error(ctx):
         c = ex["cli"][mode]
         assert c["wall_s"] > 0 and c["clusters"] > 0 and c["gpu_sketch_ms_per_batch"] > 0, (mode, c)
     assert ex["cli"]["gz"]["inflate_gb_per_sec_per_thread"] > 0 and ex["cli"]["contigs"]["runs_per_genome"] > 100
+    assert ex["cli"]["greedy"]["clusters"] > 0 and ex["cli"]["greedy"]["greedyCluster_s"] is not None
     for mode in ("minhash", "fast"):
         c = ex["cli"][mode]
         assert c["genomes"] == 64 and c["wall_s"] > 0 and c["computing_sketch_s"] > 0 and c["parse_gbp_per_sec_per_thread"] > 0
