@@ -227,7 +227,8 @@ __global__ __launch_bounds__(64) void join_repair_kernel(uint64_t* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void join_count_kernel(const T* __restrict__ ks, const uint32_t* __restrict__ vs, uint32_t K,
                                                          uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1,
-                                                         uint32_t* __restrict__ lo_out, uint32_t* __restrict__ cnt_out) {
+                                                         uint32_t* __restrict__ lo_out, uint32_t* __restrict__ cnt_out, uint32_t g0,
+                                                         unsigned long long* __restrict__ colcnt) {
   const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= K) return;
   uint32_t cnt = 0, lo = a + 1;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(256) void join_count_kernel(const T* __restrict__ k
       q = ge;
       while (p < q) { const uint32_t m = (p + q) >> 1; if (vs[m] < row1) p = m + 1; else q = m; }
       cnt = p - lo;
+      if (cnt) atomicAdd(colcnt + (g - g0), (unsigned long long)cnt);  // the column's co-occurrences: where its partners will lie
     }
   }
   lo_out[a] = lo;
@@ -313,6 +315,169 @@ __global__ __launch_bounds__(256) void join_filter_kernel(const Code* __restrict
   if (keep) {
     const unsigned long long idx = base + __popcll(m & ((1ULL << lane) - 1ULL));
     if (idx < cap) edges[idx] = rtc_cedge{row, col, common};
+  }
+}
+
+
+// ---- the column-centric second half (round 5) ---------------------------------------------------------------------------
+// The count kernel also sums, per column genome, the partners of its elements; the scan of those ng sums is an offset
+// table in which column c owns rows[coloff[c], coloff[c + 1]) -- its partner ROW ids, in no particular order, written by
+// join_emit_cols_kernel (one returning atomic per element that has partners).  A wave then counts one column's partners (a few
+// hundred to a few thousand ids, a dozen distinct) in an LDS table of its own and appends the column's edges: no second sort,
+// no run-length encode, no K-sized scan.
+__global__ __launch_bounds__(256) void join_emit_cols_kernel(const uint32_t* __restrict__ vs, const uint32_t* __restrict__ lo,
+                                                             const uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cursor,
+                                                             uint32_t g0, uint32_t K, uint32_t* __restrict__ rows) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t c = 0, l = 0;
+  uint64_t o = 0;
+  if (a < K) { c = cnt[a]; if (c) { l = lo[a]; o = atomicAdd(cursor + (vs[a] - g0), (unsigned long long)c); } }
+  const uint32_t SMALL = 24;
+  if (c && c <= SMALL)
+    for (uint32_t t = 0; t < c; t++) rows[o + t] = vs[l + t];
+  uint64_t big = __ballot(c > SMALL);
+  while (big) {  // wave-uniform
+    const int src = __builtin_ctzll(big);
+    big &= big - 1ULL;
+    const uint32_t cc = (uint32_t)__shfl((int)c, src), ll = (uint32_t)__shfl((int)l, src);
+    const uint64_t oo = ((uint64_t)(uint32_t)__shfl((int)(o >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)o, src);
+    for (uint32_t t = lane; t < cc; t += 64) rows[oo + t] = vs[ll + t];
+  }
+}
+constexpr uint32_t CC_EMPTY = 0xffffffffu;
+__device__ __forceinline__ uint32_t cc_slot(uint32_t r, uint32_t mask) { return ((r * 0x9E3779B1u) >> 12) & mask; }
+__device__ __forceinline__ bool cc_keep(uint32_t s0, uint32_t s1, int radio) {  // the reference's size filter, src/MST.cpp:1484
+  if (radio < 0) return true;
+  const uint32_t mn = s0 < s1 ? s0 : s1, mx = s0 > s1 ? s0 : s1;
+  return (uint64_t)mx <= (uint64_t)(uint32_t)radio * (uint64_t)mn;
+}
+// One wave per column (CC_COLS_PER_WAVE of them in turn): the partner rows into the wave's table (row -> count; as many
+// slots as twice the partners, 1 024 at most), the table read out through the size filter into a staging list that is
+// appended with one global atomic per ~200 edges.  A column with more than CC_LIGHT_MAX distinct partners goes on the heavy
+// list (join_colcount_heavy_kernel).
+constexpr int CC_WAVES = 4, CC_SLOTS = 1024, CC_STAGE = 256, CC_COLS_PER_WAVE = 8, CC_LIGHT_MAX = 704;
+__global__ __launch_bounds__(64 * CC_WAVES) void join_colcount_kernel(const uint32_t* __restrict__ rows, const uint64_t* __restrict__ coloff,
+                                                                     uint32_t g0, uint32_t c_lo, uint32_t c_hi, const uint32_t* __restrict__ len,
+                                                                     int radio, rtc_cedge* __restrict__ edges, unsigned long long cap,
+                                                                     unsigned long long* __restrict__ count, uint32_t* __restrict__ heavy,
+                                                                     uint32_t* __restrict__ heavy_n) {
+  __shared__ uint32_t s_key[CC_WAVES][CC_SLOTS], s_cnt[CC_WAVES][CC_SLOTS];
+  __shared__ rtc_cedge s_stage[CC_WAVES][CC_STAGE];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t* key = s_key[wave];
+  uint32_t* cnt = s_cnt[wave];
+  rtc_cedge* stage = s_stage[wave];
+  for (uint32_t i = lane; i < (uint32_t)CC_SLOTS; i += 64) { key[i] = CC_EMPTY; cnt[i] = 0; }
+  uint32_t nst = 0;  // staged edges (wave-uniform)
+  auto flush = [&]() {
+    if (!nst) return;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(count, (unsigned long long)nst);
+    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0);
+    for (uint32_t i = lane; i < nst; i += 64) if (base + i < cap) edges[base + i] = stage[i];
+    nst = 0;
+  };
+  const uint32_t first = c_lo + (blockIdx.x * CC_WAVES + wave) * CC_COLS_PER_WAVE;
+  for (uint32_t c = first; c < first + CC_COLS_PER_WAVE && c < c_hi; c++) {
+    const uint64_t beg = coloff[c - g0], end = coloff[c - g0 + 1];
+    if (beg == end) continue;  // (wave-uniform)
+    uint32_t slots = 64;
+    while (slots < (uint32_t)CC_SLOTS && (uint64_t)slots < 2 * (end - beg)) slots <<= 1;
+    const uint32_t mask = slots - 1;
+    uint32_t distinct = 0;
+    for (uint64_t i0 = beg; i0 < end && distinct <= (uint32_t)CC_LIGHT_MAX; i0 += 64) {
+      bool fresh = false;
+      if (i0 + lane < end) {
+        const uint32_t r = rows[i0 + lane];
+        uint32_t sl = cc_slot(r, mask);
+        for (;;) {  // ends: at most CC_LIGHT_MAX + 64 of the 1 024 slots are ever taken
+          const uint32_t old = atomicCAS(&key[sl], CC_EMPTY, r);
+          fresh = old == CC_EMPTY;
+          if (fresh || old == r) { atomicAdd(&cnt[sl], 1u); break; }
+          sl = (sl + 1) & mask;
+        }
+      }
+      distinct += (uint32_t)__popcll(__ballot(fresh));
+    }
+    // a table of `slots` takes (end - beg) <= slots / 2 partners whatever they are; only the full-size one can run over
+    if (distinct > (uint32_t)CC_LIGHT_MAX) {
+      for (uint32_t i = lane; i < (uint32_t)CC_SLOTS; i += 64) { key[i] = CC_EMPTY; cnt[i] = 0; }
+      if (lane == 0) heavy[atomicAdd(heavy_n, 1u)] = c;  // (at most one entry per column: the list has ng places)
+      continue;
+    }
+    const uint32_t s1 = len[c];
+    for (uint32_t sl = lane; sl < slots; sl += 64) {  // (wave-uniform trip count)
+      const uint32_t r = key[sl];
+      bool keep = r != CC_EMPTY;
+      uint32_t common = 0;
+      if (keep) {
+        common = cnt[sl];
+        key[sl] = CC_EMPTY;
+        cnt[sl] = 0;
+        keep = cc_keep(len[r], s1, radio);
+      }
+      const uint64_t m = __ballot(keep);
+      if (m) {
+        if (nst + (uint32_t)__popcll(m) > (uint32_t)CC_STAGE) flush();
+        if (keep) stage[nst + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL))] = rtc_cedge{r, c, common};
+        nst += (uint32_t)__popcll(m);
+      }
+    }
+  }
+  flush();
+}
+// The heavy list: one 256-lane workgroup per column, a table of 8 192 slots (all of the 64 KB a workgroup may declare).
+// More than CC_HEAVY_MAX distinct partners: *fail (the caller restores the edge count and runs the sort-based tail).
+constexpr int CC_HSLOTS = 8192, CC_HEAVY_MAX = 6144;
+__global__ __launch_bounds__(256) void join_colcount_heavy_kernel(const uint32_t* __restrict__ rows, const uint64_t* __restrict__ coloff,
+                                                                  uint32_t g0, const uint32_t* __restrict__ len, int radio,
+                                                                  rtc_cedge* __restrict__ edges, unsigned long long cap,
+                                                                  unsigned long long* __restrict__ count, const uint32_t* __restrict__ heavy,
+                                                                  const uint32_t* __restrict__ heavy_n, uint32_t* __restrict__ fail) {
+  __shared__ uint32_t key[CC_HSLOTS], cnt[CC_HSLOTS];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t nh = *heavy_n;
+  for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+    const uint32_t c = heavy[h];
+    const uint64_t beg = coloff[c - g0], end = coloff[c - g0 + 1];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)CC_HSLOTS; i += 256) { key[i] = CC_EMPTY; cnt[i] = 0; }
+    __syncthreads();
+    uint32_t distinct = 0;
+    for (uint64_t i0 = beg; i0 < end && distinct <= (uint32_t)CC_HEAVY_MAX; i0 += 256) {
+      int fresh = 0;
+      if (i0 + threadIdx.x < end) {
+        const uint32_t r = rows[i0 + threadIdx.x];
+        uint32_t sl = cc_slot(r, CC_HSLOTS - 1);
+        for (;;) {  // ends: at most CC_HEAVY_MAX + 256 slots are ever taken
+          const uint32_t old = atomicCAS(&key[sl], CC_EMPTY, r);
+          fresh = old == CC_EMPTY;
+          if (fresh || old == r) { atomicAdd(&cnt[sl], 1u); break; }
+          sl = (sl + 1) & (CC_HSLOTS - 1);
+        }
+      }
+      distinct += (uint32_t)__syncthreads_count(fresh);
+    }
+    if (distinct > (uint32_t)CC_HEAVY_MAX) { if (threadIdx.x == 0) *fail = 1u; return; }  // (uniform)
+    const uint32_t s1 = len[c];
+    for (uint32_t sl = threadIdx.x; sl < (uint32_t)CC_HSLOTS; sl += 256) {
+      const uint32_t r = key[sl];
+      bool keep = r != CC_EMPTY;
+      uint32_t common = 0;
+      if (keep) { common = cnt[sl]; keep = cc_keep(len[r], s1, radio); }
+      const uint64_t m = __ballot(keep);
+      if (m) {
+        const int lead = __builtin_ctzll(m);
+        unsigned long long base = 0;
+        if ((int)lane == lead) base = atomicAdd(count, (unsigned long long)__popcll(m));
+        base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), lead) << 32) | (uint32_t)__shfl((int)(uint32_t)base, lead);
+        if (keep) {
+          const unsigned long long idx = base + __popcll(m & ((1ULL << lane) - 1ULL));
+          if (idx < cap) edges[idx] = rtc_cedge{r, c, common};
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -507,8 +672,9 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   }
   const size_t b_keys = up256((size_t)K * sizeof(T)), b_vals = up256((size_t)(K + 1) * 4), b_eoff = up256((size_t)(K + 1) * 8);
   const size_t b_tmp1 = up256(std::max(tb_sort, tb_scan2));
-  // keys0 | keys1 | vals0 | vals1 | eoff | temp | lo, cnt
-  const size_t need1 = 2 * b_keys + 2 * b_vals + b_eoff + b_tmp1 + up256((size_t)(2 * (size_t)K + 1) * 4) + 256;
+  // keys0 | keys1 | vals0 | vals1 | eoff | temp | lo, cnt | colcnt, coloff, cursor | heavy
+  const size_t b_locnt = up256((size_t)(2 * (size_t)K + 1) * 4), b_col = up256((size_t)(ng + 1) * 8), b_heavy = up256((size_t)(ng + 4) * 4);
+  const size_t need1 = 2 * b_keys + 2 * b_vals + b_eoff + b_tmp1 + b_locnt + 3 * b_col + b_heavy + 256;
   if (need1 > avail / 2) return RTC_OK;
   ctx->pair_plan_valid = 0;  // scratch slots 1 and 4 are the tiled plan's
   void* ws1 = nullptr;
@@ -531,7 +697,11 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   RTC_CHECK_LAUNCH(ctx);
   // ---- 3. partners per element, their offsets, the co-occurrence count ----
   uint32_t* d_lo = (uint32_t*)((char*)ws1 + 2 * b_keys + 2 * b_vals + b_eoff + b_tmp1);
-  uint32_t* d_cnt = d_lo + K;          // K + 1 entries: the scan below reads one past the end for the total
+  uint32_t* d_cnt = d_lo + K;          // K + 1 entries: the fallback's scan reads one past the end for the total
+  uint64_t* d_colcnt = (uint64_t*)((char*)d_lo + b_locnt);  // ng + 1: co-occurrences per column genome, then their offsets and the emit cursors
+  uint64_t* d_coloff = (uint64_t*)((char*)d_colcnt + b_col);
+  uint64_t* d_cursor = (uint64_t*)((char*)d_coloff + b_col);
+  uint32_t* d_heavy = (uint32_t*)((char*)d_cursor + b_col);  // [0]: entries, [1]: fail, [4..): columns for the heavy kernel
   uint64_t E = 0;
   // radix passes only over the bits that vary: [0, end_bit) holds every hash.  u64: first on the 32 bits below
   // end_bit + repair of the rare mixed runs; when the repair gives up (a collision inside a very long posting
@@ -560,15 +730,12 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
         RTC_CHECK_LAUNCH(ctx);
       }
     }
+    RTC_HIP(ctx, hipMemsetAsync(d_colcnt, 0, (size_t)(ng + 1) * 8, s));
     hipLaunchKernelGGL(join_count_kernel<T>, dim3((K + 255) / 256), dim3(256), 0, s, (const T*)keys1, (const uint32_t*)vals1, K,
-                       row0, row1, col0, col1, d_lo, d_cnt);
+                       row0, row1, col0, col1, d_lo, d_cnt, g0, (unsigned long long*)d_colcnt);
     RTC_CHECK_LAUNCH(ctx);
-    RTC_HIP(ctx, hipMemsetAsync(d_cnt + K, 0, 4, s));
-    {
-      auto it = rocprim::make_transform_iterator((const uint32_t*)d_cnt, U32ToU64());
-      RTC_HIP(ctx, rocprim::exclusive_scan(tmp1, tb_scan2, it, d_eoff, (uint64_t)0, (size_t)K + 1, rocprim::plus<uint64_t>(), s));
-    }
-    RTC_HIP(ctx, hipMemcpyAsync(hpin, d_eoff + K, 8, hipMemcpyDeviceToHost, s));
+    RTC_HIP(ctx, rocprim::exclusive_scan(tmp1, tb_scan2, (const uint64_t*)d_colcnt, d_coloff, (uint64_t)0, (size_t)ng + 1, rocprim::plus<uint64_t>(), s));
+    RTC_HIP(ctx, hipMemcpyAsync(hpin, d_coloff + ng, 8, hipMemcpyDeviceToHost, s));
     if (halfsort) RTC_HIP(ctx, hipMemcpyAsync((char*)hpin + 8, d_fix, 8, hipMemcpyDeviceToHost, s));
     RTC_HIP(ctx, hipStreamSynchronize(s));
     E = *(const uint64_t*)hpin;
@@ -586,6 +753,46 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   // ---- cost rule, second half ----
   if (mode == 1 && t_sort + (double)E / 1.5e10 > t_tiled) { note_dense(); return RTC_OK; }
 
+  // ---- 4. the column-centric tail ----
+  if (!ctx->opt.join_sorttail) {
+    const size_t need4 = up256((size_t)E * 4) + 256;
+    if (need4 > (avail - std::min<uint64_t>(avail, need1)) / 2 + ctx->ws_bytes[4]) return RTC_OK;
+    void* ws4 = nullptr;
+    {
+      const int st = rtc_ws(ctx, 4, need4, &ws4);
+      if (st == RTC_ERR_NOMEM) return RTC_OK;
+      if (st != RTC_OK) return st;
+    }
+    uint32_t* d_rows = (uint32_t*)ws4;
+    uint64_t* d_count0 = (uint64_t*)(d_heavy + 2);  // the list's length before this tail: restored should a column not fit the heavy table
+    RTC_HIP(ctx, hipMemsetAsync(d_heavy, 0, 8, s));
+    RTC_HIP(ctx, hipMemcpyAsync(d_count0, d_count, 8, hipMemcpyDeviceToDevice, s));
+    RTC_HIP(ctx, hipMemcpyAsync(d_cursor, d_coloff, (size_t)(ng + 1) * 8, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(join_emit_cols_kernel, dim3((K + 255) / 256), dim3(256), 0, s, (const uint32_t*)vals1, (const uint32_t*)d_lo,
+                       (const uint32_t*)d_cnt, (unsigned long long*)d_cursor, g0, K, d_rows);
+    RTC_CHECK_LAUNCH(ctx);
+    const uint32_t c_lo = std::max(col0, g0), c_hi = std::min(col1, g1);
+    const uint32_t nwaves = (c_hi - c_lo + CC_COLS_PER_WAVE - 1) / CC_COLS_PER_WAVE;
+    hipLaunchKernelGGL(join_colcount_kernel, dim3((nwaves + CC_WAVES - 1) / CC_WAVES), dim3(64 * CC_WAVES), 0, s, (const uint32_t*)d_rows,
+                       (const uint64_t*)d_coloff, g0, c_lo, c_hi, d_len, radio, d_edges, (unsigned long long)cap, (unsigned long long*)d_count,
+                       d_heavy + 4, d_heavy);
+    RTC_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(join_colcount_heavy_kernel, dim3(512), dim3(256), 0, s, (const uint32_t*)d_rows, (const uint64_t*)d_coloff, g0, d_len, radio,
+                       d_edges, (unsigned long long)cap, (unsigned long long*)d_count, (const uint32_t*)(d_heavy + 4), (const uint32_t*)d_heavy,
+                       d_heavy + 1);
+    RTC_CHECK_LAUNCH(ctx);
+    RTC_HIP(ctx, hipMemcpyAsync(hpin, d_heavy, 8, hipMemcpyDeviceToHost, s));
+    RTC_HIP(ctx, hipStreamSynchronize(s));
+    if (ctx->opt.join_debug) fprintf(stderr, "[join] column tail: %u heavy columns, fail=%u\n", ((const uint32_t*)hpin)[0], ((const uint32_t*)hpin)[1]);
+    if (((const uint32_t*)hpin)[1] == 0) { *handled = 1; return RTC_OK; }
+    // a column with more distinct partners than the heavy table holds: the list as it was, and the sort-based tail
+    RTC_HIP(ctx, hipMemcpyAsync(d_count, d_count0, 8, hipMemcpyDeviceToDevice, s));
+  }
+  {
+    RTC_HIP(ctx, hipMemsetAsync(d_cnt + K, 0, 4, s));
+    auto it = rocprim::make_transform_iterator((const uint32_t*)d_cnt, U32ToU64());
+    RTC_HIP(ctx, rocprim::exclusive_scan(tmp1, tb_scan2, it, d_eoff, (uint64_t)0, (size_t)K + 1, rocprim::plus<uint64_t>(), s));
+  }
   int bits = 1;
   while ((1ull << bits) < (uint64_t)n) bits++;
   int fit = 0;
