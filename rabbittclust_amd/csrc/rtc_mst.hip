@@ -96,17 +96,48 @@ __global__ __launch_bounds__(256) void extract_edges_kernel(const uint32_t* __re
   }
 }
 
+// The running minimum as the atomic unit has it: a load that goes to the L2, not to the CU's own cache.  The plain load it
+// replaces could stay stale for a whole launch, and every edge of a large component then went through to the atomic unit,
+// where atomics on one address queue up (~10 ns each: the third Boruvka round of the headline took 213 us of its 0.7 ms).
+__device__ __forceinline__ unsigned long long peek_min(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// key[c] = min(key[c], k) for the lanes with `on`, called by whole waves.  Lanes that name the same component pool their
+// values first (the edge list comes out of the pair phase column by column, so a wave's 64 edges touch a handful of
+// components from the second round on): one atomic per component for the first four of a wave, lane by lane beyond.
+__device__ __forceinline__ void wave_min_update(unsigned long long* __restrict__ key, uint32_t c, unsigned long long k, bool on) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint64_t todo = __ballot(on);
+  for (int it = 0; it < 4 && todo; it++) {  // (wave-uniform)
+    const int lead = __builtin_ctzll(todo);
+    const uint32_t c0 = (uint32_t)__shfl((int)c, lead);
+    const bool mine = ((todo >> lane) & 1ULL) && c == c0;
+    unsigned long long kk = mine ? k : ~0ULL;
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(kk, o); kk = t < kk ? t : kk; }
+    if ((int)lane == lead && kk < peek_min(&key[c0])) atomicMin(&key[c0], kk);
+    todo &= ~__ballot(mine);
+  }
+  if (((todo >> lane) & 1ULL) && k < peek_min(&key[c])) atomicMin(&key[c], k);
+}
+
 __global__ __launch_bounds__(256) void boruvka_minweight_kernel(const rtc_cedge* __restrict__ edges, uint64_t m,
                                                                 const uint32_t* __restrict__ len, int is_containment,
                                                                 const uint32_t* __restrict__ comp,
                                                                 unsigned long long* __restrict__ wkey) {
-  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += (uint64_t)gridDim.x * blockDim.x) {
-    const rtc_cedge ed = edges[e];
-    const uint32_t ci = comp[ed.i], cj = comp[ed.j];
-    if (ci == cj) continue;
-    const uint64_t key = weight_key(ed.common, len[ed.i], len[ed.j], is_containment);
-    if (key < wkey[ci]) atomicMin(&wkey[ci], (unsigned long long)key);
-    if (key < wkey[cj]) atomicMin(&wkey[cj], (unsigned long long)key);
+  for (uint64_t e0 = (uint64_t)blockIdx.x * blockDim.x; e0 < m; e0 += (uint64_t)gridDim.x * blockDim.x) {  // whole waves stay together
+    const uint64_t e = e0 + threadIdx.x;
+    bool on = e < m;
+    uint32_t ci = 0, cj = 0;
+    unsigned long long key = 0;
+    if (on) {
+      const rtc_cedge ed = edges[e];
+      ci = comp[ed.i]; cj = comp[ed.j];
+      on = ci != cj;
+      if (on) key = weight_key(ed.common, len[ed.i], len[ed.j], is_containment);
+    }
+    wave_min_update(wkey, ci, key, on);
+    wave_min_update(wkey, cj, key, on);
   }
 }
 
@@ -115,14 +146,23 @@ __global__ __launch_bounds__(256) void boruvka_minedge_kernel(const rtc_cedge* _
                                                               const uint32_t* __restrict__ comp,
                                                               const unsigned long long* __restrict__ wkey,
                                                               unsigned long long* __restrict__ ekey) {
-  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += (uint64_t)gridDim.x * blockDim.x) {
-    const rtc_cedge ed = edges[e];
-    const uint32_t ci = comp[ed.i], cj = comp[ed.j];
-    if (ci == cj) continue;
-    const uint64_t key = weight_key(ed.common, len[ed.i], len[ed.j], is_containment);
-    const unsigned long long id = ((unsigned long long)ed.i << 32) | ed.j;
-    if (key == wkey[ci] && id < ekey[ci]) atomicMin(&ekey[ci], id);
-    if (key == wkey[cj] && id < ekey[cj]) atomicMin(&ekey[cj], id);
+  for (uint64_t e0 = (uint64_t)blockIdx.x * blockDim.x; e0 < m; e0 += (uint64_t)gridDim.x * blockDim.x) {  // whole waves stay together
+    const uint64_t e = e0 + threadIdx.x;
+    bool oi = false, oj = false;
+    uint32_t ci = 0, cj = 0;
+    unsigned long long id = 0;
+    if (e < m) {
+      const rtc_cedge ed = edges[e];
+      ci = comp[ed.i]; cj = comp[ed.j];
+      if (ci != cj) {
+        const uint64_t key = weight_key(ed.common, len[ed.i], len[ed.j], is_containment);
+        id = ((unsigned long long)ed.i << 32) | ed.j;
+        oi = key == wkey[ci];
+        oj = key == wkey[cj];
+      }
+    }
+    wave_min_update(ekey, ci, id, oi);
+    wave_min_update(ekey, cj, id, oj);
   }
 }
 
@@ -148,14 +188,19 @@ __global__ void fill_u64_kernel(unsigned long long* p, uint64_t n, unsigned long
 __global__ __launch_bounds__(256) void boruvka_minkey_kernel(const rtc_cedge* __restrict__ edges, uint64_t m,
                                                              const uint32_t* __restrict__ comp, uint32_t s_fixed,
                                                              int idx_bits, unsigned long long* __restrict__ key) {
-  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += (uint64_t)gridDim.x * blockDim.x) {
-    const rtc_cedge ed = edges[e];
-    const uint32_t ci = comp[ed.i], cj = comp[ed.j];
-    if (ci == cj) continue;
-    const unsigned long long k = ((unsigned long long)(s_fixed - ed.common) << (2 * idx_bits)) |
-                                 ((unsigned long long)ed.i << idx_bits) | (unsigned long long)ed.j;
-    if (k < key[ci]) atomicMin(&key[ci], k);
-    if (k < key[cj]) atomicMin(&key[cj], k);
+  for (uint64_t e0 = (uint64_t)blockIdx.x * blockDim.x; e0 < m; e0 += (uint64_t)gridDim.x * blockDim.x) {  // whole waves stay together
+    const uint64_t e = e0 + threadIdx.x;
+    bool on = e < m;
+    uint32_t ci = 0, cj = 0;
+    unsigned long long k = 0;
+    if (on) {
+      const rtc_cedge ed = edges[e];
+      ci = comp[ed.i]; cj = comp[ed.j];
+      on = ci != cj;
+      k = ((unsigned long long)(s_fixed - ed.common) << (2 * idx_bits)) | ((unsigned long long)ed.i << idx_bits) | (unsigned long long)ed.j;
+    }
+    wave_min_update(key, ci, k, on);
+    wave_min_update(key, cj, k, on);
   }
 }
 

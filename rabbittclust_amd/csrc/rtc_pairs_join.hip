@@ -42,7 +42,14 @@ __global__ __launch_bounds__(256) void join_maxkey_kernel(const T* __restrict__ 
   unsigned long long m = 0;
   if (i < ng) { const uint32_t L = len[g0 + i]; if (L) m = (unsigned long long)hashes[start[g0 + i] + L - 1]; }
   for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o); m = t > m ? t : m; }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  // one atomic per workgroup (atomics on one address queue up)
+  __shared__ unsigned long long s_m[4];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) m = s_m[w] > m ? s_m[w] : m;
+    if (m) atomicMax(out, m);
+  }
 }
 
 // A look at the density of the input before anything is sorted: 1/64 of the hash space (by a multiplicative hash of the value)
@@ -71,7 +78,15 @@ __global__ __launch_bounds__(256) void join_sample_sum_kernel(const uint32_t* __
     su += c;
   }
   for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o); sq += __shfl_xor(sq, o); su += __shfl_xor(su, o); }
-  if ((threadIdx.x & 63) == 0 && su) { atomicAdd(out, acc); atomicAdd(out + 1, sq); atomicAdd(out + 2, su); }
+  // one set of atomics per workgroup: the three sums share a cache line, and atomics on one line queue up (~13 ns each; a set per
+  // wave of 256 workgroups made this kernel 43 us for a 4 MB read)
+  __shared__ unsigned long long s_r[4][3];
+  if ((threadIdx.x & 63) == 0) { s_r[threadIdx.x >> 6][0] = acc; s_r[threadIdx.x >> 6][1] = sq; s_r[threadIdx.x >> 6][2] = su; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const unsigned long long v = s_r[0][threadIdx.x] + s_r[1][threadIdx.x] + s_r[2][threadIdx.x] + s_r[3][threadIdx.x];
+    if (v) atomicAdd(out + threadIdx.x, v);
+  }
 }
 
 // keys[off[g - g0] + e] = element e of sketch g, vals[...] = g; one workgroup per genome
@@ -160,6 +175,10 @@ __global__ __launch_bounds__(256) void join_semi_kernel(const T* __restrict__ ha
 // looks for (a few per million hashes).  fix[0] = inversions found, fix[1] = "could not repair", fix[2..] = positions.
 constexpr uint32_t FIX_CAP = 1u << 20;
 constexpr uint32_t FIX_RUN_MAX = 2048;
+// Every wave that sees an inversion takes a place in the list with an atomic on ONE counter, and those queue up (~7.5 ns
+// each: 2.2 ms for the 291 000 inversions of K = 10^8 on 32 bits, against 0.75 ms for a fifth radix pass): past this many
+// expected inversions another radix pass is the cheaper way.
+constexpr uint32_t FIX_EXPECT_MAX = 1u << 16;
 __global__ __launch_bounds__(256) void join_inversions_kernel(const uint64_t* __restrict__ ks, uint32_t K, int sh, uint32_t* __restrict__ fix) {
   const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
   bool inv = false;
@@ -221,17 +240,25 @@ __global__ __launch_bounds__(64) void join_repair_kernel(uint64_t* __restrict__ 
   }
 }
 
-// Element a of the sorted list: [a + 1, ge) are the later members of its posting list (genomes ascending).
-// lo[a] = first of them whose genome is >= row0, cnt[a] = how many of them are rows of the tile; nothing when
-// the element's own genome is not a column of the tile.
+// ---- the column-centric second half (round 5) ---------------------------------------------------------------------------
+// Element a of the sorted list: [a + 1, ge) are the later members of its posting list (genomes ascending); those that are
+// rows of the tile are a contiguous part [lo, lo + cnt) of it -- the element's PARTNERS.  An element whose own genome g is a
+// column of the tile and that has partners leaves the descriptor (lo, cnt) in its column's part of `desc` (column g owns
+// places off[g - g0] .. off[g - g0 + 1]: as many as the genome has hashes; the order inside is whatever the atomics made
+// it) and adds itself to the column's counter = elements << 40 | partners (a 64-byte line per column: atomics on one line
+// queue up behind each other).  A wave then counts one column's partners (a few hundred to a few thousand row ids, a dozen
+// distinct) in an LDS table of its own, reading the partner lists where the sort left them, and appends the column's edges:
+// no second sort, no run-length encode, no copy of the co-occurrences, no K-sized scan.
+constexpr int CC_ESHIFT = 40;
+constexpr unsigned long long CC_PMASK = (1ULL << CC_ESHIFT) - 1ULL;
+constexpr int CC_CSTRIDE = 1;  // counters, in 8-byte words, from one column to the next (a 64-byte line each was measured: the count kernel 145 -> 234 us)
 template <typename T>
 __global__ __launch_bounds__(256) void join_count_kernel(const T* __restrict__ ks, const uint32_t* __restrict__ vs, uint32_t K,
-                                                         uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1,
-                                                         uint32_t* __restrict__ lo_out, uint32_t* __restrict__ cnt_out, uint32_t g0,
-                                                         unsigned long long* __restrict__ colcnt) {
+                                                         uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, uint32_t g0,
+                                                         const uint64_t* __restrict__ off, unsigned long long* __restrict__ colcnt,
+                                                         uint2* __restrict__ desc) {
   const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= K) return;
-  uint32_t cnt = 0, lo = a + 1;
   const T key = ks[a];
   if (a + 1 < K && ks[a + 1] == key) {
     const uint32_t g = vs[a];
@@ -246,128 +273,55 @@ __global__ __launch_bounds__(256) void join_count_kernel(const T* __restrict__ k
       // genomes ascend in [a + 1, ge): the rows of the tile are a contiguous part of it
       uint32_t p = a + 1, q = ge;
       while (p < q) { const uint32_t m = (p + q) >> 1; if (vs[m] < row0) p = m + 1; else q = m; }
-      lo = p;
+      const uint32_t lo = p;
       q = ge;
       while (p < q) { const uint32_t m = (p + q) >> 1; if (vs[m] < row1) p = m + 1; else q = m; }
-      cnt = p - lo;
-      if (cnt) atomicAdd(colcnt + (g - g0), (unsigned long long)cnt);  // the column's co-occurrences: where its partners will lie
+      const uint32_t cnt = p - lo;
+      if (cnt) {
+        const unsigned long long was = atomicAdd(colcnt + (size_t)(g - g0) * CC_CSTRIDE, (1ULL << CC_ESHIFT) | (unsigned long long)cnt);
+        desc[off[g - g0] + (was >> CC_ESHIFT)] = make_uint2(lo, cnt);
+      }
     }
   }
-  lo_out[a] = lo;
-  cnt_out[a] = cnt;
 }
+struct ColPartners {  // the partners of column i, for the sum over the columns
+  const unsigned long long* colcnt;
+  __device__ unsigned long long operator()(uint32_t i) const { return colcnt[(size_t)i * CC_CSTRIDE] & CC_PMASK; }
+};
 
-// codes[eoff[a] + t] = (row << bits) | col for the t-th partner of element a.  One lane per element; an
-// element with many partners (a long posting list) is written by its whole wave.
-// Code: uint32_t when two genome indices fit 32 bits (up to 65 536 genomes: the second sort then moves half the bytes at
-// more than twice the key rate), uint64_t otherwise.
-template <typename Code>
-__global__ __launch_bounds__(256) void join_emit_kernel(const uint32_t* __restrict__ vs, const uint32_t* __restrict__ lo,
-                                                        const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ eoff,
-                                                        uint32_t K, int bits, Code* __restrict__ codes) {
-  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t lane = threadIdx.x & 63;
-  uint32_t c = 0, l = 0, col = 0;
-  uint64_t o = 0;
-  if (a < K) { c = cnt[a]; if (c) { l = lo[a]; col = vs[a]; o = eoff[a]; } }
-  const uint32_t SMALL = 24;
-  if (c && c <= SMALL)
-    for (uint32_t t = 0; t < c; t++) codes[o + t] = (Code)(((Code)vs[l + t] << bits) | col);
-  uint64_t big = __ballot(c > SMALL);
-  while (big) {  // wave-uniform
-    const int src = __builtin_ctzll(big);
-    big &= big - 1ULL;
-    const uint32_t cc = (uint32_t)__shfl((int)c, src), ll = (uint32_t)__shfl((int)l, src), colc = (uint32_t)__shfl((int)col, src);
-    const uint64_t oo = ((uint64_t)(uint32_t)__shfl((int)(o >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)o, src);
-    for (uint32_t t = lane; t < cc; t += 64) codes[oo + t] = (Code)(((Code)vs[ll + t] << bits) | colc);
-  }
-}
-
-// run r of the sorted codes = pair (row, col) with common = run length: the reference's filters, then append
-template <typename Code>
-__global__ __launch_bounds__(256) void join_filter_kernel(const Code* __restrict__ uq, const uint32_t* __restrict__ rc,
-                                                          const uint32_t* __restrict__ nruns, int bits,
-                                                          const uint32_t* __restrict__ len, int radio,
-                                                          rtc_cedge* __restrict__ edges, unsigned long long cap,
-                                                          unsigned long long* __restrict__ count) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t lane = threadIdx.x & 63;
-  bool keep = false;
-  uint32_t row = 0, col = 0, common = 0;
-  if (r < *nruns) {
-    const uint64_t code = (uint64_t)uq[r];
-    row = (uint32_t)(code >> bits);
-    col = (uint32_t)(code & ((1ULL << bits) - 1ULL));
-    common = rc[r];
-    keep = true;
-    if (radio >= 0) {  // src/MST.cpp:1484
-      const uint32_t s0 = len[row], s1 = len[col];
-      const uint32_t mn = s0 < s1 ? s0 : s1, mx = s0 > s1 ? s0 : s1;
-      if ((uint64_t)mx > (uint64_t)(uint32_t)radio * (uint64_t)mn) keep = false;
-    }
-  }
-  const uint64_t m = __ballot(keep);
-  if (!m) return;
-  unsigned long long base = 0;
-  if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(count, (unsigned long long)__popcll(m));
-  base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), __builtin_ctzll(m)) << 32) |
-         (uint32_t)__shfl((int)(uint32_t)base, __builtin_ctzll(m));
-  if (keep) {
-    const unsigned long long idx = base + __popcll(m & ((1ULL << lane) - 1ULL));
-    if (idx < cap) edges[idx] = rtc_cedge{row, col, common};
-  }
-}
-
-
-// ---- the column-centric second half (round 5) ---------------------------------------------------------------------------
-// The count kernel also sums, per column genome, the partners of its elements; the scan of those ng sums is an offset
-// table in which column c owns rows[coloff[c], coloff[c + 1]) -- its partner ROW ids, in no particular order, written by
-// join_emit_cols_kernel (one returning atomic per element that has partners).  A wave then counts one column's partners (a few
-// hundred to a few thousand ids, a dozen distinct) in an LDS table of its own and appends the column's edges: no second sort,
-// no run-length encode, no K-sized scan.
-__global__ __launch_bounds__(256) void join_emit_cols_kernel(const uint32_t* __restrict__ vs, const uint32_t* __restrict__ lo,
-                                                             const uint32_t* __restrict__ cnt, unsigned long long* __restrict__ cursor,
-                                                             uint32_t g0, uint32_t K, uint32_t* __restrict__ rows) {
-  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t lane = threadIdx.x & 63;
-  uint32_t c = 0, l = 0;
-  uint64_t o = 0;
-  if (a < K) { c = cnt[a]; if (c) { l = lo[a]; o = atomicAdd(cursor + (vs[a] - g0), (unsigned long long)c); } }
-  const uint32_t SMALL = 24;
-  if (c && c <= SMALL)
-    for (uint32_t t = 0; t < c; t++) rows[o + t] = vs[l + t];
-  uint64_t big = __ballot(c > SMALL);
-  while (big) {  // wave-uniform
-    const int src = __builtin_ctzll(big);
-    big &= big - 1ULL;
-    const uint32_t cc = (uint32_t)__shfl((int)c, src), ll = (uint32_t)__shfl((int)l, src);
-    const uint64_t oo = ((uint64_t)(uint32_t)__shfl((int)(o >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)o, src);
-    for (uint32_t t = lane; t < cc; t += 64) rows[oo + t] = vs[ll + t];
-  }
-}
 constexpr uint32_t CC_EMPTY = 0xffffffffu;
 __device__ __forceinline__ uint32_t cc_slot(uint32_t r, uint32_t mask) { return ((r * 0x9E3779B1u) >> 12) & mask; }
 __device__ __forceinline__ bool cc_keep(uint32_t s0, uint32_t s1, int radio) {  // the reference's size filter, src/MST.cpp:1484
-  if (radio < 0) return true;
   const uint32_t mn = s0 < s1 ? s0 : s1, mx = s0 > s1 ? s0 : s1;
   return (uint64_t)mx <= (uint64_t)(uint32_t)radio * (uint64_t)mn;
 }
-// One wave per column (CC_COLS_PER_WAVE of them in turn): the partner rows into the wave's table (row -> count; as many
-// slots as twice the partners, 1 024 at most), the table read out through the size filter into a staging list that is
-// appended with one global atomic per ~200 edges.  A column with more than CC_LIGHT_MAX distinct partners goes on the heavy
-// list (join_colcount_heavy_kernel).
-constexpr int CC_WAVES = 4, CC_SLOTS = 1024, CC_STAGE = 256, CC_COLS_PER_WAVE = 8, CC_LIGHT_MAX = 704;
-__global__ __launch_bounds__(64 * CC_WAVES) void join_colcount_kernel(const uint32_t* __restrict__ rows, const uint64_t* __restrict__ coloff,
-                                                                     uint32_t g0, uint32_t c_lo, uint32_t c_hi, const uint32_t* __restrict__ len,
-                                                                     int radio, rtc_cedge* __restrict__ edges, unsigned long long cap,
-                                                                     unsigned long long* __restrict__ count, uint32_t* __restrict__ heavy,
-                                                                     uint32_t* __restrict__ heavy_n) {
-  __shared__ uint32_t s_key[CC_WAVES][CC_SLOTS], s_cnt[CC_WAVES][CC_SLOTS];
+// One wave per column (cpw of them in turn when there are more columns than the chip has wave slots).  64 descriptors per
+// step, one per lane: the lists of up to CC_SHORT partners are laid end to end as addresses in the wave's `src` (a prefix
+// sum over the lanes says where), then read back 256 at a time -- four independent gathers per lane in flight -- into the
+// wave's table (row -> count); a longer list is walked by the whole wave.  A row that is in the table already costs one
+// plain read and one add; a first sight takes the compare-and-swap and notes its slot, so that reading the table out (and
+// clearing it) walks the distinct partners, not the slots: through the size filter into a staging list.  Staged edges are
+// appended with ONE global atomic per workgroup (atomics on the one list counter are what the chip serialises: ~13 ns each).
+// A column with more than CC_LIGHT_MAX distinct partners goes on the heavy list (join_colcount_heavy_kernel).
+constexpr int CC_WAVES = 4, CC_SLOTS = 1024, CC_STAGE = 64, CC_DEPTH = 4, CC_SHORT = 8, CC_LIGHT_MAX = 640;
+__global__ __launch_bounds__(64 * CC_WAVES) void join_colcount_kernel(const uint32_t* __restrict__ vs, const uint2* __restrict__ desc,
+                                                                     const uint64_t* __restrict__ off, const unsigned long long* __restrict__ colcnt,
+                                                                     uint32_t g0, uint32_t c_lo, uint32_t c_hi, uint32_t cpw,
+                                                                     const uint32_t* __restrict__ len, int radio, rtc_cedge* __restrict__ edges,
+                                                                     unsigned long long cap, unsigned long long* __restrict__ count,
+                                                                     uint32_t* __restrict__ heavy, uint32_t* __restrict__ heavy_n) {
+  __shared__ uint32_t s_key[CC_WAVES][CC_SLOTS], s_cnt[CC_WAVES][CC_SLOTS], s_src[CC_WAVES][64 * CC_SHORT];
+  __shared__ uint16_t s_seen[CC_WAVES][CC_SLOTS];
   __shared__ rtc_cedge s_stage[CC_WAVES][CC_STAGE];
+  __shared__ uint32_t s_nst[CC_WAVES];
+  __shared__ unsigned long long s_base;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint32_t* key = s_key[wave];
   uint32_t* cnt = s_cnt[wave];
+  uint32_t* src = s_src[wave];
+  uint16_t* seen = s_seen[wave];
   rtc_cedge* stage = s_stage[wave];
+  const uint32_t first = min(c_hi, c_lo + (blockIdx.x * CC_WAVES + wave) * cpw);  // (c_hi: a wave without columns, there for the barriers)
   for (uint32_t i = lane; i < (uint32_t)CC_SLOTS; i += 64) { key[i] = CC_EMPTY; cnt[i] = 0; }
   uint32_t nst = 0;  // staged edges (wave-uniform)
   auto flush = [&]() {
@@ -378,104 +332,170 @@ __global__ __launch_bounds__(64 * CC_WAVES) void join_colcount_kernel(const uint
     for (uint32_t i = lane; i < nst; i += 64) if (base + i < cap) edges[base + i] = stage[i];
     nst = 0;
   };
-  const uint32_t first = c_lo + (blockIdx.x * CC_WAVES + wave) * CC_COLS_PER_WAVE;
-  for (uint32_t c = first; c < first + CC_COLS_PER_WAVE && c < c_hi; c++) {
-    const uint64_t beg = coloff[c - g0], end = coloff[c - g0 + 1];
-    if (beg == end) continue;  // (wave-uniform)
+  for (uint32_t c = first; c < first + cpw && c < c_hi; c++) {
+    const unsigned long long cc = colcnt[(size_t)(c - g0) * CC_CSTRIDE];
+    const uint32_t ne = (uint32_t)(cc >> CC_ESHIFT);
+    if (!ne) continue;  // (wave-uniform)
+    const unsigned long long partners = cc & CC_PMASK;
+    const uint2* d = desc + off[c - g0];
+    const uint32_t s1 = len[c];
     uint32_t slots = 64;
-    while (slots < (uint32_t)CC_SLOTS && (uint64_t)slots < 2 * (end - beg)) slots <<= 1;
+    while (slots < (uint32_t)CC_SLOTS && (unsigned long long)slots < 2 * partners) slots <<= 1;
     const uint32_t mask = slots - 1;
     uint32_t distinct = 0;
-    for (uint64_t i0 = beg; i0 < end && distinct <= (uint32_t)CC_LIGHT_MAX; i0 += 64) {
+    auto insert = [&](uint32_t r) {  // (a row id is never the marker: ids stay below 2^31)
       bool fresh = false;
-      if (i0 + lane < end) {
-        const uint32_t r = rows[i0 + lane];
-        uint32_t sl = cc_slot(r, mask);
-        for (;;) {  // ends: at most CC_LIGHT_MAX + 64 of the 1 024 slots are ever taken
-          const uint32_t old = atomicCAS(&key[sl], CC_EMPTY, r);
-          fresh = old == CC_EMPTY;
-          if (fresh || old == r) { atomicAdd(&cnt[sl], 1u); break; }
-          sl = (sl + 1) & mask;
+      uint32_t at = 0;
+      if (r != CC_EMPTY) {
+        at = cc_slot(r, mask);
+        for (;;) {  // ends: at most CC_LIGHT_MAX + 64 CC_DEPTH of the 1 024 slots are ever taken
+          uint32_t o = key[at];
+          if (o == CC_EMPTY) { o = atomicCAS(&key[at], CC_EMPTY, r); fresh = o == CC_EMPTY; }
+          if (o == r || fresh) break;
+          at = (at + 1) & mask;
         }
+        atomicAdd(&cnt[at], 1u);
       }
-      distinct += (uint32_t)__popcll(__ballot(fresh));
+      const uint64_t fm = __ballot(fresh);
+      if (fresh) seen[distinct + (uint32_t)__popcll(fm & ((1ULL << lane) - 1ULL))] = (uint16_t)at;
+      distinct += (uint32_t)__popcll(fm);
+    };
+    uint2 dn = lane < ne ? d[lane] : make_uint2(0, 0);
+    for (uint32_t e0 = 0; e0 < ne && distinct <= (uint32_t)CC_LIGHT_MAX; e0 += 64) {
+      const uint2 de = dn;
+      dn = e0 + 64 + lane < ne ? d[e0 + 64 + lane] : make_uint2(0, 0);  // the next step's descriptors are on their way
+      // the short lists end to end
+      const uint32_t ns = de.y <= (uint32_t)CC_SHORT ? de.y : 0;
+      uint32_t pos = ns;  // inclusive prefix sum over the lanes
+#pragma unroll
+      for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)pos, sft); if ((int)lane >= sft) pos += o; }
+      const uint32_t total = (uint32_t)__shfl((int)pos, 63);
+      pos -= ns;
+      for (uint32_t t = 0; t < ns; t++) src[pos + t] = de.x + t;
+      for (uint32_t i0 = 0; i0 < total && distinct <= (uint32_t)CC_LIGHT_MAX; i0 += 64 * CC_DEPTH) {
+        uint32_t r[CC_DEPTH];
+#pragma unroll
+        for (int k = 0; k < CC_DEPTH; k++) { const uint32_t i = i0 + 64 * k + lane; r[k] = i < total ? vs[src[i]] : CC_EMPTY; }
+#pragma unroll
+        for (int k = 0; k < CC_DEPTH; k++) insert(r[k]);
+      }
+      // the longer lists, by the whole wave
+      uint64_t big = __ballot(de.y > (uint32_t)CC_SHORT);
+      while (big && distinct <= (uint32_t)CC_LIGHT_MAX) {  // (wave-uniform)
+        const int sl = __builtin_ctzll(big);
+        big &= big - 1ULL;
+        const uint32_t lo = (uint32_t)__shfl((int)de.x, sl), n = (uint32_t)__shfl((int)de.y, sl);
+        for (uint32_t i = 0; i < n && distinct <= (uint32_t)CC_LIGHT_MAX; i += 64) insert(i + lane < n ? vs[lo + i + lane] : CC_EMPTY);
+      }
     }
-    // a table of `slots` takes (end - beg) <= slots / 2 partners whatever they are; only the full-size one can run over
-    if (distinct > (uint32_t)CC_LIGHT_MAX) {
-      for (uint32_t i = lane; i < (uint32_t)CC_SLOTS; i += 64) { key[i] = CC_EMPTY; cnt[i] = 0; }
-      if (lane == 0) heavy[atomicAdd(heavy_n, 1u)] = c;  // (at most one entry per column: the list has ng places)
-      continue;
-    }
-    const uint32_t s1 = len[c];
-    for (uint32_t sl = lane; sl < slots; sl += 64) {  // (wave-uniform trip count)
-      const uint32_t r = key[sl];
-      bool keep = r != CC_EMPTY;
-      uint32_t common = 0;
-      if (keep) {
+    // a table of `slots` takes partners <= slots / 2 whatever they are; only the full-size one can run over
+    const bool over = distinct > (uint32_t)CC_LIGHT_MAX;
+    if (over && lane == 0) heavy[atomicAdd(heavy_n, 1u)] = c;  // (at most one entry per column: the list has ng places)
+    for (uint32_t i0 = 0; i0 < distinct; i0 += 64) {  // (wave-uniform trip count)
+      bool keep = false;
+      uint32_t rr = 0, common = 0;
+      if (i0 + lane < distinct) {
+        const uint32_t sl = seen[i0 + lane];
+        rr = key[sl];
         common = cnt[sl];
         key[sl] = CC_EMPTY;
         cnt[sl] = 0;
-        keep = cc_keep(len[r], s1, radio);
+        keep = !over && (radio < 0 || cc_keep(len[rr], s1, radio));
       }
       const uint64_t m = __ballot(keep);
       if (m) {
         if (nst + (uint32_t)__popcll(m) > (uint32_t)CC_STAGE) flush();
-        if (keep) stage[nst + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL))] = rtc_cedge{r, c, common};
+        if (keep) stage[nst + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL))] = rtc_cedge{rr, c, common};
         nst += (uint32_t)__popcll(m);
       }
     }
   }
-  flush();
+  // what is still staged: one global atomic for the workgroup
+  if (lane == 0) s_nst[wave] = nst;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int w = 0; w < CC_WAVES; w++) tot += s_nst[w];
+    s_base = tot ? atomicAdd(count, (unsigned long long)tot) : 0ull;
+  }
+  __syncthreads();
+  unsigned long long base = s_base;
+  for (uint32_t w = 0; w < wave; w++) base += s_nst[w];
+  for (uint32_t i = lane; i < nst; i += 64) if (base + i < cap) edges[base + i] = stage[i];
 }
-// The heavy list: one 256-lane workgroup per column, a table of 8 192 slots (all of the 64 KB a workgroup may declare).
-// More than CC_HEAVY_MAX distinct partners: *fail (the caller restores the edge count and runs the sort-based tail).
-constexpr int CC_HSLOTS = 8192, CC_HEAVY_MAX = 6144;
-__global__ __launch_bounds__(256) void join_colcount_heavy_kernel(const uint32_t* __restrict__ rows, const uint64_t* __restrict__ coloff,
-                                                                  uint32_t g0, const uint32_t* __restrict__ len, int radio,
-                                                                  rtc_cedge* __restrict__ edges, unsigned long long cap,
+// The heavy list: one 256-lane workgroup per column and a counter per ROW id, CC_HW ids at a time (the 64 KB a workgroup
+// may declare): the column's partner lists are walked once per occupied id range (a first walk marks which ranges hold
+// any).  Any number of distinct partners; nothing is hashed.  Short lists by a lane each, longer ones by a wave.
+constexpr uint32_t CC_HW = 16384 - 64;
+__global__ __launch_bounds__(256) void join_colcount_heavy_kernel(const uint32_t* __restrict__ vs, const uint2* __restrict__ desc,
+                                                                  const uint64_t* __restrict__ off, const unsigned long long* __restrict__ colcnt,
+                                                                  uint32_t g0, uint32_t row0, uint32_t row1, const uint32_t* __restrict__ len,
+                                                                  int radio, rtc_cedge* __restrict__ edges, unsigned long long cap,
                                                                   unsigned long long* __restrict__ count, const uint32_t* __restrict__ heavy,
-                                                                  const uint32_t* __restrict__ heavy_n, uint32_t* __restrict__ fail) {
-  __shared__ uint32_t key[CC_HSLOTS], cnt[CC_HSLOTS];
+                                                                  const uint32_t* __restrict__ heavy_n) {
+  __shared__ uint32_t cnt[CC_HW];
+  __shared__ uint32_t s_occ[64];  // bit p of word w: id range 32 w + p holds a partner (ranges past 2 048 share the last bit)
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t nh = *heavy_n;
+  // f(id) for every partner id of the column
+  auto walk = [&](const uint2* d, uint32_t ne, auto&& f) {
+    for (uint32_t e0 = 0; e0 < ne; e0 += 256) {  // (uniform trip count)
+      const uint32_t e = e0 + threadIdx.x;
+      const uint2 de = e < ne ? d[e] : make_uint2(0, 0);
+      if (de.y <= (uint32_t)CC_SHORT)
+        for (uint32_t t = 0; t < de.y; t++) f(vs[de.x + t]);
+      uint64_t big = __ballot(de.y > (uint32_t)CC_SHORT);
+      while (big) {  // (wave-uniform)
+        const int sl = __builtin_ctzll(big);
+        big &= big - 1ULL;
+        const uint32_t lo = (uint32_t)__shfl((int)de.x, sl), n = (uint32_t)__shfl((int)de.y, sl);
+        for (uint32_t i = lane; i < n; i += 64) f(vs[lo + i]);
+      }
+    }
+  };
   for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
     const uint32_t c = heavy[h];
-    const uint64_t beg = coloff[c - g0], end = coloff[c - g0 + 1];
-    for (uint32_t i = threadIdx.x; i < (uint32_t)CC_HSLOTS; i += 256) { key[i] = CC_EMPTY; cnt[i] = 0; }
+    const uint32_t ne = (uint32_t)(colcnt[(size_t)(c - g0) * CC_CSTRIDE] >> CC_ESHIFT);
+    const uint2* d = desc + off[c - g0];
+    const uint32_t rlo = max(c + 1, row0);  // a partner's id is above its column's
+    const uint32_t npass = (row1 - rlo + CC_HW - 1) / CC_HW;
+    if (threadIdx.x < 64) s_occ[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t distinct = 0;
-    for (uint64_t i0 = beg; i0 < end && distinct <= (uint32_t)CC_HEAVY_MAX; i0 += 256) {
-      int fresh = 0;
-      if (i0 + threadIdx.x < end) {
-        const uint32_t r = rows[i0 + threadIdx.x];
-        uint32_t sl = cc_slot(r, CC_HSLOTS - 1);
-        for (;;) {  // ends: at most CC_HEAVY_MAX + 256 slots are ever taken
-          const uint32_t old = atomicCAS(&key[sl], CC_EMPTY, r);
-          fresh = old == CC_EMPTY;
-          if (fresh || old == r) { atomicAdd(&cnt[sl], 1u); break; }
-          sl = (sl + 1) & (CC_HSLOTS - 1);
-        }
-      }
-      distinct += (uint32_t)__syncthreads_count(fresh);
-    }
-    if (distinct > (uint32_t)CC_HEAVY_MAX) { if (threadIdx.x == 0) *fail = 1u; return; }  // (uniform)
+    walk(d, ne, [&](uint32_t id) {
+      const uint32_t p = min((id - rlo) / CC_HW, 2047u);
+      atomicOr(&s_occ[p >> 5], 1u << (p & 31));
+    });
+    __syncthreads();
     const uint32_t s1 = len[c];
-    for (uint32_t sl = threadIdx.x; sl < (uint32_t)CC_HSLOTS; sl += 256) {
-      const uint32_t r = key[sl];
-      bool keep = r != CC_EMPTY;
-      uint32_t common = 0;
-      if (keep) { common = cnt[sl]; keep = cc_keep(len[r], s1, radio); }
-      const uint64_t m = __ballot(keep);
-      if (m) {
-        const int lead = __builtin_ctzll(m);
-        unsigned long long base = 0;
-        if ((int)lane == lead) base = atomicAdd(count, (unsigned long long)__popcll(m));
-        base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), lead) << 32) | (uint32_t)__shfl((int)(uint32_t)base, lead);
-        if (keep) {
-          const unsigned long long idx = base + __popcll(m & ((1ULL << lane) - 1ULL));
-          if (idx < cap) edges[idx] = rtc_cedge{r, c, common};
+    for (uint32_t p = 0; p < npass; p++) {
+      const uint32_t pb = min(p, 2047u);
+      if (!((s_occ[pb >> 5] >> (pb & 31)) & 1u)) continue;  // (uniform)
+      const uint32_t base = rlo + p * CC_HW;
+      for (uint32_t i = threadIdx.x; i < CC_HW; i += 256) cnt[i] = 0;
+      __syncthreads();
+      walk(d, ne, [&](uint32_t id) {
+        const uint32_t dd = id - base;  // (below base: wraps past CC_HW)
+        if (dd < CC_HW) atomicAdd(&cnt[dd], 1u);
+      });
+      __syncthreads();
+      for (uint32_t i0 = 0; i0 < CC_HW; i0 += 256) {  // (uniform trip count)
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t common = i < CC_HW ? cnt[i] : 0;
+        const uint32_t r = base + i;
+        const bool keep = common != 0 && (radio < 0 || cc_keep(len[r], s1, radio));
+        const uint64_t m = __ballot(keep);
+        if (m) {
+          const int lead = __builtin_ctzll(m);
+          unsigned long long at = 0;
+          if ((int)lane == lead) at = atomicAdd(count, (unsigned long long)__popcll(m));
+          at = ((unsigned long long)(uint32_t)__shfl((int)(at >> 32), lead) << 32) | (uint32_t)__shfl((int)(uint32_t)at, lead);
+          if (keep) {
+            const unsigned long long idx = at + __popcll(m & ((1ULL << lane) - 1ULL));
+            if (idx < cap) edges[idx] = rtc_cedge{r, c, common};
+          }
         }
       }
+      __syncthreads();
     }
     __syncthreads();
   }
@@ -483,44 +503,6 @@ __global__ __launch_bounds__(256) void join_colcount_heavy_kernel(const uint32_t
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-
-// The second half of the join: one code (row << bits | col) per co-occurrence, sorted, run lengths = |A_row n A_col|,
-// the reference's filters, append.  *fit = 0: the scratch does not fit (the caller's alternative runs).
-template <typename Code>
-int join_pairs_tail(rtc_ctx* ctx, const uint32_t* vals1, const uint32_t* d_lo, const uint32_t* d_cnt, const uint64_t* d_eoff, uint32_t K,
-                    uint64_t E, int bits, const uint32_t* d_len, int radio, rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count,
-                    uint64_t avail, size_t need1, int* fit) {
-  *fit = 0;
-  hipStream_t s = ctx->stream;
-  size_t tb_s2 = 0, tb_rle = 0;
-  RTC_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb_s2, (const Code*)nullptr, (Code*)nullptr, (size_t)E, 0u, (unsigned)(2 * bits), s));
-  RTC_HIP(ctx, rocprim::run_length_encode(nullptr, tb_rle, (const Code*)nullptr, (unsigned)E, (Code*)nullptr,
-                                          (uint32_t*)nullptr, (uint32_t*)nullptr, s));
-  const size_t b_codes = up256((size_t)E * sizeof(Code)), b_rc = up256((size_t)E * 4), b_tmp2 = up256(std::max(tb_s2, tb_rle));
-  const size_t need4 = 2 * b_codes + b_rc + b_tmp2 + 512;
-  if (need4 > (avail - std::min<uint64_t>(avail, need1)) / 2 + ctx->ws_bytes[4]) return RTC_OK;
-  void* ws4 = nullptr;
-  {
-    const int st = rtc_ws(ctx, 4, need4, &ws4);
-    if (st == RTC_ERR_NOMEM) return RTC_OK;
-    if (st != RTC_OK) return st;
-  }
-  Code* codes0 = (Code*)ws4;
-  Code* codes1 = (Code*)((char*)ws4 + b_codes);
-  uint32_t* d_rc = (uint32_t*)((char*)ws4 + 2 * b_codes);
-  uint32_t* d_nruns = (uint32_t*)((char*)ws4 + 2 * b_codes + b_rc);
-  void* tmp2 = (char*)ws4 + 2 * b_codes + b_rc + 256;
-  hipLaunchKernelGGL(join_emit_kernel<Code>, dim3((K + 255) / 256), dim3(256), 0, s, vals1, d_lo, d_cnt, d_eoff, K, bits, codes0);
-  RTC_CHECK_LAUNCH(ctx);
-  RTC_HIP(ctx, rocprim::radix_sort_keys(tmp2, tb_s2, (const Code*)codes0, codes1, (size_t)E, 0u, (unsigned)(2 * bits), s));
-  Code* d_uq = codes0;
-  RTC_HIP(ctx, rocprim::run_length_encode(tmp2, tb_rle, (const Code*)codes1, (unsigned)E, d_uq, d_rc, d_nruns, s));
-  hipLaunchKernelGGL(join_filter_kernel<Code>, dim3((uint32_t)((E + 255) / 256)), dim3(256), 0, s, (const Code*)d_uq, (const uint32_t*)d_rc,
-                     (const uint32_t*)d_nruns, bits, d_len, radio, d_edges, (unsigned long long)cap, (unsigned long long*)d_count);
-  RTC_CHECK_LAUNCH(ctx);
-  *fit = 1;
-  return RTC_OK;
-}
 
 template <typename T>
 int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const uint32_t* d_len, uint32_t n, uint32_t row0,
@@ -562,7 +544,7 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
       RTC_HIP(ctx, hipMemsetAsync(d_tab, 0, b_tab, s));
       hipLaunchKernelGGL(join_sample_kernel<T>, dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, g0, d_tab);
       RTC_CHECK_LAUNCH(ctx);
-      hipLaunchKernelGGL(join_sample_sum_kernel, dim3(256), dim3(256), 0, s, (const uint32_t*)d_tab, (unsigned long long*)(d_off + ng + 2));
+      hipLaunchKernelGGL(join_sample_sum_kernel, dim3(128), dim3(256), 0, s, (const uint32_t*)d_tab, (unsigned long long*)(d_off + ng + 2));
       RTC_CHECK_LAUNCH(ctx);
     }
   }
@@ -658,25 +640,25 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     }
   }
 
-  const uint64_t avail = rtc_free_hbm(ctx) + ctx->ws_bytes[1] + ctx->ws_bytes[4];
+  const uint64_t avail = rtc_free_hbm(ctx) + ctx->ws_bytes[1];
 
   // ---- 2. flat copy + stable sort by hash ----
   size_t tb_sort = 0;
   RTC_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb_sort, (const T*)nullptr, (T*)nullptr, (const uint32_t*)nullptr,
                                          (uint32_t*)nullptr, (size_t)K, 0u, (unsigned)(8 * sizeof(T)), s));
-  size_t tb_scan2 = 0;
+  size_t tb_red = 0;
   {
-    auto it = rocprim::make_transform_iterator((const uint32_t*)nullptr, U32ToU64());
-    RTC_HIP(ctx, rocprim::exclusive_scan(nullptr, tb_scan2, it, (uint64_t*)nullptr, (uint64_t)0, (size_t)K + 1,
-                                         rocprim::plus<uint64_t>(), s));
+    auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0), ColPartners{nullptr});
+    RTC_HIP(ctx, rocprim::reduce(nullptr, tb_red, it, (unsigned long long*)nullptr, 0ull, (size_t)ng, rocprim::plus<unsigned long long>(), s));
   }
-  const size_t b_keys = up256((size_t)K * sizeof(T)), b_vals = up256((size_t)(K + 1) * 4), b_eoff = up256((size_t)(K + 1) * 8);
-  const size_t b_tmp1 = up256(std::max(tb_sort, tb_scan2));
-  // keys0 | keys1 | vals0 | vals1 | eoff | temp | lo, cnt | colcnt, coloff, cursor | heavy
-  const size_t b_locnt = up256((size_t)(2 * (size_t)K + 1) * 4), b_col = up256((size_t)(ng + 1) * 8), b_heavy = up256((size_t)(ng + 4) * 4);
-  const size_t need1 = 2 * b_keys + 2 * b_vals + b_eoff + b_tmp1 + b_locnt + 3 * b_col + b_heavy + 256;
+  const size_t b_keys = up256((size_t)K * sizeof(T)), b_vals = up256((size_t)(K + 1) * 4);
+  const size_t b_tmp1 = up256(std::max(tb_sort, tb_red));
+  // keys0 | vals0 | keys1 | vals1 | temp | colcnt, total | heavy.  The descriptors (8 bytes per element) lie over
+  // keys0 | vals0, which the sort has read by then.
+  const size_t b_col = up256(((size_t)ng * CC_CSTRIDE + 8) * 8), b_heavy = up256((size_t)(ng + 4) * 4);
+  const size_t need1 = 2 * b_keys + 2 * b_vals + b_tmp1 + b_col + b_heavy + 256;
   if (need1 > avail / 2) return RTC_OK;
-  ctx->pair_plan_valid = 0;  // scratch slots 1 and 4 are the tiled plan's
+  ctx->pair_plan_valid = 0;  // scratch slot 1 is the tiled plan's
   void* ws1 = nullptr;
   {
     const int st = rtc_ws(ctx, 1, need1, &ws1);
@@ -684,24 +666,16 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     if (st != RTC_OK) return st;
   }
   T* keys0 = (T*)ws1;
-  T* keys1 = (T*)((char*)ws1 + b_keys);
-  uint32_t* vals0 = (uint32_t*)((char*)ws1 + 2 * b_keys);
+  uint32_t* vals0 = (uint32_t*)((char*)ws1 + b_keys);
+  T* keys1 = (T*)((char*)ws1 + b_keys + b_vals);
   uint32_t* vals1 = (uint32_t*)((char*)ws1 + 2 * b_keys + b_vals);
-  uint64_t* d_eoff = (uint64_t*)((char*)ws1 + 2 * b_keys + 2 * b_vals);
-  void* tmp1 = (char*)ws1 + 2 * b_keys + 2 * b_vals + b_eoff;
-  if (semi)
-    hipLaunchKernelGGL((join_semi_kernel<T, true>), dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, g0, row0, wshift,
-                       (const unsigned long long*)d_bloom, (uint32_t*)nullptr, (const uint64_t*)d_off, keys0, vals0);
-  else
-    hipLaunchKernelGGL(join_flatten_kernel<T>, dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, d_off, g0, keys0, vals0);
-  RTC_CHECK_LAUNCH(ctx);
-  // ---- 3. partners per element, their offsets, the co-occurrence count ----
-  uint32_t* d_lo = (uint32_t*)((char*)ws1 + 2 * b_keys + 2 * b_vals + b_eoff + b_tmp1);
-  uint32_t* d_cnt = d_lo + K;          // K + 1 entries: the fallback's scan reads one past the end for the total
-  uint64_t* d_colcnt = (uint64_t*)((char*)d_lo + b_locnt);  // ng + 1: co-occurrences per column genome, then their offsets and the emit cursors
-  uint64_t* d_coloff = (uint64_t*)((char*)d_colcnt + b_col);
-  uint64_t* d_cursor = (uint64_t*)((char*)d_coloff + b_col);
-  uint32_t* d_heavy = (uint32_t*)((char*)d_cursor + b_col);  // [0]: entries, [1]: fail, [4..): columns for the heavy kernel
+  void* tmp1 = (char*)ws1 + 2 * b_keys + 2 * b_vals;
+  uint2* d_desc = (uint2*)ws1;
+  static_assert(sizeof(uint2) <= sizeof(T) + 4, "the descriptors fit the unsorted copy");
+  // ---- 3. partners per element (descriptors by column), the co-occurrence count ----
+  uint64_t* d_colcnt = (uint64_t*)((char*)ws1 + 2 * b_keys + 2 * b_vals + b_tmp1);  // a line per column genome: elements << 40 | partners
+  uint64_t* d_total = d_colcnt + (size_t)ng * CC_CSTRIDE;                            // all partners
+  uint32_t* d_heavy = (uint32_t*)((char*)d_colcnt + b_col);  // [0]: entries, [4..): columns for the heavy kernel
   uint64_t E = 0;
   // radix passes only over the bits that vary: [0, end_bit) holds every hash.  u64: first on the 32 bits below
   // end_bit + repair of the rare mixed runs; when the repair gives up (a collision inside a very long posting
@@ -710,13 +684,20 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   unsigned end_bit = 1;
   while (end_bit < 8 * sizeof(T) && (maxkey >> end_bit)) end_bit++;
   // distinct hashes that agree in the b sorted bits: about K^2 / 2^(b + 3) inversions (measured 3 535 at K = 10^7, b = 32);
-  // b grows by a radix pass (8 bits) while that would not fit half the repair list
+  // b grows by a radix pass (8 bits) while they would cost more in the repair list's atomics than the pass does
   unsigned sort_bits = 32;
-  while (sort_bits < 64 && (double)K * (double)K / std::ldexp(1.0, (int)sort_bits + 3) > (double)(FIX_CAP / 2)) sort_bits += 8;
+  while (sort_bits < 64 && (double)K * (double)K / std::ldexp(1.0, (int)sort_bits + 3) > (double)FIX_EXPECT_MAX) sort_bits += 8;
   const unsigned half_bit = end_bit > sort_bits ? end_bit - sort_bits : 0;
   for (int attempt = 0; attempt < 2; attempt++) {
     const bool halfsort = sizeof(T) == 8 && attempt == 0 && half_bit > 0 && (end_bit < 64 || K >= (1u << 22)) &&
                           !ctx->opt.join_fullsort;
+    // (the flat copy anew for the second attempt: the first one's descriptors lie over it)
+    if (semi)
+      hipLaunchKernelGGL((join_semi_kernel<T, true>), dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, g0, row0, wshift,
+                         (const unsigned long long*)d_bloom, (uint32_t*)nullptr, (const uint64_t*)d_off, keys0, vals0);
+    else
+      hipLaunchKernelGGL(join_flatten_kernel<T>, dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, d_off, g0, keys0, vals0);
+    RTC_CHECK_LAUNCH(ctx);
     RTC_HIP(ctx, rocprim::radix_sort_pairs(tmp1, tb_sort, (const T*)keys0, keys1, (const uint32_t*)vals0, vals1, (size_t)K,
                                            halfsort ? half_bit : 0u, end_bit, s));
     if constexpr (sizeof(T) == 8) {
@@ -730,12 +711,15 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
         RTC_CHECK_LAUNCH(ctx);
       }
     }
-    RTC_HIP(ctx, hipMemsetAsync(d_colcnt, 0, (size_t)(ng + 1) * 8, s));
+    RTC_HIP(ctx, hipMemsetAsync(d_colcnt, 0, (size_t)ng * CC_CSTRIDE * 8, s));
     hipLaunchKernelGGL(join_count_kernel<T>, dim3((K + 255) / 256), dim3(256), 0, s, (const T*)keys1, (const uint32_t*)vals1, K,
-                       row0, row1, col0, col1, d_lo, d_cnt, g0, (unsigned long long*)d_colcnt);
+                       row0, row1, col0, col1, g0, (const uint64_t*)d_off, (unsigned long long*)d_colcnt, d_desc);
     RTC_CHECK_LAUNCH(ctx);
-    RTC_HIP(ctx, rocprim::exclusive_scan(tmp1, tb_scan2, (const uint64_t*)d_colcnt, d_coloff, (uint64_t)0, (size_t)ng + 1, rocprim::plus<uint64_t>(), s));
-    RTC_HIP(ctx, hipMemcpyAsync(hpin, d_coloff + ng, 8, hipMemcpyDeviceToHost, s));
+    {
+      auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0), ColPartners{(const unsigned long long*)d_colcnt});
+      RTC_HIP(ctx, rocprim::reduce(tmp1, tb_red, it, (unsigned long long*)d_total, 0ull, (size_t)ng, rocprim::plus<unsigned long long>(), s));
+    }
+    RTC_HIP(ctx, hipMemcpyAsync(hpin, d_total, 8, hipMemcpyDeviceToHost, s));
     if (halfsort) RTC_HIP(ctx, hipMemcpyAsync((char*)hpin + 8, d_fix, 8, hipMemcpyDeviceToHost, s));
     RTC_HIP(ctx, hipStreamSynchronize(s));
     E = *(const uint64_t*)hpin;
@@ -754,51 +738,19 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   if (mode == 1 && t_sort + (double)E / 1.5e10 > t_tiled) { note_dense(); return RTC_OK; }
 
   // ---- 4. the column-centric tail ----
-  if (!ctx->opt.join_sorttail) {
-    const size_t need4 = up256((size_t)E * 4) + 256;
-    if (need4 > (avail - std::min<uint64_t>(avail, need1)) / 2 + ctx->ws_bytes[4]) return RTC_OK;
-    void* ws4 = nullptr;
-    {
-      const int st = rtc_ws(ctx, 4, need4, &ws4);
-      if (st == RTC_ERR_NOMEM) return RTC_OK;
-      if (st != RTC_OK) return st;
-    }
-    uint32_t* d_rows = (uint32_t*)ws4;
-    uint64_t* d_count0 = (uint64_t*)(d_heavy + 2);  // the list's length before this tail: restored should a column not fit the heavy table
-    RTC_HIP(ctx, hipMemsetAsync(d_heavy, 0, 8, s));
-    RTC_HIP(ctx, hipMemcpyAsync(d_count0, d_count, 8, hipMemcpyDeviceToDevice, s));
-    RTC_HIP(ctx, hipMemcpyAsync(d_cursor, d_coloff, (size_t)(ng + 1) * 8, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(join_emit_cols_kernel, dim3((K + 255) / 256), dim3(256), 0, s, (const uint32_t*)vals1, (const uint32_t*)d_lo,
-                       (const uint32_t*)d_cnt, (unsigned long long*)d_cursor, g0, K, d_rows);
-    RTC_CHECK_LAUNCH(ctx);
-    const uint32_t c_lo = std::max(col0, g0), c_hi = std::min(col1, g1);
-    const uint32_t nwaves = (c_hi - c_lo + CC_COLS_PER_WAVE - 1) / CC_COLS_PER_WAVE;
-    hipLaunchKernelGGL(join_colcount_kernel, dim3((nwaves + CC_WAVES - 1) / CC_WAVES), dim3(64 * CC_WAVES), 0, s, (const uint32_t*)d_rows,
-                       (const uint64_t*)d_coloff, g0, c_lo, c_hi, d_len, radio, d_edges, (unsigned long long)cap, (unsigned long long*)d_count,
-                       d_heavy + 4, d_heavy);
-    RTC_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(join_colcount_heavy_kernel, dim3(512), dim3(256), 0, s, (const uint32_t*)d_rows, (const uint64_t*)d_coloff, g0, d_len, radio,
-                       d_edges, (unsigned long long)cap, (unsigned long long*)d_count, (const uint32_t*)(d_heavy + 4), (const uint32_t*)d_heavy,
-                       d_heavy + 1);
-    RTC_CHECK_LAUNCH(ctx);
-    RTC_HIP(ctx, hipMemcpyAsync(hpin, d_heavy, 8, hipMemcpyDeviceToHost, s));
-    RTC_HIP(ctx, hipStreamSynchronize(s));
-    if (ctx->opt.join_debug) fprintf(stderr, "[join] column tail: %u heavy columns, fail=%u\n", ((const uint32_t*)hpin)[0], ((const uint32_t*)hpin)[1]);
-    if (((const uint32_t*)hpin)[1] == 0) { *handled = 1; return RTC_OK; }
-    // a column with more distinct partners than the heavy table holds: the list as it was, and the sort-based tail
-    RTC_HIP(ctx, hipMemcpyAsync(d_count, d_count0, 8, hipMemcpyDeviceToDevice, s));
-  }
-  {
-    RTC_HIP(ctx, hipMemsetAsync(d_cnt + K, 0, 4, s));
-    auto it = rocprim::make_transform_iterator((const uint32_t*)d_cnt, U32ToU64());
-    RTC_HIP(ctx, rocprim::exclusive_scan(tmp1, tb_scan2, it, d_eoff, (uint64_t)0, (size_t)K + 1, rocprim::plus<uint64_t>(), s));
-  }
-  int bits = 1;
-  while ((1ull << bits) < (uint64_t)n) bits++;
-  int fit = 0;
-  if (2 * bits <= 32) RTC_TRY((join_pairs_tail<uint32_t>(ctx, vals1, d_lo, d_cnt, d_eoff, K, E, bits, d_len, radio, d_edges, cap, d_count, avail, need1, &fit)));
-  else RTC_TRY((join_pairs_tail<uint64_t>(ctx, vals1, d_lo, d_cnt, d_eoff, K, E, bits, d_len, radio, d_edges, cap, d_count, avail, need1, &fit)));
-  if (!fit) return RTC_OK;
+  RTC_HIP(ctx, hipMemsetAsync(d_heavy, 0, 4, s));
+  const uint32_t c_lo = std::max(col0, g0), c_hi = std::min(col1, g1);
+  // two columns per wave (half the atomics on the list counter), more when the columns outnumber the chip's wave slots
+  const uint32_t cpw = std::min<uint32_t>(8, std::max<uint32_t>(2, (c_hi - c_lo) / (256 * 16 * 2)));
+  const uint32_t nwaves = (c_hi - c_lo + cpw - 1) / cpw;
+  hipLaunchKernelGGL(join_colcount_kernel, dim3((nwaves + CC_WAVES - 1) / CC_WAVES), dim3(64 * CC_WAVES), 0, s, (const uint32_t*)vals1,
+                     (const uint2*)d_desc, (const uint64_t*)d_off, (const unsigned long long*)d_colcnt, g0, c_lo, c_hi, cpw, d_len, radio, d_edges,
+                     (unsigned long long)cap, (unsigned long long*)d_count, d_heavy + 4, d_heavy);
+  RTC_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(join_colcount_heavy_kernel, dim3(512), dim3(256), 0, s, (const uint32_t*)vals1, (const uint2*)d_desc, (const uint64_t*)d_off,
+                     (const unsigned long long*)d_colcnt, g0, row0, row1, d_len, radio, d_edges, (unsigned long long)cap, (unsigned long long*)d_count,
+                     (const uint32_t*)(d_heavy + 4), (const uint32_t*)d_heavy);
+  RTC_CHECK_LAUNCH(ctx);
   *handled = 1;
   return RTC_OK;
 }

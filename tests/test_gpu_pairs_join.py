@@ -133,60 +133,45 @@ def test_join_long_posting_lists(ctx, oracle):
     assert np.array_equal(_edges(ctx, dev, 1, 120, 0, 119, 4, mode=0), want)
 
 
-def _with_env(name, value, fn):
-    os.environ[name] = value
-    _reload_options()
-    try:
-        return fn()
-    finally:
-        os.environ.pop(name, None)
-        _reload_options()
-
-
-@pytest.mark.parametrize("sharers", [300, 1500, 7000])
-def test_join_column_tail_light_heavy_and_sort_fallback(ctx, sharers):
-    """The join's second half counts a column's partners in an LDS table: up to 704 distinct partners in a wave's table,
-    up to 6 144 in the heavy kernel's, beyond that the launch falls back to the sort-based tail.  `sharers` genomes hold one
-    common hash (column 0 then has sharers - 1 distinct partners) beside family hashes with multiplicities; every size gives
-    the tiled kernel's triples, and so does the sort-based tail forced on."""
+@pytest.mark.parametrize("sharers,n", [(120, 400), (300, 500), (1500, 1700), (7000, 7200), (1500, 40000)])
+def test_join_column_tail_light_and_heavy_columns(ctx, sharers, n):
+    """The join's second half counts a column's partners in LDS: up to 640 distinct partners in a wave's hash table, more
+    in the heavy kernel's per-row counters (16 320 row ids per walk: the 40 000-genome case takes three).  `sharers` genomes
+    spread over the set hold one common hash (the first of them then has sharers - 1 distinct partners) beside family hashes
+    with multiplicities; every size gives the tiled kernel's triples, also appended behind edges that are already there."""
+    import torch
     from rabbittclust_amd import api
-    rng = np.random.default_rng(sharers)
-    n = sharers + 200
+    rng = np.random.default_rng(sharers + n)
     common = np.uint64(0x123456789ABCDEF)
-    fam = [np.unique(rng.integers(1 << 40, 1 << 62, size=24, dtype=np.uint64)) for _ in range(40)]
+    fam = [np.unique(rng.integers(1 << 40, 1 << 62, size=24, dtype=np.uint64)) for _ in range(max(40, n // 100))]
+    holds = np.zeros(n, dtype=bool)
+    holds[rng.choice(n, size=sharers, replace=False)] = True
     sk = []
     for g in range(n):
         own = rng.integers(1 << 40, 1 << 62, size=int(rng.integers(4, 12)), dtype=np.uint64)
         f = fam[int(rng.integers(0, len(fam)))]
         parts = [own, f[rng.random(len(f)) < 0.7]]
-        if g < sharers:
+        if holds[g]:
             parts.append(np.array([common], dtype=np.uint64))
         sk.append(np.unique(np.concatenate(parts)))
     dev = api.SketchSet.from_host(sk, ctx.device)
-    for (r0, r1, c0, c1, radio) in [(1, n, 0, n - 1, -1), (n // 3, n, 0, n - 1, 2)]:
-        want = _edges(ctx, dev, r0, r1, c0, c1, radio, mode=0, cap=1 << 26)
-        assert len(want) >= (sharers - 1) * (sharers - 2) // 4
-        got = _edges(ctx, dev, r0, r1, c0, c1, radio, mode=2, cap=1 << 26)
-        assert np.array_equal(got, want), (sharers, r0, radio)
-        got = _with_env("RTC_JOIN_SORTTAIL", "1", lambda: _edges(ctx, dev, r0, r1, c0, c1, radio, mode=2, cap=1 << 26))
-        assert np.array_equal(got, want), (sharers, r0, radio, "sort tail")
-    # the fallback after a failed column tail appends where the list stood: 40 edges already there
-    import torch
     cap = 1 << 26
+    for (r0, r1, c0, c1, radio) in [(1, n, 0, n - 1, -1), (n // 3, n, 0, n - 1, 2)]:
+        want = _edges(ctx, dev, r0, r1, c0, c1, radio, mode=0, cap=cap)
+        assert len(want) >= (sharers - 1) * (sharers - 2) // 8
+        got = _edges(ctx, dev, r0, r1, c0, c1, radio, mode=2, cap=cap)
+        assert np.array_equal(got, want), (sharers, n, r0, radio)
+    want = _edges(ctx, dev, 1, n, 0, n - 1, -1, mode=0, cap=cap)
     edges = torch.full((cap, 3), -1, dtype=torch.int32, device=ctx.device)
     count = torch.tensor([40], dtype=torch.int64, device=ctx.device)
-    want = _edges(ctx, dev, 1, n, 0, n - 1, -1, mode=0, cap=1 << 26)
-
-    def run():
-        os.environ["RTC_PAIR_JOIN"] = "2"
+    os.environ["RTC_PAIR_JOIN"] = "2"
+    _reload_options()
+    try:
+        ctx.check(ctx.lib.rtc_pair_edges_dev(ctx.h, api._t_ptr(dev.hashes), dev.width, api._t_ptr(dev.start), api._t_ptr(dev.len),
+                                             dev.n, 1, n, 0, n - 1, -1, api._t_ptr(edges), cap, api._t_ptr(count)))
+    finally:
+        os.environ.pop("RTC_PAIR_JOIN", None)
         _reload_options()
-        try:
-            ctx.check(ctx.lib.rtc_pair_edges_dev(ctx.h, api._t_ptr(dev.hashes), dev.width, api._t_ptr(dev.start), api._t_ptr(dev.len),
-                                                 dev.n, 1, n, 0, n - 1, -1, api._t_ptr(edges), cap, api._t_ptr(count)))
-        finally:
-            os.environ.pop("RTC_PAIR_JOIN", None)
-            _reload_options()
-    run()
     m = int(count.item())
     assert m == 40 + len(want)
     e = edges[:m].cpu().numpy()
