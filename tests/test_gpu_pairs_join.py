@@ -133,34 +133,45 @@ def test_join_long_posting_lists(ctx, oracle):
     assert np.array_equal(_edges(ctx, dev, 1, 120, 0, 119, 4, mode=0), want)
 
 
-@pytest.mark.parametrize("sharers,n", [(120, 400), (300, 500), (1500, 1700), (7000, 7200), (1500, 40000)])
-def test_join_column_tail_light_and_heavy_columns(ctx, sharers, n):
+@pytest.mark.parametrize("sharers,n,width", [(120, 400, 8), (300, 500, 8), (1500, 1700, 8), (7000, 7200, 8), (1500, 40000, 8),
+                                              (300, 500, 4), (1500, 1700, 4), (900, 40000, 4)])
+def test_join_column_tail_light_and_heavy_columns(ctx, sharers, n, width):
     """The join's second half counts a column's partners in LDS: up to 640 distinct partners in a wave's hash table, more
     in the heavy kernel's per-row counters (16 320 row ids per walk: the 40 000-genome case takes three).  `sharers` genomes
     spread over the set hold one common hash (the first of them then has sharers - 1 distinct partners) beside family hashes
     with multiplicities; every size gives the tiled kernel's triples, also appended behind edges that are already there."""
     import torch
     from rabbittclust_amd import api
-    rng = np.random.default_rng(sharers + n)
-    common = np.uint64(0x123456789ABCDEF)
-    fam = [np.unique(rng.integers(1 << 40, 1 << 62, size=24, dtype=np.uint64)) for _ in range(max(40, n // 100))]
+    rng = np.random.default_rng(sharers + n + width)
+    dt = np.uint64 if width == 8 else np.uint32
+    lo_h, hi_h = (1 << 40, 1 << 62) if width == 8 else (1 << 10, 1 << 31)
+    common = np.uint64(0x123456789ABCDEF if width == 8 else 0x1234567)
+    fam = [np.unique(rng.integers(lo_h, hi_h, size=24, dtype=np.uint64)) for _ in range(max(40, n // 100))]
     holds = np.zeros(n, dtype=bool)
     holds[rng.choice(n, size=sharers, replace=False)] = True
     sk = []
     for g in range(n):
-        own = rng.integers(1 << 40, 1 << 62, size=int(rng.integers(4, 12)), dtype=np.uint64)
+        own = rng.integers(lo_h, hi_h, size=int(rng.integers(4, 12)), dtype=np.uint64)
         f = fam[int(rng.integers(0, len(fam)))]
         parts = [own, f[rng.random(len(f)) < 0.7]]
         if holds[g]:
             parts.append(np.array([common], dtype=np.uint64))
-        sk.append(np.unique(np.concatenate(parts)))
-    dev = api.SketchSet.from_host(sk, ctx.device)
+        sk.append(np.unique(np.concatenate(parts)).astype(dt))
+    dev = api.SketchSet.from_host(sk, ctx.device, width=width)
     cap = 1 << 26
     for (r0, r1, c0, c1, radio) in [(1, n, 0, n - 1, -1), (n // 3, n, 0, n - 1, 2)]:
         want = _edges(ctx, dev, r0, r1, c0, c1, radio, mode=0, cap=cap)
         assert len(want) >= (sharers - 1) * (sharers - 2) // 8
         got = _edges(ctx, dev, r0, r1, c0, c1, radio, mode=2, cap=cap)
         assert np.array_equal(got, want), (sharers, n, r0, radio)
+        if r0 > 1:  # the semi-join in front of the sort (descriptors then lie in the kept hashes' layout)
+            os.environ["RTC_JOIN_SEMI"] = "2"
+            _reload_options()
+            try:
+                assert np.array_equal(_edges(ctx, dev, r0, r1, c0, c1, radio, mode=2, cap=cap), want), (sharers, n, "semi")
+            finally:
+                os.environ.pop("RTC_JOIN_SEMI", None)
+                _reload_options()
     want = _edges(ctx, dev, 1, n, 0, n - 1, -1, mode=0, cap=cap)
     edges = torch.full((cap, 3), -1, dtype=torch.int32, device=ctx.device)
     count = torch.tensor([40], dtype=torch.int64, device=ctx.device)
