@@ -9,7 +9,10 @@ L = int(sys.argv[5]) if len(sys.argv) > 5 else 5_000_000
 STAGING = sys.argv[6] if len(sys.argv) > 6 else None  # "packed": bench.py --staging packed
 K, S = 21, 1000
 want = ("synth_kernel", "sketch_minhash_kernel", "sketch_minhash_packed_kernel", "sketch_kssd", "transpose_slices_kernel", "pair_tiled_kernel", "pair_join_phase")
-JOIN_PARTS = ("rocprim", "join_")  # pair_join_phase = every kernel of the inverted join: rocPRIM sort / scan / encode + join_*
+# pair_join_phase = every kernel of the inverted join: rocPRIM sort / scan / reduce + join_* (and the forest's two rocPRIM sorts).
+# The library's rocPRIM is /opt/rocm's (inline namespace ROCPRIM_400200_NS); torch carries its own (ROCPRIM_400001_NS: the
+# partition / scan kernels of bench.py's packing of a batch with torch ops are NOT part of the phase).
+JOIN_PARTS = ("ROCPRIM_400200_NS", "join_")
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
 for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
