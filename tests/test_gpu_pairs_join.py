@@ -272,6 +272,47 @@ def test_join_u64_hashes_that_share_their_upper_half(ctx, oracle, prefixes):
         _reload_options()
 
 
+@pytest.mark.parametrize("seed", list(range(1, int(os.environ.get("RTC_SOAK_SEEDS", "3")) + 1)))
+def test_join_equals_tiled_on_mid_scale_random_families(ctx, seed):
+    """A few thousand to thirty thousand small sketches in families of random size (1 .. 1 500 members: partner lists from one to
+    over a thousand entries, columns on both sides of the 640-partner table limit, several columns per wave beyond 24 576
+    columns), u64 or u32, random tiles and size filters, the semi-join forced now and then: the join gives the tiled kernel's
+    triples."""
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(31000 + seed)
+    width = 8 if seed % 2 else 4
+    dt = np.uint64 if width == 8 else np.uint32
+    lo_h, hi_h = (1 << 40, 1 << 62) if width == 8 else (1 << 8, 1 << 31)
+    n = int(rng.choice([3000, 6000, 30000]))
+    sk, g = [], 0
+    while g < n:
+        members = int(min(n - g, rng.choice([1, 2, 5, 20, 90, 700, 1500], p=[0.3, 0.2, 0.2, 0.15, 0.1, 0.04, 0.01])))
+        core = np.unique(rng.integers(lo_h, hi_h, size=int(rng.integers(3, 30)), dtype=np.uint64))
+        keep_p = float(rng.choice([0.3, 0.8, 1.0]))
+        for _ in range(members):
+            own = rng.integers(lo_h, hi_h, size=int(rng.integers(0, 6)), dtype=np.uint64)
+            sk.append(np.unique(np.concatenate([own, core[rng.random(len(core)) < keep_p]])).astype(dt))
+        g += members
+    order = rng.permutation(n)  # families scattered over the ids
+    sk = [sk[i] for i in order]
+    dev = api.SketchSet.from_host(sk, ctx.device, width=width)
+    cap = 1 << 25
+    for t in range(3):
+        r0 = 1 if t == 0 else int(rng.integers(1, n)); r1 = n if t == 0 else int(rng.integers(r0 + 1, n + 1))
+        c0 = 0 if t == 0 else int(rng.integers(0, r1 - 1)); c1 = r1 - 1 if t == 0 else int(rng.integers(c0 + 1, r1))
+        radio = int(rng.choice([-1, 2, 4]))
+        want = _edges(ctx, dev, r0, r1, c0, c1, radio, mode=0, cap=cap)
+        assert np.array_equal(_edges(ctx, dev, r0, r1, c0, c1, radio, mode=2, cap=cap), want), (seed, r0, r1, c0, c1, radio)
+        if t == 2:
+            os.environ["RTC_JOIN_SEMI"] = "2"
+            _reload_options()
+            try:
+                assert np.array_equal(_edges(ctx, dev, r0, r1, c0, c1, radio, mode=2, cap=cap), want), (seed, r0, r1, c0, c1, radio, "semi")
+            finally:
+                os.environ.pop("RTC_JOIN_SEMI", None)
+                _reload_options()
+
+
 SOAK_SEEDS = int(os.environ.get("RTC_SOAK_SEEDS", "3"))  # RTC_SOAK_SEEDS=40: a longer walk through random tiles
 
 
