@@ -740,8 +740,9 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   // ---- 4. the column-centric tail ----
   RTC_HIP(ctx, hipMemsetAsync(d_heavy, 0, 4, s));
   const uint32_t c_lo = std::max(col0, g0), c_hi = std::min(col1, g1);
-  // two columns per wave (half the atomics on the list counter), more when the columns outnumber the chip's wave slots
-  const uint32_t cpw = std::min<uint32_t>(8, std::max<uint32_t>(2, (c_hi - c_lo) / (256 * 16 * 2)));
+  // a column per wave; more (up to 8) when the columns outnumber the chip's wave slots (1 / 2 / 4 per wave at 10 000 columns:
+  // pair phase 0.99-1.00 / 1.02-1.03 / 1.03-1.05 ms on one box, profiles/r05_join_column_tail_ab.txt)
+  const uint32_t cpw = std::min<uint32_t>(8, std::max<uint32_t>(1, (c_hi - c_lo) / (256 * 16 * 2)));
   const uint32_t nwaves = (c_hi - c_lo + cpw - 1) / cpw;
   hipLaunchKernelGGL(join_colcount_kernel, dim3((nwaves + CC_WAVES - 1) / CC_WAVES), dim3(64 * CC_WAVES), 0, s, (const uint32_t*)vals1,
                      (const uint2*)d_desc, (const uint64_t*)d_off, (const unsigned long long*)d_colcnt, g0, c_lo, c_hi, cpw, d_len, radio, d_edges,
