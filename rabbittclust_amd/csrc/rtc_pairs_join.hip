@@ -297,20 +297,20 @@ __device__ __forceinline__ bool cc_keep(uint32_t s0, uint32_t s1, int radio) {  
 }
 // One wave per column (cpw of them in turn when there are more columns than the chip has wave slots).  64 descriptors per
 // step, one per lane: the lists of up to CC_SHORT partners are laid end to end as addresses in the wave's `src` (a prefix
-// sum over the lanes says where), then read back 256 at a time -- four independent gathers per lane in flight -- into the
-// wave's table (row -> count); a longer list is walked by the whole wave.  A row that is in the table already costs one
+// sum over the lanes says where; CC_SRC addresses at a time), then read back 256 at a time -- four independent gathers per
+// lane in flight -- into the wave's table (row -> count); a longer list is walked by the whole wave.  A row that is in the table already costs one
 // plain read and one add; a first sight takes the compare-and-swap and notes its slot, so that reading the table out (and
 // clearing it) walks the distinct partners, not the slots: through the size filter into a staging list.  Staged edges are
 // appended with ONE global atomic per workgroup (atomics on the one list counter are what the chip serialises: ~13 ns each).
 // A column with more than CC_LIGHT_MAX distinct partners goes on the heavy list (join_colcount_heavy_kernel).
-constexpr int CC_WAVES = 4, CC_SLOTS = 1024, CC_STAGE = 64, CC_DEPTH = 4, CC_SHORT = 8, CC_LIGHT_MAX = 640;
+constexpr int CC_WAVES = 4, CC_SLOTS = 1024, CC_STAGE = 64, CC_DEPTH = 4, CC_SHORT = 64, CC_SRC = 1024, CC_LIGHT_MAX = 640;
 __global__ __launch_bounds__(64 * CC_WAVES) void join_colcount_kernel(const uint32_t* __restrict__ vs, const uint2* __restrict__ desc,
                                                                      const uint64_t* __restrict__ off, const unsigned long long* __restrict__ colcnt,
                                                                      uint32_t g0, uint32_t c_lo, uint32_t c_hi, uint32_t cpw,
                                                                      const uint32_t* __restrict__ len, int radio, rtc_cedge* __restrict__ edges,
                                                                      unsigned long long cap, unsigned long long* __restrict__ count,
                                                                      uint32_t* __restrict__ heavy, uint32_t* __restrict__ heavy_n) {
-  __shared__ uint32_t s_key[CC_WAVES][CC_SLOTS], s_cnt[CC_WAVES][CC_SLOTS], s_src[CC_WAVES][64 * CC_SHORT];
+  __shared__ uint32_t s_key[CC_WAVES][CC_SLOTS], s_cnt[CC_WAVES][CC_SLOTS], s_src[CC_WAVES][CC_SRC];
   __shared__ uint16_t s_seen[CC_WAVES][CC_SLOTS];
   __shared__ rtc_cedge s_stage[CC_WAVES][CC_STAGE];
   __shared__ uint32_t s_nst[CC_WAVES];
@@ -371,13 +371,19 @@ __global__ __launch_bounds__(64 * CC_WAVES) void join_colcount_kernel(const uint
       for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)pos, sft); if ((int)lane >= sft) pos += o; }
       const uint32_t total = (uint32_t)__shfl((int)pos, 63);
       pos -= ns;
-      for (uint32_t t = 0; t < ns; t++) src[pos + t] = de.x + t;
-      for (uint32_t i0 = 0; i0 < total && distinct <= (uint32_t)CC_LIGHT_MAX; i0 += 64 * CC_DEPTH) {
-        uint32_t r[CC_DEPTH];
+      // CC_SRC addresses at a time (one window is all of it unless the lists are long: 64 lists of up to 64)
+      for (uint32_t w0 = 0; w0 < total && distinct <= (uint32_t)CC_LIGHT_MAX; w0 += (uint32_t)CC_SRC) {
+        const uint32_t t0 = pos < w0 ? w0 - pos : 0u;
+        const uint32_t t1 = min(ns, w0 + (uint32_t)CC_SRC > pos ? w0 + (uint32_t)CC_SRC - pos : 0u);
+        for (uint32_t t = t0; t < t1; t++) src[pos + t - w0] = de.x + t;
+        const uint32_t wn = min((uint32_t)CC_SRC, total - w0);
+        for (uint32_t i0 = 0; i0 < wn && distinct <= (uint32_t)CC_LIGHT_MAX; i0 += 64 * CC_DEPTH) {
+          uint32_t r[CC_DEPTH];
 #pragma unroll
-        for (int k = 0; k < CC_DEPTH; k++) { const uint32_t i = i0 + 64 * k + lane; r[k] = i < total ? vs[src[i]] : CC_EMPTY; }
+          for (int k = 0; k < CC_DEPTH; k++) { const uint32_t i = i0 + 64 * k + lane; r[k] = i < wn ? vs[src[i]] : CC_EMPTY; }
 #pragma unroll
-        for (int k = 0; k < CC_DEPTH; k++) insert(r[k]);
+          for (int k = 0; k < CC_DEPTH; k++) insert(r[k]);
+        }
       }
       // the longer lists, by the whole wave
       uint64_t big = __ballot(de.y > (uint32_t)CC_SHORT);
@@ -502,6 +508,10 @@ __global__ __launch_bounds__(256) void join_colcount_heavy_kernel(const uint32_t
 }
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+// co-occurrences per second through the column kernel, the cost rule's figure: families of 40 .. 1 000 among 10 000 sketches
+// (4.7e7 .. 1.1e9 co-occurrences) leave 0.85e11 .. 1.36e11 after the K-proportional part (tools/ab_join_families.sh,
+// profiles/r05_join_column_tail_ab.txt)
+constexpr double JOIN_E_RATE = 1.0e11;
 
 
 template <typename T>
@@ -615,8 +625,9 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
 
   // ---- cost rule, first half: the sort alone against the tiled kernel's probes ----
   // tiled: every column of a 1024-column block probes the table of every 64-row block below the diagonal with all
-  // of its hashes, ~4.0e11 probes/s (round 4's kernel, planning included); join: ~1.1e10 (u64) / 2.8e10 (u32) sorted keys/s, ~1.5e10 co-occurrences/s
-  // (radix sort on 2*bits bits + encode + emit), measured on MI355X (tools/ubench/sort_rates.hip).
+  // of its hashes, ~4.0e11 probes/s (round 4's kernel, planning included); join: ~1.1e10 (u64) / 2.8e10 (u32) sorted keys/s
+  // (tools/ubench/sort_rates.hip; the count and the column kernel's per-list work are in that figure), 1.0e11 co-occurrences/s through
+  // the column kernel (the sort + encode + emit of rounds 3-4 ran at 1.5e10), measured on MI355X.
   const double avg = (double)K_all / ng;
   const double rows = (double)(row1 - row0);
   const double cols_mean = std::max(1.0, 0.5 * ((double)std::min(col1, row0) + (double)std::min(col1, row1 - 1)) - (double)col0);
@@ -624,10 +635,10 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   const double t_sort = (double)K / (sizeof(T) == 8 ? 1.1e10 : 2.8e10);
   if (mode == 1 && t_sort > 0.7 * t_tiled) return RTC_OK;
   if (sampled) {
-    // the sample's verdict, with a margin of 1.5 for its noise (what it lets through is still counted exactly below):
+    // the sample's verdict, with a margin of 1.1 for its noise (what it lets through is still counted exactly below):
     // the tile holds rows x cols_mean of the ng (ng - 1) / 2 pairs the sample looked at
     const double frac = std::min(1.0, rows * cols_mean / (0.5 * (double)ng * (double)(ng - 1)));
-    if (t_sort + E_sample * frac / 1.5e10 > 1.5 * t_tiled) {
+    if (t_sort + E_sample * frac / JOIN_E_RATE > 1.1 * t_tiled) {
       // How many candidate edges such a set is likely to yield, for the caller's list: genomes that share a hash come in
       // groups about as large as the posting list a sampled hash sees (Sum c^2 / Sum c), and a group of g yields g (g - 1) / 2
       // pairs.  1.5 x that, never more than the tile holds; a list that turns out too short is grown and the launch redone as ever.
@@ -723,19 +734,19 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     if (halfsort) RTC_HIP(ctx, hipMemcpyAsync((char*)hpin + 8, d_fix, 8, hipMemcpyDeviceToHost, s));
     RTC_HIP(ctx, hipStreamSynchronize(s));
     E = *(const uint64_t*)hpin;
-    if (ctx->opt.join_debug) fprintf(stderr, "[join] K=%u attempt=%d halfsort=%d E=%llu inversions=%u giveup=%u\n", K, attempt, (int)halfsort,
-                                          (unsigned long long)E, halfsort ? ((const uint32_t*)hpin)[2] : 0u, halfsort ? ((const uint32_t*)hpin)[3] : 0u);
+    if (ctx->opt.join_debug) fprintf(stderr, "[join] K=%u attempt=%d halfsort=%d E=%llu (sample: %.3g) inversions=%u giveup=%u t_sort=%.3g t_tiled=%.3g ms\n", K, attempt, (int)halfsort,
+                                          (unsigned long long)E, E_sample, halfsort ? ((const uint32_t*)hpin)[2] : 0u, halfsort ? ((const uint32_t*)hpin)[3] : 0u, t_sort * 1e3, t_tiled * 1e3);
     if (halfsort && ((const uint32_t*)hpin)[3]) {  // not repaired: sort on all bits -- unless the (approximate) count
       // of the unrepaired lists already says the input is dense: then the tiled kernel runs, without a second sort
-      if (E >= (1ull << 31) || (mode == 1 && t_sort + (double)E / 1.5e10 > t_tiled)) { note_dense(); return RTC_OK; }
+      if (E >= (1ull << 31) || (mode == 1 && t_sort + (double)E / JOIN_E_RATE > t_tiled)) { note_dense(); return RTC_OK; }  // (a second sort is still to come)
       continue;
     }
     break;
   }
   if (E == 0) { *handled = 1; return RTC_OK; }  // no two genomes of the tile share a hash: no candidates
   if (E >= (1ull << 31)) { note_dense(); return RTC_OK; }
-  // ---- cost rule, second half ----
-  if (mode == 1 && t_sort + (double)E / 1.5e10 > t_tiled) { note_dense(); return RTC_OK; }
+  // ---- cost rule, second half: the sort and the count are paid for; what is still to come against the tiled kernel ----
+  if (mode == 1 && (double)E / JOIN_E_RATE > t_tiled) { note_dense(); return RTC_OK; }
 
   // ---- 4. the column-centric tail ----
   RTC_HIP(ctx, hipMemsetAsync(d_heavy, 0, 4, s));
