@@ -254,34 +254,44 @@ constexpr unsigned long long CC_PMASK = (1ULL << CC_ESHIFT) - 1ULL;
 constexpr int CC_CSTRIDE = 1;  // counters, in 8-byte words, from one column to the next (a 64-byte line each was measured: the count kernel 145 -> 234 us)
 template <typename T>
 __global__ __launch_bounds__(256) void join_count_kernel(const T* __restrict__ ks, const uint32_t* __restrict__ vs, uint32_t K,
-                                                         uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, uint32_t g0,
+                                                         uint32_t row0, uint32_t col0, uint32_t col1, uint32_t g0,
                                                          const uint64_t* __restrict__ off, unsigned long long* __restrict__ colcnt,
                                                          uint2* __restrict__ desc) {
-  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= K) return;
-  const T key = ks[a];
-  if (a + 1 < K && ks[a + 1] == key) {
-    const uint32_t g = vs[a];
-    if (g >= col0 && g < col1) {
-      // gallop to the end of the posting list: largest ge with ks[ge - 1] == key
-      uint32_t step = 1, known = a + 1;  // ks[known] == key
-      while (known + step < K && ks[known + step] == key) { known += step; step <<= 1; }
-      uint32_t hi_ex = min(K, known + step);  // ks[hi_ex] != key (or K)
-      uint32_t l = known + 1, h = hi_ex;
-      while (l < h) { const uint32_t m = (l + h) >> 1; if (ks[m] == key) l = m + 1; else h = m; }
-      const uint32_t ge = l;
-      // genomes ascend in [a + 1, ge): the rows of the tile are a contiguous part of it
-      uint32_t p = a + 1, q = ge;
-      while (p < q) { const uint32_t m = (p + q) >> 1; if (vs[m] < row0) p = m + 1; else q = m; }
-      const uint32_t lo = p;
-      q = ge;
-      while (p < q) { const uint32_t m = (p + q) >> 1; if (vs[m] < row1) p = m + 1; else q = m; }
-      const uint32_t cnt = p - lo;
-      if (cnt) {
-        const unsigned long long was = atomicAdd(colcnt + (size_t)(g - g0) * CC_CSTRIDE, (1ULL << CC_ESHIFT) | (unsigned long long)cnt);
-        desc[off[g - g0] + (was >> CC_ESHIFT)] = make_uint2(lo, cnt);
-      }
-    }
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;  // (whole waves stay: the vote below)
+  const uint32_t lane = threadIdx.x & 63;
+  const bool in = a < K;
+  const T key = in ? ks[a] : (T)0;
+  const bool same_next = in && a + 1 < K && ks[a + 1] == key;
+  // Where the posting lists end inside this wave: no loads for a list that does (nearly all of them: lists are a few to a few
+  // dozen elements, a wave holds 64).  One that runs past the wave's last element is followed from there.
+  const uint64_t ends = __ballot(!same_next);
+  if (!same_next) return;
+  const uint32_t g = vs[a];
+  if (g < col0 || g >= col1) return;
+  uint32_t ge;  // one past the list's last element
+  const uint64_t m = ends >> lane;
+  if (m) ge = a + (uint32_t)__builtin_ctzll(m) + 1;
+  else {
+    // gallop from the first element behind the wave (it holds the key: the wave's last lane said "same"): largest ge with
+    // ks[ge - 1] == key
+    uint32_t step = 1, known = a - lane + 64;
+    while (known + step < K && ks[known + step] == key) { known += step; step <<= 1; }
+    uint32_t hi_ex = min(K, known + step);  // ks[hi_ex] != key (or K)
+    uint32_t l = known + 1, h = hi_ex;
+    while (l < h) { const uint32_t mid = (l + h) >> 1; if (ks[mid] == key) l = mid + 1; else h = mid; }
+    ge = l;
+  }
+  // genomes ascend in (a, ge) and are all above g and below row1 (the flat copy ends there): only a column below row0 - 1 has
+  // to look for its first partner that is a row
+  uint32_t lo = a + 1;
+  if (row0 > g + 1) {
+    uint32_t q = ge;
+    while (lo < q) { const uint32_t mid = (lo + q) >> 1; if (vs[mid] < row0) lo = mid + 1; else q = mid; }
+  }
+  const uint32_t cnt = ge - lo;
+  if (cnt) {
+    const unsigned long long was = atomicAdd(colcnt + (size_t)(g - g0) * CC_CSTRIDE, (1ULL << CC_ESHIFT) | (unsigned long long)cnt);
+    desc[off[g - g0] + (was >> CC_ESHIFT)] = make_uint2(lo, cnt);
   }
 }
 struct ColPartners {  // the partners of column i, for the sum over the columns
@@ -724,7 +734,7 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     }
     RTC_HIP(ctx, hipMemsetAsync(d_colcnt, 0, (size_t)ng * CC_CSTRIDE * 8, s));
     hipLaunchKernelGGL(join_count_kernel<T>, dim3((K + 255) / 256), dim3(256), 0, s, (const T*)keys1, (const uint32_t*)vals1, K,
-                       row0, row1, col0, col1, g0, (const uint64_t*)d_off, (unsigned long long*)d_colcnt, d_desc);
+                       row0, col0, col1, g0, (const uint64_t*)d_off, (unsigned long long*)d_colcnt, d_desc);
     RTC_CHECK_LAUNCH(ctx);
     {
       auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0), ColPartners{(const unsigned long long*)d_colcnt});
