@@ -439,33 +439,47 @@ __global__ __launch_bounds__(64 * CC_WAVES) void join_colcount_kernel(const uint
   for (uint32_t w = 0; w < wave; w++) base += s_nst[w];
   for (uint32_t i = lane; i < nst; i += 64) if (base + i < cap) edges[base + i] = stage[i];
 }
-// The heavy list: one 256-lane workgroup per column and a counter per ROW id, CC_HW ids at a time (the 64 KB a workgroup
-// may declare): the column's partner lists are walked once per occupied id range (a first walk marks which ranges hold
-// any).  Any number of distinct partners; nothing is hashed.  Short lists by a lane each, longer ones by a wave.
-constexpr uint32_t CC_HW = 16384 - 64;
+// The heavy list: one 256-lane workgroup per column over the 64 KB a workgroup may declare.  First as ONE hash table row ->
+// count of 8 192 slots for the whole workgroup (a column of a very large set has hundreds to thousands of chance partners
+// spread over all the row ids): one walk over the column's partner lists, good for up to ~6 000 distinct partners (each
+// wave stops at a quarter of that, so the probes always end).  Beyond that a counter per ROW id, CC_HW ids at a time: the
+// lists are walked once per occupied id range (a first walk marks which ranges hold any) -- any number of distinct
+// partners, nothing hashed.  Short lists by a lane each, longer ones by a wave.
+constexpr uint32_t CC_HW = 16384 - 64, CC_HSLOTS = 8192, CC_HWAVE_MAX = 1536;
 __global__ __launch_bounds__(256) void join_colcount_heavy_kernel(const uint32_t* __restrict__ vs, const uint2* __restrict__ desc,
                                                                   const uint64_t* __restrict__ off, const unsigned long long* __restrict__ colcnt,
                                                                   uint32_t g0, uint32_t row0, uint32_t row1, const uint32_t* __restrict__ len,
                                                                   int radio, rtc_cedge* __restrict__ edges, unsigned long long cap,
                                                                   unsigned long long* __restrict__ count, const uint32_t* __restrict__ heavy,
                                                                   const uint32_t* __restrict__ heavy_n) {
-  __shared__ uint32_t cnt[CC_HW];
-  __shared__ uint32_t s_occ[64];  // bit p of word w: id range 32 w + p holds a partner (ranges past 2 048 share the last bit)
+  __shared__ uint32_t lds[16384];
+  uint32_t* hkey = lds;              // hash table form: keys and counts
+  uint32_t* hcnt = lds + CC_HSLOTS;
+  uint32_t* cnt = lds;               // id-range form: CC_HW counters and the occupancy bits
+  uint32_t* s_occ = lds + CC_HW;     // bit p of word w: id range 32 w + p holds a partner (ranges past 2 048 share the last bit)
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t nh = *heavy_n;
-  // f(id) for every partner id of the column
-  auto walk = [&](const uint2* d, uint32_t ne, auto&& f) {
+  // f(id) for every partner id of the column; step() by the whole wave after every id per lane
+  auto walk = [&](const uint2* d, uint32_t ne, auto&& f, auto&& step) {
     for (uint32_t e0 = 0; e0 < ne; e0 += 256) {  // (uniform trip count)
       const uint32_t e = e0 + threadIdx.x;
       const uint2 de = e < ne ? d[e] : make_uint2(0, 0);
-      if (de.y <= (uint32_t)CC_SHORT)
-        for (uint32_t t = 0; t < de.y; t++) f(vs[de.x + t]);
+      const uint32_t ns = de.y <= (uint32_t)CC_SHORT ? de.y : 0;
+      uint32_t nmax = ns;  // the wave's longest short list
+      for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, o));
+      for (uint32_t t = 0; t < nmax; t++) {  // (wave-uniform)
+        if (t < ns) f(vs[de.x + t]);
+        step();
+      }
       uint64_t big = __ballot(de.y > (uint32_t)CC_SHORT);
       while (big) {  // (wave-uniform)
         const int sl = __builtin_ctzll(big);
         big &= big - 1ULL;
         const uint32_t lo = (uint32_t)__shfl((int)de.x, sl), n = (uint32_t)__shfl((int)de.y, sl);
-        for (uint32_t i = lane; i < n; i += 64) f(vs[lo + i]);
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {  // (wave-uniform)
+          if (i0 + lane < n) f(vs[lo + i0 + lane]);
+          step();
+        }
       }
     }
   };
@@ -473,6 +487,47 @@ __global__ __launch_bounds__(256) void join_colcount_heavy_kernel(const uint32_t
     const uint32_t c = heavy[h];
     const uint32_t ne = (uint32_t)(colcnt[(size_t)(c - g0) * CC_CSTRIDE] >> CC_ESHIFT);
     const uint2* d = desc + off[c - g0];
+    const uint32_t s1 = len[c];
+    // ---- the hash table form ----
+    for (uint32_t i = threadIdx.x; i < CC_HSLOTS; i += 256) { hkey[i] = CC_EMPTY; hcnt[i] = 0; }
+    __syncthreads();
+    uint32_t wave_fresh = 0, lane_fresh = 0;  // first sights by this wave (uniform) / by this lane since the last step
+    walk(d, ne, [&](uint32_t id) {
+      if (wave_fresh > CC_HWAVE_MAX) return;  // given up: the id-range form below starts over
+      uint32_t at = cc_slot(id, CC_HSLOTS - 1);
+      bool fresh = false;
+      for (;;) {  // ends: the four waves together take at most 4 (CC_HWAVE_MAX + 64) of the 8 192 slots
+        uint32_t o = hkey[at];
+        if (o == CC_EMPTY) { o = atomicCAS(&hkey[at], CC_EMPTY, id); fresh = o == CC_EMPTY; }
+        if (o == id || fresh) break;
+        at = (at + 1) & (CC_HSLOTS - 1);
+      }
+      atomicAdd(&hcnt[at], 1u);
+      lane_fresh += fresh;
+    }, [&]() {  // after every id per lane: the wave's first sights so far
+      wave_fresh += (uint32_t)__popcll(__ballot(lane_fresh != 0));
+      lane_fresh = 0;
+    });
+    if (!__syncthreads_or(wave_fresh > CC_HWAVE_MAX)) {
+      for (uint32_t i0 = 0; i0 < CC_HSLOTS; i0 += 256) {  // (uniform trip count)
+        const uint32_t r = hkey[i0 + threadIdx.x];
+        const bool keep = r != CC_EMPTY && (radio < 0 || cc_keep(len[r], s1, radio));
+        const uint64_t m = __ballot(keep);
+        if (m) {
+          const int lead = __builtin_ctzll(m);
+          unsigned long long at = 0;
+          if ((int)lane == lead) at = atomicAdd(count, (unsigned long long)__popcll(m));
+          at = ((unsigned long long)(uint32_t)__shfl((int)(at >> 32), lead) << 32) | (uint32_t)__shfl((int)(uint32_t)at, lead);
+          if (keep) {
+            const unsigned long long idx = at + __popcll(m & ((1ULL << lane) - 1ULL));
+            if (idx < cap) edges[idx] = rtc_cedge{r, c, hcnt[i0 + threadIdx.x]};
+          }
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    // ---- the id-range form ----
     const uint32_t rlo = max(c + 1, row0);  // a partner's id is above its column's
     const uint32_t npass = (row1 - rlo + CC_HW - 1) / CC_HW;
     if (threadIdx.x < 64) s_occ[threadIdx.x] = 0;
@@ -480,9 +535,8 @@ __global__ __launch_bounds__(256) void join_colcount_heavy_kernel(const uint32_t
     walk(d, ne, [&](uint32_t id) {
       const uint32_t p = min((id - rlo) / CC_HW, 2047u);
       atomicOr(&s_occ[p >> 5], 1u << (p & 31));
-    });
+    }, [] {});
     __syncthreads();
-    const uint32_t s1 = len[c];
     for (uint32_t p = 0; p < npass; p++) {
       const uint32_t pb = min(p, 2047u);
       if (!((s_occ[pb >> 5] >> (pb & 31)) & 1u)) continue;  // (uniform)
@@ -492,7 +546,7 @@ __global__ __launch_bounds__(256) void join_colcount_heavy_kernel(const uint32_t
       walk(d, ne, [&](uint32_t id) {
         const uint32_t dd = id - base;  // (below base: wraps past CC_HW)
         if (dd < CC_HW) atomicAdd(&cnt[dd], 1u);
-      });
+      }, [] {});
       __syncthreads();
       for (uint32_t i0 = 0; i0 < CC_HW; i0 += 256) {  // (uniform trip count)
         const uint32_t i = i0 + threadIdx.x;
