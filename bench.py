@@ -881,7 +881,7 @@ def main():
         sk_kernel = (("sketch_minhash_packed_kernel" if packed else "sketch_minhash_kernel") if mode == "minhash" else
                      "sketch_kssd_packed_kernel" if packed else "sketch_kssd_bloom_kernel")
         sk_traffic, sk_src = measured_traffic(sk_kernel, wl)
-        # the pair phase's device path: 3 = inverted join (rocPRIM radix sorts + the join kernels), 2 = tiled kernel
+        # the pair phase's device path: 3 = inverted join (one rocPRIM radix sort + the join kernels), 2 = tiled kernel
         pair_path = int(round(ph.get("pair_path", 2.0)))
         pr_kernel = "pair_join_phase" if pair_path == 3 else "pair_tiled_kernel"
         pr_traffic, pr_src = measured_traffic(pr_kernel, wl)
@@ -889,7 +889,7 @@ def main():
         if pair_path == 3:
             dist_algo = hashes_local * world * (width + 4) / (ph["pair_ms"] * 1e-3) / 1e9  # every (hash, genome) once
             dist_note = ("pair phase = inverted join (rtc_pairs_join.hip): achieved/frac = PMC-measured HBM bytes of all kernels "
-                         "of the phase (profiles/%s: 'pair_join_phase' = the rocPRIM sort / scan / encode kernels + join_*) / "
+                         "of the phase (profiles/%s: 'pair_join_phase' = the library's rocPRIM sort / scan / reduce kernels + join_*) / "
                          "pair-phase time; algorithmic_* = (hash, genome) records read once = %d B per hash / time -- the "
                          "radix passes move each record several times; survey_8d_* = %s x the pairs of the tile / pair-phase time: "
                          "far above the peak because the join never touches a pair that shares no hash -- a data-dependent figure, "
