@@ -186,7 +186,7 @@ int rtc_extract_edges_dev(rtc_ctx* ctx, const uint32_t* d_common, uint64_t ld, u
  * directly -- no dense matrix is written.  radio < 0 disables the size-ratio test (greedy
  * clustering filters on the host).  d_count as above.  Two device paths with identical results:
  * the inverted join (the reference's index, src/MST.cpp:1408-1435, as a device sort of
- * (hash, genome) + posting-list pair emission + run-length encoding; cost ~ hashes +
+ * (hash, genome) + a count of every column's partner lists in on-chip tables; cost ~ hashes +
  * co-occurrences) where the tile is sparse enough for it to win, otherwise the tiled kernel
  * (cost ~ rows x cols x s / 64, independent of the data).  RTC_PAIR_JOIN=0 in the environment
  * disables the join, =2 takes it wherever its scratch fits.

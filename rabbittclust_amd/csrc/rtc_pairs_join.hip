@@ -5,18 +5,19 @@
 // GPU: the index is a sort.
 //   1. flatten   every hash of the genomes [g0, g1) with its genome id            (one streaming pass)
 //   2. sort      (hash, genome) by hash -- stable, so genomes ascend inside a posting list   (radix sort)
-//   3. count     element a of a posting list pairs with the later elements of the list whose genome is a
-//                row of the tile; the list end is found by galloping on the sorted hashes
-//   4. emit      one 64-bit code (row << bits | col) per co-occurrence
-//   5. sort      the codes on their 2*bits significant bits                        (radix sort)
-//   6. encode    run lengths of equal codes = |A_row ∩ A_col|                      (run-length encode)
-//   7. filter    the reference's candidate filters (src/MST.cpp:1468-1487) -> (i, j, common) triples
+//   3. count     element a of a posting list pairs with the later elements of the list whose genome is a row of the
+//                tile: its partners, a contiguous part of the sorted list; a descriptor (first partner, partners) per
+//                element that has any, kept in its column genome's part of a flat array
+//   4. columns   a wave per column genome counts the column's partner lists in an LDS table row -> count:
+//                the counts are |A_row ∩ A_col|; the reference's candidate filters (src/MST.cpp:1468-1487) ->
+//                (i, j, common) triples
+// (until round 5 steps 4-7 wrote one code (row << bits | col) per co-occurrence, sorted the codes and run-length-encoded them)
 // Results are the integers the tiled kernel (rtc_pairs_tiled.hip) produces for the same tile, pair for pair;
 // the cost is O(hashes + co-occurrences) instead of O(rows * cols * s / 64).  The tiled kernel stays the
-// general path: it is taken when the co-occurrence count (known exactly after step 3) would make the join the
-// slower of the two (many near-identical genomes: posting lists of thousands), when the scratch would not fit,
-// and by callers that hold a tiled plan across launches.  Sorting, scanning and run-length encoding are
-// rocPRIM device primitives; the kernels around them are below.
+// general path: it is taken when the co-occurrence count (estimated from a sample before the sort, known exactly after
+// step 3) would make the join the slower of the two (many near-identical genomes: posting lists of thousands), when the
+// scratch would not fit, and by callers that hold a tiled plan across launches.  The sort, the offset scan and the
+// reduction are rocPRIM device primitives; the kernels around them are below.
 #include <cstring>
 
 #include <hip/hip_runtime.h>
