@@ -272,6 +272,25 @@ def test_join_u64_hashes_that_share_their_upper_half(ctx, oracle, prefixes):
         _reload_options()
 
 
+def test_cost_rule_takes_the_join_for_families_of_forty_and_the_tiled_kernel_for_families_of_four_hundred(ctx):
+    """The rule that picks the pair phase's path (RTC_PAIR_JOIN unset): 10 000 MinHash sketches of 1 000 hashes in families of
+    40 near relatives go through the inverted join (its column kernel counts ~1e11 co-occurrences a second: 1.3 ms against
+    the tiled kernel's 1.9), families of 400 through the tiled kernel (refused by the density sample, before any sort);
+    either way the edges are the other path's."""
+    from rabbittclust_amd import api
+    L = 100_000
+    for fam, path in ((40, 3), (400, 2)):
+        desc = api.synth_family_descs(10000 // fam, fam, global_seed=7)
+        off = np.arange(len(desc) + 1, dtype=np.uint64) * np.uint64(L)
+        sk = ctx.sketch_minhash(ctx.synth_genomes(desc, off), off, k=21, size=1000)
+        n = sk.n
+        got = _edges(ctx, sk, 1, n, 0, n - 1, 4, mode=1, cap=1 << 25)
+        assert ctx.pair_last_path() == path, (fam, ctx.pair_last_path())
+        other = _edges(ctx, sk, 1, n, 0, n - 1, 4, mode=0 if path == 3 else 2, cap=1 << 25)
+        assert ctx.pair_last_path() == (2 if path == 3 else 3)
+        assert np.array_equal(got, other), fam
+
+
 @pytest.mark.parametrize("seed", list(range(1, int(os.environ.get("RTC_SOAK_SEEDS", "3")) + 1)))
 def test_join_equals_tiled_on_mid_scale_random_families(ctx, seed):
     """A few thousand to thirty thousand small sketches in families of random size (1 .. 1 500 members: partner lists from one to

@@ -1,4 +1,6 @@
 #!/bin/bash
+# The pair phase of bench.py over family sizes (FAMS="10 40 ..."), by the cost rule (RTC_PAIR_JOIN=1), tiled kernel only (0), join forced (2):
+# which path the rule picks against what either path costs.  Usage (on the GPU box): bash tools/ab_join_families.sh <outdir under gpurun_out>
 cd $GRAFT_REPO_ROOT; O=gpurun_out/$1; mkdir -p $O
 for fam in ${FAMS:-10 16 20 25 40}; do
  for pj in 1 0 2; do
