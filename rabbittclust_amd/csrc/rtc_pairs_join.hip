@@ -306,16 +306,18 @@ __device__ __forceinline__ bool cc_keep(uint32_t s0, uint32_t s1, int radio) {  
   const uint32_t mn = s0 < s1 ? s0 : s1, mx = s0 > s1 ? s0 : s1;
   return (uint64_t)mx <= (uint64_t)(uint32_t)radio * (uint64_t)mn;
 }
-// One wave per column (cpw of them in turn when there are more columns than the chip has wave slots).  128 descriptors per
-// step, two per lane: the lists of up to CC_SHORT partners are laid end to end as addresses in the wave's `src` (a prefix
-// sum over the lanes says where; CC_SRC addresses at a time), then read back 512 at a time -- eight independent gathers per
-// lane in flight (four, from 64 descriptors a step: pair phase 0.98-1.00 instead of 0.95-0.97 ms) -- into the wave's table
-// (row -> count); a longer list is walked by the whole wave.  A row that is in the table already costs one
+// One wave per column (cpw of them in turn when there are more columns than the chip has wave slots).  256 descriptors per
+// step, CC_DPL = four per lane: the lists of up to CC_SHORT partners are laid end to end as addresses in the wave's `src` (a
+// prefix sum over the lanes says where; CC_SRC addresses at a time), then read back 1 024 at a time -- sixteen independent
+// gathers per lane in flight (pair phase of the headline with 4 / 8 / 16 of them, from 64 / 128 / 256 descriptors a step:
+// 0.98-1.00 / 0.97 / 0.95-0.96 ms; the kernel waits on memory, not on the table) -- into the wave's table (row -> count);
+// a longer list is walked by the whole wave.  A row that is in the table already costs one
 // plain read and one add; a first sight takes the compare-and-swap and notes its slot, so that reading the table out (and
 // clearing it) walks the distinct partners, not the slots: through the size filter into a staging list.  Staged edges are
 // appended with ONE global atomic per workgroup (atomics on the one list counter are what the chip serialises: ~13 ns each).
 // A column with more than CC_LIGHT_MAX distinct partners goes on the heavy list (join_colcount_heavy_kernel).
-constexpr int CC_WAVES = 4, CC_SLOTS = 1024, CC_STAGE = 64, CC_DEPTH = 8, CC_SHORT = 64, CC_SRC = 1024, CC_LIGHT_MAX = 640;
+constexpr int CC_WAVES = 4, CC_SLOTS = 1024, CC_STAGE = 64, CC_DPL = 4, CC_DEPTH = 16, CC_SHORT = 64, CC_SRC = 1024, CC_LIGHT_MAX = 640;
+static_assert(CC_DEPTH % 4 == 0 && CC_LIGHT_MAX + 256 + 64 <= CC_SLOTS, "the table's margin");
 __global__ __launch_bounds__(64 * CC_WAVES) void join_colcount_kernel(const uint32_t* __restrict__ vs, const uint2* __restrict__ desc,
                                                                      const uint64_t* __restrict__ off, const unsigned long long* __restrict__ colcnt,
                                                                      uint32_t g0, uint32_t c_lo, uint32_t c_hi, uint32_t cpw,
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(64 * CC_WAVES) void join_colcount_kernel(const uint
       uint32_t at = 0;
       if (r != CC_EMPTY) {
         at = cc_slot(r, mask);
-        for (;;) {  // ends: at most CC_LIGHT_MAX + 32 CC_DEPTH of the 1 024 slots are ever taken
+        for (;;) {  // ends: at most CC_LIGHT_MAX + 256 of the 1 024 slots are ever taken
           uint32_t o = key[at];
           if (o == CC_EMPTY) { o = atomicCAS(&key[at], CC_EMPTY, r); fresh = o == CC_EMPTY; }
           if (o == r || fresh) break;
@@ -372,29 +374,33 @@ __global__ __launch_bounds__(64 * CC_WAVES) void join_colcount_kernel(const uint
       if (fresh) seen[distinct + (uint32_t)__popcll(fm & ((1ULL << lane) - 1ULL))] = (uint16_t)at;
       distinct += (uint32_t)__popcll(fm);
     };
-    uint2 dn0 = lane < ne ? d[lane] : make_uint2(0, 0), dn1 = 64 + lane < ne ? d[64 + lane] : make_uint2(0, 0);
-    for (uint32_t e0 = 0; e0 < ne && distinct <= (uint32_t)CC_LIGHT_MAX; e0 += 128) {
-      const uint2 da = dn0, db = dn1;
-      dn0 = e0 + 128 + lane < ne ? d[e0 + 128 + lane] : make_uint2(0, 0);  // the next step's descriptors are on their way
-      dn1 = e0 + 192 + lane < ne ? d[e0 + 192 + lane] : make_uint2(0, 0);
-      // the short lists end to end
-      const uint32_t nsa = da.y <= (uint32_t)CC_SHORT ? da.y : 0, nsb = db.y <= (uint32_t)CC_SHORT ? db.y : 0;
-      uint32_t pos = nsa + nsb;  // inclusive prefix sum over the lanes
+    uint2 dn[CC_DPL];
 #pragma unroll
-      for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)pos, sft); if ((int)lane >= sft) pos += o; }
-      const uint32_t total = (uint32_t)__shfl((int)pos, 63);
-      pos -= nsa + nsb;
-      const uint32_t posb = pos + nsa;
+    for (int j = 0; j < CC_DPL; j++) dn[j] = 64 * j + lane < ne ? d[64 * j + lane] : make_uint2(0, 0);
+    for (uint32_t e0 = 0; e0 < ne && distinct <= (uint32_t)CC_LIGHT_MAX; e0 += 64 * CC_DPL) {
+      uint2 de[CC_DPL];
+      uint32_t ns[CC_DPL], pos[CC_DPL];
+      uint32_t mine = 0;
+#pragma unroll
+      for (int j = 0; j < CC_DPL; j++) {
+        de[j] = dn[j];
+        dn[j] = e0 + 64 * (CC_DPL + j) + lane < ne ? d[e0 + 64 * (CC_DPL + j) + lane] : make_uint2(0, 0);  // the next step's descriptors are on their way
+        ns[j] = de[j].y <= (uint32_t)CC_SHORT ? de[j].y : 0;  // the short lists end to end
+        mine += ns[j];
+      }
+      uint32_t incl = mine;  // inclusive prefix sum over the lanes
+#pragma unroll
+      for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, sft); if ((int)lane >= sft) incl += o; }
+      const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+      pos[0] = incl - mine;
+#pragma unroll
+      for (int j = 1; j < CC_DPL; j++) pos[j] = pos[j - 1] + ns[j - 1];
       for (uint32_t w0 = 0; w0 < total && distinct <= (uint32_t)CC_LIGHT_MAX; w0 += (uint32_t)CC_SRC) {
-        {
-          const uint32_t t0 = pos < w0 ? w0 - pos : 0u;
-          const uint32_t t1 = min(nsa, w0 + (uint32_t)CC_SRC > pos ? w0 + (uint32_t)CC_SRC - pos : 0u);
-          for (uint32_t t = t0; t < t1; t++) src[pos + t - w0] = da.x + t;
-        }
-        {
-          const uint32_t t0 = posb < w0 ? w0 - posb : 0u;
-          const uint32_t t1 = min(nsb, w0 + (uint32_t)CC_SRC > posb ? w0 + (uint32_t)CC_SRC - posb : 0u);
-          for (uint32_t t = t0; t < t1; t++) src[posb + t - w0] = db.x + t;
+#pragma unroll
+        for (int j = 0; j < CC_DPL; j++) {
+          const uint32_t t0 = pos[j] < w0 ? w0 - pos[j] : 0u;
+          const uint32_t t1 = min(ns[j], w0 + (uint32_t)CC_SRC > pos[j] ? w0 + (uint32_t)CC_SRC - pos[j] : 0u);
+          for (uint32_t t = t0; t < t1; t++) src[pos[j] + t - w0] = de[j].x + t;
         }
         const uint32_t wn = min((uint32_t)CC_SRC, total - w0);
         for (uint32_t i0 = 0; i0 < wn && distinct <= (uint32_t)CC_LIGHT_MAX; i0 += 64 * CC_DEPTH) {
@@ -402,21 +408,22 @@ __global__ __launch_bounds__(64 * CC_WAVES) void join_colcount_kernel(const uint
 #pragma unroll
           for (int k = 0; k < CC_DEPTH; k++) { const uint32_t i = i0 + 64 * k + lane; r[k] = i < wn ? vs[src[i]] : CC_EMPTY; }
 #pragma unroll
-          for (int k = 0; k < CC_DEPTH / 2; k++) insert(r[k]);
-          if (distinct <= (uint32_t)CC_LIGHT_MAX) {  // (the table's margin is 64 CC_DEPTH / 2 first sights between two looks)
+          for (int k0 = 0; k0 < CC_DEPTH; k0 += 4) {  // (the table's margin is 256 first sights between two looks)
+            if (distinct <= (uint32_t)CC_LIGHT_MAX) {
 #pragma unroll
-            for (int k = CC_DEPTH / 2; k < CC_DEPTH; k++) insert(r[k]);
+              for (int k = k0; k < k0 + 4; k++) insert(r[k]);
+            }
           }
         }
       }
       // the longer lists, by the whole wave
-      for (int w = 0; w < 2; w++) {
-        const uint2 de = w ? db : da;
-        uint64_t big = __ballot(de.y > (uint32_t)CC_SHORT);
+#pragma unroll
+      for (int j = 0; j < CC_DPL; j++) {
+        uint64_t big = __ballot(de[j].y > (uint32_t)CC_SHORT);
         while (big && distinct <= (uint32_t)CC_LIGHT_MAX) {  // (wave-uniform)
           const int sl = __builtin_ctzll(big);
           big &= big - 1ULL;
-          const uint32_t lo = (uint32_t)__shfl((int)de.x, sl), n = (uint32_t)__shfl((int)de.y, sl);
+          const uint32_t lo = (uint32_t)__shfl((int)de[j].x, sl), n = (uint32_t)__shfl((int)de[j].y, sl);
           for (uint32_t i = 0; i < n && distinct <= (uint32_t)CC_LIGHT_MAX; i += 64) insert(i + lane < n ? vs[lo + i + lane] : CC_EMPTY);
         }
       }

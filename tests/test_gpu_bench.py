@@ -14,6 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_default_line_has_every_extra_without_error(ctx):
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()  # the child needs ~130 GB for the north-star extras: nothing cached by earlier tests of this process may stay
     env = {k: v for k, v in os.environ.items() if not k.startswith("RTC_PAIR")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--extra-steps", "1",
                         "--cli-genomes", "64", "--cpu-sample-genomes", "32", "--cpu-sample-sketches", "2000"],
