@@ -1,5 +1,7 @@
 #!/bin/bash
-# usage: sweep.sh outdir  (runs base + variants, headline pair_ms x2, config3, config5)
+# Same-box A/B of the pair phase: the in-tree library against every _variants/lib_<name>.so (tools/build_variant.sh) -- the headline twice
+# (bench.py --no-extra: pair_ms), then BASELINE configs 5 and 3 on one GPU (--only config5_1gpu / config3_1gpu).
+# Usage (on the GPU box): bash tools/ab_join_sweep.sh <outdir under gpurun_out>
 O=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
