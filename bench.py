@@ -2,18 +2,25 @@
 """bench.py -- sketch + all-pairs Mash distance (clust-mst hot path) on MI355X.
 
 One step = one pass of the hot path over one batch of synthetic genomes already resident in HBM:
-  sketch (MinHash k=21 s=1000, or KSSD with --mode kssd) -> [N>1: all-gather sketches over RCCL] ->
+  sketch (MinHash k=21 s=1000, or KSSD with --mode kssd) -> [N>1: gather of the sketch rows over RCCL] ->
   row-sharded N x N sorted-sketch intersection with fused candidate-edge emission -> minimum spanning
   forest (device Boruvka; N>1: one all-reduce(MIN) per round in fixed-size mode).
 
-Workloads (BASELINE.json configs; 1 000-family synthetic genomes, substitution rate U[0,0.08]):
-  --mode minhash  N=1: configs[1] = 10 000 x 5 Mbp.  N>1: 12 500 genomes per GPU, i.e. configs[2]
-                  (100 000 x 5 Mbp) at N=8; the pair space is (N*12 500)^2/2, row-sharded.
-  --mode kssd     25 000 x 2 Mbp per GPU, i.e. configs[4] (200 000 x 2 Mbp) at N=8.
+Workloads (BASELINE.json configs; 1 000-family synthetic genomes, substitution rate U[0,0.08]), the batch resident in the
+command lines' 2-bit staging format (--staging packed, north_star's "packed sequence"; --staging ascii: as characters):
+  N=1            configs[1] = 10 000 x 5 Mbp (--mode kssd: 25 000 x 2 Mbp).
+  N>1            --scaling strong (the default): configs[2] = exactly 100 000 x 5 Mbp (--mode kssd: configs[4] =
+                 200 000 x 2 Mbp) split over the N ranks -- north_star's own job at every N; its N=1 point is
+                 `config3_total_s` / `config5_total_s` of the N=1 line (`bench.py --gpus 1 --scaling strong` runs it as
+                 the headline).  --scaling weak: 12 500 (25 000) genomes per GPU, i.e. the same job only at N=8.
 
-`python bench.py --gpus N` with N > 1 and no torchrun environment re-launches itself under
-torch.distributed.run with N ranks (one per GPU, backend nccl = RCCL); `n_gpus` in the output is the
-world size the process group reports.  Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` with N > 1 and no torchrun environment re-launches itself under torch.distributed.run with N
+ranks (one per GPU, backend nccl = RCCL); `n_gpus` in the output is the world size the process group reports.
+
+Output (rank 0, stdout): the compact headline object (< 4 KB: metric, value, roofline, cpu_baseline, phase_ms and the
+scalars lifted from the extra workloads) is printed as soon as it is known, the extra workloads follow as ONE line
+{"extra": ...} (also written to bench_extra.json), and the compact headline -- now with the extras' scalars -- is
+printed again as the LAST line.  README.md ("Reading the bench line") explains every field; no prose travels in the line.
 """
 import argparse
 import json
@@ -34,7 +41,6 @@ def _profile_jsons():
 
 
 PROFILE_JSON = _profile_jsons()
-SURVEY_8D_PAIR_NOTE = ("SURVEY 8(d): algorithmic bytes of one genome pair = (|A| + |B|) * width (16 000 B at s = 1000, u64)")
 
 
 def parse():
@@ -43,30 +49,35 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mode", choices=("minhash", "kssd"), default="minhash")
-    ap.add_argument("--genomes", type=int, default=0, help="genomes per GPU (0 = the BASELINE shape for --gpus/--mode)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="strong: BASELINE configs[2] (100 000 x 5 Mbp; --mode kssd: configs[4], 200 000 x 2 Mbp) split over the ranks, "
+                         "the default for N > 1; weak: a fixed number of genomes per GPU (N = 1: configs[1], the default there)")
+    ap.add_argument("--genomes", type=int, default=0, help="weak: genomes per GPU, strong: genomes of the whole job (0 = the BASELINE shape)")
     ap.add_argument("--length", type=int, default=0, help="bases per genome (0 = 5 000 000 minhash / 2 000 000 kssd)")
     ap.add_argument("--family", type=int, default=10)
     ap.add_argument("-k", type=int, default=21)
     ap.add_argument("-s", type=int, default=1000)
     ap.add_argument("--drlevel", type=int, default=3)
     ap.add_argument("--threshold", type=float, default=0.05)
-    ap.add_argument("--staging", choices=("ascii", "packed"), default="ascii",
-                    help="the batch resident in HBM as characters (rtc_sketch_minhash_dev / rtc_sketch_kssd_dev, the library "
-                         "boundary's form and the judged line) or in the command lines' 2-bit staging format "
-                         "(rtc_sketch_minhash_packed_dev / rtc_sketch_kssd_packed_dev)")
+    ap.add_argument("--staging", choices=("ascii", "packed"), default="packed",
+                    help="the batch resident in HBM in the command lines' 2-bit staging format (rtc_sketch_minhash_packed_dev / "
+                         "rtc_sketch_kssd_packed_dev: north_star's packed sequence, what clust-mst / clust-greedy run) or as characters "
+                         "(rtc_sketch_minhash_dev / rtc_sketch_kssd_dev); the roofline stays at SURVEY 8(d)'s 1 B/base either way")
     ap.add_argument("--comm", choices=("native", "torch"), default="native",
                     help="N>1 collectives: the C ABI's own RCCL communicator (rtc_comm_*, what the C++ hosts use) "
-                         "or torch.distributed's; both are RCCL over xGMI")
+                         "or torch.distributed's; both are RCCL over xGMI (strong scaling is native only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
-                    help="N=1 only: skip the extra workloads timed after the headline region (KSSD 25 000 x 2 Mbp, "
-                         "greedy config 4, the 12 500-genome first point of the weak-scaling curve)")
+                    help="N=1 only: skip the extra workloads timed after the headline region")
     ap.add_argument("--extra-steps", type=int, default=3)
-    ap.add_argument("--only", choices=("dense_pairs", "cli", "greedy", "kssd", "kssd_packed", "minhash_packed", "config3_1gpu", "config5_1gpu", "weak_first_point"), default=None,
+    ap.add_argument("--only", choices=tuple(n for n, _ in EXTRAS), default=None,
                     help="run ONE of the extra workloads alone and print {\"extra\": {...}} (the profile collection's driver)")
     ap.add_argument("--cli-genomes", type=int, default=2048, help="extra.cli: FASTA files written to /dev/shm")
+    ap.add_argument("--cli-genomes-large", type=int, default=8192,
+                    help="extra.cli: one more MinHash run of the command line on this many genomes when /dev/shm has the room (0: skip)")
     ap.add_argument("--cpu-sample-genomes", type=int, default=0, help="0 = 1024 (SURVEY 8d: >= 1k genomes)")
     ap.add_argument("--cpu-sample-sketches", type=int, default=8000)
+    ap.add_argument("--extra-json", default=os.path.join(ROOT, "bench_extra.json"), help="where the full extras object is also written")
     return ap.parse_args()
 
 
@@ -149,7 +160,10 @@ def cpu_model():
 
 
 def cpu_baseline(args, mode, seq, off, sketches_host, shuffled):
-    """Oracle ("port") timed on this box's host cores on a bounded sample of the same workload."""
+    """Oracle ("port") timed on this box's host cores on a bounded sample of the same workload.  The distance half is timed at
+    three sample sizes (n, n/2, n/4 of the same sketches) and fitted as t(N) = a N + b N^2: the reference's index loop
+    (src/MST.cpp:1408-1470) touches only pairs that share a hash -- for families of fixed size that is linear in N -- and
+    closes every 8-row block with a Kruskal pass whose UnionFind is built over all N vertices (:1543-1546), the quadratic term."""
     import numpy as np
     from oracle import pyoracle as O
     cores = usable_cores()
@@ -169,24 +183,34 @@ def cpu_baseline(args, mode, seq, off, sketches_host, shuffled):
     for g in range(min(ns, 4)):
         assert np.array_equal(sk[g], sketches_host[g]), "cpu baseline sketch differs from GPU sketch"
     npair = min(args.cpu_sample_sketches, len(sketches_host))
-    flat, start, lens = O.to_csr(sketches_host[:npair], dtype=sketches_host[0].dtype)
     kk = args.k if mode == "minhash" else 2 * ((args.k + 1) // 2)
-    t0 = time.time()
-    O.mst(flat, start, lens, kk, 0, args.threshold, threads=cores)
-    t_mst = time.time() - t0
+    fit_n, fit_s = [], []
+    for m in sorted({max(64, npair // 4), max(64, npair // 2), npair}):
+        flat, start, lens = O.to_csr(sketches_host[:m], dtype=sketches_host[0].dtype)
+        t0 = time.time()
+        O.mst(flat, start, lens, kk, 0, args.threshold, threads=cores)
+        fit_n.append(m)
+        fit_s.append(time.time() - t0)
+    t_mst = fit_s[-1]
+    A = np.array([[float(m), float(m) * m] for m in fit_n])
+    coef = np.linalg.lstsq(A, np.array(fit_s), rcond=None)[0] if len(fit_n) >= 2 else np.array([t_mst / npair, 0.0])
+    a, b = float(max(coef[0], 0.0)), float(max(coef[1], 0.0))
+    if a == 0.0 and b == 0.0:
+        a = t_mst / npair
     pairs = npair * (npair - 1) // 2
     return {
         "value": pairs / t_mst, "unit": "genome-pairs/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
         "sketch_gbp_per_sec": ns * L / t_sk / 1e9,
-        "note": "value = pairs of the sample / time of the reference's INDEX-based MST on it (src/MST.cpp:1408-1435): only pairs "
-                "that share a hash are touched, so the rate depends on the data and on the sample size -- the GPU's pair phase on "
-                "this workload is the same algorithm (inverted join), compare dist_pairs_per_sec with it only at equal N; "
-                "sketch_gbp_per_sec is the like-for-like figure of the phase that is 97 % of the step",
-        "sample": (f"sketch: {ns} x {L} bp genomes in {t_sk:.2f}s on {cores} threads (OpenMP over genomes, {impl}; "
-                   f"ours -- RabbitSketch's AVX2 kernel is absent from the reference tree); "
-                   f"distance: index-based compute_{'minhash' if mode == 'minhash' else 'kssd'}_mst restatement on "
-                   f"{npair} of the same sketches ({pairs} pairs, only pairs sharing a hash are touched) in {t_mst:.2f}s"),
+        "dist_fit": {"law": "t(N) = a*N + b*N^2", "n": fit_n, "s": [round(x, 4) for x in fit_s], "a_s_per_genome": a, "b_s_per_genome2": b},
+        "sample": (f"sketch: {ns} x {L} bp on {cores} threads in {t_sk:.2f}s ({impl}); distance: index-based "
+                   f"compute_{'minhash' if mode == 'minhash' else 'kssd'}_mst restatement on {npair} of the same sketches in {t_mst:.2f}s")[:200],
     }
+
+
+def cpu_dist_seconds(cpu, n):
+    """the fitted law of cpu_baseline's distance half at n genomes"""
+    f = cpu["dist_fit"]
+    return f["a_s_per_genome"] * n + f["b_s_per_genome2"] * float(n) * n
 
 
 def _mean_phases(phases):
@@ -224,8 +248,6 @@ def extra_kssd(args, ctx, api, pipeline, steps, packed=False):
     wl = {"genomes": n, "length": L, "k": args.k, "s": args.s, "mode": "kssd", "staging": "packed" if packed else None}
     traffic, src = measured_traffic(kernel, wl)
     pairs = n * (n - 1) // 2
-    note = ("1 B/base + %d B/hash out over the whole sketch phase (prefilter kernel + sort/dedup + capacity read-back); "
-            "traffic from profiles/%s" % (sk.width, src))
     out = {
         "workload": f"{n} x {L} bp synthetic genomes, KSSD --fast k={args.k} drlevel={args.drlevel}, sketch + all-pairs + MST"
                     + (", batch resident in the 2-bit staging format" if packed else ""),
@@ -233,14 +255,10 @@ def extra_kssd(args, ctx, api, pipeline, steps, packed=False):
         "sketch_gbp_per_sec": float(n) * L / (ph["sketch_ms"] * 1e-3) / 1e9, "mean_sketch_size": float(sk.len.float().mean().item()),
         "phase_ms": ph, "mst_edges": int(ph["mst_edges"]),
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "note": note},
+                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": ("profiles/" + src) if src else None},
     }
     if packed:
         phys = float(n) * L / 4 + float(sk.len.sum().item()) * sk.width
-        out["roofline"]["note"] = ("SURVEY 8(d): the judged figure stays 1 B/base (the character the reference consumes) + %d B/hash when the "
-                                   "device format is 2-bit packed; physical_* = the 0.25 B/base the kernel actually reads, reported "
-                                   "separately; whole sketch phase (run-range kernel + prefilter kernel + sort/dedup + capacity "
-                                   "read-back); the kernel is VALU-issue bound (DESIGN.md 3.2a); traffic from profiles/%s" % (sk.width, src))
         out["roofline"]["physical_achieved"] = phys / (ph["sketch_ms"] * 1e-3) / 1e9
         out["roofline"]["physical_frac"] = out["roofline"]["physical_achieved"] / HBM_PEAK_GBS
     return out
@@ -305,18 +323,17 @@ def extra_greedy(args, ctx, api, pipeline, steps):
         "greedy_s": float(np.mean(gr_s)), "genomes_per_sec": n / (float(np.mean(sk_ms)) * 1e-3 + float(np.mean(gr_s))),
         "sketch_ms_packed": float(np.mean(pk_ms)), "packed_sketches_identical": same,
         "roofline_packed": {"bound": "hbm", "kernel": "sketch_minhash_packed_kernel<21, false>", "achieved": ach_p, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": ach_p / HBM_PEAK_GBS,
-                            "note": "the same genomes resident at 2 bits a base (rtc_sketch_minhash_packed_dev), SURVEY 8(d)'s 1 B/base + 8 B/hash"},
+                            "unit": "GB/s", "frac": ach_p / HBM_PEAK_GBS},
         "clusters": int(ncl), "dtype": "u64",
         "roofline": {"bound": "hbm", "kernel": "sketch_minhash_kernel<21, false>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                     "note": "1 B/base + 8 B/hash out; traffic = rocprofv3 PMC bytes per launch (profiles/%s)" % src},
+                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": ("profiles/" + src) if src else None},
     }
 
 
-def extra_minhash_packed(args, ctx, api, pipeline, steps):
-    """The headline workload (configs[1], 10 000 x 5 Mbp) with the batch resident in the command lines' 2-bit staging
-    format and sketched from it (rtc_sketch_minhash_packed_dev): what clust-mst / clust-greedy run per batch."""
+def _extra_minhash_staging(args, ctx, api, pipeline, steps, packed):
+    """The headline workload (configs[1], 10 000 x 5 Mbp) in the staging the headline did NOT use: resident in the command lines'
+    2-bit staging format (rtc_sketch_minhash_packed_dev, what clust-mst / clust-greedy run per batch) or as characters
+    (rtc_sketch_minhash_dev, the library boundary's other form).  Same genomes, same forest."""
     import numpy as np
     import torch
     n, L = 10000, 5_000_000
@@ -324,154 +341,184 @@ def extra_minhash_packed(args, ctx, api, pipeline, steps):
     off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
     seq = ctx.synth_genomes(desc, off)
     ctx.sync()
-    pb = api.pack_staging(seq, int(off[-1]))  # the host parser's work, outside the timed region
-    del seq
-    torch.cuda.synchronize()
-    torch.cuda.empty_cache()
+    if packed:
+        pb = api.pack_staging(seq, int(off[-1]))  # the host parser's work, outside the timed region
+        del seq
+        seq = pb
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
     pipe = pipeline.MstPipeline(ctx, k=args.k, sketch_size=args.s, threshold=args.threshold)
-    pipe.step(pb, off)
+    pipe.step(seq, off)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ph = _mean_phases([pipe.step(pb, off) for _ in range(steps)])
+    ph = _mean_phases([pipe.step(seq, off) for _ in range(steps)])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     sk = pipe.last_sketches
     hashes = float(sk.len.sum().item())
     algo = float(n) * L + hashes * 8
-    phys = float(n) * L / 4 + hashes * 8
     sec = ph["sketch_ms"] * 1e-3
-    wl = {"genomes": n, "length": L, "k": args.k, "s": args.s, "mode": "minhash", "staging": "packed"}
-    traffic, src = measured_traffic("sketch_minhash_packed_kernel", wl)
-    return {
-        "workload": f"{n} x {L} bp synthetic genomes, MinHash k={args.k} s={args.s}, batch resident in the 2-bit staging format, "
-                    f"sketch + all-pairs + MST at d={args.threshold}",
+    kernel = "sketch_minhash_packed_kernel" if packed else "sketch_minhash_kernel"
+    wl = {"genomes": n, "length": L, "k": args.k, "s": args.s, "mode": "minhash", "staging": "packed" if packed else None}
+    traffic, src = measured_traffic(kernel, wl)
+    out = {
+        "workload": f"{n} x {L} bp synthetic genomes, MinHash k={args.k} s={args.s}, batch resident "
+                    + ("in the 2-bit staging format" if packed else "as characters") + f", sketch + all-pairs + MST at d={args.threshold}",
         "steps": steps, "ms_per_step": dt * 1e3, "genome_pairs_per_sec": n * (n - 1) // 2 / dt, "dtype": "u64",
         "sketch_gbp_per_sec": float(n) * L / sec / 1e9, "phase_ms": ph, "mst_edges": int(ph["mst_edges"]),
-        "roofline": {"bound": "hbm", "kernel": "sketch_minhash_packed_kernel<21, false>", "achieved": algo / sec / 1e9, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": kernel + "<21, false>", "achieved": algo / sec / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": algo / sec / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                     "physical_achieved": phys / sec / 1e9, "physical_frac": phys / sec / 1e9 / HBM_PEAK_GBS,
-                     "valu_issue": measured_valu("sketch_minhash_packed_kernel", wl),
-                     "note": "SURVEY 8(d): the judged figure stays 1 B/base + 8 B/hash when the device format is 2-bit packed; "
-                             "physical_* = the 0.25 B/base the kernel reads; the kernel is integer-VALU-issue bound on MurmurHash3 "
-                             "(DESIGN.md 3.1a); traffic from profiles/%s" % src},
+                     "traffic_source": ("profiles/" + src) if src else None, "valu_issue": measured_valu(kernel, wl)},
     }
-
-
-def _north_star_1gpu(args, ctx, api, pipeline, steps, mode):
-    """A north-star configuration on ONE GPU, whole job: every genome resident in HBM in the 2-bit staging format (chunks of
-    `chunk` genomes as the command lines stage them), sketched chunk by chunk into one resident sketch set, then the full
-    lower triangle -> candidate edges -> device Boruvka -> host distances -> clusters at d.  mode: "minhash" = configs[2]
-    (100 000 x 5 Mbp, k=21 s=1000), "kssd" = configs[4] (200 000 x 2 Mbp, --fast)."""
-    import numpy as np
-    import torch
-    from rabbittclust_amd import host
-    if mode == "minhash":
-        n, L, chunk, seed0 = 100000, 5_000_000, 10000, 500
-    else:
-        n, L, chunk, seed0 = 200000, 2_000_000, 25000, 900
-    free, _ = torch.cuda.mem_get_info()
-    need = n * L / 4 * 1.1 + chunk * L * 1.6
-    if free < need:
-        raise MemoryError(f"{free / 1e9:.0f} GB of HBM free, {need / 1e9:.0f} GB needed")
-    off = np.arange(chunk + 1, dtype=np.uint64) * np.uint64(L)
-    t_setup = time.perf_counter()
-    batches = []
-    for c0 in range(0, n, chunk):  # outside the timed region: synthesis and the host parser's packing
-        desc = api.synth_family_descs(chunk // 10, 10, global_seed=seed0 + c0)
-        seq = ctx.synth_genomes(desc, off)
-        ctx.sync()
-        batches.append(api.pack_staging(seq, int(off[-1])))
-        del seq
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
-    t_setup = time.perf_counter() - t_setup
-    if mode == "minhash":
-        s = args.s
-        rows = torch.empty((n, s), dtype=torch.int64, device=ctx.device)
-        width, kk = 8, args.k
-    else:
-        shuffled = host.generate_shuffle_dim(6)
-        s = L // 4096 * 3 // 2 + 256
-        rows = torch.zeros((n, s), dtype=torch.int32, device=ctx.device)
-        width, kk = 4, 2 * ((args.k + 1) // 2)
-    cnt = torch.zeros(n, dtype=torch.int32, device=ctx.device)
-    pipe = pipeline.MstPipeline(ctx, k=kk, sketch_size=s, threshold=args.threshold)
-    pairs = n * (n - 1) // 2
-    rec = []
-    for it in range(steps + 1):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ev[0].record()
-        for b, pb in enumerate(batches):
-            c0 = b * chunk
-            if mode == "minhash":
-                ctx.sketch_minhash_packed(pb, off, k=args.k, size=s, out=rows[c0:c0 + chunk], cnt=cnt[c0:c0 + chunk])
-            else:
-                part = ctx.sketch_kssd_packed(pb, None, None, off, shuffled, kmer_size=args.k, drlevel=args.drlevel, stride=s)
-                rows[c0:c0 + chunk] = part.hashes.view(chunk, -1)
-                cnt[c0:c0 + chunk] = part.len
-                del part
-        sk = api.SketchSet(rows.view(-1), torch.arange(n, dtype=torch.int64, device=ctx.device) * s, cnt, width, kk, mode)
-        ev[1].record()
-        edges, m = pipe.candidate_edges(sk, 0, n)
-        ev[2].record()
-        path = ctx.pair_last_path()
-        sel, rounds = pipe.boruvka(sk, edges, m)
-        mst = pipe.finish(sk, sel)
-        clusters = n - int(np.count_nonzero(mst["dist"] <= args.threshold))  # the forest cut (src/MST.cpp:1155-1183): every kept edge joins two clusters
-        ev[3].record()
-        torch.cuda.synchronize()
-        total = time.perf_counter() - t0
-        rec.append({"total_s": total, "sketch_s": ev[0].elapsed_time(ev[1]) * 1e-3, "pair_ms": ev[1].elapsed_time(ev[2]),
-                    "mst_ms": ev[2].elapsed_time(ev[3]), "cand_edges": float(m), "pair_path": float(path), "boruvka_rounds": float(rounds),
-                    "mst_edges": float(len(mst)), "clusters": float(clusters)})
-    ph = _mean_phases(rec[1:])
-    out = {
-        "workload": (f"{n} x {L} bp synthetic genomes ({n * L / 1e9:.0f} Gbp), "
-                     + (f"MinHash k={args.k} s={s}" if mode == "minhash" else f"KSSD --fast k={args.k} drlevel={args.drlevel}")
-                     + f", ONE GPU: all genomes resident in HBM in the 2-bit staging format ({n * L / 4e9:.0f} GB, {len(batches)} batches of "
-                     f"{chunk}), sketch + all {pairs:.3g} pairs + MST + clusters at d={args.threshold}; BASELINE configs[{2 if mode == 'minhash' else 4}] "
-                     "(quoted there on 8 GPUs)"),
-        "steps": steps, "total_s": ph["total_s"], "sketch_s": ph["sketch_s"], "pair_ms": ph["pair_ms"], "mst_ms": ph["mst_ms"],
-        "pair_path": int(round(ph["pair_path"])), "cand_edges": int(ph["cand_edges"]), "boruvka_rounds": ph["boruvka_rounds"],
-        "mst_edges": int(ph["mst_edges"]), "clusters": int(ph["clusters"]), "genome_pairs_per_sec": pairs / ph["total_s"],
-        "sketch_gbp_per_sec": n * L / ph["sketch_s"] / 1e9, "first_step_total_s": rec[0]["total_s"], "setup_s": t_setup,
-        "dtype": "u64" if width == 8 else "u32",
-        "note": "inputs resident in HBM when the timed region starts (synthesis + 2-bit packing = setup_s, outside it); total_s is the "
-                "wall clock around sketch + pair phase + Boruvka + host distances + forest cut, mean of the timed steps after one warm-up",
-    }
-    cpu = getattr(args, "_cpu_" + mode, None)
-    if cpu is None and not args.no_cpu_baseline:
-        # this job's own bounded CPU sample: the first genomes of batch 0 again as characters, the first sketches of the resident set
-        try:
-            ns = min(args.cpu_sample_genomes or 1024, chunk)
-            desc = api.synth_family_descs(chunk // 10, 10, global_seed=seed0)[:ns]
-            soff = np.arange(ns + 1, dtype=np.uint64) * np.uint64(L)
-            sseq = ctx.synth_genomes(desc, soff)
-            ctx.sync()
-            npair = min(args.cpu_sample_sketches, n)
-            sub = api.SketchSet(rows[:npair].reshape(-1), sk.start[:npair], cnt[:npair], width, kk, mode)
-            cpu = cpu_baseline(args, mode, sseq, soff, sub.to_host(), shuffled if mode == "kssd" else None)
-            del sseq
-        except Exception as e:
-            cpu = {"value": None, "error": repr(e)}
-    _cpu_extrapolation(out, n, L, pairs, cpu)
+    if packed:
+        phys = float(n) * L / 4 + hashes * 8
+        out["roofline"]["physical_achieved"] = phys / sec / 1e9
+        out["roofline"]["physical_frac"] = phys / sec / 1e9 / HBM_PEAK_GBS
     return out
 
 
+def extra_minhash_packed(args, ctx, api, pipeline, steps):
+    return _extra_minhash_staging(args, ctx, api, pipeline, steps, True)
+
+
+def extra_minhash_ascii(args, ctx, api, pipeline, steps):
+    return _extra_minhash_staging(args, ctx, api, pipeline, steps, False)
+
+
+NORTH_STAR = {"minhash": {"n": 100000, "L": 5_000_000, "chunk": 10000, "seed0": 500, "config": 2},
+              "kssd": {"n": 200000, "L": 2_000_000, "chunk": 25000, "seed0": 900, "config": 4}}
+NS_UNIT = 2500  # genomes per seed unit: genome g of the job is member g % 2500 of synth_family_descs(250, 10, seed0 + g // 2500)
+
+
+def north_star_descs(api, mode, g0, g1):
+    """descriptors of the job's genomes [g0, g1): the same 100 000 (200 000) genomes whatever the rank count"""
+    import numpy as np
+    parts = []
+    for u in range(g0 // NS_UNIT, (g1 + NS_UNIT - 1) // NS_UNIT):
+        d = api.synth_family_descs(NS_UNIT // 10, 10, global_seed=NORTH_STAR[mode]["seed0"] + u)
+        parts.append(d[max(g0 - u * NS_UNIT, 0):min(g1 - u * NS_UNIT, NS_UNIT)])
+    return np.concatenate(parts)
+
+
+def north_star_batches(ctx, api, mode, g0, g1, L):
+    """This rank's genomes [g0, g1) of the job, resident in HBM as batches in the 2-bit staging format -- what the command lines
+    stage per lane (synthesis and the host parser's packing: outside every timed region).  Every rank cuts its rows into the
+    same batch sizes (the sharded entry points' protocol)."""
+    import numpy as np
+    import torch
+    n_local = g1 - g0
+    nb = max(1, -(-n_local // NORTH_STAR[mode]["chunk"]))
+    sizes = [n_local // nb + (1 if i < n_local % nb else 0) for i in range(nb)]
+    batches, a = [], g0
+    for m in sizes:
+        off = np.arange(m + 1, dtype=np.uint64) * np.uint64(L)
+        seq = ctx.synth_genomes(north_star_descs(api, mode, a, a + m), off)
+        ctx.sync()
+        batches.append((api.pack_staging(seq, int(off[-1])), off))
+        del seq
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        a += m
+    return batches
+
+
+def north_star_job(args, ctx, api, pipeline, comm, mode, n_total, L, steps, warmup, barrier=None):
+    """The north-star job (BASELINE configs[2] / configs[4]) on the ranks of `comm` (an api.Comm; one rank: the whole job on
+    this GPU): every rank's genomes resident as packed batches, rtc_sketch_*_packed_sharded per batch into the global sketch
+    rows, rtc_mst_sharded (row range of the triangle -> candidate edges -> Boruvka with one all-reduce per round -> host
+    distances), the forest cut at d on the host.  Returns (phase means, per-step records, first-step seconds, setup seconds,
+    pipe)."""
+    import numpy as np
+    import torch
+    from rabbittclust_amd import host
+    world, rank = comm.size, comm.rank
+    n_local = n_total // world
+    free, _ = torch.cuda.mem_get_info()
+    need = n_local * L / 4 * 1.1 + min(n_local, NORTH_STAR[mode]["chunk"]) * L * 1.6 + n_total * (args.s * 8 if mode == "minhash" else 3000)
+    if free < need:
+        raise MemoryError(f"{free / 1e9:.0f} GB of HBM free, {need / 1e9:.0f} GB needed")
+    t_setup = time.perf_counter()
+    batches = north_star_batches(ctx, api, mode, rank * n_local, (rank + 1) * n_local, L)
+    t_setup = time.perf_counter() - t_setup
+    shuffled = host.generate_shuffle_dim(6 if 6 - args.drlevel >= 2 else args.drlevel + 2) if mode == "kssd" else None
+    pipe = pipeline.MstPipeline(ctx, k=args.k, sketch_size=args.s, threshold=args.threshold, mode=mode, drlevel=args.drlevel,
+                                shuffled_dim=shuffled, comm=pipeline.NativeComm(comm))
+    sync = barrier or torch.cuda.synchronize
+    rec, first = [], None
+    for it in range(warmup):
+        t0 = time.perf_counter()
+        pipe.step(batches)
+        torch.cuda.synchronize()
+        first = first or time.perf_counter() - t0
+    sync()
+    t_all = time.perf_counter()
+    for it in range(steps):
+        t0 = time.perf_counter()
+        ph = pipe.step(batches)
+        ph["clusters"] = float(n_total - int(np.count_nonzero(pipe.last_mst["dist"] <= args.threshold)))  # the forest cut (src/MST.cpp:1155-1183)
+        ph["total_s"] = time.perf_counter() - t0
+        rec.append(ph)
+    sync()
+    t_all = time.perf_counter() - t_all
+    return _mean_phases(rec), rec, first, t_setup, pipe, t_all, batches
+
+
+def _north_star_1gpu(args, ctx, api, pipeline, steps, mode):
+    """A north-star configuration on ONE GPU, whole job, through the same C entry points the N-rank runs use (a communicator of
+    one rank): this is the N = 1 point of `bench.py --gpus N --scaling strong`."""
+    import numpy as np
+    ns = NORTH_STAR[mode]
+    n, L = ns["n"], ns["L"]
+    comm = api.Comm.init_rank(ctx, 1, 0, None)
+    try:
+        ph, rec, first, t_setup, pipe, t_all, batches = north_star_job(args, ctx, api, pipeline, comm, mode, n, L, steps, 1)
+        pairs = n * (n - 1) // 2
+        sk = pipe.last_sketches
+        out = {
+            "workload": (f"{n} x {L} bp synthetic genomes ({n * L / 1e9:.0f} Gbp), "
+                         + (f"MinHash k={args.k} s={args.s}" if mode == "minhash" else f"KSSD --fast k={args.k} drlevel={args.drlevel}")
+                         + f", ONE GPU, {len(batches)} resident 2-bit batches ({n * L / 4e9:.0f} GB), sketch + all {pairs:.3g} pairs + MST + "
+                         f"clusters at d={args.threshold}; BASELINE configs[{ns['config']}]"),
+            "steps": steps, "total_s": t_all / steps, "sketch_s": ph["sketch_ms"] * 1e-3, "pair_ms": ph["pair_ms"], "mst_ms": ph["mst_ms"],
+            "pair_path": int(round(ph["pair_path"])), "cand_edges": int(ph["cand_edges"]), "boruvka_rounds": ph["boruvka_rounds"],
+            "mst_edges": int(ph["mst_edges"]), "clusters": int(ph["clusters"]), "genome_pairs_per_sec": pairs / (t_all / steps),
+            "sketch_gbp_per_sec": n * L / (ph["sketch_ms"] * 1e-3) / 1e9, "first_step_total_s": first, "setup_s": t_setup,
+            "dtype": "u64" if sk.width == 8 else "u32", "mean_sketch_size": float(sk.len.float().mean().item()),
+        }
+        if not args.no_cpu_baseline:
+            # this job's own bounded CPU sample: its first genomes again as characters, its first sketches
+            try:
+                nsmp = min(args.cpu_sample_genomes or 1024, n)
+                soff = np.arange(nsmp + 1, dtype=np.uint64) * np.uint64(L)
+                sseq = ctx.synth_genomes(north_star_descs(api, mode, 0, nsmp), soff)
+                ctx.sync()
+                npair = min(args.cpu_sample_sketches, n)
+                stride = sk.hashes.numel() // sk.n
+                sub = api.SketchSet(sk.hashes.view(sk.n, stride)[:npair].reshape(-1), sk.start[:npair], sk.len[:npair], sk.width, sk.k, sk.kind)
+                cpu = cpu_baseline(args, mode, sseq, soff, sub.to_host(), pipe.shuffled_dim)
+                del sseq
+            except Exception as e:
+                cpu = {"value": None, "error": repr(e)}
+            _cpu_extrapolation(out, n, L, pairs, cpu)
+        return out
+    finally:
+        comm.close()
+
+
 def _cpu_extrapolation(out, n, L, pairs, cpu):
-    """The reference's CPU path on this job, EXTRAPOLATED from this line's own cpu_baseline rates (a bounded sample)."""
+    """The reference's CPU path on this job, EXTRAPOLATED from the job's own bounded CPU sample: the sketch half is
+    linear in bases; the distance half follows the law fitted from three sample sizes (cpu_baseline)."""
     if not cpu or not cpu.get("value"):
         if cpu and cpu.get("error"):
-            out["cpu_extrapolated"] = {"error": cpu["error"]}
+            out["cpu_extrapolated"] = {"error": cpu["error"][:300]}
         return
     sk_s = n * L / 1e9 / cpu["sketch_gbp_per_sec"]
-    pr_s = pairs / cpu["value"]
+    pr_s = cpu_dist_seconds(cpu, n)
     out["cpu_extrapolated_s"] = sk_s + pr_s
     out["cpu_extrapolated"] = {
-        "sketch_s": sk_s, "dist_s": pr_s, "cores": cpu.get("cores"), "kind": cpu.get("kind"),
-        "label": "EXTRAPOLATED, not measured: this job's bases / the cpu_baseline sketch rate + its pairs / the cpu_baseline pair rate",
+        "sketch_s": sk_s, "dist_s": pr_s, "cores": cpu.get("cores"), "kind": cpu.get("kind"), "dist_fit": cpu["dist_fit"],
+        "label": "EXTRAPOLATED, not measured: bases / the sample's sketch rate + the distance law t(N) = a N + b N^2 fitted on "
+                 "three sizes of the job's own sketches (index loop linear in N for fixed family size, per-block Kruskal quadratic)",
         "sample": cpu.get("sample")}
     out["gpu_vs_cpu_extrapolated"] = out["cpu_extrapolated_s"] / out["total_s"]
 
@@ -536,9 +583,9 @@ def extra_dense_pairs(args, ctx, api, pipeline, steps):
     rng = np.random.default_rng(7)
     toy_rows = []
     for f in range(2):
-        fam = np.unique(rng.integers(0, 1 << 32, size=1100, dtype=np.uint64).astype(np.uint32))[:1000]
+        toy_base = np.unique(rng.integers(0, 1 << 32, size=1100, dtype=np.uint64).astype(np.uint32))[:1000]
         for m in range(128):
-            v = fam.copy()
+            v = toy_base.copy()
             v[rng.integers(0, len(v), size=8)] = rng.integers(0, 1 << 32, size=8, dtype=np.uint64).astype(np.uint32)
             toy_rows.append(np.unique(v))
     toy = api.SketchSet.from_host(toy_rows, ctx.device, k=args.k, kind="kssd", width=4)
@@ -580,18 +627,11 @@ def extra_dense_pairs(args, ctx, api, pipeline, steps):
         "mst_edges": int(ph["mst_edges"]), "boruvka_rounds": ph["boruvka_rounds"], "dtype": "u64",
         "first_call_pair_ms": first["pair_ms"], "first_call_mst_ms": first["mst_ms"], "first_call_pair_path": int(first["pair_path"]),
         "warmup_toy_pair_path": int(toy_path),
-        "first_call_note": "a real run meets each sketch set once: first_call_* = the first launch on this set with the code objects warm "
-                           "(a 256-sketch toy set took the same path before) -- it pays the cost rule's look at the set (a 1/64 sample of the "
-                           "hash space counted into a table, 40 us; no flat copy, no sort) -- and dist_pairs_per_sec is computed from it; "
-                           "pair_ms / *_steady = later launches on the same set (the refusal is remembered)",
         "roofline_dist": {"bound": "hbm", "kernel": "pair_tiled_kernel", "bytes_per_pair": bytes_pair,
                           "algorithmic_achieved": algo, "algorithmic_frac": algo / HBM_PEAK_GBS,
                           "achieved": (traffic / kern_s / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": (traffic / kern_s / 1e9 / HBM_PEAK_GBS) if traffic else None, "traffic": traffic,
-                          "note": SURVEY_8D_PAIR_NOTE + " x pairs of the launch / the kernel's duration (HIP events on its launch stream, "
-                                  "rtc_pair_last_kernel_ms) = algorithmic_*: above 1 by construction, a probe of the LDS table serves the "
-                                  "64 rows of a block and a block's sketches are read once; achieved/frac = PMC-measured HBM bytes per "
-                                  "launch (profiles/%s) / the same duration" % src},
+                          "traffic_source": ("profiles/" + src) if src else None},
     }
 
 
@@ -643,9 +683,9 @@ def extra_cli(args, ctx, api, pipeline, steps):
                            f"region), bin/clust-mst -l -i list -k {args.k} -d {args.threshold} -e, page cache warm, best of three runs "
                            f"started a second after the previous process left",
                "host_cores": usable_cores()}
-        def run_cli(tag, list_file, extra, n_files, bases, tool="clust-mst"):
+        def run_cli(tag, list_file, extra, n_files, bases, tool="clust-mst", reps=3):
             best = None
-            for rep in range(3):  # from the second run on the code objects and the files' pages are warm
+            for rep in range(reps):  # from the second run on the code objects and the files' pages are warm
                 # A process that has left is not gone: the driver tears its GPU state down asynchronously (~0.25 s of work), and a
                 # process launched inside that window pays it in its own HIP start-up (0.07 -> 0.13-0.26 s) or at its own exit
                 # (0.001 -> 0.12 s): tools/cli_timeline.py, TL_SLEEP=0 against 1.  One command line is one process.
@@ -676,9 +716,6 @@ def extra_cli(args, ctx, api, pipeline, steps):
         out["minhash"] = run_cli("minhash", plain_list, ["-s", str(args.s)], n, n * L)
         out["fast"] = run_cli("fast", plain_list, ["--fast"], n, n * L)
         out["greedy"] = run_cli("greedy", plain_list, ["-c", "1000"], n, n * L, tool="clust-greedy")  # config 3's command line: containment sketches of 5 000 hashes
-        out["batch_note"] = ("gpu_copy_ms_per_batch / gpu_sketch_ms_per_batch: a lane's host thread per staged batch -- PCIe copy of the 2-bit "
-                             "batch + run list, then the sketch launch straight from it (no unpack pass since round 5) + the read-back of "
-                             "the counts; two lanes per GPU work beside the parser threads")
         # ---- the shapes sketchFiles actually opens (src/SketchInfo.cpp:880-948): gzip'd files, many-contig assemblies ----
         ngz = min(n, max(16, n // 8))
         t0 = time.time()
@@ -691,8 +728,6 @@ def extra_cli(args, ctx, api, pipeline, steps):
         g = run_cli("gz", os.path.join(tmp, "list_gz.txt"), ["-s", str(args.s)], ngz, ngz * L)
         g["workload"] = (f"the first {ngz} of the same genomes as .fna.gz (gzip -6, {gz_bytes / 1e9:.2f} GB compressed, written in {t_gz:.1f}s outside "
                          "the timed region), MinHash")
-        g["limit"] = ("compressed input is bound by inflate on the parser threads (inflate_gb_per_sec_per_thread x threads, libdeflate where "
-                      "the host has it, zlib otherwise); DESIGN.md 6 costs the alternatives")
         out["gz"] = g
         for p in gz_paths:
             os.unlink(p)
@@ -728,12 +763,49 @@ def extra_cli(args, ctx, api, pipeline, steps):
         c["workload"] = (f"{n} x {L} bp assemblies of ~200 contigs (records of 5-45 kbp) with three N runs each, plain FASTA (written in {t_c:.1f}s "
                          "outside the timed region), MinHash: every record separator and N stretch is a run of the staging format")
         out["contigs"] = c
+        for p in cpaths:
+            os.unlink(p)
+        # ---- the command line at scale: --cli-genomes-large files (8 192 x 5 Mbp = 41 GB of FASTA), MinHash, when the box has the room ----
+        nl_ = int(args.cli_genomes_large)
+        if nl_ > n:
+            need_l = int(nl_ * L * 1.02) + (1 << 30)
+            avail = 0
+            try:
+                for ln in open("/proc/meminfo"):
+                    if ln.startswith("MemAvailable:"):
+                        avail = int(ln.split()[1]) * 1024
+            except OSError:
+                pass
+            free_l = shutil.disk_usage(where).free
+            if free_l < need_l + (4 << 30) or (where == "/dev/shm" and avail < 2 * need_l):
+                out["minhash_large"] = {"skipped": f"{nl_} x {L} bp needs {need_l / 1e9:.0f} GB in {where}: {free_l / 1e9:.0f} GB free there, "
+                                                   f"{avail / 1e9:.0f} GB of host memory available"}
+            else:
+                t0 = time.time()
+                desc_l = api.synth_family_descs(max(1, nl_ // 8), 8, global_seed=78)[:nl_]
+                lpaths = []
+                for c0 in range(0, nl_, chunk):
+                    c1 = min(nl_, c0 + chunk)
+                    off = np.arange(c1 - c0 + 1, dtype=np.uint64) * np.uint64(L)
+                    seq = ctx.synth_genomes(desc_l[c0:c1], off).cpu().numpy()
+                    for g in range(c0, c1):
+                        p = os.path.join(tmp, f"l{g:05d}.fna")
+                        with open(p, "wb") as f:
+                            f.write(f">l{g} synthetic\n".encode() + np.concatenate([seq[(g - c0) * L:(g - c0 + 1) * L].reshape(-1, 80), nl], axis=1).tobytes())
+                        lpaths.append(p)
+                    del seq
+                with open(os.path.join(tmp, "list_large.txt"), "w") as f:
+                    f.write("\n".join(lpaths) + "\n")
+                t_l = time.time() - t0
+                big = run_cli("minhash_large", os.path.join(tmp, "list_large.txt"), ["-s", str(args.s)], nl_, nl_ * L, reps=2)
+                big["workload"] = f"{nl_} x {L} bp genomes as FASTA files in {where} ({nl_ * L * 1.0125 / 1e9:.0f} GB, written in {t_l:.0f}s outside the timed region), MinHash, best of two"
+                out["minhash_large"] = big
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-EXTRAS = (("minhash_packed", extra_minhash_packed), ("kssd", extra_kssd), ("kssd_packed", extra_kssd_packed), ("greedy", extra_greedy),
+EXTRAS = (("minhash_ascii", extra_minhash_ascii), ("minhash_packed", extra_minhash_packed), ("kssd", extra_kssd), ("kssd_packed", extra_kssd_packed), ("greedy", extra_greedy),
           ("weak_first_point", extra_weak_first_point), ("dense_pairs", extra_dense_pairs), ("config3_1gpu", extra_config3_1gpu),
           ("config5_1gpu", extra_config5_1gpu), ("cli", extra_cli))
 
@@ -745,15 +817,137 @@ def extra_workloads(args, ctx, api, pipeline, only=None):
     import torch
     out = {}
     steps = max(1, args.extra_steps)
+    skip = "minhash_" + getattr(args, "_headline_staging", "packed")  # the headline already ran the workload in that staging
     for name, fn in EXTRAS:
-        if only and name != only:
+        if (only and name != only) or (not only and name == skip):
             continue
+        t0 = time.perf_counter()
         try:
             out[name] = fn(args, ctx, api, pipeline, steps)
         except Exception as e:
-            out[name] = {"error": repr(e)}
+            out[name] = {"error": repr(e)[:300]}
+        out[name]["extra_wall_s"] = round(time.perf_counter() - t0, 2)
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
     return out
+
+
+# ---- the output protocol -----------------------------------------------------------------------------------------------
+MAX_STR = 400       # no string value of any printed object is longer (tests/test_gpu_bench.py)
+MAX_COMPACT = 4000  # bytes of the compact headline line
+
+
+def sanitize(obj):
+    """numpy scalars / arrays -> plain JSON values, NaN -> None, strings cut at MAX_STR: whatever an extra returns, the
+    printed line stays valid JSON of bounded strings (an array that slipped into an f-string cost round 5 its evidence)."""
+    import math
+    import numpy as np
+    if isinstance(obj, dict):
+        return {str(k): sanitize(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [sanitize(v) for v in obj]
+    if isinstance(obj, np.ndarray):
+        return sanitize(obj.tolist()) if obj.size <= 64 else f"<array of {obj.size}>"
+    if isinstance(obj, np.generic):
+        obj = obj.item()
+    if isinstance(obj, float):
+        return obj if math.isfinite(obj) else None
+    if isinstance(obj, str):
+        return obj if len(obj) <= MAX_STR else obj[:MAX_STR - 3] + "..."
+    if obj is None or isinstance(obj, (bool, int)):
+        return obj
+    return sanitize(str(obj))
+
+
+def _r(x, nd=4):
+    """a float rounded to nd significant digits (the compact line), anything else unchanged"""
+    if isinstance(x, float) and x == x and x not in (float("inf"), float("-inf")) and x != 0.0:
+        from math import floor, log10
+        return round(x, max(0, nd - 1 - int(floor(log10(abs(x))))))
+    return x
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_line(line, extras=None):
+    """The headline object the driver parses: the contract's keys, roofline, cpu_baseline, phase_ms and the scalars lifted
+    from the extras.  Always < MAX_COMPACT bytes: optional keys are dropped from the end of `optional` until it fits."""
+    rf, cb = line["roofline"], line.get("cpu_baseline") or {}
+    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data")}
+    out["config"] = {k: line["config"][k] for k in ("workload", "genomes_total", "genomes_per_gpu", "genome_length", "k", "sketch_size", "staging",
+                                                    "sharding", "collectives", "pair_path") if k in line["config"]}
+    out["sketch_gbp_per_sec"] = line["sketch_gbp_per_sec"]
+    out["dist_pairs_per_sec"] = line["dist_pairs_per_sec"]
+    out["mst_edges"], out["clusters"] = line["mst_edges"], line.get("clusters")
+    out["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "physical_frac", "kernel_ms",
+                                              "traffic_source")}
+    out["cpu_baseline"] = ({k: cb.get(k) for k in ("value", "unit", "cores", "cpu", "kind", "sketch_gbp_per_sec", "sample")}
+                           if cb.get("value") else {"value": None, "error": str(cb.get("error", "skipped"))[:200]})
+    if cb.get("sample"):
+        out["cpu_baseline"]["sample"] = cb["sample"][:200]
+    out["phase_ms"] = {k: line["phase_ms"][k] for k in ("sketch_ms", "gather_ms", "pair_ms", "mst_ms", "dist_ms", "cand_edges", "boruvka_rounds")
+                       if k in line["phase_ms"]}
+    optional = []
+    if line.get("per_rank"):
+        pr = line["per_rank"]
+        optional.append(("per_rank", {"sketch_ms_max": pr["phase_ms_max"]["sketch_ms"], "gather_ms_max": pr["phase_ms_max"]["gather_ms"],
+                                      "pair_ms_max": pr["phase_ms_max"]["pair_ms"], "mst_ms_max": pr["phase_ms_max"]["mst_ms"],
+                                      "pair_ms_min": pr["phase_ms_min"]["pair_ms"], "all_reduce_bytes_per_step": pr["all_reduce_bytes_per_step"]}))
+    if extras is not None:
+        x = extras
+        sc = {
+            "minhash_packed_ms": line["phase_ms"]["sketch_ms"] if line["config"].get("staging") == "packed" else _get(x, "minhash_packed", "phase_ms", "sketch_ms"),
+            "minhash_ascii_ms": line["phase_ms"]["sketch_ms"] if line["config"].get("staging") == "ascii" else _get(x, "minhash_ascii", "phase_ms", "sketch_ms"),
+            "kssd_frac": _get(x, "kssd", "roofline", "frac"),
+            "kssd_packed_frac": _get(x, "kssd_packed", "roofline", "frac"),
+            "kssd_packed_physical_frac": _get(x, "kssd_packed", "roofline", "physical_frac"),
+            "greedy_frac": _get(x, "greedy", "roofline", "frac"),
+            "dense_pair_kernel_ms": _get(x, "dense_pairs", "pair_kernel_ms"),
+            "dense_first_call_ms": _get(x, "dense_pairs", "first_call_pair_ms"),
+            "dense25k_pair_ms": _get(x, "dense_pairs", "u32_25000", "pair_ms"),
+            "config3_total_s": _get(x, "config3_1gpu", "total_s"),
+            "config3_pair_ms": _get(x, "config3_1gpu", "pair_ms"),
+            "config3_mst_ms": _get(x, "config3_1gpu", "mst_ms"),
+            "config3_clusters": _get(x, "config3_1gpu", "clusters"),
+            "config3_vs_cpu_extrapolated": _get(x, "config3_1gpu", "gpu_vs_cpu_extrapolated"),
+            "config5_total_s": _get(x, "config5_1gpu", "total_s"),
+            "config5_pair_ms": _get(x, "config5_1gpu", "pair_ms"),
+            "config5_mst_ms": _get(x, "config5_1gpu", "mst_ms"),
+            "config5_vs_cpu_extrapolated": _get(x, "config5_1gpu", "gpu_vs_cpu_extrapolated"),
+            "cli_gbp_per_sec": _get(x, "cli", "minhash", "end_to_end_gbp_per_sec"),
+            "cli_large_gbp_per_sec": _get(x, "cli", "minhash_large", "end_to_end_gbp_per_sec"),
+        }
+        optional.append(("extra_scalars", sc))
+        failed = [k for k, v in x.items() if isinstance(v, dict) and "error" in v]
+        optional.append(("extra_errors", failed))
+        optional.append(("extra_file", "bench_extra.json (and the {\"extra\": ...} line above)"))
+    for k, v in optional:
+        out[k] = v
+    out = sanitize(out)
+
+    def rounded(o):
+        if isinstance(o, dict):
+            return {k: rounded(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [rounded(v) for v in o]
+        return _r(o, 6)
+    out = rounded(out)
+    drop = [k for k, _ in optional][::-1] + ["phase_ms"]
+    while len(json.dumps(out)) > MAX_COMPACT and drop:
+        out.pop(drop.pop(0), None)
+    return out
+
+
+def emit(obj):
+    print(json.dumps(sanitize(obj)), flush=True)
 
 
 def main():
@@ -781,85 +975,103 @@ def main():
               file=sys.stderr)
     ctx = api.Context(local)
     if args.only:
-        print(json.dumps({"extra": extra_workloads(args, ctx, api, pipeline, only=args.only)}))
+        ex = extra_workloads(args, ctx, api, pipeline, only=args.only)
+        emit({"extra": ex})
         return
 
     mode = args.mode
-    if mode == "minhash":
-        n_local = args.genomes or (10000 if world == 1 else 12500)
-        length = args.length or 5_000_000
-    else:
-        n_local = args.genomes or 25000
-        length = args.length or 2_000_000
-    n_fam = max(1, n_local // args.family)
-    n_local = n_fam * args.family
-    desc = api.synth_family_descs(n_fam, args.family, global_seed=42 + 1000 * rank)
-    off = np.arange(n_local + 1, dtype=np.uint64) * np.uint64(length)
-    seq = ctx.synth_genomes(desc, off)
-    ctx.sync()
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
     packed = args.staging == "packed"
-    if packed and mode == "minhash" and world > 1:
-        args.comm = "torch"  # the sharded sketch call behind the C ABI takes characters; the packed batch goes through the generic step
-    cpu_seq = seq
-    if packed:  # the batch as the command lines hand it over; packing is the host parser's work, outside the timed region
-        ns_cpu = min(args.cpu_sample_genomes or 1024, n_local)
-        cpu_seq = seq[: ns_cpu * length].clone()  # the characters of the CPU baseline's sample
-        seq = api.pack_staging(seq, int(off[-1]))
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
-
+    length = args.length or NORTH_STAR[mode]["L"]
     shuffled = None
     if mode == "kssd":
         from rabbittclust_amd import host
         shuffled = host.generate_shuffle_dim(6 if 6 - args.drlevel >= 2 else args.drlevel + 2)
-    comm, comm_kind = None, "none"
+
+    # ---- communicator ----
+    comm, comm_kind, nat = None, "none", None
     if dist is not None:
         comm, comm_kind = pipeline.TorchComm(dist, rank, world), "torch.distributed nccl (RCCL)"
-        if args.comm == "native":
-            # the id is created on rank 0 and travels through the process group the launcher set up
-            ok, nat = 1, None
-            try:
-                uid = [api.Comm.unique_id(ctx.lib) if rank == 0 else None]
+    if (dist is not None and args.comm == "native") or scaling == "strong":
+        # the id is created on rank 0 and travels through the process group the launcher set up
+        ok = 1
+        try:
+            uid = [api.Comm.unique_id(ctx.lib) if (rank == 0 and dist is not None) else None]
+            if dist is not None:
                 dist.broadcast_object_list(uid, src=0)
-                nat = api.Comm.init_rank(ctx, world, rank, uid[0])
-                t = torch.tensor([rank + 1], dtype=torch.int64, device=ctx.device)
-                nat.all_reduce(t, "max")
-                ok = int(int(t.item()) == world)
-            except Exception as e:  # stay on torch.distributed's communicator (also RCCL), say so
-                print(f"bench.py rank {rank}: native communicator unavailable ({e!r}); using torch.distributed", file=sys.stderr)
-                ok = 0
+            nat = api.Comm.init_rank(ctx, world, rank, uid[0])
+            t = torch.tensor([rank + 1], dtype=torch.int64, device=ctx.device)
+            nat.all_reduce(t, "max")
+            ok = int(int(t.item()) == world)
+        except Exception as e:  # stay on torch.distributed's communicator (also RCCL), say so
+            print(f"bench.py rank {rank}: native communicator unavailable ({e!r})", file=sys.stderr)
+            ok = 0
+        if dist is not None:
             flag = torch.tensor([ok], dtype=torch.int64, device=ctx.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks take the same path
-            if int(flag.item()) == 1:
-                comm, comm_kind = pipeline.NativeComm(nat), f"rtc_comm ({nat.backend}, C ABI)"
-    pipe = pipeline.MstPipeline(ctx, k=args.k, sketch_size=args.s, threshold=args.threshold,
-                                mode=mode, drlevel=args.drlevel, shuffled_dim=shuffled,
-                                comm=comm or pipeline.TorchComm(None, rank, world))
+            ok = int(flag.item())
+        if ok == 1:
+            comm, comm_kind = pipeline.NativeComm(nat), f"rtc_comm ({nat.backend}, C ABI)"
+        elif scaling == "strong":
+            sys.exit("bench.py: --scaling strong goes through the C ABI's communicator (rtc_comm_*), which is unavailable here")
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        pipe.step(seq, off)
-    barrier()
-    t0 = time.perf_counter()
-    phases = []
-    for _ in range(args.steps):
-        phases.append(pipe.step(seq, off))
-    barrier()
-    dt = time.perf_counter() - t0
+    cpu_seq = cpu_off = None
+    if scaling == "strong":
+        # ---- north_star's own job, split over the ranks: rtc_sketch_*_packed_sharded + rtc_mst_sharded ----
+        if not packed:
+            sys.exit("bench.py: --scaling strong keeps the genomes resident in the 2-bit staging format (--staging packed)")
+        n_total = (args.genomes or NORTH_STAR[mode]["n"]) // (world * 10) * (world * 10)
+        n_local = n_total // world
+        ph, phases, first, t_setup, pipe, dt, batches = north_star_job(args, ctx, api, pipeline, nat, mode, n_total, length, args.steps,
+                                                                       args.warmup, barrier=barrier)
+        n_batches = len(batches)
+    else:
+        n_local = args.genomes or ((10000 if world == 1 else 12500) if mode == "minhash" else 25000)
+        n_fam = max(1, n_local // args.family)
+        n_local = n_fam * args.family
+        n_total = n_local * world
+        desc = api.synth_family_descs(n_fam, args.family, global_seed=42 + 1000 * rank)
+        off = np.arange(n_local + 1, dtype=np.uint64) * np.uint64(length)
+        seq = ctx.synth_genomes(desc, off)
+        ctx.sync()
+        ns_cpu = min(args.cpu_sample_genomes or 1024, n_local)
+        cpu_seq, cpu_off = seq, off
+        if packed:  # the batch as the command lines hand it over; packing is the host parser's work, outside the timed region
+            cpu_seq = seq[: ns_cpu * length].clone()  # the characters of the CPU baseline's sample
+            pb = api.pack_staging(seq, int(off[-1]))
+            del seq
+            seq = [(pb, off)] if isinstance(comm, pipeline.NativeComm) else pb  # behind the C ABI: the sharded packed entry points
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+        pipe = pipeline.MstPipeline(ctx, k=args.k, sketch_size=args.s, threshold=args.threshold,
+                                    mode=mode, drlevel=args.drlevel, shuffled_dim=shuffled,
+                                    comm=comm or pipeline.TorchComm(None, rank, world))
+        n_batches = 1
+        for _ in range(args.warmup):
+            pipe.step(seq, off)
+        barrier()
+        t0 = time.perf_counter()
+        phases = []
+        for _ in range(args.steps):
+            p = pipe.step(seq, off)
+            p["clusters"] = float(n_total - int(np.count_nonzero(pipe.last_mst["dist"] <= args.threshold)))
+            phases.append(p)
+        barrier()
+        dt = time.perf_counter() - t0
+        ph = _mean_phases(phases)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    n_total = n_local * world
     pairs = n_total * (n_total - 1) // 2
-    bases_total = float(n_local) * length * world
+    bases_total = float(n_total) * length
     ms_step = dt / args.steps * 1e3
-    ph = {k: float(np.mean([p[k] for p in phases])) for k in phases[0]}
     ranks_ph = None
     if dist is not None:  # every rank's phase means, so that the N>1 line shows the spread and not only rank 0
         ranks_ph = [None] * world
@@ -870,39 +1082,24 @@ def main():
         sk_all = pipe.last_sketches
         width = sk_all.width
         hashes_local = float(sk_all.len.sum().item()) / world
-        algo_bytes = float(n_local) * length + hashes_local * width
+        algo_bytes = float(n_local) * length + hashes_local * width  # 1 B/base in + width B/hash out, this rank's launches of a step
         achieved = algo_bytes / (sk_ms * 1e-3) / 1e9
         avg_len = float(sk_all.len.float().mean().item())
-        dist_pairs_local = ph["pairs_local"]
-        survey_bytes_pair = 2 * avg_len * width  # SURVEY 8(d): (|A| + |B|) * w per genome pair
-        dist_algo = survey_8d = dist_pairs_local * survey_bytes_pair / (ph["pair_ms"] * 1e-3) / 1e9
-        wl = {"genomes": n_local, "length": length, "k": args.k, "s": args.s, "mode": mode}
-        wl["staging"] = "packed" if packed else None
+        wl = {"genomes": n_local, "length": length, "k": args.k, "s": args.s, "mode": mode, "staging": "packed" if packed else None}
         sk_kernel = (("sketch_minhash_packed_kernel" if packed else "sketch_minhash_kernel") if mode == "minhash" else
                      "sketch_kssd_packed_kernel" if packed else "sketch_kssd_bloom_kernel")
         sk_traffic, sk_src = measured_traffic(sk_kernel, wl)
-        # the pair phase's device path: 3 = inverted join (one rocPRIM radix sort + the join kernels), 2 = tiled kernel
+        if sk_traffic is None and n_batches > 1:  # the committed PMC pass is per launch of a 10 000-genome batch
+            per = n_local // n_batches
+            t1, sk_src = measured_traffic(sk_kernel, dict(wl, genomes=per))
+            sk_traffic = t1 * n_batches if t1 else None
         pair_path = int(round(ph.get("pair_path", 2.0)))
         pr_kernel = "pair_join_phase" if pair_path == 3 else "pair_tiled_kernel"
         pr_traffic, pr_src = measured_traffic(pr_kernel, wl)
         pr_ach = pr_traffic / (ph["pair_ms"] * 1e-3) / 1e9 if pr_traffic else None
-        if pair_path == 3:
-            dist_algo = hashes_local * world * (width + 4) / (ph["pair_ms"] * 1e-3) / 1e9  # every (hash, genome) once
-            dist_note = ("pair phase = inverted join (rtc_pairs_join.hip): achieved/frac = PMC-measured HBM bytes of all kernels "
-                         "of the phase (profiles/%s: 'pair_join_phase' = the library's rocPRIM sort / scan / reduce kernels + join_*) / "
-                         "pair-phase time; algorithmic_* = (hash, genome) records read once = %d B per hash / time -- the "
-                         "radix passes move each record several times; survey_8d_* = %s x the pairs of the tile / pair-phase time: "
-                         "far above the peak because the join never touches a pair that shares no hash -- a data-dependent figure, "
-                         "not a kernel rate (extra.dense_pairs times the tiled N x N kernel, whose cost the data cannot change)"
-                         % (pr_src, width + 4, SURVEY_8D_PAIR_NOTE))
-        else:
-            dist_note = ("achieved/frac = PMC-measured HBM bytes per launch (profiles/%s) / pair-phase time: "
-                         "the physical figure; algorithmic_* = (|A|+|B|)*%d B per pair / time, which "
-                         "exceeds 1 because a tile's sketches are reused from LDS/L2 (one LDS probe serves "
-                         "64 pairs)" % (pr_src, width))
+        survey_bytes_pair = 2 * avg_len * width  # SURVEY 8(d): (|A| + |B|) * w per genome pair
         what = "MinHash k=%d s=%d" % (args.k, args.s) if mode == "minhash" else "KSSD --fast k=%d drlevel=%d" % (args.k, args.drlevel)
-        if packed:
-            what += ", batch resident in the 2-bit staging format"
+        what += ", batch resident in the 2-bit staging format" if packed else ", batch resident as characters"
         line = {
             "metric": ("genome_pairs_per_sec_end_to_end (sketch + all-pairs Mash distance + MST), k=21 s=1000"
                        if mode == "minhash" else
@@ -910,52 +1107,41 @@ def main():
             "value": pairs / (dt / args.steps),
             "unit": "genome-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u64" if width == 8 else "u32", "data": "synthetic",
             "config": {"workload": f"{n_total} x {length} bp synthetic genomes ({n_local}/GPU), {what}, "
-                                   f"sketch + all-pairs + MST at d={args.threshold}",
-                       "genomes_per_gpu": n_local, "genome_length": length, "k": args.k,
-                       "sketch_size": args.s if mode == "minhash" else round(avg_len, 1), "sharding": f"rows/{world}",
-                       "collectives": comm_kind,
-                       "pair_phase": ("inverted join on the device (rtc_pairs_join.hip): exact |A n B| of every pair that shares a hash, "
-                                      "the reference's own algorithm (src/MST.cpp:1408-1435); pairs that share none carry no edge there "
-                                      "either (:1468), nothing of the step is skipped or cached between steps"
-                                      if pair_path == 3 else
-                                      "tiled N x N kernel (rtc_pairs_tiled.hip): every pair probed"),
-                       "scaling_note": "weak in genomes: per-GPU genomes (and sketch work) fixed as N grows; the pair "
-                                       "space is (N x genomes_per_gpu)^2/2, so pairs per GPU grow with N",
-                       "value_note": "value = N(N-1)/2 pairs / step time, and the step is ~97 % O(N) sketching: the figure grows "
-                                     "with the genome count by construction (6.2e8 at 10 000 genomes, 7.8e8 at 12 500); "
-                                     "sketch_gbp_per_sec is the size-independent headline, dist_pairs_per_sec and "
-                                     "extra.dense_pairs the distance half"},
+                                   f"sketch + all-pairs + MST at d={args.threshold}"
+                                   + (f" (BASELINE configs[{NORTH_STAR[mode]['config']}], the same genomes at every N)" if scaling == "strong" and not args.genomes else ""),
+                       "genomes_total": n_total, "genomes_per_gpu": n_local, "genome_length": length, "k": args.k,
+                       "sketch_size": args.s if mode == "minhash" else round(avg_len, 1), "staging": args.staging, "sharding": f"rows/{world}",
+                       "collectives": comm_kind, "pair_path": {3: "inverted join (rtc_pairs_join.hip)", 2: "tiled kernel (rtc_pairs_tiled.hip)"}.get(pair_path, "merge kernel"),
+                       "batches_per_gpu": n_batches},
             "sketch_gbp_per_sec": bases_total / (sk_ms * 1e-3) / 1e9,
             "dist_pairs_per_sec": pairs / (ph["dist_ms"] * 1e-3),
             "per_gpu": {"sketch_gbp_per_sec": float(n_local) * length / (sk_ms * 1e-3) / 1e9,
                         "genome_pairs_per_sec": pairs / (dt / args.steps) / world,
-                        "dist_pairs_per_sec_rank0": dist_pairs_local / (ph["dist_ms"] * 1e-3),
-                        "note": "rank 0's phases; N=1 runs 10 000 genomes (configs[1]), N>1 12 500 per GPU (configs[2] at N=8): "
-                                "extra.weak_first_point of the N=1 line is the 12 500-genome load on one GPU"},
+                        "dist_pairs_per_sec_rank0": ph["pairs_local"] / (ph["dist_ms"] * 1e-3)},
             "phase_ms": ph,
-            "mst_edges": int(phases[-1]["mst_edges"]),
-            "roofline": {"bound": "hbm", "kernel": sk_kernel, "achieved": achieved,
+            "mst_edges": int(phases[-1]["mst_edges"]), "clusters": int(phases[-1]["clusters"]),
+            "roofline": {"bound": "hbm", "kernel": sk_kernel + ("<21, false>" if mode == "minhash" and args.k == 21 else ""), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": sk_traffic, "valu_issue": measured_valu(sk_kernel, wl),
-                         "note": "algorithmic bytes = 1 B/base + %d B/hash out per launch; traffic = rocprofv3 PMC "
-                                 "bytes per launch (profiles/%s); the kernel is integer-VALU-issue bound, "
-                                 "see DESIGN.md 3.1" % (width, sk_src)},
+                         "traffic": sk_traffic, "traffic_source": ("profiles/" + sk_src) if sk_src else None,
+                         "kernel_ms": sk_ms / n_batches, "launches_per_step": n_batches,
+                         "algorithmic_bytes_per_launch": algo_bytes / n_batches,
+                         "valu_issue": measured_valu(sk_kernel, wl)},
             "roofline_dist": {"bound": "hbm", "kernel": pr_kernel, "achieved": pr_ach, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": (pr_ach / HBM_PEAK_GBS) if pr_ach else None,
-                              "traffic": pr_traffic, "algorithmic_achieved": dist_algo,
-                              "algorithmic_frac": dist_algo / HBM_PEAK_GBS,
-                              "survey_8d_bytes_per_pair": survey_bytes_pair, "survey_8d_achieved": survey_8d,
-                              "survey_8d_frac": survey_8d / HBM_PEAK_GBS, "note": dist_note},
+                              "traffic": pr_traffic, "traffic_source": ("profiles/" + pr_src) if pr_src else None,
+                              "records_achieved": hashes_local * world * (width + 4) / (ph["pair_ms"] * 1e-3) / 1e9,
+                              "survey_8d_bytes_per_pair": survey_bytes_pair,
+                              "survey_8d_achieved": ph["pairs_local"] * survey_bytes_pair / (ph["pair_ms"] * 1e-3) / 1e9},
         }
         if packed:
             phys = float(n_local) * length / 4 + hashes_local * width
             line["roofline"]["physical_achieved"] = phys / (sk_ms * 1e-3) / 1e9
             line["roofline"]["physical_frac"] = line["roofline"]["physical_achieved"] / HBM_PEAK_GBS
-            line["roofline"]["note"] += ("; the batch is resident at 2 bits a base: achieved/frac keep SURVEY 8(d)'s 1 B/base, "
-                                         "physical_* = the 0.25 B/base the kernel reads")
+        if scaling == "strong":
+            line["first_step_s"], line["setup_s"] = first, t_setup
         if ranks_ph:
             keys = ("sketch_ms", "gather_ms", "pair_ms", "mst_ms", "dist_ms", "cand_edges", "pairs_local")
             s_fixed = pipe.fixed_size(sk_all)
@@ -963,27 +1149,49 @@ def main():
             line["per_rank"] = {
                 "phase_ms_min": {k: min(r[k] for r in ranks_ph) for k in keys},
                 "phase_ms_max": {k: max(r[k] for r in ranks_ph) for k in keys},
-                "gather_ms_exposed_max": max(r["gather_ms"] for r in ranks_ph),
                 "boruvka_rounds": rounds,
-                "all_reduce_bytes_per_step": rounds * n_total * (8 if s_fixed else 20),
-                "note": "gather_ms = what is left of the sketch all-gather after the local sketching (the first 80 % travel beside "
-                        "the second sketch launch); every Boruvka round all-reduces (MIN) one u64[n] key array when all sketches "
-                        "have one size, else u64 + u64 + u32 arrays; cand_edges / pairs_local are per-rank counts (row ranges of "
-                        "equal cost, not equal pairs)"}
+                "all_reduce_bytes_per_step": rounds * n_total * (8 if s_fixed else 20)}
         if not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(args, mode, cpu_seq, off, pipe.last_sketches.to_host()[:n_local], shuffled)
-                if world > 1:
-                    line["cpu_baseline"]["sample"] += " -- rank 0's genomes and host cores only, timed after the multi-GPU region"
+                if cpu_seq is None:  # strong scaling: rank 0's first genomes again as characters
+                    ns_cpu = min(args.cpu_sample_genomes or 1024, n_local)
+                    cpu_off = np.arange(ns_cpu + 1, dtype=np.uint64) * np.uint64(length)
+                    cpu_seq = ctx.synth_genomes(north_star_descs(api, mode, 0, ns_cpu), cpu_off)
+                    ctx.sync()
+                npair = min(args.cpu_sample_sketches, n_local)
+                stride = sk_all.hashes.numel() // sk_all.n
+                sub = api.SketchSet(sk_all.hashes.view(sk_all.n, stride)[:npair].reshape(-1), sk_all.start[:npair], sk_all.len[:npair],
+                                    width, sk_all.k, sk_all.kind)
+                line["cpu_baseline"] = cpu_baseline(args, mode, cpu_seq, cpu_off, sub.to_host(), shuffled)
+                if scaling == "strong":  # the whole job on this box's host cores, by the fitted law
+                    _cpu_extrapolation(line.setdefault("job_vs_cpu", {"total_s": dt / args.steps}), n_total, length, pairs, line["cpu_baseline"])
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
-        if world == 1 and not args.no_extra and mode == "minhash" and not args.genomes and not args.length:
-            args._cpu_minhash = line.get("cpu_baseline")
-            del seq
-            pipe.last_sketches = None
+        del cpu_seq
+        # ---- the evidence: the compact headline at once, the extras after it, the compact headline again as the LAST line ----
+        emit(compact_line(line))
+        want_extra = world == 1 and dist is None and not args.no_extra and mode == "minhash" and not args.genomes and not args.length and scaling == "weak"
+        extras = None
+        if want_extra:
+            seq = batches = pb = None
+            pipe.last_sketches = pipe._rows = None
+            pipe = None
+            if nat is not None:
+                nat.close()
+                nat = None
+            import gc
+            gc.collect()
             torch.cuda.empty_cache()
-            line["extra"] = extra_workloads(args, ctx, api, pipeline)
-        print(json.dumps(line))
+            args._headline_staging = args.staging
+            extras = extra_workloads(args, ctx, api, pipeline)
+        full = sanitize({"headline": line, "extra": extras} if extras is not None else {"headline": line})
+        emit(full)
+        try:
+            with open(args.extra_json, "w") as f:
+                json.dump(full, f, indent=1)
+        except OSError as e:
+            print(f"bench.py: could not write {args.extra_json}: {e}", file=sys.stderr)
+        emit(compact_line(line, extras))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

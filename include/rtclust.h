@@ -116,7 +116,9 @@ int rtc_sketch_minhash_dev(rtc_ctx* ctx, const uint8_t* d_seq, const uint64_t* h
  * (record separators and the gaps between genomes are runs too): a k-mer counts exactly when none of its k characters
  * lies in a run nor outside its genome's [h_off[g], h_off[g + 1]) -- what update() does with a character outside ACGT.
  * Every k in 1..32 and every sketch size; everything else as rtc_sketch_minhash_dev, whose results it reproduces bit
- * for bit. */
+ * for bit.  The run list's contract is checked on the device beside the sketching (no host round trip): a violation is
+ * reported as RTC_ERR_ARG by rtc_ctx_sync -- call it before the sketches of a packed batch are consumed -- or, failing
+ * that, by the next packed call on the context. */
 int rtc_sketch_minhash_packed_dev(rtc_ctx* ctx, const uint8_t* d_packed, uint64_t n_bases, const uint64_t* d_runs,
                                   uint64_t n_runs, const uint64_t* h_off, uint32_t n, int k, uint32_t seed,
                                   const uint32_t* h_sizes, uint32_t size, uint64_t* d_out, uint32_t stride,
@@ -200,6 +202,11 @@ int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width, const uint
 /* Which path the last rtc_pair_edges_dev of this context took: 0 none yet, 1 per-pair merge kernel,
  * 2 tiled kernel, 3 inverted join (measurement: bench.py names the kernels of the pair phase by it). */
 int rtc_pair_last_path(const rtc_ctx* ctx);
+/* Which paths this context has taken since it was created (tests and measurement): out[0] tiles the inverted join took,
+ * out[1] tiles the tiled kernel took, out[2] tiles of the merge kernel, out[3] candidate lists contracted to their forest
+ * between row chunks, out[4] greedy runs replayed from one global join, out[5] query blocks of greedy's block loop, out[6]
+ * estimates rtc_pair_edges_dev handed back instead of a launch; out[7] reserved. */
+int rtc_diag_counters(const rtc_ctx* ctx, uint64_t out[8]);
 /* Duration of this context's last tiled pair kernel launch (rtc_pair_last_path == 2), from HIP events recorded on the
  * stream it was launched on; waits for the launch to finish (measurement: bench.py's roofline_dist). */
 int rtc_pair_last_kernel_ms(rtc_ctx* ctx, float* ms_out);
@@ -341,6 +348,30 @@ int rtc_triangle_rows(uint32_t n, int world, double fixed_cols, uint32_t* h_boun
 int rtc_sketch_minhash_sharded(rtc_ctx* ctx, rtc_comm* comm, const uint8_t* d_seq, const uint64_t* h_off,
                                uint32_t n_local, int k, uint32_t seed, const uint32_t* h_sizes, uint32_t size,
                                uint64_t* d_out_global, uint32_t stride, uint32_t* d_cnt_global);
+/* The same phase for a rank whose genomes are resident as batches in the 2-bit staging format (layout: rtc_unpack_bases_dev;
+ * what both command lines stage, src/SketchInfo.cpp:928-948 being the records they hold): one call per batch, in the order
+ * of the rank's rows.  The batch's n_batch genomes become rows [row_first, row_first + n_batch) of this rank's block of
+ * n_local rows; they are sketched straight from the packed bases (rtc_sketch_minhash_packed_dev) and their gather starts on
+ * the communicator's side stream behind the sketch kernel, i.e. it travels beside the NEXT batch's kernel.  last != 0 marks
+ * the rank's final batch: it is cut in two parts (as rtc_sketch_minhash_sharded cuts a rank's genomes) and the call returns
+ * with the context stream waiting for every gather.  Every rank passes the same sequence of (row_first, n_batch) and the
+ * same n_local / stride (checked on the first batch).  With one rank the calls sketch into the rows and nothing travels. */
+int rtc_sketch_minhash_packed_sharded(rtc_ctx* ctx, rtc_comm* comm, const uint8_t* d_packed, uint64_t n_bases,
+                                      const uint64_t* d_runs, uint64_t n_runs, const uint64_t* h_off, uint32_t n_batch,
+                                      uint32_t row_first, uint32_t n_local, int last, int k, uint32_t seed,
+                                      const uint32_t* h_sizes, uint32_t size, uint64_t* d_out_global, uint32_t stride,
+                                      uint32_t* d_cnt_global);
+/* --fast: sketchFileWithKssd (src/SketchInfo.cpp:994-1252) over the rank's packed batches, same protocol
+ * (rtc_sketch_kssd_packed_dev per batch).  d_out_global: size * n_local * stride tuples of *width_out bytes (4 or 8,
+ * src/SketchInfo.cpp:1021).  KSSD sketches vary in length and the rows travel at the caller's stride, so a tight one saves
+ * link time.  A batch whose longest sketch exceeds the stride is still gathered -- the ranks' collectives stay matched --
+ * and the call with last != 0 returns RTC_ERR_OVERFLOW on EVERY rank with *h_need = the longest sketch any rank produced;
+ * the caller repeats the phase with wider rows. */
+int rtc_sketch_kssd_packed_sharded(rtc_ctx* ctx, rtc_comm* comm, const uint8_t* d_packed, uint64_t n_bases,
+                                   const uint64_t* d_runs, uint64_t n_runs, const uint64_t* h_off, uint32_t n_batch,
+                                   uint32_t row_first, uint32_t n_local, int last, int kmer_size, int drlevel,
+                                   const int32_t* h_shuffled_dim, void* d_out_global, uint32_t stride,
+                                   uint32_t* d_cnt_global, int* width_out, uint32_t* h_need);
 typedef struct {
   uint32_t row0, row1;  /* this rank's rows of the pair space */
   uint64_t cand_edges;  /* candidate edges it produced */

@@ -77,6 +77,7 @@ SIGNATURES = {
     "rtc_pair_mash_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u64]),
     "rtc_extract_edges_dev": (_i, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _vp, _i, _vp, _u64, _vp]),
     "rtc_pair_last_path": (_i, [_vp]),
+    "rtc_diag_counters": (_i, [_vp, _vp]),
     "rtc_pair_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_float)]),
     "rtc_pair_edges_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _i, _vp, _u64, _vp]),
     "rtc_boruvka_key_bits": (_i, [_u32, _u32]),
@@ -103,6 +104,10 @@ SIGNATURES = {
     "rtc_comm_broadcast": (_i, [_vp, _vp, C.c_size_t, _i]),
     "rtc_triangle_rows": (_i, [_u32, _i, C.c_double, _vp]),
     "rtc_sketch_minhash_sharded": (_i, [_vp, _vp, _vp, _vp, _u32, _i, _u32, _vp, _u32, _vp, _u32, _vp]),
+    "rtc_sketch_minhash_packed_sharded": (_i, [_vp, _vp, _vp, _u64, _vp, _u64, _vp, _u32, _u32, _u32, _i, _i, _u32, _vp, _u32, _vp,
+                                               _u32, _vp]),
+    "rtc_sketch_kssd_packed_sharded": (_i, [_vp, _vp, _vp, _u64, _vp, _u64, _vp, _u32, _u32, _u32, _i, _i, _i, _vp, _vp, _u32, _vp,
+                                            C.POINTER(_i), C.POINTER(_u32)]),
     "rtc_mst_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64), _vp]),
     "rtc_mst": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64)]),
     "rtc_mst_append": (_i, [_vp, _vp, _i, _vp, _vp, _u32, _u32, _i, _i, C.c_double, _vp, C.POINTER(_u64)]),

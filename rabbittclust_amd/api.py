@@ -154,6 +154,13 @@ class Context:
         """Path of the last pair_edges call: 0 none, 1 merge kernel, 2 tiled kernel, 3 inverted join."""
         return int(self.lib.rtc_pair_last_path(self.h))
 
+    def diag(self):
+        """rtc_diag_counters as a dict: which paths this context has taken since it was created"""
+        a = (C.c_uint64 * 8)()
+        self.check(self.lib.rtc_diag_counters(self.h, a))
+        names = ("join_tiles", "tiled_tiles", "merge_tiles", "contractions", "greedy_global", "greedy_blocks", "estimates")
+        return {k: int(a[i]) for i, k in enumerate(names)}
+
     def pair_last_kernel_ms(self):
         """Duration of the last tiled pair kernel launch (HIP events on its launch stream)."""
         ms = C.c_float()
@@ -387,6 +394,63 @@ class Context:
             _np_ptr(sizes) if sizes is not None else None, int(size), _t_ptr(out), max(stride, 1), _t_ptr(cnt)))
         start = torch.arange(n, dtype=torch.int64, device=self.device) * max(stride, 1)
         return SketchSet(out.view(-1), start, cnt[:n], 8, k, "minhash")
+
+    def sketch_packed_sharded(self, comm, batches, mode="minhash", k=21, size=1000, seed=42, drlevel=3, shuffled_dim=None,
+                              stride=None, out=None, cnt=None):
+        """Multi-GPU sketch phase behind the C ABI for a rank whose genomes are resident as batches in the 2-bit staging
+        format: `batches` = [(PackedBatch, off), ...] in the order of the rank's rows (every rank: the same batch sizes).
+        rtc_sketch_minhash_packed_sharded / rtc_sketch_kssd_packed_sharded per batch; a batch's gather travels beside the
+        next batch's sketch kernel.  Returns the global SketchSet (comm.size * n_local genomes, canonical order).
+        `out` / `cnt`: caller-provided global rows (reused between steps)."""
+        offs = [np.ascontiguousarray(o, dtype=np.uint64) for _, o in batches]
+        n_local = sum(len(o) - 1 for o in offs)
+        n = comm.size * n_local
+        kssd = mode == "kssd"
+        if kssd:
+            sd = np.ascontiguousarray(shuffled_dim, dtype=np.int32)
+            half_k = (k + 1) // 2
+            width = 8 if half_k - drlevel > 8 else 4
+            kk = half_k * 2
+            if stride is None:  # 1.25 x the expected count of the longest genome: ample for genomes of one length
+                longest = max(int((o[1:] - o[:-1]).max()) for o in offs)
+                stride = (int(longest / (16 ** drlevel) * 1.25) + 64 + 3) // 4 * 4
+                stride = int(comm.all_reduce_host([stride], "max")[0])
+        else:
+            width, kk = 8, k
+            stride = int(size) if stride is None else int(stride)
+        t_dt = torch.int64 if width == 8 else torch.int32
+        while True:
+            if out is None or out.shape != (max(n, 1), stride) or out.dtype != t_dt:
+                out = torch.empty((max(n, 1), stride), dtype=t_dt, device=self.device)
+                cnt = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+            row = 0
+            st = _lib.RTC_OK
+            need = C.c_uint32()
+            for i, ((pb, _), off) in enumerate(zip(batches, offs)):
+                nb = len(off) - 1
+                last = int(i == len(batches) - 1)
+                n_runs = int(pb.runs.numel() // 2) if pb.runs is not None else 0
+                runs = _t_ptr(pb.runs) if n_runs else None
+                if kssd:
+                    w = C.c_int()
+                    st = self.lib.rtc_sketch_kssd_packed_sharded(self.h, comm.h, _t_ptr(pb.packed), pb.n_bases, runs, n_runs, _np_ptr(off), nb,
+                                                                 row, n_local, last, k, drlevel, _np_ptr(sd), _t_ptr(out), stride,
+                                                                 _t_ptr(cnt), C.byref(w), C.byref(need))
+                else:
+                    st = self.lib.rtc_sketch_minhash_packed_sharded(self.h, comm.h, _t_ptr(pb.packed), pb.n_bases, runs, n_runs, _np_ptr(off),
+                                                                    nb, row, n_local, last, k, seed, None, int(size), _t_ptr(out), stride,
+                                                                    _t_ptr(cnt))
+                if st != _lib.RTC_OK:
+                    break
+                row += nb
+            if kssd and st == _lib.RTC_ERR_OVERFLOW:  # every rank got it, with the same need: wider rows, once more
+                stride = (int(need.value) + 64 + 3) // 4 * 4
+                out = None
+                continue
+            self.check(st)
+            break
+        start = torch.arange(n, dtype=torch.int64, device=self.device) * stride
+        return SketchSet(out.view(-1), start, cnt[:n], width, kk, "kssd" if kssd else "minhash")
 
     def mst_sharded(self, comm, sk, threshold, is_containment=False):
         """rtc_mst across the ranks of `comm`; returns (edge.mst records, ShardStats)."""

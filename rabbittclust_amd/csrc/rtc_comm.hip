@@ -156,6 +156,8 @@ struct rtc_comm {
   bool side_front_pending = false;
   bool side_busy = false;
   bool broken = false;             // a collective timed out and the communicator was aborted
+  uint32_t kssd_need = 0;          // rtc_sketch_kssd_packed_sharded: longest sketch of this rank's batches so far
+  int kssd_width = 0;              // ... and the tuple width they came out with
 };
 
 #define RTC_NCCL(ctx, call)                                                                     \
@@ -218,7 +220,18 @@ int comm_watch(rtc_comm* c, hipStream_t stream, const char* what) {
     if (e != hipErrorNotReady) return rtc_fail(ctx, RTC_ERR_HIP, "%s: hipEventQuery -> %s", what, hipGetErrorString(e));
     if (!reached) {
       const hipError_t f = hipEventQuery(front);
-      if (f == hipErrorNotReady) { if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50)); continue; }
+      if (f == hipErrorNotReady) {
+        // the stream has not arrived yet: work queued ahead of the collective is running.  That wait is not charged to the
+        // peers, but it is bounded too (ten limits): a kernel that never ends, or a side stream stuck behind an earlier
+        // collective nobody watched, must not keep the host here forever.
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0 * limit) {
+          if (const Rccl* nc = rccl()) (void)nc->CommAbort(c->nccl);
+          c->nccl = nullptr;
+          return comm_broken(c, what);
+        }
+        if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        continue;
+      }
       reached = true;  // (an event never recorded reads as complete: the clock then starts at once, as before)
       t0 = std::chrono::steady_clock::now();
     }
@@ -292,9 +305,16 @@ int comm_gather_rows_on(rtc_comm* c, void* d_global, size_t row_bytes, uint32_t 
     for (int r = 0; r < c->size; r++) {
       char* p = (char*)d_global + ((size_t)r * n_local + a) * row_bytes;
       ncclResult_t st = nc__->Broadcast(p, p, bytes, ncclInt8, r, c->nccl, stream);
-      if (st != ncclSuccess) { (void)nc__->GroupEnd(); return rtc_fail(ctx, RTC_ERR_HIP, "ncclBroadcast -> %s", nc__->GetErrorString(st)); }
+      if (st != ncclSuccess) {
+        (void)nc__->GroupEnd();
+        c->side_front_pending = false;
+        return rtc_fail(ctx, RTC_ERR_HIP, "ncclBroadcast -> %s", nc__->GetErrorString(st));
+      }
     }
-    RTC_NCCL(ctx, nc__->GroupEnd());
+    if (ncclResult_t st = nc__->GroupEnd(); st != ncclSuccess) {
+      c->side_front_pending = false;
+      return rtc_fail(ctx, RTC_ERR_HIP, "ncclGroupEnd -> %s", nc__->GetErrorString(st));
+    }
     return stream == c->side ? RTC_OK : comm_watch(c, stream, "gather");  // side stream: rtc_comm_wait watches it
   }
   LocalGroup& g = *c->local;
@@ -511,6 +531,99 @@ int rtc_sketch_minhash_sharded(rtc_ctx* ctx, rtc_comm* c, const uint8_t* d_seq, 
   return rtc_comm_wait(c);
 }
 
+// The same phase for a rank whose genomes are resident as batches in the 2-bit staging format (the command lines' form;
+// north_star's "packed sequence"): one call per batch, in the order of the rank's rows.  Batch rows [row_first,
+// row_first + n_batch) of this rank's block are sketched straight from the packed bases and their gather is started on the
+// side stream behind the sketch kernel, so it travels beside the NEXT batch's kernel; the last batch (last != 0) is cut in
+// two parts like the character form, and the call returns with the context stream waiting for every gather.  Every rank
+// passes the same sequence of (row_first, n_batch).
+namespace {
+int sharded_shape_check(rtc_ctx* ctx, rtc_comm* c, uint32_t n_local, uint32_t stride, uint32_t n_batch) {
+  int64_t v[6] = {(int64_t)n_local, -(int64_t)n_local, (int64_t)stride, -(int64_t)stride, (int64_t)n_batch, -(int64_t)n_batch};
+  RTC_TRY(rtc_comm_all_reduce_host(c, v, 6, 1));
+  if (v[0] != (int64_t)n_local || -v[1] != (int64_t)n_local || v[2] != (int64_t)stride || -v[3] != (int64_t)stride ||
+      v[4] != (int64_t)n_batch || -v[5] != (int64_t)n_batch)
+    return rtc_fail(ctx, RTC_ERR_ARG, "ranks disagree on genomes per rank (%u here, %lld..%lld), stride (%u here, %lld..%lld) or first batch "
+                    "(%u here, %lld..%lld)", n_local, (long long)-v[1], (long long)v[0], stride, (long long)-v[3], (long long)v[2],
+                    n_batch, (long long)-v[5], (long long)v[4]);
+  return RTC_OK;
+}
+// the two parts of a rank's last batch: the first a whole number of full rounds of the sketch kernel (one genome per
+// workgroup slot) so that the extra launch boundary costs no idle tail
+uint32_t last_batch_split(const rtc_ctx* ctx, const rtc_comm* c, uint32_t n_batch) {
+  if (c->size <= 1 || n_batch < 8) return n_batch;
+  const uint32_t slots = 3u * (uint32_t)ctx->num_cu;
+  return n_batch >= 2 * slots ? std::max(slots, (uint32_t)(0.8 * n_batch) / slots * slots) : (3 * n_batch) / 4;
+}
+}  // namespace
+
+int rtc_sketch_minhash_packed_sharded(rtc_ctx* ctx, rtc_comm* c, const uint8_t* d_packed, uint64_t n_bases, const uint64_t* d_runs,
+                                      uint64_t n_runs, const uint64_t* h_off, uint32_t n_batch, uint32_t row_first, uint32_t n_local,
+                                      int last, int k, uint32_t seed, const uint32_t* h_sizes, uint32_t size, uint64_t* d_out_global,
+                                      uint32_t stride, uint32_t* d_cnt_global) {
+  if (!ctx || !c || c->ctx != ctx || !h_off || (n_batch && (!d_packed || !d_out_global || !d_cnt_global))) return RTC_ERR_ARG;
+  if ((uint64_t)row_first + n_batch > n_local) return rtc_fail(ctx, RTC_ERR_ARG, "batch rows [%u, %u) outside the rank's %u rows", row_first, row_first + n_batch, n_local);
+  if (row_first == 0) RTC_TRY(sharded_shape_check(ctx, c, n_local, stride, n_batch));  // the canonical order needs identical block shapes
+  uint64_t* my_out = d_out_global + ((size_t)c->rank * n_local + row_first) * stride;
+  uint32_t* my_cnt = d_cnt_global + (size_t)c->rank * n_local + row_first;
+  const uint32_t parts[3] = {0, last ? last_batch_split(ctx, c, n_batch) : n_batch, n_batch};
+  for (int p = 0; p < 2; p++) {
+    const uint32_t a = parts[p], b = parts[p + 1];
+    if (b <= a) continue;
+    RTC_TRY(rtc_sketch_minhash_packed_dev(ctx, d_packed, n_bases, d_runs, n_runs, h_off + a, b - a, k, seed, h_sizes ? h_sizes + a : nullptr,
+                                          size, my_out + (size_t)a * stride, stride, my_cnt + a));
+    RTC_TRY(rtc_comm_gather_rows(c, d_out_global, (size_t)stride * 8, n_local, row_first + a, row_first + b, 1));
+    RTC_TRY(rtc_comm_gather_rows(c, d_cnt_global, 4, n_local, row_first + a, row_first + b, 1));
+  }
+  return last ? rtc_comm_wait(c) : RTC_OK;
+}
+
+// --fast: sketchFileWithKssd (src/SketchInfo.cpp:994-1252) over the rank's packed batches, same protocol.  KSSD sketches vary
+// in length: the rows travel at the caller's `stride` (a tight one saves link time: 1.25 x the expected count is ample for
+// genomes of one length).  A batch whose longest sketch exceeds it is still gathered -- the collectives of all ranks stay
+// matched -- and the call with last != 0 returns RTC_ERR_OVERFLOW on EVERY rank with *h_need = the longest sketch any rank
+// produced; the caller then repeats the phase with wider rows.  *width_out: 4 or 8, identical on all ranks.
+int rtc_sketch_kssd_packed_sharded(rtc_ctx* ctx, rtc_comm* c, const uint8_t* d_packed, uint64_t n_bases, const uint64_t* d_runs,
+                                   uint64_t n_runs, const uint64_t* h_off, uint32_t n_batch, uint32_t row_first, uint32_t n_local,
+                                   int last, int kmer_size, int drlevel, const int32_t* h_shuffled_dim, void* d_out_global,
+                                   uint32_t stride, uint32_t* d_cnt_global, int* width_out, uint32_t* h_need) {
+  if (!ctx || !c || c->ctx != ctx || !h_off || !width_out || (n_batch && (!d_packed || !d_out_global || !d_cnt_global))) return RTC_ERR_ARG;
+  if ((uint64_t)row_first + n_batch > n_local) return rtc_fail(ctx, RTC_ERR_ARG, "batch rows [%u, %u) outside the rank's %u rows", row_first, row_first + n_batch, n_local);
+  if (row_first == 0) {
+    RTC_TRY(sharded_shape_check(ctx, c, n_local, stride, n_batch));
+    c->kssd_need = 0;
+    c->kssd_width = 0;
+  }
+  const int width = ((kmer_size + 1) / 2 - drlevel > 8) ? 8 : 4;  // src/SketchInfo.cpp:1021
+  char* my_out = (char*)d_out_global + ((size_t)c->rank * n_local + row_first) * stride * width;
+  uint32_t* my_cnt = d_cnt_global + (size_t)c->rank * n_local + row_first;
+  const uint32_t parts[3] = {0, last ? last_batch_split(ctx, c, n_batch) : n_batch, n_batch};
+  int failed = RTC_OK;
+  for (int p = 0; p < 2; p++) {
+    const uint32_t a = parts[p], b = parts[p + 1];
+    if (b <= a) continue;
+    uint32_t need = 0;
+    int w = width;
+    const int st = rtc_sketch_kssd_packed_dev(ctx, d_packed, n_bases, d_runs, n_runs, h_off + a, b - a, kmer_size, drlevel, h_shuffled_dim,
+                                              my_out + (size_t)a * stride * width, stride, my_cnt + a, &w, &need);
+    if (st == RTC_OK || st == RTC_ERR_OVERFLOW) { c->kssd_need = std::max(c->kssd_need, need); c->kssd_width = w; }
+    else if (failed == RTC_OK) failed = st;  // (an argument error: every rank sees it; a device fault: nothing to save)
+    if (failed != RTC_OK) break;
+    RTC_TRY(rtc_comm_gather_rows(c, d_out_global, (size_t)stride * width, n_local, row_first + a, row_first + b, 1));
+    RTC_TRY(rtc_comm_gather_rows(c, d_cnt_global, 4, n_local, row_first + a, row_first + b, 1));
+  }
+  *width_out = width;
+  if (failed != RTC_OK) return failed;
+  if (!last) return RTC_OK;
+  RTC_TRY(rtc_comm_wait(c));
+  int64_t v[3] = {(int64_t)c->kssd_need, (int64_t)c->kssd_width, -(int64_t)c->kssd_width};
+  RTC_TRY(rtc_comm_all_reduce_host(c, v, 3, 1));
+  if (h_need) *h_need = (uint32_t)v[0];
+  if (v[1] != -v[2]) return rtc_fail(ctx, RTC_ERR_ARG, "ranks disagree on the KSSD tuple width (%lld / %lld)", (long long)v[1], (long long)-v[2]);
+  if (v[0] > (int64_t)stride) return rtc_fail(ctx, RTC_ERR_OVERFLOW, "a genome produced %lld KSSD tuples on some rank, the rows hold %u", (long long)v[0], stride);
+  return RTC_OK;
+}
+
 // compute_minhash_mst / compute_kssd_mst (src/MST.cpp:1290-1737, :216-807) across the ranks of `c`:
 // this rank evaluates its row range of the pair space, the Boruvka rounds all-reduce their key
 // arrays, every rank returns the identical forest (identical to rtc_mst on one GPU: the total order
@@ -557,6 +670,8 @@ int rtc_mst_sharded(rtc_ctx* ctx, rtc_comm* c, const void* d_hashes, int width, 
     st = rtc_candidate_edges_device(ctx, d_hashes, width, d_start, d_len, n, row0, row1, kmer_size, is_containment,
                                     threshold, s_fixed, &el);
     (void)hipEventRecord(e1, ctx->stream);
+    // (the count read-backs above have synchronised the stream: a packed batch whose run list broke its contract is known by now)
+    if (st == RTC_OK) st = rtc_sticky_error(ctx);
   }
   uint64_t nsel = 0;
   int rounds = 0;

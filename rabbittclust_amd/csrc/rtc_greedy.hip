@@ -254,11 +254,13 @@ extern "C" int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const u
         if (fetch_status != RTC_OK) { cleanup(); return fetch_status; }
       }
       global_done = true;
+      ctx->diag[4]++;
     }
   }
 
   for (uint32_t q0 = 1; q0 < n && !global_done; q0 += B) {
     const uint32_t q1 = std::min(n, q0 + B), nb = q1 - q0;
+    ctx->diag[5]++;
     const uint32_t nr = (uint32_t)reps.size();
     const uint32_t nv = nr + nb;
     // virtual sketch set: [representatives in creation order..., this batch in processing order...]

@@ -63,6 +63,10 @@ struct rtc_ctx {
   // launches (the row-chunk loop of the dense candidate-edge path).
   int quiet = 0;           // rtc_warmup's context: no RTC_VERBOSE lines
   int pair_last_path = 0;  // rtc_pair_last_path
+  // rtc_diag_counters: [0] pair tiles the join took, [1] tiled-kernel tiles, [2] merge-kernel tiles, [3] candidate lists contracted
+  // to their forest, [4] greedy runs replayed from ONE global join, [5] greedy query blocks of the block loop, [6] estimates handed
+  // back instead of a launch (rtc_pair_edges_dev's overflow protocol)
+  uint64_t diag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // the inverted join's last refusal for density: the input it counted
   // keyed on the sketch buffer, its generation (every sketch / gather call on this context bumps sketch_gen) and the tile
   struct { const void* hashes = nullptr; uint64_t gen = 0; uint32_t n = 0, row0 = 0, row1 = 0, col0 = 0, col1 = 0; uint64_t K = 0, maxkey = 0; uint64_t edges_hint = 0; /* set by a refusal from the sample, for this call only: candidate edges to expect */ } join_dense;

@@ -479,14 +479,16 @@ int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, co
   };
   unsigned long long cnt = 0;
   RTC_TRY(run_rows(row0, row1, &cnt));
-  if (cnt <= el->cap) {
-    el->m = cnt;
-    if (obs && cnt) RTC_TRY(obs->on_new(obs->self, el->d_edges, cnt));
-    return RTC_OK;
-  }
-  if (cnt <= budget) {  // grow to the exact need and redo the launch
-    RTC_TRY(ensure(cnt));
+  // A count past the capacity is either exact (the kernel ran and dropped what did not fit) or the join's ESTIMATE from its
+  // density sample (nothing ran, rtc_pair_edges_dev): grow to it and launch again -- the repeated call always runs to the end
+  // and counts exactly, and when the estimate was short that exact count can be past the grown list too (or past the
+  // budget: the chunked path below).  Two rounds settle every case; the bound only keeps a broken counter from looping.
+  for (int redo = 0; cnt > el->cap && cnt <= budget; redo++) {
+    if (redo == 3) return rtc_fail(ctx, RTC_ERR_HIP, "candidate edge count %llu still past the list (%llu) after three launches", cnt, (unsigned long long)el->cap);
+    RTC_TRY(ensure(std::min<uint64_t>(budget, cnt + cnt / 16)));
     RTC_TRY(run_rows(row0, row1, &cnt));
+  }
+  if (cnt <= el->cap) {
     el->m = cnt;
     if (obs && cnt) RTC_TRY(obs->on_new(obs->self, el->d_edges, cnt));
     return RTC_OK;
@@ -507,6 +509,7 @@ int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, co
     RTC_HIP(ctx, hipMemcpyAsync(el->d_edges, d_sel, ns * sizeof(rtc_cedge), hipMemcpyDeviceToDevice, ctx->stream));
     el->m = ns;
     el->contractions++;
+    ctx->diag[3]++;
     return RTC_OK;
   };
   while (r0 < row1 && st == RTC_OK) {
@@ -912,6 +915,7 @@ int rtc_mst_mash(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* 
       if (st != RTC_OK) break;
       if (hipMemcpyAsync(d_edges, d_sel, nsel * sizeof(rtc_cedge), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { st = rtc_fail(ctx, RTC_ERR_HIP, "forest copy"); break; }
       m = nsel;
+      ctx->diag[3]++;
     }
     hipLaunchKernelGGL(all_pairs_edges_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>((r1 + 255) / 256, 64)), std::min<uint32_t>(r1 - r0, 4096)),
                        dim3(256), 0, ctx->stream, d_common, (uint64_t)n, r0, r1, d_edges + m);

@@ -146,6 +146,11 @@ extern "C" int rtc_pair_common_dev(rtc_ctx* ctx, const void* d_hashes, int width
 namespace { __global__ void add_count_kernel(unsigned long long* count, unsigned long long add) { *count += add; } }
 
 extern "C" int rtc_pair_last_path(const rtc_ctx* ctx) { return ctx ? ctx->pair_last_path : 0; }
+extern "C" int rtc_diag_counters(const rtc_ctx* ctx, uint64_t out[8]) {
+  if (!ctx || !out) return RTC_ERR_ARG;
+  for (int i = 0; i < 8; i++) out[i] = ctx->diag[i];
+  return RTC_OK;
+}
 
 extern "C" int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start,
                                   const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0,
@@ -160,7 +165,7 @@ extern "C" int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width,
   if (!ctx->opt.pair_force_merge) {
     RTC_TRY(rtc_pair_edges_join(ctx, d_hashes, width, d_start, d_len, n, row0, row1, col0, col1, radio, d_edges, cap, d_count,
                                 1.0, &handled));
-    if (handled) { ctx->pair_last_path = 3; return RTC_OK; }
+    if (handled) { ctx->pair_last_path = 3; ctx->diag[0]++; return RTC_OK; }
     // The join has just refused the set as dense from its sample and expects more candidate edges than the caller's list
     // holds: say so through the count (the protocol of an overflowing list: "count past the capacity, grow, call again") BEFORE
     // the tiled kernel walks the whole tile for a list that cannot take its output.  The second call finds the refusal
@@ -170,13 +175,15 @@ extern "C" int rtc_pair_edges_dev(rtc_ctx* ctx, const void* d_hashes, int width,
       hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, ctx->stream, (unsigned long long*)d_count, (unsigned long long)hint);
       RTC_CHECK_LAUNCH(ctx);
       ctx->pair_last_path = 2;
+      ctx->diag[6]++;
       return RTC_OK;
     }
     RTC_TRY(rtc_pair_edges_tiled(ctx, d_hashes, width, d_start, d_len, n, row0, row1, col0, col1, 1, radio, d_edges, cap,
                                  d_count, &handled));
   }
-  if (handled) { ctx->pair_last_path = 2; return RTC_OK; }
+  if (handled) { ctx->pair_last_path = 2; ctx->diag[1]++; return RTC_OK; }
   ctx->pair_last_path = 1;
+  ctx->diag[2]++;
   const uint64_t ld = col1 - col0;
   uint32_t rows_per = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(row1 - row0, ((uint64_t)1 << 30) / (ld * 4)));
   rows_per = std::min<uint32_t>(rows_per, 262140);

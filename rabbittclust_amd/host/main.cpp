@@ -565,6 +565,7 @@ static void sketch_files(vector<Gpu>& gpus, const string& inputFile, const Sketc
     }
     const bool temp = !resident || row_overflow;
     CHECK(c, rtc_copy_d2h(c, cnt.data(), d_cnt, (size_t)nb * 4));
+    if (dir) CHECK(c, rtc_ctx_sync(c));  // the stream is idle after the copy: this only reports a run list that broke its contract, against THIS batch
     if (row0 >= 0) for (uint32_t g = 0; g < nb; g++) rs.counts[row0 + g] = cnt[g];
     if (to_host || temp) {
       vector<unsigned char> out((size_t)nb * stride * w);
@@ -1671,7 +1672,12 @@ static int append_clust_greedy(const Options& o, vector<Gpu>& gpus) {
 // Will this run use exactly one GPU?  Answered without the HIP runtime (its environment must be final before it starts): a
 // --gpus / RTC_GPUS choice that names one device, or "all" on a host whose driver topology lists one GPU node.
 static bool single_gpu_run(const string& spec) {
-  if (spec != "all") return spec.find(',') == string::npos;
+  if (spec != "all") {  // as the spec is parsed further down: digits alone are a COUNT (--gpus 4 = four GPUs), a comma list names devices
+    if (spec.find(',') == string::npos && spec.find_first_not_of("0123456789") == string::npos && atoi(spec.c_str()) > 0) return atoi(spec.c_str()) == 1;
+    int named = 0;
+    for (size_t p0 = 0; p0 <= spec.size();) { size_t p1 = spec.find(',', p0); if (p1 == string::npos) p1 = spec.size(); if (p1 > p0) named++; p0 = p1 + 1; }
+    return named == 1;
+  }
   for (const char* v : {"HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"})
     if (const char* e = getenv(v)) return *e != 0 && strchr(e, ',') == nullptr;
   int gpus = 0;

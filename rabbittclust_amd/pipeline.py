@@ -425,7 +425,13 @@ class MstPipeline:
         ctx, comm = self.ctx, self.comm.c
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        if self.mode == "kssd":
+        if isinstance(seq, list):  # the rank's genomes as batches in the 2-bit staging format: [(PackedBatch, off), ...]
+            rows = getattr(self, "_rows", (None, None))
+            sk = ctx.sketch_packed_sharded(comm, seq, mode=self.mode, k=self.k, size=self.s, drlevel=self.drlevel,
+                                           shuffled_dim=self.shuffled_dim, out=rows[0], cnt=rows[1])
+            self._rows = (sk.hashes.view(sk.n, -1), sk.len)  # the global rows are reused by the next step
+            ev[1].record()
+        elif self.mode == "kssd":
             sk = self._kssd_sketch_and_gather_native(seq, off, ev[1])
         else:
             sk = ctx.sketch_minhash_sharded(comm, seq, off, k=self.k, size=self.s, sizes=sizes)
@@ -450,8 +456,10 @@ class MstPipeline:
             "mst_edges": float(len(mst)),
         }
 
-    def step(self, seq, off, sizes=None):
+    def step(self, seq, off=None, sizes=None):
         from .api import PackedBatch
+        if isinstance(seq, list) and not isinstance(self.comm, NativeComm):
+            raise TypeError("a list of packed batches goes through the C ABI's sharded entry points: give the pipeline a NativeComm")
         if isinstance(self.comm, NativeComm):
             return self.step_native(seq, off, sizes)
         ctx = self.ctx

@@ -100,16 +100,26 @@ def test_greedy_global_join_equals_the_batch_loop_and_the_oracle(ctx, oracle, mo
         want_n, want = oracle.greedy_minhash(flat, start, lens, cfg, 21, cont, 0.05)
         run = lambda: ctx.greedy(dev, 0.05, size_cfg=cfg, is_containment=cont)
     assert len(sk) > 2 * 1024
+    # the library reads its switches when a context is created: ctx.env sets them AND makes this context read them again;
+    # the path counters say which path really ran (a switch nobody read would leave the default path and a green test)
     for join in ("2", "0"):
-        monkeypatch.setenv("RTC_PAIR_JOIN", join)
-        got_n, got = run()
+        with ctx.env(RTC_PAIR_JOIN=join):
+            d0 = ctx.diag()
+            got_n, got = run()
+            d1 = ctx.diag()
         assert got_n == want_n, join
         assert np.array_equal(got, want), join
+        if join == "2":
+            assert d1["greedy_global"] == d0["greedy_global"] + 1 and d1["greedy_blocks"] == d0["greedy_blocks"], (d0, d1)
+        else:
+            assert d1["greedy_global"] == d0["greedy_global"] and d1["greedy_blocks"] > d0["greedy_blocks"] and d1["join_tiles"] == d0["join_tiles"], (d0, d1)
     # the global join's pair list over its memory budget: the run falls through to the block loop, same decisions
-    monkeypatch.setenv("RTC_PAIR_JOIN", "2")
-    monkeypatch.setenv("RTC_GREEDY_GLOBAL_PAIRS", "1000")
-    got_n, got = run()
+    with ctx.env(RTC_PAIR_JOIN="2", RTC_GREEDY_GLOBAL_PAIRS="1000"):
+        d0 = ctx.diag()
+        got_n, got = run()
+        d1 = ctx.diag()
     assert got_n == want_n and np.array_equal(got, want)
+    assert d1["greedy_global"] == d0["greedy_global"] and d1["greedy_blocks"] > d0["greedy_blocks"], (d0, d1)
     assert 1 < want_n < len(sk)
 
 

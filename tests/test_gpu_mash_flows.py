@@ -161,10 +161,11 @@ def test_mst_mash_equals_dense_loop_restatement(ctx, oracle, containment, monkey
     assert np.array_equal(np.sort(part["dist"]).view(np.uint64), np.sort(_kruskal_weights(D, 20)).view(np.uint64))
     assert np.all(part["sufNode"] >= 20)
     # the same forest when the edge list has to be contracted between row chunks
-    monkeypatch.setenv("RTC_EDGE_BUDGET", "1024")
-    again = ctx.mst_mash(sk, s, is_containment=containment)
+    with ctx.env(RTC_EDGE_BUDGET="1024"):  # (the library reads its switches at context creation: ctx.env makes this context read them again)
+        c0 = ctx.diag()["contractions"]
+        again = ctx.mst_mash(sk, s, is_containment=containment)
+        assert ctx.diag()["contractions"] > c0, "the contraction path did not run"
     assert np.array_equal(again, mst)
-    monkeypatch.delenv("RTC_EDGE_BUDGET")
     # --dense by-products: EVERY pair counts (src/MST.cpp:868-879)
     mst2, dense, ani = ctx.mst_mash(sk, s, is_containment=containment, span=100)
     assert np.array_equal(mst2, mst)

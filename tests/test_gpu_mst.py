@@ -179,6 +179,35 @@ def test_mst_dense_input_edge_budget_contraction(ctx, oracle):
     assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
 
 
+def test_mst_when_the_join_estimate_of_the_edge_count_is_short(ctx, oracle):
+    """One family of 3 000 sketches at pairwise Jaccard ~0.3, default dispatch: the join's density sample refuses the set and
+    hands back an ESTIMATE of the candidate edges (1.5 x n x (g - 1) / 2 with g = the posting-list length a sampled hash sees,
+    ~0.46 n) that is SHORT of the truth -- every one of the 4.5 M pairs shares a hash.  The list grown to the estimate is too
+    short again; rtc_candidate_edges_device must grow it a second time from the exact count and never hand Boruvka a count
+    past the allocation (round 5's advisor finding: el->m = cnt > cap)."""
+    from rabbittclust_amd import api
+    rng = np.random.default_rng(77)
+    n, s = 3000, 120
+    pool = np.unique(rng.integers(1, 1 << 62, size=400, dtype=np.uint64))[:260]
+    sk = [np.sort(rng.choice(pool, size=s, replace=False)) for _ in range(n)]
+    dev = api.SketchSet.from_host(sk, ctx.device, k=21)
+    flat, start, lens = oracle.to_csr(sk)
+    want = oracle.mst(flat, start, lens, 21, 0, 0.05, threads=8)
+    d0 = ctx.diag()
+    got = ctx.mst(dev, 0.05)
+    d1 = ctx.diag()
+    assert d1["estimates"] == d0["estimates"] + 1, (d0, d1)                       # the early-out was taken ...
+    assert d1["tiled_tiles"] >= d0["tiled_tiles"] + 2, (d0, d1)                   # ... and the list was short for the first real launch too
+    assert len(got) == len(want) == n - 1
+    assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
+    # the pipeline's own loop around rtc_pair_edges_dev follows the same protocol
+    from rabbittclust_amd import pipeline
+    pipe = pipeline.MstPipeline(ctx, k=21, sketch_size=s, threshold=0.05)
+    dev2 = api.SketchSet.from_host(sk, ctx.device, k=21)  # a new sketch buffer: no remembered refusal
+    edges, m = pipe.candidate_edges(dev2, 0, n)
+    assert m == n * (n - 1) // 2 and edges.shape[0] >= m
+
+
 def test_pair_tiled_falls_back_when_transposed_copy_exceeds_budget(ctx, oracle):
     """one huge sketch among many small ones inflates the partition-major transposed copy.
     With a tiny budget the tiled path must decline (handled = 0) and the merge kernel must give the

@@ -95,6 +95,123 @@ def test_sharded_step_in_process_ranks_equal_single_gpu(oracle, world, fixed):
         c.close()
 
 
+@pytest.mark.parametrize("mode", ["minhash", "kssd"])
+@pytest.mark.parametrize("world", [8, 3])
+def test_packed_sharded_step_in_process_ranks_equal_single_launch(oracle, mode, world):
+    """The strong-scaling step from PACKED input: `world` contexts on device 0, one host thread each, every rank's genomes
+    resident as batches in the 2-bit staging format (unequal batch sizes, several batches per rank, N runs inside), sketched
+    by rtc_sketch_minhash_packed_sharded / rtc_sketch_kssd_packed_sharded into the global rows, then rtc_mst_sharded.  Every
+    rank must end with the sketches of the single launch over all genomes (bit for bit, canonical order) and its forest."""
+    import torch
+    from rabbittclust_amd import api, host, pipeline
+    ctxs = [api.Context(0) for _ in range(world)]
+    comms = api.Comm.init_all(ctxs)
+    assert all(c.backend == "in-process" for c in comms)
+    n_local, L = 27, (60_000 if mode == "minhash" else 300_000)
+    sizes = [11, 9, 7]  # the rank's batches
+    sd = host.generate_shuffle_dim(6) if mode == "kssd" else None
+    one = api.Context(0)
+    desc = api.synth_family_descs(world * n_local // 9 + 1, 9, global_seed=31, n_every=20_011)[: world * n_local]
+    off_all = np.arange(world * n_local + 1, dtype=np.uint64) * L
+    seq_all = one.synth_genomes(desc, off_all)
+    one.sync()
+    if mode == "minhash":
+        want = one.sketch_minhash(seq_all, off_all, k=21, size=250)
+    else:
+        want = one.sketch_kssd(seq_all, off_all, sd, kmer_size=21, drlevel=3)
+    want_mst = one.mst(want, 0.05)
+    want_sk = want.to_host()
+    assert len(want_mst) > world * n_local // 2
+    batches = []
+    for r in range(world):
+        bs, a = [], r * n_local
+        for m in sizes:
+            o = np.arange(m + 1, dtype=np.uint64) * L
+            piece = seq_all[a * L:(a + m) * L].clone()
+            bs.append((api.pack_staging(piece, m * L), o))
+            a += m
+        batches.append(bs)
+    torch.cuda.synchronize()
+
+    def rank_fn(r):
+        def f():
+            pipe = pipeline.MstPipeline(ctxs[r], k=21, sketch_size=250, threshold=0.05, mode=mode, shuffled_dim=sd,
+                                        comm=pipeline.NativeComm(comms[r]))
+            st = pipe.step(batches[r])
+            again = pipe.step(batches[r])  # the global rows are reused by the next step
+            ctxs[r].sync()
+            return pipe.last_sketches.to_host(), pipe.last_mst, st, again
+        return f
+
+    res = _threads([rank_fn(r) for r in range(world)])
+    for r in range(world):
+        got_sk, got_mst, st, again = res[r]
+        assert len(got_sk) == world * n_local
+        assert all(np.array_equal(a, b) for a, b in zip(got_sk, want_sk)), f"rank {r}: gathered sketches differ from the single launch"
+        assert np.array_equal(got_mst, want_mst), f"rank {r}: forest differs from the single-GPU forest"
+        assert st["mst_edges"] == again["mst_edges"] == len(want_mst)
+    assert sum(x[2]["pairs_local"] for x in res) == world * n_local * (world * n_local - 1) // 2
+    flat, start, lens = oracle.to_csr(want_sk, dtype=want_sk[0].dtype)
+    omst = oracle.mst(flat, start, lens, want.k, 0, 0.05)
+    assert np.array_equal(np.sort(want_mst["dist"]).view(np.uint64), np.sort(omst["dist"]).view(np.uint64))
+    for c in comms:
+        c.close()
+    for c in ctxs + [one]:
+        c.close()
+
+
+def test_packed_sharded_kssd_overflow_is_agreed_by_all_ranks():
+    """rows too narrow for one rank's sketches: every rank gets RTC_ERR_OVERFLOW with the same need, nobody hangs; the api
+    wrapper then repeats the phase with wider rows."""
+    import torch
+    from rabbittclust_amd import _lib, api, host
+    import ctypes as C
+    world = 2
+    ctxs = [api.Context(0) for _ in range(world)]
+    comms = api.Comm.init_all(ctxs)
+    sd = host.generate_shuffle_dim(6)
+    n_local, Ls = 12, [120_000, 400_000]  # rank 1's genomes yield ~100 tuples, rank 0's ~30
+    batches = []
+    for r in range(world):
+        off = np.arange(n_local + 1, dtype=np.uint64) * Ls[r]
+        seq = ctxs[r].synth_genomes(api.synth_family_descs(3, 4, global_seed=5 + r), off)
+        ctxs[r].sync()
+        batches.append([(api.pack_staging(seq, int(off[-1])), off)])
+    torch.cuda.synchronize()
+
+    def raw(r):
+        def f():
+            c, pb, off = ctxs[r], batches[r][0][0], batches[r][0][1]
+            out = torch.empty((world * n_local, 48), dtype=torch.int32, device=c.device)
+            cnt = torch.zeros(world * n_local, dtype=torch.int32, device=c.device)
+            w, need = C.c_int(), C.c_uint32()
+            st = c.lib.rtc_sketch_kssd_packed_sharded(c.h, comms[r].h, api._t_ptr(pb.packed), pb.n_bases, api._t_ptr(pb.runs) if pb.runs.numel() else None,
+                                                      pb.runs.numel() // 2, api._np_ptr(off), n_local, 0, n_local, 1, 21, 3, api._np_ptr(np.ascontiguousarray(sd, dtype=np.int32)),
+                                                      api._t_ptr(out), 48, api._t_ptr(cnt), C.byref(w), C.byref(need))
+            return st, int(need.value), int(w.value)
+        return f
+    res = _threads([raw(r) for r in range(world)])
+    assert res[0][0] == res[1][0] == _lib.RTC_ERR_OVERFLOW and res[0][1] == res[1][1] > 48 and res[0][2] == res[1][2] == 4
+    # the wrapper: too tight a stride on purpose, then the agreed need
+    def wrapped(r):
+        def f():
+            sk = ctxs[r].sketch_packed_sharded(comms[r], batches[r], mode="kssd", k=21, drlevel=3, shuffled_dim=sd, stride=48)
+            ctxs[r].sync()
+            return sk.to_host()
+        return f
+    got = _threads([wrapped(r) for r in range(world)])
+    one = api.Context(0)
+    want = []
+    for r in range(world):
+        want += one.sketch_kssd_packed(batches[r][0][0], None, None, batches[r][0][1], sd, kmer_size=21, drlevel=3).to_host()
+    for r in range(world):
+        assert all(np.array_equal(a, b) for a, b in zip(got[r], want))
+    for c in comms:
+        c.close()
+    for c in ctxs + [one]:
+        c.close()
+
+
 def test_rccl_calls_single_rank(oracle):
     """One rank, communicator forced through RCCL: ncclCommInitRank, ncclAllReduce(MIN/MAX) and the
     grouped in-place ncclBroadcast run on the GPU; the sharded step equals rtc_mst."""
