@@ -153,6 +153,7 @@ struct rtc_comm {
   hipStream_t side = nullptr;      // gathers overlap compute on the context stream
   hipEvent_t ev_ready = nullptr, ev_done = nullptr, ev_watch = nullptr;
   hipEvent_t ev_front = nullptr, ev_front_side = nullptr;  // in front of the collective(s) being watched (context / side stream)
+  hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};        // rtc_mst_sharded's phase timing
   bool side_front_pending = false;
   bool side_busy = false;
   bool broken = false;             // a collective timed out and the communicator was aborted
@@ -401,6 +402,7 @@ void rtc_comm_destroy(rtc_comm* c) {
   if (c->ev_watch) (void)hipEventDestroy(c->ev_watch);
   if (c->ev_front) (void)hipEventDestroy(c->ev_front);
   if (c->ev_front_side) (void)hipEventDestroy(c->ev_front_side);
+  for (hipEvent_t e : c->ev_t) if (e) (void)hipEventDestroy(e);
   if (c->nccl && rccl()) (void)rccl()->CommDestroy(c->nccl);
   delete c;
 }
@@ -637,10 +639,12 @@ int rtc_mst_sharded(rtc_ctx* ctx, rtc_comm* c, const void* d_hashes, int width, 
   if (n < 2) return RTC_OK;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
   RTC_TRY(rtc_comm_wait(c));
-  std::vector<uint32_t> h_len(n);
-  RTC_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  rtc_mst_bufs_t B{};
+  RTC_TRY(rtc_mst_bufs(ctx, n, &B));
+  uint32_t* const h_len = B.h_len;
+  RTC_HIP(ctx, hipMemcpyAsync(h_len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const uint32_t s_fixed = rtc_fixed_size_of(h_len.data(), n);
+  const uint32_t s_fixed = rtc_fixed_size_of(h_len, n);
   double mean = 0;
   for (uint32_t g = 0; g < n; g++) mean += h_len[g];
   mean /= n;
@@ -659,12 +663,17 @@ int rtc_mst_sharded(rtc_ctx* ctx, rtc_comm* c, const void* d_hashes, int width, 
     if (local == RTC_OK && v != RTC_OK) return rtc_fail(ctx, (int)v, "another rank of the sharded MST step failed (status %d)", (int)v);
     return local != RTC_OK ? local : (int)v;
   };
-  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
   int st = RTC_OK;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess)
-    st = rtc_fail(ctx, RTC_ERR_HIP, "hipEventCreate failed");
+  if (!c->ev_t[0]) {  // the phase events live with the communicator
+    for (int i = 0; i < 3 && st == RTC_OK; i++)
+      if (hipEventCreate(&c->ev_t[i]) != hipSuccess) st = rtc_fail(ctx, RTC_ERR_HIP, "hipEventCreate failed");
+  }
+  hipEvent_t e0 = c->ev_t[0], e1 = c->ev_t[1], e2 = c->ev_t[2];
   rtc_edge_list el{};
-  rtc_cedge* d_sel = nullptr;
+  rtc_cedge* const d_sel = B.d_sel;
+  const bool verbose = ctx->opt.verbose && !ctx->quiet;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tv0 = now();
   if (st == RTC_OK) {
     (void)hipEventRecord(e0, ctx->stream);
     st = rtc_candidate_edges_device(ctx, d_hashes, width, d_start, d_len, n, row0, row1, kmer_size, is_containment,
@@ -673,35 +682,35 @@ int rtc_mst_sharded(rtc_ctx* ctx, rtc_comm* c, const void* d_hashes, int width, 
     // (the count read-backs above have synchronised the stream: a packed batch whose run list broke its contract is known by now)
     if (st == RTC_OK) st = rtc_sticky_error(ctx);
   }
+  const double tv1 = now();
   uint64_t nsel = 0;
   int rounds = 0;
-  std::vector<rtc_cedge> sel;
-  if (st == RTC_OK && hipMalloc((void**)&d_sel, (size_t)n * sizeof(rtc_cedge)) != hipSuccess)
-    st = rtc_fail(ctx, RTC_ERR_NOMEM, "hipMalloc forest list");
   st = agree(st);
   const rtc_reduce_hook hook{hook_all_reduce, c};
   if (st == RTC_OK) st = rtc_msf_device(ctx, el.d_edges, el.m, d_len, n, is_containment, s_fixed, (c->size > 1 || c->nccl) ? &hook : nullptr, d_sel, &nsel, &rounds);
+  const double tv2 = now();
   if (st == RTC_OK && nsel) {
-    sel.resize(nsel);
-    hipError_t e = hipMemcpyAsync(sel.data(), d_sel, nsel * sizeof(rtc_cedge), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipMemcpyAsync(B.h_sel, d_sel, nsel * sizeof(rtc_cedge), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) st = rtc_fail(ctx, RTC_ERR_HIP, "forest read-back -> %s", hipGetErrorString(e));
   }
-  if (e2) { (void)hipEventRecord(e2, ctx->stream); (void)hipEventSynchronize(e2); }
+  if (st == RTC_OK) { (void)hipEventRecord(e2, ctx->stream); (void)hipEventSynchronize(e2); }
   if (stats && st == RTC_OK) {
     (void)hipEventElapsedTime(&stats->pair_ms, e0, e1);
     (void)hipEventElapsedTime(&stats->mst_ms, e1, e2);
     stats->row0 = row0; stats->row1 = row1; stats->cand_edges = el.m; stats->rounds = (uint32_t)rounds;
     stats->s_fixed = s_fixed; stats->contractions = (uint32_t)el.contractions;
   }
-  if (e0) (void)hipEventDestroy(e0);
-  if (e1) (void)hipEventDestroy(e1);
-  if (e2) (void)hipEventDestroy(e2);
-  if (d_sel) (void)hipFree(d_sel);
-  rtc_edge_list_free(&el);
+  const uint64_t m_edges = el.m;
+  rtc_edge_list_free(&el, ctx);
   if (st != RTC_OK) return st;
-  RTC_TRY(rtc_edges_to_mst_host(sel.data(), nsel, h_len.data(), kmer_size, is_containment, h_edges_out));
+  const double tv3 = now();
+  RTC_TRY(rtc_edges_to_mst_host_fixed(B.h_sel, nsel, h_len, kmer_size, is_containment, s_fixed, h_edges_out));
   *h_n_edges = nsel;
+  if (verbose)
+    fprintf(stderr, "[mst]   rank %d of %d, %u sketches, rows [%u, %u): %llu candidate edges in %.4fs, forest (%d rounds, %llu edges) %.4fs, read-back "
+            "%.4fs, host distances %.4fs\n", c->rank, c->size, n, row0, row1, (unsigned long long)m_edges, tv1 - tv0, rounds,
+            (unsigned long long)nsel, tv2 - tv1, tv3 - tv2, now() - tv3);
   return RTC_OK;
 }
 

@@ -139,7 +139,10 @@ void rtc_ctx_destroy(rtc_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < 6; i++)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+  if (ctx->edge_cache) (void)hipFree(ctx->edge_cache);
+  if (ctx->edge_cache_count) (void)hipFree(ctx->edge_cache_count);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->mst_pinned) (void)hipHostFree(ctx->mst_pinned);
   if (ctx->sticky) (void)hipHostFree(ctx->sticky);
   if (ctx->kssd.d_index) (void)hipFree(ctx->kssd.d_index);
   if (ctx->kssd.d_table) (void)hipFree(ctx->kssd.d_table);

@@ -212,13 +212,13 @@ extern "C" int rtc_greedy(rtc_ctx* ctx, const void* d_hashes, int width, const u
       unsigned long long cnt = 0;
       G_HIP(hipMemcpyAsync(&cnt, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
       G_HIP(hipStreamSynchronize(ctx->stream));
+      if (cnt > global_pair_budget) { handled = 0; break; }
       if (cnt <= ecap) { m = cnt; break; }
       // The whole set's candidate pairs at once: 12 B each here, ~20 B each on the host while they are bucketed.  The
       // join's cost rule weighs time, not this memory: beyond the budget (2^27 pairs = 1.6 GB + 2.7 GB by default), or
       // when the larger list cannot be allocated, the block loop below takes over -- it never holds more than one block
       // of queries' candidates.
       const uint64_t old_cap = ecap;
-      if (cnt > global_pair_budget) { handled = 0; break; }
       (void)hipFree(d_edges); d_edges = nullptr;
       ecap = cnt + cnt / 4;
       if (hipMalloc(&d_edges, ecap * sizeof(rtc_cedge)) != hipSuccess) {

@@ -71,6 +71,14 @@ struct rtc_ctx {
   // keyed on the sketch buffer, its generation (every sketch / gather call on this context bumps sketch_gen) and the tile
   struct { const void* hashes = nullptr; uint64_t gen = 0; uint32_t n = 0, row0 = 0, row1 = 0, col0 = 0, col1 = 0; uint64_t K = 0, maxkey = 0; uint64_t edges_hint = 0; /* set by a refusal from the sample, for this call only: candidate edges to expect */ } join_dense;
   uint64_t sketch_gen = 1;
+  // the candidate edge list of the last clustering call (rtc_edge_list_free keeps it, rtc_candidate_edges_device takes it): a
+  // command line clusters once, a service or a benchmark loop many times over sets of one size -- the second call then starts with
+  // a list that held the first one's edges, no allocation and no overflow redo
+  void* mst_pinned = nullptr;      // rtc_mst_bufs: page-locked sketch sizes + forest of a whole-MST call
+  size_t mst_pinned_bytes = 0;
+  void* edge_cache = nullptr;
+  uint64_t edge_cache_cap = 0;
+  void* edge_cache_count = nullptr;
   int pair_plan_hold = 0, pair_plan_valid = 0;
   uint32_t pair_plan_tc1_hint = 0;
   struct {
@@ -136,7 +144,8 @@ int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, co
                                const uint32_t* d_len, uint32_t n, uint32_t row0, uint32_t row1, int kmer_size,
                                int is_containment, double threshold, uint32_t s_fixed, rtc_edge_list* el,
                                const rtc_edge_observer* obs = nullptr);
-void rtc_edge_list_free(rtc_edge_list* el);
+// (ctx != NULL: a list of up to 1 GiB stays with the context for its next clustering call instead of going back to the driver)
+void rtc_edge_list_free(rtc_edge_list* el, rtc_ctx* ctx = nullptr);
 // rtc_pairs_join.hip: candidate edges of a lower-triangle tile by the inverted join; *handled = 0 when it declines
 int rtc_pair_edges_join(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start, const uint32_t* d_len,
                         uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, int radio,
@@ -147,6 +156,11 @@ int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uin
                    uint64_t* n_sel_out, int* rounds_out, bool sorted = true);
 int rtc_sort_forest_device(rtc_ctx* ctx, rtc_cedge* d_sel, uint64_t ns, const uint32_t* d_len, int wmode);
 uint32_t rtc_fixed_size_of(const uint32_t* h_len, uint32_t n);
+size_t rtc_msf_scratch_bytes(uint32_t n);
+struct rtc_mst_bufs_t { uint32_t* h_len; rtc_cedge* h_sel; rtc_cedge* d_sel; };  // page-locked sizes + forest, device forest list
+int rtc_mst_bufs(rtc_ctx* ctx, uint32_t n, rtc_mst_bufs_t* b);
+int rtc_edges_to_mst_host_fixed(const rtc_cedge* h_sel, uint64_t m, const uint32_t* h_len, int kmer_size, int is_containment,
+                                uint32_t s_fixed, rtc_edge* h_out);
 
 #define RTC_HIP(ctx, call)                                                                  \
   do {                                                                                      \

@@ -124,7 +124,8 @@ __device__ __forceinline__ void wave_min_update(unsigned long long* __restrict__
 __global__ __launch_bounds__(256) void boruvka_minweight_kernel(const rtc_cedge* __restrict__ edges, uint64_t m,
                                                                 const uint32_t* __restrict__ len, int is_containment,
                                                                 const uint32_t* __restrict__ comp,
-                                                                unsigned long long* __restrict__ wkey) {
+                                                                unsigned long long* __restrict__ wkey, const uint32_t* __restrict__ go = nullptr) {
+  if (go && !*go) return;
   for (uint64_t e0 = (uint64_t)blockIdx.x * blockDim.x; e0 < m; e0 += (uint64_t)gridDim.x * blockDim.x) {  // whole waves stay together
     const uint64_t e = e0 + threadIdx.x;
     bool on = e < m;
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(256) void boruvka_minedge_kernel(const rtc_cedge* _
                                                               const uint32_t* __restrict__ len, int is_containment,
                                                               const uint32_t* __restrict__ comp,
                                                               const unsigned long long* __restrict__ wkey,
-                                                              unsigned long long* __restrict__ ekey) {
+                                                              unsigned long long* __restrict__ ekey, const uint32_t* __restrict__ go = nullptr) {
+  if (go && !*go) return;
   for (uint64_t e0 = (uint64_t)blockIdx.x * blockDim.x; e0 < m; e0 += (uint64_t)gridDim.x * blockDim.x) {  // whole waves stay together
     const uint64_t e = e0 + threadIdx.x;
     bool oi = false, oj = false;
@@ -169,7 +171,8 @@ __global__ __launch_bounds__(256) void boruvka_minedge_kernel(const rtc_cedge* _
 __global__ __launch_bounds__(256) void boruvka_fetch_kernel(const rtc_cedge* __restrict__ edges, uint64_t m,
                                                             const uint32_t* __restrict__ comp,
                                                             const unsigned long long* __restrict__ ekey,
-                                                            uint32_t* __restrict__ ecommon) {
+                                                            uint32_t* __restrict__ ecommon, const uint32_t* __restrict__ go = nullptr) {
+  if (go && !*go) return;
   for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += (uint64_t)gridDim.x * blockDim.x) {
     const rtc_cedge ed = edges[e];
     const uint32_t ci = comp[ed.i], cj = comp[ed.j];
@@ -187,7 +190,9 @@ __global__ void fill_u64_kernel(unsigned long long* p, uint64_t n, unsigned long
 // fixed-size mode: key = (s - common) << 2B | i << B | j   (B = index bits; smaller key = closer pair)
 __global__ __launch_bounds__(256) void boruvka_minkey_kernel(const rtc_cedge* __restrict__ edges, uint64_t m,
                                                              const uint32_t* __restrict__ comp, uint32_t s_fixed,
-                                                             int idx_bits, unsigned long long* __restrict__ key) {
+                                                             int idx_bits, unsigned long long* __restrict__ key,
+                                                             const uint32_t* __restrict__ go = nullptr) {
+  if (go && !*go) return;
   for (uint64_t e0 = (uint64_t)blockIdx.x * blockDim.x; e0 < m; e0 += (uint64_t)gridDim.x * blockDim.x) {  // whole waves stay together
     const uint64_t e = e0 + threadIdx.x;
     bool on = e < m;
@@ -233,9 +238,14 @@ __device__ __forceinline__ bool round_edge(const RoundKeys& K, uint32_t c, uint3
 __global__ __launch_bounds__(256) void boruvka_hook_kernel(RoundKeys K, const uint32_t* __restrict__ comp, uint32_t n,
                                                            uint32_t* __restrict__ succ, rtc_cedge* __restrict__ sel,
                                                            unsigned long long* __restrict__ nsel,
-                                                           uint32_t* __restrict__ added) {
-  const uint32_t lane = threadIdx.x & 63;
-  for (uint32_t v0 = blockIdx.x * blockDim.x; v0 < n; v0 += gridDim.x * blockDim.x) {  // whole waves stay together
+                                                           uint32_t* __restrict__ added, const uint32_t* __restrict__ go) {
+  if (go && !*go) return;  // the round before added nothing: the forest is complete (rounds are enqueued ahead of the host's look)
+  // the forest counter is ONE address: a block reserves its edges with one atomic (a wave each cost 75 us of queueing at the
+  // atomic unit in the first rounds of 200 000 vertices -- 3 125 waves, two atomics each)
+  __shared__ uint32_t s_cnt[4];
+  __shared__ unsigned long long s_base;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t v0 = blockIdx.x * blockDim.x; v0 < n; v0 += gridDim.x * blockDim.x) {  // whole blocks stay together
     const uint32_t v = v0 + threadIdx.x;
     uint32_t s = v, i = 0, j = 0, cm = 0;
     bool append = false;
@@ -253,12 +263,20 @@ __global__ __launch_bounds__(256) void boruvka_hook_kernel(RoundKeys K, const ui
     }
     if (v < n) succ[v] = s;
     const uint64_t bal = __ballot(append);
-    if (bal) {
-      unsigned long long base = 0;
-      if (lane == 0) { base = atomicAdd(nsel, (unsigned long long)__popcll(bal)); atomicAdd(added, (uint32_t)__popcll(bal)); }
-      base = __shfl(base, 0);
-      if (append) sel[base + (uint64_t)__popcll(bal & ((1ULL << lane) - 1ULL))] = rtc_cedge{i, j, cm};
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+      s_base = tot ? atomicAdd(nsel, (unsigned long long)tot) : 0ull;
+      if (tot) atomicAdd(added, tot);
     }
+    __syncthreads();
+    if (append) {
+      uint32_t before = 0;
+      for (uint32_t w = 0; w < wave; w++) before += s_cnt[w];
+      sel[s_base + before + (uint64_t)__popcll(bal & ((1ULL << lane) - 1ULL))] = rtc_cedge{i, j, cm};
+    }
+    __syncthreads();
   }
 }
 
@@ -286,8 +304,8 @@ __global__ __launch_bounds__(256) void boruvka_begin_kernel(uint32_t* __restrict
 __global__ __launch_bounds__(256) void boruvka_relabel_reset_kernel(uint32_t* __restrict__ comp, const uint32_t* __restrict__ succ,
                                                                     uint32_t n, unsigned long long* __restrict__ wkey,
                                                                     unsigned long long* __restrict__ ekey,
-                                                                    uint32_t* __restrict__ added_next) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *added_next = 0;
+                                                                    const uint32_t* __restrict__ go) {
+  if (go && !*go) return;
   for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
     uint32_t r = comp[v];
     while (true) { const uint32_t nx = succ[r]; if (nx == r) break; r = nx; }
@@ -347,6 +365,69 @@ static double host_mst_distance(int common, int size0, int size1, int kmer_size,
   return -inv_kmer_size * log(containment);
 }
 
+// scratch slot 3 of a forest call: two u64 and three u32 per vertex, the forest counter and the rounds' counters
+size_t rtc_msf_scratch_bytes(uint32_t n) { return (((size_t)n * (8 + 8 + 4 + 4 + 4) + 64 + 8 + 4 * 64 + 64) + 255) & ~(size_t)255; }
+
+// rtc_edges_to_mst_host with the caller's knowledge that every sketch holds s_fixed hashes (0: sizes vary): the distance is then a
+// function of `common` alone and comes from a table of s_fixed + 1 host-libm values -- the same doubles, one log() per distinct
+// count instead of one per edge.
+int rtc_edges_to_mst_host_fixed(const rtc_cedge* h_sel, uint64_t m, const uint32_t* h_len, int kmer_size, int is_containment,
+                                uint32_t s_fixed, rtc_edge* h_out) {
+  if ((m && (!h_sel || !h_out)) || !h_len) return RTC_ERR_ARG;
+  std::vector<double> table;
+  if (s_fixed && s_fixed <= (1u << 20) && m > 64) {
+    table.resize((size_t)s_fixed + 1);
+    for (uint32_t c = 0; c <= s_fixed; c++) table[c] = host_mst_distance((int)c, (int)s_fixed, (int)s_fixed, kmer_size, is_containment);
+  }
+  auto fill = [&](uint64_t e0, uint64_t e1) {
+    for (uint64_t e = e0; e < e1; e++) {
+      h_out[e].preNode = (int32_t)h_sel[e].i;
+      h_out[e].sufNode = (int32_t)h_sel[e].j;
+      h_out[e].dist = !table.empty() && h_sel[e].common <= s_fixed
+                          ? table[h_sel[e].common]
+                          : host_mst_distance((int)h_sel[e].common, (int)h_len[h_sel[e].i], (int)h_len[h_sel[e].j], kmer_size, is_containment);
+    }
+  };
+  // the distances are the host libm's (the reference's); beyond a few thousand edges the loop is split over threads
+  const uint64_t per = table.empty() ? 4096 : 65536;
+  const unsigned nt = (unsigned)std::min<uint64_t>(std::min<uint64_t>(8, std::max(1u, std::thread::hardware_concurrency())), (m + per - 1) / per);
+  if (nt <= 1) fill(0, m);
+  else {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(fill, m * t / nt, m * (t + 1) / nt);
+    fill(0, m / nt);
+    for (auto& x : th) x.join();
+  }
+  auto less = [](const rtc_edge& a, const rtc_edge& b) {
+    if (a.dist != b.dist) return a.dist < b.dist;
+    if (a.preNode != b.preNode) return a.preNode < b.preNode;
+    return a.sufNode < b.sufNode;
+  };
+  // forests that come from the device are already in this order (rtc_sort.hip): one pass instead of a sort
+  if (!std::is_sorted(h_out, h_out + m, less)) std::sort(h_out, h_out + m, less);
+  return RTC_OK;
+}
+
+// Page-locked staging and device scratch of a whole-MST call, from the context's own pools (no hipMalloc / hipFree and no
+// pageable copies per call -- together 0.8 ms of the 4.2 ms a 200 000-genome forest took): the sketch sizes and the forest on the
+// host side, the forest list on the device side (behind rtc_msf_device's arrays in scratch slot 3).
+int rtc_mst_bufs(rtc_ctx* ctx, uint32_t n, rtc_mst_bufs_t* b) {
+  const size_t b_len = ((size_t)n * 4 + 255) & ~(size_t)255;
+  const size_t want = b_len + (size_t)n * sizeof(rtc_cedge) + 256;  // a block of its own: the shared staging block (rtc_pinned) is rewritten by the pair phase's planners
+  if (want > ctx->mst_pinned_bytes) {
+    if (ctx->mst_pinned) RTC_HIP(ctx, hipHostFree(ctx->mst_pinned));
+    ctx->mst_pinned = nullptr; ctx->mst_pinned_bytes = 0;
+    RTC_HIP(ctx, hipHostMalloc(&ctx->mst_pinned, want + want / 4, hipHostMallocDefault));
+    ctx->mst_pinned_bytes = want + want / 4;
+  }
+  b->h_len = (uint32_t*)ctx->mst_pinned;
+  b->h_sel = (rtc_cedge*)((char*)ctx->mst_pinned + b_len);
+  void* ws3 = nullptr;
+  RTC_TRY(rtc_ws(ctx, 3, rtc_msf_scratch_bytes(n) + (size_t)n * sizeof(rtc_cedge) + 256, &ws3));
+  b->d_sel = (rtc_cedge*)((char*)ws3 + rtc_msf_scratch_bytes(n));
+  return RTC_OK;
+}
+
 // ---- minimum spanning forest of a device-resident candidate list (shared by rtc_mst and the
 // multi-GPU step; `hook` all-reduces the per-round key arrays across ranks, NULL on one GPU) ----
 int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_len, uint32_t n,
@@ -359,51 +440,60 @@ int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uin
   const int idx_bits = rtc_boruvka_key_bits(n, s_fixed);
   if (s_fixed && !idx_bits) s_fixed = 0;
   void* ws3 = nullptr;
-  RTC_TRY(rtc_ws(ctx, 3, (size_t)n * (8 + 8 + 4 + 4 + 4) + 256, &ws3));
+  RTC_TRY(rtc_ws(ctx, 3, rtc_msf_scratch_bytes(n), &ws3));
   uint64_t* d_wkey = (uint64_t*)ws3;
   uint64_t* d_ekey = d_wkey + n;
   uint32_t* d_ecommon = (uint32_t*)(d_ekey + n);
   uint32_t* d_comp = d_ecommon + n;
   uint32_t* d_succ = d_comp + n;
   uint64_t* d_nsel = (uint64_t*)(((uintptr_t)(d_succ + n) + 63) & ~(uintptr_t)63);
-  if (!hook) {  // one GPU: four (fixed sizes) or six (variable) operations per round instead of six / ten
+  if (!hook) {  // one GPU: three (fixed sizes) or five (variable) kernels per round, the host looks in every third round
     unsigned long long* wkey = (unsigned long long*)d_wkey;
     unsigned long long* ekey = s_fixed ? nullptr : (unsigned long long*)d_ekey;
-    uint32_t* d_added = (uint32_t*)(d_nsel + 1);  // two alternating counters
+    // d_added[r] = forest edges round r added.  Rounds are enqueued in groups of GROUP without a host round trip between them:
+    // every kernel of round r > 0 first looks at d_added[r - 1] and returns at once when it is 0 (the forest was complete), so
+    // the rounds enqueued past the end cost a few empty launches instead of a synchronisation per round (20 us each, a quarter
+    // of a round at 200 000 vertices).
+    uint32_t* d_added = (uint32_t*)(d_nsel + 1);
+    constexpr int MAX_ROUNDS = 64, GROUP = 3;
     const dim3 gn(grid_for(n, ctx->num_cu)), gm(grid_for(std::max<uint64_t>(m, 1), ctx->num_cu)), blk(256);
-    RTC_HIP(ctx, hipMemsetAsync(d_nsel, 0, 16, ctx->stream));
+    RTC_HIP(ctx, hipMemsetAsync(d_nsel, 0, 8 + 4 * MAX_ROUNDS, ctx->stream));
     hipLaunchKernelGGL(boruvka_begin_kernel, gn, blk, 0, ctx->stream, d_comp, wkey, ekey, n);
     RTC_CHECK_LAUNCH(ctx);
     void* hp = nullptr;
-    RTC_TRY(rtc_pinned(ctx, 64, &hp));
+    RTC_TRY(rtc_pinned(ctx, 8 + 4 * MAX_ROUNDS, &hp));
     const RoundKeys K{s_fixed ? wkey : ekey, d_ecommon, s_fixed, idx_bits};
     int rounds = 0;
-    for (int round = 0; round < 64; round++) {
-      const int a = round & 1;
-      if (m) {
-        if (s_fixed) {
-          hipLaunchKernelGGL(boruvka_minkey_kernel, gm, blk, 0, ctx->stream, d_edges, m, (const uint32_t*)d_comp, s_fixed, idx_bits, wkey);
-        } else {
-          hipLaunchKernelGGL(boruvka_minweight_kernel, gm, blk, 0, ctx->stream, d_edges, m, d_len, is_containment, (const uint32_t*)d_comp, wkey);
-          hipLaunchKernelGGL(boruvka_minedge_kernel, gm, blk, 0, ctx->stream, d_edges, m, d_len, is_containment, (const uint32_t*)d_comp,
-                             (const unsigned long long*)wkey, ekey);
-          hipLaunchKernelGGL(boruvka_fetch_kernel, gm, blk, 0, ctx->stream, d_edges, m, (const uint32_t*)d_comp,
-                             (const unsigned long long*)ekey, d_ecommon);
+    for (int round = 0; round < MAX_ROUNDS && !rounds;) {
+      const int first = round;
+      for (int g = 0; g < (first == 0 ? 2 : GROUP) && round < MAX_ROUNDS; g++, round++) {
+        const uint32_t* go = round ? d_added + round - 1 : nullptr;
+        if (m) {
+          if (s_fixed) {
+            hipLaunchKernelGGL(boruvka_minkey_kernel, gm, blk, 0, ctx->stream, d_edges, m, (const uint32_t*)d_comp, s_fixed, idx_bits, wkey, go);
+          } else {
+            hipLaunchKernelGGL(boruvka_minweight_kernel, gm, blk, 0, ctx->stream, d_edges, m, d_len, is_containment, (const uint32_t*)d_comp, wkey, go);
+            hipLaunchKernelGGL(boruvka_minedge_kernel, gm, blk, 0, ctx->stream, d_edges, m, d_len, is_containment, (const uint32_t*)d_comp,
+                               (const unsigned long long*)wkey, ekey, go);
+            hipLaunchKernelGGL(boruvka_fetch_kernel, gm, blk, 0, ctx->stream, d_edges, m, (const uint32_t*)d_comp,
+                               (const unsigned long long*)ekey, d_ecommon, go);
+          }
+          RTC_CHECK_LAUNCH(ctx);
         }
+        hipLaunchKernelGGL(boruvka_hook_kernel, gn, blk, 0, ctx->stream, K, (const uint32_t*)d_comp, n, d_succ, d_sel,
+                           (unsigned long long*)d_nsel, d_added + round, go);
+        RTC_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(boruvka_relabel_reset_kernel, gn, blk, 0, ctx->stream, d_comp, (const uint32_t*)d_succ, n, wkey, ekey, go);
         RTC_CHECK_LAUNCH(ctx);
       }
-      hipLaunchKernelGGL(boruvka_hook_kernel, gn, blk, 0, ctx->stream, K, (const uint32_t*)d_comp, n, d_succ, d_sel,
-                         (unsigned long long*)d_nsel, d_added + a);
-      RTC_CHECK_LAUNCH(ctx);
-      hipLaunchKernelGGL(boruvka_relabel_reset_kernel, gn, blk, 0, ctx->stream, d_comp, (const uint32_t*)d_succ, n, wkey, ekey,
-                         d_added + (a ^ 1));
-      RTC_CHECK_LAUNCH(ctx);
-      RTC_HIP(ctx, hipMemcpyAsync(hp, d_nsel, 16, hipMemcpyDeviceToHost, ctx->stream));
+      RTC_HIP(ctx, hipMemcpyAsync(hp, d_nsel, 8 + 4 * (size_t)round, hipMemcpyDeviceToHost, ctx->stream));
       RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      rounds++;
       *n_sel_out = ((const unsigned long long*)hp)[0];
-      if (!((const uint32_t*)hp)[2 + a]) break;
+      const uint32_t* added = (const uint32_t*)((const char*)hp + 8);
+      for (int r = first; r < round; r++)
+        if (!added[r]) { rounds = r + 1; break; }  // round r found no edge that leaves a component: it was the last one that ran
     }
+    if (!rounds) rounds = MAX_ROUNDS;
     if (rounds_out) *rounds_out = rounds;
     if (sorted) RTC_TRY(rtc_sort_forest_device(ctx, d_sel, *n_sel_out, d_len, is_containment));
     return RTC_OK;
@@ -453,6 +543,10 @@ int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, co
   el->m = 0;
   if (row1 <= std::max<uint32_t>(row0, 1)) return RTC_OK;
   row0 = std::max<uint32_t>(row0, 1);
+  if (!el->d_edges && !el->d_count && ctx->edge_cache) {  // the list the context kept from its last clustering call
+    el->d_edges = (rtc_cedge*)ctx->edge_cache; el->cap = ctx->edge_cache_cap; el->d_count = (unsigned long long*)ctx->edge_cache_count;
+    ctx->edge_cache = nullptr; ctx->edge_cache_cap = 0; ctx->edge_cache_count = nullptr;
+  }
   if (!el->d_count) RTC_HIP(ctx, hipMalloc((void**)&el->d_count, 64));
   auto ensure = [&](uint64_t want) -> int {
     if (want <= el->cap) return RTC_OK;
@@ -467,7 +561,8 @@ int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, co
     ctx->free_hbm_at = -1.0;  // (allocated and freed behind rtc_free_hbm's back: the pair phase sizes its scratch from it)
     return RTC_OK;
   };
-  RTC_TRY(ensure(std::min<uint64_t>(budget, std::max<uint64_t>((uint64_t)1 << 20, (uint64_t)n * 16))));
+  // the first list: 160 edges a genome (BASELINE configs[2]: 116 at 100 000 genomes of families of ten, 190 MB), a one-shot run's only launch then fits
+  RTC_TRY(ensure(std::min<uint64_t>(budget, std::max<uint64_t>((uint64_t)1 << 20, (uint64_t)n * 160))));
   auto run_rows = [&](uint32_t r0, uint32_t r1, unsigned long long* cnt_out) -> int {
     unsigned long long mm = el->m;
     RTC_HIP(ctx, hipMemcpyAsync(el->d_count, &mm, 8, hipMemcpyHostToDevice, ctx->stream));
@@ -534,9 +629,17 @@ int rtc_candidate_edges_device(rtc_ctx* ctx, const void* d_hashes, int width, co
   return st;
 }
 
-void rtc_edge_list_free(rtc_edge_list* el) {
+void rtc_edge_list_free(rtc_edge_list* el, rtc_ctx* ctx) {
+  if (ctx && el->d_edges && el->d_count && el->cap * sizeof(rtc_cedge) <= ((size_t)1 << 30)) {
+    if (ctx->edge_cache) (void)hipFree(ctx->edge_cache);
+    if (ctx->edge_cache_count) (void)hipFree(ctx->edge_cache_count);
+    ctx->edge_cache = el->d_edges; ctx->edge_cache_cap = el->cap; ctx->edge_cache_count = el->d_count;
+    *el = rtc_edge_list{};
+    return;
+  }
   if (el->d_edges) (void)hipFree(el->d_edges);
   if (el->d_count) (void)hipFree(el->d_count);
+  if (ctx) ctx->free_hbm_at = -1.0;
   *el = rtc_edge_list{};
 }
 
@@ -633,7 +736,7 @@ int rtc_boruvka_union_dev(rtc_ctx* ctx, uint32_t n, uint32_t s_fixed, const uint
   uint32_t* d_added = (uint32_t*)(d_nsel + 1);
   RTC_HIP(ctx, hipMemsetAsync(d_added, 0, 4, ctx->stream));
   hipLaunchKernelGGL(boruvka_hook_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(256), 0, ctx->stream, K, d_comp, n, d_succ,
-                     d_sel, (unsigned long long*)d_nsel, d_added);
+                     d_sel, (unsigned long long*)d_nsel, d_added, (const uint32_t*)nullptr);
   RTC_CHECK_LAUNCH(ctx);
   hipLaunchKernelGGL(boruvka_relabel_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(256), 0, ctx->stream, d_comp, d_succ, n);
   RTC_CHECK_LAUNCH(ctx);
@@ -691,33 +794,7 @@ int rtc_boruvka_fetch_dev(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, co
 
 int rtc_edges_to_mst_host(const rtc_cedge* h_sel, uint64_t m, const uint32_t* h_len, int kmer_size,
                           int is_containment, rtc_edge* h_out) {
-  if ((m && (!h_sel || !h_out)) || !h_len) return RTC_ERR_ARG;
-  auto fill = [&](uint64_t e0, uint64_t e1) {
-    for (uint64_t e = e0; e < e1; e++) {
-      h_out[e].preNode = (int32_t)h_sel[e].i;
-      h_out[e].sufNode = (int32_t)h_sel[e].j;
-      h_out[e].dist = host_mst_distance((int)h_sel[e].common, (int)h_len[h_sel[e].i], (int)h_len[h_sel[e].j],
-                                        kmer_size, is_containment);
-    }
-  };
-  // the distances are the host libm's (the reference's); beyond a few thousand edges the loop is split over threads
-  const uint64_t per = 4096;
-  const unsigned nt = (unsigned)std::min<uint64_t>(std::min<uint64_t>(8, std::max(1u, std::thread::hardware_concurrency())), (m + per - 1) / per);
-  if (nt <= 1) fill(0, m);
-  else {
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back(fill, m * t / nt, m * (t + 1) / nt);
-    fill(0, m / nt);
-    for (auto& x : th) x.join();
-  }
-  auto less = [](const rtc_edge& a, const rtc_edge& b) {
-    if (a.dist != b.dist) return a.dist < b.dist;
-    if (a.preNode != b.preNode) return a.preNode < b.preNode;
-    return a.sufNode < b.sufNode;
-  };
-  // forests that come from the device are already in this order (rtc_sort.hip): one pass instead of a sort
-  if (!std::is_sorted(h_out, h_out + m, less)) std::sort(h_out, h_out + m, less);
-  return RTC_OK;
+  return rtc_edges_to_mst_host_fixed(h_sel, m, h_len, kmer_size, is_containment, 0, h_out);
 }
 
 int rtc_boruvka_merge_host(uint32_t n, const uint64_t* h_ekey, const uint32_t* h_ecommon, uint32_t* h_comp,
@@ -804,17 +881,19 @@ int rtc_mst_dense(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t*
   if (dense_span) { memset(h_dense, 0, (size_t)dense_span * n * sizeof(int32_t)); memset(h_ani, 0, 101 * sizeof(uint64_t)); }
   if (n < 2 || start_index >= n) return RTC_OK;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
-  std::vector<uint32_t> h_len(n);
-  RTC_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  rtc_mst_bufs_t B{};
+  RTC_TRY(rtc_mst_bufs(ctx, n, &B));
+  uint32_t* const h_len = B.h_len;
+  RTC_HIP(ctx, hipMemcpyAsync(h_len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const uint32_t s_fixed = rtc_fixed_size_of(h_len.data(), n);
+  const uint32_t s_fixed = rtc_fixed_size_of(h_len, n);
 
   const bool verbose = ctx->opt.verbose && !ctx->quiet;
   auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
   const double tv0 = now();
   rtc_edge_list el{};
-  rtc_cedge* d_sel = nullptr;
-  DenseAcc acc{ctx, h_len.data(), n, kmer_size, is_containment, dense_span, s_fixed, h_dense, h_ani, {}, {}, {}, {}};
+  rtc_cedge* const d_sel = B.d_sel;
+  DenseAcc acc{ctx, h_len, n, kmer_size, is_containment, dense_span, s_fixed, h_dense, h_ani, {}, {}, {}, {}};
   rtc_edge_observer obs{DenseAcc::on_new, &acc};
   if (dense_span) {
     const double step = 1.0 / dense_span;                              // src/MST.cpp:1333-1340
@@ -833,24 +912,19 @@ int rtc_mst_dense(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t*
     }
   }
   uint64_t nsel = 0;
-  std::vector<rtc_cedge> sel;
   const double tv1 = now();
-  if (st == RTC_OK && hipMalloc((void**)&d_sel, (size_t)n * sizeof(rtc_cedge)) != hipSuccess)
-    st = rtc_fail(ctx, RTC_ERR_NOMEM, "hipMalloc forest list");
   int rounds = 0;
   if (st == RTC_OK) st = rtc_msf_device(ctx, el.d_edges, el.m, d_len, n, is_containment, s_fixed, nullptr, d_sel, &nsel, &rounds);
   const double tv2 = now();
   if (st == RTC_OK && nsel) {
-    sel.resize(nsel);
-    hipError_t e = hipMemcpyAsync(sel.data(), d_sel, nsel * sizeof(rtc_cedge), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipMemcpyAsync(B.h_sel, d_sel, nsel * sizeof(rtc_cedge), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) st = rtc_fail(ctx, RTC_ERR_HIP, "forest read-back -> %s", hipGetErrorString(e));
   }
   const uint64_t m_edges = el.m;
-  if (d_sel) (void)hipFree(d_sel);
-  rtc_edge_list_free(&el);
+  rtc_edge_list_free(&el, ctx);
   if (st != RTC_OK) return st;
-  RTC_TRY(rtc_edges_to_mst_host(sel.data(), nsel, h_len.data(), kmer_size, is_containment, h_edges_out));
+  RTC_TRY(rtc_edges_to_mst_host_fixed(B.h_sel, nsel, h_len, kmer_size, is_containment, s_fixed, h_edges_out));
   *h_n_edges = nsel;
   if (verbose)
     fprintf(stderr, "[mst]   %u sketches: %llu candidate edges in %.4fs, forest (%d rounds, %llu edges) in %.4fs, finish %.4fs\n", n,

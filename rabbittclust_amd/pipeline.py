@@ -447,7 +447,8 @@ class MstPipeline:
             "sketch_ms": ev[0].elapsed_time(ev[1]),
             "gather_ms": ev[1].elapsed_time(ev[2]),
             "pair_ms": float(st.pair_ms),
-            "mst_ms": float(st.mst_ms),
+            "mst_ms": ev[2].elapsed_time(ev[3]) - float(st.pair_ms),  # Boruvka + forest read-back + host distances: the rest of the call
+            "boruvka_ms": float(st.mst_ms),                            # its device rounds alone (HIP events inside rtc_mst_sharded)
             "dist_ms": ev[2].elapsed_time(ev[3]),
             "pairs_local": float(pairs_local),
             "cand_edges": float(st.cand_edges),

@@ -179,33 +179,61 @@ def test_mst_dense_input_edge_budget_contraction(ctx, oracle):
     assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
 
 
-def test_mst_when_the_join_estimate_of_the_edge_count_is_short(ctx, oracle):
-    """One family of 3 000 sketches at pairwise Jaccard ~0.3, default dispatch: the join's density sample refuses the set and
-    hands back an ESTIMATE of the candidate edges (1.5 x n x (g - 1) / 2 with g = the posting-list length a sampled hash sees,
-    ~0.46 n) that is SHORT of the truth -- every one of the 4.5 M pairs shares a hash.  The list grown to the estimate is too
-    short again; rtc_candidate_edges_device must grow it a second time from the exact count and never hand Boruvka a count
-    past the allocation (round 5's advisor finding: el->m = cnt > cap)."""
+def test_mst_when_the_join_estimate_of_the_edge_count_is_short(oracle):
+    """One family of 8 000 sketches (s = 500) at pairwise Jaccard ~0.3, default dispatch: the sort would be cheaper than the tiled
+    kernel, so the join looks at its density sample, refuses the set and hands back an ESTIMATE of the candidate edges (1.5 x n x
+    (g - 1) / 2 with g = the posting-list length a sampled hash sees, ~0.46 n: 22 M) that is SHORT of the truth -- every one of
+    the 32 M pairs shares a hash.  The list grown to the estimate is too short again; rtc_candidate_edges_device must grow it a
+    second time from the exact count and never hand Boruvka a count past the allocation (round 5's advisor finding: el->m = cnt
+    > cap).  Checked against the forest of the tiled kernel alone (RTC_PAIR_JOIN=0: no sample, no estimate) and, edge by edge,
+    against intersections counted in numpy."""
     from rabbittclust_amd import api
     rng = np.random.default_rng(77)
-    n, s = 3000, 120
-    pool = np.unique(rng.integers(1, 1 << 62, size=400, dtype=np.uint64))[:260]
-    sk = [np.sort(rng.choice(pool, size=s, replace=False)) for _ in range(n)]
+    n, s = 8000, 500
+    pool = np.unique(rng.integers(1, 1 << 62, size=1500, dtype=np.uint64))[:1090]
+    member = np.zeros((n, len(pool)), dtype=np.float32)
+    sk = []
+    for g in range(n):
+        idx = np.sort(rng.choice(len(pool), size=s, replace=False))
+        member[g, idx] = 1.0
+        sk.append(pool[idx])
+    ctx = api.Context(0)  # a context of its own: the session's may hold a long edge list from an earlier clustering call (it keeps the last one)
     dev = api.SketchSet.from_host(sk, ctx.device, k=21)
-    flat, start, lens = oracle.to_csr(sk)
-    want = oracle.mst(flat, start, lens, 21, 0, 0.05, threads=8)
     d0 = ctx.diag()
     got = ctx.mst(dev, 0.05)
     d1 = ctx.diag()
     assert d1["estimates"] == d0["estimates"] + 1, (d0, d1)                       # the early-out was taken ...
     assert d1["tiled_tiles"] >= d0["tiled_tiles"] + 2, (d0, d1)                   # ... and the list was short for the first real launch too
-    assert len(got) == len(want) == n - 1
-    assert np.array_equal(np.sort(got["dist"]).view(np.uint64), np.sort(want["dist"]).view(np.uint64))
+    assert len(got) == n - 1
+    with ctx.env(RTC_PAIR_JOIN="0"):
+        dev_b = api.SketchSet.from_host(sk, ctx.device, k=21)
+        want = ctx.mst(dev_b, 0.05)
+    assert ctx.diag()["estimates"] == d1["estimates"]
+    assert np.array_equal(got, want)
+    for e in got[:: max(1, len(got) // 300)]:
+        common = int(member[e["preNode"]] @ member[e["sufNode"]])
+        assert e["dist"] == api.mst_distance(common, s, s, 21, False)
+    # the forest is a spanning tree of minimum weight: no pair is closer than the heaviest edge allows on a cut -- spot check:
+    # every genome's best neighbour (most shared hashes) is at least as close as its lightest forest edge
+    inter = member[:200] @ member.T
+    inter[np.arange(200), np.arange(200)] = 0
+    best = inter.max(axis=1)
+    lightest = np.full(n, np.inf)
+    for e in got:
+        lightest[e["preNode"]] = min(lightest[e["preNode"]], e["dist"]); lightest[e["sufNode"]] = min(lightest[e["sufNode"]], e["dist"])
+    for g in range(200):
+        assert lightest[g] == api.mst_distance(int(best[g]), s, s, 21, False)
     # the pipeline's own loop around rtc_pair_edges_dev follows the same protocol
     from rabbittclust_amd import pipeline
     pipe = pipeline.MstPipeline(ctx, k=21, sketch_size=s, threshold=0.05)
-    dev2 = api.SketchSet.from_host(sk, ctx.device, k=21)  # a new sketch buffer: no remembered refusal
+    dev2 = api.SketchSet.from_host(sk, ctx.device, k=21)
     edges, m = pipe.candidate_edges(dev2, 0, n)
     assert m == n * (n - 1) // 2 and edges.shape[0] >= m
+    # the context kept the list: the next clustering call starts with it -- no estimate, one launch
+    got2 = ctx.mst(dev, 0.05)
+    d2 = ctx.diag()
+    assert np.array_equal(got2, got) and d2["estimates"] == d1["estimates"]
+    ctx.close()
 
 
 def test_pair_tiled_falls_back_when_transposed_copy_exceeds_budget(ctx, oracle):
