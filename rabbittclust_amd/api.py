@@ -455,13 +455,13 @@ class Context:
     def mst_sharded(self, comm, sk, threshold, is_containment=False):
         """rtc_mst across the ranks of `comm`; returns (edge.mst records, ShardStats)."""
         n = sk.n
-        out = np.zeros(max(n, 1), dtype=EDGE_DT)
+        out = np.empty(max(n, 1), dtype=EDGE_DT)  # (the call writes the first m records; the caller gets a view of them)
         m = C.c_uint64()
         stats = _lib.ShardStats()
         self.check(self.lib.rtc_mst_sharded(self.h, comm.h, _t_ptr(sk.hashes), sk.width, _t_ptr(sk.start), _t_ptr(sk.len),
                                             n, sk.k, int(is_containment), float(threshold), _np_ptr(out), C.byref(m),
                                             C.byref(stats)))
-        return out[:m.value].copy(), stats
+        return out[:m.value], stats
 
     def mst_mash(self, sk, sketch_size, is_containment=False, start_index=0, span=0):
         """modifyMST (the dense loop): spanning tree over EVERY pair, Mash-estimator / containDistance weights.

@@ -21,7 +21,13 @@
 #include <math.h>
 #include <time.h>
 
+#include <sched.h>
+
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <numeric>
 #include <thread>
 #include <vector>
@@ -108,6 +114,11 @@ __device__ __forceinline__ unsigned long long peek_min(const unsigned long long*
 // components from the second round on): one atomic per component for the first four of a wave, lane by lane beyond.
 __device__ __forceinline__ void wave_min_update(unsigned long long* __restrict__ key, uint32_t c, unsigned long long k, bool on) {
   const uint32_t lane = threadIdx.x & 63;
+  // A lane whose key cannot lower its component's running minimum drops out before anything is pooled: the minimum settles after
+  // the first few edges of a component, and from then on nearly every edge fails this one look (11.6 M edges of 100 000 genomes,
+  // most of them chance collisions of unrelated genomes with one common hash: 200 -> 70 us a round).  The value read can only be
+  // above the final minimum, so nothing that could still win is dropped.
+  if (on) on = k < peek_min(&key[c]);
   uint64_t todo = __ballot(on);
   for (int it = 0; it < 4 && todo; it++) {  // (wave-uniform)
     const int lead = __builtin_ctzll(todo);
@@ -368,6 +379,79 @@ static double host_mst_distance(int common, int size0, int size1, int kmer_size,
 // scratch slot 3 of a forest call: two u64 and three u32 per vertex, the forest counter and the rounds' counters
 size_t rtc_msf_scratch_bytes(uint32_t n) { return (((size_t)n * (8 + 8 + 4 + 4 + 4) + 64 + 8 + 4 * 64 + 64) + 255) & ~(size_t)255; }
 
+// ---- host threads of the distance loop: a pool that lives with the process ----
+// Spawning eight threads per call cost more than the 200 000 logarithms they shared (2.2 ms of a 4.7 ms MST phase); the pool's
+// workers sleep on a condition variable between calls.  Size: the cores this process may really use (affinity mask and cgroup-v2
+// CPU quota -- the GPU boxes show 256 CPUs under a 16-CPU quota), at most 16, the caller being one of them.
+namespace {
+unsigned host_usable_cores() {
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32] = {0};
+    unsigned long long period = 0;
+    if (fscanf(f, "%31s %llu", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      const unsigned long long quota = strtoull(q, nullptr, 10);
+      if (quota > 0) n = std::min<unsigned>(n, (unsigned)std::max<unsigned long long>(1, (quota + period - 1) / period));
+    }
+    fclose(f);
+  }
+  return n;
+}
+class HostPool {
+ public:
+  static HostPool& get() { static HostPool p; return p; }
+  unsigned size() const { return (unsigned)th_.size() + 1; }
+  // fn(part, parts) on every member of the pool (the caller is part 0); returns when all are done.  One caller at a time.
+  void run(const std::function<void(unsigned, unsigned)>& fn) {
+    std::lock_guard<std::mutex> one(call_);
+    const unsigned parts = size();
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn; pending_ = parts - 1; gen_++;
+    }
+    cv_.notify_all();
+    fn(0, parts);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+ private:
+  HostPool() {
+    const unsigned n = std::min(16u, host_usable_cores());
+    for (unsigned t = 1; t < n; t++) th_.emplace_back([this, t] { work(t); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  void work(unsigned part) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(unsigned, unsigned)>* fn;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+        fn = fn_;
+      }
+      (*fn)(part, size());
+      { std::lock_guard<std::mutex> lk(m_); if (--pending_ == 0) done_.notify_one(); }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_, call_;
+  std::condition_variable cv_, done_;
+  const std::function<void(unsigned, unsigned)>* fn_ = nullptr;
+  unsigned pending_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+}  // namespace
+
 // rtc_edges_to_mst_host with the caller's knowledge that every sketch holds s_fixed hashes (0: sizes vary): the distance is then a
 // function of `common` alone and comes from a table of s_fixed + 1 host-libm values -- the same doubles, one log() per distinct
 // count instead of one per edge.
@@ -388,23 +472,32 @@ int rtc_edges_to_mst_host_fixed(const rtc_cedge* h_sel, uint64_t m, const uint32
                           : host_mst_distance((int)h_sel[e].common, (int)h_len[h_sel[e].i], (int)h_len[h_sel[e].j], kmer_size, is_containment);
     }
   };
-  // the distances are the host libm's (the reference's); beyond a few thousand edges the loop is split over threads
-  const uint64_t per = table.empty() ? 4096 : 65536;
-  const unsigned nt = (unsigned)std::min<uint64_t>(std::min<uint64_t>(8, std::max(1u, std::thread::hardware_concurrency())), (m + per - 1) / per);
-  if (nt <= 1) fill(0, m);
-  else {
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back(fill, m * t / nt, m * (t + 1) / nt);
-    fill(0, m / nt);
-    for (auto& x : th) x.join();
-  }
   auto less = [](const rtc_edge& a, const rtc_edge& b) {
     if (a.dist != b.dist) return a.dist < b.dist;
     if (a.preNode != b.preNode) return a.preNode < b.preNode;
     return a.sufNode < b.sufNode;
   };
-  // forests that come from the device are already in this order (rtc_sort.hip): one pass instead of a sort
-  if (!std::is_sorted(h_out, h_out + m, less)) std::sort(h_out, h_out + m, less);
+  // the distances are the host libm's (the reference's); beyond a few thousand edges the loop is shared by the pool's threads,
+  // each of which also checks the order of its own stretch (forests that come from the device are already in the reference's
+  // output order, rtc_sort.hip: a check instead of a sort)
+  const uint64_t per = table.empty() ? 4096 : 32768;
+  std::atomic<int> unsorted{0};
+  if (m <= per) {
+    fill(0, m);
+    if (!std::is_sorted(h_out, h_out + m, less)) unsorted = 1;
+  } else {
+    HostPool::get().run([&](unsigned part, unsigned parts) {
+      const uint64_t e0 = m * part / parts, e1 = m * (part + 1) / parts;
+      fill(e0, e1);
+      if (!std::is_sorted(h_out + e0, h_out + e1, less)) unsorted = 1;
+    });
+    const unsigned parts = HostPool::get().size();
+    for (unsigned p = 1; p < parts && !unsorted; p++) {  // the seams
+      const uint64_t e = m * p / parts;
+      if (e > 0 && e < m && less(h_out[e], h_out[e - 1])) unsorted = 1;
+    }
+  }
+  if (unsorted) std::sort(h_out, h_out + m, less);
   return RTC_OK;
 }
 
