@@ -1095,7 +1095,7 @@ def main():
             sk_traffic = t1 * n_batches if t1 else None
         pair_path = int(round(ph.get("pair_path", 2.0)))
         pr_kernel = "pair_join_phase" if pair_path == 3 else "pair_tiled_kernel"
-        pr_traffic, pr_src = measured_traffic(pr_kernel, wl)
+        pr_traffic, pr_src = measured_traffic(pr_kernel, dict(wl, staging=None))  # (the pair phase does not see the staging: its PMC pass is the character run's)
         pr_ach = pr_traffic / (ph["pair_ms"] * 1e-3) / 1e9 if pr_traffic else None
         survey_bytes_pair = 2 * avg_len * width  # (|A| + |B|) * w per genome pair
         what = "MinHash k=%d s=%d" % (args.k, args.s) if mode == "minhash" else "KSSD --fast k=%d drlevel=%d" % (args.k, args.drlevel)

@@ -161,11 +161,16 @@ def test_mst_mash_equals_dense_loop_restatement(ctx, oracle, containment, monkey
     assert np.array_equal(np.sort(part["dist"]).view(np.uint64), np.sort(_kruskal_weights(D, 20)).view(np.uint64))
     assert np.all(part["sufNode"] >= 20)
     # the same forest when the edge list has to be contracted between row chunks
+    # (the 630 pairs of these 36 sketches fit the smallest budget the library accepts: a set of 72, 2 556 pairs, does not)
+    sizes2 = np.array([200 + 20 * (g % 7) for g in range(72)], dtype=np.uint32) if containment else None
+    sk2, host2 = _sketches(ctx, oracle, 12, 6, 120_000, s, 73, sizes2)
+    plain = ctx.mst_mash(sk2, s, is_containment=containment)
     with ctx.env(RTC_EDGE_BUDGET="1024"):  # (the library reads its switches at context creation: ctx.env makes this context read them again)
         c0 = ctx.diag()["contractions"]
-        again = ctx.mst_mash(sk, s, is_containment=containment)
+        again = ctx.mst_mash(sk2, s, is_containment=containment)
         assert ctx.diag()["contractions"] > c0, "the contraction path did not run"
-    assert np.array_equal(again, mst)
+    assert np.array_equal(again, plain) and len(plain) == 71
+    assert np.array_equal(np.sort(plain["dist"]).view(np.uint64), np.sort(_kruskal_weights(_dist_matrix(host2, s, k, containment))).view(np.uint64))
     # --dense by-products: EVERY pair counts (src/MST.cpp:868-879)
     mst2, dense, ani = ctx.mst_mash(sk, s, is_containment=containment, span=100)
     assert np.array_equal(mst2, mst)

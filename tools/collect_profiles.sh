@@ -3,11 +3,11 @@
 #   bench.py JSON line                                     -> gpurun_out/prof/<section>/bench.jsonl
 #   rocprofv3 --kernel-trace --stats of the same command   -> gpurun_out/prof/<section>/stats/  (kernel_stats.csv)
 #   rocprofv3 --pmc passes (own runs, --pmc only)          -> gpurun_out/prof/<section>/pmc*/  and <tag>_<section>_pmc_traffic.json
-# Sections: minhash (BASELINE config[1], the judged line with every extra), minhash_packed (the same batch from the 2-bit
-# staging format), kssd / kssd_packed (config[4]'s per-GPU shape), greedy (config[3]), dense (tiled N x N kernel regime).
+# Sections: minhash (BASELINE config[1] from the 2-bit staging format, the judged line with every extra), minhash_ascii (the same
+# batch resident as characters), kssd / kssd_packed (config[4]'s per-GPU shape), greedy (config[3]), dense (tiled N x N kernel regime).
 # Usage: bash tools/collect_profiles.sh [tag] [section ...]     (tag names the files, e.g. r05; no section = all)
-TAG=${1:-r05}; shift
-SECTIONS=${@:-minhash minhash_packed kssd kssd_packed greedy dense}
+TAG=${1:-r06}; shift
+SECTIONS=${@:-minhash minhash_ascii kssd kssd_packed greedy dense}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
@@ -25,7 +25,7 @@ run_section() {
     case $which in full) full+=("$a");; stats) stats+=("$a");; pmc) pmc+=("$a");; esac
   done
   python $R/bench.py "${full[@]}" > $D/bench.jsonl 2> $D/bench.err
-  tail -c 400 $D/bench.jsonl; echo
+  tail -n 1 $D/bench.jsonl | tail -c 600; echo
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python $R/bench.py "${stats[@]}" > $D/stats.log 2>&1
   python $R/tools/kstats.py $D/stats | head -10
   local i=0
@@ -36,17 +36,17 @@ run_section() {
 }
 for S in $SECTIONS; do
   case $S in
-    minhash)
+    minhash)   # the judged line: BASELINE config[1], batch resident in the 2-bit staging format, every extra
       run_section minhash --steps 5 --warmup 2 -- --steps 3 --warmup 1 --no-cpu-baseline --no-extra -- --steps 1 --warmup 0 --no-cpu-baseline --no-extra
-      python $R/tools/make_pmc_json.py $OUT/minhash $TAG > $OUT/${TAG}_pmc_traffic.json;;
-    minhash_packed)
-      run_section minhash_packed --staging packed --steps 5 --warmup 2 --no-extra -- --staging packed --steps 3 --warmup 1 --no-cpu-baseline --no-extra -- --staging packed --steps 1 --warmup 0 --no-cpu-baseline --no-extra
-      python $R/tools/make_pmc_json.py $OUT/minhash_packed ${TAG}_minhash_packed minhash 10000 5000000 packed > $OUT/${TAG}_minhash_packed_pmc_traffic.json;;
+      python $R/tools/make_pmc_json.py $OUT/minhash $TAG minhash 10000 5000000 packed > $OUT/${TAG}_pmc_traffic.json;;
+    minhash_ascii)   # the same batch resident as characters
+      run_section minhash_ascii --staging ascii --steps 5 --warmup 2 --no-extra -- --staging ascii --steps 3 --warmup 1 --no-cpu-baseline --no-extra -- --staging ascii --steps 1 --warmup 0 --no-cpu-baseline --no-extra
+      python $R/tools/make_pmc_json.py $OUT/minhash_ascii ${TAG}_minhash_ascii minhash 10000 5000000 > $OUT/${TAG}_minhash_ascii_pmc_traffic.json;;
     kssd)
-      run_section kssd --mode kssd --steps 3 --warmup 1 -- --mode kssd --steps 3 --warmup 1 --no-cpu-baseline -- --mode kssd --steps 1 --warmup 0 --no-cpu-baseline
+      run_section kssd --mode kssd --staging ascii --steps 3 --warmup 1 -- --mode kssd --staging ascii --steps 3 --warmup 1 --no-cpu-baseline -- --mode kssd --staging ascii --steps 1 --warmup 0 --no-cpu-baseline
       python $R/tools/make_pmc_json.py $OUT/kssd ${TAG}_kssd kssd 25000 2000000 > $OUT/${TAG}_kssd_pmc_traffic.json;;
     kssd_packed)
-      run_section kssd_packed --mode kssd --staging packed --steps 3 --warmup 1 -- --mode kssd --staging packed --steps 3 --warmup 1 --no-cpu-baseline -- --mode kssd --staging packed --steps 1 --warmup 0 --no-cpu-baseline
+      run_section kssd_packed --mode kssd --steps 3 --warmup 1 -- --mode kssd --steps 3 --warmup 1 --no-cpu-baseline -- --mode kssd --steps 1 --warmup 0 --no-cpu-baseline
       python $R/tools/make_pmc_json.py $OUT/kssd_packed ${TAG}_kssd_packed kssd 25000 2000000 packed > $OUT/${TAG}_kssd_packed_pmc_traffic.json;;
     greedy)
       # 50 000 prefix genomes of 0.4 .. 2 Mbp: 64 Gbp, mean length 1.28 Mbp (the "derived" per-step figures use genomes x this length)

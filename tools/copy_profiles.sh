@@ -2,10 +2,10 @@
 # Copies what tools/collect_profiles.sh left under gpurun_out/prof into profiles/ under the round's tag (the newest run of each
 # kind: gpurun merges every collection into the same directories), then rewrites profiles/README.md's table from the CSVs.
 # Usage: bash tools/copy_profiles.sh [tag]
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$(cd "$(dirname "$0")/.." && pwd)
 P=$R/gpurun_out/prof
-for S in minhash minhash_packed kssd kssd_packed greedy dense; do
+for S in minhash minhash_ascii minhash_packed kssd kssd_packed greedy dense; do
   [ -d $P/$S ] || continue
   N=${TAG}_$S; [ $S = minhash ] && N=${TAG}
   [ -s $P/$S/bench.jsonl ] && cp $P/$S/bench.jsonl $R/profiles/${N}_bench.jsonl
