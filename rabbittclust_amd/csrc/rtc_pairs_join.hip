@@ -27,6 +27,7 @@
 #include <cmath>
 
 #include "rtc_internal.h"
+#include "rtc_bucket_sort.h"
 
 namespace {
 
@@ -257,7 +258,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void join_count_kernel(const T* __restrict__ ks, const uint32_t* __restrict__ vs, uint32_t K,
                                                          uint32_t row0, uint32_t col0, uint32_t col1, uint32_t g0,
                                                          const uint64_t* __restrict__ off, unsigned long long* __restrict__ colcnt,
-                                                         uint2* __restrict__ desc) {
+                                                         uint2* __restrict__ desc, const uint32_t* __restrict__ unsorted) {
+  if (unsorted && *unsorted) return;  // the bucket sort left a group alone: nothing here may be trusted, the caller sorts again
   const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;  // (whole waves stay: the vote below)
   const uint32_t lane = threadIdx.x & 63;
   const bool in = a < K;
@@ -751,7 +753,11 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     RTC_HIP(ctx, rocprim::reduce(nullptr, tb_red, it, (unsigned long long*)nullptr, 0ull, (size_t)ng, rocprim::plus<unsigned long long>(), s));
   }
   const size_t b_keys = up256((size_t)K * sizeof(T)), b_vals = up256((size_t)(K + 1) * 4);
-  const size_t b_tmp1 = up256(std::max(tb_sort, tb_red));
+  unsigned end_bit = 1;  // [0, end_bit) holds every hash
+  while (end_bit < 8 * sizeof(T) && (maxkey >> end_bit)) end_bit++;
+  const rtc_bsort::Plan plan = rtc_bsort::make_plan(K, end_bit);
+  const bool own_sort = !ctx->opt.join_rocprim;
+  const size_t b_tmp1 = up256(std::max(std::max(tb_sort, tb_red), own_sort ? plan.scratch : (size_t)0));
   // keys0 | vals0 | keys1 | vals1 | temp | colcnt, total | heavy.  The descriptors (8 bytes per element) lie over
   // keys0 | vals0, which the sort has read by then.
   const size_t b_col = up256(((size_t)ng * CC_CSTRIDE + 8) * 8), b_heavy = up256((size_t)(ng + 4) * 4);
@@ -780,25 +786,37 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   // end_bit + repair of the rare mixed runs; when the repair gives up (a collision inside a very long posting
   // list), once more on all of them.  rocPRIM 4.2 mis-sorts ranges [b > 0, 64) below ~1M keys (its merge-sort
   // path, tools/ubench/sort_check.hip): those inputs take the full range.
-  unsigned end_bit = 1;
-  while (end_bit < 8 * sizeof(T) && (maxkey >> end_bit)) end_bit++;
   // distinct hashes that agree in the b sorted bits: about K^2 / 2^(b + 3) inversions (measured 3 535 at K = 10^7, b = 32);
   // b grows by a radix pass (8 bits) while they would cost more in the repair list's atomics than the pass does
   unsigned sort_bits = 32;
   while (sort_bits < 64 && (double)K * (double)K / std::ldexp(1.0, (int)sort_bits + 3) > (double)FIX_EXPECT_MAX) sort_bits += 8;
   const unsigned half_bit = end_bit > sort_bits ? end_bit - sort_bits : 0;
-  for (int attempt = 0; attempt < 2; attempt++) {
-    const bool halfsort = sizeof(T) == 8 && attempt == 0 && half_bit > 0 && (end_bit < 64 || K >= (1u << 22)) &&
+  // attempt -1: the join's own bucket sort (rtc_bucket_sort.h); 0 / 1: the library's radix sort (RTC_JOIN_ROCPRIM=1, or a key
+  // distribution the bucket sort's groups did not fit) on half the bits + repair, then on all of them
+  for (int attempt = own_sort ? -1 : 0; attempt < 2; attempt++) {
+    const bool use_own = attempt < 0;
+    const bool halfsort = !use_own && sizeof(T) == 8 && attempt == 0 && half_bit > 0 && (end_bit < 64 || K >= (1u << 22)) &&
                           !ctx->opt.join_fullsort;
-    // (the flat copy anew for the second attempt: the first one's descriptors lie over it)
+    // (the flat copy anew for every attempt: the one before left its descriptors over it).  The bucket sort changes buffers
+    // once per pass and must end in keys1 | vals1: with an even number of passes it starts there.
+    const int flips = use_own ? plan.passes + (plan.lo_bits > 0 ? 1 : 0) : 1;
+    T* kin = (flips & 1) ? keys0 : keys1;
+    uint32_t* vin = (flips & 1) ? vals0 : vals1;
     if (semi)
       hipLaunchKernelGGL((join_semi_kernel<T, true>), dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, g0, row0, wshift,
-                         (const unsigned long long*)d_bloom, (uint32_t*)nullptr, (const uint64_t*)d_off, keys0, vals0);
+                         (const unsigned long long*)d_bloom, (uint32_t*)nullptr, (const uint64_t*)d_off, kin, vin);
     else
-      hipLaunchKernelGGL(join_flatten_kernel<T>, dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, d_off, g0, keys0, vals0);
+      hipLaunchKernelGGL(join_flatten_kernel<T>, dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, d_off, g0, kin, vin);
     RTC_CHECK_LAUNCH(ctx);
-    RTC_HIP(ctx, rocprim::radix_sort_pairs(tmp1, tb_sort, (const T*)keys0, keys1, (const uint32_t*)vals0, vals1, (size_t)K,
-                                           halfsort ? half_bit : 0u, end_bit, s));
+    uint32_t* d_unsorted = nullptr;
+    if (use_own) {
+      bool in_a = false;
+      RTC_HIP(ctx, rtc_bsort::sort_pairs<T>(plan, kin, vin, (flips & 1) ? keys1 : keys0, (flips & 1) ? vals1 : vals0, K, end_bit, tmp1, s, &in_a, &d_unsorted));
+      if (in_a != ((flips & 1) == 0)) return rtc_fail(ctx, RTC_ERR_HIP, "bucket sort: result in the wrong buffer");
+    } else {
+      RTC_HIP(ctx, rocprim::radix_sort_pairs(tmp1, tb_sort, (const T*)keys0, keys1, (const uint32_t*)vals0, vals1, (size_t)K,
+                                             halfsort ? half_bit : 0u, end_bit, s));
+    }
     if constexpr (sizeof(T) == 8) {
       if (halfsort) {
         RTC_HIP(ctx, hipMemsetAsync(d_fix, 0, 8, s));
@@ -812,8 +830,9 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     }
     RTC_HIP(ctx, hipMemsetAsync(d_colcnt, 0, (size_t)ng * CC_CSTRIDE * 8, s));
     hipLaunchKernelGGL(join_count_kernel<T>, dim3((K + 255) / 256), dim3(256), 0, s, (const T*)keys1, (const uint32_t*)vals1, K,
-                       row0, col0, col1, g0, (const uint64_t*)d_off, (unsigned long long*)d_colcnt, d_desc);
+                       row0, col0, col1, g0, (const uint64_t*)d_off, (unsigned long long*)d_colcnt, d_desc, (const uint32_t*)d_unsorted);
     RTC_CHECK_LAUNCH(ctx);
+    if (use_own) RTC_HIP(ctx, hipMemcpyAsync((char*)hpin + 48, d_unsorted, 4, hipMemcpyDeviceToHost, s));  // (before the reduction below reuses tmp1)
     {
       auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0), ColPartners{(const unsigned long long*)d_colcnt});
       RTC_HIP(ctx, rocprim::reduce(tmp1, tb_red, it, (unsigned long long*)d_total, 0ull, (size_t)ng, rocprim::plus<unsigned long long>(), s));
@@ -822,8 +841,11 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     if (halfsort) RTC_HIP(ctx, hipMemcpyAsync((char*)hpin + 8, d_fix, 8, hipMemcpyDeviceToHost, s));
     RTC_HIP(ctx, hipStreamSynchronize(s));
     E = *(const uint64_t*)hpin;
-    if (ctx->opt.join_debug) fprintf(stderr, "[join] K=%u attempt=%d halfsort=%d E=%llu (sample: %.3g) inversions=%u giveup=%u t_sort=%.3g t_tiled=%.3g ms\n", K, attempt, (int)halfsort,
+    const bool unsorted = use_own && *(const uint32_t*)((const char*)hpin + 48) != 0;
+    if (ctx->opt.join_debug) fprintf(stderr, "[join] K=%u attempt=%d %s E=%llu (sample: %.3g) inversions=%u giveup=%u t_sort=%.3g t_tiled=%.3g ms\n", K, attempt,
+                                          use_own ? (unsorted ? "bucket sort: a group did not fit" : "bucket sort") : (halfsort ? "halfsort" : "fullsort"),
                                           (unsigned long long)E, E_sample, halfsort ? ((const uint32_t*)hpin)[2] : 0u, halfsort ? ((const uint32_t*)hpin)[3] : 0u, t_sort * 1e3, t_tiled * 1e3);
+    if (unsorted) continue;  // keys crowded into few groups: the library's sort does not care
     if (halfsort && ((const uint32_t*)hpin)[3]) {  // not repaired: sort on all bits -- unless the (approximate) count
       // of the unrepaired lists already says the input is dense: then the tiled kernel runs, without a second sort
       if (E >= (1ull << 31) || (mode == 1 && t_sort + (double)E / JOIN_E_RATE > t_tiled)) { note_dense(); return RTC_OK; }  // (a second sort is still to come)
