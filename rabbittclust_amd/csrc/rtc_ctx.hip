@@ -83,7 +83,6 @@ void rtc_options_from_env(rtc_options* o) {
   o->join_semi = (int)num("RTC_JOIN_SEMI", 1);
   o->join_fullsort = flag("RTC_JOIN_FULLSORT");
   o->join_debug = flag("RTC_JOIN_DEBUG");
-  o->join_rocprim = flag("RTC_JOIN_ROCPRIM");
   o->pair_force_merge = flag("RTC_PAIR_FORCE_MERGE");
   o->pair_ktarget = (uint32_t)std::max<long long>(0, num("RTC_PAIR_KTARGET", 0));
   if (const char* e = getenv("RTC_PAIR_TCOLS_BUDGET")) o->pair_tcols_budget = std::max<uint64_t>(strtoull(e, nullptr, 10), 1);

@@ -19,7 +19,6 @@ struct rtc_options {
   int join_semi = 1;               // RTC_JOIN_SEMI: 0 never, 1 by rule, 2 always
   int join_fullsort = 0;           // RTC_JOIN_FULLSORT
   int join_debug = 0;              // RTC_JOIN_DEBUG
-  int join_rocprim = 0;            // RTC_JOIN_ROCPRIM: the library's radix sort instead of rtc_bucket_sort.h (A/B; also its fallback)
   int pair_force_merge = 0;        // RTC_PAIR_FORCE_MERGE
   uint32_t pair_ktarget = 0;       // RTC_PAIR_KTARGET (0: the kernel's default)
   uint64_t pair_tcols_budget = 0;  // RTC_PAIR_TCOLS_BUDGET (0: default)

@@ -27,7 +27,6 @@
 #include <cmath>
 
 #include "rtc_internal.h"
-#include "rtc_bucket_sort.h"
 
 namespace {
 
@@ -174,14 +173,23 @@ __global__ __launch_bounds__(256) void join_semi_kernel(const T* __restrict__ ha
 // 64-bit hashes are sorted on their 32 most significant bits that vary only (half the radix passes; bottom-s MinHash
 // values are small, the bits above the largest hash are skipped as well).  Distinct hashes that agree in those bits
 // end up in one run in input order; such a run is out of order somewhere, which is what this kernel
-// looks for (a few per million hashes).  fix[0] = inversions found, fix[1] = "could not repair", fix[2..] = positions.
+// looks for (a few per million hashes).  An inversion is noted in one of the FIX_SLOTS places of its workgroup's own row of
+// `slots` -- no shared counter: until round 6 every wave that saw one took its place in ONE list with an atomic, and atomics on one
+// address queue up (~7.5 ns each: 2.2 ms for the 291 000 inversions of K = 10^8 on 32 bits, which is why such sets were sorted on
+// 40 bits, a fifth radix pass of 0.78 ms).  Only a workgroup with more inversions than its row holds (one in a thousand at that
+// density) spills into the list: fix[0] = entries of the list, fix[1] = "could not repair", fix[2..] = positions.
 constexpr uint32_t FIX_CAP = 1u << 20;
 constexpr uint32_t FIX_RUN_MAX = 2048;
-// Every wave that sees an inversion takes a place in the list with an atomic on ONE counter, and those queue up (~7.5 ns
-// each: 2.2 ms for the 291 000 inversions of K = 10^8 on 32 bits, against 0.75 ms for a fifth radix pass): past this many
-// expected inversions another radix pass is the cheaper way.
-constexpr uint32_t FIX_EXPECT_MAX = 1u << 16;
-__global__ __launch_bounds__(256) void join_inversions_kernel(const uint64_t* __restrict__ ks, uint32_t K, int sh, uint32_t* __restrict__ fix) {
+constexpr uint32_t FIX_SLOTS = 4, FIX_NONE = 0xffffffffu;
+// past this many expected inversions another radix pass is the cheaper way (the repair itself is a lane per inversion)
+constexpr uint32_t FIX_EXPECT_MAX = 1u << 20;
+__global__ __launch_bounds__(256) void join_inversions_kernel(const uint64_t* __restrict__ ks, uint32_t K, int sh, uint32_t* __restrict__ fix,
+                                                              uint32_t* __restrict__ slots) {
+  __shared__ uint32_t s_n;
+  __shared__ uint32_t s_at[FIX_SLOTS];
+  if (threadIdx.x == 0) s_n = 0;
+  if (threadIdx.x < FIX_SLOTS) s_at[threadIdx.x] = FIX_NONE;
+  __syncthreads();
   const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
   bool inv = false;
   if (a + 1 < K) {
@@ -189,42 +197,51 @@ __global__ __launch_bounds__(256) void join_inversions_kernel(const uint64_t* __
     if ((x >> sh) > (y >> sh)) fix[1] = 1;  // not sorted on the bits asked for: never seen, never trusted
     inv = x > y;
   }
-  const uint64_t bal = __ballot(inv);  // one atomic per wave
-  if (!bal) return;
-  const uint32_t lane = threadIdx.x & 63;
-  uint32_t base = 0;
-  if (lane == (uint32_t)__builtin_ctzll(bal)) base = atomicAdd(&fix[0], (uint32_t)__popcll(bal));
-  base = (uint32_t)__shfl((int)base, __builtin_ctzll(bal));
   if (inv) {
-    const uint32_t i = base + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
-    if (i < FIX_CAP) fix[2 + i] = a;
+    const uint32_t i = atomicAdd(&s_n, 1u);  // (LDS)
+    if (i < FIX_SLOTS) s_at[i] = a;
+    else {
+      const uint32_t j = atomicAdd(&fix[0], 1u);
+      if (j < FIX_CAP) fix[2 + j] = a;
+    }
   }
+  __syncthreads();
+  if (threadIdx.x < FIX_SLOTS) slots[(size_t)blockIdx.x * FIX_SLOTS + threadIdx.x] = s_at[threadIdx.x];
+}
+
+// entry t of the inversions: the workgroups' rows first, the spill list behind them
+__device__ __forceinline__ uint32_t* fix_entry(uint32_t t, uint32_t nslots, uint32_t* slots, uint32_t* fix) {
+  if (t < nslots) return slots + t;
+  const uint32_t j = t - nslots;
+  return j < min(fix[0], FIX_CAP) ? fix + 2 + j : nullptr;
 }
 
 // One lane per inversion.  First (read-only) pass: is this the first inversion of its run?  The others are struck
 // out (bit 31).  Second pass: the remaining lanes each sort their run by the full hash with a stable insertion
 // sort (two or three posting lists interleaved, rarely more than a few dozen elements); the runs are disjoint.
-__global__ __launch_bounds__(64) void join_repair_owner_kernel(const uint64_t* __restrict__ ks, int sh, uint32_t* __restrict__ fix) {
+__global__ __launch_bounds__(64) void join_repair_owner_kernel(const uint64_t* __restrict__ ks, int sh, uint32_t* __restrict__ fix,
+                                                               uint32_t* __restrict__ slots, uint32_t nslots) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t nf = fix[0];
-  if (nf > FIX_CAP) { if (i == 0) fix[1] = 1; return; }
-  if (i >= nf) return;
-  const uint32_t a = fix[2 + i];
+  if (fix[0] > FIX_CAP) { if (i == 0) fix[1] = 1; return; }
+  uint32_t* ent = fix_entry(i, nslots, slots, fix);
+  if (!ent || *ent == FIX_NONE) return;
+  const uint32_t a = *ent;
   const uint64_t pre = ks[a] >> sh;
   uint32_t s = a;
   while (s > 0 && (ks[s - 1] >> sh) == pre) {
     s--;
     if (a - s > FIX_RUN_MAX) { fix[1] = 1; return; }
-    if (ks[s] > ks[s + 1]) { fix[2 + i] = a | 0x80000000u; return; }  // an earlier inversion of the same run
+    if (ks[s] > ks[s + 1]) { *ent = a | 0x80000000u; return; }  // an earlier inversion of the same run
   }
 }
 __global__ __launch_bounds__(64) void join_repair_kernel(uint64_t* __restrict__ ks, uint32_t* __restrict__ vs, uint32_t K, int sh,
-                                                         uint32_t* __restrict__ fix) {
+                                                         uint32_t* __restrict__ fix, uint32_t* __restrict__ slots, uint32_t nslots) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t nf = fix[0];
-  if (nf > FIX_CAP || fix[1] || i >= nf) return;
-  const uint32_t a = fix[2 + i];
-  if (a & 0x80000000u) return;
+  if (fix[0] > FIX_CAP || fix[1]) return;
+  uint32_t* ent = fix_entry(i, nslots, slots, fix);
+  if (!ent) return;
+  const uint32_t a = *ent;
+  if (a & 0x80000000u) return;  // (struck out, or FIX_NONE)
   const uint64_t pre = ks[a] >> sh;
   uint32_t s = a;
   while (s > 0 && (ks[s - 1] >> sh) == pre) s--;
@@ -258,8 +275,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void join_count_kernel(const T* __restrict__ ks, const uint32_t* __restrict__ vs, uint32_t K,
                                                          uint32_t row0, uint32_t col0, uint32_t col1, uint32_t g0,
                                                          const uint64_t* __restrict__ off, unsigned long long* __restrict__ colcnt,
-                                                         uint2* __restrict__ desc, const uint32_t* __restrict__ unsorted) {
-  if (unsorted && *unsorted) return;  // the bucket sort left a group alone: nothing here may be trusted, the caller sorts again
+                                                         uint2* __restrict__ desc) {
   const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;  // (whole waves stay: the vote below)
   const uint32_t lane = threadIdx.x & 63;
   const bool in = a < K;
@@ -753,11 +769,7 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     RTC_HIP(ctx, rocprim::reduce(nullptr, tb_red, it, (unsigned long long*)nullptr, 0ull, (size_t)ng, rocprim::plus<unsigned long long>(), s));
   }
   const size_t b_keys = up256((size_t)K * sizeof(T)), b_vals = up256((size_t)(K + 1) * 4);
-  unsigned end_bit = 1;  // [0, end_bit) holds every hash
-  while (end_bit < 8 * sizeof(T) && (maxkey >> end_bit)) end_bit++;
-  const rtc_bsort::Plan plan = rtc_bsort::make_plan(K, end_bit);
-  const bool own_sort = !ctx->opt.join_rocprim;
-  const size_t b_tmp1 = up256(std::max(std::max(tb_sort, tb_red), own_sort ? plan.scratch : (size_t)0));
+  const size_t b_tmp1 = up256(std::max(std::max(tb_sort, tb_red), ((size_t)K / 256 + 2) * FIX_SLOTS * 4));  // (+ the half-key sort's rows of inversions)
   // keys0 | vals0 | keys1 | vals1 | temp | colcnt, total | heavy.  The descriptors (8 bytes per element) lie over
   // keys0 | vals0, which the sort has read by then.
   const size_t b_col = up256(((size_t)ng * CC_CSTRIDE + 8) * 8), b_heavy = up256((size_t)(ng + 4) * 4);
@@ -786,53 +798,44 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   // end_bit + repair of the rare mixed runs; when the repair gives up (a collision inside a very long posting
   // list), once more on all of them.  rocPRIM 4.2 mis-sorts ranges [b > 0, 64) below ~1M keys (its merge-sort
   // path, tools/ubench/sort_check.hip): those inputs take the full range.
+  unsigned end_bit = 1;
+  while (end_bit < 8 * sizeof(T) && (maxkey >> end_bit)) end_bit++;
   // distinct hashes that agree in the b sorted bits: about K^2 / 2^(b + 3) inversions (measured 3 535 at K = 10^7, b = 32);
   // b grows by a radix pass (8 bits) while they would cost more in the repair list's atomics than the pass does
   unsigned sort_bits = 32;
   while (sort_bits < 64 && (double)K * (double)K / std::ldexp(1.0, (int)sort_bits + 3) > (double)FIX_EXPECT_MAX) sort_bits += 8;
   const unsigned half_bit = end_bit > sort_bits ? end_bit - sort_bits : 0;
-  // attempt -1: the join's own bucket sort (rtc_bucket_sort.h); 0 / 1: the library's radix sort (RTC_JOIN_ROCPRIM=1, or a key
-  // distribution the bucket sort's groups did not fit) on half the bits + repair, then on all of them
-  for (int attempt = own_sort ? -1 : 0; attempt < 2; attempt++) {
-    const bool use_own = attempt < 0;
-    const bool halfsort = !use_own && sizeof(T) == 8 && attempt == 0 && half_bit > 0 && (end_bit < 64 || K >= (1u << 22)) &&
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const bool halfsort = sizeof(T) == 8 && attempt == 0 && half_bit > 0 && (end_bit < 64 || K >= (1u << 22)) &&
                           !ctx->opt.join_fullsort;
-    // (the flat copy anew for every attempt: the one before left its descriptors over it).  The bucket sort changes buffers
-    // once per pass and must end in keys1 | vals1: with an even number of passes it starts there.
-    const int flips = use_own ? plan.passes + (plan.lo_bits > 0 ? 1 : 0) : 1;
-    T* kin = (flips & 1) ? keys0 : keys1;
-    uint32_t* vin = (flips & 1) ? vals0 : vals1;
+    // (the flat copy anew for the second attempt: the first one's descriptors lie over it)
     if (semi)
       hipLaunchKernelGGL((join_semi_kernel<T, true>), dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, g0, row0, wshift,
-                         (const unsigned long long*)d_bloom, (uint32_t*)nullptr, (const uint64_t*)d_off, kin, vin);
+                         (const unsigned long long*)d_bloom, (uint32_t*)nullptr, (const uint64_t*)d_off, keys0, vals0);
     else
-      hipLaunchKernelGGL(join_flatten_kernel<T>, dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, d_off, g0, kin, vin);
+      hipLaunchKernelGGL(join_flatten_kernel<T>, dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, d_off, g0, keys0, vals0);
     RTC_CHECK_LAUNCH(ctx);
-    uint32_t* d_unsorted = nullptr;
-    if (use_own) {
-      bool in_a = false;
-      RTC_HIP(ctx, rtc_bsort::sort_pairs<T>(plan, kin, vin, (flips & 1) ? keys1 : keys0, (flips & 1) ? vals1 : vals0, K, end_bit, tmp1, s, &in_a, &d_unsorted));
-      if (in_a != ((flips & 1) == 0)) return rtc_fail(ctx, RTC_ERR_HIP, "bucket sort: result in the wrong buffer");
-    } else {
-      RTC_HIP(ctx, rocprim::radix_sort_pairs(tmp1, tb_sort, (const T*)keys0, keys1, (const uint32_t*)vals0, vals1, (size_t)K,
-                                             halfsort ? half_bit : 0u, end_bit, s));
-    }
+    RTC_HIP(ctx, rocprim::radix_sort_pairs(tmp1, tb_sort, (const T*)keys0, keys1, (const uint32_t*)vals0, vals1, (size_t)K,
+                                           halfsort ? half_bit : 0u, end_bit, s));
     if constexpr (sizeof(T) == 8) {
       if (halfsort) {
+        // (the workgroups' rows of inversions lie in the sort's temporary storage: the sort is done, the reduction below comes later)
+        uint32_t* d_slots = (uint32_t*)tmp1;
+        const uint32_t nwg = (K + 255) / 256, nslots = nwg * FIX_SLOTS;
         RTC_HIP(ctx, hipMemsetAsync(d_fix, 0, 8, s));
-        hipLaunchKernelGGL(join_inversions_kernel, dim3((K + 255) / 256), dim3(256), 0, s, (const uint64_t*)keys1, K, (int)half_bit, d_fix);
+        hipLaunchKernelGGL(join_inversions_kernel, dim3(nwg), dim3(256), 0, s, (const uint64_t*)keys1, K, (int)half_bit, d_fix, d_slots);
         RTC_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL(join_repair_owner_kernel, dim3(FIX_CAP / 64), dim3(64), 0, s, (const uint64_t*)keys1, (int)half_bit, d_fix);
+        const uint32_t nent = nslots + FIX_CAP;
+        hipLaunchKernelGGL(join_repair_owner_kernel, dim3((nent + 63) / 64), dim3(64), 0, s, (const uint64_t*)keys1, (int)half_bit, d_fix, d_slots, nslots);
         RTC_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL(join_repair_kernel, dim3(FIX_CAP / 64), dim3(64), 0, s, (uint64_t*)keys1, vals1, K, (int)half_bit, d_fix);
+        hipLaunchKernelGGL(join_repair_kernel, dim3((nent + 63) / 64), dim3(64), 0, s, (uint64_t*)keys1, vals1, K, (int)half_bit, d_fix, d_slots, nslots);
         RTC_CHECK_LAUNCH(ctx);
       }
     }
     RTC_HIP(ctx, hipMemsetAsync(d_colcnt, 0, (size_t)ng * CC_CSTRIDE * 8, s));
     hipLaunchKernelGGL(join_count_kernel<T>, dim3((K + 255) / 256), dim3(256), 0, s, (const T*)keys1, (const uint32_t*)vals1, K,
-                       row0, col0, col1, g0, (const uint64_t*)d_off, (unsigned long long*)d_colcnt, d_desc, (const uint32_t*)d_unsorted);
+                       row0, col0, col1, g0, (const uint64_t*)d_off, (unsigned long long*)d_colcnt, d_desc);
     RTC_CHECK_LAUNCH(ctx);
-    if (use_own) RTC_HIP(ctx, hipMemcpyAsync((char*)hpin + 48, d_unsorted, 4, hipMemcpyDeviceToHost, s));  // (before the reduction below reuses tmp1)
     {
       auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0), ColPartners{(const unsigned long long*)d_colcnt});
       RTC_HIP(ctx, rocprim::reduce(tmp1, tb_red, it, (unsigned long long*)d_total, 0ull, (size_t)ng, rocprim::plus<unsigned long long>(), s));
@@ -841,11 +844,8 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     if (halfsort) RTC_HIP(ctx, hipMemcpyAsync((char*)hpin + 8, d_fix, 8, hipMemcpyDeviceToHost, s));
     RTC_HIP(ctx, hipStreamSynchronize(s));
     E = *(const uint64_t*)hpin;
-    const bool unsorted = use_own && *(const uint32_t*)((const char*)hpin + 48) != 0;
-    if (ctx->opt.join_debug) fprintf(stderr, "[join] K=%u attempt=%d %s E=%llu (sample: %.3g) inversions=%u giveup=%u t_sort=%.3g t_tiled=%.3g ms\n", K, attempt,
-                                          use_own ? (unsorted ? "bucket sort: a group did not fit" : "bucket sort") : (halfsort ? "halfsort" : "fullsort"),
+    if (ctx->opt.join_debug) fprintf(stderr, "[join] K=%u attempt=%d halfsort=%d E=%llu (sample: %.3g) inversions=%u giveup=%u t_sort=%.3g t_tiled=%.3g ms\n", K, attempt, (int)halfsort,
                                           (unsigned long long)E, E_sample, halfsort ? ((const uint32_t*)hpin)[2] : 0u, halfsort ? ((const uint32_t*)hpin)[3] : 0u, t_sort * 1e3, t_tiled * 1e3);
-    if (unsorted) continue;  // keys crowded into few groups: the library's sort does not care
     if (halfsort && ((const uint32_t*)hpin)[3]) {  // not repaired: sort on all bits -- unless the (approximate) count
       // of the unrepaired lists already says the input is dense: then the tiled kernel runs, without a second sort
       if (E >= (1ull << 31) || (mode == 1 && t_sort + (double)E / JOIN_E_RATE > t_tiled)) { note_dense(); return RTC_OK; }  // (a second sort is still to come)

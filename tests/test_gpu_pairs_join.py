@@ -372,12 +372,12 @@ def test_pair_paths_on_random_tiles(ctx, oracle, seed):
 
 @pytest.mark.parametrize("width", [8, 4])
 @pytest.mark.parametrize("shape", ["even", "crowded", "two_values", "large"])
-def test_join_bucket_sort_shapes_equal_library_sort_and_tiled(ctx, oracle, width, shape):
-    """The join's own sort (rtc_bucket_sort.h: partition passes over the top bits + a sort of every group inside LDS) on key
-    distributions that stress its plan: hashes spread evenly (the groups it aims at), hashes CROWDED into a sliver below the
-    largest one (one group would hold nearly everything: the flag goes up and the library's sort takes over), two distinct
-    values (posting lists of thousands), and a set large enough for two partition passes.  Forced join with the bucket sort,
-    forced join with the library's sort (RTC_JOIN_ROCPRIM=1) and the tiled kernel give the same triples."""
+def test_join_on_key_distributions_that_stress_its_sort(ctx, oracle, width, shape):
+    """Key distributions that stress the sort in front of the join's count: hashes spread evenly, hashes CROWDED into a sliver
+    below the largest one (the radix passes over the bits that vary see one digit), two distinct values (posting lists of
+    thousands) and a set of 2.4 million records.  For u64 sets the sort runs on half the key bits and repairs the runs of distinct
+    hashes that agree in them: `crowded` is nothing but such runs.  Forced join == tiled kernel, whole triangle, a row shard
+    (semi-join in front of the sort) and a column window; the first 300 sketches against the oracle."""
     from rabbittclust_amd import api
     rng = np.random.default_rng({"even": 1, "crowded": 2, "two_values": 3, "large": 4}[shape] * 10 + width)
     dt = np.uint64 if width == 8 else np.uint32
@@ -393,7 +393,7 @@ def test_join_bucket_sort_shapes_equal_library_sort_and_tiled(ctx, oracle, width
         n, s = 2500, 2
         pool = np.array([7, (1 << hi) + 12345], dtype=dt)
     else:
-        n, s = 12000, 200   # K = 2.4e6: two partition passes, ~1 200 groups of ~2 000 ... ~1 100
+        n, s = 12000, 200
         pool = np.unique(rng.integers(1, 1 << hi, size=600000, dtype=np.uint64)).astype(dt)
     sk = [np.sort(rng.choice(pool, size=min(s, len(pool)), replace=False)) for _ in range(n)]
     dev = api.SketchSet.from_host(sk, ctx.device, width=width, kind="kssd" if width == 4 else "minhash")
@@ -402,10 +402,7 @@ def test_join_bucket_sort_shapes_equal_library_sort_and_tiled(ctx, oracle, width
     d0 = ctx.diag()
     own = _edges(ctx, dev, 1, n, 0, n - 1, -1, 2, cap=cap)
     assert ctx.diag()["join_tiles"] == d0["join_tiles"] + 1, "the join did not run"
-    with ctx.env(RTC_JOIN_ROCPRIM="1"):
-        lib = _edges(ctx, dev, 1, n, 0, n - 1, -1, 2, cap=cap)
-    assert len(tiled) > 0 and np.array_equal(own, tiled) and np.array_equal(lib, tiled)
-    # a row shard of the same set (the semi-join in front of the sort) and a column window
+    assert len(tiled) > 0 and np.array_equal(own, tiled)
     r0 = n - n // 8
     assert np.array_equal(_edges(ctx, dev, r0, n, 0, n - 1, -1, 2, cap=cap), _edges(ctx, dev, r0, n, 0, n - 1, -1, 0, cap=cap))
     assert np.array_equal(_edges(ctx, dev, n // 2, n, 100, n // 3, -1, 2, cap=cap), _edges(ctx, dev, n // 2, n, 100, n // 3, -1, 0, cap=cap))
