@@ -562,6 +562,43 @@ def extra_weak_first_point(args, ctx, api, pipeline, steps):
 DENSE_N, DENSE_FAM, DENSE_RATE, DENSE_L = 10000, 10, 0.01, 500_000
 
 
+def _dense_u32_25000(args, ctx, api, pipeline, steps):
+    """25 000 KSSD sketches (u32 tuples, ~488 each) in 25 families of 1 000 near-identical 2 Mbp genomes: the dense regime at the
+    size where wider column blocks of the tiled kernel were costed to start paying; default dispatch."""
+    import numpy as np
+    import torch
+    from rabbittclust_amd import host
+    n, fam, L = 25000, 25, 2_000_000
+    desc = api.synth_family_descs(fam, n // fam, global_seed=44, max_rate=DENSE_RATE)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    seq = ctx.synth_genomes(desc, off)
+    sk = ctx.sketch_kssd(seq, off, host.generate_shuffle_dim(6), kmer_size=args.k, drlevel=3)
+    ctx.sync()
+    del seq
+    torch.cuda.empty_cache()
+    pipe = pipeline.MstPipeline(ctx, k=sk.k, threshold=args.threshold)
+    rec = []
+    for it in range(steps + 1):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        edges, m = pipe.candidate_edges(sk, 0, n)
+        ev[1].record()
+        path = ctx.pair_last_path()
+        kms = ctx.pair_last_kernel_ms() if path == 2 else float("nan")
+        sel, rounds = pipe.boruvka(sk, edges, m)
+        mst = pipe.finish(sk, sel)
+        ev[2].record()
+        torch.cuda.synchronize()
+        rec.append({"pair_ms": ev[0].elapsed_time(ev[1]), "mst_ms": ev[1].elapsed_time(ev[2]), "kernel_ms": kms, "cand_edges": float(m),
+                    "pair_path": float(path), "mst_edges": float(len(mst))})
+    first, ph = rec[0], _mean_phases(rec[1:])
+    return {"workload": f"{n} u32 KSSD sketches of {float(sk.len.float().mean().item()):.0f} tuples: {fam} families of {n // fam} genomes ({L} bp, "
+                        f"substitution rate <= {DENSE_RATE}), all-pairs candidate edges + MST; default dispatch",
+            "pair_path": int(round(ph["pair_path"])), "pair_ms": ph["pair_ms"], "pair_kernel_ms": ph["kernel_ms"], "mst_ms": ph["mst_ms"],
+            "first_call_pair_ms": first["pair_ms"], "cand_edges": int(ph["cand_edges"]), "mst_edges": int(ph["mst_edges"]),
+            "pair_phase_pairs_per_sec": n * (n - 1) // 2 / (ph["pair_ms"] * 1e-3)}
+
+
 def extra_dense_pairs(args, ctx, api, pipeline, steps):
     """The dense regime of the distance half: 10 000 u64 sketches (s = 1000) in 10 families of 1 000 near-identical genomes
     (substitution rate <= 1 %): posting lists as long as a family, 3.5e9 co-occurrences -- the input on which the reference's
@@ -617,7 +654,13 @@ def extra_dense_pairs(args, ctx, api, pipeline, steps):
     traffic, src = measured_traffic("pair_tiled_kernel", wl)
     kern_s = ph["kernel_ms"] * 1e-3
     algo = pairs * bytes_pair / kern_s / 1e9
+    big = None
+    try:  # the same regime at BASELINE configs[4]'s per-GPU shape: 25 000 u32 KSSD sketches (2 Mbp genomes), 25 families of 1 000
+        big = _dense_u32_25000(args, ctx, api, pipeline, steps)
+    except Exception as e:
+        big = {"error": repr(e)[:300]}
     return {
+        "u32_25000": big,
         "workload": f"{n} u64 sketches of {int(avg_len)} hashes: {fam} families of {n // fam} genomes ({DENSE_L} bp, substitution rate "
                     f"<= {DENSE_RATE}), all-pairs candidate edges + MST at d={args.threshold}; default dispatch",
         "steps": steps, "pair_path": int(round(ph["pair_path"])), "pair_ms": ph["pair_ms"], "pair_kernel_ms": ph["kernel_ms"],

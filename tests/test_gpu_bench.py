@@ -72,7 +72,7 @@ def test_bench_default_line_has_every_extra_without_error(ctx, tmp_path):
     assert line["extra_errors"] == [], line["extra_errors"]
     sc = line["extra_scalars"]
     for k in ("minhash_packed_ms", "minhash_ascii_ms", "kssd_frac", "kssd_packed_frac", "kssd_packed_physical_frac", "greedy_frac",
-              "dense_pair_kernel_ms", "dense_first_call_ms", "config3_total_s", "config5_total_s", "cli_gbp_per_sec", "cli_large_gbp_per_sec"):
+              "dense_pair_kernel_ms", "dense_first_call_ms", "dense25k_pair_ms", "config3_total_s", "config5_total_s", "cli_gbp_per_sec", "cli_large_gbp_per_sec"):
         assert sc[k] is not None and sc[k] > 0, (k, sc)
     assert json.load(open(xj)) == full
     head = full["headline"]
