@@ -485,6 +485,32 @@ def _north_star_1gpu(args, ctx, api, pipeline, steps, mode):
             "sketch_gbp_per_sec": n * L / (ph["sketch_ms"] * 1e-3) / 1e9, "first_step_total_s": first, "setup_s": t_setup,
             "dtype": "u64" if sk.width == 8 else "u32", "mean_sketch_size": float(sk.len.float().mean().item()),
         }
+        # What each rank of an N-GPU run of this job would do in its pair phase, measured here one rank after the other on the
+        # resident sketch set (the row ranges rtc_mst_sharded cuts: equal cost, not equal pairs): the balance of the split and the
+        # part of the step that shrinks with N.  The sketch phase divides by N (whole genomes per rank); the Boruvka rounds do not.
+        try:
+            from rabbittclust_amd.pipeline import triangle_row_ranges
+            import torch
+            ppipe = pipeline.MstPipeline(ctx, k=sk.k, sketch_size=args.s, threshold=args.threshold)
+            shards = {}
+            for W in (2, 4, 8):
+                b = triangle_row_ranges(n, W, fixed_cols=1.84 * out["mean_sketch_size"])
+                ms, ed = [], []
+                for r in range(W):
+                    for rep in range(2):  # (the first call sizes the list)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        _, m = ppipe.candidate_edges(sk, b[r], b[r + 1])
+                        torch.cuda.synchronize()
+                        dt = (time.perf_counter() - t0) * 1e3
+                    ms.append(dt)
+                    ed.append(int(m))
+                shards[str(W)] = {"pair_ms_max": max(ms), "pair_ms_min": min(ms), "pair_ms_sum": sum(ms), "cand_edges_max": max(ed),
+                                  "sketch_s_per_rank": out["sketch_s"] / W}
+            out["row_shards_on_one_gpu"] = shards
+            ppipe = None
+        except Exception as e:
+            out["row_shards_on_one_gpu"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline:
             # this job's own bounded CPU sample: its first genomes again as characters, its first sketches
             try:
@@ -1193,7 +1219,7 @@ def main():
                 "phase_ms_min": {k: min(r[k] for r in ranks_ph) for k in keys},
                 "phase_ms_max": {k: max(r[k] for r in ranks_ph) for k in keys},
                 "boruvka_rounds": rounds,
-                "all_reduce_bytes_per_step": rounds * n_total * (8 if s_fixed else 20)}
+                "all_reduce_bytes_per_step": rounds * n_total * (8 if s_fixed else 16)}
         if not args.no_cpu_baseline:
             try:
                 if cpu_seq is None:  # strong scaling: rank 0's first genomes again as characters

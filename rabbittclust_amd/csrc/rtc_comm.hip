@@ -687,7 +687,8 @@ int rtc_mst_sharded(rtc_ctx* ctx, rtc_comm* c, const void* d_hashes, int width, 
   int rounds = 0;
   st = agree(st);
   const rtc_reduce_hook hook{hook_all_reduce, c};
-  if (st == RTC_OK) st = rtc_msf_device(ctx, el.d_edges, el.m, d_len, n, is_containment, s_fixed, (c->size > 1 || c->nccl) ? &hook : nullptr, d_sel, &nsel, &rounds);
+  if (st == RTC_OK) st = rtc_msf_device(ctx, el.d_edges, el.m, d_len, n, is_containment, s_fixed, (c->size > 1 || c->nccl) ? &hook : nullptr, d_sel, &nsel, &rounds,
+                                        true, s_fixed ? 0u : *std::max_element(h_len, h_len + n));
   const double tv2 = now();
   if (st == RTC_OK && nsel) {
     hipError_t e = hipMemcpyAsync(B.h_sel, d_sel, nsel * sizeof(rtc_cedge), hipMemcpyDeviceToHost, ctx->stream);

@@ -150,10 +150,11 @@ void rtc_edge_list_free(rtc_edge_list* el, rtc_ctx* ctx = nullptr);
 int rtc_pair_edges_join(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t* d_start, const uint32_t* d_len,
                         uint32_t n, uint32_t row0, uint32_t row1, uint32_t col0, uint32_t col1, int radio,
                         rtc_cedge* d_edges, uint64_t cap, uint64_t* d_count, double tiled_scale, int* handled);
-// sorted: leave the forest in the reference's output order (weight, i, j) -- rtc_sort.hip; contractions pass false
+// sorted: leave the forest in the reference's output order (weight, i, j) -- rtc_sort.hip; contractions pass false.
+// max_len: the longest sketch when the caller knows it (sizes vary): the edge id of a round then carries the count too
 int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_len, uint32_t n,
                    int is_containment, uint32_t s_fixed, const rtc_reduce_hook* hook, rtc_cedge* d_sel,
-                   uint64_t* n_sel_out, int* rounds_out, bool sorted = true);
+                   uint64_t* n_sel_out, int* rounds_out, bool sorted = true, uint32_t max_len = 0);
 int rtc_sort_forest_device(rtc_ctx* ctx, rtc_cedge* d_sel, uint64_t ns, const uint32_t* d_len, int wmode);
 uint32_t rtc_fixed_size_of(const uint32_t* h_len, uint32_t n);
 size_t rtc_msf_scratch_bytes(uint32_t n);

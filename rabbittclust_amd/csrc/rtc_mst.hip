@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void boruvka_minedge_kernel(const rtc_cedge* _
                                                               const uint32_t* __restrict__ len, int is_containment,
                                                               const uint32_t* __restrict__ comp,
                                                               const unsigned long long* __restrict__ wkey,
-                                                              unsigned long long* __restrict__ ekey, const uint32_t* __restrict__ go = nullptr) {
+                                                              unsigned long long* __restrict__ ekey, const uint32_t* __restrict__ go = nullptr,
+                                                              int idx_bits = 0, int cbits = 0) {
   if (go && !*go) return;
   for (uint64_t e0 = (uint64_t)blockIdx.x * blockDim.x; e0 < m; e0 += (uint64_t)gridDim.x * blockDim.x) {  // whole waves stay together
     const uint64_t e = e0 + threadIdx.x;
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(256) void boruvka_minedge_kernel(const rtc_cedge* _
       ci = comp[ed.i]; cj = comp[ed.j];
       if (ci != cj) {
         const uint64_t key = weight_key(ed.common, len[ed.i], len[ed.j], is_containment);
-        id = ((unsigned long long)ed.i << 32) | ed.j;
+        // cbits != 0: the id carries the count too, (i << B | j) << cbits | common -- the same order on (i, j), no third pass
+        id = cbits ? (((((unsigned long long)ed.i << idx_bits) | ed.j) << cbits) | ed.common) : (((unsigned long long)ed.i << 32) | ed.j);
         oi = key == wkey[ci];
         oj = key == wkey[cj];
       }
@@ -225,6 +227,7 @@ struct RoundKeys {
   const uint32_t* ecommon;        // variable mode only
   uint32_t s_fixed;               // 0: variable mode
   int idx_bits;
+  int cbits;                      // variable mode: != 0 when the edge id carries the count (key = (i << idx_bits | j) << cbits | common)
 };
 
 __device__ __forceinline__ bool round_edge(const RoundKeys& K, uint32_t c, uint32_t& i, uint32_t& j, uint32_t& common) {
@@ -235,6 +238,11 @@ __device__ __forceinline__ bool round_edge(const RoundKeys& K, uint32_t c, uint3
     j = (uint32_t)(k & mask);
     i = (uint32_t)((k >> K.idx_bits) & mask);
     common = K.s_fixed - (uint32_t)(k >> (2 * K.idx_bits));
+  } else if (K.cbits) {
+    const unsigned long long mask = (1ULL << K.idx_bits) - 1ULL;
+    common = (uint32_t)(k & ((1ULL << K.cbits) - 1ULL));
+    j = (uint32_t)((k >> K.cbits) & mask);
+    i = (uint32_t)(k >> (K.cbits + K.idx_bits));
   } else {
     i = (uint32_t)(k >> 32);
     j = (uint32_t)k;
@@ -374,6 +382,24 @@ static double host_mst_distance(int common, int size0, int size1, int kmer_size,
   if (containment == 1.0) return 0.0;
   if (containment == 0.0) return 1.0;
   return -inv_kmer_size * log(containment);
+}
+
+// the union step of a round (hook + relabel + the counter read back): rtc_boruvka_union_dev and the multi-GPU rounds
+static int boruvka_union_round(rtc_ctx* ctx, uint32_t n, const RoundKeys& K, uint32_t* d_comp, uint32_t* d_succ, rtc_cedge* d_sel,
+                               uint64_t* d_nsel, uint32_t* h_added) {
+  uint32_t* d_added = (uint32_t*)(d_nsel + 1);
+  RTC_HIP(ctx, hipMemsetAsync(d_added, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(boruvka_hook_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(256), 0, ctx->stream, K, (const uint32_t*)d_comp, n, d_succ,
+                     d_sel, (unsigned long long*)d_nsel, d_added, (const uint32_t*)nullptr);
+  RTC_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(boruvka_relabel_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(256), 0, ctx->stream, d_comp, (const uint32_t*)d_succ, n);
+  RTC_CHECK_LAUNCH(ctx);
+  void* hp = nullptr;
+  RTC_TRY(rtc_pinned(ctx, 64, &hp));
+  RTC_HIP(ctx, hipMemcpyAsync(hp, d_added, 4, hipMemcpyDeviceToHost, ctx->stream));
+  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *h_added = *(const uint32_t*)hp;
+  return RTC_OK;
 }
 
 // scratch slot 3 of a forest call: two u64 and three u32 per vertex, the forest counter and the rounds' counters
@@ -525,13 +551,25 @@ int rtc_mst_bufs(rtc_ctx* ctx, uint32_t n, rtc_mst_bufs_t* b) {
 // multi-GPU step; `hook` all-reduces the per-round key arrays across ranks, NULL on one GPU) ----
 int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_len, uint32_t n,
                    int is_containment, uint32_t s_fixed, const rtc_reduce_hook* hook, rtc_cedge* d_sel,
-                   uint64_t* n_sel_out, int* rounds_out, bool sorted) {
+                   uint64_t* n_sel_out, int* rounds_out, bool sorted, uint32_t max_len) {
   *n_sel_out = 0;
   if (rounds_out) *rounds_out = 0;
   if (n < 2) return RTC_OK;
   if (n >= (1u << 31)) return rtc_fail(ctx, RTC_ERR_UNSUPPORTED, "%u sketches: edge ids (i << 32 | j) must stay below the empty key 2^63 - 1", n);
-  const int idx_bits = rtc_boruvka_key_bits(n, s_fixed);
+  int idx_bits = rtc_boruvka_key_bits(n, s_fixed);
   if (s_fixed && !idx_bits) s_fixed = 0;
+  // Sketches of different sizes (--fast, containment): the weight needs its own 64 bits, but the edge id that breaks ties can
+  // carry the count when the caller knows the longest sketch: two vertex indices + the count in 63 bits (200 000 sketches of up
+  // to 1 000 000 hashes: 18 + 18 + 20).  Then a round is two passes over the edges instead of three -- and two all-reduces
+  // across GPUs instead of three, which at eight GPUs are the larger part of a round.
+  int cbits = 0;
+  if (!s_fixed && max_len) {
+    int b = 1;
+    while (b < 32 && (1ull << b) < (uint64_t)n) b++;
+    int w = 1;
+    while (w < 32 && (1ull << w) <= (uint64_t)max_len) w++;
+    if (2 * b + w <= 63) { idx_bits = b; cbits = w; }
+  }
   void* ws3 = nullptr;
   RTC_TRY(rtc_ws(ctx, 3, rtc_msf_scratch_bytes(n), &ws3));
   uint64_t* d_wkey = (uint64_t*)ws3;
@@ -555,7 +593,7 @@ int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uin
     RTC_CHECK_LAUNCH(ctx);
     void* hp = nullptr;
     RTC_TRY(rtc_pinned(ctx, 8 + 4 * MAX_ROUNDS, &hp));
-    const RoundKeys K{s_fixed ? wkey : ekey, d_ecommon, s_fixed, idx_bits};
+    const RoundKeys K{s_fixed ? wkey : ekey, d_ecommon, s_fixed, idx_bits, cbits};
     int rounds = 0;
     for (int round = 0; round < MAX_ROUNDS && !rounds;) {
       const int first = round;
@@ -567,9 +605,10 @@ int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uin
           } else {
             hipLaunchKernelGGL(boruvka_minweight_kernel, gm, blk, 0, ctx->stream, d_edges, m, d_len, is_containment, (const uint32_t*)d_comp, wkey, go);
             hipLaunchKernelGGL(boruvka_minedge_kernel, gm, blk, 0, ctx->stream, d_edges, m, d_len, is_containment, (const uint32_t*)d_comp,
-                               (const unsigned long long*)wkey, ekey, go);
-            hipLaunchKernelGGL(boruvka_fetch_kernel, gm, blk, 0, ctx->stream, d_edges, m, (const uint32_t*)d_comp,
-                               (const unsigned long long*)ekey, d_ecommon, go);
+                               (const unsigned long long*)wkey, ekey, go, idx_bits, cbits);
+            if (!cbits)
+              hipLaunchKernelGGL(boruvka_fetch_kernel, gm, blk, 0, ctx->stream, d_edges, m, (const uint32_t*)d_comp,
+                                 (const unsigned long long*)ekey, d_ecommon, go);
           }
           RTC_CHECK_LAUNCH(ctx);
         }
@@ -597,6 +636,17 @@ int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uin
     if (s_fixed) {
       RTC_TRY(rtc_boruvka_minkey_dev(ctx, d_edges, m, d_comp, n, s_fixed, d_wkey));
       if (hook) RTC_TRY(hook->all_reduce(hook->self, d_wkey, n, 2, 0));
+    } else if (cbits) {  // the edge id carries the count: MIN(weight), MIN(id) -- no third exchange
+      RTC_TRY(rtc_boruvka_minweight_dev(ctx, d_edges, m, d_len, is_containment, d_comp, n, d_wkey));
+      if (hook) RTC_TRY(hook->all_reduce(hook->self, d_wkey, n, 2, 0));
+      hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(256), 0, ctx->stream, (unsigned long long*)d_ekey, (uint64_t)n,
+                         (unsigned long long)KEY_NONE);
+      if (m)
+        hipLaunchKernelGGL(boruvka_minedge_kernel, dim3(grid_for(m, ctx->num_cu)), dim3(256), 0, ctx->stream, d_edges, m, d_len, is_containment,
+                           (const uint32_t*)d_comp, (const unsigned long long*)d_wkey, (unsigned long long*)d_ekey, (const uint32_t*)nullptr,
+                           idx_bits, cbits);
+      RTC_CHECK_LAUNCH(ctx);
+      if (hook) RTC_TRY(hook->all_reduce(hook->self, d_ekey, n, 2, 0));
     } else {
       RTC_TRY(rtc_boruvka_minweight_dev(ctx, d_edges, m, d_len, is_containment, d_comp, n, d_wkey));
       if (hook) RTC_TRY(hook->all_reduce(hook->self, d_wkey, n, 2, 0));
@@ -606,7 +656,8 @@ int rtc_msf_device(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uin
       if (hook) RTC_TRY(hook->all_reduce(hook->self, d_ecommon, n, 1, 1));
     }
     uint32_t added = 0;
-    RTC_TRY(rtc_boruvka_union_dev(ctx, n, s_fixed, s_fixed ? d_wkey : d_ekey, d_ecommon, d_comp, d_succ, d_sel, d_nsel, &added));
+    RTC_TRY(boruvka_union_round(ctx, n, RoundKeys{(const unsigned long long*)(s_fixed ? d_wkey : d_ekey), d_ecommon, s_fixed, idx_bits, cbits},
+                                d_comp, d_succ, d_sel, d_nsel, &added));
     rounds++;
     if (!added) break;
   }
@@ -824,21 +875,9 @@ int rtc_boruvka_union_dev(rtc_ctx* ctx, uint32_t n, uint32_t s_fixed, const uint
   *h_added = 0;
   if (!n) return RTC_OK;
   RTC_HIP(ctx, hipSetDevice(ctx->device));
-  RoundKeys K{(const unsigned long long*)d_key, d_ecommon, s_fixed, rtc_boruvka_key_bits(n, s_fixed)};
+  RoundKeys K{(const unsigned long long*)d_key, d_ecommon, s_fixed, rtc_boruvka_key_bits(n, s_fixed), 0};
   if (s_fixed && !K.idx_bits) return rtc_fail(ctx, RTC_ERR_ARG, "fused Boruvka key does not fit: n=%u s=%u", n, s_fixed);
-  uint32_t* d_added = (uint32_t*)(d_nsel + 1);
-  RTC_HIP(ctx, hipMemsetAsync(d_added, 0, 4, ctx->stream));
-  hipLaunchKernelGGL(boruvka_hook_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(256), 0, ctx->stream, K, d_comp, n, d_succ,
-                     d_sel, (unsigned long long*)d_nsel, d_added, (const uint32_t*)nullptr);
-  RTC_CHECK_LAUNCH(ctx);
-  hipLaunchKernelGGL(boruvka_relabel_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(256), 0, ctx->stream, d_comp, d_succ, n);
-  RTC_CHECK_LAUNCH(ctx);
-  void* hp = nullptr;
-  RTC_TRY(rtc_pinned(ctx, 64, &hp));
-  RTC_HIP(ctx, hipMemcpyAsync(hp, d_added, 4, hipMemcpyDeviceToHost, ctx->stream));
-  RTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  *h_added = *(const uint32_t*)hp;
-  return RTC_OK;
+  return boruvka_union_round(ctx, n, K, d_comp, d_succ, d_sel, d_nsel, h_added);
 }
 
 int rtc_boruvka_minweight_dev(rtc_ctx* ctx, const rtc_cedge* d_edges, uint64_t m, const uint32_t* d_len,
@@ -1007,7 +1046,8 @@ int rtc_mst_dense(rtc_ctx* ctx, const void* d_hashes, int width, const uint64_t*
   uint64_t nsel = 0;
   const double tv1 = now();
   int rounds = 0;
-  if (st == RTC_OK) st = rtc_msf_device(ctx, el.d_edges, el.m, d_len, n, is_containment, s_fixed, nullptr, d_sel, &nsel, &rounds);
+  if (st == RTC_OK) st = rtc_msf_device(ctx, el.d_edges, el.m, d_len, n, is_containment, s_fixed, nullptr, d_sel, &nsel, &rounds, true,
+                                        s_fixed ? 0u : *std::max_element(h_len, h_len + n));
   const double tv2 = now();
   if (st == RTC_OK && nsel) {
     hipError_t e = hipMemcpyAsync(B.h_sel, d_sel, nsel * sizeof(rtc_cedge), hipMemcpyDeviceToHost, ctx->stream);
