@@ -420,7 +420,7 @@ def test_pipeline_multi_gpu_code_path_on_one_gpu(ctx, oracle):
     assert all(np.array_equal(a, b) for a, b in zip(pipe.last_sketches.to_host(), ref.last_sketches.to_host()))
 
 
-@pytest.mark.parametrize("comm", ["native", "torch"])
+@pytest.mark.parametrize("comm", ["native", "torch", "native-strong"])
 def test_bench_rccl_path_single_rank(tmp_path, comm):
     """bench.py under torch.distributed.run with one rank and RTC_FORCE_DIST=1: the sketch gather and
     the per-round all-reduces go through RCCL exactly as in the multi-GPU run -- through the C ABI's
@@ -431,15 +431,21 @@ def test_bench_rccl_path_single_rank(tmp_path, comm):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RTC_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", RTC_COMM_FORCE_RCCL="1")
+    strong = comm == "native-strong"  # the strong-scaling form: packed batches through rtc_sketch_minhash_packed_sharded, RCCL forced for the one rank
+    comm = comm.split("-")[0]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", "29611" if comm == "native" else "29612", os.path.join(root, "bench.py"), "--gpus", "1",
-           "--steps", "1", "--warmup", "1", "--genomes", "200", "--length", "200000", "--no-cpu-baseline", "--comm", comm]
+           "127.0.0.1", "--master-port", {"native": "29611", "torch": "29612"}[comm] if not strong else "29613", os.path.join(root, "bench.py"), "--gpus", "1",
+           "--steps", "1", "--warmup", "1", "--genomes", "200", "--length", "200000", "--no-cpu-baseline", "--comm", comm,
+           "--extra-json", str(tmp_path / "x.json")] + (["--scaling", "strong"] if strong else [])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    line = json.loads(last)
+    assert len(last) < 4096
     assert line["n_gpus"] == 1 and line["mst_edges"] > 0 and line["value"] > 0
-    assert line["roofline"]["frac"] > 0 and line["scaling"] == "weak"
+    assert line["roofline"]["frac"] > 0 and line["scaling"] == ("strong" if strong else "weak")
     assert line["config"]["collectives"].startswith("rtc_comm (rccl" if comm == "native" else "torch.distributed")
+    assert line["config"]["staging"] == "packed" and line["roofline"]["kernel"].startswith("sketch_minhash_packed_kernel")
 
 
 def test_bench_kssd_mode_small(tmp_path):
