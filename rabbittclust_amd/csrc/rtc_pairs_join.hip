@@ -126,13 +126,17 @@ __global__ __launch_bounds__(256) void join_bloom_build_kernel(const T* __restri
     atomicOr(&bloom[w], m);
   }
 }
-// FILL = false: kept[g - g0] = hashes of genome g that pass; FILL = true: write them (and g) at off[g - g0], in order
+// FILL = false: kept[g - g0] = hashes of genome g that pass, and a byte per hash (at the genome's place among ALL hashes,
+// off_all) that says whether it did; FILL = true: write the ones marked (and g) at off[g - g0], in order -- from the bytes, not
+// from the filter again: the probe is a random 8-byte read per hash (0.8 ms per pass over the 10^8 column hashes of a row shard of
+// BASELINE configs[4], the largest part of a rank's pair phase at eight GPUs until round 6).
 template <typename T, bool FILL>
 __global__ __launch_bounds__(256) void join_semi_kernel(const T* __restrict__ hashes, const uint64_t* __restrict__ start,
                                                         const uint32_t* __restrict__ len, uint32_t g0, uint32_t row0, int wshift,
                                                         const unsigned long long* __restrict__ bloom, uint32_t* __restrict__ kept,
                                                         const uint64_t* __restrict__ off, T* __restrict__ keys,
-                                                        uint32_t* __restrict__ vals) {
+                                                        uint32_t* __restrict__ vals, const uint64_t* __restrict__ off_all,
+                                                        uint8_t* __restrict__ passed) {
   __shared__ uint32_t wtot[4];
   const uint32_t g = g0 + blockIdx.x;
   const uint32_t L = len[g];
@@ -140,6 +144,7 @@ __global__ __launch_bounds__(256) void join_semi_kernel(const T* __restrict__ ha
   const bool is_row = g >= row0;  // rows are later rows' columns too, and their own hashes all pass by construction
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint64_t base = FILL ? off[blockIdx.x] : 0;
+  uint8_t* mine = passed + off_all[blockIdx.x];
   uint32_t total = 0;
   for (uint32_t e0 = 0; e0 < L; e0 += 256) {
     const uint32_t e = e0 + threadIdx.x;
@@ -149,10 +154,14 @@ __global__ __launch_bounds__(256) void join_semi_kernel(const T* __restrict__ ha
       key = src[e];
       keep = is_row;
       if (!is_row) {
-        uint32_t w; unsigned long long m;
-        bloom_slot<T>(key, wshift, w, m);
-        keep = (bloom[w] & m) == m;
+        if (FILL) keep = mine[e] != 0;
+        else {
+          uint32_t w; unsigned long long m;
+          bloom_slot<T>(key, wshift, w, m);
+          keep = (bloom[w] & m) == m;
+        }
       }
+      if (!FILL) mine[e] = keep ? 1 : 0;
     }
     const uint64_t bal = __ballot(keep);
     if (lane == 0) wtot[wave] = (uint32_t)__popcll(bal);
@@ -689,6 +698,8 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
   const int semi_mode = ctx->opt.join_semi;
   const bool semi = row0 > g0 && K_rows > 0 && (semi_mode >= 2 || (semi_mode == 1 && K_rows * 4 < K64 && K64 >= (1u << 22)));
   uint32_t* d_kept = nullptr;
+  uint64_t* d_off_all = nullptr;  // semi-join: the places of the genomes among ALL hashes, and a "passed the filter" byte per hash
+  uint8_t* d_passed = nullptr;
   unsigned long long* d_bloom = nullptr;
   int wshift = 0;
   if (semi) {
@@ -697,25 +708,29 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     wshift = 64;
     for (uint64_t w = words; w > 1; w >>= 1) wshift--;
     void* ws2 = nullptr;
-    const size_t b_bloom = up256(words * 8), b_kept = up256((size_t)ng * 4);
+    const size_t b_bloom = up256(words * 8), b_kept = up256((size_t)ng * 4), b_offall = up256((size_t)(ng + 1) * 8), b_passed = up256((size_t)K_all + 64);
     size_t tb_sk = 0;
     {
       auto it = rocprim::make_transform_iterator((const uint32_t*)nullptr, U32ToU64());
       RTC_HIP(ctx, rocprim::inclusive_scan(nullptr, tb_sk, it, (uint64_t*)nullptr, (size_t)ng, rocprim::plus<uint64_t>(), s));
     }
     {
-      const int st = rtc_ws(ctx, 2, b_bloom + b_kept + up256(tb_sk) + 256, &ws2);
+      const int st = rtc_ws(ctx, 2, b_bloom + b_kept + up256(tb_sk) + b_offall + b_passed + 256, &ws2);
       if (st == RTC_ERR_NOMEM) return RTC_OK;
       if (st != RTC_OK) return st;
     }
     d_bloom = (unsigned long long*)ws2;
     d_kept = (uint32_t*)((char*)ws2 + b_bloom);
     void* tmpk = (char*)ws2 + b_bloom + b_kept;
+    d_off_all = (uint64_t*)((char*)ws2 + b_bloom + b_kept + up256(tb_sk));
+    d_passed = (uint8_t*)((char*)d_off_all + b_offall);
+    RTC_HIP(ctx, hipMemcpyAsync(d_off_all, d_off, (size_t)(ng + 1) * 8, hipMemcpyDeviceToDevice, s));  // (d_off becomes the offsets of the kept hashes below)
     RTC_HIP(ctx, hipMemsetAsync(d_bloom, 0, words * 8, s));
     hipLaunchKernelGGL(join_bloom_build_kernel<T>, dim3(row1 - row0), dim3(256), 0, s, d_hashes, d_start, d_len, row0, wshift, d_bloom);
     RTC_CHECK_LAUNCH(ctx);
     hipLaunchKernelGGL((join_semi_kernel<T, false>), dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, g0, row0, wshift,
-                       (const unsigned long long*)d_bloom, d_kept, (const uint64_t*)nullptr, (T*)nullptr, (uint32_t*)nullptr);
+                       (const unsigned long long*)d_bloom, d_kept, (const uint64_t*)nullptr, (T*)nullptr, (uint32_t*)nullptr,
+                       (const uint64_t*)d_off_all, d_passed);
     RTC_CHECK_LAUNCH(ctx);
     auto it = rocprim::make_transform_iterator((const uint32_t*)d_kept, U32ToU64());
     RTC_HIP(ctx, rocprim::inclusive_scan(tmpk, tb_sk, it, d_off + 1, (size_t)ng, rocprim::plus<uint64_t>(), s));  // d_off[0] stays 0
@@ -811,7 +826,8 @@ int join_impl(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const ui
     // (the flat copy anew for the second attempt: the first one's descriptors lie over it)
     if (semi)
       hipLaunchKernelGGL((join_semi_kernel<T, true>), dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, g0, row0, wshift,
-                         (const unsigned long long*)d_bloom, (uint32_t*)nullptr, (const uint64_t*)d_off, keys0, vals0);
+                         (const unsigned long long*)d_bloom, (uint32_t*)nullptr, (const uint64_t*)d_off, keys0, vals0,
+                         (const uint64_t*)d_off_all, d_passed);
     else
       hipLaunchKernelGGL(join_flatten_kernel<T>, dim3(ng), dim3(256), 0, s, d_hashes, d_start, d_len, d_off, g0, keys0, vals0);
     RTC_CHECK_LAUNCH(ctx);
