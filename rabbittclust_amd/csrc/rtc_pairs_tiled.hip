@@ -41,7 +41,9 @@ constexpr int NB = 1 << LOG2NB;         // buckets of four 4-byte slots (64 KiB)
 constexpr int BUCKET = 4;
 constexpr uint32_t ECAP = 5120;         // entries {key, row mask} of 16 bytes (80 KiB): one per (row, element) of a table build
 constexpr uint32_t KCAP_HARD = ECAP;    // max keys per table build
-constexpr uint32_t KTARGET = 2048;      // planned mean keys per table: half a key per bucket
+constexpr uint32_t KTARGET = 4096;      // planned mean keys per table: a key per bucket (2 048 until round 6: half the partitions -- half the
+                                        // table builds, barriers and slice tails -- now pay more than the fuller buckets cost: kernel 1.53 -> 1.39 ms at
+                                        // 10 000 u64 sketches, 2.88 -> 2.60 ms at 25 000 u32, sparse shapes -2 %, same box, RTC_PAIR_KTARGET A/B)
 constexpr int RPW = ROWS / (TW / 64);   // rows a wave builds at once
 constexpr int LPR = 64 / RPW;           // lanes per row in the build
 constexpr int MAXP = 512;
@@ -634,8 +636,7 @@ int build_plan(rtc_ctx* ctx, const T* d_hashes, const uint64_t* d_start, const u
   const double avg = (double)tot / n;
   uint32_t ktarget = KTARGET;
   if (ctx->opt.pair_ktarget >= 256 && ctx->opt.pair_ktarget <= KCAP_HARD) ktarget = ctx->opt.pair_ktarget;  // tuning experiments
-  int P = 1;
-  while (P < MAXP && (double)ROWS * avg / P > ktarget) P <<= 1;
+  int P = (int)std::min<double>((double)MAXP, std::max(1.0, std::ceil((double)ROWS * avg / ktarget)));  // (any count: the bounds are sample quantiles)
   std::sort(sample.begin(), sample.end());
   T* h_bounds_pin = (T*)((char*)hpin + bhead + bsamp + 64 - ((bhead + bsamp + 64) % 8));
   const uint32_t tnc = tc1 - tc0;
