@@ -77,7 +77,7 @@ int rtc_device_count(void) {
 void rtc_options_from_env(rtc_options* o) {
   *o = rtc_options();
   auto num = [](const char* name, long long dflt) -> long long { const char* e = getenv(name); return e ? atoll(e) : dflt; };
-  auto flag = [](const char* name) -> int { return getenv(name) != nullptr; };
+  auto flag = [](const char* name) -> int { const char* e = getenv(name); return e != nullptr && strcmp(e, "0") != 0 && *e != 0; };  // set, and not to "0" / ""
   o->verbose = flag("RTC_VERBOSE");
   o->pair_join = (int)num("RTC_PAIR_JOIN", 1);
   o->join_semi = (int)num("RTC_JOIN_SEMI", 1);
